@@ -1,0 +1,138 @@
+"""Pin the oracle to the reference: oracle/ vs the golden vectors recorded from /root/reference.
+
+The reference ships no tests or fixtures; tests/golden/*.npz were produced
+by tests/golden/gen_golden.py from the unmodified reference in the build container.
+fp64 oracle paths must reproduce them to <=1e-12 (they are the same arithmetic in the same
+order); integer outputs and done flags must be identical.
+"""
+import numpy as np
+import pytest
+
+from oracle import spec as ospec
+from oracle.mpe_loop import LoopEnv
+from oracle.mpe_batched import BatchedOracle, seeded_initial_state
+
+CASES = [
+    ("simple", ospec.simple(), False),
+    ("simple_spread", ospec.simple_spread(3), True),
+    ("simple_tag", ospec.simple_tag(), True),
+    ("simple_spread_n5", ospec.simple_spread(5), True),
+    ("simple_spread_n64", ospec.simple_spread(64), True),
+]
+TOL = 1e-12
+
+
+def _close(a, b, tol=TOL):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    scale = np.maximum(1.0, np.abs(b))
+    assert np.all(np.abs(a - b) <= tol * scale), float(np.max(np.abs(a - b) / scale))
+
+
+@pytest.mark.parametrize("name,spec,bench", CASES, ids=[c[0] for c in CASES])
+def test_batched_fp64_matches_reference(name, spec, bench, golden):
+    g = golden(name)
+    T, W, A = g["rew"].shape
+    assert spec.obs_dims() == [g["obs%d" % i].shape[-1] for i in range(A)]
+    orc = BatchedOracle(spec, W, np.float64, benchmark=bench)
+    orc.set_state(g["pos0"], g["vel0"])
+    for i, o in enumerate(orc.observe()):
+        _close(o, g["obs_reset%d" % i])
+    for t in range(T):
+        obs, rew, done, info = orc.step(np.transpose(g["act"][t], (1, 0, 2)))
+        _close(orc.pos, g["pos"][t])
+        _close(orc.vel, g["vel"][t])
+        for i in range(A):
+            _close(obs[i], g["obs%d" % i][t])
+        _close(rew.T, g["rew"][t])
+        assert not done.any() and not g["done"][t].any()
+        if "info_collisions" in g:
+            assert np.array_equal(info["collisions"].T, g["info_collisions"][t])
+        if "info_occupied" in g:
+            assert np.array_equal(info["occupied_landmarks"].T, g["info_occupied"][t])
+            _close(info["min_dists"].T, g["info_min_dists"][t])
+            _close(info["rew"].T, g["info_rew"][t])
+
+
+def test_batched_integer_action_ids(golden):
+    g = golden("simple_spread_ids")
+    T, W, A = g["rew"].shape
+    orc = BatchedOracle(ospec.simple_spread(3), W, np.float64, benchmark=True)
+    orc.set_state(g["pos0"], g["vel0"])
+    for t in range(T):
+        obs, rew, done, info = orc.step(ids=g["ids"][t].T)
+        _close(orc.pos, g["pos"][t])
+        for i in range(A):
+            _close(obs[i], g["obs%d" % i][t])
+        _close(rew.T, g["rew"][t])
+        assert np.array_equal(info["collisions"].T, g["info_collisions"][t])
+
+
+def test_seeded_reset_matches_reference(golden):
+    for name, spec in [("simple", ospec.simple()), ("simple_tag", ospec.simple_tag())]:
+        g = golden(name)
+        W = len(g["seeds"])
+        plain = [w for w in range(W) if name == "simple" or w % 3 != 2]  # squeezed worlds differ
+        pos, vel = seeded_initial_state(spec, g["seeds"][plain])
+        assert np.array_equal(pos, g["pos0"][plain])
+        assert np.array_equal(vel, g["vel0"][plain])
+
+
+@pytest.mark.parametrize("name,spec,bench", CASES[:4], ids=[c[0] for c in CASES[:4]])
+def test_loop_port_matches_reference(name, spec, bench, golden):
+    """The per-object loop (the cpu_baseline port) replays golden worlds one at a time."""
+    g = golden(name)
+    T, W, A = g["rew"].shape
+    env = LoopEnv(spec, benchmark=bench)
+    for w in range(min(W, 6)):
+        env.set_state(g["pos0"][w], g["vel0"][w])
+        for t in range(min(T, 12)):
+            obs, rew, done, info = env.step([g["act"][t, w, i] for i in range(A)])
+            for i in range(A):
+                _close(obs[i], g["obs%d" % i][t, w])
+            _close(np.array(rew, dtype=np.float64), g["rew"][t, w])
+            assert done == [False] * A
+            if name.startswith("simple_spread"):
+                assert [x[1] for x in info["n"]] == list(g["info_collisions"][t, w])
+                assert [x[3] for x in info["n"]] == list(g["info_occupied"][t, w])
+            if name == "simple_tag":
+                assert list(info["n"]) == list(g["info_collisions"][t, w])
+
+
+def test_loop_port_seeded_reset_and_kat():
+    """SURVEY.md appendix A.3 known-answer vectors (recorded from the reference, fp64)."""
+    env = LoopEnv(ospec.simple_spread(3))
+    np.random.seed(0)
+    env.reset()
+    flat = np.concatenate([p for p in env.pos])
+    kat = [0.0976270079, 0.4303787327, 0.2055267521, 0.0897663660, -0.1526904013, 0.2917882261,
+           -0.1248255775, 0.7835460016, 0.9273255210, -0.2331169623, 0.5834500762, 0.0577898395]
+    assert np.allclose(flat, kat, atol=1e-9)
+    act = [np.eye(5)[(i % 4) + 1] for i in range(3)]
+    obs, rew, done, _ = env.step(act)
+    o0 = [0.6214080569, 0.0672186731, 0.1597678135, 0.4371006001, -0.2845933910, 0.3464454015,
+          0.7675577075, -0.6702175624, 0.4236822626, -0.3793107606, -0.0042410614, -0.3473342341,
+          -0.3245990205, -0.1020342412, 0, 0, 0, 0]
+    assert np.allclose(obs[0], o0, atol=1e-9)
+    assert np.allclose(rew, [-8.1422486230] * 3, atol=1e-9)
+    for t in range(24):
+        act = [np.eye(5)[(i + t) % 5] for i in range(3)]
+        obs, rew, done, _ = env.step(act)
+    assert np.allclose(env.pos[0], [0.3828512256, 0.5227536118], atol=1e-9)
+    assert np.allclose(env.vel[0], [-0.1222033166, 0.4483753008], atol=1e-9)
+    assert np.allclose(rew, [-8.4552941772] * 3, atol=1e-9)
+
+
+def test_contact_kat():
+    """Two r=.15 agents at (0,0),(0.2,0), zero action: force (-10,0)/(+10,0)."""
+    orc = BatchedOracle(ospec.simple_spread(2, 0), 1)
+    orc.set_state([[[0.0, 0.0], [0.2, 0.0]]], np.zeros((1, 2, 2)))
+    f = orc.forces(orc.decode(np.zeros((2, 1, 5))))
+    assert np.allclose(f[0], [[-10.0, 0.0]], atol=1e-9) and np.allclose(f[1], [[10.0, 0.0]], atol=1e-9)
+    orc.integrate(f)
+    assert np.allclose(orc.pos[0], [[-0.1, 0.0], [0.3, 0.0]], atol=1e-9)
+    assert np.allclose(orc.vel[0], [[-1.0, 0.0], [1.0, 0.0]], atol=1e-9)
+    for d, fx in [(0.2999, -0.0744396660), (0.3, -0.0693147181), (0.3001, -0.0644396660)]:
+        orc.set_state([[[0.0, 0.0], [d, 0.0]]], np.zeros((1, 2, 2)))
+        f = orc.forces(orc.decode(np.zeros((2, 1, 5))))
+        assert abs(f[0][0, 0] - fx) < 1e-9
