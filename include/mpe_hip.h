@@ -1,0 +1,160 @@
+/*
+ * mpe_hip.h -- C ABI of libmpe_hip.so: the batched particle-world hot path for MI355X (gfx950).
+ *
+ * The reference (openai/multiagent-particle-envs) has no native/FFI boundary: its hot path is
+ * Python.  Each entry point below therefore names the reference *Python*
+ * function(s) whose body it replaces; INTEGRATION.md shows the ctypes stub that binds it.
+ *
+ * Conventions (all entry points)
+ *   - plain C, no C++/torch types; every array argument is a raw DEVICE pointer into memory the
+ *     caller owns (torch tensors in our host layer).  The library never allocates device memory,
+ *     never keeps a pointer after returning and has no global state besides a thread-local
+ *     error string.
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *     no hidden synchronisation.  The device is whatever the caller made current.
+ *   - returns 0 on success, a negative MPE_E* code for argument errors, or a positive hipError_t.
+ *     Never throws, never exits.  mpe_last_error() describes the last failure on this thread.
+ *   - B independent worlds are stepped in lock-step; world b never reads another world's data.
+ *
+ * Device data layout (fp32, structure-of-arrays, batch index innermost => coalesced over b)
+ *   pos   [E][2][B]   entity positions, agents first then landmarks   (EntityState.p_pos, core.py:4-9)
+ *   vel   [A][2][B]   agent velocities (landmarks are never integrated) (EntityState.p_vel; core.py:160)
+ *   act   [A][B][5]   per-agent action rows as the reference takes them  (environment.py:174-175)
+ *   ids   [A][B]      int32 action ids, the discrete_action_input form    (environment.py:161-167)
+ *   obs   agent i's block starts at float offset B*obs_off[i]; inside it [B][D_i] row-major, i.e.
+ *         exactly the [B, D_i] array obs_n[i] of the drop-in API        (environment.py:93)
+ *   rew   [A][B]   done [A][B] (uint8, always 0: environment.py:132-135)
+ *   info_* [A][B]  benchmark_data columns                                (simple_spread.py:47-63, simple_tag.py:57-66)
+ */
+#ifndef MPE_HIP_H_
+#define MPE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPE_ABI_VERSION 1
+#define MPE_MAX_ENTITIES 512 /* agents + landmarks per world */
+#define MPE_ACTION_DIM 5     /* Discrete(dim_p*2+1), environment.py:45 */
+
+/* error codes (negative); positive return values are hipError_t */
+#define MPE_OK 0
+#define MPE_EINVAL (-1)       /* NULL / inconsistent argument */
+#define MPE_EUNSUPPORTED (-2) /* shape or feature this build has no kernel for */
+
+/* Which Scenario's observation()/reward() the fused output stage computes. */
+enum MpeScenarioKind {
+  MPE_SCN_GENERIC = 0, /* physics only (World.step); obs/reward are the caller's business      */
+  MPE_SCN_SIMPLE = 1,  /* multiagent/scenarios/simple.py:41-50                                 */
+  MPE_SCN_SPREAD = 2,  /* multiagent/scenarios/simple_spread.py:47-100                         */
+  MPE_SCN_TAG = 3      /* multiagent/scenarios/simple_tag.py:57-147                            */
+};
+
+/*
+ * Per-scenario constants: what the reference keeps as attributes on World / Entity / Agent
+ * objects (core.py:27-51, 59-79, 83-99) and sets in Scenario.make_world.  Host POD, read during
+ * the call only.  Entities are ordered agents [0,A) then landmarks [A,A+L) (core.py:103-104).
+ */
+typedef struct MpeScenarioDesc {
+  int32_t kind;          /* enum MpeScenarioKind */
+  int32_t n_agents;      /* A >= 1 */
+  int32_t n_landmarks;   /* L >= 0 */
+  int32_t dim_c;         /* World.dim_c; in-scope agents are silent so only obs width uses it */
+  int32_t n_adversaries; /* simple_tag: agents [0,n_adversaries) are adversaries              */
+  int32_t collaborative; /* world.collaborative: every agent gets the SUM (environment.py:100-102) */
+  float dt;              /* World.dt              0.1  */
+  float damping;         /* World.damping         0.25 */
+  float contact_force;   /* World.contact_force   1e2  */
+  float contact_margin;  /* World.contact_margin  1e-3 */
+  float size[MPE_MAX_ENTITIES];      /* Entity.size                                            */
+  float mass[MPE_MAX_ENTITIES];      /* Entity.mass (= initial_mass, 1.0)                      */
+  float accel[MPE_MAX_ENTITIES];     /* action sensitivity: Agent.accel or 5.0 (environment.py:178-181) */
+  float max_speed[MPE_MAX_ENTITIES]; /* Entity.max_speed; < 0 means None (no clamp)            */
+  uint8_t movable[MPE_MAX_ENTITIES]; /* Entity.movable (must be 0 for landmarks)               */
+  uint8_t collide[MPE_MAX_ENTITIES]; /* Entity.collide                                         */
+  int32_t obs_off[MPE_MAX_ENTITIES + 1]; /* prefix sums of per-agent obs widths D_i, [A+1] used */
+} MpeScenarioDesc;
+
+/* Device buffers of one batch of worlds (see layout above).  NULL = not used by this call. */
+typedef struct MpeBuffers {
+  float *pos;
+  float *vel;
+  const float *act;   /* exactly one of act / ids / u for calls that consume actions */
+  const int32_t *ids;
+  const float *u;     /* [A][2][B] already-decoded Action.u (World.step() entered directly, core.py:117) */
+  float *obs;
+  float *rew;
+  uint8_t *done;
+  float *info_rew;          /* spread: per-agent reward before the shared sum                  */
+  int32_t *info_collisions; /* spread: #agents in contact incl. self (Q1); tag: adversary's #prey contacts */
+  float *info_min_dists;    /* spread */
+  int32_t *info_occupied;   /* spread */
+  float *force;             /* [A][2][B] scratch, only for the phase-level entry points        */
+  const float *entity_table; /* device copy of mpe_fill_entity_table(); needed when A+L > 16   */
+} MpeBuffers;
+
+/* ---- library / binding sanity -------------------------------------------------------------- */
+int mpe_abi_version(void);
+const char *mpe_last_error(void);
+size_t mpe_sizeof_desc(void);
+size_t mpe_sizeof_buffers(void);
+/* Observation widths of the built-in scenarios: fills desc->obs_off[0..A]; returns D_total or <0. */
+int mpe_fill_obs_layout(MpeScenarioDesc *desc);
+/* Per-entity constants as one float table for the workgroup-per-world kernels:
+ * returns the number of floats; writes them to host_out when it is not NULL. */
+int mpe_fill_entity_table(const MpeScenarioDesc *desc, float *host_out);
+
+/* ---- the fused hot path --------------------------------------------------------------------
+ * mpe_step: one MultiAgentEnv.step for B worlds in ONE kernel launch --
+ *   _set_action (environment.py:144-181) -> World.step (core.py:117-131: apply_action_force
+ *   :134-140, apply_environment_force :143-155 / get_collision_force :180-196, integrate_state
+ *   :158-169, update_agent_state :171-177) -> per agent observation/reward/done/info
+ *   (environment.py:92-97 -> Scenario.observation/reward/benchmark_data) -> shared-reward sum
+ *   (environment.py:100-102).  Reads pos, vel, act|ids; writes pos, vel, obs, rew, done, info_*. */
+int mpe_step(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, void *stream);
+
+/* mpe_observe: the output half only (used by reset(): environment.py:106-116 -> _get_obs, and by
+ * the phase-level tests): obs (+ rew/done/info when those pointers are set) from the current state. */
+int mpe_observe(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, void *stream);
+
+/* mpe_world_step: World.step only (core.py:117-131) incl. action decode; for user-written
+ * scenarios whose observation/reward stay host-side tensor code. */
+int mpe_world_step(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, void *stream);
+
+/* ---- phase-level entry points (one reference function each; tests + generic path) ----------- */
+/* _set_action + World.apply_action_force (environment.py:144-181, core.py:134-140): force = u   */
+int mpe_apply_action_force(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, void *stream);
+/* World.apply_environment_force + get_collision_force (core.py:143-155,180-196): force += contacts */
+int mpe_collision_force(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, void *stream);
+/* World.integrate_state (core.py:158-169): vel,pos <- force */
+int mpe_integrate_state(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, void *stream);
+
+/* ---- device-side reset and synthetic actions (counter-based Philox4x32-10) -------------------
+ * mpe_reset: Scenario.reset_world (simple_spread.py:31-45, simple_tag.py:39-54, simple.py:24-39)
+ *   for the worlds whose mask byte is non-zero (mask == NULL: all): agents then landmarks,
+ *   pos ~ U[-1,1)^2 (landmarks U[-r,r)^2 with r = landmark_range), vel = 0.  The reference draws
+ *   from NumPy's global MT19937; this draws from Philox keyed by (seed, world, episode) -- same
+ *   distribution, different stream (seed-exact resets are done host-side).
+ *   The generator is indexed by the GLOBAL world number world_offset + b, so a batch sharded over
+ *   several GPUs (rank r owns worlds [r*B, (r+1)*B)) draws exactly what one big batch would.     */
+int mpe_reset(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, const uint8_t *mask,
+              float landmark_range, uint64_t seed, uint64_t episode, int64_t world_offset, void *stream);
+/* Uniform random moves: one-hot rows into act [A][B][5] and/or ids [A][B] (either may be NULL). */
+int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed,
+                       uint64_t step, int64_t world_offset, void *stream);
+
+/* mpe_rollout_random: T consecutive env steps with in-kernel uniform random moves and an
+ * in-kernel reset every `episode_len` steps (0 = never), state kept in registers between steps;
+ * every step's obs/rew/done are still written (to the same buffers as mpe_step).
+ * Bit-identical to T x { mpe_random_actions(step0+t); [mpe_reset]; mpe_step }.                  */
+int mpe_rollout_random(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, int32_t T,
+                       int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0,
+                       int64_t world_offset, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPE_HIP_H_ */

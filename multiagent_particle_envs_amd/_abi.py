@@ -1,0 +1,96 @@
+"""ctypes binding of libmpe_hip.so (the C ABI declared in include/mpe_hip.h).
+
+There is no CPU fallback: if the shared object is missing this module raises at import of the
+library handle (`lib()`), and every compute entry point needs device pointers.
+"""
+import ctypes as C
+import os
+
+MPE_ABI_VERSION = 1
+MPE_MAX_ENTITIES = 512
+MPE_ACTION_DIM = 5
+MPE_SCN_GENERIC, MPE_SCN_SIMPLE, MPE_SCN_SPREAD, MPE_SCN_TAG = 0, 1, 2, 3
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmpe_hip.so")
+
+_M = MPE_MAX_ENTITIES
+
+
+class MpeScenarioDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("n_agents", C.c_int32), ("n_landmarks", C.c_int32), ("dim_c", C.c_int32),
+        ("n_adversaries", C.c_int32), ("collaborative", C.c_int32),
+        ("dt", C.c_float), ("damping", C.c_float), ("contact_force", C.c_float), ("contact_margin", C.c_float),
+        ("size", C.c_float * _M), ("mass", C.c_float * _M), ("accel", C.c_float * _M),
+        ("max_speed", C.c_float * _M), ("movable", C.c_uint8 * _M), ("collide", C.c_uint8 * _M),
+        ("obs_off", C.c_int32 * (_M + 1)),
+    ]
+
+
+class MpeBuffers(C.Structure):
+    _fields_ = [
+        ("pos", C.c_void_p), ("vel", C.c_void_p), ("act", C.c_void_p), ("ids", C.c_void_p), ("u", C.c_void_p),
+        ("obs", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p),
+        ("info_rew", C.c_void_p), ("info_collisions", C.c_void_p), ("info_min_dists", C.c_void_p),
+        ("info_occupied", C.c_void_p), ("force", C.c_void_p), ("entity_table", C.c_void_p),
+    ]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "mpe_abi_version": (C.c_int, []),
+    "mpe_last_error": (C.c_char_p, []),
+    "mpe_sizeof_desc": (C.c_size_t, []),
+    "mpe_sizeof_buffers": (C.c_size_t, []),
+    "mpe_fill_obs_layout": (C.c_int, [C.POINTER(MpeScenarioDesc)]),
+    "mpe_fill_entity_table": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(C.c_float)]),
+    "mpe_step": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
+    "mpe_observe": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
+    "mpe_world_step": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
+    "mpe_apply_action_force": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
+    "mpe_collision_force": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
+    "mpe_integrate_state": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
+    "mpe_reset": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p, C.c_float,
+                            C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]),
+    "mpe_random_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64,
+                                     C.c_int64, C.c_void_p]),
+    "mpe_rollout_random": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_int32,
+                                     C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]),
+}
+
+_lib = None
+
+
+class MpeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmpe_hip.so once.  torch is imported first so that the HIP runtime already mapped by
+    torch (same SONAME libamdhip64.so.7) is the one our kernels register with."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MpeError(
+            "%s is missing: build it with `python -m multiagent_particle_envs_amd._build` "
+            "(there is no CPU fallback for the step path)" % LIB_PATH)
+    import torch  # noqa: F401  (maps torch's libamdhip64 before ours resolves its NEEDED entry)
+    handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL if hasattr(C, "RTLD_GLOBAL") else 0)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(handle, name)  # AttributeError => symbol not exported
+        fn.restype = res
+        fn.argtypes = args
+    if handle.mpe_abi_version() != MPE_ABI_VERSION:
+        raise MpeError("ABI version mismatch: library %d, binding %d" % (handle.mpe_abi_version(), MPE_ABI_VERSION))
+    if handle.mpe_sizeof_desc() != C.sizeof(MpeScenarioDesc) or handle.mpe_sizeof_buffers() != C.sizeof(MpeBuffers):
+        raise MpeError("struct layout mismatch between include/mpe_hip.h and _abi.py")
+    _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().mpe_last_error().decode("utf-8", "replace")
+        raise MpeError("%s failed (code %d): %s" % (what or "libmpe_hip call", rc, msg))

@@ -1,0 +1,341 @@
+"""Batched world model: the reference's Entity/Agent/Landmark/World API over SoA device tensors.
+
+The reference keeps one Python object per entity, each holding its own 2-vector
+(multiagent/core.py:4-79).  Here a World owns the state of B independent worlds as two
+structure-of-arrays tensors with the batch index innermost,
+
+    world.pos  [E, 2, B] fp32     agents first, then landmarks   (core.py:103-104 ordering)
+    world.vel  [A, 2, B] fp32     landmarks are never integrated (core.py:160)
+
+which is the layout the HIP kernels read with coalesced 256-byte wave accesses.  The familiar
+attribute paths still work: `agent.state.p_pos` is a live [B, 2] *view* of that storage and
+assigning to it copies into the storage, so scenario code written against the reference's names
+(`entity.state.p_pos - agent.state.p_pos`) runs unchanged on batched tensors.
+
+World.step() = core.py:117-131 executed by libmpe_hip.so (`mpe_world_step`), never on the CPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi
+
+
+class EntityState(object):
+    """p_pos / p_vel of one entity for all B worlds (reference: core.py:4-9)."""
+
+    def __init__(self):
+        self._world = None
+        self._index = None
+        self._is_agent = False
+        self._pending = {}
+
+    def _bind(self, world, index, is_agent):
+        self._world, self._index, self._is_agent = world, index, is_agent
+        for k, v in self._pending.items():
+            setattr(self, k, v)
+        self._pending = {}
+
+    @property
+    def p_pos(self):
+        if self._world is None:
+            return self._pending.get("p_pos")
+        return self._world.pos[self._index].t()
+
+    @p_pos.setter
+    def p_pos(self, value):
+        if self._world is None:
+            self._pending["p_pos"] = value
+            return
+        self._world.pos[self._index].t().copy_(self._world._as_batch(value, 2))
+
+    @property
+    def p_vel(self):
+        if self._world is None:
+            return self._pending.get("p_vel")
+        if not self._is_agent:
+            return self._world._zero_vel
+        return self._world.vel[self._index].t()
+
+    @p_vel.setter
+    def p_vel(self, value):
+        if self._world is None:
+            self._pending["p_vel"] = value
+            return
+        if not self._is_agent:
+            return  # landmark velocities are identically zero (never integrated, never observed)
+        self._world.vel[self._index].t().copy_(self._world._as_batch(value, 2))
+
+
+class AgentState(EntityState):
+    """Adds the communication utterance c (reference: core.py:12-16)."""
+
+    def __init__(self):
+        super(AgentState, self).__init__()
+        self.c = None
+
+
+class Action(object):
+    """Physical action u [B,2] and communication action c (reference: core.py:19-24)."""
+
+    def __init__(self):
+        self.u = None
+        self.c = None
+
+
+class Entity(object):
+    """Per-entity constants, identical across the B worlds (reference: core.py:27-51)."""
+
+    def __init__(self):
+        self.name = ''
+        self.size = 0.050
+        self.movable = False
+        self.collide = True
+        self.density = 25.0
+        self.color = None
+        self.max_speed = None
+        self.accel = None
+        self.state = EntityState()
+        self.initial_mass = 1.0
+
+    @property
+    def mass(self):
+        return self.initial_mass
+
+
+class Landmark(Entity):
+    def __init__(self):
+        super(Landmark, self).__init__()
+
+
+class Agent(Entity):
+    """reference: core.py:59-79."""
+
+    def __init__(self):
+        super(Agent, self).__init__()
+        self.movable = True
+        self.silent = False
+        self.blind = False
+        self.u_noise = None
+        self.c_noise = None
+        self.u_range = 1.0
+        self.state = AgentState()
+        self.action = Action()
+        self.action_callback = None
+
+
+class World(object):
+    """B particle worlds stepped in lock-step (reference: core.py:82-196 for one world)."""
+
+    def __init__(self, batch_size=1, device=None):
+        self.agents = []
+        self.landmarks = []
+        self.dim_c = 0
+        self.dim_p = 2
+        self.dim_color = 3
+        self.dt = 0.1
+        self.damping = 0.25
+        self.contact_force = 1e+2
+        self.contact_margin = 1e-3
+        self.batch_size = int(batch_size)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() \
+                else torch.device("cpu")
+        self.device = torch.device(device)
+        self.pos = None
+        self.vel = None
+        self._zero_vel = None
+        self._desc = None
+        self._entity_table = None
+        self._u = None
+        self._bufs = None
+        self.rng_mode = "device"   # 'device' (Philox, mpe_reset) | 'numpy' (reference-order global np.random)
+        self.seed = 0
+        self.world_offset = 0      # global index of this batch's world 0 (multi-GPU sharding by batch index)
+        self._episode = 0
+
+    # ---- reference properties (core.py:101-114) --------------------------------------------------
+    @property
+    def entities(self):
+        return self.agents + self.landmarks
+
+    @property
+    def policy_agents(self):
+        return [agent for agent in self.agents if agent.action_callback is None]
+
+    @property
+    def scripted_agents(self):
+        return [agent for agent in self.agents if agent.action_callback is not None]
+
+    # ---- SoA storage -----------------------------------------------------------------------------
+    def allocate(self):
+        """Create the SoA tensors and bind every entity's state to its slice.  Called by
+        Scenario.make_world once the agent/landmark lists are final ("no agents created or
+        destroyed at runtime", environment.py:8)."""
+        A, E, B = len(self.agents), len(self.entities), self.batch_size
+        self.pos = torch.zeros((E, 2, B), dtype=torch.float32, device=self.device)
+        self.vel = torch.zeros((A, 2, B), dtype=torch.float32, device=self.device)
+        self._zero_vel = torch.zeros((B, 2), dtype=torch.float32, device=self.device)
+        for i, ent in enumerate(self.entities):
+            ent.state._bind(self, i, i < A)
+        self._desc = None
+        return self
+
+    def _as_batch(self, value, width):
+        t = torch.as_tensor(value, dtype=torch.float32, device=self.device)
+        if t.dim() == 1:
+            t = t.unsqueeze(0)
+        return t.expand(self.batch_size, width)
+
+    def set_state(self, pos, vel=None):
+        """Upload states: pos [B, E, 2], vel [B, A, 2] (host order, as the oracle keeps them)."""
+        p = torch.as_tensor(pos, dtype=torch.float32).reshape(self.batch_size, len(self.entities), 2)
+        self.pos.copy_(p.permute(1, 2, 0))
+        if vel is None:
+            self.vel.zero_()
+        else:
+            v = torch.as_tensor(vel, dtype=torch.float32).reshape(self.batch_size, len(self.agents), 2)
+            self.vel.copy_(v.permute(1, 2, 0))
+
+    def get_state(self):
+        """(pos [B,E,2], vel [B,A,2]) as host NumPy arrays."""
+        return (self.pos.permute(2, 0, 1).contiguous().cpu().numpy(),
+                self.vel.permute(2, 0, 1).contiguous().cpu().numpy())
+
+    # ---- reset_world bodies shared by the built-in scenarios ---------------------------------------
+    def reset_uniform(self, landmark_range=1.0, mask=None):
+        """Scenario.reset_world for the in-scope scenarios (simple_spread.py:38-45,
+        simple_tag.py:46-54, simple.py:33-39): agents ~ U[-1,1)^2, landmarks ~ U[-r,r)^2, vel = 0.
+        rng_mode 'device': Philox on the GPU (`mpe_reset`), keyed by (seed, world, episode);
+        rng_mode 'numpy' : the process-global np.random in the reference's draw order (agents then
+                           landmarks, world by world) -- seed-identical to the reference for B=1."""
+        import numpy as np
+        A, E, B = len(self.agents), len(self.entities), self.batch_size
+        if self.rng_mode == "numpy":
+            pos, _ = self.get_state() if mask is not None else (np.zeros((B, E, 2), np.float32), None)
+            m = None if mask is None else torch.as_tensor(mask).cpu().numpy().astype(bool)
+            for b in range(B):
+                if m is not None and not m[b]:
+                    continue
+                for e in range(E):
+                    r = 1.0 if e < A else landmark_range
+                    pos[b, e] = np.random.uniform(-r, +r, self.dim_p)
+            if m is None:
+                self.set_state(pos, None)
+            else:
+                _, vel = self.get_state()
+                vel[m] = 0.0
+                self.set_state(pos, vel)
+            return
+        self._require_device()
+        desc = self.scenario_desc(_abi.MPE_SCN_GENERIC)
+        bufs = _abi.MpeBuffers()
+        bufs.pos, bufs.vel = self.pos.data_ptr(), self.vel.data_ptr()
+        mptr = None
+        if mask is not None:
+            mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            mptr = C.c_void_p(mask.data_ptr())
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _abi.check(_abi.lib().mpe_reset(C.byref(desc), C.byref(bufs), B, mptr, float(landmark_range),
+                                        int(self.seed) & (2 ** 64 - 1), int(self._episode), int(self.world_offset),
+                                        C.c_void_p(stream)),
+                   "mpe_reset")
+        self._episode += 1
+
+    def reset_from_numpy_seeds(self, seeds, landmark_range=1.0):
+        """World b starts exactly as the reference would after `np.random.seed(seeds[b]);
+        env.reset()` (MT19937 draws on the host, then one upload) -- the parity-test reset."""
+        import numpy as np
+        A, E, B = len(self.agents), len(self.entities), self.batch_size
+        assert len(seeds) == B
+        pos = np.zeros((B, E, 2), np.float64)
+        for b, s in enumerate(seeds):
+            rs = np.random.RandomState(int(s))
+            for e in range(E):
+                r = 1.0 if e < A else landmark_range
+                pos[b, e] = rs.uniform(-r, +r, self.dim_p)
+        self.set_state(pos, None)
+
+    # ---- descriptor handed to the C ABI ----------------------------------------------------------
+    def scenario_desc(self, kind=_abi.MPE_SCN_GENERIC, n_adversaries=0):
+        """MpeScenarioDesc for this world (cached per kind).  Constants are read off the entity
+        objects exactly where the reference reads them (size/movable/collide/accel/max_speed/mass,
+        core.py:27-51; accel -> sensitivity default 5.0, environment.py:178-181)."""
+        key = (kind, n_adversaries)
+        if self._desc is None:
+            self._desc = {}
+        if key in self._desc:
+            return self._desc[key]
+        ents = self.entities
+        A, L = len(self.agents), len(self.landmarks)
+        if A + L > _abi.MPE_MAX_ENTITIES:
+            raise _abi.MpeError("too many entities: %d > %d" % (A + L, _abi.MPE_MAX_ENTITIES))
+        d = _abi.MpeScenarioDesc()
+        d.kind, d.n_agents, d.n_landmarks, d.dim_c = kind, A, L, int(self.dim_c)
+        d.n_adversaries = int(n_adversaries)
+        d.collaborative = 1 if getattr(self, "collaborative", False) else 0
+        d.dt, d.damping = self.dt, self.damping
+        d.contact_force, d.contact_margin = self.contact_force, self.contact_margin
+        for e, ent in enumerate(ents):
+            d.size[e] = ent.size
+            d.mass[e] = ent.mass
+            d.accel[e] = 5.0 if ent.accel is None else ent.accel
+            d.max_speed[e] = -1.0 if ent.max_speed is None else ent.max_speed
+            d.movable[e] = 1 if ent.movable else 0
+            d.collide[e] = 1 if ent.collide else 0
+        if kind != _abi.MPE_SCN_GENERIC:
+            total = _abi.lib().mpe_fill_obs_layout(C.byref(d))
+            if total < 0:
+                _abi.check(total, "mpe_fill_obs_layout")
+        self._desc[key] = d
+        return d
+
+    def entity_table(self, desc):
+        """Device copy of the per-entity constant table (workgroup-per-world kernels)."""
+        if self._entity_table is None:
+            n = _abi.lib().mpe_fill_entity_table(C.byref(desc), None)
+            host = (C.c_float * n)()
+            _abi.lib().mpe_fill_entity_table(C.byref(desc), host)
+            self._entity_table = torch.tensor(list(host), dtype=torch.float32, device=self.device)
+        return self._entity_table
+
+    def _require_device(self):
+        if self.pos is None:
+            raise _abi.MpeError("World.allocate() has not been called")
+        if not self.pos.is_cuda:
+            raise _abi.MpeError("the step path runs on a HIP device only (world tensors are on %s); "
+                                "there is no CPU fallback" % self.pos.device)
+
+    # ---- World.step (core.py:117-131) -----------------------------------------------------------
+    def step(self):
+        """Advance all B worlds using each agent's `action.u` ([B,2] tensors), physics only:
+        apply_action_force, apply_environment_force, integrate_state, update_agent_state."""
+        self._require_device()
+        for agent in self.scripted_agents:
+            agent.action = agent.action_callback(agent, self)
+        A, B = len(self.agents), self.batch_size
+        if self._u is None:
+            self._u = torch.zeros((A, 2, B), dtype=torch.float32, device=self.device)
+        for i, agent in enumerate(self.agents):
+            if agent.movable and agent.action.u is not None:
+                u = self._as_batch(agent.action.u, 2)
+                if agent.u_noise:
+                    u = u + torch.randn_like(u) * agent.u_noise
+                self._u[i].t().copy_(u)
+            else:
+                self._u[i].zero_()
+        desc = self.scenario_desc(_abi.MPE_SCN_GENERIC)
+        bufs = _abi.MpeBuffers()
+        bufs.pos, bufs.vel, bufs.u = self.pos.data_ptr(), self.vel.data_ptr(), self._u.data_ptr()
+        if A + len(self.landmarks) > 16:
+            bufs.entity_table = self.entity_table(desc).data_ptr()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _abi.check(_abi.lib().mpe_world_step(C.byref(desc), C.byref(bufs), B, C.c_void_p(stream)), "mpe_world_step")
+        for agent in self.agents:  # update_agent_state (core.py:171-177)
+            if agent.silent:
+                agent.state.c = torch.zeros((B, self.dim_c), dtype=torch.float32, device=self.device)
+            else:
+                c = agent.action.c
+                if c is not None and agent.c_noise:
+                    c = c + torch.randn_like(c) * agent.c_noise
+                agent.state.c = c

@@ -1,0 +1,266 @@
+// mpe_abi.hip -- the extern "C" surface declared in include/mpe_hip.h (host code only).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "mpe_internal.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int hip_result(int rc, const char *what) {
+  if (rc == 0) return 0;
+  if (rc == MPE_EUNSUPPORTED) return fail(rc, "%s: no kernel built for this scenario shape", what);
+  return fail(rc, "%s: %s", what, hipGetErrorString((hipError_t)rc));
+}
+
+int check_desc(const MpeScenarioDesc *d, const char *what) {
+  if (!d) return fail(MPE_EINVAL, "%s: desc is NULL", what);
+  if (d->n_agents < 1 || d->n_landmarks < 0 || d->n_agents + d->n_landmarks > MPE_MAX_ENTITIES)
+    return fail(MPE_EINVAL, "%s: need 1 <= A, 0 <= L, A+L <= %d (got A=%d L=%d)", what, MPE_MAX_ENTITIES,
+                d->n_agents, d->n_landmarks);
+  if (d->kind < MPE_SCN_GENERIC || d->kind > MPE_SCN_TAG) return fail(MPE_EINVAL, "%s: bad kind %d", what, d->kind);
+  for (int e = d->n_agents; e < d->n_agents + d->n_landmarks; ++e)
+    if (d->movable[e]) return fail(MPE_EUNSUPPORTED, "%s: movable landmarks are not supported (entity %d)", what, e);
+  for (int e = 0; e < d->n_agents; ++e)
+    if (!(d->mass[e] > 0.f)) return fail(MPE_EINVAL, "%s: mass[%d] must be > 0", what, e);
+  if (d->kind == MPE_SCN_TAG && (d->n_adversaries < 1 || d->n_adversaries >= d->n_agents))
+    return fail(MPE_EINVAL, "%s: simple_tag needs 1 <= n_adversaries < A", what);
+  if ((d->kind == MPE_SCN_SPREAD || d->kind == MPE_SCN_TAG) && d->dim_c != 2)
+    return fail(MPE_EUNSUPPORTED, "%s: built-in spread/tag kernels assume dim_c == 2 (got %d)", what, d->dim_c);
+  return 0;
+}
+
+bool use_narrow(const MpeScenarioDesc *d) {
+  return d->n_agents + d->n_landmarks <= mpe::kNarrowMaxE &&
+         mpe::narrow_supports(d->kind, d->n_agents, d->n_landmarks, d->n_adversaries);
+}
+
+mpe::NarrowDesc make_narrow(const MpeScenarioDesc *d, const MpeBuffers *b, size_t B) {
+  mpe::NarrowDesc n;
+  std::memset(&n, 0, sizeof(n));
+  const int E = d->n_agents + d->n_landmarks;
+  for (int e = 0; e < E; ++e) {
+    n.size[e] = d->size[e];
+    n.mass[e] = d->mass[e];
+    n.accel[e] = d->accel[e];
+    n.max_speed[e] = d->max_speed[e];
+    if (d->movable[e]) n.movable |= 1u << e;
+    if (d->collide[e]) n.collide |= 1u << e;
+  }
+  bool vec4 = b->obs && (reinterpret_cast<uintptr_t>(b->obs) % 16 == 0);
+  for (int i = 0; i <= d->n_agents; ++i) {
+    n.obs_off[i] = d->obs_off[i];
+    if (((size_t)d->obs_off[i] * B) % 4 != 0) vec4 = false;
+  }
+  n.dt = d->dt;
+  n.damp = 1.0f - d->damping;  // (1 - self.damping), core.py:161 (0.75 exactly for the default)
+  n.cforce = d->contact_force;
+  n.cmargin = d->contact_margin;
+  n.collaborative = d->collaborative;
+  n.vec4 = vec4 ? 1 : 0;
+  return n;
+}
+
+mpe::WideDesc make_wide(const MpeScenarioDesc *d) {
+  mpe::WideDesc w;
+  w.kind = d->kind;
+  w.A = d->n_agents;
+  w.L = d->n_landmarks;
+  w.dim_c = d->dim_c;
+  w.collaborative = d->collaborative;
+  w.D = d->obs_off[1] - d->obs_off[0];
+  w.dt = d->dt;
+  w.damp = 1.0f - d->damping;
+  w.cforce = d->contact_force;
+  w.cmargin = d->contact_margin;
+  return w;
+}
+
+int need(const void *p, const char *what, const char *name) {
+  return p ? 0 : fail(MPE_EINVAL, "%s: bufs->%s is NULL", what, name);
+}
+
+int check_state(const MpeBuffers *b, int64_t B, const char *what) {
+  if (!b) return fail(MPE_EINVAL, "%s: bufs is NULL", what);
+  if (B < 0) return fail(MPE_EINVAL, "%s: B < 0", what);
+  if (int rc = need(b->pos, what, "pos")) return rc;
+  if (int rc = need(b->vel, what, "vel")) return rc;
+  return 0;
+}
+
+int check_actions(const MpeBuffers *b, const char *what) {
+  if ((b->act != nullptr) + (b->ids != nullptr) + (b->u != nullptr) != 1)
+    return fail(MPE_EINVAL, "%s: exactly one of bufs->act / bufs->ids / bufs->u must be set", what);
+  return 0;
+}
+
+int check_info(const MpeScenarioDesc *d, const MpeBuffers *b, const char *what) {
+  if (d->kind == MPE_SCN_SPREAD && b->info_rew &&
+      !(b->info_collisions && b->info_min_dists && b->info_occupied))
+    return fail(MPE_EINVAL, "%s: spread benchmark_data needs all four info_* buffers", what);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpe_abi_version(void) { return MPE_ABI_VERSION; }
+const char *mpe_last_error(void) { return g_err; }
+size_t mpe_sizeof_desc(void) { return sizeof(MpeScenarioDesc); }
+size_t mpe_sizeof_buffers(void) { return sizeof(MpeBuffers); }
+
+int mpe_fill_obs_layout(MpeScenarioDesc *d) {
+  if (int rc = check_desc(d, "mpe_fill_obs_layout")) return rc;
+  const int A = d->n_agents, L = d->n_landmarks;
+  d->obs_off[0] = 0;
+  for (int i = 0; i < A; ++i) {
+    int D = 0;
+    switch (d->kind) {
+      case MPE_SCN_SIMPLE: D = 2 + 2 * L; break;                                   // simple.py:45-50
+      case MPE_SCN_SPREAD: D = 4 + 2 * L + 2 * (A - 1) + d->dim_c * (A - 1); break;  // simple_spread.py:84-100
+      case MPE_SCN_TAG: {                                                          // simple_tag.py:131-147
+        const int good_others = (A - d->n_adversaries) - (i >= d->n_adversaries ? 1 : 0);
+        D = 4 + 2 * L + 2 * (A - 1) + 2 * good_others;
+        break;
+      }
+      default: D = 0;
+    }
+    d->obs_off[i + 1] = d->obs_off[i] + D;
+  }
+  return d->obs_off[A];
+}
+
+int mpe_fill_entity_table(const MpeScenarioDesc *d, float *out) {
+  if (int rc = check_desc(d, "mpe_fill_entity_table")) return rc;
+  const int E = d->n_agents + d->n_landmarks;
+  if (out) {
+    for (int e = 0; e < E; ++e) {
+      out[0 * E + e] = d->size[e];
+      out[1 * E + e] = d->mass[e];
+      out[2 * E + e] = d->accel[e];
+      out[3 * E + e] = d->max_speed[e];
+      out[4 * E + e] = d->movable[e] ? 1.f : 0.f;
+      out[5 * E + e] = d->collide[e] ? 1.f : 0.f;
+    }
+  }
+  return mpe::kEntityTableCols * E;
+}
+
+static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
+               void *stream) {
+  if (int rc = check_desc(d, what)) return rc;
+  if (int rc = check_state(b, B, what)) return rc;
+  if (phys) if (int rc = check_actions(b, what)) return rc;
+  if (out) {
+    if (d->kind == MPE_SCN_GENERIC) return fail(MPE_EINVAL, "%s: kind GENERIC has no output stage", what);
+    if (int rc = need(b->obs, what, "obs")) return rc;
+    if (int rc = check_info(d, b, what)) return rc;
+  }
+  if (B == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int kind = out ? d->kind : MPE_SCN_GENERIC;
+  MpeScenarioDesc dd;
+  const MpeScenarioDesc *use = d;
+  if (!out && d->kind != MPE_SCN_GENERIC) {  // physics-only call on a built-in scenario
+    dd = *d;
+    dd.kind = MPE_SCN_GENERIC;
+    use = &dd;
+  }
+  if (use_narrow(use)) {
+    const mpe::NarrowDesc n = make_narrow(use, b, (size_t)B);
+    return hip_result(mpe::launch_narrow(phys ? mpe::NarrowOp::Step : mpe::NarrowOp::Observe, kind, d->n_agents,
+                                         d->n_landmarks, d->n_adversaries, n, *b, (size_t)B, s), what);
+  }
+  if (kind == MPE_SCN_GENERIC || kind == MPE_SCN_SPREAD) {
+    if (int rc = need(b->entity_table, what, "entity_table (required by the workgroup-per-world kernels)")) return rc;
+    mpe::WideDesc w = make_wide(use);
+    w.kind = kind;
+    return hip_result(mpe::launch_wide(phys, out, w, *b, (size_t)B, s), what);
+  }
+  return fail(MPE_EUNSUPPORTED, "%s: no kernel for kind=%d A=%d L=%d n_adv=%d", what, d->kind, d->n_agents,
+              d->n_landmarks, d->n_adversaries);
+}
+
+int mpe_step(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, void *stream) {
+  return run("mpe_step", true, true, d, b, B, stream);
+}
+int mpe_observe(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, void *stream) {
+  return run("mpe_observe", false, true, d, b, B, stream);
+}
+int mpe_world_step(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, void *stream) {
+  return run("mpe_world_step", true, false, d, b, B, stream);
+}
+
+static int run_phase(const char *what, int phase, const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
+                     void *stream) {
+  if (int rc = check_desc(d, what)) return rc;
+  if (int rc = check_state(b, B, what)) return rc;
+  if (int rc = need(b->force, what, "force")) return rc;
+  if (phase == 0) if (int rc = check_actions(b, what)) return rc;
+  if (d->n_agents + d->n_landmarks > mpe::kNarrowMaxE)
+    return fail(MPE_EUNSUPPORTED, "%s: phase-level entry points cover A+L <= %d", what, mpe::kNarrowMaxE);
+  if (B == 0) return 0;
+  const mpe::NarrowDesc n = make_narrow(d, b, (size_t)B);
+  return hip_result(mpe::launch_phase(phase, d->n_agents, d->n_landmarks, n, *b, (size_t)B,
+                                      static_cast<hipStream_t>(stream)), what);
+}
+int mpe_apply_action_force(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, void *stream) {
+  return run_phase("mpe_apply_action_force", 0, d, b, B, stream);
+}
+int mpe_collision_force(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, void *stream) {
+  return run_phase("mpe_collision_force", 1, d, b, B, stream);
+}
+int mpe_integrate_state(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, void *stream) {
+  return run_phase("mpe_integrate_state", 2, d, b, B, stream);
+}
+
+int mpe_reset(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, const uint8_t *mask, float landmark_range,
+              uint64_t seed, uint64_t episode, int64_t world_offset, void *stream) {
+  const char *what = "mpe_reset";
+  if (int rc = check_desc(d, what)) return rc;
+  if (int rc = check_state(b, B, what)) return rc;
+  if (B == 0) return 0;
+  return hip_result(mpe::launch_reset(d->n_agents, d->n_landmarks, *b, (size_t)B, mask, landmark_range, seed,
+                                      episode, (uint64_t)world_offset, static_cast<hipStream_t>(stream)), what);
+}
+
+int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed, uint64_t step,
+                       int64_t world_offset, void *stream) {
+  const char *what = "mpe_random_actions";
+  if (!act && !ids) return fail(MPE_EINVAL, "%s: act and ids are both NULL", what);
+  if (n_agents < 1 || B < 0) return fail(MPE_EINVAL, "%s: bad n_agents/B", what);
+  if (B == 0) return 0;
+  return hip_result(mpe::launch_random_actions(act, ids, n_agents, (size_t)B, seed, step, (uint64_t)world_offset,
+                                               static_cast<hipStream_t>(stream)), what);
+}
+
+int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, int32_t T, int32_t episode_len,
+                       float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset, void *stream) {
+  const char *what = "mpe_rollout_random";
+  if (int rc = check_desc(d, what)) return rc;
+  if (int rc = check_state(b, B, what)) return rc;
+  if (int rc = need(b->obs, what, "obs")) return rc;
+  if (int rc = check_info(d, b, what)) return rc;
+  if (T < 0 || episode_len < 0) return fail(MPE_EINVAL, "%s: T, episode_len must be >= 0", what);
+  if (B == 0 || T == 0) return 0;
+  if (!use_narrow(d)) return fail(MPE_EUNSUPPORTED, "%s: fused rollout exists for the thread-per-world shapes only", what);
+  const mpe::NarrowDesc n = make_narrow(d, b, (size_t)B);
+  return hip_result(mpe::launch_rollout(d->kind, d->n_agents, d->n_landmarks, d->n_adversaries, n, *b, (size_t)B, T,
+                                        episode_len, landmark_range, seed, step0, (uint64_t)world_offset,
+                                        static_cast<hipStream_t>(stream)),
+                    what);
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+// mpe_device.h -- device-side building blocks shared by the gfx950 kernels (internal).
+//
+// Arithmetic follows the reference's operation order in fp32.  The file
+// is compiled with -ffp-contract=off so that a*a + b*b is two roundings + an add exactly as
+// NumPy's sqrt(sum(square(delta))) in float32 -- the strict `dist < dist_min` tests that feed the
+// integer outputs (collision counts, occupied landmarks) are then bit-exact functions of the
+// positions (parity protocol).  sqrtf and '/' are the correctly rounded forms (hipcc
+// default -fhip-fp32-correctly-rounded-divide-sqrt).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mpe_hip.h"
+
+namespace mpe {
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kNarrowMaxE = 16;  // entity limit of the thread-per-world kernels' kernarg descriptor
+
+// Scenario constants as kernel arguments (SGPR-resident, uniform): thread-per-world kernels.
+struct NarrowDesc {
+  float size[kNarrowMaxE];
+  float mass[kNarrowMaxE];
+  float accel[kNarrowMaxE];
+  float max_speed[kNarrowMaxE];
+  int32_t obs_off[kNarrowMaxE + 1];
+  uint32_t movable;  // bit e
+  uint32_t collide;  // bit e
+  float dt, damp /* 1 - damping */, cforce, cmargin;
+  int32_t collaborative;
+  int32_t vec4;  // obs rows may be written with 16-byte stores (alignment checked on the host)
+};
+
+// np.logaddexp(0, x) (core.py:192) in the form NumPy evaluates it; stable for |x| ~ 1e3 (H6).
+__device__ __forceinline__ float softplus0(float x) {
+  const float l = log1pf(expf(-fabsf(x)));
+  return x > 0.f ? x + l : l;
+}
+
+// sqrt(dx^2 + dy^2) with NumPy's rounding sequence (no fma).
+__device__ __forceinline__ float dist2d(float dx, float dy) {
+  const float sx = dx * dx;
+  const float sy = dy * dy;
+  return sqrtf(sx + sy);
+}
+
+// World.get_collision_force (core.py:180-196) for one pair; returns the force on `a`
+// (the force on `b` is its negation).  dx,dy = pos_a - pos_b.
+__device__ __forceinline__ void contact_force(float dx, float dy, float dist_min, float cforce,
+                                              float k, float &fx, float &fy) {
+  const float dist = dist2d(dx, dy);
+  const float pen = softplus0(-(dist - dist_min) / k) * k;
+  fx = cforce * dx / dist * pen;
+  fy = cforce * dy / dist * pen;
+}
+
+// World.integrate_state body for one movable entity (core.py:161-169); max_speed < 0 == None.
+__device__ __forceinline__ void integrate_one(float &px, float &py, float &vx, float &vy, float fx,
+                                              float fy, float mass, float max_speed, float damp,
+                                              float dt) {
+  vx = vx * damp;
+  vy = vy * damp;
+  vx += (fx / mass) * dt;
+  vy += (fy / mass) * dt;
+  if (max_speed >= 0.f) {
+    const float speed = sqrtf(vx * vx + vy * vy);
+    if (speed > max_speed) {
+      vx = vx / speed * max_speed;
+      vy = vy / speed * max_speed;
+    }
+  }
+  px += vx * dt;
+  py += vy * dt;
+}
+
+// _set_action (environment.py:161-181): one action row -> u = (a1-a2, a3-a4) * sensitivity, or the
+// integer form 1:-x 2:+x 3:-y 4:+y (the reference's opposite sign convention).
+__device__ __forceinline__ void decode_row(const float *__restrict__ a, float sens, float &ux, float &uy) {
+  ux = (a[1] - a[2]) * sens;
+  uy = (a[3] - a[4]) * sens;
+}
+__device__ __forceinline__ void decode_id(int id, float sens, float &ux, float &uy) {
+  ux = (id == 1 ? -1.f : (id == 2 ? 1.f : 0.f)) * sens;
+  uy = (id == 3 ? -1.f : (id == 4 ? 1.f : 0.f)) * sens;
+}
+
+// Action force of agent i in world w from whichever action form the caller supplied.
+__device__ __forceinline__ void fetch_action(const MpeBuffers &b, size_t B, int i, size_t w, float sens, float &ux,
+                                             float &uy) {
+  if (b.act) decode_row(b.act + ((size_t)i * B + w) * MPE_ACTION_DIM, sens, ux, uy);
+  else if (b.ids) decode_id(b.ids[(size_t)i * B + w], sens, ux, uy);
+  else { ux = b.u[(size_t)(2 * i) * B + w]; uy = b.u[(size_t)(2 * i + 1) * B + w]; }
+}
+
+// simple_tag.py:103-108
+__device__ __forceinline__ float tag_bound(float x) {
+  if (x < 0.9f) return 0.f;
+  if (x < 1.0f) return (x - 0.9f) * 10.f;
+  return fminf(expf(2.f * x - 2.f), 10.f);
+}
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter-based: reset + synthetic actions -------------
+struct U4 { uint32_t x, y, z, w; };
+__host__ __device__ inline U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c.x;
+    const uint64_t p1 = (uint64_t)M1 * c.z;
+    U4 n;
+    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (uint32_t)p1;
+    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (uint32_t)p0;
+    c = n;
+    k0 += W0;
+    k1 += W1;
+  }
+  return c;
+}
+// 24-bit uniform in [0,1), then lo + (hi-lo)*u evaluated as u*(2r) - r (two roundings, no fma)
+__host__ __device__ inline float uniform_pm(uint32_t bits, float r) {
+  const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
+  return u * (2.f * r) - r;
+}
+// streams: word 3 of the counter separates the uses
+constexpr uint32_t kStreamReset = 0x52455345u;   // "RESE"
+constexpr uint32_t kStreamAction = 0x41435449u;  // "ACTI"
+
+// Position pair of entity e in world b for episode `ep`.
+__host__ __device__ inline void reset_draw(uint64_t seed, uint64_t b, uint64_t ep, int e, float r,
+                                           float &x, float &y) {
+  // counter = (world lo, world hi ^ episode hi, entity pair index, stream ^ episode lo)
+  U4 c;
+  c.x = (uint32_t)b;
+  c.y = (uint32_t)(b >> 32) ^ (uint32_t)(ep >> 32);
+  c.z = (uint32_t)(e >> 1);
+  c.w = kStreamReset ^ (uint32_t)ep;
+  const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  if (e & 1) { x = uniform_pm(o.z, r); y = uniform_pm(o.w, r); }
+  else       { x = uniform_pm(o.x, r); y = uniform_pm(o.y, r); }
+}
+// Uniform move in {0..4} for agent i of world b at global step `t`.
+__host__ __device__ inline int action_draw(uint64_t seed, uint64_t b, uint64_t t, int i) {
+  U4 c;
+  c.x = (uint32_t)b;
+  c.y = (uint32_t)(b >> 32) ^ (uint32_t)(t >> 32);
+  c.z = (uint32_t)(i >> 2);
+  c.w = kStreamAction ^ (uint32_t)t;
+  const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t w = (i & 3) == 0 ? o.x : (i & 3) == 1 ? o.y : (i & 3) == 2 ? o.z : o.w;
+  return (int)(((uint64_t)w * 5u) >> 32);
+}
+
+// ---- wave-private LDS transpose: 64 per-lane rows of D floats -> one contiguous 64*D-float run ----
+// The drop-in obs layout is row-major [B][D] per agent (72-byte rows at D=18): a thread-per-world
+// store would be stride-D scattered.  Each wave parks its 64 rows in its own LDS tile (row stride
+// D|1: odd => the column writes are bank-conflict-free) and streams the tile out as 16-byte
+// stores over the contiguous 256*D-byte segment it owns.  No workgroup barrier is involved.
+template <int D>
+__device__ __forceinline__ void store_rows(float *tile, const float (&row)[D], float *__restrict__ g,
+                                           int nvalid, int lane, bool vec4) {
+  constexpr int DP = D | 1;
+#pragma unroll
+  for (int c = 0; c < D; ++c) tile[lane * DP + c] = row[c];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int nfl = nvalid * D;
+  constexpr int NQ = 16 * D;  // float4 slots in a full tile
+#pragma unroll
+  for (int it = 0; it < (NQ + kWave - 1) / kWave; ++it) {
+    const int q = lane + kWave * it;
+    const int j = 4 * q;
+    if (q < NQ && j < nfl) {
+      float v[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int jj = j + m;
+        const int r = jj / D, c = jj - r * D;
+        v[m] = (jj < 64 * D) ? tile[r * DP + c] : 0.f;
+      }
+      if (vec4 && j + 3 < nfl) {
+        *reinterpret_cast<float4 *>(g + j) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (j + m < nfl) g[j + m] = v[m];
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int D>
+constexpr int tile_floats() { return kWave * (D | 1); }
+
+}  // namespace mpe

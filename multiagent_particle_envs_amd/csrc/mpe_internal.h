@@ -1,0 +1,34 @@
+// mpe_internal.h -- launch entry points shared between the kernel translation units and the C ABI.
+#pragma once
+#include "mpe_device.h"
+
+namespace mpe {
+
+enum class NarrowOp { Step, Observe };
+
+// thread-per-world family (mpe_narrow.hip)
+bool narrow_supports(int kind, int A, int L, int nadv);
+int launch_narrow(NarrowOp op, int kind, int A, int L, int nadv, const NarrowDesc &d, const MpeBuffers &b,
+                  size_t B, hipStream_t stream);
+int launch_phase(int phase, int A, int L, const NarrowDesc &d, const MpeBuffers &b, size_t B,
+                 hipStream_t stream);
+
+// workgroup-per-world family (mpe_wide.hip)
+struct WideDesc {
+  int32_t kind, A, L, dim_c, collaborative;
+  int32_t D;  // obs width (spread: same for every agent)
+  float dt, damp, cforce, cmargin;
+};
+constexpr int kEntityTableCols = 6;  // size, mass, accel, max_speed, movable, collide  -> [6][E] floats
+int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream);
+
+// reset / synthetic actions / fused rollout (mpe_rng.hip)
+int launch_reset(int A, int L, const MpeBuffers &b, size_t B, const uint8_t *mask, float landmark_range,
+                 uint64_t seed, uint64_t episode, uint64_t world_offset, hipStream_t stream);
+int launch_random_actions(float *act, int32_t *ids, int A, size_t B, uint64_t seed, uint64_t step,
+                          uint64_t world_offset, hipStream_t stream);
+int launch_rollout(int kind, int A, int L, int nadv, const NarrowDesc &d, const MpeBuffers &b, size_t B, int T,
+                   int episode_len, float landmark_range, uint64_t seed, uint64_t step0, uint64_t world_offset,
+                   hipStream_t stream);
+
+}  // namespace mpe

@@ -1,0 +1,374 @@
+"""Batched MultiAgentEnv: the reference's Gym-style adapter (multiagent/environment.py:9-283) for
+B worlds at once, with the body of step() replaced by ONE HIP kernel launch.
+
+API kept from the reference (same names, same return structure):
+    env.n, env.action_space[i], env.observation_space[i], env.world, env.agents,
+    env.shared_reward, env.discrete_action_input, env.force_discrete_action
+    obs_n = env.reset()
+    obs_n, reward_n, done_n, info_n = env.step(action_n)      # lists of length n
+With batch_size=B each list entry gains a leading batch axis: obs_n[i] is a [B, D_i] tensor,
+reward_n[i] a [B] tensor, done_n[i] a [B] bool tensor (always False: environment.py:132-135),
+info_n = {'n': [...]}.  In reference-compatibility mode (`batch_size=None` in make_env: one
+world, NumPy in / NumPy out, NumPy-global-RNG resets) the env is used exactly like the reference's.
+
+Two execution paths:
+  fused    built-in scenarios (simple, simple_spread, simple_tag): action decode, World.step and
+           every agent's observation/reward/done/info in one `mpe_step` launch (csrc/mpe_narrow.hip
+           thread-per-world, csrc/mpe_wide.hip workgroup-per-world for large N).
+  generic  any user Scenario: actions decoded with tensor ops (all of _set_action's modes,
+           environment.py:144-192), physics by `mpe_world_step`, then the user's Python
+           reward/observation callbacks on [B, .] tensor views.
+There is no CPU fallback on either path.
+
+Output lifetime: step()/reset() return views of ping-pong device buffers -- the arrays returned by
+call k stay intact until call k+2 returns (so `obs_n`/`new_obs_n` of the usual training loop never
+alias).  Pass fresh_outputs=True for reference-style freshly allocated outputs on every call.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi, spaces
+
+
+class _OutputSet(object):
+    """One set of device output buffers + the ctypes MpeBuffers that points at them."""
+
+    def __init__(self, env):
+        w, dev = env.world, env.world.device
+        A, B = len(w.agents), w.batch_size
+        off = env._obs_off
+        self.obs = torch.zeros(int(off[-1]) * B, dtype=torch.float32, device=dev)
+        self.obs_n = [self.obs[off[i] * B: off[i + 1] * B].view(B, off[i + 1] - off[i]) for i in range(A)]
+        self.rew = torch.zeros((A, B), dtype=torch.float32, device=dev)
+        self.done = torch.zeros((A, B), dtype=torch.bool, device=dev)
+        self.info = {}
+        if env._benchmark:
+            if env._kind == _abi.MPE_SCN_SPREAD:
+                self.info = {"rew": torch.zeros((A, B), dtype=torch.float32, device=dev),
+                             "collisions": torch.zeros((A, B), dtype=torch.int32, device=dev),
+                             "min_dists": torch.zeros((A, B), dtype=torch.float32, device=dev),
+                             "occupied_landmarks": torch.zeros((A, B), dtype=torch.int32, device=dev)}
+            elif env._kind == _abi.MPE_SCN_TAG:
+                self.info = {"collisions": torch.zeros((A, B), dtype=torch.int32, device=dev)}
+        b = _abi.MpeBuffers()
+        b.pos, b.vel = w.pos.data_ptr(), w.vel.data_ptr()
+        b.obs, b.rew, b.done = self.obs.data_ptr(), self.rew.data_ptr(), self.done.data_ptr()
+        if "rew" in self.info:
+            b.info_rew = self.info["rew"].data_ptr()
+            b.info_min_dists = self.info["min_dists"].data_ptr()
+            b.info_occupied = self.info["occupied_landmarks"].data_ptr()
+        if "collisions" in self.info:
+            b.info_collisions = self.info["collisions"].data_ptr()
+        if env._entity_table is not None:
+            b.entity_table = env._entity_table.data_ptr()
+        self.bufs = b
+        self.reward_n = [self.rew[i] for i in range(A)]
+        self.done_n = [self.done[i] for i in range(A)]
+
+    def info_n(self, env):
+        A = len(env.agents)
+        if not env._benchmark:
+            return {"n": [{} for _ in range(A)]}
+        if env._kind == _abi.MPE_SCN_SPREAD:
+            i_ = self.info
+            return {"n": [(i_["rew"][i], i_["collisions"][i], i_["min_dists"][i], i_["occupied_landmarks"][i])
+                          for i in range(A)]}
+        if env._kind == _abi.MPE_SCN_TAG:
+            return {"n": [self.info["collisions"][i] for i in range(A)]}
+        return {"n": [{} for _ in range(A)]}
+
+
+class MultiAgentEnv(object):
+    metadata = {'render.modes': []}
+
+    def __init__(self, world, reset_callback=None, reward_callback=None, observation_callback=None,
+                 info_callback=None, done_callback=None, shared_viewer=True,
+                 numpy_io=False, fresh_outputs=False, fused=None):
+        self.world = world
+        self.agents = self.world.policy_agents
+        self.n = len(world.policy_agents)
+        self.batch_size = world.batch_size
+        self.reset_callback = reset_callback
+        self.reward_callback = reward_callback
+        self.observation_callback = observation_callback
+        self.info_callback = info_callback
+        self.done_callback = done_callback
+        # environment parameters (reference defaults, environment.py:28-36)
+        self.discrete_action_space = True
+        self.discrete_action_input = False
+        self.force_discrete_action = world.discrete_action if hasattr(world, 'discrete_action') else False
+        self.shared_reward = world.collaborative if hasattr(world, 'collaborative') else False
+        self.time = 0
+        self.numpy_io = bool(numpy_io)
+        self.fresh_outputs = bool(fresh_outputs)
+
+        # ---- can the whole step run as one fused kernel? ---------------------------------------------
+        sc = getattr(observation_callback, "__self__", None)
+        kind = getattr(sc, "kind", None)
+        pkg = __name__.rsplit(".", 1)[0] + ".scenarios."
+        builtin = next((c for c in type(sc).__mro__ if c.__module__.startswith(pkg)), None) if sc is not None else None
+        own = builtin is not None and kind is not None and \
+            getattr(reward_callback, "__self__", None) is sc and \
+            getattr(reset_callback, "__self__", None) is sc and \
+            getattr(reward_callback, "__func__", None) is builtin.__dict__.get("reward") and \
+            getattr(observation_callback, "__func__", None) is builtin.__dict__.get("observation") and \
+            (info_callback is None or (getattr(info_callback, "__self__", None) is sc and
+                                       info_callback.__func__ is builtin.__dict__.get("benchmark_data"))) and \
+            done_callback is None and len(world.scripted_agents) == 0 and \
+            all(a.silent and not a.u_noise for a in world.agents)
+        if fused is None:
+            fused = own
+        if fused and not own:
+            raise _abi.MpeError("fused=True needs the unmodified callbacks of a built-in scenario")
+        self.fused = bool(fused)
+        self._scenario = sc
+        self._kind = kind if self.fused else _abi.MPE_SCN_GENERIC
+        self._benchmark = self.fused and info_callback is not None
+
+        # ---- spaces (environment.py:38-70) -------------------------------------------------------------
+        self.action_space = []
+        self.observation_space = []
+        if self.fused:
+            self._desc = world.scenario_desc(kind, getattr(sc, "num_adversaries", 0))
+            self._obs_off = [int(self._desc.obs_off[i]) for i in range(len(world.agents) + 1)]
+            obs_dims = [self._obs_off[i + 1] - self._obs_off[i] for i in range(len(world.agents))]
+        else:
+            self._desc = None
+            obs_dims = [int(observation_callback(agent, self.world).shape[-1]) for agent in self.agents]
+        for agent, obs_dim in zip(self.agents, obs_dims):
+            total_action_space = []
+            if self.discrete_action_space:
+                u_action_space = spaces.Discrete(world.dim_p * 2 + 1)
+            else:
+                u_action_space = spaces.Box(low=-agent.u_range, high=+agent.u_range, shape=(world.dim_p,),
+                                            dtype=np.float32)
+            if agent.movable:
+                total_action_space.append(u_action_space)
+            if self.discrete_action_space:
+                c_action_space = spaces.Discrete(world.dim_c)
+            else:
+                c_action_space = spaces.Box(low=0.0, high=1.0, shape=(world.dim_c,), dtype=np.float32)
+            if not agent.silent:
+                total_action_space.append(c_action_space)
+            if len(total_action_space) > 1:
+                if all(isinstance(sp, spaces.Discrete) for sp in total_action_space):
+                    act_space = spaces.MultiDiscrete([[0, sp.n - 1] for sp in total_action_space])
+                else:
+                    act_space = spaces.Tuple(total_action_space)
+                self.action_space.append(act_space)
+            else:
+                self.action_space.append(total_action_space[0])
+            self.observation_space.append(spaces.Box(low=-np.inf, high=+np.inf, shape=(obs_dim,), dtype=np.float32))
+            agent.action.c = torch.zeros((self.batch_size, world.dim_c), dtype=torch.float32, device=world.device)
+
+        # ---- device buffers for the fused path ----------------------------------------------------------
+        self._sets = None
+        self._flip = 0
+        self._act = None
+        self._ids = None
+        self._entity_table = None
+        self.shared_viewer = shared_viewer
+
+    # ------------------------------------------------------------------------------------------
+    def _ensure_buffers(self):
+        if self._sets is not None:
+            return
+        w = self.world
+        w._require_device()
+        A, B = len(w.agents), w.batch_size
+        if A + len(w.landmarks) > 16:
+            self._entity_table = w.entity_table(self._desc)
+        self._sets = [_OutputSet(self), _OutputSet(self)]
+        self._act = torch.zeros((A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=w.device)
+        self._ids = torch.zeros((A, B), dtype=torch.int32, device=w.device)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.world.device).cuda_stream)
+
+    def _next_set(self):
+        if self.fresh_outputs:
+            return _OutputSet(self)
+        self._flip ^= 1
+        return self._sets[self._flip]
+
+    def _stage_actions(self, action_n):
+        """Bring the caller's actions into the [A,B,5] fp32 (or [A,B] int32) device layout; a tensor
+        that already has it is used in place (zero copy)."""
+        A, B = len(self.agents), self.batch_size
+        if self.discrete_action_input:
+            if torch.is_tensor(action_n) and action_n.shape == (A, B) and action_n.dtype == torch.int32 \
+                    and action_n.is_cuda and action_n.is_contiguous():
+                return None, action_n
+            for i in range(A):
+                self._ids[i].copy_(torch.as_tensor(action_n[i]).reshape(-1).expand(B) if not torch.is_tensor(
+                    action_n[i]) else action_n[i].reshape(-1).expand(B))
+            return None, self._ids
+        if torch.is_tensor(action_n) and action_n.shape == (A, B, _abi.MPE_ACTION_DIM) \
+                and action_n.dtype == torch.float32 and action_n.is_cuda and action_n.is_contiguous():
+            act = action_n
+        else:
+            for i in range(A):
+                a = action_n[i]
+                a = a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), dtype=torch.float32)
+                self._act[i].copy_(a.reshape(-1, _abi.MPE_ACTION_DIM).expand(B, _abi.MPE_ACTION_DIM))
+            act = self._act
+        if self.force_discrete_action:  # environment.py:169-172: argmax -> one-hot
+            idx = act.argmax(dim=-1, keepdim=True)
+            act = torch.zeros_like(act).scatter_(-1, idx, 1.0)
+        return act, None
+
+    # ------------------------------------------------------------------------------------------
+    def step(self, action_n):
+        """environment.py:80-104 for B worlds."""
+        self.agents = self.world.policy_agents
+        if not self.fused:
+            return self._step_generic(action_n)
+        self._ensure_buffers()
+        act, ids = self._stage_actions(action_n)
+        out = self._next_set()
+        b = out.bufs
+        b.act = act.data_ptr() if act is not None else None
+        b.ids = ids.data_ptr() if ids is not None else None
+        b.u = None
+        _abi.check(_abi.lib().mpe_step(C.byref(self._desc), C.byref(b), self.batch_size, self._stream()), "mpe_step")
+        return self._deliver(out.obs_n, out.reward_n, out.done_n, out.info_n(self))
+
+    def reset(self, seeds=None, mask=None):
+        """environment.py:106-116.  `seeds` (one per world) gives reference-exact initial states
+        (`np.random.seed(s); env.reset()` per world, drawn on the host); `mask` resets a subset."""
+        world = self.world
+        if seeds is not None:
+            world.reset_from_numpy_seeds(seeds, getattr(self._scenario, "landmark_range", 1.0))
+        elif mask is not None:
+            self.reset_callback(world, mask)
+        else:
+            self.reset_callback(world)
+        self.agents = world.policy_agents
+        if not self.fused:
+            obs_n = [self._get_obs(agent) for agent in self.agents]
+            return self._deliver(obs_n, None, None, None)[0]
+        self._ensure_buffers()
+        out = self._next_set()
+        b = out.bufs
+        saved = (b.rew, b.done, b.info_rew, b.info_collisions, b.info_min_dists, b.info_occupied)
+        b.rew = b.done = b.info_rew = b.info_collisions = b.info_min_dists = b.info_occupied = None
+        b.act = b.ids = b.u = None
+        try:
+            _abi.check(_abi.lib().mpe_observe(C.byref(self._desc), C.byref(b), self.batch_size, self._stream()),
+                       "mpe_observe")
+        finally:
+            b.rew, b.done, b.info_rew, b.info_collisions, b.info_min_dists, b.info_occupied = saved
+        return self._deliver(out.obs_n, None, None, None)[0]
+
+    def _deliver(self, obs_n, reward_n, done_n, info_n):
+        if not self.numpy_io:
+            return list(obs_n), (list(reward_n) if reward_n is not None else None), \
+                (list(done_n) if done_n is not None else None), info_n
+        # reference-compatible single-world view: 1-D float arrays, Python floats/bools
+        obs = [o[0].detach().cpu().numpy().astype(np.float64) for o in obs_n]
+        rew = [float(r[0]) for r in reward_n] if reward_n is not None else None
+        done = [bool(d[0]) for d in done_n] if done_n is not None else None
+        info = None
+        if info_n is not None:
+            def conv(x):
+                if isinstance(x, tuple):
+                    return tuple(conv(y) for y in x)
+                if torch.is_tensor(x):
+                    v = x[0].item()
+                    return v
+                return x
+            info = {"n": [conv(x) for x in info_n["n"]]}
+        return obs, rew, done, info
+
+    # ---- generic path: user callbacks + HIP physics ------------------------------------------------
+    def _get_info(self, agent):
+        if self.info_callback is None:
+            return {}
+        return self.info_callback(agent, self.world)
+
+    def _get_obs(self, agent):
+        if self.observation_callback is None:
+            return torch.zeros((self.batch_size, 0), device=self.world.device)
+        return self.observation_callback(agent, self.world)
+
+    def _get_done(self, agent):
+        if self.done_callback is None:
+            return torch.zeros(self.batch_size, dtype=torch.bool, device=self.world.device)
+        return self.done_callback(agent, self.world)
+
+    def _get_reward(self, agent):
+        if self.reward_callback is None:
+            return torch.zeros(self.batch_size, dtype=torch.float32, device=self.world.device)
+        return self.reward_callback(agent, self.world)
+
+    def _set_action(self, action, agent, action_space, time=None):
+        """environment.py:144-192 with every scalar widened to a [B, .] tensor."""
+        w, B, dev = self.world, self.batch_size, self.world.device
+        agent.action.u = torch.zeros((B, w.dim_p), dtype=torch.float32, device=dev)
+        agent.action.c = torch.zeros((B, w.dim_c), dtype=torch.float32, device=dev)
+        if not torch.is_tensor(action):
+            action = torch.as_tensor(np.asarray(action), device=dev)
+        action = action.to(dev)
+        if isinstance(action_space, spaces.MultiDiscrete):
+            if self.discrete_action_input:
+                act = [action.reshape(B, -1)[:, k] for k in range(action_space.num_discrete_space)]
+            else:
+                sizes = [int(s) for s in (action_space.high - action_space.low + 1)]
+                flat = action.reshape(-1, sum(sizes)).expand(B, sum(sizes))
+                act, index = [], 0
+                for s in sizes:
+                    act.append(flat[:, index:index + s])
+                    index += s
+        else:
+            act = [action]
+        if agent.movable:
+            if self.discrete_action_input:
+                k = act[0].reshape(-1).expand(B)
+                u = agent.action.u
+                u[:, 0] = (k == 2).float() - (k == 1).float()   # 1:-x 2:+x (environment.py:164-165)
+                u[:, 1] = (k == 4).float() - (k == 3).float()   # 3:-y 4:+y
+            else:
+                a = act[0].float().reshape(-1, act[0].shape[-1]).expand(B, act[0].shape[-1])
+                if self.force_discrete_action:
+                    d = a.argmax(dim=-1, keepdim=True)
+                    a = torch.zeros_like(a).scatter_(-1, d, 1.0)
+                if self.discrete_action_space:
+                    agent.action.u[:, 0] += a[:, 1] - a[:, 2]
+                    agent.action.u[:, 1] += a[:, 3] - a[:, 4]
+                else:
+                    agent.action.u = a.clone()
+            sensitivity = 5.0
+            if agent.accel is not None:
+                sensitivity = agent.accel
+            agent.action.u *= sensitivity
+            act = act[1:]
+        if not agent.silent:
+            if self.discrete_action_input:
+                k = act[0].reshape(-1).expand(B).long()
+                agent.action.c = torch.zeros((B, w.dim_c), dtype=torch.float32, device=dev)
+                agent.action.c.scatter_(1, k[:, None], 1.0)
+            else:
+                agent.action.c = act[0].float().reshape(-1, w.dim_c).expand(B, w.dim_c).clone()
+            act = act[1:]
+        assert len(act) == 0
+
+    def _step_generic(self, action_n):
+        for i, agent in enumerate(self.agents):
+            self._set_action(action_n[i], agent, self.action_space[i])
+        self.world.step()
+        obs_n, reward_n, done_n, info_n = [], [], [], {'n': []}
+        for agent in self.agents:
+            obs_n.append(self._get_obs(agent))
+            reward_n.append(self._get_reward(agent))
+            done_n.append(self._get_done(agent))
+            info_n['n'].append(self._get_info(agent))
+        if self.shared_reward:  # environment.py:100-102: every agent gets the sum
+            total = torch.stack([torch.as_tensor(r, device=self.world.device) for r in reward_n]).sum(dim=0)
+            reward_n = [total] * self.n
+        return self._deliver(obs_n, reward_n, done_n, info_n)
+
+    # rendering is a GUI concern of the reference (environment.py:200-263) and is not provided
+    def render(self, mode='human'):
+        raise NotImplementedError("rendering is out of scope of the MI355X hot-path build (see DESIGN.md)")

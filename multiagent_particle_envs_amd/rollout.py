@@ -1,0 +1,103 @@
+"""Random-action rollout driver: the throughput workload of BASELINE.json ("steps/sec on
+random-action rollouts"), with the host taken out of the per-step loop.
+
+A rollout of K env steps is: every `episode_len` steps a device-side reset (`mpe_reset`,
+MADDPG's 25-step episodes: SURVEY.md 8d), and every step one `mpe_step` launch that reads a
+one-hot action tensor resident in HBM (a pool of pre-generated uniform random moves,
+`mpe_random_actions`) and writes that step's obs / reward / done into the env's output buffers.
+Three ways to issue it:
+  eager    K C-ABI calls from Python (host-bound below ~5 us per step)
+  graph    the same K launches captured once into a HIP graph and replayed (no host in the loop)
+  fused    `mpe_rollout_random`: one persistent launch, state kept in registers between steps,
+           moves drawn in-kernel (bit-identical to the pool's), outputs still written every step
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi
+
+
+class RandomRollout(object):
+    def __init__(self, env, episode_len=25, pool=16, seed=None):
+        if not env.fused:
+            raise _abi.MpeError("RandomRollout drives the fused built-in scenarios")
+        self.env = env
+        self.world = env.world
+        self.episode_len = int(episode_len)
+        self.seed = int(env.world.seed if seed is None else seed) & (2 ** 64 - 1)
+        env._ensure_buffers()
+        A, B = len(self.world.agents), self.world.batch_size
+        self.A, self.B = A, B
+        self.pool = [torch.empty((A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=self.world.device)
+                     for _ in range(pool)]
+        self.t = 0          # global step counter (also indexes the Philox action stream)
+        self._L = _abi.lib()
+        self._lr = float(getattr(env._scenario, "landmark_range", 1.0))
+        self._gen_desc = self.world.scenario_desc(_abi.MPE_SCN_GENERIC)
+        # scenario_desc caches one descriptor: take private copies of both
+        self._gen_desc = _copy_struct(self._gen_desc)
+        self._desc = _copy_struct(env._desc)
+        self._fill_pool()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.world.device).cuda_stream)
+
+    def _fill_pool(self):
+        """Action tensor p holds the moves of global steps t with t % len(pool) == p, as drawn at
+        step index p (the pool is cycled; the fused kernel draws fresh moves every step)."""
+        for p, act in enumerate(self.pool):
+            _abi.check(self._L.mpe_random_actions(act.data_ptr(), None, self.A, self.B, self.seed, p,
+                                                  int(self.world.world_offset), self._stream()), "mpe_random_actions")
+
+    def enqueue(self, steps):
+        """Enqueue `steps` env steps (and the resets that fall among them) on the current stream."""
+        env, w = self.env, self.world
+        L, desc, B = self._L, self._desc, self.B
+        st = self._stream()
+        for _ in range(steps):
+            if self.episode_len and self.t % self.episode_len == 0:
+                b = env._sets[0].bufs
+                _abi.check(L.mpe_reset(C.byref(self._gen_desc), C.byref(b), B, None, self._lr, self.seed,
+                                       self.t // self.episode_len, int(w.world_offset), st), "mpe_reset")
+            out = env._sets[self.t & 1]
+            b = out.bufs
+            b.act = self.pool[self.t % len(self.pool)].data_ptr()
+            b.ids = None
+            b.u = None
+            _abi.check(L.mpe_step(C.byref(desc), C.byref(b), B, st), "mpe_step")
+            self.t += 1
+        return env._sets[(self.t - 1) & 1]
+
+    def capture(self, steps):
+        """Capture `steps` env steps into a HIP graph (torch.cuda.CUDAGraph); replay() re-runs them.
+        `steps` should be a multiple of lcm(episode_len, pool, 2) for the replay to be periodic."""
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(device=self.world.device)
+        s.wait_stream(torch.cuda.current_stream(self.world.device))
+        t0 = self.t
+        with torch.cuda.stream(s):
+            self.enqueue(2)          # warm the code objects outside capture
+            self.t = t0
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                self.enqueue(steps)
+        torch.cuda.current_stream(self.world.device).wait_stream(s)
+        return g
+
+    def fused(self, steps):
+        """One `mpe_rollout_random` launch covering `steps` env steps."""
+        out = self.env._sets[0]
+        b = out.bufs
+        b.act = b.ids = b.u = None
+        _abi.check(self._L.mpe_rollout_random(C.byref(self._desc), C.byref(b), self.B, int(steps), self.episode_len,
+                                              self._lr, self.seed, self.t, int(self.world.world_offset),
+                                              self._stream()), "mpe_rollout_random")
+        self.t += steps
+        return out
+
+
+def _copy_struct(s):
+    c = type(s)()
+    C.memmove(C.byref(c), C.byref(s), C.sizeof(s))
+    return c

@@ -1,0 +1,145 @@
+"""GPU tests that drive libmpe_hip.so through raw ctypes (no env layer): the phase-level entry
+points against the oracle's phases, device reset / random moves bit-exact against the NumPy
+Philox restatement, and the library's error behaviour with real device pointers."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from multiagent_particle_envs_amd import _abi, make_env
+from oracle import spec as ospec, philox
+from oracle.mpe_batched import BatchedOracle, seeded_initial_state
+
+pytestmark = pytest.mark.gpu
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def soa(x):
+    """[B, N, 2] host array -> [N, 2, B] device tensor."""
+    return torch.as_tensor(np.ascontiguousarray(np.transpose(x, (1, 2, 0))), dtype=torch.float32).cuda()
+
+
+def aos(t):
+    return t.permute(2, 0, 1).contiguous().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["simple_spread", "simple_tag"])
+def test_phase_entry_points_match_oracle_phases(name):
+    """apply_action_force -> collision_force -> integrate_state, each checked on its own."""
+    spec = ospec.by_name(name)
+    B = 1536
+    env = make_env(name, batch_size=B)
+    desc = env.world.scenario_desc(_abi.MPE_SCN_GENERIC)
+    rs = np.random.RandomState(5)
+    pos, vel = seeded_initial_state(spec, np.arange(B) + 9)
+    pos[::2] *= 0.3
+    vel = rs.uniform(-1, 1, vel.shape)
+    p32, v32 = pos.astype(np.float32), vel.astype(np.float32)
+    A = spec.n_agents
+    act = rs.uniform(-1, 1, (A, B, 5)).astype(np.float32)
+    orc = BatchedOracle(spec, B)
+    orc.set_state(p32, v32)
+    u = orc.decode(act)
+
+    d_pos, d_vel = soa(p32), soa(v32)
+    d_act = torch.as_tensor(act).cuda()
+    d_force = torch.zeros((A, 2, B), device="cuda")
+    b = _abi.MpeBuffers()
+    b.pos, b.vel, b.act, b.force = d_pos.data_ptr(), d_vel.data_ptr(), d_act.data_ptr(), d_force.data_ptr()
+    L = _abi.lib()
+    _abi.check(L.mpe_apply_action_force(C.byref(desc), C.byref(b), B, stream()))
+    got = aos(d_force)
+    assert np.abs(got - np.transpose(u, (1, 0, 2))).max() <= 1e-5
+    f = orc.forces(u)
+    _abi.check(L.mpe_collision_force(C.byref(desc), C.byref(b), B, stream()))
+    got = aos(d_force)
+    want = np.stack([f[i] for i in range(A)], axis=1)
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err.max() <= 1e-5, err.max()
+    # integrate from the ORACLE's force so that this phase is judged alone
+    d_force.copy_(soa(want))
+    orc.integrate(f)
+    _abi.check(L.mpe_integrate_state(C.byref(desc), C.byref(b), B, stream()))
+    assert np.abs(aos(d_pos) - orc.pos).max() <= 1e-5
+    assert np.abs(aos(d_vel) - orc.vel).max() <= 1e-5
+
+
+def test_contact_force_known_answers():
+    """SURVEY A.3 contact KAT: force on agent a vs distance, incl. d = 0 -> NaN (Q7)."""
+    env = make_env("simple_spread", batch_size=8, num_agents=2, num_landmarks=2)
+    desc = env.world.scenario_desc(_abi.MPE_SCN_GENERIC)
+    ds = [0.2, 0.2999, 0.3, 0.3001, 0.305, 0.31, 0.5, 0.0]
+    want = [-10.0, -0.0744396660, -0.0693147181, -0.0644396660, -6.715e-4, -4.54e-6, 0.0, np.nan]
+    pos = np.zeros((8, 4, 2), np.float32)
+    pos[:, 1, 0] = ds
+    pos[:, 2:] = 5.0
+    d_pos, d_vel = soa(pos), torch.zeros((2, 2, 8), device="cuda")
+    d_force = torch.zeros((2, 2, 8), device="cuda")
+    b = _abi.MpeBuffers()
+    b.pos, b.vel, b.force = d_pos.data_ptr(), d_vel.data_ptr(), d_force.data_ptr()
+    _abi.check(_abi.lib().mpe_collision_force(C.byref(desc), C.byref(b), 8, stream()))
+    fx = d_force[0, 0].cpu().numpy()
+    for k in range(7):
+        assert abs(fx[k] - want[k]) <= 1e-5 * max(1.0, abs(want[k])), (ds[k], fx[k], want[k])
+    assert np.isnan(fx[7])
+    assert np.allclose(d_force[1, 0].cpu().numpy()[:7], -fx[:7], atol=0, rtol=0)   # equal and opposite
+
+
+@pytest.mark.parametrize("name,B,offset", [("simple_spread", 5000, 0), ("simple_tag", 777, 123456789012)])
+def test_device_reset_is_bit_exact_philox(name, B, offset):
+    spec = ospec.by_name(name)
+    env = make_env(name, batch_size=B, seed=0xDEADBEEF12345678)
+    env.world.world_offset = offset
+    for ep in range(3):
+        env.world._episode = ep
+        env.scenario.reset_world(env.world)
+        pos, vel = env.world.get_state()
+        want = philox.reset_positions(0xDEADBEEF12345678, B, ep, spec.n_agents, spec.n_landmarks,
+                                      spec.landmark_range, world_offset=offset)
+        assert np.array_equal(pos, want)
+        assert not vel.any()
+    # distribution sanity: uniform on [-1,1) for agents, [-r,r) for landmarks
+    assert -1.0 <= pos[:, :spec.n_agents].min() and pos[:, :spec.n_agents].max() < 1.0
+    assert abs(pos[:, :spec.n_agents].mean()) < 0.05
+    r = spec.landmark_range
+    assert -r <= pos[:, spec.n_agents:].min() and pos[:, spec.n_agents:].max() < r
+    # masked reset touches only the selected worlds
+    before, _ = env.world.get_state()
+    mask = torch.zeros(B, dtype=torch.bool, device="cuda")
+    mask[::5] = True
+    env.scenario.reset_world(env.world, mask)
+    after, _ = env.world.get_state()
+    m = mask.cpu().numpy()
+    assert np.array_equal(after[~m], before[~m]) and not np.array_equal(after[m], before[m])
+
+
+def test_random_actions_bit_exact_and_uniform():
+    A, B, seed = 5, 40000, 42
+    act = torch.zeros((A, B, 5), device="cuda")
+    ids = torch.zeros((A, B), dtype=torch.int32, device="cuda")
+    for step in (0, 1, 2 ** 33 + 5):
+        _abi.check(_abi.lib().mpe_random_actions(act.data_ptr(), ids.data_ptr(), A, B, seed, step, 17, stream()))
+        want = philox.action_ids(seed, B, step, A, world_offset=17)
+        assert np.array_equal(ids.cpu().numpy(), want)
+        assert np.array_equal(act.cpu().numpy(), philox.one_hot(want))
+    counts = np.bincount(want.ravel(), minlength=5) / want.size
+    assert np.abs(counts - 0.2).max() < 0.01
+
+
+def test_error_reporting():
+    L = _abi.lib()
+    env = make_env("simple_spread", batch_size=64)
+    desc = env.world.scenario_desc(_abi.MPE_SCN_SPREAD)
+    b = _abi.MpeBuffers()
+    assert L.mpe_step(None, C.byref(b), 64, None) == -1
+    assert L.mpe_step(C.byref(desc), C.byref(b), 64, None) == -1 and b"pos" in L.mpe_last_error()
+    b.pos, b.vel = env.world.pos.data_ptr(), env.world.vel.data_ptr()
+    assert L.mpe_step(C.byref(desc), C.byref(b), 64, None) == -1 and b"act" in L.mpe_last_error()
+    # a tag shape no kernel was built for
+    envt = make_env("simple_tag", batch_size=8, num_adversaries=5, num_good_agents=2, num_landmarks=1)
+    with pytest.raises(_abi.MpeError):
+        envt.reset()
