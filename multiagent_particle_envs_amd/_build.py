@@ -42,6 +42,9 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    if not force and not _stale(LIB, srcs + hdrs):
+        return LIB  # the shipped .so is newer than every source: nothing to do (GPU box)
     jobs = []
     objs = []
     for src in SOURCES:

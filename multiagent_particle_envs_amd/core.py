@@ -327,8 +327,7 @@ class World(object):
         desc = self.scenario_desc(_abi.MPE_SCN_GENERIC)
         bufs = _abi.MpeBuffers()
         bufs.pos, bufs.vel, bufs.u = self.pos.data_ptr(), self.vel.data_ptr(), self._u.data_ptr()
-        if A + len(self.landmarks) > 16:
-            bufs.entity_table = self.entity_table(desc).data_ptr()
+        bufs.entity_table = self.entity_table(desc).data_ptr()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _abi.check(_abi.lib().mpe_world_step(C.byref(desc), C.byref(bufs), B, C.c_void_p(stream)), "mpe_world_step")
         for agent in self.agents:  # update_agent_state (core.py:171-177)

@@ -178,8 +178,7 @@ class MultiAgentEnv(object):
         w = self.world
         w._require_device()
         A, B = len(w.agents), w.batch_size
-        if A + len(w.landmarks) > 16:
-            self._entity_table = w.entity_table(self._desc)
+        self._entity_table = w.entity_table(self._desc)   # read by the workgroup-per-world kernels only
         self._sets = [_OutputSet(self), _OutputSet(self)]
         self._act = torch.zeros((A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=w.device)
         self._ids = torch.zeros((A, B), dtype=torch.int32, device=w.device)
