@@ -7,13 +7,17 @@
 
 Workload (BASELINE.json metric config): simple_spread, 3 agents / 3 landmarks, 65536 worlds PER GPU
 (weak scaling: rank r owns worlds [r*B, (r+1)*B); no collective on the step path), fp32,
-uniform random one-hot moves resident in HBM, device-side reset every 25 steps (MADDPG episode).
+uniform random one-hot moves, device-side reset every 25 steps (MADDPG episode length).
 One "step" = every world of the batch advanced once with all agents' obs/reward/done written.
 
 Timed region: barrier + synchronize, K steps, synchronize + barrier; max over ranks; rank 0 prints
-ONE JSON line.  `--mode graph` (default) replays the K launches from a HIP graph (no host in the
-loop), `--mode eager` issues them from Python through the C ABI, `--mode api` goes through
-MultiAgentEnv.step(), `--mode fused` uses the persistent T-step rollout kernel.
+ONE JSON line.  Modes:
+  graph  (default, `value`)  K `mpe_step` launches (+ resets) replayed from a HIP graph; every launch
+         reads its one-hot action tensor from HBM (pool of pre-generated tensors) and writes all outputs
+  eager  the same launches issued from Python through the C ABI
+  api    through MultiAgentEnv.step()/reset() (the drop-in API, Python in the loop)
+  fused  `mpe_rollout_random`: one launch per 25-step episode, state in registers, moves drawn in-kernel,
+         every step's outputs written to its own trajectory block (reported under "extra" by default)
 """
 import argparse
 import json
@@ -25,28 +29,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# algorithmic (compulsory) HBM bytes per env-step, SURVEY.md 8(d): read agent pos+vel, landmark
-# pos, one-hot actions; write agent pos+vel, obs, reward (fp32) and done (1 byte per agent)
-def algorithmic_bytes(scenario, A, L, obs_total):
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def algorithmic_bytes(A, L, obs_total):
+    """Compulsory HBM bytes per env-step: read agent pos+vel, landmark pos, one-hot
+    actions; write agent pos+vel, obs, reward (fp32) + done (1 byte per agent)."""
     reads = 4 * A + 2 * L + 5 * A
     writes = 4 * A + obs_total + A
     return 4 * (reads + writes) + A
 
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-
-
-def cpu_baseline(scenario, kw, seconds, procs):
-    """The oracle's per-object fp64 loop (oracle/mpe_loop.py -- the reference's algorithm and cost
-    structure; /root/reference itself cannot travel to the GPU box) timed on the host cores."""
-    import multiprocessing as mp
-    t0 = time.time()
-    with mp.get_context("fork").Pool(procs) as pool:
-        res = pool.map(_cpu_worker, [(scenario, kw, seconds, i) for i in range(procs)])
-    steps = sum(r[0] for r in res)
-    wall = max(r[1] for r in res)
-    single = res[0][0] / res[0][1]
-    return steps / wall, single, time.time() - t0
+def usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2 CPU quota
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def _cpu_worker(arg):
@@ -70,6 +72,18 @@ def _cpu_worker(arg):
     return n, time.perf_counter() - t0
 
 
+def cpu_baseline(scenario, okw, seconds, procs):
+    """oracle/mpe_loop.py -- the reference's per-object Python/NumPy loop restated (the reference
+    tree itself cannot travel to the GPU box) -- timed on the host cores: 1 process, then `procs`."""
+    import multiprocessing as mp
+    single = _cpu_worker((scenario, okw, min(seconds, 4.0), 0))
+    with mp.get_context("fork").Pool(procs) as pool:
+        res = pool.map(_cpu_worker, [(scenario, okw, seconds, i + 1) for i in range(procs)])
+    steps = sum(r[0] for r in res)
+    wall = max(r[1] for r in res)
+    return steps / wall, single[0] / single[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,9 +95,12 @@ def main():
     ap.add_argument("--episode-len", type=int, default=25)
     ap.add_argument("--mode", default="graph", choices=["graph", "eager", "api", "fused"])
     ap.add_argument("--repeats", type=int, default=5)
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (fused-rollout) measurement")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="cut the per-GPU batch into this many independent sub-batches, one HIP stream each")
     args = ap.parse_args()
 
     import torch
@@ -94,126 +111,147 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the step path has no CPU fallback)")
     torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 
     import multiagent_particle_envs_amd as mpe
-    from multiagent_particle_envs_amd.rollout import RandomRollout
-    kw = {}
+    from multiagent_particle_envs_amd import sharding
+    from multiagent_particle_envs_amd.rollout import RandomRollout, StreamedRollout, Trajectory
+    kw, okw = {}, {}
     if args.scenario == "simple_spread" and args.agents != 3:
         kw["num_agents"] = args.agents
-    B, K, W = args.batch, args.steps, args.warmup
-    env = mpe.make_env(args.scenario, batch_size=B, seed=args.seed, **kw)
-    env.world.world_offset = rank * B          # global world numbering: shards never share an RNG stream
+        okw["n"] = args.agents
+    B, K, W, EP = args.batch, args.steps, args.warmup, args.episode_len
+    S = max(1, args.streams)
+    assert B % S == 0, "--batch must be a multiple of --streams"
+    envs = []
+    for s_ in range(S):                        # S sub-batches of B/S worlds, one HIP stream each
+        e = mpe.make_env(args.scenario, batch_size=B // S, seed=args.seed, **kw)
+        e.world.world_offset = rank * B + s_ * (B // S)   # global world numbering: no shared RNG streams
+        envs.append(e)
+    env = envs[0]
     A, Lm = len(env.world.agents), len(env.world.landmarks)
-    roll = RandomRollout(env, episode_len=args.episode_len, pool=16)
-    dev = torch.device("cuda", local)
+    rolls = [RandomRollout(e, episode_len=EP, pool=16) for e in envs]
+    roll = StreamedRollout(rolls)
+    obs_total = int(env._obs_off[-1])
+    bytes_step = algorithmic_bytes(A, Lm, obs_total)
+    can_fuse = A <= 6 and args.scenario in ("simple", "simple_spread", "simple_tag")
+    trajs = None
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def fused_steps(n):
+        nonlocal trajs
+        T = EP if EP else 25
+        if trajs is None:
+            trajs = [Trajectory(e, T) for e in envs]
+        done = 0
+        while done < n:
+            k = min(T, n - done)
+            roll.fused(k, trajs)
+            done += k
 
-    # ---- the K-step body ---------------------------------------------------------------------------
-    graph = None
-    if args.mode == "graph":
-        graph = roll.capture(K)
+    def make_body(mode, n):
+        if mode == "graph":
+            g = roll.capture(n)
+            return g.replay
+        if mode == "eager":
+            return lambda: roll.enqueue(n)
+        if mode == "fused":
+            return lambda: fused_steps(n)
 
-        def body():
-            graph.replay()
-    elif args.mode == "eager":
-        def body():
-            roll.enqueue(K)
-    elif args.mode == "fused":
-        def body():
-            roll.fused(K)
-    else:
-        def body():
-            for k in range(K):
-                if args.episode_len and k % args.episode_len == 0:
+        def api():
+            assert S == 1, "--mode api drives one env"
+            for k in range(n):
+                if EP and k % EP == 0:
                     env.reset()
-                env.step(roll.pool[k % len(roll.pool)])
+                env.step(rolls[0].pool[k % len(rolls[0].pool)])
+        return api
 
-    # warmup: W untimed steps
-    roll.enqueue(W) if args.mode != "fused" else roll.fused(W)
-    barrier()
-    times = []
-    kern_ms = []
-    for rep in range(args.repeats):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        barrier()
-        t0 = time.perf_counter()
-        e0.record()
-        body()
-        e1.record()
-        torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
-        times.append(dt)
-        kern_ms.append(e0.elapsed_time(e1))
-    dt = sorted(times)[len(times) // 2]                 # median of the repeats
-    ev_ms = sorted(kern_ms)[len(kern_ms) // 2]
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(mode):
+        """median over repeats of the wall time of exactly K steps, max over ranks"""
+        body = make_body(mode, K)
+        if mode == "fused":
+            fused_steps(W)
+        else:
+            roll.enqueue(W)
+        sharding.barrier(dev)
+        walls = []
+        for _ in range(args.repeats):
+            sharding.barrier(dev)
+            t0 = time.perf_counter()
+            body()
+            torch.cuda.synchronize()
+            sharding.barrier(dev)
+            walls.append(time.perf_counter() - t0)
+        return sharding.reduce_max(sorted(walls)[len(walls) // 2], dev)
 
-    # ---- dominant kernel's own launch duration: back-to-back launches between two HIP events on the
-    # launch stream (no resets in between); includes the ~1.5 us dependent-launch boundary ----------
-    n_k = 400
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if args.mode == "fused":
-        roll.episode_len, keep = 0, roll.episode_len
-        torch.cuda.synchronize()
-        e0.record()
-        roll.fused(n_k)
-        e1.record()
-        torch.cuda.synchronize()
-        roll.episode_len = keep
-    else:
-        roll.episode_len, keep = 0, roll.episode_len
-        gk = roll.capture(n_k)
-        torch.cuda.synchronize()
-        e0.record()
-        gk.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        roll.episode_len = keep
-    kernel_us = e0.elapsed_time(e1) * 1e3 / n_k
+    def kernel_time_us(mode, n=400):
+        """The dominant kernel's time per env step, from HIP events on the launch stream around n
+        back-to-back steps with no resets in between (graph replay / fused launches)."""
+        roll.set_episode_len(0)
+        try:
+            body = make_body("fused" if mode == "fused" else "graph", n)
+            body()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            body()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / n
+        finally:
+            roll.set_episode_len(EP)
+
+    dt = timed(args.mode)
+    k_us = kernel_time_us(args.mode)
+    extra = {}
+    if not args.no_extra and can_fuse and args.mode != "fused":
+        dtf = timed("fused")
+        kf = kernel_time_us("fused")
+        extra["fused_rollout"] = {
+            "what": "mpe_rollout_random: one launch per %d-step episode, state in registers, moves drawn in-kernel, "
+                    "every step's obs/rew/done written to its own trajectory block" % (EP or 25),
+            "value": B * K * world / dtf, "unit": "env-steps/s", "ms_per_step": dtf * 1e3 / K,
+            "kernel_us_per_step": kf,
+            "achieved_GBps_at_411B_convention": bytes_step * B / (kf * 1e-6) / 1e9,
+            "compulsory_bytes_per_env_step": 4 * (obs_total + A) + A,
+            "achieved_GBps_compulsory": (4 * (obs_total + A) + A) * B / (kf * 1e-6) / 1e9}
 
     if rank == 0:
-        obs_total = int(env._obs_off[-1])
-        bytes_step = algorithmic_bytes(args.scenario, A, Lm, obs_total)
-        total_steps = float(B) * K * world
-        value = total_steps / dt
-        achieved = bytes_step * B / (kernel_us * 1e-6) / 1e9
+        achieved = bytes_step * B / (k_us * 1e-6) / 1e9
         out = {
             "metric": "env steps/sec (whole node), %s N=%d, batch=%d per GPU" % (args.scenario, A, B),
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": B * K * world / dt, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s A=%d L=%d, %d worlds/GPU, one-hot random moves, reset every %d steps"
-                                   % (args.scenario, A, Lm, B, args.episode_len),
+            "config": {"workload": "%s A=%d L=%d, %d worlds/GPU, one-hot random moves in HBM, reset every %d steps"
+                                   % (args.scenario, A, Lm, B, EP),
                        "batch_per_gpu": B, "global_batch": B * world, "mode": args.mode,
-                       "repeats": args.repeats, "sharding": "worlds by batch index, no collective"},
+                       "repeats": args.repeats, "streams_per_gpu": S,
+                       "sharding": "worlds by batch index, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_env_step": bytes_step,
-                         "kernel": "mpe::k_narrow" if A <= 6 else "mpe::k_wide",
-                         "kernel_us_per_step": kernel_us, "env_steps_per_launch": B},
-            "event_ms_timed_region": ev_ms,
+                         "kernel": ("mpe::k_split" if os.environ.get("MPE_STEP_IMPL") != "thread" else "mpe::k_narrow")
+                         if A <= 6 else "mpe::k_wide",
+                         "kernel_us_per_launch": k_us, "env_steps_per_launch": B,
+                         "note": "kernel_us_per_launch = HIP-event time of n back-to-back steps / n; with S>1 streams the "
+                                 "S sub-batch launches of one step overlap, so this is time per full-batch step"},
         }
+        if extra:
+            out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
-            procs = os.cpu_count() or 1
-            agg, single, wall = cpu_baseline(args.scenario, kw, args.cpu_seconds, procs)
-            out["cpu_baseline"] = {"value": agg, "unit": "env-steps/s", "cores": procs, "kind": "port",
-                                   "sample": "oracle/mpe_loop.py (per-object fp64 loop, same algorithm and cost "
-                                             "structure as the reference), %d processes x %.0f s, reset every 25 "
-                                             "steps; single process: %.0f env-steps/s" % (procs, args.cpu_seconds, single),
-                                   "single_core": single}
+            procs = usable_cores()
+            agg, single = cpu_baseline(args.scenario, okw, args.cpu_seconds, procs)
+            out["cpu_baseline"] = {
+                "value": agg, "unit": "env-steps/s", "cores": procs, "kind": "port",
+                "sample": "oracle/mpe_loop.py (the reference's per-object fp64 Python/NumPy loop restated; "
+                          "/root/reference is absent on the GPU box), %d processes x %.0f s each, same move "
+                          "distribution, reset every 25 steps; 1 process alone: %.0f env-steps/s"
+                          % (procs, args.cpu_seconds, single),
+                "single_core": single}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

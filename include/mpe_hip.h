@@ -146,13 +146,17 @@ int mpe_reset(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, co
 int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed,
                        uint64_t step, int64_t world_offset, void *stream);
 
-/* mpe_rollout_random: T consecutive env steps with in-kernel uniform random moves and an
- * in-kernel reset every `episode_len` steps (0 = never), state kept in registers between steps;
- * every step's obs/rew/done are still written (to the same buffers as mpe_step).
- * Bit-identical to T x { mpe_random_actions(step0+t); [mpe_reset]; mpe_step }.                  */
+/* mpe_rollout_random: T consecutive env steps in ONE launch, with in-kernel uniform random moves
+ * (the rows mpe_random_actions(step0+t) would write) and an in-kernel reset whenever the global
+ * step index step0+t is a multiple of `episode_len` (0 = never; episode = (step0+t)/episode_len,
+ * as mpe_reset draws it).  State stays in registers between steps; pos/vel are written after the
+ * last step.  Every step's obs/rew/done/info ARE written: with trajectory != 0 the output buffers
+ * hold T consecutive per-step blocks (obs: T x [B*obs_off[A]] floats; rew/done/info: T x [A][B]),
+ * with trajectory == 0 step t overwrites the single block.
+ * Bit-identical to T x { [mpe_reset]; mpe_random_actions(step0+t); mpe_step }.                  */
 int mpe_rollout_random(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, int32_t T,
                        int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0,
-                       int64_t world_offset, void *stream);
+                       int64_t world_offset, int32_t trajectory, void *stream);
 
 #ifdef __cplusplus
 }

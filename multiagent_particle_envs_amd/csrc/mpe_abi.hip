@@ -1,6 +1,7 @@
 // mpe_abi.hip -- the extern "C" surface declared in include/mpe_hip.h (host code only).
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "mpe_internal.h"
@@ -22,6 +23,15 @@ int hip_result(int rc, const char *what) {
   if (rc == 0) return 0;
   if (rc == MPE_EUNSUPPORTED) return fail(rc, "%s: no kernel built for this scenario shape", what);
   return fail(rc, "%s: %s", what, hipGetErrorString((hipError_t)rc));
+}
+
+// Which kernel family serves mpe_step for the small-entity shapes.  Default: wave-per-agent
+// (mpe_split.hip).  MPE_STEP_IMPL=thread selects the thread-per-world kernel (mpe_narrow.hip) --
+// a tuning / A-B switch read at call time, not a behavioural one: both give bit-identical results.
+enum class StepImpl { Split, Thread };
+StepImpl step_impl() {
+  const char *e = std::getenv("MPE_STEP_IMPL");
+  return (e && std::strcmp(e, "thread") == 0) ? StepImpl::Thread : StepImpl::Split;
 }
 
 int check_desc(const MpeScenarioDesc *d, const char *what) {
@@ -52,7 +62,7 @@ mpe::NarrowDesc make_narrow(const MpeScenarioDesc *d, const MpeBuffers *b, size_
   const int E = d->n_agents + d->n_landmarks;
   for (int e = 0; e < E; ++e) {
     n.size[e] = d->size[e];
-    n.mass[e] = d->mass[e];
+    n.inv_mass[e] = d->mass[e] > 0.f ? 1.0f / d->mass[e] : 1.0f;
     n.accel[e] = d->accel[e];
     n.max_speed[e] = d->max_speed[e];
     if (d->movable[e]) n.movable |= 1u << e;
@@ -67,6 +77,7 @@ mpe::NarrowDesc make_narrow(const MpeScenarioDesc *d, const MpeBuffers *b, size_
   n.damp = 1.0f - d->damping;  // (1 - self.damping), core.py:161 (0.75 exactly for the default)
   n.cforce = d->contact_force;
   n.cmargin = d->contact_margin;
+  n.cmargin_inv = 1.0f / d->contact_margin;
   n.collaborative = d->collaborative;
   n.vec4 = vec4 ? 1 : 0;
   return n;
@@ -84,6 +95,7 @@ mpe::WideDesc make_wide(const MpeScenarioDesc *d) {
   w.damp = 1.0f - d->damping;
   w.cforce = d->contact_force;
   w.cmargin = d->contact_margin;
+  w.cmargin_inv = 1.0f / d->contact_margin;
   return w;
 }
 
@@ -178,6 +190,16 @@ static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, 
     dd.kind = MPE_SCN_GENERIC;
     use = &dd;
   }
+  if (phys && out && d->n_agents + d->n_landmarks <= mpe::kNarrowMaxE && step_impl() != StepImpl::Thread &&
+      mpe::split_supports(kind, d->n_agents, d->n_landmarks, d->n_adversaries)) {
+    // the fused step: wave-per-agent / lane-per-world (mpe_split.hip)
+    const mpe::NarrowDesc n = make_narrow(use, b, (size_t)B);
+    mpe::RollArgs ra;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.T = 1;
+    return hip_result(mpe::launch_split(false, kind, d->n_agents, d->n_landmarks, d->n_adversaries, n, *b, (size_t)B,
+                                        ra, s), what);
+  }
   if (use_narrow(use)) {
     const mpe::NarrowDesc n = make_narrow(use, b, (size_t)B);
     return hip_result(mpe::launch_narrow(phys ? mpe::NarrowOp::Step : mpe::NarrowOp::Observe, kind, d->n_agents,
@@ -247,7 +269,8 @@ int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, ui
 }
 
 int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, int32_t T, int32_t episode_len,
-                       float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset, void *stream) {
+                       float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
+                       int32_t trajectory, void *stream) {
   const char *what = "mpe_rollout_random";
   if (int rc = check_desc(d, what)) return rc;
   if (int rc = check_state(b, B, what)) return rc;
@@ -255,12 +278,20 @@ int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
   if (int rc = check_info(d, b, what)) return rc;
   if (T < 0 || episode_len < 0) return fail(MPE_EINVAL, "%s: T, episode_len must be >= 0", what);
   if (B == 0 || T == 0) return 0;
-  if (!use_narrow(d)) return fail(MPE_EUNSUPPORTED, "%s: fused rollout exists for the thread-per-world shapes only", what);
+  if (d->n_agents + d->n_landmarks > mpe::kNarrowMaxE ||
+      !mpe::split_supports(d->kind, d->n_agents, d->n_landmarks, d->n_adversaries))
+    return fail(MPE_EUNSUPPORTED, "%s: the fused rollout exists for the wave-per-agent shapes only", what);
   const mpe::NarrowDesc n = make_narrow(d, b, (size_t)B);
-  return hip_result(mpe::launch_rollout(d->kind, d->n_agents, d->n_landmarks, d->n_adversaries, n, *b, (size_t)B, T,
-                                        episode_len, landmark_range, seed, step0, (uint64_t)world_offset,
-                                        static_cast<hipStream_t>(stream)),
-                    what);
+  mpe::RollArgs ra;
+  ra.T = T;
+  ra.episode_len = episode_len;
+  ra.trajectory = trajectory ? 1 : 0;
+  ra.landmark_range = landmark_range;
+  ra.seed = seed;
+  ra.step0 = step0;
+  ra.world_offset = (uint64_t)world_offset;
+  return hip_result(mpe::launch_split(true, d->kind, d->n_agents, d->n_landmarks, d->n_adversaries, n, *b, (size_t)B,
+                                      ra, static_cast<hipStream_t>(stream)), what);
 }
 
 }  // extern "C"

@@ -20,21 +20,26 @@ constexpr int kNarrowMaxE = 16;  // entity limit of the thread-per-world kernels
 // Scenario constants as kernel arguments (SGPR-resident, uniform): thread-per-world kernels.
 struct NarrowDesc {
   float size[kNarrowMaxE];
-  float mass[kNarrowMaxE];
+  float inv_mass[kNarrowMaxE];  // 1 / Entity.mass (mass == 1.0 everywhere in scope: exact)
   float accel[kNarrowMaxE];
   float max_speed[kNarrowMaxE];
   int32_t obs_off[kNarrowMaxE + 1];
   uint32_t movable;  // bit e
   uint32_t collide;  // bit e
-  float dt, damp /* 1 - damping */, cforce, cmargin;
+  float dt, damp /* 1 - damping */, cforce, cmargin, cmargin_inv /* 1 / contact_margin */;
   int32_t collaborative;
   int32_t vec4;  // obs rows may be written with 16-byte stores (alignment checked on the host)
 };
 
-// np.logaddexp(0, x) (core.py:192) in the form NumPy evaluates it; stable for |x| ~ 1e3 (H6).
+// np.logaddexp(0, x) (core.py:192): max(x,0) + log1p(exp(-|x|)), stable for |x| ~ 1e3 (H6), on the
+// native base-2 transcendental units (v_exp_f32 / v_log_f32, ~1 ulp).  The log term is at most ln 2
+// and its absolute error is <= 6e-8 (1 + e rounds e's low bits away when e is small), i.e. 6e-11
+// on the penetration and < 1e-8 on the force -- far inside the 1e-5 bar, and ~100 fewer
+// instructions per pair than the libm forms.  NaN propagates (fmaxf(NaN,0)=0, 0+NaN=NaN).
 __device__ __forceinline__ float softplus0(float x) {
-  const float l = log1pf(expf(-fabsf(x)));
-  return x > 0.f ? x + l : l;
+  const float e = __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896341f);
+  const float l = __builtin_amdgcn_logf(1.0f + e) * 0.693147180559945309f;
+  return fmaxf(x, 0.f) + l;
 }
 
 // sqrt(dx^2 + dy^2) with NumPy's rounding sequence (no fma).
@@ -46,27 +51,32 @@ __device__ __forceinline__ float dist2d(float dx, float dy) {
 
 // World.get_collision_force (core.py:180-196) for one pair; returns the force on `a`
 // (the force on `b` is its negation).  dx,dy = pos_a - pos_b.
+// Evaluated as delta * ((C * pen) / dist) with one reciprocal instead of the reference's
+// ((C*delta)/dist)*pen with two IEEE divisions, and (dist_min - dist) * (1/k) instead of a third:
+// a few ulp (<= 3e-7 relative) of regrouping.  dist == 0 still gives NaN (0 * inf), SURVEY Q7.
 __device__ __forceinline__ void contact_force(float dx, float dy, float dist_min, float cforce,
-                                              float k, float &fx, float &fy) {
+                                              float k, float kinv, float &fx, float &fy) {
   const float dist = dist2d(dx, dy);
-  const float pen = softplus0(-(dist - dist_min) / k) * k;
-  fx = cforce * dx / dist * pen;
-  fy = cforce * dy / dist * pen;
+  const float pen = softplus0((dist_min - dist) * kinv) * k;
+  const float s = (cforce * pen) * __builtin_amdgcn_rcpf(dist);
+  fx = dx * s;
+  fy = dy * s;
 }
 
 // World.integrate_state body for one movable entity (core.py:161-169); max_speed < 0 == None.
 __device__ __forceinline__ void integrate_one(float &px, float &py, float &vx, float &vy, float fx,
-                                              float fy, float mass, float max_speed, float damp,
+                                              float fy, float inv_mass, float max_speed, float damp,
                                               float dt) {
   vx = vx * damp;
   vy = vy * damp;
-  vx += (fx / mass) * dt;
-  vy += (fy / mass) * dt;
+  vx += (fx * inv_mass) * dt;  // f / mass with mass == 1.0: exact
+  vy += (fy * inv_mass) * dt;
   if (max_speed >= 0.f) {
     const float speed = sqrtf(vx * vx + vy * vy);
-    if (speed > max_speed) {
-      vx = vx / speed * max_speed;
-      vy = vy / speed * max_speed;
+    if (speed > max_speed) {  // v / speed * max_speed (core.py:166-168) with one division
+      const float s = max_speed / speed;
+      vx = vx * s;
+      vy = vy * s;
     }
   }
   px += vx * dt;
@@ -157,12 +167,11 @@ __host__ __device__ inline int action_draw(uint64_t seed, uint64_t b, uint64_t t
 // store would be stride-D scattered.  Each wave parks its 64 rows in its own LDS tile (row stride
 // D|1: odd => the column writes are bank-conflict-free) and streams the tile out as 16-byte
 // stores over the contiguous 256*D-byte segment it owns.  No workgroup barrier is involved.
+// flush_rows: the tile (row stride D|1, rows = lanes) already holds the wave's 64 rows.
 template <int D>
-__device__ __forceinline__ void store_rows(float *tile, const float (&row)[D], float *__restrict__ g,
-                                           int nvalid, int lane, bool vec4) {
+__device__ __forceinline__ void flush_rows(const float *tile, float *__restrict__ g, int nvalid, int lane,
+                                           bool vec4) {
   constexpr int DP = D | 1;
-#pragma unroll
-  for (int c = 0; c < D; ++c) tile[lane * DP + c] = row[c];
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int nfl = nvalid * D;
@@ -190,6 +199,15 @@ __device__ __forceinline__ void store_rows(float *tile, const float (&row)[D], f
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+}
+
+template <int D>
+__device__ __forceinline__ void store_rows(float *tile, const float (&row)[D], float *__restrict__ g,
+                                           int nvalid, int lane, bool vec4) {
+  constexpr int DP = D | 1;
+#pragma unroll
+  for (int c = 0; c < D; ++c) tile[lane * DP + c] = row[c];
+  flush_rows<D>(tile, g, nvalid, lane, vec4);
 }
 
 template <int D>

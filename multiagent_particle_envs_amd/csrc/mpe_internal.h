@@ -17,7 +17,7 @@ int launch_phase(int phase, int A, int L, const NarrowDesc &d, const MpeBuffers 
 struct WideDesc {
   int32_t kind, A, L, dim_c, collaborative;
   int32_t D;  // obs width (spread: same for every agent)
-  float dt, damp, cforce, cmargin;
+  float dt, damp, cforce, cmargin, cmargin_inv;
 };
 constexpr int kEntityTableCols = 6;  // size, mass, accel, max_speed, movable, collide  -> [6][E] floats
 int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream);
@@ -27,8 +27,17 @@ int launch_reset(int A, int L, const MpeBuffers &b, size_t B, const uint8_t *mas
                  uint64_t seed, uint64_t episode, uint64_t world_offset, hipStream_t stream);
 int launch_random_actions(float *act, int32_t *ids, int A, size_t B, uint64_t seed, uint64_t step,
                           uint64_t world_offset, hipStream_t stream);
-int launch_rollout(int kind, int A, int L, int nadv, const NarrowDesc &d, const MpeBuffers &b, size_t B, int T,
-                   int episode_len, float landmark_range, uint64_t seed, uint64_t step0, uint64_t world_offset,
-                   hipStream_t stream);
+
+// wave-per-agent / lane-per-world family (mpe_split.hip): fused step and fused T-step rollout
+struct RollArgs {
+  int32_t T;            // steps in this launch (ignored by the single-step kernel)
+  int32_t episode_len;  // in-kernel reset every episode_len global steps; 0 = never
+  int32_t trajectory;   // outputs of step t go to block t of the output buffers (else: overwrite block 0)
+  float landmark_range;
+  uint64_t seed, step0, world_offset;
+};
+bool split_supports(int kind, int A, int L, int nadv);
+int launch_split(bool roll, int kind, int A, int L, int nadv, const NarrowDesc &d, const MpeBuffers &b, size_t B,
+                 const RollArgs &ra, hipStream_t stream);
 
 }  // namespace mpe

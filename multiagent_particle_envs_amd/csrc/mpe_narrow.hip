@@ -229,7 +229,7 @@ __device__ __forceinline__ void pair_forces(const NarrowDesc &d, const float (&p
       const bool mc = c < A && ((d.movable >> c) & 1u);
       if (both && (ma || mc)) {  // uniform: kernarg bits
         float gx, gy;
-        contact_force(px[a] - px[c], py[a] - py[c], d.size[a] + d.size[c], d.cforce, d.cmargin, gx, gy);
+        contact_force(px[a] - px[c], py[a] - py[c], d.size[a] + d.size[c], d.cforce, d.cmargin, d.cmargin_inv, gx, gy);
         if (ma) { constexpr int z = 0; const int ia = a < A ? a : z; fx[ia] = gx + fx[ia]; fy[ia] = gy + fy[ia]; }
         if (mc) { constexpr int z = 0; const int ic = c < A ? c : z; fx[ic] = -gx + fx[ic]; fy[ic] = -gy + fy[ic]; }
       }
@@ -280,7 +280,7 @@ k_narrow(const NarrowDesc d, const MpeBuffers b, const size_t B) {
 #pragma unroll
     for (int i = 0; i < A; ++i) {
       if ((d.movable >> i) & 1u) {
-        integrate_one(px[i], py[i], vx[i], vy[i], fx[i], fy[i], d.mass[i], d.max_speed[i], d.damp, d.dt);
+        integrate_one(px[i], py[i], vx[i], vy[i], fx[i], fy[i], d.inv_mass[i], d.max_speed[i], d.damp, d.dt);
         if (live) {
           b.pos[(size_t)(2 * i) * B + w] = px[i];
           b.pos[(size_t)(2 * i + 1) * B + w] = py[i];
@@ -339,7 +339,7 @@ k_phase(const NarrowDesc d, const MpeBuffers b, const size_t B) {
       float px = b.pos[(size_t)(2 * i) * B + w], py = b.pos[(size_t)(2 * i + 1) * B + w];
       float vx = b.vel[(size_t)(2 * i) * B + w], vy = b.vel[(size_t)(2 * i + 1) * B + w];
       integrate_one(px, py, vx, vy, b.force[(size_t)(2 * i) * B + w], b.force[(size_t)(2 * i + 1) * B + w],
-                    d.mass[i], d.max_speed[i], d.damp, d.dt);
+                    d.inv_mass[i], d.max_speed[i], d.damp, d.dt);
       b.pos[(size_t)(2 * i) * B + w] = px;
       b.pos[(size_t)(2 * i + 1) * B + w] = py;
       b.vel[(size_t)(2 * i) * B + w] = vx;
@@ -418,11 +418,6 @@ int launch_phase(int phase, int A, int L, const NarrowDesc &d, const MpeBuffers 
   const unsigned grid = (unsigned)((B + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, stream, d, b, B);
   return (int)hipGetLastError();
-}
-
-int launch_rollout(int, int, int, int, const NarrowDesc &, const MpeBuffers &, size_t, int, int, float, uint64_t,
-                   uint64_t, uint64_t, hipStream_t) {
-  return MPE_EUNSUPPORTED;
 }
 
 }  // namespace mpe

@@ -1,0 +1,368 @@
+// mpe_split.hip -- wave-per-agent / lane-per-world kernels: the fused step and the fused T-step rollout.
+//
+// Why: at the benchmark batch (65 536 worlds per GPU) a thread-per-world launch is 1024 waves --
+// one per SIMD on 256 CUs -- and each lane walks ~2000 dependent VALU / transcendental
+// instructions, so the step is latency-bound at ~10 us although its 27 MB would stream in ~4 us.
+// Here a workgroup is A waves x 64 lanes: lane = world, WAVE = AGENT.  Every global access is
+// still a 256-byte coalesced wave access over the batch axis, each lane does one agent's share
+// of the work (its contacts, its integration, its observation row, its landmark distances), and
+// the chip holds A times as many waves to hide latency.  Agents of one world meet once per step
+// in LDS: after integrating, wave i publishes (pos_i, vel_i[, |pos_i - landmark_l|]) and, behind
+// one __syncthreads, reads the other agents' new state.  Arithmetic per pair / per agent is the
+// same code (mpe_device.h) in the same order as the thread-per-world kernels, so results are
+// bit-identical to them.
+//
+// ROLL = true is the fused rollout (mpe_rollout_random): T steps in one launch, each wave keeps
+// its agent's state in registers, moves are drawn in-kernel (Philox, identical to
+// mpe_random_actions), resets happen in-kernel (identical to mpe_reset), and every step's
+// obs/rew/done are still written -- to per-step trajectory blocks or over the same block.
+#include "mpe_internal.h"
+
+namespace mpe {
+
+template <int KIND, int A, int L, int NADV>
+struct SplitShape {
+  static constexpr int E = A + L;
+  static constexpr int XW = KIND == MPE_SCN_SPREAD ? 4 + L : 4;  // floats an agent publishes per world
+  static constexpr int DMAX = KIND == MPE_SCN_SIMPLE   ? 2 + 2 * L
+                              : KIND == MPE_SCN_SPREAD ? 4 + 2 * L + 4 * (A - 1)
+                              : KIND == MPE_SCN_TAG    ? 4 + 2 * L + 2 * (A - 1) + 2 * (A - NADV)
+                                                       : 1;
+  static constexpr int TILE = kWave * (DMAX | 1);
+  static constexpr size_t lds_bytes(bool roll) {
+    return sizeof(float) * ((roll ? 2 : 1) * A * XW * kWave + A * TILE);
+  }
+};
+
+template <int KIND, int A, int L, int NADV, bool ROLL>
+__global__ void __launch_bounds__(A *kWave)
+k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs ra) {
+  using S = SplitShape<KIND, A, L, NADV>;
+  constexpr int E = A + L, XW = S::XW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int i = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // this wave's agent (uniform)
+  const size_t w0 = (size_t)blockIdx.x * kWave;
+  if (w0 >= B) return;  // workgroup-uniform
+  const int nvalid = (B - w0) < (size_t)kWave ? (int)(B - w0) : kWave;
+  const bool live = lane < nvalid;
+  const size_t w = live ? w0 + lane : B - 1;
+  float *const xch = smem;
+  float *const tile = smem + (ROLL ? 2 : 1) * A * XW * kWave + i * S::TILE;
+
+  // this agent's constants, selected from the kernarg arrays without dynamic indexing
+  float size_i = 0.f, mass_i = 1.f, accel_i = 0.f, maxspd_i = -1.f;
+  int obs_off_i = 0;
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+    if (a == i) { size_i = d.size[a]; mass_i = d.inv_mass[a]; accel_i = d.accel[a]; maxspd_i = d.max_speed[a]; obs_off_i = d.obs_off[a]; }
+  const bool movable_i = (d.movable >> i) & 1u;
+  const bool collide_i = (d.collide >> i) & 1u;
+
+  float px[E], py[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    px[e] = b.pos[(size_t)(2 * e) * B + w];
+    py[e] = b.pos[(size_t)(2 * e + 1) * B + w];
+  }
+  float mx = 0.f, my = 0.f;
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+    if (a == i) { mx = px[a]; my = py[a]; }
+  float mvx = b.vel[(size_t)(2 * i) * B + w];
+  float mvy = b.vel[(size_t)(2 * i + 1) * B + w];
+
+  const uint64_t gw = ra.world_offset + w;  // global world number (RNG streams)
+  const int T = ROLL ? ra.T : 1;
+  const size_t obs_stride = ra.trajectory ? (size_t)d.obs_off[A] * B : 0;
+  const size_t row_stride = ra.trajectory ? (size_t)A * B : 0;
+
+  for (int t = 0; t < T; ++t) {
+    float ux, uy;
+    if (ROLL) {
+      const uint64_t gt = ra.step0 + (uint64_t)t;
+      if (ra.episode_len > 0 && gt % (uint64_t)ra.episode_len == 0) {  // reset_world, as mpe_reset does it
+        const uint64_t ep = gt / (uint64_t)ra.episode_len;
+#pragma unroll
+        for (int e = 0; e < E; ++e) reset_draw(ra.seed, gw, ep, e, e < A ? 1.0f : ra.landmark_range, px[e], py[e]);
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+          if (a == i) { mx = px[a]; my = py[a]; }
+        mvx = 0.f;
+        mvy = 0.f;
+      }
+      const int m = action_draw(ra.seed, gw, gt, i);  // the one-hot row mpe_random_actions would write
+      ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * accel_i;
+      uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * accel_i;
+    } else {
+      fetch_action(b, B, i, w, accel_i, ux, uy);
+    }
+
+    // ---- World.step for agent i (core.py:117-169): action force, contacts with every other entity
+    //      in ascending order (Q9), integrate ------------------------------------------------------
+    if (movable_i) {
+      float fx = ux + 0.f, fy = uy + 0.f;
+      if (collide_i) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+          if (j == i) continue;                        // uniform
+          if (!((d.collide >> j) & 1u)) continue;      // uniform
+          float gx, gy;
+          contact_force(mx - px[j], my - py[j], size_i + d.size[j], d.cforce, d.cmargin, d.cmargin_inv, gx, gy);
+          fx = gx + fx;
+          fy = gy + fy;
+        }
+      }
+      integrate_one(mx, my, mvx, mvy, fx, fy, mass_i, maxspd_i, d.damp, d.dt);
+      if (live && (!ROLL || t == T - 1)) {
+        b.pos[(size_t)(2 * i) * B + w] = mx;
+        b.pos[(size_t)(2 * i + 1) * B + w] = my;
+        b.vel[(size_t)(2 * i) * B + w] = mvx;
+        b.vel[(size_t)(2 * i + 1) * B + w] = mvy;
+      }
+    }
+
+    // ---- publish this agent's new state; read everybody's ------------------------------------------
+    float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
+    X[(i * XW + 0) * kWave + lane] = mx;
+    X[(i * XW + 1) * kWave + lane] = my;
+    X[(i * XW + 2) * kWave + lane] = mvx;
+    X[(i * XW + 3) * kWave + lane] = mvy;
+    if (KIND == MPE_SCN_SPREAD) {
+#pragma unroll
+      for (int l = 0; l < L; ++l) X[(i * XW + 4 + l) * kWave + lane] = dist2d(mx - px[A + l], my - py[A + l]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      px[a] = X[(a * XW + 0) * kWave + lane];
+      py[a] = X[(a * XW + 1) * kWave + lane];
+    }
+
+    // ---- outputs of agent i for this step -----------------------------------------------------------
+    float *const obs_t = b.obs + (size_t)t * obs_stride;
+    const size_t ro = (size_t)t * row_stride + (size_t)i * B + w;
+    if (KIND == MPE_SCN_SIMPLE) {
+      constexpr int D = 2 + 2 * L, DP = D | 1;
+      tile[lane * DP + 0] = mvx;
+      tile[lane * DP + 1] = mvy;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        tile[lane * DP + 2 + 2 * l] = px[A + l] - mx;
+        tile[lane * DP + 3 + 2 * l] = py[A + l] - my;
+      }
+      flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      if (live) {
+        if (b.rew) {
+          const float dx = mx - px[A], dy = my - py[A];
+          const float sx = dx * dx, sy = dy * dy;
+          b.rew[ro] = -(sx + sy);
+        }
+        if (b.done) b.done[ro] = 0;
+      }
+    }
+    if (KIND == MPE_SCN_SPREAD) {
+      constexpr int D = 4 + 2 * L + 4 * (A - 1), DP = D | 1;
+      tile[lane * DP + 0] = mvx;
+      tile[lane * DP + 1] = mvy;
+      tile[lane * DP + 2] = mx;
+      tile[lane * DP + 3] = my;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        tile[lane * DP + 4 + 2 * l] = px[A + l] - mx;
+        tile[lane * DP + 5 + 2 * l] = py[A + l] - my;
+      }
+      int k = 4 + 2 * L;  // uniform running column
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        if (j == i) continue;
+        tile[lane * DP + k] = px[j] - mx;
+        tile[lane * DP + k + 1] = py[j] - my;
+        k += 2;
+      }
+#pragma unroll
+      for (int z = 0; z < 2 * (A - 1); ++z) tile[lane * DP + k + z] = 0.f;
+      flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      if (b.rew || b.info_rew) {
+        // landmark term from the published agent-landmark distances; contact counts from the new positions
+        float lm_term = 0.f, md = 0.f;
+        int occupied = 0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          float m = X[(0 * XW + 4 + l) * kWave + lane];
+#pragma unroll
+          for (int a = 1; a < A; ++a) m = fminf(m, X[(a * XW + 4 + l) * kWave + lane]);
+          lm_term = lm_term - m;
+          md = md + m;
+          occupied += (m < 0.1f) ? 1 : 0;
+        }
+        int cnt[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) cnt[a] = 0;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+#pragma unroll
+          for (int c = a; c < A; ++c) {
+            const bool hit = dist2d(px[a] - px[c], py[a] - py[c]) < d.size[a] + d.size[c];
+            if (c == a) { cnt[a] += hit ? 1 : 0; }          // the agent against itself (Q1)
+            else { cnt[a] += hit ? 1 : 0; cnt[c] += hit ? 1 : 0; }
+          }
+        }
+        float r[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          const int c = ((d.collide >> a) & 1u) ? cnt[a] : 0;
+          cnt[a] = c;
+          float ra_ = lm_term;
+#pragma unroll
+          for (int s = 0; s < A; ++s) ra_ = ra_ - (c > s ? 1.f : 0.f);
+          r[a] = ra_;
+        }
+        float rest = 0.f;
+#pragma unroll
+        for (int a = 1; a < A; ++a) rest += r[a];
+        const float total = A > 1 ? r[0] + rest : r[0];
+        float r_own = 0.f;
+        int c_own = 0;
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+          if (a == i) { r_own = r[a]; c_own = cnt[a]; }
+        if (live) {
+          if (b.rew) b.rew[ro] = d.collaborative ? total : r_own;
+          if (b.info_rew) {
+            b.info_rew[ro] = r_own;
+            b.info_collisions[ro] = c_own;
+            b.info_min_dists[ro] = md;
+            b.info_occupied[ro] = occupied;
+          }
+        }
+      }
+      if (b.done && live) b.done[ro] = 0;
+    }
+    if (KIND == MPE_SCN_TAG) {
+      constexpr int NG = A - NADV;
+      constexpr int DA = 4 + 2 * L + 2 * (A - 1) + 2 * NG, DG = DA - 2;
+      const bool adv = i < NADV;
+      const int DP = adv ? (DA | 1) : (DG | 1);
+      tile[lane * DP + 0] = mvx;
+      tile[lane * DP + 1] = mvy;
+      tile[lane * DP + 2] = mx;
+      tile[lane * DP + 3] = my;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        tile[lane * DP + 4 + 2 * l] = px[A + l] - mx;
+        tile[lane * DP + 5 + 2 * l] = py[A + l] - my;
+      }
+      int k = 4 + 2 * L;
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        if (j == i) continue;
+        tile[lane * DP + k] = px[j] - mx;
+        tile[lane * DP + k + 1] = py[j] - my;
+        k += 2;
+      }
+#pragma unroll
+      for (int j = NADV; j < A; ++j) {
+        if (j == i) continue;
+        tile[lane * DP + k] = X[(j * XW + 2) * kWave + lane];
+        tile[lane * DP + k + 1] = X[(j * XW + 3) * kWave + lane];
+        k += 2;
+      }
+      if (adv) flush_rows<DA>(tile, obs_t + B * obs_off_i + w0 * DA, nvalid, lane, d.vec4);
+      else     flush_rows<DG>(tile, obs_t + B * obs_off_i + w0 * DG, nvalid, lane, d.vec4);
+      if (b.rew || b.info_collisions) {
+        bool hit[NG][NADV];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int v = 0; v < NADV; ++v)
+            hit[g][v] = dist2d(px[NADV + g] - px[v], py[NADV + g] - py[v]) < d.size[NADV + g] + d.size[v];
+        float r = 0.f;
+        int c = 0;
+        if (adv) {
+          if (collide_i) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+              for (int v = 0; v < NADV; ++v) r += hit[g][v] ? 10.f : 0.f;
+          }
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int v = 0; v < NADV; ++v)
+              if (v == i) c += hit[g][v] ? 1 : 0;
+        } else {
+          if (collide_i) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+              for (int v = 0; v < NADV; ++v)
+                if (g + NADV == i) r -= hit[g][v] ? 10.f : 0.f;
+          }
+          r -= tag_bound(fabsf(mx));
+          r -= tag_bound(fabsf(my));
+        }
+        if (live) {
+          if (b.rew) b.rew[ro] = r;
+          if (b.info_collisions) b.info_collisions[ro] = c;
+        }
+      }
+      if (b.done && live) b.done[ro] = 0;
+    }
+  }
+  if (ROLL && ra.episode_len > 0 && live) {
+    // in-kernel resets moved the landmarks: hand their positions back (wave i writes landmarks l = i mod A)
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+      if (l % A == i) {
+        b.pos[(size_t)(2 * (A + l)) * B + w] = px[A + l];
+        b.pos[(size_t)(2 * (A + l) + 1) * B + w] = py[A + l];
+      }
+    if (!movable_i) {  // an immovable agent is never integrated, but a reset did place it
+      b.pos[(size_t)(2 * i) * B + w] = mx;
+      b.pos[(size_t)(2 * i + 1) * B + w] = my;
+      b.vel[(size_t)(2 * i) * B + w] = mvx;
+      b.vel[(size_t)(2 * i + 1) * B + w] = mvy;
+    }
+  }
+}
+
+// ---- dispatch -----------------------------------------------------------------------------------
+using SplitFn = void (*)(const NarrowDesc, const MpeBuffers, const size_t, const RollArgs);
+struct SplitEntry {
+  int kind, A, L, nadv;
+  SplitFn step, roll;
+  size_t lds_step, lds_roll;
+};
+#define MPE_SPLIT_ENTRY(KIND, A, L, NADV)                                                     \
+  { KIND, A, L, NADV, k_split<KIND, A, L, NADV, false>, k_split<KIND, A, L, NADV, true>,       \
+    SplitShape<KIND, A, L, NADV>::lds_bytes(false), SplitShape<KIND, A, L, NADV>::lds_bytes(true) }
+
+static const SplitEntry kSplitTable[] = {
+    MPE_SPLIT_ENTRY(MPE_SCN_SIMPLE, 1, 1, 0),
+    MPE_SPLIT_ENTRY(MPE_SCN_SPREAD, 1, 1, 0), MPE_SPLIT_ENTRY(MPE_SCN_SPREAD, 2, 2, 0),
+    MPE_SPLIT_ENTRY(MPE_SCN_SPREAD, 3, 3, 0), MPE_SPLIT_ENTRY(MPE_SCN_SPREAD, 4, 4, 0),
+    MPE_SPLIT_ENTRY(MPE_SCN_SPREAD, 5, 5, 0), MPE_SPLIT_ENTRY(MPE_SCN_SPREAD, 6, 6, 0),
+    MPE_SPLIT_ENTRY(MPE_SCN_TAG, 4, 2, 3), MPE_SPLIT_ENTRY(MPE_SCN_TAG, 2, 1, 1),
+    MPE_SPLIT_ENTRY(MPE_SCN_TAG, 6, 3, 4),
+};
+
+static const SplitEntry *find_split(int kind, int A, int L, int nadv) {
+  for (const SplitEntry &e : kSplitTable)
+    if (e.kind == kind && e.A == A && e.L == L && (kind != MPE_SCN_TAG || e.nadv == nadv)) return &e;
+  return nullptr;
+}
+
+bool split_supports(int kind, int A, int L, int nadv) { return find_split(kind, A, L, nadv) != nullptr; }
+
+int launch_split(bool roll, int kind, int A, int L, int nadv, const NarrowDesc &d, const MpeBuffers &b, size_t B,
+                 const RollArgs &ra, hipStream_t stream) {
+  const SplitEntry *e = find_split(kind, A, L, nadv);
+  if (!e) return MPE_EUNSUPPORTED;
+  const unsigned grid = (unsigned)((B + kWave - 1) / kWave);
+  hipLaunchKernelGGL(roll ? e->roll : e->step, dim3(grid), dim3(A * kWave), roll ? e->lds_roll : e->lds_step, stream,
+                     d, b, B, ra);
+  return (int)hipGetLastError();
+}
+
+}  // namespace mpe

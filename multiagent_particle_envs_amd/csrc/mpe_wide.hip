@@ -105,7 +105,7 @@ __global__ void k_wide(const WideDesc d, const MpeBuffers b, const size_t B, con
   }
   for (int i = tid; i < A; i += nthr) {
     s.vel[i] = make_float2(b.vel[(size_t)(2 * i) * B + w], b.vel[(size_t)(2 * i + 1) * B + w]);
-    s.mass[i] = tab[1 * E + i];
+    s.mass[i] = 1.0f / tab[1 * E + i];  // inverse mass
     s.maxspd[i] = tab[3 * E + i];
     if (PHYS) {
       float ux, uy;
@@ -132,7 +132,7 @@ __global__ void k_wide(const WideDesc d, const MpeBuffers b, const size_t B, con
           const float2 pj = s.pos[j];
           const float dmin = j > i ? ri + s.size[j] : s.size[j] + ri;
           float gx, gy;
-          contact_force(me.x - pj.x, me.y - pj.y, dmin, d.cforce, d.cmargin, gx, gy);
+          contact_force(me.x - pj.x, me.y - pj.y, dmin, d.cforce, d.cmargin, d.cmargin_inv, gx, gy);
           px_ = gx + px_;
           py_ = gy + py_;
         }

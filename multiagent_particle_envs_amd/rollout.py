@@ -85,16 +85,105 @@ class RandomRollout(object):
         torch.cuda.current_stream(self.world.device).wait_stream(s)
         return g
 
-    def fused(self, steps):
-        """One `mpe_rollout_random` launch covering `steps` env steps."""
-        out = self.env._sets[0]
-        b = out.bufs
+    def fused(self, steps, trajectory=None):
+        """One `mpe_rollout_random` launch covering `steps` env steps.  With `trajectory` (a
+        Trajectory of at least `steps` blocks) every step's outputs land in their own block;
+        without it each step overwrites the env's output set 0."""
+        if trajectory is None:
+            b = self.env._sets[0].bufs
+            ret = self.env._sets[0]
+        else:
+            assert trajectory.T >= steps
+            b = trajectory.bufs
+            ret = trajectory
         b.act = b.ids = b.u = None
         _abi.check(self._L.mpe_rollout_random(C.byref(self._desc), C.byref(b), self.B, int(steps), self.episode_len,
                                               self._lr, self.seed, self.t, int(self.world.world_offset),
-                                              self._stream()), "mpe_rollout_random")
+                                              1 if trajectory is not None else 0, self._stream()),
+                   "mpe_rollout_random")
         self.t += steps
-        return out
+        return ret
+
+
+class StreamedRollout(object):
+    """S independent sub-batches of worlds, each advanced on its own HIP stream.
+
+    Worlds never interact, so a batch can be cut into S slices that progress independently: step
+    t+1 of slice 0 overlaps step t of slice 1.  A dependent chain of small launches is bound by
+    per-launch latency (dispatch, wave ramp-up, the load -> compute -> store chain, drain), not by
+    bandwidth; running S chains side by side hides that latency exactly like more waves per SIMD
+    hide instruction latency.  Each slice is an ordinary env (own tensors, `world_offset` = its
+    first global world), so results are identical to one big batch (shard invariance).
+    """
+
+    def __init__(self, rollouts):
+        self.rollouts = list(rollouts)
+        dev = self.rollouts[0].world.device
+        self.device = dev
+        self.streams = [torch.cuda.Stream(device=dev) for _ in self.rollouts]
+
+    @property
+    def B(self):
+        return sum(r.B for r in self.rollouts)
+
+    def _fan(self, fn):
+        cur = torch.cuda.current_stream(self.device)
+        for r, s in zip(self.rollouts, self.streams):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                fn(r)
+        for s in self.streams:
+            cur.wait_stream(s)
+
+    def enqueue(self, steps):
+        self._fan(lambda r: r.enqueue(steps))
+
+    def fused(self, steps, trajectories=None):
+        it = iter(trajectories) if trajectories is not None else None
+        self._fan(lambda r: r.fused(steps, next(it) if it is not None else None))
+
+    def capture(self, steps):
+        g = torch.cuda.CUDAGraph()
+        main = torch.cuda.Stream(device=self.device)
+        main.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(main):
+            t0 = [r.t for r in self.rollouts]
+            self.enqueue(2)                      # load code objects outside capture
+            for r, t in zip(self.rollouts, t0):
+                r.t = t
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=main):
+                self.enqueue(steps)
+        torch.cuda.current_stream(self.device).wait_stream(main)
+        return g
+
+    def set_episode_len(self, n):
+        for r in self.rollouts:
+            r.episode_len = n
+
+
+class Trajectory(object):
+    """Device buffers for T consecutive steps' outputs (what a rollout collector keeps for training):
+    obs[t][i] is the [B, D_i] observation of agent i after step t, rew[t] / done[t] are [A, B]."""
+
+    def __init__(self, env, T):
+        env._ensure_buffers()
+        w = env.world
+        A, B, dev = len(w.agents), w.batch_size, w.device
+        off = env._obs_off
+        self.T, self.A, self.B = int(T), A, B
+        per = int(off[-1]) * B
+        self.obs_flat = torch.zeros(self.T * per, dtype=torch.float32, device=dev)
+        self.obs = [[self.obs_flat[t * per + off[i] * B: t * per + off[i + 1] * B].view(B, off[i + 1] - off[i])
+                     for i in range(A)] for t in range(self.T)]
+        self.rew = torch.zeros((self.T, A, B), dtype=torch.float32, device=dev)
+        self.done = torch.zeros((self.T, A, B), dtype=torch.bool, device=dev)
+        b = _abi.MpeBuffers()
+        b.pos, b.vel = w.pos.data_ptr(), w.vel.data_ptr()
+        b.obs, b.rew, b.done = self.obs_flat.data_ptr(), self.rew.data_ptr(), self.done.data_ptr()
+        if env._entity_table is not None:
+            b.entity_table = env._entity_table.data_ptr()
+        self.bufs = b
 
 
 def _copy_struct(s):
