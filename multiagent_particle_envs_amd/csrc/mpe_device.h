@@ -49,6 +49,25 @@ __device__ __forceinline__ float dist2d(float dx, float dy) {
   return sqrtf(sx + sy);
 }
 
+// rn(sqrtf(s2)) < m, decided EXACTLY (same truth value as the correctly rounded sqrt followed by the
+// compare, i.e. as NumPy's float32 `sqrt(sum(square(delta))) < dist_min`) without the ~18-instruction
+// sqrt in all but a 1e-6-wide band around the threshold: if s2 < m^2 (1 - 4e-7) then
+// sqrt(s2) < m (1 - 2e-7) is more than an ulp below m, and symmetrically above; only inside the band is
+// the real sqrt evaluated.  Used for the integer outputs (collision counts) -- see DESIGN.md 4.
+__device__ __forceinline__ bool sqrt_lt(float s2, float m) {
+  const float m2 = m * m;
+  if (m2 > 1e-30f) {
+    if (s2 < m2 * 0.9999996f) return true;
+    if (s2 > m2 * 1.0000004f) return false;
+  }
+  return sqrtf(s2) < m;
+}
+__device__ __forceinline__ float sq2d(float dx, float dy) {
+  const float sx = dx * dx;
+  const float sy = dy * dy;
+  return sx + sy;
+}
+
 // World.get_collision_force (core.py:180-196) for one pair; returns the force on `a`
 // (the force on `b` is its negation).  dx,dy = pos_a - pos_b.
 // Evaluated as delta * ((C * pen) / dist) with one reciprocal instead of the reference's

@@ -90,9 +90,12 @@ __device__ __forceinline__ void out_spread(const NarrowDesc &d, const MpeBuffers
   int occupied = 0;
 #pragma unroll
   for (int l = 0; l < L; ++l) {
-    float m = dist2d(px[0] - px[A + l], py[0] - py[A + l]);
+    // min over agents on squared distances, then ONE correctly rounded sqrt: sqrt is monotone, so this
+    // is exactly min over agents of the rounded distances (what min(dists) is in the reference)
+    float m2 = sq2d(px[0] - px[A + l], py[0] - py[A + l]);
 #pragma unroll
-    for (int a = 1; a < A; ++a) m = fminf(m, dist2d(px[a] - px[A + l], py[a] - py[A + l]));
+    for (int a = 1; a < A; ++a) m2 = fminf(m2, sq2d(px[a] - px[A + l], py[a] - py[A + l]));
+    const float m = sqrtf(m2);
     lm_term = lm_term - m;
     md = md + m;
     occupied += (m < 0.1f) ? 1 : 0;
@@ -105,7 +108,7 @@ __device__ __forceinline__ void out_spread(const NarrowDesc &d, const MpeBuffers
     if ((d.collide >> i) & 1u) {
 #pragma unroll
       for (int a = 0; a < A; ++a)
-        c += (dist2d(px[a] - px[i], py[a] - py[i]) < d.size[a] + d.size[i]) ? 1 : 0;
+        c += sqrt_lt(sq2d(px[a] - px[i], py[a] - py[i]), d.size[a] + d.size[i]) ? 1 : 0;
     }
     cnt[i] = c;
     float ri = lm_term;
@@ -183,7 +186,7 @@ __device__ __forceinline__ void out_tag(const NarrowDesc &d, const MpeBuffers &b
   for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int v = 0; v < NADV; ++v)
-      hit[g][v] = dist2d(px[NADV + g] - px[v], py[NADV + g] - py[v]) < d.size[NADV + g] + d.size[v];
+      hit[g][v] = sqrt_lt(sq2d(px[NADV + g] - px[v], py[NADV + g] - py[v]), d.size[NADV + g] + d.size[v]);
   float adv_rew = 0.f;  // adversary_reward :115-129 -- same value for every adversary
 #pragma unroll
   for (int g = 0; g < NG; ++g)

@@ -77,12 +77,23 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   const size_t obs_stride = ra.trajectory ? (size_t)d.obs_off[A] * B : 0;
   const size_t row_stride = ra.trajectory ? (size_t)A * B : 0;
 
+  // resets fall on global steps that are multiples of episode_len: one 64-bit divide up front, then a
+  // countdown (a per-step 64-bit modulo costs ~130 instructions on this ISA)
+  int countdown = -1;
+  uint64_t ep = 0;
+  if (ROLL && ra.episode_len > 0) {
+    const uint64_t len = (uint64_t)ra.episode_len, r = ra.step0 % len;
+    countdown = r == 0 ? 0 : (int)(len - r);
+    ep = ra.step0 / len + (r ? 1 : 0);
+  }
+
   for (int t = 0; t < T; ++t) {
     float ux, uy;
     if (ROLL) {
       const uint64_t gt = ra.step0 + (uint64_t)t;
-      if (ra.episode_len > 0 && gt % (uint64_t)ra.episode_len == 0) {  // reset_world, as mpe_reset does it
-        const uint64_t ep = gt / (uint64_t)ra.episode_len;
+      const bool reset_now = countdown == 0;
+      if (countdown >= 0) countdown = reset_now ? ra.episode_len - 1 : countdown - 1;
+      if (reset_now) {  // reset_world, as mpe_reset does it for episode ep = gt / episode_len
 #pragma unroll
         for (int e = 0; e < E; ++e) reset_draw(ra.seed, gw, ep, e, e < A ? 1.0f : ra.landmark_range, px[e], py[e]);
 #pragma unroll
@@ -90,6 +101,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
           if (a == i) { mx = px[a]; my = py[a]; }
         mvx = 0.f;
         mvy = 0.f;
+        ++ep;
       }
       const int m = action_draw(ra.seed, gw, gt, i);  // the one-hot row mpe_random_actions would write
       ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * accel_i;
@@ -130,7 +142,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
     X[(i * XW + 3) * kWave + lane] = mvy;
     if (KIND == MPE_SCN_SPREAD) {
 #pragma unroll
-      for (int l = 0; l < L; ++l) X[(i * XW + 4 + l) * kWave + lane] = dist2d(mx - px[A + l], my - py[A + l]);
+      for (int l = 0; l < L; ++l) X[(i * XW + 4 + l) * kWave + lane] = sq2d(mx - px[A + l], my - py[A + l]);
     }
     __syncthreads();
 #pragma unroll
@@ -189,9 +201,10 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         int occupied = 0;
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-          float m = X[(0 * XW + 4 + l) * kWave + lane];
+          float m2 = X[(0 * XW + 4 + l) * kWave + lane];  // published SQUARED distances: min first,
 #pragma unroll
-          for (int a = 1; a < A; ++a) m = fminf(m, X[(a * XW + 4 + l) * kWave + lane]);
+          for (int a = 1; a < A; ++a) m2 = fminf(m2, X[(a * XW + 4 + l) * kWave + lane]);
+          const float m = sqrtf(m2);                      // then one correctly rounded sqrt (monotone => same value)
           lm_term = lm_term - m;
           md = md + m;
           occupied += (m < 0.1f) ? 1 : 0;
@@ -203,7 +216,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         for (int a = 0; a < A; ++a) {
 #pragma unroll
           for (int c = a; c < A; ++c) {
-            const bool hit = dist2d(px[a] - px[c], py[a] - py[c]) < d.size[a] + d.size[c];
+            const bool hit = sqrt_lt(sq2d(px[a] - px[c], py[a] - py[c]), d.size[a] + d.size[c]);
             if (c == a) { cnt[a] += hit ? 1 : 0; }          // the agent against itself (Q1)
             else { cnt[a] += hit ? 1 : 0; cnt[c] += hit ? 1 : 0; }
           }
@@ -276,7 +289,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         for (int g = 0; g < NG; ++g)
 #pragma unroll
           for (int v = 0; v < NADV; ++v)
-            hit[g][v] = dist2d(px[NADV + g] - px[v], py[NADV + g] - py[v]) < d.size[NADV + g] + d.size[v];
+            hit[g][v] = sqrt_lt(sq2d(px[NADV + g] - px[v], py[NADV + g] - py[v]), d.size[NADV + g] + d.size[v]);
         float r = 0.f;
         int c = 0;
         if (adv) {
