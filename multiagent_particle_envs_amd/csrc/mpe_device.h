@@ -42,7 +42,14 @@ __device__ __forceinline__ float softplus0(float x) {
   return fmaxf(x, 0.f) + l;
 }
 
-// sqrt(dx^2 + dy^2) with NumPy's rounding sequence (no fma).
+// Hardware square root / reciprocal square root (v_sqrt_f32 / v_rsq_f32: one instruction, 1 ulp)
+// for the FLOAT outputs (forces, rewards, speed clamp), whose bar is 1e-5 against fp64.  hipcc's
+// sqrtf is the correctly rounded form, ~17 instructions (denormal scaling + two fma fix-ups + class
+// test): it is kept only where an INTEGER output hangs on the rounding (sqrt_lt's guard band).
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// sqrt(dx^2 + dy^2), correctly rounded, with NumPy's rounding sequence (no fma).
 __device__ __forceinline__ float dist2d(float dx, float dy) {
   const float sx = dx * dx;
   const float sy = dy * dy;
@@ -70,14 +77,17 @@ __device__ __forceinline__ float sq2d(float dx, float dy) {
 
 // World.get_collision_force (core.py:180-196) for one pair; returns the force on `a`
 // (the force on `b` is its negation).  dx,dy = pos_a - pos_b.
-// Evaluated as delta * ((C * pen) / dist) with one reciprocal instead of the reference's
-// ((C*delta)/dist)*pen with two IEEE divisions, and (dist_min - dist) * (1/k) instead of a third:
-// a few ulp (<= 3e-7 relative) of regrouping.  dist == 0 still gives NaN (0 * inf), SURVEY Q7.
+// Evaluated as delta * ((C * pen) * rsqrt(d2)) with dist = d2 * rsqrt(d2): ONE transcendental
+// (v_rsq_f32) instead of the reference's sqrt plus the two IEEE divisions of ((C*delta)/dist)*pen, and
+// (dist_min - dist) * (1/k) instead of a third: a few ulp (<= 4e-7 relative) of regrouping.
+// dist == 0 still gives NaN (0 * inf), SURVEY Q7.
 __device__ __forceinline__ void contact_force(float dx, float dy, float dist_min, float cforce,
                                               float k, float kinv, float &fx, float &fy) {
-  const float dist = dist2d(dx, dy);
+  const float d2 = sq2d(dx, dy);
+  const float r = fast_rsq(d2);
+  const float dist = d2 * r;
   const float pen = softplus0((dist_min - dist) * kinv) * k;
-  const float s = (cforce * pen) * __builtin_amdgcn_rcpf(dist);
+  const float s = (cforce * pen) * r;
   fx = dx * s;
   fy = dy * s;
 }
@@ -91,9 +101,9 @@ __device__ __forceinline__ void integrate_one(float &px, float &py, float &vx, f
   vx += (fx * inv_mass) * dt;  // f / mass with mass == 1.0: exact
   vy += (fy * inv_mass) * dt;
   if (max_speed >= 0.f) {
-    const float speed = sqrtf(vx * vx + vy * vy);
-    if (speed > max_speed) {  // v / speed * max_speed (core.py:166-168) with one division
-      const float s = max_speed / speed;
+    const float v2 = vx * vx + vy * vy;
+    if (v2 > max_speed * max_speed) {  // speed > max_speed (core.py:166), compared on the squares
+      const float s = max_speed * fast_rsq(v2);  // v / speed * max_speed as v * (max_speed / speed)
       vx = vx * s;
       vy = vy * s;
     }
@@ -121,11 +131,31 @@ __device__ __forceinline__ void fetch_action(const MpeBuffers &b, size_t B, int 
   else { ux = b.u[(size_t)(2 * i) * B + w]; uy = b.u[(size_t)(2 * i + 1) * B + w]; }
 }
 
+// A wave-uniform element offset pinned to SGPRs.  The value is uniform by construction (kernel
+// arguments, blockIdx, the wave's agent index); passing its halves through readfirstlane keeps LLVM
+// from re-associating "uniform offset + lane" into per-lane 64-bit multiply-adds, so that
+// (base + wave_off(u))[lane] becomes one global_load/store with a scalar base and a 32-bit vector offset.
+__device__ __forceinline__ size_t wave_off(size_t u) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)u >> 32));
+  return (size_t)(((uint64_t)hi << 32) | lo);
+}
+
+// The same with the address split into a wave-uniform row base (SGPRs: world w0 = first world of the
+// wave) and a 32-bit lane offset, so the loads take the scalar-base addressing form instead of
+// per-lane 64-bit address arithmetic.
+__device__ __forceinline__ void fetch_action_wave(const MpeBuffers &b, size_t B, int i, size_t w0, unsigned ln, float sens,
+                                                  float &ux, float &uy) {
+  if (b.act) decode_row(b.act + wave_off(((size_t)i * B + w0) * MPE_ACTION_DIM) + ln * MPE_ACTION_DIM, sens, ux, uy);
+  else if (b.ids) decode_id((b.ids + wave_off((size_t)i * B + w0))[ln], sens, ux, uy);
+  else { ux = (b.u + wave_off((size_t)(2 * i) * B + w0))[ln]; uy = (b.u + wave_off((size_t)(2 * i + 1) * B + w0))[ln]; }
+}
+
 // simple_tag.py:103-108
 __device__ __forceinline__ float tag_bound(float x) {
   if (x < 0.9f) return 0.f;
   if (x < 1.0f) return (x - 0.9f) * 10.f;
-  return fminf(expf(2.f * x - 2.f), 10.f);
+  return fminf(__builtin_amdgcn_exp2f((2.f * x - 2.f) * 1.44269504088896341f), 10.f);
 }
 
 // ---- Philox4x32-10 (Salmon et al. 2011), counter-based: reset + synthetic actions -------------
@@ -183,14 +213,34 @@ __host__ __device__ inline int action_draw(uint64_t seed, uint64_t b, uint64_t t
 
 // ---- wave-private LDS transpose: 64 per-lane rows of D floats -> one contiguous 64*D-float run ----
 // The drop-in obs layout is row-major [B][D] per agent (72-byte rows at D=18): a thread-per-world
-// store would be stride-D scattered.  Each wave parks its 64 rows in its own LDS tile (row stride
-// D|1: odd => the column writes are bank-conflict-free) and streams the tile out as 16-byte
-// stores over the contiguous 256*D-byte segment it owns.  No workgroup barrier is involved.
-// flush_rows: the tile (row stride D|1, rows = lanes) already holds the wave's 64 rows.
+// store would be stride-D scattered.  Each wave parks its 64 rows in its own LDS tile and streams
+// the tile out as 16-byte stores over the contiguous 256*D-byte segment it owns.  No workgroup
+// barrier is involved.
+// Row stride S of the tile:
+//   D/2 odd (D = 18, 14, 30 ...)  S = D: the tile IS the output segment, the flush is one
+//       ds_read_b128 + one 16-byte store per lane with no index arithmetic, and rows written as
+//       float2 (8-byte) pieces are bank-conflict-free (stride D/2 odd in 8-byte units);
+//   otherwise                      S = D|1 (odd => conflict-free 4-byte column writes) and the flush
+//       gathers each 16-byte piece with a divide-by-constant per element.
+template <int D>
+constexpr int tile_stride() { return ((D % 2) == 0 && ((D / 2) % 2) == 1) ? D : (D | 1); }
+
+// columns c, c+1 (c even) of this lane's row
+template <int S>
+__device__ __forceinline__ void put2(float *tile, int lane, int c, float x, float y) {
+  if constexpr ((S & 1) == 0) {
+    *reinterpret_cast<float2 *>(tile + lane * S + c) = make_float2(x, y);
+  } else {
+    tile[lane * S + c] = x;
+    tile[lane * S + c + 1] = y;
+  }
+}
+
+// flush_rows: the tile (row stride tile_stride<D>(), rows = lanes) already holds the wave's 64 rows.
 template <int D>
 __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict__ g, int nvalid, int lane,
                                            bool vec4) {
-  constexpr int DP = D | 1;
+  constexpr int S = tile_stride<D>();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int nfl = nvalid * D;
@@ -201,11 +251,16 @@ __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict_
     const int j = 4 * q;
     if (q < NQ && j < nfl) {
       float v[4];
+      if constexpr (S == D) {
+        const float4 t = *reinterpret_cast<const float4 *>(tile + j);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int jj = j + m;
-        const int r = jj / D, c = jj - r * D;
-        v[m] = (jj < 64 * D) ? tile[r * DP + c] : 0.f;
+        for (int m = 0; m < 4; ++m) {
+          const int jj = j + m;
+          const int r = jj / D, c = jj - r * D;
+          v[m] = (jj < 64 * D) ? tile[r * S + c] : 0.f;
+        }
       }
       if (vec4 && j + 3 < nfl) {
         *reinterpret_cast<float4 *>(g + j) = make_float4(v[0], v[1], v[2], v[3]);
@@ -223,13 +278,18 @@ __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict_
 template <int D>
 __device__ __forceinline__ void store_rows(float *tile, const float (&row)[D], float *__restrict__ g,
                                            int nvalid, int lane, bool vec4) {
-  constexpr int DP = D | 1;
+  constexpr int S = tile_stride<D>();
+  if constexpr ((S & 1) == 0) {
 #pragma unroll
-  for (int c = 0; c < D; ++c) tile[lane * DP + c] = row[c];
+    for (int c = 0; c < D; c += 2) put2<S>(tile, lane, c, row[c], row[c + 1]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < D; ++c) tile[lane * S + c] = row[c];
+  }
   flush_rows<D>(tile, g, nvalid, lane, vec4);
 }
 
 template <int D>
-constexpr int tile_floats() { return kWave * (D | 1); }
+constexpr int tile_floats() { return kWave * tile_stride<D>(); }
 
 }  // namespace mpe

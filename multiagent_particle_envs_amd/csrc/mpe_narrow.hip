@@ -20,7 +20,7 @@ struct ObsTile {  // LDS floats one wave needs for its widest observation row
       : KIND == MPE_SCN_SPREAD ? 4 + 2 * L + 2 * (A - 1) + DC * (A - 1)
       : KIND == MPE_SCN_TAG    ? 4 + 2 * L + 2 * (A - 1) + 2 * (A - NADV)
                                : 1;
-  static constexpr int floats = kWave * (D | 1);
+  static constexpr int floats = kWave * (D | 1);  // >= kWave * tile_stride<D>()
 };
 
 // ---- scenario output stages: Scenario.observation / reward / benchmark_data per world ----------
@@ -90,15 +90,15 @@ __device__ __forceinline__ void out_spread(const NarrowDesc &d, const MpeBuffers
   int occupied = 0;
 #pragma unroll
   for (int l = 0; l < L; ++l) {
-    // min over agents on squared distances, then ONE correctly rounded sqrt: sqrt is monotone, so this
-    // is exactly min over agents of the rounded distances (what min(dists) is in the reference)
+    // min over agents on squared distances, then ONE square root (sqrt is monotone: min(dists) of the
+    // reference is the distance of the nearest agent)
     float m2 = sq2d(px[0] - px[A + l], py[0] - py[A + l]);
 #pragma unroll
     for (int a = 1; a < A; ++a) m2 = fminf(m2, sq2d(px[a] - px[A + l], py[a] - py[A + l]));
-    const float m = sqrtf(m2);
+    const float m = fast_sqrt(m2);
     lm_term = lm_term - m;
     md = md + m;
-    occupied += (m < 0.1f) ? 1 : 0;
+    occupied += sqrt_lt(m2, 0.1f) ? 1 : 0;  // the integer output takes the exact test
   }
   float r[A];
   int cnt[A];

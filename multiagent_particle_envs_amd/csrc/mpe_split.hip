@@ -16,6 +16,8 @@
 // its agent's state in registers, moves are drawn in-kernel (Philox, identical to
 // mpe_random_actions), resets happen in-kernel (identical to mpe_reset), and every step's
 // obs/rew/done are still written -- to per-step trajectory blocks or over the same block.
+#include <type_traits>
+
 #include "mpe_internal.h"
 
 namespace mpe {
@@ -28,7 +30,7 @@ struct SplitShape {
                               : KIND == MPE_SCN_SPREAD ? 4 + 2 * L + 4 * (A - 1)
                               : KIND == MPE_SCN_TAG    ? 4 + 2 * L + 2 * (A - 1) + 2 * (A - NADV)
                                                        : 1;
-  static constexpr int TILE = kWave * (DMAX | 1);
+  static constexpr int TILE = kWave * (DMAX | 1);  // >= kWave * tile_stride<D>() of every row width used
   static constexpr size_t lds_bytes(bool roll) {
     return sizeof(float) * ((roll ? 2 : 1) * A * XW * kWave + A * TILE);
   }
@@ -46,7 +48,11 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   if (w0 >= B) return;  // workgroup-uniform
   const int nvalid = (B - w0) < (size_t)kWave ? (int)(B - w0) : kWave;
   const bool live = lane < nvalid;
-  const size_t w = live ? w0 + lane : B - 1;
+  // dead lanes of a ragged last wave shadow its last live world (their stores are masked).  Every
+  // global address below is "wave-uniform base (SGPRs) + ln": scalar-base addressing, no per-lane
+  // 64-bit arithmetic.
+  const unsigned ln = (unsigned)(live ? lane : nvalid - 1) & 63u;
+  const size_t w = w0 + (size_t)ln;
   float *const xch = smem;
   float *const tile = smem + (ROLL ? 2 : 1) * A * XW * kWave + i * S::TILE;
 
@@ -62,15 +68,15 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   float px[E], py[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    px[e] = b.pos[(size_t)(2 * e) * B + w];
-    py[e] = b.pos[(size_t)(2 * e + 1) * B + w];
+    px[e] = (b.pos + wave_off((size_t)(2 * e) * B + w0))[ln];
+    py[e] = (b.pos + wave_off((size_t)(2 * e + 1) * B + w0))[ln];
   }
   float mx = 0.f, my = 0.f;
 #pragma unroll
   for (int a = 0; a < A; ++a)
     if (a == i) { mx = px[a]; my = py[a]; }
-  float mvx = b.vel[(size_t)(2 * i) * B + w];
-  float mvy = b.vel[(size_t)(2 * i + 1) * B + w];
+  float mvx = (b.vel + wave_off((size_t)(2 * i) * B + w0))[ln];
+  float mvy = (b.vel + wave_off((size_t)(2 * i + 1) * B + w0))[ln];
 
   const uint64_t gw = ra.world_offset + w;  // global world number (RNG streams)
   const int T = ROLL ? ra.T : 1;
@@ -107,7 +113,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * accel_i;
       uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * accel_i;
     } else {
-      fetch_action(b, B, i, w, accel_i, ux, uy);
+      fetch_action_wave(b, B, i, w0, ln, accel_i, ux, uy);
     }
 
     // ---- World.step for agent i (core.py:117-169): action force, contacts with every other entity
@@ -127,10 +133,10 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       }
       integrate_one(mx, my, mvx, mvy, fx, fy, mass_i, maxspd_i, d.damp, d.dt);
       if (live && (!ROLL || t == T - 1)) {
-        b.pos[(size_t)(2 * i) * B + w] = mx;
-        b.pos[(size_t)(2 * i + 1) * B + w] = my;
-        b.vel[(size_t)(2 * i) * B + w] = mvx;
-        b.vel[(size_t)(2 * i + 1) * B + w] = mvy;
+        (b.pos + wave_off((size_t)(2 * i) * B + w0))[ln] = mx;
+        (b.pos + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = my;
+        (b.vel + wave_off((size_t)(2 * i) * B + w0))[ln] = mvx;
+        (b.vel + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = mvy;
       }
     }
 
@@ -153,47 +159,37 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 
     // ---- outputs of agent i for this step -----------------------------------------------------------
     float *const obs_t = b.obs + (size_t)t * obs_stride;
-    const size_t ro = (size_t)t * row_stride + (size_t)i * B + w;
+    const size_t ro = (size_t)t * row_stride + (size_t)i * B + w0;  // wave-uniform; element = [ro + ln]
     if (KIND == MPE_SCN_SIMPLE) {
-      constexpr int D = 2 + 2 * L, DP = D | 1;
-      tile[lane * DP + 0] = mvx;
-      tile[lane * DP + 1] = mvy;
+      constexpr int D = 2 + 2 * L, RS = tile_stride<D>();
+      put2<RS>(tile, lane, 0, mvx, mvy);
 #pragma unroll
-      for (int l = 0; l < L; ++l) {
-        tile[lane * DP + 2 + 2 * l] = px[A + l] - mx;
-        tile[lane * DP + 3 + 2 * l] = py[A + l] - my;
-      }
+      for (int l = 0; l < L; ++l) put2<RS>(tile, lane, 2 + 2 * l, px[A + l] - mx, py[A + l] - my);
       flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       if (live) {
         if (b.rew) {
           const float dx = mx - px[A], dy = my - py[A];
           const float sx = dx * dx, sy = dy * dy;
-          b.rew[ro] = -(sx + sy);
+          (b.rew + wave_off(ro))[ln] = -(sx + sy);
         }
-        if (b.done) b.done[ro] = 0;
+        if (b.done) (b.done + wave_off(ro))[ln] = 0;
       }
     }
     if (KIND == MPE_SCN_SPREAD) {
-      constexpr int D = 4 + 2 * L + 4 * (A - 1), DP = D | 1;
-      tile[lane * DP + 0] = mvx;
-      tile[lane * DP + 1] = mvy;
-      tile[lane * DP + 2] = mx;
-      tile[lane * DP + 3] = my;
+      constexpr int D = 4 + 2 * L + 4 * (A - 1), RS = tile_stride<D>();
+      put2<RS>(tile, lane, 0, mvx, mvy);
+      put2<RS>(tile, lane, 2, mx, my);
 #pragma unroll
-      for (int l = 0; l < L; ++l) {
-        tile[lane * DP + 4 + 2 * l] = px[A + l] - mx;
-        tile[lane * DP + 5 + 2 * l] = py[A + l] - my;
-      }
+      for (int l = 0; l < L; ++l) put2<RS>(tile, lane, 4 + 2 * l, px[A + l] - mx, py[A + l] - my);
       int k = 4 + 2 * L;  // uniform running column
 #pragma unroll
       for (int j = 0; j < A; ++j) {
         if (j == i) continue;
-        tile[lane * DP + k] = px[j] - mx;
-        tile[lane * DP + k + 1] = py[j] - my;
+        put2<RS>(tile, lane, k, px[j] - mx, py[j] - my);
         k += 2;
       }
 #pragma unroll
-      for (int z = 0; z < 2 * (A - 1); ++z) tile[lane * DP + k + z] = 0.f;
+      for (int z = 0; z < 2 * (A - 1); z += 2) put2<RS>(tile, lane, k + z, 0.f, 0.f);
       flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       if (b.rew || b.info_rew) {
         // landmark term from the published agent-landmark distances; contact counts from the new positions
@@ -204,10 +200,10 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
           float m2 = X[(0 * XW + 4 + l) * kWave + lane];  // published SQUARED distances: min first,
 #pragma unroll
           for (int a = 1; a < A; ++a) m2 = fminf(m2, X[(a * XW + 4 + l) * kWave + lane]);
-          const float m = sqrtf(m2);                      // then one correctly rounded sqrt (monotone => same value)
+          const float m = fast_sqrt(m2);                  // then one square root (monotone)
           lm_term = lm_term - m;
           md = md + m;
-          occupied += (m < 0.1f) ? 1 : 0;
+          occupied += sqrt_lt(m2, 0.1f) ? 1 : 0;          // the integer output takes the exact test
         }
         int cnt[A];
 #pragma unroll
@@ -241,48 +237,44 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         for (int a = 0; a < A; ++a)
           if (a == i) { r_own = r[a]; c_own = cnt[a]; }
         if (live) {
-          if (b.rew) b.rew[ro] = d.collaborative ? total : r_own;
+          if (b.rew) (b.rew + wave_off(ro))[ln] = d.collaborative ? total : r_own;
           if (b.info_rew) {
-            b.info_rew[ro] = r_own;
-            b.info_collisions[ro] = c_own;
-            b.info_min_dists[ro] = md;
-            b.info_occupied[ro] = occupied;
+            (b.info_rew + wave_off(ro))[ln] = r_own;
+            (b.info_collisions + wave_off(ro))[ln] = c_own;
+            (b.info_min_dists + wave_off(ro))[ln] = md;
+            (b.info_occupied + wave_off(ro))[ln] = occupied;
           }
         }
       }
-      if (b.done && live) b.done[ro] = 0;
+      if (b.done && live) (b.done + wave_off(ro))[ln] = 0;
     }
     if (KIND == MPE_SCN_TAG) {
       constexpr int NG = A - NADV;
       constexpr int DA = 4 + 2 * L + 2 * (A - 1) + 2 * NG, DG = DA - 2;
       const bool adv = i < NADV;
-      const int DP = adv ? (DA | 1) : (DG | 1);
-      tile[lane * DP + 0] = mvx;
-      tile[lane * DP + 1] = mvy;
-      tile[lane * DP + 2] = mx;
-      tile[lane * DP + 3] = my;
+      auto row = [&](auto dsel) {  // one observation row of width D (adversaries DA, good agents DG)
+        constexpr int D = decltype(dsel)::value, RS = tile_stride<D>();
+        put2<RS>(tile, lane, 0, mvx, mvy);
+        put2<RS>(tile, lane, 2, mx, my);
 #pragma unroll
-      for (int l = 0; l < L; ++l) {
-        tile[lane * DP + 4 + 2 * l] = px[A + l] - mx;
-        tile[lane * DP + 5 + 2 * l] = py[A + l] - my;
-      }
-      int k = 4 + 2 * L;
+        for (int l = 0; l < L; ++l) put2<RS>(tile, lane, 4 + 2 * l, px[A + l] - mx, py[A + l] - my);
+        int k = 4 + 2 * L;
 #pragma unroll
-      for (int j = 0; j < A; ++j) {
-        if (j == i) continue;
-        tile[lane * DP + k] = px[j] - mx;
-        tile[lane * DP + k + 1] = py[j] - my;
-        k += 2;
-      }
+        for (int j = 0; j < A; ++j) {
+          if (j == i) continue;
+          put2<RS>(tile, lane, k, px[j] - mx, py[j] - my);
+          k += 2;
+        }
 #pragma unroll
-      for (int j = NADV; j < A; ++j) {
-        if (j == i) continue;
-        tile[lane * DP + k] = X[(j * XW + 2) * kWave + lane];
-        tile[lane * DP + k + 1] = X[(j * XW + 3) * kWave + lane];
-        k += 2;
-      }
-      if (adv) flush_rows<DA>(tile, obs_t + B * obs_off_i + w0 * DA, nvalid, lane, d.vec4);
-      else     flush_rows<DG>(tile, obs_t + B * obs_off_i + w0 * DG, nvalid, lane, d.vec4);
+        for (int j = NADV; j < A; ++j) {
+          if (j == i) continue;
+          put2<RS>(tile, lane, k, X[(j * XW + 2) * kWave + lane], X[(j * XW + 3) * kWave + lane]);
+          k += 2;
+        }
+        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      };
+      if (adv) row(std::integral_constant<int, DA>{});
+      else     row(std::integral_constant<int, DG>{});
       if (b.rew || b.info_collisions) {
         bool hit[NG][NADV];
 #pragma unroll
@@ -316,11 +308,11 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
           r -= tag_bound(fabsf(my));
         }
         if (live) {
-          if (b.rew) b.rew[ro] = r;
-          if (b.info_collisions) b.info_collisions[ro] = c;
+          if (b.rew) (b.rew + wave_off(ro))[ln] = r;
+          if (b.info_collisions) (b.info_collisions + wave_off(ro))[ln] = c;
         }
       }
-      if (b.done && live) b.done[ro] = 0;
+      if (b.done && live) (b.done + wave_off(ro))[ln] = 0;
     }
   }
   if (ROLL && ra.episode_len > 0 && live) {
@@ -328,14 +320,14 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 #pragma unroll
     for (int l = 0; l < L; ++l)
       if (l % A == i) {
-        b.pos[(size_t)(2 * (A + l)) * B + w] = px[A + l];
-        b.pos[(size_t)(2 * (A + l) + 1) * B + w] = py[A + l];
+        (b.pos + wave_off((size_t)(2 * (A + l)) * B + w0))[ln] = px[A + l];
+        (b.pos + wave_off((size_t)(2 * (A + l) + 1) * B + w0))[ln] = py[A + l];
       }
     if (!movable_i) {  // an immovable agent is never integrated, but a reset did place it
-      b.pos[(size_t)(2 * i) * B + w] = mx;
-      b.pos[(size_t)(2 * i + 1) * B + w] = my;
-      b.vel[(size_t)(2 * i) * B + w] = mvx;
-      b.vel[(size_t)(2 * i + 1) * B + w] = mvy;
+      (b.pos + wave_off((size_t)(2 * i) * B + w0))[ln] = mx;
+      (b.pos + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = my;
+      (b.vel + wave_off((size_t)(2 * i) * B + w0))[ln] = mvx;
+      (b.vel + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = mvy;
     }
   }
 }

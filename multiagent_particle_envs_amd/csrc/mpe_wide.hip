@@ -1,27 +1,45 @@
-// mpe_wide.hip -- workgroup-per-world kernel for large entity counts (simple_spread N=64: 128 entities).
+// mpe_wide.hip -- wave-per-world kernel for large entity counts (simple_spread N=64: 128 entities).
 //
-// One workgroup owns one world.  The world's positions/velocities are staged once in LDS
-// ((E + A) float2 -- 1.5 KiB at N=64, a sliver of the CU's 160 KiB, so many worlds are resident per
-// CU) and everything else runs out of LDS:
-//   contacts   thread = (agent i, partner chunk q).  Pass 1 builds a bitmask of the partners that can
-//              exert a non-zero force (squared distance under (r_i + r_j + 0.02)^2: beyond that the
-//              fp32 soft-plus term is exactly 0), pass 2 evaluates only those, in ascending order.
-//              At N=64 that is ~1-5 of 32 partners per thread instead of all of them.
-//   reward     per-landmark min over agents on SQUARED distances (sqrt is monotone: one correctly
-//              rounded sqrt per landmark afterwards gives the same value as min over sqrt's), per-agent
-//              contact counts with the exact sqrt_lt test, partials combined through LDS, the sums by
-//              wave64 shuffle reductions.
-//   obs        98 % of the kernel's HBM bytes (A rows x D floats: 98 KiB per world at N=64).  Rows are
-//              computed straight from LDS in output order: consecutive lanes write consecutive 16-byte
-//              pieces of a row, consecutive waves consecutive KiB, so each row (1536 B) is one short
-//              sequential burst -- the order HBM rewards (see the note at the store loop).
-// Per pair the arithmetic is mpe_device.h's, as in the thread-per-world kernels; partial sums are
-// regrouped by partner chunk / reduction tree (documented in DESIGN.md 4).
+// One WAVE owns one world; lane = agent (agents lane, lane+64, ... when A > 64).  The world's
+// positions and velocities are staged once in a wave-private LDS block (2 KiB at N=64) and every
+// phase of the step runs out of it with no workgroup barrier at all -- the only synchronisation is
+// the wave's own program order plus LDS fences.  A 256-thread workgroup is four independent waves
+// (four consecutive worlds) that merely share the per-entity constant table.
+//
+// Why a wave and not a workgroup per world (the first version): with a workgroup per world every
+// phase ends in __syncthreads and all co-resident workgroups run their phases in lock-step, so the
+// physics (latency-bound, ~40 us at B=4096) and the observation stores (~90 us) added up.  A wave
+// per world has no barriers, four to eight worlds per SIMD slide against each other, and the whole
+// batch is resident at once: the kernel is the store stream plus one world's latency.
+//
+//   contacts   lane i, two passes over the collidable entities (ascending): pass 1 marks
+//              the partners close enough to exert a non-zero force (squared distance under
+//              (r_i + r_j + 20k)^2: beyond it the fp32 soft-plus term is exactly 0) in a 64-bit mask,
+//              pass 2 evaluates only those.  ~4 of 63 partners at N=64.
+//   obs        98 % of the HBM bytes (A rows x D floats = 98 KiB per world at N=64).  Rows are
+//              computed straight from LDS in output order: consecutive lanes write consecutive
+//              16-byte pieces of a row, a full 1 KiB per wave store.
+//   reward     lane l: min over agents of the SQUARED distance to landmark l (sqrt is monotone: one
+//              sqrt per landmark afterwards), lane i: contact count of agent i with the exact
+//              sqrt_lt test; sums by wave64 shuffle reductions.
+// State loads are 4-byte accesses 4*B bytes apart (the SoA layout is batch-innermost), so a 128-byte
+// line serves 32 neighbouring worlds: the world -> workgroup map keeps each such group of worlds on
+// ONE XCD (blockIdx % 8 selects the XCD), so that the line is fetched into one L2, not eight.
+// Per pair the arithmetic is mpe_device.h's, as in the small-N kernels; sums over landmarks / agents
+// are reduction trees (documented in DESIGN.md 4).
 #include <cstdlib>
 
 #include "mpe_internal.h"
 
 namespace mpe {
+
+namespace {
+
+constexpr int kWavesPerWg = 4;
+constexpr int kMovable = 1, kCollide = 2;
+// Beyond dist_min + kFarX * contact_margin the fp32 soft-plus term is exactly zero:
+// x = (dist_min - d)/k < -16.64 => 1 + exp(x) rounds to 1 => log = 0 => penetration = 0 => force +-0.
+constexpr float kFarX = 20.0f;
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -33,378 +51,300 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
   return v;
 }
-
-struct WideLds {  // carve-up of the dynamic LDS block (all offsets multiples of 16 bytes)
-  float2 *pos, *vel, *u, *part;
-  float *size, *inv_mass, *maxspd, *lmin, *lpart;
-  int *flags, *cnt, *cpart;
-  float *red;
-};
+// order LDS traffic between lanes of this wave (no workgroup barrier anywhere in this file)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-__host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 
-// partial-result slots: Q partner chunks per agent (forces), Qr agent chunks per landmark (min
-// distance), Qc agent chunks per agent (contact counts) -- all "threads / items", at least 1
-struct WideSplit { int Q, Qr, Qc; };
-__host__ __device__ inline WideSplit wide_split(int A, int L, int nthr) {
-  WideSplit s;
-  s.Q = imax(1, nthr / A);
-  s.Qr = imax(1, nthr / imax(L, 1));
-  s.Qc = imax(1, nthr / A);
-  return s;
-}
-
-__host__ __device__ inline size_t wide_lds_bytes(int A, int L, int nthr) {
+// LDS carve-up.  Shared by the workgroup (constants, staged once): sizeq, cpart, agent constants.
+// Private to each wave: the world.  Positions sit in OBSERVATION order
+//   Q = [ landmark 0 .. L-1 | agent 0 .. A-1 ]
+// so that the observation row of agent i is  Q[idx + (idx >= L+i)] - Q[L+i]  for idx = 0 .. L+A-2.
+struct Carve {
+  size_t sizeq, cpart, aconst, shared_bytes;  // shared block offsets
+  size_t q, v, u, qn, wave_bytes;             // per-wave block offsets (relative to the wave's base)
+};
+__host__ __device__ inline Carve carve(int A, int L) {
   const int E = A + L;
-  const WideSplit sp = wide_split(A, L, nthr);
-  size_t n = 0;
-  n += align16(sizeof(float2) * E);            // pos
-  n += align16(sizeof(float2) * A);            // vel
-  n += align16(sizeof(float2) * A);            // u
-  n += align16(sizeof(float2) * A * sp.Q);     // partial forces
-  n += align16(sizeof(float) * E);             // size
-  n += align16(sizeof(float) * A);             // inverse mass
-  n += align16(sizeof(float) * A);             // max_speed
-  n += align16(sizeof(float) * imax(L, 1));    // per-landmark min distance
-  n += align16(sizeof(float) * imax(L, 1) * sp.Qr);  // partial min of squared distances
-  n += align16(sizeof(int) * E);               // flags
-  n += align16(sizeof(int) * A);               // counts
-  n += align16(sizeof(int) * A * sp.Qc);       // partial counts
-  n += align16(sizeof(float) * 8);             // reduction results
-  return n;
-}
-
-__device__ inline WideLds carve(char *base, int A, int L, int nthr) {
-  const int E = A + L;
-  const WideSplit sp = wide_split(A, L, nthr);
-  WideLds s;
+  Carve c;
   size_t o = 0;
-  s.pos = reinterpret_cast<float2 *>(base + o); o += align16(sizeof(float2) * E);
-  s.vel = reinterpret_cast<float2 *>(base + o); o += align16(sizeof(float2) * A);
-  s.u = reinterpret_cast<float2 *>(base + o); o += align16(sizeof(float2) * A);
-  s.part = reinterpret_cast<float2 *>(base + o); o += align16(sizeof(float2) * A * sp.Q);
-  s.size = reinterpret_cast<float *>(base + o); o += align16(sizeof(float) * E);
-  s.inv_mass = reinterpret_cast<float *>(base + o); o += align16(sizeof(float) * A);
-  s.maxspd = reinterpret_cast<float *>(base + o); o += align16(sizeof(float) * A);
-  s.lmin = reinterpret_cast<float *>(base + o); o += align16(sizeof(float) * imax(L, 1));
-  s.lpart = reinterpret_cast<float *>(base + o); o += align16(sizeof(float) * imax(L, 1) * sp.Qr);
-  s.flags = reinterpret_cast<int *>(base + o); o += align16(sizeof(int) * E);
-  s.cnt = reinterpret_cast<int *>(base + o); o += align16(sizeof(int) * A);
-  s.cpart = reinterpret_cast<int *>(base + o); o += align16(sizeof(int) * A * sp.Qc);
-  s.red = reinterpret_cast<float *>(base + o);
-  return s;
+  c.sizeq = o;  o += align16(sizeof(float) * E);       // Entity.size by Q index
+  c.cpart = o;  o += align16(sizeof(int2) * E);        // collidable entities: (Q index, size bits), ascending entity order
+  c.aconst = o; o += align16(sizeof(float4) * A);      // per agent: (1/mass, max_speed, sensitivity, flags)
+  c.shared_bytes = o;
+  o = 0;
+  c.q = o;  o += align16(sizeof(float2) * E);
+  c.v = o;  o += align16(sizeof(float2) * A);
+  c.u = o;  o += align16(sizeof(float2) * A);          // action force; later the contact counts
+  c.qn = o; o += align16(sizeof(float2) * (A > kWave ? A : 0));  // new positions while A > 64 agents integrate in batches
+  c.wave_bytes = o;
+  return c;
 }
 
-constexpr int kMovable = 1, kCollide = 2;
-constexpr int kPF = 2;  // entities prefetched per thread => E <= kPF * blockDim
-// Beyond dist_min + kFarMargin the fp32 soft-plus term is exactly zero: x = (dist_min - d)/k < -16.64
-// => 1 + exp(x) rounds to 1 => log = 0 => penetration = 0 => force = +-0 (k = 1e-3 => 0.01664; the
-// margin is scaled by k/1e-3 on the host side of the comparison below).
-constexpr float kFarX = 20.0f;  // in units of contact_margin
-
-// observation element pair kp (floats 2kp, 2kp+1) of agent i's row -- simple_spread.py:84-100:
-// [vel_i | pos_i | landmark_l - pos_i ... | pos_j - pos_i (j != i, ascending) ... | zeros]
-__device__ __forceinline__ float2 spread_pair(const WideLds &s, int A, int L, int i, int kp, float2 me) {
-  if (kp >= 2 + L + (A - 1)) return make_float2(0.f, 0.f);
-  if (kp == 0) return s.vel[i];
-  if (kp == 1) return me;
-  int src;
-  if (kp < 2 + L) src = A + (kp - 2);
-  else { const int jj = kp - 2 - L; src = jj + (jj >= i ? 1 : 0); }
-  const float2 p = s.pos[src];
-  return make_float2(p.x - me.x, p.y - me.y);
-}
-
-__device__ __forceinline__ bool getenv_world_major(const WideDesc &d) { return d.obs_world_major != 0; }
-
-template <bool PHYS, bool OUT>
-__global__ void k_wide(const WideDesc d, const MpeBuffers b, const size_t B) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int A = d.A, L = d.L, E = A + L;
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & (kWave - 1), wave = tid >> 6;
-  const WideLds s = carve(smem, A, L, nthr);
-  const WideSplit sp = wide_split(A, L, nthr);
-  const float *tab = b.entity_table;  // [6][E]: size, mass, accel, max_speed, movable, collide
-
-  // per-entity constants: staged once per workgroup (the workgroup then walks over several worlds)
-  for (int e = tid; e < E; e += nthr) {
-    s.size[e] = tab[0 * E + e];
-    s.flags[e] = (tab[4 * E + e] != 0.f ? kMovable : 0) | (tab[5 * E + e] != 0.f ? kCollide : 0);
-  }
-  for (int i = tid; i < A; i += nthr) {
-    s.inv_mass[i] = 1.0f / tab[1 * E + i];
-    s.maxspd[i] = tab[3 * E + i];
-  }
-
-  // Persistent workgroup: worlds w = blockIdx.x, + gridDim.x, ...  The next world's state and action
-  // rows are fetched into registers (entity e = tid + k*nthr, k < kPF) while this world's
-  // observation rows are being stored; stores are fire-and-forget, so a world's 98 KiB drain while
-  // the next world's contacts are computed.
-  float2 npos[kPF], nvel[kPF], nu[kPF];
-  float sens[kPF];
+// One world's observation rows (simple_spread.py:84-100), row by row:
+//   row i = [vel_i | pos_i | landmark_l - pos_i ... | pos_j - pos_i (j != i, ascending) ... | zeros]
+//         = [vel_i | pos_i | Q[idx + (idx >= L+i)] - Q[L+i]  for idx = 0 .. L+A-2 | zeros]
+// The row index is wave-uniform, so the row base address, pos_i, vel_i and the self-skip threshold
+// live in scalar registers / broadcast LDS reads, and a lane's share of the row -- pieces
+// lane, lane+64, ... of VEC floats -- costs two LDS reads, four subtractions and one store per piece
+// with no per-lane address arithmetic: consecutive lanes write consecutive pieces, 1 KiB (VEC = 4) per
+// wave store.  Wave-pieces that lie entirely in the zero tail skip the LDS reads.
+template <int VEC>
+__device__ __forceinline__ void emit_rows(const float2 *Q, const float2 *V, int A, int L, int D,
+                                          float *obs_w, size_t rowlen, int lane) {
+  constexpr int PP = VEC / 2;       // (x, y) pairs per piece
+  const int E = A + L;
+  const int P = D / VEC;            // pieces per row
+  const int kpz = 2 + L + (A - 1);  // first all-zero pair
+  const int K = (P + kWave - 1) / kWave;
+  float2 me = Q[L], vel = V[0];
+  for (int i = 0; i < A; ++i) {
+    const int thr = L + i;
+    float *const row = obs_w + (size_t)i * rowlen;  // wave-uniform
+    const int inext = min(i + 1, A - 1);
+    const float2 me_n = Q[L + inext], vel_n = V[inext];  // next row's operands: in flight under this row
+    for (int k = 0; k < K; ++k) {
+      const int p = lane + kWave * k;
+      float o[VEC];
+      if (PP * kWave * k >= kpz) {  // uniform: the whole wave-piece is zero tail
 #pragma unroll
-  for (int k = 0; k < kPF; ++k) {
-    const int e = tid + k * nthr;
-    sens[k] = (PHYS && e < A) ? tab[2 * E + e] : 0.f;
-    npos[k] = nvel[k] = nu[k] = make_float2(0.f, 0.f);
-  }
-  auto prefetch = [&](size_t wn) {
+        for (int m = 0; m < VEC; ++m) o[m] = 0.f;
+      } else {
+        const bool tail = PP * kWave * (k + 1) > kpz;  // uniform: some lanes reach the zero tail
 #pragma unroll
-    for (int k = 0; k < kPF; ++k) {
-      const int e = tid + k * nthr;
-      if (e < E) npos[k] = make_float2(b.pos[(size_t)(2 * e) * B + wn], b.pos[(size_t)(2 * e + 1) * B + wn]);
-      if (e < A) {
-        nvel[k] = make_float2(b.vel[(size_t)(2 * e) * B + wn], b.vel[(size_t)(2 * e + 1) * B + wn]);
-        if (PHYS) {  // decode actions (environment.py:144-181)
-          float ux, uy;
-          fetch_action(b, B, e, wn, sens[k], ux, uy);
-          nu[k] = make_float2(ux + 0.f, uy + 0.f);
+        for (int h = 0; h < PP; ++h) {
+          const int kp = PP * p + h;
+          const int idx = kp - 2;
+          int sidx = idx + (idx >= thr ? 1 : 0);
+          if (k == 0) sidx = max(sidx, 0);
+          if (tail) sidx = min(sidx, E - 1);
+          const float2 pj = Q[sidx];
+          float2 v = make_float2(pj.x - me.x, pj.y - me.y);
+          if (tail && kp >= kpz) v = make_float2(0.f, 0.f);
+          o[2 * h] = v.x;
+          o[2 * h + 1] = v.y;
+        }
+        if (k == 0) {  // the row's header
+          if (VEC == 4) {
+            if (p == 0) { o[0] = vel.x; o[1] = vel.y; o[2] = me.x; o[3] = me.y; }
+          } else {
+            if (p == 0) { o[0] = vel.x; o[1] = vel.y; }
+            if (p == 1) { o[0] = me.x; o[1] = me.y; }
+          }
         }
       }
+      if (p < P) {
+        if (VEC == 4) *reinterpret_cast<float4 *>(row + (unsigned)(4 * p)) = make_float4(o[0], o[1], o[2], o[3]);
+        else          *reinterpret_cast<float2 *>(row + (unsigned)(2 * p)) = make_float2(o[0], o[1]);
+      }
     }
-  };
-  size_t w = blockIdx.x;
-  if (w < B) prefetch(w);
-  if (d.stagger > 0) {  // experiment: break the phase lockstep of co-resident workgroups
-    const int gen = (int)(blockIdx.x >> 8) & 7;   // dispatch round on a 256-CU part
-    for (int k = 0; k < gen * d.stagger; ++k) __builtin_amdgcn_s_sleep(127);
+    me = me_n;
+    vel = vel_n;
   }
+}
 
-  for (; w < B; w += gridDim.x) {
-  // ---- commit the prefetched world to LDS ------------------------------------------------------------
-#pragma unroll
-  for (int k = 0; k < kPF; ++k) {
-    const int e = tid + k * nthr;
-    if (e < E) s.pos[e] = npos[k];
-    if (e < A) {
-      s.vel[e] = nvel[k];
-      if (PHYS) s.u[e] = nu[k];
+template <bool PHYS, bool OUT>
+__global__ void __launch_bounds__(kWavesPerWg *kWave)
+k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_groups_padded) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int A = d.A, L = d.L, E = A + L;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Carve cv = carve(A, L);
+  float *const sizeq = reinterpret_cast<float *>(smem + cv.sizeq);
+  int2 *const cpart = reinterpret_cast<int2 *>(smem + cv.cpart);
+  float4 *const aconst = reinterpret_cast<float4 *>(smem + cv.aconst);
+  char *const wbase = smem + cv.shared_bytes + (size_t)wave * cv.wave_bytes;
+  float2 *const Q = reinterpret_cast<float2 *>(wbase + cv.q);
+  float2 *const V = reinterpret_cast<float2 *>(wbase + cv.v);
+  float2 *const U = reinterpret_cast<float2 *>(wbase + cv.u);
+  int *const CNT = reinterpret_cast<int *>(wbase + cv.u);
+  float2 *const QN = A > kWave ? reinterpret_cast<float2 *>(wbase + cv.qn) : Q + L;
+
+  // ---- per-entity constants: staged once per workgroup, the only __syncthreads of the kernel ------
+  const float *tab = b.entity_table;  // [6][E]: size, mass, accel, max_speed, movable, collide
+  for (int e = tid; e < E; e += blockDim.x) sizeq[e < A ? L + e : e - A] = tab[0 * E + e];
+  for (int i = tid; i < A; i += blockDim.x) {
+    const int fl = (tab[4 * E + i] != 0.f ? kMovable : 0) | (tab[5 * E + i] != 0.f ? kCollide : 0);
+    aconst[i] = make_float4(1.0f / tab[1 * E + i], tab[3 * E + i], tab[2 * E + i], __int_as_float(fl));
+  }
+  if (tid < kWave) {  // compact the collidable entities in ascending entity order (wave 0: ballot + prefix count)
+    int n = 0;
+    for (int e0 = 0; e0 < E; e0 += kWave) {
+      const int e = e0 + lane;
+      const bool c = e < E && tab[5 * E + e] != 0.f;
+      const unsigned long long m = __ballot(c);
+      if (c) {
+        const int k = n + __popcll(m & ((1ull << lane) - 1ull));
+        cpart[k] = make_int2(e < A ? L + e : e - A, __float_as_int(tab[0 * E + e]));
+      }
+      n += __popcll(m);
     }
   }
+  // number of collidable entities: uniform, recomputed by every wave from the table (E/64 loads)
+  int nC = 0;
+  for (int e0 = 0; e0 < E; e0 += kWave) {
+    const int e = e0 + lane;
+    nC += __popcll(__ballot(e < E && tab[5 * E + e] != 0.f));
+  }
+  nC = __builtin_amdgcn_readfirstlane(nC);
   __syncthreads();
 
-  if (PHYS) {
-    // ---- pairwise contact force (core.py:143-155,180-196): agent i x partner chunk q ------------
-    const int Q = sp.Q;
-    const int CS = (E + Q - 1) / Q;
-    const float far = kFarX * d.cmargin;
-    for (int item = tid; item < A * Q; item += nthr) {
-      const int i = item % A, q = item / A;
-      float ax = 0.f, ay = 0.f;
-      const int fi = s.flags[i];
-      if ((fi & kCollide) && (fi & kMovable)) {
-        const float2 me = s.pos[i];
-        const float ri = s.size[i];
-        const int j1 = min(E, (q + 1) * CS);
-        for (int jb = q * CS; jb < j1; jb += 64) {
-          const int je = min(j1, jb + 64);
+  const float far = kFarX * d.cmargin;
+  const int D = d.D;
+
+  // ---- persistent loop over groups of kWavesPerWg consecutive worlds ------------------------------
+  // x -> group: XCD = x % 8 (hardware round-robin), slot = x / 8;  eight consecutive slots of one XCD
+  // own eight consecutive groups (32 worlds = one 128-byte line of every state row).
+  for (unsigned x = blockIdx.x; x < n_groups_padded; x += gridDim.x) {
+    const unsigned xcd = x & 7u, slot = x >> 3;
+    const unsigned g = ((slot >> 3) << 6) | (xcd << 3) | (slot & 7u);
+    const size_t w = (size_t)g * kWavesPerWg + wave;
+    if (w >= B) continue;  // wave-uniform
+
+    // ---- stage the world -----------------------------------------------------------------------
+    for (int e = lane; e < E; e += kWave)
+      Q[e < A ? L + e : e - A] = make_float2(b.pos[(size_t)(2 * e) * B + w], b.pos[(size_t)(2 * e + 1) * B + w]);
+    for (int i = lane; i < A; i += kWave) {
+      V[i] = make_float2(b.vel[(size_t)(2 * i) * B + w], b.vel[(size_t)(2 * i + 1) * B + w]);
+      if (PHYS) {  // decode actions (environment.py:144-181)
+        float ux, uy;
+        fetch_action(b, B, i, w, aconst[i].z, ux, uy);
+        U[i] = make_float2(ux + 0.f, uy + 0.f);
+      }
+    }
+    wave_sync();
+
+    if (PHYS) {
+      // ---- pairwise contact force (core.py:143-155,180-196) + integrate (core.py:158-169) -----------
+      for (int i0 = 0; i0 < A; i0 += kWave) {
+        const int i = i0 + lane;
+        const bool have = i < A;
+        const float4 ac = aconst[have ? i : 0];
+        const int fi = have ? __float_as_int(ac.w) : 0;
+        const float2 me = Q[L + (have ? i : 0)];
+        const float ri = sizeq[L + (have ? i : 0)];
+        const float2 u = U[have ? i : 0];
+        float ax = u.x, ay = u.y;  // action force first, then the partners in ascending order (Q9)
+        const bool pushes = (fi & kCollide) && (fi & kMovable);
+        for (int kb = 0; kb < nC; kb += 64) {
+          const int ke = min(nC, kb + 64);
           unsigned long long near = 0ull;
-          for (int j = jb; j < je; ++j) {  // pass 1: who is close enough to push at all
-            if (j == i || !(s.flags[j] & kCollide)) continue;
-            const float2 pj = s.pos[j];
-            const float reach = ri + s.size[j] + far;
-            if (sq2d(me.x - pj.x, me.y - pj.y) < reach * reach) near |= 1ull << (j - jb);
+#pragma unroll 8
+          for (int k = kb; k < ke; ++k) {  // pass 1: who is close enough to push at all (uniform k: broadcast reads)
+            const int2 cp = cpart[k];
+            const float2 pj = Q[cp.x];
+            const float reach = ri + __int_as_float(cp.y) + far;
+            const bool hit = sq2d(me.x - pj.x, me.y - pj.y) < reach * reach && cp.x != L + i;
+            near |= hit ? (1ull << (k - kb)) : 0ull;
           }
+          if (!pushes) near = 0ull;
           while (near) {  // pass 2: those only, ascending (Q9)
-            const int j = jb + __ffsll((long long)near) - 1;
+            const int k = kb + __ffsll((long long)near) - 1;
             near &= near - 1;
-            const float2 pj = s.pos[j];
+            const int2 cp = cpart[k];
+            const float2 pj = Q[cp.x];
             float gx, gy;
-            contact_force(me.x - pj.x, me.y - pj.y, ri + s.size[j], d.cforce, d.cmargin, d.cmargin_inv, gx, gy);
+            contact_force(me.x - pj.x, me.y - pj.y, ri + __int_as_float(cp.y), d.cforce, d.cmargin, d.cmargin_inv, gx, gy);
             ax = gx + ax;
             ay = gy + ay;
           }
         }
-      }
-      s.part[q * A + i] = make_float2(ax, ay);
-    }
-    __syncthreads();
-    // ---- integrate (core.py:158-169) ----------------------------------------------------------
-    for (int i = tid; i < A; i += nthr) {
-      if (!(s.flags[i] & kMovable)) continue;
-      float2 f = s.u[i];
-      for (int q = 0; q < Q; ++q) {
-        const float2 p = s.part[q * A + i];
-        f.x = p.x + f.x;
-        f.y = p.y + f.y;
-      }
-      float2 p = s.pos[i], v = s.vel[i];
-      integrate_one(p.x, p.y, v.x, v.y, f.x, f.y, s.inv_mass[i], s.maxspd[i], d.damp, d.dt);
-      s.pos[i] = p;
-      s.vel[i] = v;
-      b.pos[(size_t)(2 * i) * B + w] = p.x;
-      b.pos[(size_t)(2 * i + 1) * B + w] = p.y;
-      b.vel[(size_t)(2 * i) * B + w] = v.x;
-      b.vel[(size_t)(2 * i + 1) * B + w] = v.y;
-    }
-    __syncthreads();
-  }
-
-  if (OUT) {
-  // ---- reward (simple_spread.py:72-82) -----------------------------------------------------------
-  if (b.rew || b.info_rew) {
-    {  // partial min over an agent chunk of the squared distance to landmark l
-      const int Qr = sp.Qr, CA = (A + Qr - 1) / Qr;
-      for (int item = tid; item < L * Qr; item += nthr) {
-        const int l = item % L, q = item / L;
-        const float2 pl = s.pos[A + l];
-        float m2 = INFINITY;
-        const int a1 = min(A, (q + 1) * CA);
-        for (int a = q * CA; a < a1; ++a) {
-          const float2 pa = s.pos[a];
-          m2 = fminf(m2, sq2d(pa.x - pl.x, pa.y - pl.y));
+        if (have && (fi & kMovable)) {
+          float2 p = me, v = V[i];
+          integrate_one(p.x, p.y, v.x, v.y, ax, ay, ac.x, ac.y, d.damp, d.dt);
+          QN[i] = p;
+          V[i] = v;
+          b.pos[(size_t)(2 * i) * B + w] = p.x;
+          b.pos[(size_t)(2 * i + 1) * B + w] = p.y;
+          b.vel[(size_t)(2 * i) * B + w] = v.x;
+          b.vel[(size_t)(2 * i + 1) * B + w] = v.y;
+        } else if (have && A > kWave) {
+          QN[i] = me;
         }
-        s.lpart[q * L + l] = m2;
+      }
+      wave_sync();
+      if (A > kWave) {  // batches integrated against the OLD positions; publish the new ones now
+        for (int i = lane; i < A; i += kWave) Q[L + i] = QN[i];
+        wave_sync();
       }
     }
-    {  // partial contact count of agent i against an agent chunk (includes i itself)
-      const int Qc = sp.Qc, CA = (A + Qc - 1) / Qc;
-      for (int item = tid; item < A * Qc; item += nthr) {
-        const int i = item % A, q = item / A;
-        const float2 pi = s.pos[i];
-        const float ri = s.size[i];
-        int c = 0;
-        const int a1 = min(A, (q + 1) * CA);
-        for (int a = q * CA; a < a1; ++a) {
-          const float2 pa = s.pos[a];
-          c += sqrt_lt(sq2d(pa.x - pi.x, pa.y - pi.y), s.size[a] + ri) ? 1 : 0;
+
+    if (OUT) {
+      // ---- observation rows (simple_spread.py:84-100): issued first, they drain while the reward is computed
+      const bool world_major = d.obs_world_major != 0;
+      const size_t rowlen = world_major ? (size_t)D : (size_t)B * D;
+      float *const obs_w = b.obs + (world_major ? w * (size_t)A * D : w * (size_t)D);
+      if ((D & 3) == 0 && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && (world_major || ((B * (size_t)D) & 3) == 0))
+        emit_rows<4>(Q, V, A, L, D, obs_w, rowlen, lane);
+      else
+        emit_rows<2>(Q, V, A, L, D, obs_w, rowlen, lane);  // D is even (checked on the host)
+
+      // ---- reward (simple_spread.py:72-82) + benchmark_data (:47-63) --------------------------------
+      if (b.rew || b.info_rew) {
+        float neg = 0.f, csum = 0.f;
+        int occ = 0;
+        const int nb = (max(A, L) + kWave - 1) / kWave;
+        for (int k0 = 0; k0 < nb; ++k0) {
+          const int t = k0 * kWave + lane;
+          const bool hl = t < L, hi = t < A;
+          const float2 pl = Q[hl ? t : 0];          // landmark t
+          const float2 pi = Q[L + (hi ? t : 0)];    // agent t
+          const float ri = sizeq[L + (hi ? t : 0)];
+          float m2 = INFINITY;
+          int c = 0;
+#pragma unroll 4
+          for (int a = 0; a < A; ++a) {  // uniform a: broadcast reads
+            const float2 pa = Q[L + a];
+            m2 = fminf(m2, sq2d(pa.x - pl.x, pa.y - pl.y));
+            c += sqrt_lt(sq2d(pa.x - pi.x, pa.y - pi.y), sizeq[L + a] + ri) ? 1 : 0;  // includes a == t
+          }
+          if (hl) {
+            neg = neg - fast_sqrt(m2);
+            occ += sqrt_lt(m2, 0.1f) ? 1 : 0;
+          }
+          if (hi) {
+            c = (__float_as_int(aconst[t].w) & kCollide) ? c : 0;
+            CNT[t] = c;
+            csum += (float)c;
+          }
         }
-        s.cpart[q * A + i] = c;
+        neg = wave_sum(neg);
+        occ = wave_sum_i(occ);
+        csum = wave_sum(csum);
+        const float tot = (float)A * neg - csum;  // environment.py:100-102: sum over agents of (neg - count_i)
+        wave_sync();
+        for (int i = lane; i < A; i += kWave) {
+          const int c = CNT[i];
+          const float r = neg - (float)c;
+          if (b.rew) b.rew[(size_t)i * B + w] = d.collaborative ? tot : r;
+          if (b.done) b.done[(size_t)i * B + w] = 0;
+          if (b.info_rew) {
+            b.info_rew[(size_t)i * B + w] = r;
+            b.info_collisions[(size_t)i * B + w] = c;
+            b.info_min_dists[(size_t)i * B + w] = -neg;
+            b.info_occupied[(size_t)i * B + w] = occ;
+          }
+        }
+      } else if (b.done) {
+        for (int i = lane; i < A; i += kWave) b.done[(size_t)i * B + w] = 0;
       }
     }
-    __syncthreads();
-    for (int l = tid; l < L; l += nthr) {
-      float m2 = s.lpart[l];
-      for (int q = 1; q < sp.Qr; ++q) m2 = fminf(m2, s.lpart[q * L + l]);
-      s.lmin[l] = sqrtf(m2);  // == min over agents of the rounded distances
-    }
-    for (int i = tid; i < A; i += nthr) {
-      int c = 0;
-      for (int q = 0; q < sp.Qc; ++q) c += s.cpart[q * A + i];
-      s.cnt[i] = (s.flags[i] & kCollide) ? c : 0;
-    }
-    __syncthreads();
-    if (wave == 0) {
-      float neg = 0.f;
-      int occ = 0;
-      for (int l = lane; l < L; l += kWave) {
-        const float m = s.lmin[l];
-        neg = neg - m;
-        occ += (m < 0.1f) ? 1 : 0;
-      }
-      neg = wave_sum(neg);
-      occ = wave_sum_i(occ);
-      float tot = 0.f;
-      for (int i = lane; i < A; i += kWave) {
-        float r = neg;
-        const int c = s.cnt[i];
-        for (int k = 0; k < c; ++k) r = r - 1.f;
-        tot += r;
-      }
-      tot = wave_sum(tot);
-      if (lane == 0) {
-        s.red[0] = neg;
-        s.red[1] = tot;
-        s.red[2] = __int_as_float(occ);
-      }
-    }
-    __syncthreads();
-    const float neg = s.red[0], tot = s.red[1];
-    const int occ = __float_as_int(s.red[2]);
-    for (int i = tid; i < A; i += nthr) {
-      float r = neg;
-      const int c = s.cnt[i];
-      for (int k = 0; k < c; ++k) r = r - 1.f;
-      if (b.rew) b.rew[(size_t)i * B + w] = d.collaborative ? tot : r;
-      if (b.done) b.done[(size_t)i * B + w] = 0;
-      if (b.info_rew) {
-        b.info_rew[(size_t)i * B + w] = r;
-        b.info_collisions[(size_t)i * B + w] = c;
-        b.info_min_dists[(size_t)i * B + w] = -neg;
-        b.info_occupied[(size_t)i * B + w] = occ;
-      }
-    }
-  } else if (b.done) {
-    for (int i = tid; i < A; i += nthr) b.done[(size_t)i * B + w] = 0;
-  }
-
-  // next world's loads go out now and complete under the store loop below
-  if (w + gridDim.x < B) prefetch(w + gridDim.x);
-
-  // ---- observation rows (simple_spread.py:84-100) ---------------------------------------------
-  const int D = d.D;
-  // agent-major (default): agent i's rows form one [B][D] block => rows of one world are B*D apart;
-  // world-major: one world's A rows are contiguous ([B][A][D])
-  const bool world_major = getenv_world_major(d);
-  const size_t rowlen = world_major ? (size_t)D : (size_t)B * D;
-  float *const obs_w = b.obs + (world_major ? w * (size_t)A * D : w * (size_t)D);
-  if ((D & 3) == 0 && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0) {
-    // Flat order: consecutive lanes write consecutive 16-byte pieces of a row and consecutive waves
-    // consecutive KiB, rows in order -- every row is completed within one sweep of the workgroup.
-    // (Measured on MI355X, N=64, B=4096: 83 us for the 403 MB of rows vs 118 us when the same bytes
-    // are written region by region with cheaper per-thread operands: HBM wants the sequential stream.)
-    const int Dq = D >> 2;                     // 16-byte columns per row
-    const int kpz = 2 + L + (A - 1);           // first all-zero pair
-    int i = tid / Dq, q4 = tid - i * Dq;       // one division per thread, then incremental
-    const int di = nthr / Dq, dq = nthr - di * Dq;
-    for (; i < A;) {
-      const float2 me = s.pos[i];
-      float2 o[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int kp = 2 * q4 + h;
-        // source entity of pair kp: landmark kp-2, or other agent jj = kp-2-L shifted past i
-        const int jj = kp - 2 - L;
-        int src = kp < 2 + L ? A + (kp - 2) : jj + (jj >= i ? 1 : 0);
-        src = min(max(src, 0), E - 1);
-        const float2 p = s.pos[src];
-        float2 v = make_float2(p.x - me.x, p.y - me.y);
-        if (kp == 0) v = s.vel[i];
-        if (kp == 1) v = me;
-        if (kp >= kpz) v = make_float2(0.f, 0.f);
-        o[h] = v;
-      }
-      *reinterpret_cast<float4 *>(obs_w + i * rowlen + 4 * q4) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
-      i += di;
-      q4 += dq;
-      if (q4 >= Dq) { q4 -= Dq; ++i; }
-    }
-  } else {
-    const int Dp = D >> 1;  // D is even when dim_c is (checked on the host)
-    const float inv = 1.0f / (float)Dp;
-    const int total = A * Dp;
-    for (int idx = tid; idx < total; idx += nthr) {
-      const int i = (int)(((float)idx + 0.5f) * inv);  // exact: |err| << 0.5/Dp for idx < 2^20
-      const int kp = idx - i * Dp;
-      const float2 v = spread_pair(s, A, L, i, kp, s.pos[i]);
-      float *g = obs_w + i * rowlen + 2 * kp;
-      g[0] = v.x;
-      g[1] = v.y;
-    }
-  }
-  } else if (w + gridDim.x < B) {
-    prefetch(w + gridDim.x);
-  }
-  __syncthreads();  // every LDS read of this world is done before the next one is committed
+    wave_sync();  // every LDS read of this world is done before the next one is staged
   }
 }
+
+}  // namespace
 
 int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream) {
   if (out && d.kind != MPE_SCN_SPREAD) return MPE_EUNSUPPORTED;
   if (out && (d.dim_c != 2 || (d.D & 1))) return MPE_EUNSUPPORTED;
-  const int A = d.A;
-  int nthr = A >= 48 ? 256 : A >= 24 ? 128 : 64;
-  while (nthr * kPF < d.A + d.L) nthr *= 2;   // register prefetch covers kPF entities per thread
-  if (const char *e = std::getenv("MPE_WIDE_NTHR")) nthr = std::atoi(e);  // tuning experiment switch
-  if (nthr > 1024 || nthr * kPF < d.A + d.L) return MPE_EUNSUPPORTED;
-  const size_t lds = wide_lds_bytes(d.A, d.L, nthr);
+  const Carve cv = carve(d.A, d.L);
+  const size_t lds = cv.shared_bytes + kWavesPerWg * cv.wave_bytes;
   if (lds > 64 * 1024) return MPE_EUNSUPPORTED;
-  // persistent grid: enough workgroups to fill every CU (256 CUs x 2048 threads on MI355X), each
-  // walking over worlds blockIdx.x, + gridDim.x, ...
-  int bpc = 2048 / nthr;
-  if (const char *e = std::getenv("MPE_WIDE_BPC")) bpc = std::atoi(e);
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0, v = 0;
@@ -412,11 +352,21 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
         hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
     else n_cu = 256;
   }
-  const size_t want = (size_t)n_cu * (size_t)(bpc > 0 ? bpc : 1);
-  const dim3 grid((unsigned)(B < want ? B : want)), block(nthr);
-  if (phys && out) hipLaunchKernelGGL((k_wide<true, true>), grid, block, lds, stream, d, b, B);
-  else if (phys) hipLaunchKernelGGL((k_wide<true, false>), grid, block, lds, stream, d, b, B);
-  else hipLaunchKernelGGL((k_wide<false, true>), grid, block, lds, stream, d, b, B);
+  // groups of kWavesPerWg worlds, padded to whole 64-group blocks so that the XCD-aware permutation
+  // inside the kernel is a bijection; persistent grid of up to 8 workgroups per CU (a multiple of 64,
+  // hence of 8: a workgroup's later iterations stay on its XCD's share of the worlds)
+  const size_t groups = (B + kWavesPerWg - 1) / kWavesPerWg;
+  const size_t padded = (groups + 63) / 64 * 64;
+  if (padded > 0xffffffffull) return MPE_EUNSUPPORTED;
+  int bpc = 8;
+  if (const char *e = std::getenv("MPE_WIDE_BPC")) bpc = std::atoi(e);  // tuning experiment switch
+  size_t cap = (size_t)n_cu * (size_t)(bpc > 0 ? bpc : 1) / 64 * 64;
+  if (cap < 64) cap = 64;
+  const dim3 grid((unsigned)(padded < cap ? padded : cap)), block(kWavesPerWg * kWave);
+  const unsigned np = (unsigned)padded;
+  if (phys && out) hipLaunchKernelGGL((k_wave<true, true>), grid, block, lds, stream, d, b, B, np);
+  else if (phys) hipLaunchKernelGGL((k_wave<true, false>), grid, block, lds, stream, d, b, B, np);
+  else hipLaunchKernelGGL((k_wave<false, true>), grid, block, lds, stream, d, b, B, np);
   return (int)hipGetLastError();
 }
 
