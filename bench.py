@@ -40,6 +40,18 @@ def algorithmic_bytes(A, L, obs_total):
     return 4 * (reads + writes) + A
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json; collected and corrected as MI355X_MICROARCH.md prescribes: separate
+    FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH_SIZE x2 on gfx950).  bench.py cannot run the
+    profiler around itself, so this is the profile of the same command at the same sizes, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(key)
+    except Exception:
+        return None
+
+
 def usable_cores():
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # cgroup v2 CPU quota
@@ -178,14 +190,23 @@ def main():
             roll.enqueue(W)
         sharding.barrier(dev)
         walls = []
+        evs = []
         for _ in range(args.repeats):
             sharding.barrier(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
+            e0.record()
             body()
+            e1.record()
             torch.cuda.synchronize()
             sharding.barrier(dev)
             walls.append(time.perf_counter() - t0)
+            evs.append(e0.elapsed_time(e1))
+        if mode == args.mode:
+            region_ms[:] = evs
         return sharding.reduce_max(sorted(walls)[len(walls) // 2], dev)
+
+    region_ms = []      # HIP-event time of each timed repeat (events on the launch stream)
 
     def kernel_time_us(mode, n=400):
         """The dominant kernel's time per env step, from HIP events on the launch stream around n
@@ -221,6 +242,10 @@ def main():
 
     if rank == 0:
         achieved = bytes_step * B / (k_us * 1e-6) / 1e9
+        kname = ("mpe::k_split" if os.environ.get("MPE_STEP_IMPL") != "thread" else "mpe::k_narrow") if A <= 6 \
+            else "mpe::k_wave"
+        tkey = "%s_A%d_L%d_B%d" % (args.scenario, A, Lm, B)
+        tr = pmc_traffic(tkey) if S == 1 and args.mode in ("graph", "eager") else None
         out = {
             "metric": "env steps/sec (whole node), %s N=%d, batch=%d per GPU" % (args.scenario, A, B),
             "value": B * K * world / dt, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -232,13 +257,19 @@ def main():
                        "repeats": args.repeats, "streams_per_gpu": S,
                        "sharding": "worlds by batch index, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": tr["traffic_bytes_per_launch"] if tr else None,
+                         "traffic_source": tr["source"] if tr else None,
                          "algorithmic_bytes_per_env_step": bytes_step,
-                         "kernel": ("mpe::k_split" if os.environ.get("MPE_STEP_IMPL") != "thread" else "mpe::k_narrow")
-                         if A <= 6 else "mpe::k_wide",
+                         "algorithmic_bytes_per_launch": bytes_step * B,
+                         "kernel": kname,
                          "kernel_us_per_launch": k_us, "env_steps_per_launch": B,
-                         "note": "kernel_us_per_launch = HIP-event time of n back-to-back steps / n; with S>1 streams the "
-                                 "S sub-batch launches of one step overlap, so this is time per full-batch step"},
+                         "timed_region_us_per_step": (sorted(region_ms)[len(region_ms) // 2] * 1e3 / K) if region_ms else None,
+                         "note": "achieved = algorithmic bytes per launch / kernel_us_per_launch; kernel_us_per_launch = HIP-event "
+                                 "time (launch stream) of 400 back-to-back dependent step launches / 400 (agrees with the rocprofv3 "
+                                 "kernel-trace average under profiles/); timed_region_us_per_step = HIP-event time of the timed "
+                                 "region / steps (includes the reset launches every episode); with S>1 streams the S sub-batch "
+                                 "launches of one step overlap, so both are times per full-batch step"},
         }
         if extra:
             out["extra"] = extra

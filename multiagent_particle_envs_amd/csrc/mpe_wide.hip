@@ -146,6 +146,67 @@ __device__ __forceinline__ void emit_rows(const float2 *Q, const float2 *V, int 
   }
 }
 
+// The same rows when a row has at most 128 16-byte pieces (D <= 512: every spread shape up to N = 85).
+// What a lane reads for its pieces does not depend on the row except for the self-skip: piece p covers
+// pairs kp = 2p, 2p+1, i.e. Q[idx] or Q[idx+1] for idx = kp-2.  Both candidates of both pairs of both
+// pieces are fetched ONCE per world into registers (16 VGPRs); a row is then, per pair, one compare
+// against the uniform threshold L+i, two selects and two subtractions -- no LDS traffic and no address
+// arithmetic in the row loop beyond the broadcast read of (pos_i, vel_i) for the next row.
+__device__ __forceinline__ void emit_rows_fast(const float2 *Q, const float2 *V, int A, int L, int D,
+                                               float *obs_w, size_t rowlen, int lane) {
+  const int E = A + L;
+  const int P = D >> 2;             // 16-byte pieces per row, <= 128
+  const int kpz = 2 + L + (A - 1);  // first all-zero pair
+  const bool two = P > kWave;       // uniform: rows longer than one wave store
+  float2 ca[2][2], cb[2][2];
+  int idx[2][2];
+  bool live[2][2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kp = 2 * (lane + kWave * k) + h;
+      idx[k][h] = kp - 2;
+      live[k][h] = kp < kpz;
+      ca[k][h] = Q[min(max(kp - 2, 0), E - 1)];
+      cb[k][h] = Q[min(max(kp - 1, 0), E - 1)];
+    }
+  const bool st0 = lane < P, st1 = lane + kWave < P;
+  const bool tail0 = 2 * kWave > kpz;  // uniform: the first wave store already reaches the zero tail
+  float2 me = Q[L], vel = V[0];
+  for (int i = 0; i < A; ++i) {
+    const int thr = L + i;
+    float *const row = obs_w + (size_t)i * rowlen;  // wave-uniform
+    const int inext = min(i + 1, A - 1);
+    const float2 me_n = Q[L + inext], vel_n = V[inext];  // next row's operands: in flight under this row
+    {
+      float4 o;
+      const float2 s0 = idx[0][0] >= thr ? cb[0][0] : ca[0][0];
+      const float2 s1 = idx[0][1] >= thr ? cb[0][1] : ca[0][1];
+      o.x = s0.x - me.x; o.y = s0.y - me.y;
+      o.z = s1.x - me.x; o.w = s1.y - me.y;
+      if (tail0) {
+        if (!live[0][0]) { o.x = 0.f; o.y = 0.f; }
+        if (!live[0][1]) { o.z = 0.f; o.w = 0.f; }
+      }
+      if (lane == 0) o = make_float4(vel.x, vel.y, me.x, me.y);  // the row's header
+      if (st0) *reinterpret_cast<float4 *>(row + (unsigned)(4 * lane)) = o;
+    }
+    if (two) {
+      float4 o;
+      const float2 s0 = idx[1][0] >= thr ? cb[1][0] : ca[1][0];
+      const float2 s1 = idx[1][1] >= thr ? cb[1][1] : ca[1][1];
+      o.x = s0.x - me.x; o.y = s0.y - me.y;
+      o.z = s1.x - me.x; o.w = s1.y - me.y;
+      if (!live[1][0]) { o.x = 0.f; o.y = 0.f; }
+      if (!live[1][1]) { o.z = 0.f; o.w = 0.f; }
+      if (st1) *reinterpret_cast<float4 *>(row + (unsigned)(4 * (lane + kWave))) = o;
+    }
+    me = me_n;
+    vel = vel_n;
+  }
+}
+
 template <bool PHYS, bool OUT>
 __global__ void __launch_bounds__(kWavesPerWg *kWave)
 k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_groups_padded) {
@@ -278,7 +339,11 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
       const bool world_major = d.obs_world_major != 0;
       const size_t rowlen = world_major ? (size_t)D : (size_t)B * D;
       float *const obs_w = b.obs + (world_major ? w * (size_t)A * D : w * (size_t)D);
-      if ((D & 3) == 0 && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && (world_major || ((B * (size_t)D) & 3) == 0))
+      const bool vec4 = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 &&
+                        (world_major || ((B * (size_t)D) & 3) == 0);
+      if (vec4 && D <= 8 * kWave && d.obs_flat == 0)
+        emit_rows_fast(Q, V, A, L, D, obs_w, rowlen, lane);
+      else if (vec4)
         emit_rows<4>(Q, V, A, L, D, obs_w, rowlen, lane);
       else
         emit_rows<2>(Q, V, A, L, D, obs_w, rowlen, lane);  // D is even (checked on the host)
