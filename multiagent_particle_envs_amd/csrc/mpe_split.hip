@@ -3,19 +3,25 @@
 // Why: at the benchmark batch (65 536 worlds per GPU) a thread-per-world launch is 1024 waves --
 // one per SIMD on 256 CUs -- and each lane walks ~2000 dependent VALU / transcendental
 // instructions, so the step is latency-bound at ~10 us although its 27 MB would stream in ~4 us.
-// Here a workgroup is A waves x 64 lanes: lane = world, WAVE = AGENT.  Every global access is
-// still a 256-byte coalesced wave access over the batch axis, each lane does one agent's share
-// of the work (its contacts, its integration, its observation row, its landmark distances), and
-// the chip holds A times as many waves to hide latency.  Agents of one world meet once per step
-// in LDS: after integrating, wave i publishes (pos_i, vel_i[, |pos_i - landmark_l|]) and, behind
-// one __syncthreads, reads the other agents' new state.  Arithmetic per pair / per agent is the
-// same code (mpe_device.h) in the same order as the thread-per-world kernels, so results are
-// bit-identical to them.
+// Here a workgroup is (A + 1) waves x 64 lanes: lane = world, and the waves split the work of those
+// 64 worlds by ROLE:
+//   wave i < A   AGENT i: loads the world, its contacts and its integration (core.py:117-169), stores
+//                its new state, publishes (pos_i, vel_i[, |pos_i - landmark_l|^2]) in LDS, and after
+//                ONE __syncthreads assembles and stores agent i's observation rows;
+//   wave A       REWARD: touches no global input at all -- behind the same barrier it reads what the
+//                agents published and computes every agent's reward / done / benchmark_data once
+//                (the reference recomputes the shared terms per agent: O(A^2 L) -> O(A L)).
+// Every global access is a 256-byte coalesced wave access over the batch axis, the chip holds A + 1
+// times as many waves as a thread-per-world launch to hide latency, and no wave walks both the
+// observation and the reward chain.  Arithmetic per pair / per agent is the same code (mpe_device.h)
+// in the same order as the thread-per-world kernels, so results are bit-identical to them.
 //
-// ROLL = true is the fused rollout (mpe_rollout_random): T steps in one launch, each wave keeps
+// ROLL = true is the fused rollout (mpe_rollout_random): T steps in one launch, each agent wave keeps
 // its agent's state in registers, moves are drawn in-kernel (Philox, identical to
 // mpe_random_actions), resets happen in-kernel (identical to mpe_reset), and every step's
-// obs/rew/done are still written -- to per-step trajectory blocks or over the same block.
+// obs/rew/done are still written -- to per-step trajectory blocks or over the same block.  The LDS
+// exchange block is double-buffered by step parity: the reward wave may still be reading step t's
+// block while the agents publish step t+1's; step t+2's publish is behind step t+1's barrier.
 #include <type_traits>
 
 #include "mpe_internal.h"
@@ -25,25 +31,163 @@ namespace mpe {
 template <int KIND, int A, int L, int NADV>
 struct SplitShape {
   static constexpr int E = A + L;
-  static constexpr int XW = KIND == MPE_SCN_SPREAD ? 4 + L : 4;  // floats an agent publishes per world
+  // floats an agent publishes per world: pos, vel, then squared distances to the landmarks the reward needs
+  static constexpr int XW = KIND == MPE_SCN_SPREAD ? 4 + L : KIND == MPE_SCN_SIMPLE ? 5 : 4;
   static constexpr int DMAX = KIND == MPE_SCN_SIMPLE   ? 2 + 2 * L
                               : KIND == MPE_SCN_SPREAD ? 4 + 2 * L + 4 * (A - 1)
                               : KIND == MPE_SCN_TAG    ? 4 + 2 * L + 2 * (A - 1) + 2 * (A - NADV)
                                                        : 1;
   static constexpr int TILE = kWave * (DMAX | 1);  // >= kWave * tile_stride<D>() of every row width used
+  static constexpr int WAVES = A + 1;              // A agent waves + the reward wave
   static constexpr size_t lds_bytes(bool roll) {
     return sizeof(float) * ((roll ? 2 : 1) * A * XW * kWave + A * TILE);
   }
 };
 
+// ---- the reward wave: Scenario.reward / benchmark_data / done for all A agents of 64 worlds --------
+// X is the exchange block the agent waves filled: X[(a * XW + c) * 64 + lane], c = 0,1 pos, 2,3 vel, 4.. d2.
+template <int KIND, int A, int L, int NADV>
+__device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffers &b, const float *X, int lane,
+                                            bool live, unsigned ln, size_t B, size_t ro /* uniform: row 0 of this step + w0 */) {
+  constexpr int XW = SplitShape<KIND, A, L, NADV>::XW;
+  if (KIND == MPE_SCN_SIMPLE) {  // simple.py:41-43: -|pos - landmark 0|^2
+    if (live) {
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        if (b.rew) (b.rew + wave_off(ro + (size_t)a * B))[ln] = -X[(a * XW + 4) * kWave + lane];
+        if (b.done) (b.done + wave_off(ro + (size_t)a * B))[ln] = 0;
+      }
+    }
+  }
+  if (KIND == MPE_SCN_SPREAD) {  // simple_spread.py:72-82, :47-63
+    if (b.rew || b.info_rew) {
+      float px[A], py[A];
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        px[a] = X[(a * XW + 0) * kWave + lane];
+        py[a] = X[(a * XW + 1) * kWave + lane];
+      }
+      // landmark term from the published SQUARED agent-landmark distances: min first, then one square
+      // root (monotone); contact counts from the new positions
+      float lm_term = 0.f, md = 0.f;
+      int occupied = 0;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        float m2 = X[(0 * XW + 4 + l) * kWave + lane];
+#pragma unroll
+        for (int a = 1; a < A; ++a) m2 = fminf(m2, X[(a * XW + 4 + l) * kWave + lane]);
+        const float m = fast_sqrt(m2);
+        lm_term = lm_term - m;
+        md = md + m;
+        occupied += sqrt_lt(m2, 0.1f) ? 1 : 0;  // the integer output takes the exact test
+      }
+      int cnt[A];
+#pragma unroll
+      for (int a = 0; a < A; ++a) cnt[a] = (d.size[a] + d.size[a] > 0.f) ? 1 : 0;  // the agent against itself (Q1): 0 < 2r
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+#pragma unroll
+        for (int c = a + 1; c < A; ++c) {
+          const bool hit = sqrt_lt(sq2d(px[a] - px[c], py[a] - py[c]), d.size[a] + d.size[c]);
+          cnt[a] += hit ? 1 : 0;
+          cnt[c] += hit ? 1 : 0;
+        }
+      }
+      float r[A];
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        const int c = ((d.collide >> a) & 1u) ? cnt[a] : 0;
+        cnt[a] = c;
+        float ra_ = lm_term;
+#pragma unroll
+        for (int s = 0; s < A; ++s) ra_ = ra_ - (c > s ? 1.f : 0.f);  // rew -= 1 per contact, in sequence
+        r[a] = ra_;
+      }
+      // environment.py:100-102: reward = np.sum(reward_n) = r0 + (((0 + r1) + r2) + ...) for n < 9
+      float rest = 0.f;
+#pragma unroll
+      for (int a = 1; a < A; ++a) rest += r[a];
+      const float total = A > 1 ? r[0] + rest : r[0];
+      if (live) {
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          const size_t o = ro + (size_t)a * B;
+          if (b.rew) (b.rew + wave_off(o))[ln] = d.collaborative ? total : r[a];
+          if (b.info_rew) {
+            (b.info_rew + wave_off(o))[ln] = r[a];
+            (b.info_collisions + wave_off(o))[ln] = cnt[a];
+            (b.info_min_dists + wave_off(o))[ln] = md;
+            (b.info_occupied + wave_off(o))[ln] = occupied;
+          }
+        }
+      }
+    }
+    if (b.done && live) {
+#pragma unroll
+      for (int a = 0; a < A; ++a) (b.done + wave_off(ro + (size_t)a * B))[ln] = 0;
+    }
+  }
+  if (KIND == MPE_SCN_TAG) {  // simple_tag.py:84-129, :57-66
+    constexpr int NG = A - NADV;
+    if (b.rew || b.info_collisions) {
+      float px[A], py[A];
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        px[a] = X[(a * XW + 0) * kWave + lane];
+        py[a] = X[(a * XW + 1) * kWave + lane];
+      }
+      bool hit[NG][NADV];
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int v = 0; v < NADV; ++v)
+          hit[g][v] = sqrt_lt(sq2d(px[NADV + g] - px[v], py[NADV + g] - py[v]), d.size[NADV + g] + d.size[v]);
+      float adv_rew = 0.f;  // adversary_reward :115-129 -- same value for every adversary
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int v = 0; v < NADV; ++v) adv_rew += hit[g][v] ? 10.f : 0.f;
+      if (live) {
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          float r;
+          int c = 0;
+          if (a < NADV) {
+            r = ((d.collide >> a) & 1u) ? adv_rew : 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) c += hit[g][a < NADV ? a : 0] ? 1 : 0;
+          } else {  // agent_reward :89-113
+            r = 0.f;
+            if ((d.collide >> a) & 1u) {
+#pragma unroll
+              for (int v = 0; v < NADV; ++v) r -= hit[a >= NADV ? a - NADV : 0][v] ? 10.f : 0.f;
+            }
+            r -= tag_bound(fabsf(px[a]));
+            r -= tag_bound(fabsf(py[a]));
+          }
+          const size_t o = ro + (size_t)a * B;
+          if (b.rew) (b.rew + wave_off(o))[ln] = r;
+          if (b.info_collisions) (b.info_collisions + wave_off(o))[ln] = c;  // benchmark_data :57-66
+        }
+      }
+    }
+    if (b.done && live) {
+#pragma unroll
+      for (int a = 0; a < A; ++a) (b.done + wave_off(ro + (size_t)a * B))[ln] = 0;
+    }
+  }
+}
+
 template <int KIND, int A, int L, int NADV, bool ROLL>
-__global__ void __launch_bounds__(A *kWave)
+__global__ void __launch_bounds__((A + 1) * kWave)
 k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs ra) {
   using S = SplitShape<KIND, A, L, NADV>;
   constexpr int E = A + L, XW = S::XW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & (kWave - 1);
-  const int i = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // this wave's agent (uniform)
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // uniform: agent index, or A = reward
+  const bool is_agent = role < A;
+  const int i = is_agent ? role : 0;
   const size_t w0 = (size_t)blockIdx.x * kWave;
   if (w0 >= B) return;  // workgroup-uniform
   const int nvalid = (B - w0) < (size_t)kWave ? (int)(B - w0) : kWave;
@@ -56,6 +200,21 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   float *const xch = smem;
   float *const tile = smem + (ROLL ? 2 : 1) * A * XW * kWave + i * S::TILE;
 
+  const int T = ROLL ? ra.T : 1;
+  const size_t obs_stride = ra.trajectory ? (size_t)d.obs_off[A] * B : 0;
+  const size_t row_stride = ra.trajectory ? (size_t)A * B : 0;
+
+  if (!is_agent) {
+    // ---- the reward wave --------------------------------------------------------------------------
+    for (int t = 0; t < T; ++t) {
+      const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
+      __syncthreads();
+      reward_wave<KIND, A, L, NADV>(d, b, X, lane, live, ln, B, (size_t)t * row_stride + w0);
+    }
+    return;
+  }
+
+  // ---- agent wave i ---------------------------------------------------------------------------------
   // this agent's constants, selected from the kernarg arrays without dynamic indexing
   float size_i = 0.f, mass_i = 1.f, accel_i = 0.f, maxspd_i = -1.f;
   int obs_off_i = 0;
@@ -79,9 +238,6 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   float mvy = (b.vel + wave_off((size_t)(2 * i + 1) * B + w0))[ln];
 
   const uint64_t gw = ra.world_offset + w;  // global world number (RNG streams)
-  const int T = ROLL ? ra.T : 1;
-  const size_t obs_stride = ra.trajectory ? (size_t)d.obs_off[A] * B : 0;
-  const size_t row_stride = ra.trajectory ? (size_t)A * B : 0;
 
   // resets fall on global steps that are multiples of episode_len: one 64-bit divide up front, then a
   // countdown (a per-step 64-bit modulo costs ~130 instructions on this ISA)
@@ -140,7 +296,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       }
     }
 
-    // ---- publish this agent's new state; read everybody's ------------------------------------------
+    // ---- publish this agent's new state; read the other agents' ------------------------------------
     float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
     X[(i * XW + 0) * kWave + lane] = mx;
     X[(i * XW + 1) * kWave + lane] = my;
@@ -150,32 +306,25 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 #pragma unroll
       for (int l = 0; l < L; ++l) X[(i * XW + 4 + l) * kWave + lane] = sq2d(mx - px[A + l], my - py[A + l]);
     }
+    if (KIND == MPE_SCN_SIMPLE) X[(i * XW + 4) * kWave + lane] = sq2d(mx - px[A], my - py[A]);
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < A; ++a) {
+      if (a == i) { px[a] = mx; py[a] = my; continue; }  // uniform
       px[a] = X[(a * XW + 0) * kWave + lane];
       py[a] = X[(a * XW + 1) * kWave + lane];
     }
 
-    // ---- outputs of agent i for this step -----------------------------------------------------------
+    // ---- observation row of agent i for this step -------------------------------------------------
     float *const obs_t = b.obs + (size_t)t * obs_stride;
-    const size_t ro = (size_t)t * row_stride + (size_t)i * B + w0;  // wave-uniform; element = [ro + ln]
-    if (KIND == MPE_SCN_SIMPLE) {
+    if (KIND == MPE_SCN_SIMPLE) {  // simple.py:45-50
       constexpr int D = 2 + 2 * L, RS = tile_stride<D>();
       put2<RS>(tile, lane, 0, mvx, mvy);
 #pragma unroll
       for (int l = 0; l < L; ++l) put2<RS>(tile, lane, 2 + 2 * l, px[A + l] - mx, py[A + l] - my);
       flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
-      if (live) {
-        if (b.rew) {
-          const float dx = mx - px[A], dy = my - py[A];
-          const float sx = dx * dx, sy = dy * dy;
-          (b.rew + wave_off(ro))[ln] = -(sx + sy);
-        }
-        if (b.done) (b.done + wave_off(ro))[ln] = 0;
-      }
     }
-    if (KIND == MPE_SCN_SPREAD) {
+    if (KIND == MPE_SCN_SPREAD) {  // simple_spread.py:84-100
       constexpr int D = 4 + 2 * L + 4 * (A - 1), RS = tile_stride<D>();
       put2<RS>(tile, lane, 0, mvx, mvy);
       put2<RS>(tile, lane, 2, mx, my);
@@ -189,66 +338,10 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         k += 2;
       }
 #pragma unroll
-      for (int z = 0; z < 2 * (A - 1); z += 2) put2<RS>(tile, lane, k + z, 0.f, 0.f);
+      for (int z = 0; z < 2 * (A - 1); z += 2) put2<RS>(tile, lane, k + z, 0.f, 0.f);  // silent agents' comm
       flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
-      if (b.rew || b.info_rew) {
-        // landmark term from the published agent-landmark distances; contact counts from the new positions
-        float lm_term = 0.f, md = 0.f;
-        int occupied = 0;
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-          float m2 = X[(0 * XW + 4 + l) * kWave + lane];  // published SQUARED distances: min first,
-#pragma unroll
-          for (int a = 1; a < A; ++a) m2 = fminf(m2, X[(a * XW + 4 + l) * kWave + lane]);
-          const float m = fast_sqrt(m2);                  // then one square root (monotone)
-          lm_term = lm_term - m;
-          md = md + m;
-          occupied += sqrt_lt(m2, 0.1f) ? 1 : 0;          // the integer output takes the exact test
-        }
-        int cnt[A];
-#pragma unroll
-        for (int a = 0; a < A; ++a) cnt[a] = 0;
-#pragma unroll
-        for (int a = 0; a < A; ++a) {
-#pragma unroll
-          for (int c = a; c < A; ++c) {
-            const bool hit = sqrt_lt(sq2d(px[a] - px[c], py[a] - py[c]), d.size[a] + d.size[c]);
-            if (c == a) { cnt[a] += hit ? 1 : 0; }          // the agent against itself (Q1)
-            else { cnt[a] += hit ? 1 : 0; cnt[c] += hit ? 1 : 0; }
-          }
-        }
-        float r[A];
-#pragma unroll
-        for (int a = 0; a < A; ++a) {
-          const int c = ((d.collide >> a) & 1u) ? cnt[a] : 0;
-          cnt[a] = c;
-          float ra_ = lm_term;
-#pragma unroll
-          for (int s = 0; s < A; ++s) ra_ = ra_ - (c > s ? 1.f : 0.f);
-          r[a] = ra_;
-        }
-        float rest = 0.f;
-#pragma unroll
-        for (int a = 1; a < A; ++a) rest += r[a];
-        const float total = A > 1 ? r[0] + rest : r[0];
-        float r_own = 0.f;
-        int c_own = 0;
-#pragma unroll
-        for (int a = 0; a < A; ++a)
-          if (a == i) { r_own = r[a]; c_own = cnt[a]; }
-        if (live) {
-          if (b.rew) (b.rew + wave_off(ro))[ln] = d.collaborative ? total : r_own;
-          if (b.info_rew) {
-            (b.info_rew + wave_off(ro))[ln] = r_own;
-            (b.info_collisions + wave_off(ro))[ln] = c_own;
-            (b.info_min_dists + wave_off(ro))[ln] = md;
-            (b.info_occupied + wave_off(ro))[ln] = occupied;
-          }
-        }
-      }
-      if (b.done && live) (b.done + wave_off(ro))[ln] = 0;
     }
-    if (KIND == MPE_SCN_TAG) {
+    if (KIND == MPE_SCN_TAG) {  // simple_tag.py:131-147
       constexpr int NG = A - NADV;
       constexpr int DA = 4 + 2 * L + 2 * (A - 1) + 2 * NG, DG = DA - 2;
       const bool adv = i < NADV;
@@ -275,44 +368,6 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       };
       if (adv) row(std::integral_constant<int, DA>{});
       else     row(std::integral_constant<int, DG>{});
-      if (b.rew || b.info_collisions) {
-        bool hit[NG][NADV];
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-          for (int v = 0; v < NADV; ++v)
-            hit[g][v] = sqrt_lt(sq2d(px[NADV + g] - px[v], py[NADV + g] - py[v]), d.size[NADV + g] + d.size[v]);
-        float r = 0.f;
-        int c = 0;
-        if (adv) {
-          if (collide_i) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-#pragma unroll
-              for (int v = 0; v < NADV; ++v) r += hit[g][v] ? 10.f : 0.f;
-          }
-#pragma unroll
-          for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int v = 0; v < NADV; ++v)
-              if (v == i) c += hit[g][v] ? 1 : 0;
-        } else {
-          if (collide_i) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-#pragma unroll
-              for (int v = 0; v < NADV; ++v)
-                if (g + NADV == i) r -= hit[g][v] ? 10.f : 0.f;
-          }
-          r -= tag_bound(fabsf(mx));
-          r -= tag_bound(fabsf(my));
-        }
-        if (live) {
-          if (b.rew) (b.rew + wave_off(ro))[ln] = r;
-          if (b.info_collisions) (b.info_collisions + wave_off(ro))[ln] = c;
-        }
-      }
-      if (b.done && live) (b.done + wave_off(ro))[ln] = 0;
     }
   }
   if (ROLL && ra.episode_len > 0 && live) {
@@ -365,7 +420,7 @@ int launch_split(bool roll, int kind, int A, int L, int nadv, const NarrowDesc &
   const SplitEntry *e = find_split(kind, A, L, nadv);
   if (!e) return MPE_EUNSUPPORTED;
   const unsigned grid = (unsigned)((B + kWave - 1) / kWave);
-  hipLaunchKernelGGL(roll ? e->roll : e->step, dim3(grid), dim3(A * kWave), roll ? e->lds_roll : e->lds_step, stream,
+  hipLaunchKernelGGL(roll ? e->roll : e->step, dim3(grid), dim3((A + 1) * kWave), roll ? e->lds_roll : e->lds_step, stream,
                      d, b, B, ra);
   return (int)hipGetLastError();
 }

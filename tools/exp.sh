@@ -1,8 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r1g
-python bench.py > gpurun_out/r1g/bench_default.json 2> gpurun_out/r1g/bench_default.err
-python bench.py --no-cpu-baseline --agents 64 --batch 4096 --steps 200 > gpurun_out/r1g/bench_n64.json 2>/dev/null
-python bench.py --no-cpu-baseline --scenario simple_tag --batch 16384 > gpurun_out/r1g/bench_tag.json 2>/dev/null
-python bench.py --no-cpu-baseline --batch 1048576 --steps 200 > gpurun_out/r1g/bench_1M.json 2>/dev/null
-python bench.py --no-cpu-baseline --mode api --no-extra > gpurun_out/r1g/bench_api.json 2>/dev/null
-python __graft_entry__.py smoke 2>&1 | tail -4
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+python bench.py --no-cpu-baseline > gpurun_out/exp_b.json 2>/dev/null; python3 -c "
+import json; d=json.loads(open('gpurun_out/exp_b.json').read().strip().splitlines()[-1]); r=d['roofline']; print('spread3 %.3g'%d['value'], 'us/launch %.2f'%r['kernel_us_per_launch'], 'frac %.3f'%r['frac'], 'fused us/step', d['extra']['fused_rollout']['kernel_us_per_step'])"
+python bench.py --no-cpu-baseline --scenario simple_tag --batch 16384 > gpurun_out/exp_t.json 2>/dev/null; python3 -c "
+import json; d=json.loads(open('gpurun_out/exp_t.json').read().strip().splitlines()[-1]); r=d['roofline']; print('tag %.3g'%d['value'], 'us/launch %.2f'%r['kernel_us_per_launch'], 'frac %.3f'%r['frac'], 'fused us/step', d['extra']['fused_rollout']['kernel_us_per_step'])"
