@@ -12,7 +12,7 @@ MPE_ACTION_DIM = 5
 MPE_SCN_GENERIC, MPE_SCN_SIMPLE, MPE_SCN_SPREAD, MPE_SCN_TAG = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmpe_hip.so")
+LIB_PATH = os.environ.get("MPE_HIP_LIB") or os.path.join(_HERE, "lib", "libmpe_hip.so")  # override: A/B builds
 
 _M = MPE_MAX_ENTITIES
 

@@ -63,11 +63,11 @@ __device__ __forceinline__ float dist2d(float dx, float dy) {
 // the real sqrt evaluated.  Used for the integer outputs (collision counts) -- see DESIGN.md 4.
 __device__ __forceinline__ bool sqrt_lt(float s2, float m) {
   const float m2 = m * m;
-  if (m2 > 1e-30f) {
-    if (s2 < m2 * 0.9999996f) return true;
-    if (s2 > m2 * 1.0000004f) return false;
-  }
-  return sqrtf(s2) < m;
+  const bool below = s2 < m2 * 0.9999996f;                    // surely less
+  const bool above = s2 > m2 * 1.0000004f && m2 > 1e-30f;     // surely not (a vanishing threshold has no band)
+  bool r = below;
+  if (!below && !above) r = sqrtf(s2) < m;                    // the guard band (and NaN): one rare branch
+  return r;
 }
 __device__ __forceinline__ float sq2d(float dx, float dy) {
   const float sx = dx * dx;
@@ -245,6 +245,15 @@ __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict_
   __builtin_amdgcn_wave_barrier();
   const int nfl = nvalid * D;
   constexpr int NQ = 16 * D;  // float4 slots in a full tile
+  if (S == D && vec4 && nvalid == kWave) {
+    // the common case -- a full wave of worlds, aligned rows: straight 16-byte copies, no bounds tests
+#pragma unroll
+    for (int it = 0; it < (NQ + kWave - 1) / kWave; ++it) {
+      const int q = lane + kWave * it;
+      if ((it + 1) * kWave <= NQ || q < NQ)
+        *reinterpret_cast<float4 *>(g + 4 * q) = *reinterpret_cast<const float4 *>(tile + 4 * q);
+    }
+  } else {
 #pragma unroll
   for (int it = 0; it < (NQ + kWave - 1) / kWave; ++it) {
     const int q = lane + kWave * it;
@@ -270,6 +279,7 @@ __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict_
           if (j + m < nfl) g[j + m] = v[m];
       }
     }
+  }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
