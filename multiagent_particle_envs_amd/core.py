@@ -124,6 +124,47 @@ class Agent(Entity):
         self.action_callback = None
 
 
+class EntityChoice(object):
+    """A per-world pick among `entities` -- what the reference writes as
+    `agent.goal_a = np.random.choice(world.landmarks)` (simple_adversary.py:44, simple_push.py:41, ...).
+    `index` is a [B] long tensor; attribute access gathers from the picked entity of every world, so
+    reference-style scenario code (`agent.goal_a.state.p_pos`, `agent.goal_b.color`) runs unchanged."""
+
+    def __init__(self, world, entities, index):
+        self._world = world
+        self.entities = list(entities)
+        self.index = index
+
+    def _gather(self, per_entity):
+        stack = torch.stack(per_entity, dim=0)                      # [K, B, w]
+        ar = torch.arange(stack.shape[1], device=stack.device)
+        return stack[self.index.to(stack.device), ar]
+
+    @property
+    def state(self):
+        return self
+
+    @property
+    def p_pos(self):
+        return self._gather([e.state.p_pos for e in self.entities])
+
+    @property
+    def p_vel(self):
+        return self._gather([e.state.p_vel for e in self.entities])
+
+    @property
+    def color(self):
+        return self._gather([self._world._as_batch(e.color, len(e.color) if not torch.is_tensor(e.color)
+                                                   else e.color.shape[-1]) for e in self.entities])
+
+    @property
+    def size(self):
+        sizes = [e.size for e in self.entities]
+        if all(x == sizes[0] for x in sizes):
+            return sizes[0]
+        return torch.tensor(sizes, dtype=torch.float32, device=self.index.device)[self.index]
+
+
 class World(object):
     """B particle worlds stepped in lock-step (reference: core.py:82-196 for one world)."""
 
@@ -178,6 +219,8 @@ class World(object):
         self._zero_vel = torch.zeros((B, 2), dtype=torch.float32, device=self.device)
         for i, ent in enumerate(self.entities):
             ent.state._bind(self, i, i < A)
+        for agent in self.agents:   # agent.state.c = np.zeros(world.dim_c), as every reset_world leaves it
+            agent.state.c = torch.zeros((B, self.dim_c), dtype=torch.float32, device=self.device)
         self._desc = None
         return self
 
@@ -203,58 +246,83 @@ class World(object):
                 self.vel.permute(2, 0, 1).contiguous().cpu().numpy())
 
     # ---- reset_world bodies shared by the built-in scenarios ---------------------------------------
-    def reset_uniform(self, landmark_range=1.0, mask=None):
-        """Scenario.reset_world for the in-scope scenarios (simple_spread.py:38-45,
-        simple_tag.py:46-54, simple.py:33-39): agents ~ U[-1,1)^2, landmarks ~ U[-r,r)^2, vel = 0.
-        rng_mode 'device': Philox on the GPU (`mpe_reset`), keyed by (seed, world, episode);
-        rng_mode 'numpy' : the process-global np.random in the reference's draw order (agents then
-                           landmarks, world by world) -- seed-identical to the reference for B=1."""
+    def reset_uniform(self, landmark_range=1.0, mask=None, choices=None, seeds=None, redraw=None):
+        """Scenario.reset_world for the shipped scenarios (simple_spread.py:38-45, simple_tag.py:46-54,
+        simple.py:33-39, ...): agents ~ U[-1,1)^2, landmarks ~ U[-r,r)^2, vel = 0, comm state c = 0.
+        `choices` = [n_0, n_1, ...]: the `np.random.choice` draws the scenario makes BEFORE the positions
+        (goal landmarks, simple_adversary.py:44 ...); returned as a [B, len(choices)] long tensor.
+        `redraw` = entity indices the scenario draws a SECOND time after the main pass
+        (simple_world_comm.py:108-113 places food and forests twice): it only matters for reproducing
+        the reference's random stream (host modes); the distribution is the same.
+        Where the random numbers come from:
+          seeds given       world b is drawn from np.random.RandomState(seeds[b]) in the reference's order
+                            -- exactly `np.random.seed(s); env.reset()` per world (the parity-test reset);
+          rng_mode 'numpy'  the process-global np.random in the reference's order, world by world
+                            (seed-identical to the reference for B = 1: compatibility mode);
+          rng_mode 'device' Philox on the GPU (`mpe_reset`), keyed by (seed, world, episode); choices from
+                            a torch generator keyed the same way."""
         import numpy as np
         A, E, B = len(self.agents), len(self.entities), self.batch_size
-        if self.rng_mode == "numpy":
-            pos, _ = self.get_state() if mask is not None else (np.zeros((B, E, 2), np.float32), None)
-            m = None if mask is None else torch.as_tensor(mask).cpu().numpy().astype(bool)
+        choices = list(choices or [])
+        idx = None
+        m = None if mask is None else torch.as_tensor(mask).cpu().numpy().astype(bool)
+        if seeds is not None or self.rng_mode == "numpy":
+            if seeds is not None:
+                assert len(seeds) == B
+            pos, vel = self.get_state() if m is not None else (np.zeros((B, E, 2), np.float64), np.zeros((B, A, 2)))
+            pos = pos.astype(np.float64)
+            idx_np = np.zeros((B, len(choices)), np.int64)
             for b in range(B):
                 if m is not None and not m[b]:
                     continue
-                for e in range(E):
+                rs = np.random.RandomState(int(seeds[b])) if seeds is not None else np.random
+                for k, n in enumerate(choices):
+                    idx_np[b, k] = rs.randint(0, n)        # == np.random.choice(list of n) (same stream)
+                for e in list(range(E)) + list(redraw or []):
                     r = 1.0 if e < A else landmark_range
-                    pos[b, e] = np.random.uniform(-r, +r, self.dim_p)
-            if m is None:
-                self.set_state(pos, None)
-            else:
-                _, vel = self.get_state()
-                vel[m] = 0.0
-                self.set_state(pos, vel)
-            return
-        self._require_device()
-        desc = self.scenario_desc(_abi.MPE_SCN_GENERIC)
-        bufs = _abi.MpeBuffers()
-        bufs.pos, bufs.vel = self.pos.data_ptr(), self.vel.data_ptr()
-        mptr = None
-        if mask is not None:
-            mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
-            mptr = C.c_void_p(mask.data_ptr())
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        _abi.check(_abi.lib().mpe_reset(C.byref(desc), C.byref(bufs), B, mptr, float(landmark_range),
-                                        int(self.seed) & (2 ** 64 - 1), int(self._episode), int(self.world_offset),
-                                        C.c_void_p(stream)),
-                   "mpe_reset")
-        self._episode += 1
+                    pos[b, e] = rs.uniform(-r, +r, self.dim_p)
+                vel[b] = 0.0
+            self.set_state(pos, vel)
+            idx = torch.as_tensor(idx_np, device=self.device)
+        else:
+            self._require_device()
+            desc = self.scenario_desc(_abi.MPE_SCN_GENERIC)
+            bufs = _abi.MpeBuffers()
+            bufs.pos, bufs.vel = self.pos.data_ptr(), self.vel.data_ptr()
+            mptr = None
+            if mask is not None:
+                mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+                mptr = C.c_void_p(mask.data_ptr())
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _abi.check(_abi.lib().mpe_reset(C.byref(desc), C.byref(bufs), B, mptr, float(landmark_range),
+                                            int(self.seed) & (2 ** 64 - 1), int(self._episode), int(self.world_offset),
+                                            C.c_void_p(stream)),
+                       "mpe_reset")
+            if choices:
+                g = torch.Generator(device="cpu")
+                g.manual_seed((int(self.seed) * 1000003 + int(self._episode) * 7919 + int(self.world_offset)) & (2 ** 63 - 1))
+                idx = torch.stack([torch.randint(0, n, (B,), generator=g) for n in choices], dim=1).to(self.device)
+            self._episode += 1
+        # comm state of every agent starts at zero (agent.state.c = np.zeros(world.dim_c) in every reset_world)
+        keep = None if mask is None else ~torch.as_tensor(mask, device=self.device).bool()
+        for agent in self.agents:
+            z = torch.zeros((B, self.dim_c), dtype=torch.float32, device=self.device)
+            if keep is not None and torch.is_tensor(agent.state.c):
+                z = torch.where(keep[:, None], agent.state.c, z)
+            agent.state.c = z
+        return idx if choices else None
 
     def reset_from_numpy_seeds(self, seeds, landmark_range=1.0):
         """World b starts exactly as the reference would after `np.random.seed(seeds[b]);
         env.reset()` (MT19937 draws on the host, then one upload) -- the parity-test reset."""
-        import numpy as np
-        A, E, B = len(self.agents), len(self.entities), self.batch_size
-        assert len(seeds) == B
-        pos = np.zeros((B, E, 2), np.float64)
-        for b, s in enumerate(seeds):
-            rs = np.random.RandomState(int(s))
-            for e in range(E):
-                r = 1.0 if e < A else landmark_range
-                pos[b, e] = rs.uniform(-r, +r, self.dim_p)
-        self.set_state(pos, None)
+        return self.reset_uniform(landmark_range, seeds=seeds)
+
+    @staticmethod
+    def merge_choice(old, new, mask):
+        """Per-world choice indices after a partial reset: new where mask, old elsewhere."""
+        if mask is None or old is None:
+            return new
+        return torch.where(torch.as_tensor(mask, device=new.device).bool(), new, old)
 
     # ---- descriptor handed to the C ABI ----------------------------------------------------------
     def scenario_desc(self, kind=_abi.MPE_SCN_GENERIC, n_adversaries=0):

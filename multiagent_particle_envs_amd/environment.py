@@ -238,12 +238,12 @@ class MultiAgentEnv(object):
         """environment.py:106-116.  `seeds` (one per world) gives reference-exact initial states
         (`np.random.seed(s); env.reset()` per world, drawn on the host); `mask` resets a subset."""
         world = self.world
+        kw = {}
         if seeds is not None:
-            world.reset_from_numpy_seeds(seeds, getattr(self._scenario, "landmark_range", 1.0))
-        elif mask is not None:
-            self.reset_callback(world, mask)
-        else:
-            self.reset_callback(world)
+            kw["seeds"] = seeds
+        if mask is not None:
+            kw["mask"] = mask
+        self.reset_callback(world, **kw)
         self.agents = world.policy_agents
         if not self.fused:
             obs_n = [self._get_obs(agent) for agent in self.agents]

@@ -26,8 +26,8 @@ class Scenario(BaseScenario):
         world.allocate()
         return world
 
-    def reset_world(self, world, mask=None):       # simple.py:24-39
-        world.reset_uniform(self.landmark_range, mask)
+    def reset_world(self, world, mask=None, seeds=None):       # simple.py:24-39
+        world.reset_uniform(self.landmark_range, mask, seeds=seeds)
 
     # per-agent callbacks (generic path; the env uses the fused kernel instead when unmodified)
     def reward(self, agent, world):                # simple.py:41-43

@@ -31,8 +31,8 @@ class Scenario(BaseScenario):
         world.allocate()
         return world
 
-    def reset_world(self, world, mask=None):       # simple_spread.py:31-45
-        world.reset_uniform(self.landmark_range, mask)
+    def reset_world(self, world, mask=None, seeds=None):       # simple_spread.py:31-45
+        world.reset_uniform(self.landmark_range, mask, seeds=seeds)
 
     @staticmethod
     def _dist(a, b):

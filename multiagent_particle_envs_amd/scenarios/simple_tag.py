@@ -36,8 +36,8 @@ class Scenario(BaseScenario):
         world.allocate()
         return world
 
-    def reset_world(self, world, mask=None):       # simple_tag.py:39-54
-        world.reset_uniform(self.landmark_range, mask)
+    def reset_world(self, world, mask=None, seeds=None):       # simple_tag.py:39-54
+        world.reset_uniform(self.landmark_range, mask, seeds=seeds)
 
     def good_agents(self, world):
         return [agent for agent in world.agents if not agent.adversary]

@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Golden vectors for the six scenarios outside BASELINE.json's configs, recorded from
+the UNMODIFIED reference (runs only in the build container; see gen_golden.py for the import recipe).
+
+    python tests/golden/gen_golden_scenarios.py       # rewrites tests/golden/f3_<scenario>.npz
+
+Per scenario (W worlds, T steps):
+  seeds [W]            np.random.seed(seed) immediately before env.reset()
+  choice [W,k]         the np.random.choice draws of reset_world as landmark indices (goal, key, ...)
+  pos0/vel0            state after the reset (some worlds squeezed towards the origin: contacts)
+  obs_reset{i} [W,D_i] observations of that state
+  act{i} [T,W,d_i]     action rows fed to env.step: one-hot or real-valued; d_i = 5 (move), dim_c (speak)
+                       or 5 + dim_c (MultiDiscrete: move and speak, environment.py:148-155)
+  obs{i}, rew [T,W,A], pos, vel, c{i} [T,W,dim_c]   outputs / state after each step
+"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+os.environ["SUPPRESS_MA_PROMPT"] = "1"
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+sys.path[:0] = [os.path.join(HERE, "_gym_stub"), "/root/reference"]
+
+import numpy as np  # noqa: E402
+import warnings  # noqa: E402
+
+warnings.filterwarnings("ignore")
+from make_env import make_env  # noqa: E402
+
+
+def choices_of(name, world):
+    lm = world.landmarks
+    if name in ("simple_adversary", "simple_push"):
+        return [lm.index(world.agents[0].goal_a)]
+    if name == "simple_speaker_listener":
+        return [lm.index(world.agents[0].goal_b)]
+    if name == "simple_reference":
+        return [lm.index(world.agents[0].goal_b), lm.index(world.agents[1].goal_b)]
+    if name == "simple_crypto":
+        return [lm.index(world.agents[0].goal_a), int(np.argmax(world.agents[2].key))]
+    return []
+
+
+def action_dims(env):
+    dims = []
+    for agent in env.agents:
+        d = 0
+        if agent.movable:
+            d += 5
+        if not agent.silent:
+            d += env.world.dim_c
+        dims.append(d)
+    return dims
+
+
+def draw_action(agent, world, rng, soft):
+    parts = []
+    if agent.movable:
+        parts.append(rng.uniform(-1, 1, 5) if soft else np.eye(5)[rng.randint(0, 5)])
+    if not agent.silent:
+        parts.append(rng.uniform(0, 1, world.dim_c) if soft else np.eye(world.dim_c)[rng.randint(0, world.dim_c)])
+    return np.concatenate(parts)
+
+
+def record(name, seeds, T, squeeze_every=0, squeeze=0.3):
+    env = make_env(name)
+    world = env.world
+    A, W, E = env.n, len(seeds), len(world.entities)
+    rng = np.random.RandomState(4321)
+    dims = [env.observation_space[i].shape[0] for i in range(A)]
+    adims = action_dims(env)
+    out = {"seeds": np.array(seeds), "pos0": np.zeros((W, E, 2)), "vel0": np.zeros((W, A, 2)),
+           "rew": np.zeros((T, W, A)), "pos": np.zeros((T, W, E, 2)), "vel": np.zeros((T, W, A, 2))}
+    nch = None
+    for i in range(A):
+        out["obs%d" % i] = np.zeros((T, W, dims[i]))
+        out["obs_reset%d" % i] = np.zeros((W, dims[i]))
+        out["act%d" % i] = np.zeros((T, W, adims[i]))
+        out["c%d" % i] = np.zeros((T, W, world.dim_c))
+    for w, seed in enumerate(seeds):
+        np.random.seed(int(seed))
+        obs = env.reset()
+        ch = choices_of(name, world)
+        if nch is None:
+            nch = len(ch)
+            out["choice"] = np.zeros((W, nch), np.int64)
+        out["choice"][w] = ch
+        if squeeze_every and w % squeeze_every == squeeze_every - 1:
+            for ent in world.entities:
+                ent.state.p_pos = ent.state.p_pos * squeeze
+            obs = [env._get_obs(a) for a in env.agents]
+        out["pos0"][w] = np.array([e.state.p_pos for e in world.entities])
+        out["vel0"][w] = np.array([a.state.p_vel for a in world.agents])
+        for i in range(A):
+            out["obs_reset%d" % i][w] = obs[i]
+        for t in range(T):
+            act = []
+            for i, agent in enumerate(env.agents):
+                a = draw_action(agent, world, rng, soft=((t + w + i) % 4 == 3))
+                out["act%d" % i][t, w] = a
+                act.append(a.copy())
+            obs, rew, done, info = env.step(act)
+            for i in range(A):
+                out["obs%d" % i][t, w] = obs[i]
+                out["c%d" % i][t, w] = world.agents[i].state.c
+            out["rew"][t, w] = np.array(rew, dtype=np.float64)
+            out["pos"][t, w] = np.array([e.state.p_pos for e in world.entities])
+            out["vel"][t, w] = np.array([a.state.p_vel for a in world.agents])
+    return out
+
+
+def main():
+    t0 = time.time()
+    jobs = [("simple_adversary", 24, 12, 0), ("simple_push", 24, 12, 2), ("simple_speaker_listener", 24, 12, 0),
+            ("simple_reference", 24, 12, 0), ("simple_crypto", 24, 8, 0), ("simple_world_comm", 24, 12, 2)]
+    for name, W, T, sq in jobs:
+        data = record(name, list(range(300, 300 + W)), T, squeeze_every=sq)
+        path = os.path.join(HERE, "f3_" + name + ".npz")
+        np.savez_compressed(path, **data)
+        print("%-26s %8.1f KiB  choices %s" % (name, os.path.getsize(path) / 1024.0, data["choice"][:6].tolist()))
+    print("done in %.1f s" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+"""the six scenarios outside BASELINE.json's configs, on the generic path (torch
+callbacks over the SoA views + `mpe_world_step`).  Golden vectors: tests/golden/f3_*.npz, recorded from
+the unmodified reference by tests/golden/gen_golden_scenarios.py.
+
+CPU part (no GPU needed: resets, observation() and reward() are host/torch code):
+  * `env.reset(seeds=...)` reproduces the reference's `np.random.seed(s); env.reset()` per world --
+    including the np.random.choice draws that precede the positions (goal / key landmarks);
+  * observation() and reward() evaluated on the golden states equal the reference's outputs.
+GPU part: env.step() -- _set_action in all its modes (move, speak, MultiDiscrete), World.step on the
+GPU, callbacks, shared-reward sum -- teacher-forced against the golden trajectories.
+"""
+import numpy as np
+import pytest
+import torch
+
+import multiagent_particle_envs_amd as mpe
+
+NAMES = ["simple_adversary", "simple_push", "simple_speaker_listener", "simple_reference", "simple_crypto",
+         "simple_world_comm"]
+SQUEEZED = {"simple_push": 2, "simple_world_comm": 2}
+TOL = 1e-5
+
+
+def close(a, b, tol=TOL, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    assert np.all(err <= tol), "%s: max scaled err %.3e at %s" % (what, err.max(), np.unravel_index(err.argmax(), err.shape))
+    return float(err.max()) if err.size else 0.0
+
+
+def np_(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def set_choices(env, choice):
+    sc = env.scenario
+    if choice.shape[1] == 0:
+        return
+    if hasattr(sc, "set_choices"):
+        sc.set_choices(env.world, torch.as_tensor(choice))
+    elif choice.shape[1] == 1:
+        sc.set_goal(env.world, torch.as_tensor(choice[:, 0]))
+    else:
+        sc.set_goal(env.world, torch.as_tensor(choice))
+
+
+def get_choices(env):
+    sc = env.scenario
+    for attr in ("choice_index", "goal_index"):
+        if hasattr(sc, attr):
+            v = np_(getattr(sc, attr))
+            return v.reshape(v.shape[0], -1)
+    return np.zeros((env.batch_size, 0), np.int64)
+
+
+def set_comm(env, g, t):
+    for i, agent in enumerate(env.world.agents):
+        c = g["c%d" % i][t] if t >= 0 else np.zeros_like(g["c%d" % i][0])
+        agent.state.c = torch.as_tensor(c, dtype=torch.float32, device=env.world.device)
+
+
+def rewards(env):
+    r = [np_(env._get_reward(a)).astype(np.float64) * np.ones(env.batch_size) for a in env.agents]
+    if env.shared_reward:
+        r = [np.sum(r, axis=0)] * env.n
+    return np.stack(r, axis=1)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_reset_and_callbacks_match_reference_on_cpu(name, golden):
+    g = golden("f3_" + name)
+    W = len(g["seeds"])
+    env = mpe.make_env(name, batch_size=W, device="cpu")
+    A = env.n
+    # --- seeded reset: choices, positions, observations ---------------------------------------------
+    obs = env.reset(seeds=[int(s) for s in g["seeds"]])
+    assert np.array_equal(get_choices(env), g["choice"])
+    sq = SQUEEZED.get(name, 0)
+    plain = np.array([not (sq and w % sq == sq - 1) for w in range(W)])
+    pos, vel = env.world.get_state()
+    close(pos[plain], g["pos0"][plain], what="reset pos")
+    assert not vel.any()
+    for i in range(A):
+        close(np_(obs[i])[plain], g["obs_reset%d" % i][plain], what="reset obs%d" % i)
+    # --- observation() on the (squeezed) initial states ---------------------------------------------------
+    env.world.set_state(g["pos0"], g["vel0"])
+    set_comm(env, g, -1)
+    for i, agent in enumerate(env.agents):
+        close(np_(env._get_obs(agent)), g["obs_reset%d" % i], what="obs0 %d" % i)
+    # --- observation() / reward() on every golden state ----------------------------------------------------------
+    for t in range(g["rew"].shape[0]):
+        env.world.set_state(g["pos"][t], g["vel"][t])
+        set_comm(env, g, t)
+        for i, agent in enumerate(env.agents):
+            close(np_(env._get_obs(agent)), g["obs%d" % i][t], what="t=%d obs%d" % (t, i))
+        close(rewards(env), g["rew"][t], what="t=%d rew" % t)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_compat_mode_reset_consumes_the_numpy_stream_like_the_reference(name, golden):
+    g = golden("f3_" + name)
+    env = mpe.make_env(name, device="cpu")      # batch_size=None: one world, global np.random, NumPy I/O
+    sq = SQUEEZED.get(name, 0)
+    for w in (0, 2, 4):
+        assert not (sq and w % sq == sq - 1)
+        np.random.seed(int(g["seeds"][w]))
+        env.reset_callback(env.world)            # reset_world only (the observation gather needs no GPU either)
+        assert np.array_equal(get_choices(env)[0], g["choice"][w])
+        pos, _ = env.world.get_state()
+        close(pos[0], g["pos0"][w])
+        for i, agent in enumerate(env.agents):
+            close(np_(env._get_obs(agent))[0], g["obs_reset%d" % i][w])
+
+
+def test_f3_spaces_match_the_reference():
+    want = {"simple_adversary": ([8, 10, 10], [5, 5, 5]), "simple_push": ([8, 19], [5, 5]),
+            "simple_speaker_listener": ([3, 11], [3, 5]), "simple_reference": ([21, 21], [(5, 10), (5, 10)]),
+            "simple_crypto": ([4, 8, 8], [4, 4, 4]),
+            "simple_world_comm": ([34, 34, 34, 34, 28, 28], [(5, 4), 5, 5, 5, 5, 5])}
+    for name, (obs_dims, acts) in want.items():
+        env = mpe.make_env(name, batch_size=2, device="cpu")
+        assert [sp.shape[0] for sp in env.observation_space] == obs_dims
+        for sp, a in zip(env.action_space, acts):
+            if isinstance(a, tuple):       # environment.py:58-61 MultiDiscrete([[0, n-1], ...])
+                assert list(sp.high - sp.low + 1) == list(a)
+            else:
+                assert sp.n == a
+        assert not env.fused
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_step_teacher_forced_against_reference_golden(name, golden):
+    g = golden("f3_" + name)
+    W, T = len(g["seeds"]), g["rew"].shape[0]
+    env = mpe.make_env(name, batch_size=W)
+    A = env.n
+    set_choices(env, g["choice"])
+    worst = 0.0
+    for t in range(T):
+        if t == 0:
+            env.world.set_state(g["pos0"], g["vel0"])
+            set_comm(env, g, -1)
+        else:
+            env.world.set_state(g["pos"][t - 1], g["vel"][t - 1])
+            set_comm(env, g, t - 1)
+        act = [torch.as_tensor(g["act%d" % i][t], dtype=torch.float32).cuda() for i in range(A)]
+        obs_n, rew_n, done_n, _ = env.step(act)
+        pos, vel = env.world.get_state()
+        worst = max(worst, close(pos, g["pos"][t], what="t=%d pos" % t), close(vel, g["vel"][t], what="t=%d vel" % t))
+        for i in range(A):
+            worst = max(worst, close(np_(obs_n[i]), g["obs%d" % i][t], what="t=%d obs%d" % (t, i)))
+            worst = max(worst, close(np_(rew_n[i]) * np.ones(W), g["rew"][t][:, i], what="t=%d rew%d" % (t, i)))
+            worst = max(worst, close(np_(env.world.agents[i].state.c), g["c%d" % i][t], what="t=%d c%d" % (t, i)))
+            assert not np_(done_n[i]).any()
+    print("max scaled err %s: %.3e" % (name, worst))
