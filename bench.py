@@ -225,6 +225,22 @@ def main():
         finally:
             roll.set_episode_len(EP)
 
+    def copy_ceiling_gbs():
+        """Device-to-device copy of 256 MiB (read + write counted), the practical streaming ceiling of this box."""
+        n = 64 * 1024 * 1024
+        a = torch.empty(n, dtype=torch.float32, device=dev)
+        b_ = torch.empty_like(a)
+        a.fill_(1.0)
+        b_.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b_.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        return 10 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
     dt = timed(args.mode)
     k_us = kernel_time_us(args.mode)
     extra = {}
@@ -246,6 +262,7 @@ def main():
             else "mpe::k_wave"
         tkey = "%s_A%d_L%d_B%d" % (args.scenario, A, Lm, B)
         tr = pmc_traffic(tkey) if S == 1 and args.mode in ("graph", "eager") else None
+        copy_gbs = copy_ceiling_gbs()
         out = {
             "metric": "env steps/sec (whole node), %s N=%d, batch=%d per GPU" % (args.scenario, A, B),
             "value": B * K * world / dt, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -260,6 +277,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr["traffic_bytes_per_launch"] if tr else None,
                          "traffic_source": tr["source"] if tr else None,
+                         "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          "algorithmic_bytes_per_env_step": bytes_step,
                          "algorithmic_bytes_per_launch": bytes_step * B,
                          "kernel": kname,
