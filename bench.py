@@ -199,8 +199,8 @@ def main():
             body()
             e1.record()
             torch.cuda.synchronize()
-            sharding.barrier(dev)
-            walls.append(time.perf_counter() - t0)
+            walls.append(time.perf_counter() - t0)   # this rank's K steps, from the common start to its own completion
+            sharding.barrier(dev)                      # (the MAX over ranks below is the job's time)
             evs.append(e0.elapsed_time(e1))
         if mode == args.mode:
             region_ms[:] = evs

@@ -59,20 +59,21 @@ __device__ __forceinline__ void wave_sync() {
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-// LDS carve-up.  Shared by the workgroup (constants, staged once): sizeq, cpart, agent constants.
+// LDS carve-up.  Shared by the workgroup (constants, staged once): sizeq, crank/csz, agent constants.
 // Private to each wave: the world.  Positions sit in OBSERVATION order
 //   Q = [ landmark 0 .. L-1 | agent 0 .. A-1 ]
 // so that the observation row of agent i is  Q[idx + (idx >= L+i)] - Q[L+i]  for idx = 0 .. L+A-2.
 struct Carve {
-  size_t sizeq, cpart, aconst, shared_bytes;  // shared block offsets
-  size_t q, v, u, qn, wave_bytes;             // per-wave block offsets (relative to the wave's base)
+  size_t sizeq, crank, csz, aconst, shared_bytes;  // shared block offsets
+  size_t q, v, u, qn, cpw, wave_bytes;             // per-wave block offsets (relative to the wave's base)
 };
 __host__ __device__ inline Carve carve(int A, int L) {
   const int E = A + L;
   Carve c;
   size_t o = 0;
   c.sizeq = o;  o += align16(sizeof(float) * E);       // Entity.size by Q index
-  c.cpart = o;  o += align16(sizeof(int2) * E);        // collidable entities: (Q index, size bits), ascending entity order
+  c.crank = o;  o += align16(sizeof(int) * E);         // entity e -> its rank among the collidable entities (ascending e), or -1
+  c.csz = o;    o += align16(sizeof(float) * E);       // Entity.size of the collidable entities, by rank
   c.aconst = o; o += align16(sizeof(float4) * A);      // per agent: (1/mass, max_speed, sensitivity, flags)
   c.shared_bytes = o;
   o = 0;
@@ -80,6 +81,7 @@ __host__ __device__ inline Carve carve(int A, int L) {
   c.v = o;  o += align16(sizeof(float2) * A);
   c.u = o;  o += align16(sizeof(float2) * A);          // action force; later the contact counts
   c.qn = o; o += align16(sizeof(float2) * (A > kWave ? A : 0));  // new positions while A > 64 agents integrate in batches
+  c.cpw = o; o += align16(sizeof(float2) * E);         // positions of the collidable entities, by rank (the contact partner list)
   c.wave_bytes = o;
   return c;
 }
@@ -207,6 +209,38 @@ __device__ __forceinline__ void emit_rows_fast(const float2 *Q, const float2 *V,
   }
 }
 
+// Pass 1 of the contact phase for up to 32 partners CPW[kb .. kb+n): bit 31-j of the result is set when
+// partner kb+j is within reach (squared distance under (r_i + r_j + far)^2).  Partner data come from
+// broadcast LDS reads at compile-time offsets of a uniform base (no address arithmetic); the mask is
+// accumulated with one shift-or per partner.  UNI: all collidable entities share one size, so the
+// squared reach is a per-lane constant.
+template <bool UNI>
+__device__ __forceinline__ unsigned near_mask32(const float2 *CPW, const float *csz, int kb, int n, float2 me,
+                                                float rfar, float reach2_u) {
+  unsigned near = 0u;
+#pragma unroll 8
+  for (int j = 0; j < n; ++j) {
+    const float2 pj = CPW[kb + j];
+    float r2 = reach2_u;
+    if (!UNI) {
+      const float r = rfar + csz[kb + j];
+      r2 = r * r;
+    }
+    const bool hit = sq2d(me.x - pj.x, me.y - pj.y) < r2;
+    near = (near << 1) | (hit ? 1u : 0u);
+  }
+  return near << (32 - n);
+}
+
+// sqrt_lt with the bounds of the guard band precomputed (m2 = m*m, lo = m2 (1 - 4e-7), hi = m2 (1 + 4e-7))
+__device__ __forceinline__ bool sqrt_lt_pre(float s2, float m, float lo, float hi, bool has_band) {
+  const bool below = s2 < lo;
+  const bool above = s2 > hi && has_band;
+  bool r = below;
+  if (!below && !above) r = sqrtf(s2) < m;
+  return r;
+}
+
 template <bool PHYS, bool OUT>
 __global__ void __launch_bounds__(kWavesPerWg *kWave)
 k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_groups_padded) {
@@ -216,7 +250,8 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Carve cv = carve(A, L);
   float *const sizeq = reinterpret_cast<float *>(smem + cv.sizeq);
-  int2 *const cpart = reinterpret_cast<int2 *>(smem + cv.cpart);
+  int *const crank = reinterpret_cast<int *>(smem + cv.crank);
+  float *const csz = reinterpret_cast<float *>(smem + cv.csz);
   float4 *const aconst = reinterpret_cast<float4 *>(smem + cv.aconst);
   char *const wbase = smem + cv.shared_bytes + (size_t)wave * cv.wave_bytes;
   float2 *const Q = reinterpret_cast<float2 *>(wbase + cv.q);
@@ -232,26 +267,47 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
     const int fl = (tab[4 * E + i] != 0.f ? kMovable : 0) | (tab[5 * E + i] != 0.f ? kCollide : 0);
     aconst[i] = make_float4(1.0f / tab[1 * E + i], tab[3 * E + i], tab[2 * E + i], __int_as_float(fl));
   }
-  if (tid < kWave) {  // compact the collidable entities in ascending entity order (wave 0: ballot + prefix count)
+  if (tid < kWave) {  // rank the collidable entities in ascending entity order (wave 0: ballot + prefix count)
     int n = 0;
     for (int e0 = 0; e0 < E; e0 += kWave) {
       const int e = e0 + lane;
       const bool c = e < E && tab[5 * E + e] != 0.f;
       const unsigned long long m = __ballot(c);
-      if (c) {
+      if (e < E) {
         const int k = n + __popcll(m & ((1ull << lane) - 1ull));
-        cpart[k] = make_int2(e < A ? L + e : e - A, __float_as_int(tab[0 * E + e]));
+        crank[e] = c ? k : -1;
+        if (c) csz[k] = tab[0 * E + e];
       }
       n += __popcll(m);
     }
   }
-  // number of collidable entities: uniform, recomputed by every wave from the table (E/64 loads)
+  // uniform facts every wave derives from the table itself (E/64 loads): the number of collidable
+  // entities, whether they are exactly the agents (then the partner list IS the agent block of Q),
+  // whether the collidable entities / the agents all have one size (thresholds hoist out of the loops)
   int nC = 0;
-  for (int e0 = 0; e0 < E; e0 += kWave) {
-    const int e = e0 + lane;
-    nC += __popcll(__ballot(e < E && tab[5 * E + e] != 0.f));
+  bool agents_only = true, one_csize = true, one_asize = true;
+  {
+    float first_c = 0.f;
+    bool have_c = false;
+    const float first_a = tab[0];
+    for (int e0 = 0; e0 < E; e0 += kWave) {
+      const int e = e0 + lane;
+      const bool in = e < E;
+      const bool c = in && tab[5 * E + e] != 0.f;
+      const float sz = in ? tab[0 * E + e] : 0.f;
+      const unsigned long long m = __ballot(c);
+      nC += __popcll(m);
+      if (m && !have_c) {
+        first_c = __shfl(sz, __ffsll((long long)m) - 1, kWave);
+        have_c = true;
+      }
+      agents_only = agents_only && !__any(in && (c != (e < A)));
+      one_csize = one_csize && !__any(c && sz != first_c);
+      one_asize = one_asize && !__any(in && e < A && sz != first_a);
+    }
   }
   nC = __builtin_amdgcn_readfirstlane(nC);
+  float2 *const CPW = agents_only ? Q + L : reinterpret_cast<float2 *>(wbase + cv.cpw);
   __syncthreads();
 
   const float far = kFarX * d.cmargin;
@@ -267,8 +323,14 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
     if (w >= B) continue;  // wave-uniform
 
     // ---- stage the world -----------------------------------------------------------------------
-    for (int e = lane; e < E; e += kWave)
-      Q[e < A ? L + e : e - A] = make_float2(b.pos[(size_t)(2 * e) * B + w], b.pos[(size_t)(2 * e + 1) * B + w]);
+    for (int e = lane; e < E; e += kWave) {
+      const float2 p = make_float2(b.pos[(size_t)(2 * e) * B + w], b.pos[(size_t)(2 * e + 1) * B + w]);
+      Q[e < A ? L + e : e - A] = p;
+      if (PHYS && !agents_only) {
+        const int r = crank[e];
+        if (r >= 0) CPW[r] = p;
+      }
+    }
     for (int i = lane; i < A; i += kWave) {
       V[i] = make_float2(b.vel[(size_t)(2 * i) * B + w], b.vel[(size_t)(2 * i + 1) * B + w]);
       if (PHYS) {  // decode actions (environment.py:144-181)
@@ -291,25 +353,21 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
         const float2 u = U[have ? i : 0];
         float ax = u.x, ay = u.y;  // action force first, then the partners in ascending order (Q9)
         const bool pushes = (fi & kCollide) && (fi & kMovable);
-        for (int kb = 0; kb < nC; kb += 64) {
-          const int ke = min(nC, kb + 64);
-          unsigned long long near = 0ull;
-#pragma unroll 8
-          for (int k = kb; k < ke; ++k) {  // pass 1: who is close enough to push at all (uniform k: broadcast reads)
-            const int2 cp = cpart[k];
-            const float2 pj = Q[cp.x];
-            const float reach = ri + __int_as_float(cp.y) + far;
-            const bool hit = sq2d(me.x - pj.x, me.y - pj.y) < reach * reach && cp.x != L + i;
-            near |= hit ? (1ull << (k - kb)) : 0ull;
-          }
-          if (!pushes) near = 0ull;
+        const int self_rank = pushes ? crank[i] : -1;
+        const float rfar = ri + far;
+        const float reach_u = rfar + csz[0];
+        for (int kb = 0; kb < nC; kb += 32) {
+          const int n = min(nC - kb, 32);
+          unsigned near = one_csize ? near_mask32<true>(CPW, csz, kb, n, me, rfar, reach_u * reach_u)
+                                    : near_mask32<false>(CPW, csz, kb, n, me, rfar, 0.f);
+          if (self_rank >= kb && self_rank < kb + 32) near &= ~(0x80000000u >> (self_rank - kb));  // not against itself
+          if (!pushes) near = 0u;
           while (near) {  // pass 2: those only, ascending (Q9)
-            const int k = kb + __ffsll((long long)near) - 1;
-            near &= near - 1;
-            const int2 cp = cpart[k];
-            const float2 pj = Q[cp.x];
+            const int j = __clz((int)near);
+            near &= ~(0x80000000u >> j);
+            const float2 pj = CPW[kb + j];
             float gx, gy;
-            contact_force(me.x - pj.x, me.y - pj.y, ri + __int_as_float(cp.y), d.cforce, d.cmargin, d.cmargin_inv, gx, gy);
+            contact_force(me.x - pj.x, me.y - pj.y, ri + csz[kb + j], d.cforce, d.cmargin, d.cmargin_inv, gx, gy);
             ax = gx + ax;
             ay = gy + ay;
           }
@@ -361,11 +419,23 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
           const float ri = sizeq[L + (hi ? t : 0)];
           float m2 = INFINITY;
           int c = 0;
+          if (one_asize) {
+            // every agent has the same size: the guard band of the strict `<` test is a per-lane constant
+            const float m = ri + ri, mm = m * m, lo = mm * 0.9999996f, hi_ = mm * 1.0000004f;
+            const bool has_band = mm > 1e-30f;
+#pragma unroll 8
+            for (int a = 0; a < A; ++a) {  // uniform a: broadcast reads at compile-time offsets
+              const float2 pa = Q[L + a];
+              m2 = fminf(m2, sq2d(pa.x - pl.x, pa.y - pl.y));
+              c += sqrt_lt_pre(sq2d(pa.x - pi.x, pa.y - pi.y), m, lo, hi_, has_band) ? 1 : 0;  // includes a == t
+            }
+          } else {
 #pragma unroll 4
-          for (int a = 0; a < A; ++a) {  // uniform a: broadcast reads
-            const float2 pa = Q[L + a];
-            m2 = fminf(m2, sq2d(pa.x - pl.x, pa.y - pl.y));
-            c += sqrt_lt(sq2d(pa.x - pi.x, pa.y - pi.y), sizeq[L + a] + ri) ? 1 : 0;  // includes a == t
+            for (int a = 0; a < A; ++a) {
+              const float2 pa = Q[L + a];
+              m2 = fminf(m2, sq2d(pa.x - pl.x, pa.y - pl.y));
+              c += sqrt_lt(sq2d(pa.x - pi.x, pa.y - pi.y), sizeq[L + a] + ri) ? 1 : 0;
+            }
           }
           if (hl) {
             neg = neg - fast_sqrt(m2);

@@ -144,7 +144,8 @@ def test_numpy_order_reset_matches_reference(golden):
 def test_scenario_loader_and_generic_detection(tmp_path):
     assert mpe.scenarios.load("simple.py").Scenario.kind == _abi.MPE_SCN_SIMPLE
     with pytest.raises(FileNotFoundError):
-        mpe.scenarios.load("simple_crypto.py")
+        mpe.scenarios.load("simple_no_such_scenario.py")
+    assert not hasattr(mpe.scenarios.load("simple_crypto.py").Scenario, "kind")   # generic path: no fused kernel kind
     # a subclass that overrides reward must NOT be routed to the fused kernel
     Base = mpe.scenarios.load("simple_spread.py").Scenario
 
