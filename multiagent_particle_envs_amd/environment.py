@@ -371,3 +371,48 @@ class MultiAgentEnv(object):
     # rendering is a GUI concern of the reference (environment.py:200-263) and is not provided
     def render(self, mode='human'):
         raise NotImplementedError("rendering is out of scope of the MI355X hot-path build (see DESIGN.md)")
+
+
+class BatchMultiAgentEnv(object):
+    """The reference's list-of-envs wrapper (environment.py:288-335): per-agent lists of several envs
+    concatenated, `n` = total number of agents.  Each member may itself be a batched env (the batch
+    axis is the efficient way to run many worlds; this wrapper only keeps the reference's calling
+    convention for code written against it).  The reference's `step` forwards an extra `time` argument
+    that `MultiAgentEnv.step` does not take (it never worked as shipped); here `time` is
+    accepted and ignored."""
+    metadata = {'runtime.vectorized': True, 'render.modes': []}
+
+    def __init__(self, env_batch):
+        self.env_batch = list(env_batch)
+
+    @property
+    def n(self):
+        return int(sum(env.n for env in self.env_batch))
+
+    @property
+    def action_space(self):
+        return self.env_batch[0].action_space
+
+    @property
+    def observation_space(self):
+        return self.env_batch[0].observation_space
+
+    def step(self, action_n, time=None):
+        obs_n, reward_n, done_n, info_n = [], [], [], {'n': []}
+        i = 0
+        for env in self.env_batch:
+            obs, reward, done, _ = env.step(action_n[i:(i + env.n)])
+            i += env.n
+            obs_n += obs
+            reward_n += reward
+            done_n += done
+        return obs_n, reward_n, done_n, info_n
+
+    def reset(self):
+        obs_n = []
+        for env in self.env_batch:
+            obs_n += env.reset()
+        return obs_n
+
+    def render(self, mode='human', close=True):
+        raise NotImplementedError("rendering is out of scope of the MI355X hot-path build (see DESIGN.md)")

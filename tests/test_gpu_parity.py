@@ -316,3 +316,87 @@ def test_output_lifetime_ping_pong():
     obs1, _, _, _ = env.step(act)
     assert torch.equal(obs0[0], keep)            # previous call's arrays are still intact
     assert not torch.equal(obs1[0], obs0[0])
+
+
+def test_full_size_properties_spread64_4096():
+    """BASELINE.json configs[3] at full size (simple_spread N=64, 4096 worlds): determinism, shard
+    invariance of the wave-per-world kernel (4 shards of 1024 reproduce the batch bit-for-bit -- the
+    XCD-aware world -> workgroup permutation must not leak into results), the oracle on a sample."""
+    B, N = 4096, 64
+    spec = ospec.simple_spread(N)
+    rs = np.random.RandomState(5)
+    pos = rs.uniform(-1, 1, (B, 2 * N, 2)).astype(np.float32)
+    pos[::4] *= 0.5
+    vel = rs.uniform(-0.3, 0.3, (B, N, 2)).astype(np.float32)
+    act = np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=(N, B))]
+    env = mpe.make_env("simple_spread", batch_size=B, num_agents=N, benchmark=True)
+
+    def run(env_, p, v, a):
+        env_.world.set_state(p, v)
+        o, r, d, info = env_.step(torch.as_tensor(a).cuda().contiguous())
+        ps, vs = env_.world.get_state()
+        cnt = np.stack([np_(x[1]) for x in info["n"]], axis=0)
+        return [np_(x).copy() for x in o], [np_(x).copy() for x in r], ps, vs, cnt
+    o1, r1, p1, v1, c1 = run(env, pos, vel, act)
+    o2, r2, p2, v2, c2 = run(env, pos, vel, act)
+    assert np.array_equal(p1, p2) and np.array_equal(c1, c2) and all(np.array_equal(a, b) for a, b in zip(o1, o2))
+    env_s = mpe.make_env("simple_spread", batch_size=B // 4, num_agents=N, benchmark=True)
+    for s_ in range(4):
+        sl = slice(s_ * B // 4, (s_ + 1) * B // 4)
+        os_, rs_, ps_, vs_, cs_ = run(env_s, pos[sl], vel[sl], act[:, sl])
+        assert np.array_equal(ps_, p1[sl]) and np.array_equal(vs_, v1[sl]) and np.array_equal(cs_, c1[:, sl])
+        for i in (0, 17, 63):
+            assert np.array_equal(os_[i], o1[i][sl]) and np.array_equal(rs_[i], r1[i][sl])
+    idx = np.arange(0, B, 257)
+    o64 = BatchedOracle(spec, len(idx), benchmark=True)
+    o64.set_state(pos[idx], vel[idx])
+    obs64, rew64, _, info64 = o64.step(act[:, idx])
+    close(p1[idx], o64.pos)
+    close(v1[idx], o64.vel)
+    for i in range(N):
+        close(o1[i][idx], obs64[i])
+        close(r1[i][idx], rew64[i])
+    ok = guard_ok(spec, o64.pos)
+    assert np.array_equal(c1[:, idx][:, ok], info64["collisions"][:, ok])
+
+
+def test_a_degenerate_world_does_not_poison_its_neighbours():
+    """Two agents at the same point give d = 0 -> NaN forces in the reference (core.py:193).
+    The NaNs must stay inside that world: its neighbours in the same wave / workgroup are unaffected."""
+    for name, kw, n_agents in (("simple_spread", {}, 3), ("simple_spread", {"num_agents": 16}, 16)):
+        B = 256
+        spec = ospec.simple_spread(n_agents)
+        pos, vel = seeded_initial_state(spec, np.arange(B) + 31)
+        p32 = pos.astype(np.float32)
+        bad = [5, 64, 200]
+        for w in bad:
+            p32[w, 1] = p32[w, 0]                   # agent 1 on top of agent 0
+        act = np.eye(5, dtype=np.float32)[np.random.RandomState(2).randint(0, 5, size=(n_agents, B))]
+        env = mpe.make_env(name, batch_size=B, **kw)
+        env.world.set_state(p32, vel)
+        obs_n, rew_n, _, _ = env.step(torch.as_tensor(act).cuda())
+        gpos, _ = env.world.get_state()
+        good = np.ones(B, bool)
+        good[bad] = False
+        assert np.isnan(gpos[bad]).any(axis=(1, 2)).all()          # the reference's NaN is reproduced ...
+        assert np.isfinite(gpos[good]).all()                       # ... and contained
+        o64 = BatchedOracle(spec, int(good.sum()))
+        o64.set_state(p32[good], vel[good])
+        obs64, rew64, _, _ = o64.step(act[:, good])
+        close(gpos[good], o64.pos)
+        for i in range(n_agents):
+            close(np_(obs_n[i])[good], obs64[i])
+            close(np_(rew_n[i])[good], rew64[i])
+
+
+def test_batch_multi_agent_env_concatenates_per_agent_lists():
+    """environment.py:288-335: lists of several envs concatenated; the reference's stray `time` argument is accepted."""
+    e1 = mpe.make_env("simple_spread", batch_size=8)
+    e2 = mpe.make_env("simple_tag", batch_size=8)
+    both = mpe.BatchMultiAgentEnv([e1, e2])
+    assert both.n == 7
+    obs = both.reset()
+    assert [o.shape[1] for o in obs] == [18, 18, 18, 16, 16, 16, 14]
+    act = [torch.zeros((8, 5), device="cuda") for _ in range(7)]
+    obs, rew, done, info = both.step(act, 0)
+    assert len(obs) == len(rew) == len(done) == 7 and info == {"n": []}

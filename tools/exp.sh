@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python tools/probe_dvfs.py 64 4096 3 2>&1 | grep -v amdgpu.ids
-sleep 2
-python tools/probe_dvfs.py 3 65536 2 2>&1 | grep -v amdgpu.ids
+python -m pytest tests -m gpu -x -q 2>&1 | tail -12
