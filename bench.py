@@ -32,10 +32,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def algorithmic_bytes(A, L, obs_total):
+def algorithmic_bytes(A, L, obs_total, n_choices=0):
     """Compulsory HBM bytes per env-step: read agent pos+vel, landmark pos, one-hot
-    actions; write agent pos+vel, obs, reward (fp32) + done (1 byte per agent)."""
-    reads = 4 * A + 2 * L + 5 * A
+    actions (+ the per-world goal index where the scenario has one); write agent pos+vel, obs, reward
+    (fp32) + done (1 byte per agent)."""
+    reads = 4 * A + 2 * L + 5 * A + n_choices
     writes = 4 * A + obs_total + A
     return 4 * (reads + writes) + A
 
@@ -96,6 +97,58 @@ def cpu_baseline(scenario, okw, seconds, procs):
     return steps / wall, single[0] / single[1]
 
 
+def bench_generic(args, env, dev, rank, world, sharding):
+    """Scenarios without a fused kernel: MultiAgentEnv.step() from Python -- torch
+    _set_action, `mpe_world_step` (HIP), the scenario's torch observation/reward callbacks.  Host- and
+    launch-bound by construction; reported as throughput only (no roofline claim)."""
+    import torch
+    B, K, W, EP = args.batch, args.steps, args.warmup, args.episode_len
+    g = torch.Generator(device="cpu").manual_seed(args.seed + rank)
+    pool = []
+    for _ in range(4):   # uniform random one-hot moves / utterances per agent, in the action space's own format
+        acts = []
+        for agent in env.agents:
+            parts = []
+            if agent.movable:
+                parts.append(torch.nn.functional.one_hot(torch.randint(0, 5, (B,), generator=g), 5).float())
+            if not agent.silent:
+                parts.append(torch.nn.functional.one_hot(torch.randint(0, env.world.dim_c, (B,), generator=g),
+                                                          env.world.dim_c).float())
+            acts.append(torch.cat(parts, dim=1).to(dev))
+        pool.append(acts)
+
+    def run(n):
+        for k in range(n):
+            if EP and k % EP == 0:
+                env.reset()
+            env.step(pool[k % len(pool)])
+    run(W)
+    walls = []
+    for _ in range(args.repeats):
+        sharding.barrier(dev)
+        t0 = time.perf_counter()
+        run(K)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+        sharding.barrier(dev)
+    dt = sharding.reduce_max(sorted(walls)[len(walls) // 2], dev)
+    if rank == 0:
+        A, Lm = len(env.world.agents), len(env.world.landmarks)
+        print(json.dumps({
+            "metric": "env steps/sec (whole node), %s N=%d, batch=%d per GPU" % (args.scenario, A, B),
+            "value": B * K * world / dt, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s A=%d L=%d, %d worlds/GPU, generic path (torch callbacks + mpe_world_step), "
+                                   "random one-hot actions, reset every %d steps" % (args.scenario, A, Lm, B, EP),
+                       "batch_per_gpu": B, "global_batch": B * world, "mode": "api-generic", "repeats": args.repeats},
+            "roofline": {"bound": "host", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                         "traffic": None, "note": "no fused kernel for this scenario: the step is ~100 small torch "
+                                                  "launches + one HIP physics launch, bound by the Python host"},
+        }))
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,11 +199,13 @@ def main():
         envs.append(e)
     env = envs[0]
     A, Lm = len(env.world.agents), len(env.world.landmarks)
+    if not env.fused:
+        return bench_generic(args, env, dev, rank, world, sharding)
     rolls = [RandomRollout(e, episode_len=EP, pool=16) for e in envs]
     roll = StreamedRollout(rolls)
     obs_total = int(env._obs_off[-1])
-    bytes_step = algorithmic_bytes(A, Lm, obs_total)
-    can_fuse = A <= 6 and args.scenario in ("simple", "simple_spread", "simple_tag")
+    bytes_step = algorithmic_bytes(A, Lm, obs_total, len(env.world.choice_pops))
+    can_fuse = A <= 6
     trajs = None
 
     def fused_steps(n):

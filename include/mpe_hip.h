@@ -25,6 +25,7 @@
  *         exactly the [B, D_i] array obs_n[i] of the drop-in API        (environment.py:93)
  *   rew   [A][B]   done [A][B] (uint8, always 0: environment.py:132-135)
  *   info_* [A][B]  benchmark_data columns                                (simple_spread.py:47-63, simple_tag.py:57-66)
+ *   choice [K][B]  int32 per-world picks of reset_world, e.g. the goal landmark index (simple_adversary.py:44)
  */
 #ifndef MPE_HIP_H_
 #define MPE_HIP_H_
@@ -36,9 +37,10 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 1
+#define MPE_ABI_VERSION 2
 #define MPE_MAX_ENTITIES 512 /* agents + landmarks per world */
 #define MPE_ACTION_DIM 5     /* Discrete(dim_p*2+1), environment.py:45 */
+#define MPE_MAX_CHOICES 4    /* np.random.choice draws a reset_world makes before the positions */
 
 /* error codes (negative); positive return values are hipError_t */
 #define MPE_OK 0
@@ -50,7 +52,9 @@ enum MpeScenarioKind {
   MPE_SCN_GENERIC = 0, /* physics only (World.step); obs/reward are the caller's business      */
   MPE_SCN_SIMPLE = 1,  /* multiagent/scenarios/simple.py:41-50                                 */
   MPE_SCN_SPREAD = 2,  /* multiagent/scenarios/simple_spread.py:47-100                         */
-  MPE_SCN_TAG = 3      /* multiagent/scenarios/simple_tag.py:57-147                            */
+  MPE_SCN_TAG = 3,     /* multiagent/scenarios/simple_tag.py:57-147                            */
+  MPE_SCN_ADVERSARY = 4, /* multiagent/scenarios/simple_adversary.py:76-139 (per-world goal landmark) */
+  MPE_SCN_PUSH = 5       /* multiagent/scenarios/simple_push.py:60-96      (per-world goal landmark) */
 };
 
 /*
@@ -76,6 +80,8 @@ typedef struct MpeScenarioDesc {
   uint8_t movable[MPE_MAX_ENTITIES]; /* Entity.movable (must be 0 for landmarks)               */
   uint8_t collide[MPE_MAX_ENTITIES]; /* Entity.collide                                         */
   int32_t obs_off[MPE_MAX_ENTITIES + 1]; /* prefix sums of per-agent obs widths D_i, [A+1] used */
+  int32_t n_choices;                     /* per-world picks drawn at reset (goal = np.random.choice(landmarks), */
+  int32_t choice_pop[MPE_MAX_CHOICES];   /* simple_adversary.py:44): how many, and the population size of each  */
 } MpeScenarioDesc;
 
 /* Device buffers of one batch of worlds (see layout above).  NULL = not used by this call. */
@@ -94,6 +100,8 @@ typedef struct MpeBuffers {
   int32_t *info_occupied;   /* spread */
   float *force;             /* [A][2][B] scratch, only for the phase-level entry points        */
   const float *entity_table; /* device copy of mpe_fill_entity_table(); needed when A+L > 16   */
+  int32_t *choice;           /* [n_choices][B] per-world picks (landmark indices): read by step/observe of the
+                                scenarios that have them, written by mpe_reset / in-kernel resets             */
 } MpeBuffers;
 
 /* ---- library / binding sanity -------------------------------------------------------------- */
@@ -135,7 +143,8 @@ int mpe_integrate_state(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int
 /* ---- device-side reset and synthetic actions (counter-based Philox4x32-10) -------------------
  * mpe_reset: Scenario.reset_world (simple_spread.py:31-45, simple_tag.py:39-54, simple.py:24-39)
  *   for the worlds whose mask byte is non-zero (mask == NULL: all): agents then landmarks,
- *   pos ~ U[-1,1)^2 (landmarks U[-r,r)^2 with r = landmark_range), vel = 0.  The reference draws
+ *   pos ~ U[-1,1)^2 (landmarks U[-r,r)^2 with r = landmark_range), vel = 0, and -- when desc->n_choices > 0
+ *   and bufs->choice is set -- the per-world picks choice[k][b] ~ U{0..choice_pop[k]-1}.  The reference draws
  *   from NumPy's global MT19937; this draws from Philox keyed by (seed, world, episode) -- same
  *   distribution, different stream (seed-exact resets are done host-side).
  *   The generator is indexed by the GLOBAL world number world_offset + b, so a batch sharded over

@@ -6,10 +6,11 @@ library handle (`lib()`), and every compute entry point needs device pointers.
 import ctypes as C
 import os
 
-MPE_ABI_VERSION = 1
+MPE_ABI_VERSION = 2
 MPE_MAX_ENTITIES = 512
 MPE_ACTION_DIM = 5
-MPE_SCN_GENERIC, MPE_SCN_SIMPLE, MPE_SCN_SPREAD, MPE_SCN_TAG = 0, 1, 2, 3
+MPE_SCN_GENERIC, MPE_SCN_SIMPLE, MPE_SCN_SPREAD, MPE_SCN_TAG, MPE_SCN_ADVERSARY, MPE_SCN_PUSH = 0, 1, 2, 3, 4, 5
+MPE_MAX_CHOICES = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPE_HIP_LIB") or os.path.join(_HERE, "lib", "libmpe_hip.so")  # override: A/B builds
@@ -25,6 +26,7 @@ class MpeScenarioDesc(C.Structure):
         ("size", C.c_float * _M), ("mass", C.c_float * _M), ("accel", C.c_float * _M),
         ("max_speed", C.c_float * _M), ("movable", C.c_uint8 * _M), ("collide", C.c_uint8 * _M),
         ("obs_off", C.c_int32 * (_M + 1)),
+        ("n_choices", C.c_int32), ("choice_pop", C.c_int32 * MPE_MAX_CHOICES),
     ]
 
 
@@ -34,6 +36,7 @@ class MpeBuffers(C.Structure):
         ("obs", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p),
         ("info_rew", C.c_void_p), ("info_collisions", C.c_void_p), ("info_min_dists", C.c_void_p),
         ("info_occupied", C.c_void_p), ("force", C.c_void_p), ("entity_table", C.c_void_p),
+        ("choice", C.c_void_p),
     ]
 
 

@@ -194,6 +194,8 @@ class World(object):
         self.seed = 0
         self.world_offset = 0      # global index of this batch's world 0 (multi-GPU sharding by batch index)
         self._episode = 0
+        self.choice_pops = []      # population sizes of the per-world picks reset_world draws (goal landmark, ...)
+        self.choice_i32 = None     # [K, B] int32 device tensor holding them (what the fused kernels read)
 
     # ---- reference properties (core.py:101-114) --------------------------------------------------
     @property
@@ -221,6 +223,8 @@ class World(object):
             ent.state._bind(self, i, i < A)
         for agent in self.agents:   # agent.state.c = np.zeros(world.dim_c), as every reset_world leaves it
             agent.state.c = torch.zeros((B, self.dim_c), dtype=torch.float32, device=self.device)
+        if self.choice_pops:
+            self.choice_i32 = torch.zeros((len(self.choice_pops), B), dtype=torch.int32, device=self.device)
         self._desc = None
         return self
 
@@ -289,6 +293,11 @@ class World(object):
             desc = self.scenario_desc(_abi.MPE_SCN_GENERIC)
             bufs = _abi.MpeBuffers()
             bufs.pos, bufs.vel = self.pos.data_ptr(), self.vel.data_ptr()
+            drawn = None
+            if choices:   # drawn by the same kernel, keyed like the positions (and like the fused rollout's in-kernel resets)
+                assert choices == list(self.choice_pops), "declare world.choice_pops before allocate()"
+                drawn = self.choice_i32.clone()
+                bufs.choice = drawn.data_ptr()
             mptr = None
             if mask is not None:
                 mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
@@ -299,9 +308,7 @@ class World(object):
                                             C.c_void_p(stream)),
                        "mpe_reset")
             if choices:
-                g = torch.Generator(device="cpu")
-                g.manual_seed((int(self.seed) * 1000003 + int(self._episode) * 7919 + int(self.world_offset)) & (2 ** 63 - 1))
-                idx = torch.stack([torch.randint(0, n, (B,), generator=g) for n in choices], dim=1).to(self.device)
+                idx = drawn.t().long()
             self._episode += 1
         # comm state of every agent starts at zero (agent.state.c = np.zeros(world.dim_c) in every reset_world)
         keep = None if mask is None else ~torch.as_tensor(mask, device=self.device).bool()
@@ -351,6 +358,9 @@ class World(object):
             d.max_speed[e] = -1.0 if ent.max_speed is None else ent.max_speed
             d.movable[e] = 1 if ent.movable else 0
             d.collide[e] = 1 if ent.collide else 0
+        d.n_choices = len(self.choice_pops)
+        for k, n in enumerate(self.choice_pops):
+            d.choice_pop[k] = int(n)
         if kind != _abi.MPE_SCN_GENERIC:
             total = _abi.lib().mpe_fill_obs_layout(C.byref(d))
             if total < 0:

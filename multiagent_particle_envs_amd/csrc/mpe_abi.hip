@@ -39,15 +39,22 @@ int check_desc(const MpeScenarioDesc *d, const char *what) {
   if (d->n_agents < 1 || d->n_landmarks < 0 || d->n_agents + d->n_landmarks > MPE_MAX_ENTITIES)
     return fail(MPE_EINVAL, "%s: need 1 <= A, 0 <= L, A+L <= %d (got A=%d L=%d)", what, MPE_MAX_ENTITIES,
                 d->n_agents, d->n_landmarks);
-  if (d->kind < MPE_SCN_GENERIC || d->kind > MPE_SCN_TAG) return fail(MPE_EINVAL, "%s: bad kind %d", what, d->kind);
+  if (d->kind < MPE_SCN_GENERIC || d->kind > MPE_SCN_PUSH) return fail(MPE_EINVAL, "%s: bad kind %d", what, d->kind);
   for (int e = d->n_agents; e < d->n_agents + d->n_landmarks; ++e)
     if (d->movable[e]) return fail(MPE_EUNSUPPORTED, "%s: movable landmarks are not supported (entity %d)", what, e);
   for (int e = 0; e < d->n_agents; ++e)
     if (!(d->mass[e] > 0.f)) return fail(MPE_EINVAL, "%s: mass[%d] must be > 0", what, e);
-  if (d->kind == MPE_SCN_TAG && (d->n_adversaries < 1 || d->n_adversaries >= d->n_agents))
-    return fail(MPE_EINVAL, "%s: simple_tag needs 1 <= n_adversaries < A", what);
+  const bool teams = d->kind == MPE_SCN_TAG || d->kind == MPE_SCN_ADVERSARY || d->kind == MPE_SCN_PUSH;
+  if (teams && (d->n_adversaries < 1 || d->n_adversaries >= d->n_agents))
+    return fail(MPE_EINVAL, "%s: this scenario needs 1 <= n_adversaries < A", what);
   if ((d->kind == MPE_SCN_SPREAD || d->kind == MPE_SCN_TAG) && d->dim_c != 2)
     return fail(MPE_EUNSUPPORTED, "%s: built-in spread/tag kernels assume dim_c == 2 (got %d)", what, d->dim_c);
+  if (d->n_choices < 0 || d->n_choices > MPE_MAX_CHOICES) return fail(MPE_EINVAL, "%s: bad n_choices %d", what, d->n_choices);
+  for (int k = 0; k < d->n_choices; ++k)
+    if (d->choice_pop[k] < 1) return fail(MPE_EINVAL, "%s: choice_pop[%d] must be >= 1", what, k);
+  if ((d->kind == MPE_SCN_ADVERSARY || d->kind == MPE_SCN_PUSH) &&
+      (d->n_landmarks < 1 || d->n_choices != 1 || d->choice_pop[0] != d->n_landmarks))
+    return fail(MPE_EINVAL, "%s: adversary/push pick one goal among the landmarks (n_choices = 1, choice_pop[0] = L)", what);
   return 0;
 }
 
@@ -80,6 +87,8 @@ mpe::NarrowDesc make_narrow(const MpeScenarioDesc *d, const MpeBuffers *b, size_
   n.cmargin_inv = 1.0f / d->contact_margin;
   n.collaborative = d->collaborative;
   n.vec4 = vec4 ? 1 : 0;
+  n.n_choices = d->n_choices;
+  for (int k = 0; k < MPE_MAX_CHOICES; ++k) n.choice_pop[k] = k < d->n_choices ? d->choice_pop[k] : 1;
   return n;
 }
 
@@ -150,6 +159,12 @@ int mpe_fill_obs_layout(MpeScenarioDesc *d) {
         D = 4 + 2 * L + 2 * (A - 1) + 2 * good_others;
         break;
       }
+      case MPE_SCN_ADVERSARY:                                                      // simple_adversary.py:121-139
+        D = (i < d->n_adversaries ? 0 : 2) + 2 * L + 2 * (A - 1);
+        break;
+      case MPE_SCN_PUSH:                                                           // simple_push.py:78-96
+        D = i < d->n_adversaries ? 2 + 2 * L + 2 * (A - 1) : 2 + 2 + 3 + 2 * L + 3 * L + 2 * (A - 1);
+        break;
       default: D = 0;
     }
     d->obs_off[i + 1] = d->obs_off[i] + D;
@@ -182,6 +197,8 @@ static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, 
     if (d->kind == MPE_SCN_GENERIC) return fail(MPE_EINVAL, "%s: kind GENERIC has no output stage", what);
     if (int rc = need(b->obs, what, "obs")) return rc;
     if (int rc = check_info(d, b, what)) return rc;
+    if (d->kind == MPE_SCN_ADVERSARY || d->kind == MPE_SCN_PUSH)
+      if (int rc = need(b->choice, what, "choice (the per-world goal landmark index)")) return rc;
   }
   if (B == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -256,9 +273,14 @@ int mpe_reset(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, const ui
   const char *what = "mpe_reset";
   if (int rc = check_desc(d, what)) return rc;
   if (int rc = check_state(b, B, what)) return rc;
+  if (d->n_choices > 0 && b->choice == nullptr)
+    return fail(MPE_EINVAL, "%s: desc->n_choices = %d but bufs->choice is NULL", what, d->n_choices);
   if (B == 0) return 0;
+  int32_t pop[MPE_MAX_CHOICES] = {1, 1, 1, 1};
+  for (int k = 0; k < d->n_choices; ++k) pop[k] = d->choice_pop[k];
   return hip_result(mpe::launch_reset(d->n_agents, d->n_landmarks, *b, (size_t)B, mask, landmark_range, seed,
-                                      episode, (uint64_t)world_offset, static_cast<hipStream_t>(stream)), what);
+                                      episode, (uint64_t)world_offset, d->n_choices, pop,
+                                      static_cast<hipStream_t>(stream)), what);
 }
 
 int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed, uint64_t step,
@@ -279,6 +301,8 @@ int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
   if (int rc = check_state(b, B, what)) return rc;
   if (int rc = need(b->obs, what, "obs")) return rc;
   if (int rc = check_info(d, b, what)) return rc;
+  if (d->kind == MPE_SCN_ADVERSARY || d->kind == MPE_SCN_PUSH)
+    if (int rc = need(b->choice, what, "choice (the per-world goal landmark index)")) return rc;
   if (T < 0 || episode_len < 0) return fail(MPE_EINVAL, "%s: T, episode_len must be >= 0", what);
   if (B == 0 || T == 0) return 0;
   if (d->n_agents + d->n_landmarks > mpe::kNarrowMaxE ||

@@ -29,6 +29,8 @@ struct NarrowDesc {
   float dt, damp /* 1 - damping */, cforce, cmargin, cmargin_inv /* 1 / contact_margin */;
   int32_t collaborative;
   int32_t vec4;  // obs rows may be written with 16-byte stores (alignment checked on the host)
+  int32_t n_choices;                    // per-world picks drawn at reset (goal landmark, ...)
+  int32_t choice_pop[MPE_MAX_CHOICES];  // population size of each
 };
 
 // np.logaddexp(0, x) (core.py:192): max(x,0) + log1p(exp(-|x|)), stable for |x| ~ 1e3 (H6), on the
@@ -151,6 +153,16 @@ __device__ __forceinline__ void fetch_action_wave(const MpeBuffers &b, size_t B,
   else { ux = (b.u + wave_off((size_t)(2 * i) * B + w0))[ln]; uy = (b.u + wave_off((size_t)(2 * i + 1) * B + w0))[ln]; }
 }
 
+// position of the landmark world-local index g picks (agent.goal_a = np.random.choice(world.landmarks))
+template <int A, int L>
+__device__ __forceinline__ void goal_pos(const float (&px)[A + L], const float (&py)[A + L], int g, float &gx, float &gy) {
+  gx = px[A];
+  gy = py[A];
+#pragma unroll
+  for (int l = 1; l < L; ++l)
+    if (g == l) { gx = px[A + l]; gy = py[A + l]; }
+}
+
 // simple_tag.py:103-108
 __device__ __forceinline__ float tag_bound(float x) {
   if (x < 0.9f) return 0.f;
@@ -185,6 +197,7 @@ __host__ __device__ inline float uniform_pm(uint32_t bits, float r) {
 // streams: word 3 of the counter separates the uses
 constexpr uint32_t kStreamReset = 0x52455345u;   // "RESE"
 constexpr uint32_t kStreamAction = 0x41435449u;  // "ACTI"
+constexpr uint32_t kStreamChoice = 0x43484f49u;  // "CHOI"
 
 // Position pair of entity e in world b for episode `ep`.
 __host__ __device__ inline void reset_draw(uint64_t seed, uint64_t b, uint64_t ep, int e, float r,
@@ -198,6 +211,17 @@ __host__ __device__ inline void reset_draw(uint64_t seed, uint64_t b, uint64_t e
   const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   if (e & 1) { x = uniform_pm(o.z, r); y = uniform_pm(o.w, r); }
   else       { x = uniform_pm(o.x, r); y = uniform_pm(o.y, r); }
+}
+// Per-world pick k of reset_world (np.random.choice among n, e.g. the goal landmark) for episode `ep`.
+__host__ __device__ inline int choice_draw(uint64_t seed, uint64_t b, uint64_t ep, int k, int n) {
+  U4 c;
+  c.x = (uint32_t)b;
+  c.y = (uint32_t)(b >> 32) ^ (uint32_t)(ep >> 32);
+  c.z = (uint32_t)(k >> 2);
+  c.w = kStreamChoice ^ (uint32_t)ep;
+  const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t w = (k & 3) == 0 ? o.x : (k & 3) == 1 ? o.y : (k & 3) == 2 ? o.z : o.w;
+  return (int)(((uint64_t)w * (uint32_t)n) >> 32);
 }
 // Uniform move in {0..4} for agent i of world b at global step `t`.
 __host__ __device__ inline int action_draw(uint64_t seed, uint64_t b, uint64_t t, int i) {
@@ -235,6 +259,9 @@ __device__ __forceinline__ void put2(float *tile, int lane, int c, float x, floa
     tile[lane * S + c + 1] = y;
   }
 }
+
+template <int S>
+__device__ __forceinline__ void put1(float *tile, int lane, int c, float x) { tile[lane * S + c] = x; }
 
 // flush_rows: the tile (row stride tile_stride<D>(), rows = lanes) already holds the wave's 64 rows.
 template <int D>

@@ -27,7 +27,8 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
 
 // reset / synthetic actions / fused rollout (mpe_rng.hip)
 int launch_reset(int A, int L, const MpeBuffers &b, size_t B, const uint8_t *mask, float landmark_range,
-                 uint64_t seed, uint64_t episode, uint64_t world_offset, hipStream_t stream);
+                 uint64_t seed, uint64_t episode, uint64_t world_offset, int n_choices, const int32_t *pop,
+                 hipStream_t stream);
 int launch_random_actions(float *act, int32_t *ids, int A, size_t B, uint64_t seed, uint64_t step,
                           uint64_t world_offset, hipStream_t stream);
 

@@ -19,6 +19,8 @@ struct ObsTile {  // LDS floats one wave needs for its widest observation row
       KIND == MPE_SCN_SIMPLE   ? 2 + 2 * L
       : KIND == MPE_SCN_SPREAD ? 4 + 2 * L + 2 * (A - 1) + DC * (A - 1)
       : KIND == MPE_SCN_TAG    ? 4 + 2 * L + 2 * (A - 1) + 2 * (A - NADV)
+      : KIND == MPE_SCN_ADVERSARY ? 2 + 2 * L + 2 * (A - 1)
+      : KIND == MPE_SCN_PUSH   ? 7 + 5 * L + 2 * (A - 1)
                                : 1;
   static constexpr int floats = kWave * (D | 1);  // >= kWave * tile_stride<D>()
 };
@@ -216,6 +218,118 @@ __device__ __forceinline__ void out_tag(const NarrowDesc &d, const MpeBuffers &b
   }
 }
 
+// simple_adversary.py: observation :121-139, reward :76-118 (shaped).  g = this world's goal landmark.
+template <int A, int L, int NADV>
+__device__ __forceinline__ void out_adversary(const NarrowDesc &d, const MpeBuffers &b, size_t B, size_t w,
+                                              size_t w0, int nvalid, int lane, bool live, float *tile,
+                                              const float (&px)[A + L], const float (&py)[A + L]) {
+  const int g = b.choice[w];
+  float gx, gy;
+  goal_pos<A, L>(px, py, g, gx, gy);
+#pragma unroll
+  for (int i = 0; i < A; ++i) {
+    constexpr int DG = 2 + 2 * L + 2 * (A - 1), DA = DG - 2;
+    float row[DG];
+    int k = 0;
+    if (i >= NADV) { row[k++] = gx - px[i]; row[k++] = gy - py[i]; }
+#pragma unroll
+    for (int l = 0; l < L; ++l) { row[k++] = px[A + l] - px[i]; row[k++] = py[A + l] - py[i]; }
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      if (j == i) continue;
+      row[k++] = px[j] - px[i];
+      row[k++] = py[j] - py[i];
+    }
+    if (i >= NADV) {
+      store_rows<DG>(tile, row, b.obs + B * d.obs_off[i] + w0 * DG, nvalid, lane, d.vec4);
+    } else {
+      float ra[DA];
+#pragma unroll
+      for (int c = 0; c < DA; ++c) ra[c] = row[c];
+      store_rows<DA>(tile, ra, b.obs + B * d.obs_off[i] + w0 * DA, nvalid, lane, d.vec4);
+    }
+  }
+  if (!b.rew && !b.done) return;
+  float d2g[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) d2g[a] = sq2d(px[a] - gx, py[a] - gy);
+  float adv_rew = 0.f;   // sum over adversaries of their distance to the goal (:88)
+#pragma unroll
+  for (int a = 0; a < NADV; ++a) adv_rew = adv_rew + fast_sqrt(d2g[a]);
+  float m2 = d2g[NADV];  // nearest good agent (:100-101)
+#pragma unroll
+  for (int a = NADV + 1; a < A; ++a) m2 = fminf(m2, d2g[a]);
+  const float good_rew = -fast_sqrt(m2) + adv_rew;
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < A; ++i) {
+    if (b.rew) b.rew[i * B + w] = i < NADV ? -d2g[i] : good_rew;   // adversary: -|pos - goal|^2 (:113)
+    if (b.done) b.done[i * B + w] = 0;
+  }
+}
+
+// simple_push.py: observation :78-96, reward :60-76.
+template <int A, int L, int NADV>
+__device__ __forceinline__ void out_push(const NarrowDesc &d, const MpeBuffers &b, size_t B, size_t w,
+                                         size_t w0, int nvalid, int lane, bool live, float *tile,
+                                         const float (&px)[A + L], const float (&py)[A + L],
+                                         const float (&vx)[A], const float (&vy)[A]) {
+  const int g = b.choice[w];
+  float gx, gy;
+  goal_pos<A, L>(px, py, g, gx, gy);
+#pragma unroll
+  for (int i = 0; i < A; ++i) {
+    constexpr int DG = 7 + 5 * L + 2 * (A - 1), DA = 2 + 2 * L + 2 * (A - 1);
+    if (i >= NADV) {
+      float row[DG];
+      int k = 0;
+      row[k++] = vx[i]; row[k++] = vy[i];
+      row[k++] = gx - px[i]; row[k++] = gy - py[i];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) row[k++] = (g + 1 == c) ? 0.75f : 0.25f;          // agent.color (:44-49)
+#pragma unroll
+      for (int l = 0; l < L; ++l) { row[k++] = px[A + l] - px[i]; row[k++] = py[A + l] - py[i]; }
+#pragma unroll
+      for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) row[k++] = (l + 1 == c) ? (float)(0.1 + 0.8) : 0.1f;   // landmark.color (:36-38)
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        if (j == i) continue;
+        row[k++] = px[j] - px[i];
+        row[k++] = py[j] - py[i];
+      }
+      store_rows<DG>(tile, row, b.obs + B * d.obs_off[i] + w0 * DG, nvalid, lane, d.vec4);
+    } else {
+      float row[DA];
+      int k = 0;
+      row[k++] = vx[i]; row[k++] = vy[i];
+#pragma unroll
+      for (int l = 0; l < L; ++l) { row[k++] = px[A + l] - px[i]; row[k++] = py[A + l] - py[i]; }
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        if (j == i) continue;
+        row[k++] = px[j] - px[i];
+        row[k++] = py[j] - py[i];
+      }
+      store_rows<DA>(tile, row, b.obs + B * d.obs_off[i] + w0 * DA, nvalid, lane, d.vec4);
+    }
+  }
+  if (!b.rew && !b.done) return;
+  float dg[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) dg[a] = fast_sqrt(sq2d(px[a] - gx, py[a] - gy));
+  float m = dg[NADV];   // nearest good agent to the goal (:70-71)
+#pragma unroll
+  for (int a = NADV + 1; a < A; ++a) m = fminf(m, dg[a]);
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < A; ++i) {
+    if (b.rew) b.rew[i * B + w] = i < NADV ? m - dg[i] : -dg[i];
+    if (b.done) b.done[i * B + w] = 0;
+  }
+}
+
 // World.apply_environment_force (core.py:143-155): a < c over ALL entities; per entity the
 // contributions arrive as action first, then partners in ascending order (Q9); pairs with both
 // sides immovable are evaluated by the reference but applied to nobody (Q8) -- skipped here.
@@ -299,6 +413,8 @@ k_narrow(const NarrowDesc d, const MpeBuffers b, const size_t B) {
     if constexpr (KIND == MPE_SCN_SIMPLE) out_simple<A, L>(d, b, B, w, w0, nvalid, lane, live, tile, px, py, vx, vy);
     if constexpr (KIND == MPE_SCN_SPREAD) out_spread<A, L>(d, b, B, w, w0, nvalid, lane, live, tile, px, py, vx, vy);
     if constexpr (KIND == MPE_SCN_TAG) out_tag<A, L, NADV>(d, b, B, w, w0, nvalid, lane, live, tile, px, py, vx, vy);
+    if constexpr (KIND == MPE_SCN_ADVERSARY) out_adversary<A, L, NADV>(d, b, B, w, w0, nvalid, lane, live, tile, px, py);
+    if constexpr (KIND == MPE_SCN_PUSH) out_push<A, L, NADV>(d, b, B, w, w0, nvalid, lane, live, tile, px, py, vx, vy);
   }
 }
 
@@ -372,6 +488,7 @@ static const NarrowEntry kNarrowTable[] = {
     MPE_SCN_ENTRY(MPE_SCN_SPREAD, 5, 5, 0), MPE_SCN_ENTRY(MPE_SCN_SPREAD, 6, 6, 0),
     MPE_SCN_ENTRY(MPE_SCN_TAG, 4, 2, 3), MPE_SCN_ENTRY(MPE_SCN_TAG, 2, 1, 1),
     MPE_SCN_ENTRY(MPE_SCN_TAG, 6, 3, 4),
+    MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 3, 2, 1), MPE_SCN_ENTRY(MPE_SCN_PUSH, 2, 2, 1),
     MPE_GEN_ENTRY(1, 0), MPE_GEN_ENTRY(1, 1), MPE_GEN_ENTRY(1, 2), MPE_GEN_ENTRY(1, 3),
     MPE_GEN_ENTRY(2, 0), MPE_GEN_ENTRY(2, 1), MPE_GEN_ENTRY(2, 2), MPE_GEN_ENTRY(2, 3), MPE_GEN_ENTRY(2, 4),
     MPE_GEN_ENTRY(3, 0), MPE_GEN_ENTRY(3, 1), MPE_GEN_ENTRY(3, 2), MPE_GEN_ENTRY(3, 3), MPE_GEN_ENTRY(3, 4),
@@ -382,7 +499,7 @@ static const NarrowEntry kNarrowTable[] = {
 
 static const NarrowEntry *find_narrow(int kind, int A, int L, int nadv) {
   for (const NarrowEntry &e : kNarrowTable)
-    if (e.kind == kind && e.A == A && e.L == L && (kind != MPE_SCN_TAG || e.nadv == nadv)) return &e;
+    if (e.kind == kind && e.A == A && e.L == L && (kind < MPE_SCN_TAG || e.nadv == nadv)) return &e;
   return nullptr;
 }
 

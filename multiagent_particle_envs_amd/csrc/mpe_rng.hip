@@ -14,7 +14,8 @@ constexpr int kBlock = 256;
 // one thread per (world, entity): all stores coalesced over the batch axis
 __global__ void __launch_bounds__(kBlock)
 k_reset(float *__restrict__ pos, float *__restrict__ vel, const uint8_t *__restrict__ mask, size_t B, int A, int E,
-        float landmark_range, uint64_t seed, uint64_t episode, uint64_t world_offset) {
+        float landmark_range, uint64_t seed, uint64_t episode, uint64_t world_offset, int32_t *__restrict__ choice,
+        int n_choices, int pop0, int pop1, int pop2, int pop3) {
   const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int e = blockIdx.y;
   if (w >= B) return;
@@ -26,6 +27,10 @@ k_reset(float *__restrict__ pos, float *__restrict__ vel, const uint8_t *__restr
   if (e < A) {
     vel[(size_t)(2 * e) * B + w] = 0.f;
     vel[(size_t)(2 * e + 1) * B + w] = 0.f;
+  }
+  if (e == 0 && choice) {  // the np.random.choice draws of reset_world (goal landmark, ...)
+    const int pop[MPE_MAX_CHOICES] = {pop0, pop1, pop2, pop3};
+    for (int k = 0; k < n_choices; ++k) choice[(size_t)k * B + w] = choice_draw(seed, world_offset + w, episode, k, pop[k]);
   }
 }
 
@@ -45,10 +50,11 @@ k_random_actions(float *__restrict__ act, int32_t *__restrict__ ids, size_t B, u
 }
 
 int launch_reset(int A, int L, const MpeBuffers &b, size_t B, const uint8_t *mask, float landmark_range,
-                 uint64_t seed, uint64_t episode, uint64_t world_offset, hipStream_t stream) {
+                 uint64_t seed, uint64_t episode, uint64_t world_offset, int n_choices, const int32_t *pop,
+                 hipStream_t stream) {
   const dim3 grid((unsigned)((B + kBlock - 1) / kBlock), (unsigned)(A + L));
   hipLaunchKernelGGL(k_reset, grid, dim3(kBlock), 0, stream, b.pos, b.vel, mask, B, A, A + L, landmark_range, seed,
-                     episode, world_offset);
+                     episode, world_offset, n_choices > 0 ? b.choice : nullptr, n_choices, pop[0], pop[1], pop[2], pop[3]);
   return (int)hipGetLastError();
 }
 

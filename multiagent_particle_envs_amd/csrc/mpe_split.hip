@@ -32,10 +32,13 @@ template <int KIND, int A, int L, int NADV>
 struct SplitShape {
   static constexpr int E = A + L;
   // floats an agent publishes per world: pos, vel, then squared distances to the landmarks the reward needs
-  static constexpr int XW = KIND == MPE_SCN_SPREAD ? 4 + L : KIND == MPE_SCN_SIMPLE ? 5 : 4;
+  static constexpr int XW = KIND == MPE_SCN_SPREAD ? 4 + L
+                            : (KIND == MPE_SCN_SIMPLE || KIND == MPE_SCN_ADVERSARY || KIND == MPE_SCN_PUSH) ? 5 : 4;
   static constexpr int DMAX = KIND == MPE_SCN_SIMPLE   ? 2 + 2 * L
                               : KIND == MPE_SCN_SPREAD ? 4 + 2 * L + 4 * (A - 1)
                               : KIND == MPE_SCN_TAG    ? 4 + 2 * L + 2 * (A - 1) + 2 * (A - NADV)
+                              : KIND == MPE_SCN_ADVERSARY ? 2 + 2 * L + 2 * (A - 1)
+                              : KIND == MPE_SCN_PUSH   ? 7 + 5 * L + 2 * (A - 1)
                                                        : 1;
   static constexpr int TILE = kWave * (DMAX | 1);  // >= kWave * tile_stride<D>() of every row width used
   static constexpr int WAVES = A + 1;              // A agent waves + the reward wave
@@ -176,6 +179,29 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
       for (int a = 0; a < A; ++a) (b.done + wave_off(ro + (size_t)a * B))[ln] = 0;
     }
   }
+  if (KIND == MPE_SCN_ADVERSARY || KIND == MPE_SCN_PUSH) {
+    // each agent published the SQUARED distance to this world's goal landmark (column 4)
+    if (live) {
+      float d2g[A];
+#pragma unroll
+      for (int a = 0; a < A; ++a) d2g[a] = X[(a * XW + 4) * kWave + lane];
+      float m2 = d2g[NADV];   // the good agent nearest to the goal
+#pragma unroll
+      for (int a = NADV + 1; a < A; ++a) m2 = fminf(m2, d2g[a]);
+      float adv_sum = 0.f;    // simple_adversary.py:88: sum over adversaries of their distance to the goal
+#pragma unroll
+      for (int a = 0; a < NADV; ++a) adv_sum = adv_sum + fast_sqrt(d2g[a]);
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        float r;
+        if (KIND == MPE_SCN_ADVERSARY) r = a < NADV ? -d2g[a] : -fast_sqrt(m2) + adv_sum;            // :113 / :100-107
+        else                           r = a < NADV ? fast_sqrt(m2) - fast_sqrt(d2g[a]) : -fast_sqrt(d2g[a]);  // simple_push.py:68-76 / :64-66
+        const size_t o = ro + (size_t)a * B;
+        if (b.rew) (b.rew + wave_off(o))[ln] = r;
+        if (b.done) (b.done + wave_off(o))[ln] = 0;
+      }
+    }
+  }
 }
 
 template <int KIND, int A, int L, int NADV, bool ROLL>
@@ -238,6 +264,8 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   float mvy = (b.vel + wave_off((size_t)(2 * i + 1) * B + w0))[ln];
 
   const uint64_t gw = ra.world_offset + w;  // global world number (RNG streams)
+  constexpr bool HAS_GOAL = KIND == MPE_SCN_ADVERSARY || KIND == MPE_SCN_PUSH;
+  int goal = HAS_GOAL ? (b.choice + wave_off(w0))[ln] : 0;   // this world's goal landmark (np.random.choice at reset)
 
   // resets fall on global steps that are multiples of episode_len: one 64-bit divide up front, then a
   // countdown (a per-step 64-bit modulo costs ~130 instructions on this ISA)
@@ -263,6 +291,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
           if (a == i) { mx = px[a]; my = py[a]; }
         mvx = 0.f;
         mvy = 0.f;
+        if (HAS_GOAL) goal = choice_draw(ra.seed, gw, ep, 0, d.choice_pop[0]);
         ++ep;
       }
       const int m = action_draw(ra.seed, gw, gt, i);  // the one-hot row mpe_random_actions would write
@@ -307,6 +336,11 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       for (int l = 0; l < L; ++l) X[(i * XW + 4 + l) * kWave + lane] = sq2d(mx - px[A + l], my - py[A + l]);
     }
     if (KIND == MPE_SCN_SIMPLE) X[(i * XW + 4) * kWave + lane] = sq2d(mx - px[A], my - py[A]);
+    float gx = 0.f, gy = 0.f;
+    if (HAS_GOAL) {
+      goal_pos<A, L>(px, py, goal, gx, gy);
+      X[(i * XW + 4) * kWave + lane] = sq2d(mx - gx, my - gy);
+    }
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < A; ++a) {
@@ -369,7 +403,70 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       if (adv) row(std::integral_constant<int, DA>{});
       else     row(std::integral_constant<int, DG>{});
     }
+    if (KIND == MPE_SCN_ADVERSARY) {  // simple_adversary.py:121-139
+      constexpr int DG = 2 + 2 * L + 2 * (A - 1), DA = DG - 2;
+      const bool adv = i < NADV;
+      auto row = [&](auto dsel, auto good) {
+        constexpr int D = decltype(dsel)::value, RS = tile_stride<D>();
+        int k = 0;
+        if (decltype(good)::value) { put2<RS>(tile, lane, k, gx - mx, gy - my); k += 2; }
+#pragma unroll
+        for (int l = 0; l < L; ++l) { put2<RS>(tile, lane, k, px[A + l] - mx, py[A + l] - my); k += 2; }
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+          if (j == i) continue;
+          put2<RS>(tile, lane, k, px[j] - mx, py[j] - my);
+          k += 2;
+        }
+        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      };
+      if (adv) row(std::integral_constant<int, DA>{}, std::false_type{});
+      else     row(std::integral_constant<int, DG>{}, std::true_type{});
+    }
+    if (KIND == MPE_SCN_PUSH) {  // simple_push.py:78-96
+      constexpr int DG = 7 + 5 * L + 2 * (A - 1), DA = 2 + 2 * L + 2 * (A - 1);
+      const bool adv = i < NADV;
+      auto row = [&](auto dsel, auto good) {
+        constexpr int D = decltype(dsel)::value, RS = tile_stride<D>();
+        constexpr bool GOOD = decltype(good)::value;
+        int k = 0;
+        if (GOOD || (RS & 1)) { put1<RS>(tile, lane, k, mvx); put1<RS>(tile, lane, k + 1, mvy); }
+        else put2<RS>(tile, lane, k, mvx, mvy);
+        k += 2;
+        if (GOOD) {   // goal, own colour (0.25 grey, +0.5 on channel goal+1), later the landmark colours
+          put1<RS>(tile, lane, k, gx - mx); put1<RS>(tile, lane, k + 1, gy - my);
+          k += 2;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) put1<RS>(tile, lane, k + c, (goal + 1 == c) ? 0.75f : 0.25f);
+          k += 3;
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          if ((RS & 1) || (k & 1)) { put1<RS>(tile, lane, k, px[A + l] - mx); put1<RS>(tile, lane, k + 1, py[A + l] - my); }
+          else put2<RS>(tile, lane, k, px[A + l] - mx, py[A + l] - my);
+          k += 2;
+        }
+        if (GOOD) {
+#pragma unroll
+          for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) put1<RS>(tile, lane, k + 3 * l + c, (l + 1 == c) ? (float)(0.1 + 0.8) : 0.1f);
+          k += 3 * L;
+        }
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+          if (j == i) continue;
+          if ((RS & 1) || (k & 1)) { put1<RS>(tile, lane, k, px[j] - mx); put1<RS>(tile, lane, k + 1, py[j] - my); }
+          else put2<RS>(tile, lane, k, px[j] - mx, py[j] - my);
+          k += 2;
+        }
+        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      };
+      if (adv) row(std::integral_constant<int, DA>{}, std::false_type{});
+      else     row(std::integral_constant<int, DG>{}, std::true_type{});
+    }
   }
+  if (ROLL && HAS_GOAL && ra.episode_len > 0 && live && i == 0) (b.choice + wave_off(w0))[ln] = goal;
   if (ROLL && ra.episode_len > 0 && live) {
     // in-kernel resets moved the landmarks: hand their positions back (wave i writes landmarks l = i mod A)
 #pragma unroll
@@ -405,11 +502,12 @@ static const SplitEntry kSplitTable[] = {
     MPE_SPLIT_ENTRY(MPE_SCN_SPREAD, 5, 5, 0), MPE_SPLIT_ENTRY(MPE_SCN_SPREAD, 6, 6, 0),
     MPE_SPLIT_ENTRY(MPE_SCN_TAG, 4, 2, 3), MPE_SPLIT_ENTRY(MPE_SCN_TAG, 2, 1, 1),
     MPE_SPLIT_ENTRY(MPE_SCN_TAG, 6, 3, 4),
+    MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 3, 2, 1), MPE_SPLIT_ENTRY(MPE_SCN_PUSH, 2, 2, 1),
 };
 
 static const SplitEntry *find_split(int kind, int A, int L, int nadv) {
   for (const SplitEntry &e : kSplitTable)
-    if (e.kind == kind && e.A == A && e.L == L && (kind != MPE_SCN_TAG || e.nadv == nadv)) return &e;
+    if (e.kind == kind && e.A == A && e.L == L && (kind < MPE_SCN_TAG || e.nadv == nadv)) return &e;
   return nullptr;
 }
 

@@ -63,6 +63,8 @@ class _OutputSet(object):
             b.info_collisions = self.info["collisions"].data_ptr()
         if env._entity_table is not None:
             b.entity_table = env._entity_table.data_ptr()
+        if w.choice_i32 is not None:      # per-world picks (goal landmark ...): updated in place by resets
+            b.choice = w.choice_i32.data_ptr()
         self.bufs = b
         self.reward_n = [self.rew[i] for i in range(A)]
         self.done_n = [self.done[i] for i in range(A)]
@@ -117,7 +119,8 @@ class MultiAgentEnv(object):
             (info_callback is None or (getattr(info_callback, "__self__", None) is sc and
                                        info_callback.__func__ is builtin.__dict__.get("benchmark_data"))) and \
             done_callback is None and len(world.scripted_agents) == 0 and \
-            all(a.silent and not a.u_noise for a in world.agents)
+            all(a.silent and not a.u_noise for a in world.agents) and \
+            not (info_callback is not None and kind in (_abi.MPE_SCN_ADVERSARY, _abi.MPE_SCN_PUSH))   # no fused benchmark_data there
         if fused is None:
             fused = own
         if fused and not own:

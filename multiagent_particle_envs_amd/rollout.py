@@ -183,6 +183,8 @@ class Trajectory(object):
         b.obs, b.rew, b.done = self.obs_flat.data_ptr(), self.rew.data_ptr(), self.done.data_ptr()
         if env._entity_table is not None:
             b.entity_table = env._entity_table.data_ptr()
+        if w.choice_i32 is not None:
+            b.choice = w.choice_i32.data_ptr()
         self.bufs = b
 
 

@@ -3,19 +3,24 @@ goal landmark by watching them (reference: multiagent/scenarios/simple_adversary
 Generic path: these callbacks are torch ops on [B, .] views; the physics is `mpe_world_step`."""
 import torch
 
+from .. import _abi
 from ..core import World, Agent, Landmark, EntityChoice
 from ..scenario import BaseScenario
 from . import _util as U
 
 
 class Scenario(BaseScenario):
+    kind = _abi.MPE_SCN_ADVERSARY                  # fused kernel for the reference shape (3 agents, 1 adversary)
     landmark_range = 1.0
+    num_adversaries = 1
 
     def make_world(self, batch_size=1, device=None, num_agents=3, num_adversaries=1):
         world = World(batch_size, device)          # simple_adversary.py:8-33
         world.dim_c = 2
         world.num_agents = num_agents
+        self.num_adversaries = num_adversaries
         num_landmarks = num_agents - 1
+        world.choice_pops = [num_landmarks]        # goal = np.random.choice(world.landmarks), :44
         world.agents = [Agent() for _ in range(num_agents)]
         for i, agent in enumerate(world.agents):
             agent.name = 'agent %d' % i
@@ -30,9 +35,13 @@ class Scenario(BaseScenario):
             landmark.movable = False
             landmark.size = 0.08
         world.allocate()
-        self.goal_index = torch.zeros(world.batch_size, dtype=torch.long, device=world.device)
+        self._world = world
         self._apply(world)
         return world
+
+    @property
+    def goal_index(self):                          # [B] long; stored as world.choice_i32[0] (what the kernels read)
+        return self._world.choice_i32[0].long()
 
     def reset_world(self, world, mask=None, seeds=None):   # simple_adversary.py:35-55
         idx = world.reset_uniform(self.landmark_range, mask, choices=[len(world.landmarks)], seeds=seeds)
@@ -40,7 +49,7 @@ class Scenario(BaseScenario):
 
     def set_goal(self, world, index):
         """goal = np.random.choice(world.landmarks) (:44) for every world: index [B]."""
-        self.goal_index = torch.as_tensor(index, device=world.device).long()
+        world.choice_i32[0].copy_(torch.as_tensor(index, device=world.device).int())
         self._apply(world)
 
     def _apply(self, world):

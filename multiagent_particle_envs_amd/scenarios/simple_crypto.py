@@ -21,6 +21,7 @@ class Scenario(BaseScenario):
         world = World(batch_size, device)          # simple_crypto.py:21-45
         num_agents, num_adversaries, num_landmarks = 3, 1, 2
         world.dim_c = 4
+        world.choice_pops = [num_landmarks, num_landmarks]   # goal (:63), then the key (:65)
         world.agents = [CryptoAgent() for _ in range(num_agents)]
         for i, agent in enumerate(world.agents):
             agent.name = 'agent %d' % i
@@ -34,9 +35,13 @@ class Scenario(BaseScenario):
             landmark.collide = False
             landmark.movable = False
         world.allocate()
-        self.choice_index = torch.zeros((world.batch_size, 2), dtype=torch.long, device=world.device)
+        self._world = world
         self._apply(world)
         return world
+
+    @property
+    def choice_index(self):                        # [B, 2] long: goal landmark, key landmark
+        return self._world.choice_i32.t().long()
 
     def reset_world(self, world, mask=None, seeds=None):   # simple_crypto.py:48-78: goal, then key, then positions
         n = len(world.landmarks)
@@ -46,7 +51,7 @@ class Scenario(BaseScenario):
 
     def set_choices(self, world, index):
         """index [B, 2]: goal landmark, key landmark."""
-        self.choice_index = torch.as_tensor(index, device=world.device).long().reshape(world.batch_size, 2)
+        world.choice_i32.copy_(torch.as_tensor(index, device=world.device).reshape(world.batch_size, 2).t().int())
         self._apply(world)
 
     def _apply(self, world):

@@ -2,18 +2,22 @@
 pushing it away (reference: multiagent/scenarios/simple_push.py).  Generic path."""
 import torch
 
+from .. import _abi
 from ..core import World, Agent, Landmark, EntityChoice
 from ..scenario import BaseScenario
 from . import _util as U
 
 
 class Scenario(BaseScenario):
+    kind = _abi.MPE_SCN_PUSH                       # fused kernel
     landmark_range = 1.0
+    num_adversaries = 1
 
     def make_world(self, batch_size=1, device=None):
         world = World(batch_size, device)          # simple_push.py:6-32
         world.dim_c = 2
         num_agents, num_adversaries, num_landmarks = 2, 1, 2
+        world.choice_pops = [num_landmarks]        # goal = np.random.choice(world.landmarks), :41
         world.agents = [Agent() for _ in range(num_agents)]
         for i, agent in enumerate(world.agents):
             agent.name = 'agent %d' % i
@@ -27,16 +31,20 @@ class Scenario(BaseScenario):
             landmark.movable = False
             landmark.index = i
         world.allocate()
-        self.goal_index = torch.zeros(world.batch_size, dtype=torch.long, device=world.device)
+        self._world = world
         self._apply(world)
         return world
+
+    @property
+    def goal_index(self):                          # [B] long; stored as world.choice_i32[0] (what the kernels read)
+        return self._world.choice_i32[0].long()
 
     def reset_world(self, world, mask=None, seeds=None):   # simple_push.py:34-58
         idx = world.reset_uniform(self.landmark_range, mask, choices=[len(world.landmarks)], seeds=seeds)
         self.set_goal(world, World.merge_choice(self.goal_index, idx[:, 0], mask))
 
     def set_goal(self, world, index):
-        self.goal_index = torch.as_tensor(index, device=world.device).long()
+        world.choice_i32[0].copy_(torch.as_tensor(index, device=world.device).int())
         self._apply(world)
 
     def _apply(self, world):

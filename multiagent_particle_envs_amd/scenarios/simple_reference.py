@@ -14,6 +14,7 @@ class Scenario(BaseScenario):
     def make_world(self, batch_size=1, device=None):
         world = World(batch_size, device)          # simple_reference.py:6-25
         world.dim_c = 10
+        world.choice_pops = [3, 3]                 # agents[0].goal_b, agents[1].goal_b (:35, :37)
         world.collaborative = True
         world.agents = [Agent() for _ in range(2)]
         for i, agent in enumerate(world.agents):
@@ -25,9 +26,13 @@ class Scenario(BaseScenario):
             landmark.collide = False
             landmark.movable = False
         world.allocate()
-        self.goal_index = torch.zeros((world.batch_size, 2), dtype=torch.long, device=world.device)
+        self._world = world
         self._apply(world)
         return world
+
+    @property
+    def goal_index(self):                          # [B, 2] long
+        return self._world.choice_i32.t().long()
 
     def reset_world(self, world, mask=None, seeds=None):   # simple_reference.py:27-55: two choices, then positions
         n = len(world.landmarks)
@@ -37,7 +42,7 @@ class Scenario(BaseScenario):
 
     def set_goal(self, world, index):
         """index [B, 2]: agents[0].goal_b, agents[1].goal_b."""
-        self.goal_index = torch.as_tensor(index, device=world.device).long().reshape(world.batch_size, 2)
+        world.choice_i32.copy_(torch.as_tensor(index, device=world.device).reshape(world.batch_size, 2).t().int())
         self._apply(world)
 
     def _apply(self, world):

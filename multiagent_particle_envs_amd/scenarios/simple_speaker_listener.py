@@ -14,6 +14,7 @@ class Scenario(BaseScenario):
         world = World(batch_size, device)          # simple_speaker_listener.py:6-32
         world.dim_c = 3
         num_landmarks = 3
+        world.choice_pops = [num_landmarks]        # agents[0].goal_b = np.random.choice(world.landmarks), :41
         world.collaborative = True
         world.agents = [Agent() for _ in range(2)]
         for i, agent in enumerate(world.agents):
@@ -29,16 +30,20 @@ class Scenario(BaseScenario):
             landmark.movable = False
             landmark.size = 0.04
         world.allocate()
-        self.goal_index = torch.zeros(world.batch_size, dtype=torch.long, device=world.device)
+        self._world = world
         self._apply(world)
         return world
+
+    @property
+    def goal_index(self):
+        return self._world.choice_i32[0].long()
 
     def reset_world(self, world, mask=None, seeds=None):   # simple_speaker_listener.py:34-59
         idx = world.reset_uniform(self.landmark_range, mask, choices=[len(world.landmarks)], seeds=seeds)
         self.set_goal(world, World.merge_choice(self.goal_index, idx[:, 0], mask))
 
     def set_goal(self, world, index):
-        self.goal_index = torch.as_tensor(index, device=world.device).long()
+        world.choice_i32[0].copy_(torch.as_tensor(index, device=world.device).int())
         self._apply(world)
 
     def _apply(self, world):

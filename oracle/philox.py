@@ -12,6 +12,7 @@ M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 W0, W1 = 0x9E3779B9, 0xBB67AE85
 STREAM_RESET = 0x52455345
 STREAM_ACTION = 0x41435449
+STREAM_CHOICE = 0x43484F49   # "CHOI"
 MASK = np.uint64(0xFFFFFFFF)
 
 
@@ -57,6 +58,24 @@ def reset_positions(seed, batch, episode, n_agents, n_landmarks, landmark_range,
             pos[:, e, 0] = uniform_pm(o[2 * half], r)
             pos[:, e, 1] = uniform_pm(o[2 * half + 1], r)
     return pos
+
+
+def reset_choices(seed, batch, episode, pops, world_offset=0):
+    """choice [K, B] int32 as mpe_reset draws the per-world picks (goal landmark, ...) for `episode`."""
+    b = np.arange(batch, dtype=np.uint64) + np.uint64(world_offset)
+    out = np.zeros((len(pops), batch), np.int32)
+    for quad in range((len(pops) + 3) // 4):
+        c0 = b & MASK
+        c1 = ((b >> np.uint64(32)) ^ np.uint64((episode >> 32) & 0xFFFFFFFF)) & MASK
+        c2 = np.full(batch, quad, np.uint64)
+        c3 = np.full(batch, (STREAM_CHOICE ^ (episode & 0xFFFFFFFF)) & 0xFFFFFFFF, np.uint64)
+        o = philox4x32_10(c0, c1, c2, c3, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        for k in range(4):
+            i = 4 * quad + k
+            if i >= len(pops):
+                break
+            out[i] = ((o[k].astype(np.uint64) * np.uint64(pops[i])) >> np.uint64(32)).astype(np.int32)
+    return out
 
 
 def action_ids(seed, batch, step, n_agents, world_offset=0):

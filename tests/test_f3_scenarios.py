@@ -72,7 +72,7 @@ def rewards(env):
 def test_reset_and_callbacks_match_reference_on_cpu(name, golden):
     g = golden("f3_" + name)
     W = len(g["seeds"])
-    env = mpe.make_env(name, batch_size=W, device="cpu")
+    env = mpe.make_env(name, batch_size=W, device="cpu", fused=False)   # the torch callbacks (generic path)
     A = env.n
     # --- seeded reset: choices, positions, observations ---------------------------------------------
     obs = env.reset(seeds=[int(s) for s in g["seeds"]])
@@ -101,7 +101,7 @@ def test_reset_and_callbacks_match_reference_on_cpu(name, golden):
 @pytest.mark.parametrize("name", NAMES)
 def test_compat_mode_reset_consumes_the_numpy_stream_like_the_reference(name, golden):
     g = golden("f3_" + name)
-    env = mpe.make_env(name, device="cpu")      # batch_size=None: one world, global np.random, NumPy I/O
+    env = mpe.make_env(name, device="cpu", fused=False)      # batch_size=None: one world, global np.random, NumPy I/O
     sq = SQUEEZED.get(name, 0)
     for w in (0, 2, 4):
         assert not (sq and w % sq == sq - 1)
@@ -121,21 +121,26 @@ def test_f3_spaces_match_the_reference():
             "simple_world_comm": ([34, 34, 34, 34, 28, 28], [(5, 4), 5, 5, 5, 5, 5])}
     for name, (obs_dims, acts) in want.items():
         env = mpe.make_env(name, batch_size=2, device="cpu")
+        assert env.fused == (name in ("simple_adversary", "simple_push"))   # these two have fused kernels
         assert [sp.shape[0] for sp in env.observation_space] == obs_dims
         for sp, a in zip(env.action_space, acts):
             if isinstance(a, tuple):       # environment.py:58-61 MultiDiscrete([[0, n-1], ...])
                 assert list(sp.high - sp.low + 1) == list(a)
             else:
                 assert sp.n == a
-        assert not env.fused
+
+
+FUSED = ["simple_adversary", "simple_push"]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", NAMES)
-def test_step_teacher_forced_against_reference_golden(name, golden):
+@pytest.mark.parametrize("name,fused", [(n, False) for n in NAMES] + [(n, True) for n in FUSED],
+                         ids=[n + "-generic" for n in NAMES] + [n + "-fused" for n in FUSED])
+def test_step_teacher_forced_against_reference_golden(name, fused, golden):
     g = golden("f3_" + name)
     W, T = len(g["seeds"]), g["rew"].shape[0]
-    env = mpe.make_env(name, batch_size=W)
+    env = mpe.make_env(name, batch_size=W, fused=fused)
+    assert env.fused == fused
     A = env.n
     set_choices(env, g["choice"])
     worst = 0.0
@@ -156,3 +161,57 @@ def test_step_teacher_forced_against_reference_golden(name, golden):
             worst = max(worst, close(np_(env.world.agents[i].state.c), g["c%d" % i][t], what="t=%d c%d" % (t, i)))
             assert not np_(done_n[i]).any()
     print("max scaled err %s: %.3e" % (name, worst))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FUSED)
+def test_fused_kernel_equals_generic_path_at_size(name):
+    """65 536 random worlds: the fused kernel (KIND specialisation of k_split) against the generic path
+    (torch callbacks written from the reference + mpe_world_step), same states, goals and actions."""
+    B = 65536
+    rs = np.random.RandomState(9)
+    ef = mpe.make_env(name, batch_size=B)
+    eg = mpe.make_env(name, batch_size=B, fused=False)
+    assert ef.fused and not eg.fused
+    A, E = len(ef.world.agents), len(ef.world.entities)
+    pos = rs.uniform(-1, 1, (B, E, 2)).astype(np.float32)
+    pos[::3] *= 0.3
+    vel = rs.uniform(-0.5, 0.5, (B, A, 2)).astype(np.float32)
+    goal = torch.as_tensor(rs.randint(0, len(ef.world.landmarks), size=B))
+    for env in (ef, eg):
+        env.world.set_state(pos, vel)
+        env.scenario.set_goal(env.world, goal)
+    act = torch.as_tensor(np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=(A, B))]).cuda()
+    of, rf, df, _ = ef.step(act)
+    og, rg, dg, _ = eg.step([act[i] for i in range(A)])
+    pf, vf = ef.world.get_state()
+    pg, vg = eg.world.get_state()
+    close(pf, pg, what="pos")
+    close(vf, vg, what="vel")
+    for i in range(A):
+        close(np_(of[i]), np_(og[i]), what="obs%d" % i)
+        close(np_(rf[i]), np_(rg[i]), what="rew%d" % i)
+        assert not np_(df[i]).any()
+    # reset(): the fused kernel's observe half against the torch observation()
+    seeds = list(range(1000, 1000 + B))[:256]
+    ef2 = mpe.make_env(name, batch_size=256)
+    eg2 = mpe.make_env(name, batch_size=256, fused=False)
+    o_f, o_g = ef2.reset(seeds=seeds), eg2.reset(seeds=seeds)
+    for i in range(A):
+        close(np_(o_f[i]), np_(o_g[i]), what="reset obs%d" % i)
+
+
+@pytest.mark.gpu
+def test_device_reset_draws_goal_landmarks_bit_exact():
+    from oracle import philox
+    B, seed, offset = 5000, 0x1234567890ABCDEF, 77
+    env = mpe.make_env("simple_adversary", batch_size=B, seed=seed)
+    env.world.world_offset = offset
+    for ep in range(3):
+        env.world._episode = ep
+        env.scenario.reset_world(env.world)
+        want = philox.reset_choices(seed, B, ep, [2], world_offset=offset)
+        assert np.array_equal(np_(env.world.choice_i32), want)
+        assert np.array_equal(np_(env.scenario.goal_index), want[0])
+    frac = float(np_(env.world.choice_i32).mean())
+    assert 0.45 < frac < 0.55

@@ -31,15 +31,19 @@ def impl_env():
 
 
 @pytest.mark.parametrize("name,kw,B", [("simple", {}, 3000), ("simple_spread", {}, 5000), ("simple_tag", {}, 4097),
-                                       ("simple_spread", {"num_agents": 5}, 777)])
+                                       ("simple_spread", {"num_agents": 5}, 777),
+                                       ("simple_adversary", {}, 2000), ("simple_push", {}, 1111)])
 def test_split_and_thread_kernels_bit_identical(name, kw, B, impl_env):
     rs = np.random.RandomState(1)
     outs = {}
     for impl in ("split", "thread"):
         os.environ["MPE_STEP_IMPL"] = impl
-        env = mpe.make_env(name, benchmark=True, batch_size=B, **kw)
+        env = mpe.make_env(name, benchmark=name not in ("simple_adversary", "simple_push"), batch_size=B, **kw)
+        assert env.fused
         A, E = len(env.world.agents), len(env.world.entities)
         rs = np.random.RandomState(1)
+        if env.world.choice_i32 is not None:   # per-world goal landmarks
+            env.world.choice_i32.copy_(torch.as_tensor(rs.randint(0, len(env.world.landmarks), size=(1, B)).astype(np.int32)))
         pos = rs.uniform(-1, 1, (B, E, 2)).astype(np.float32)
         pos[::2] *= 0.3
         vel = rs.uniform(-1, 1, (B, A, 2)).astype(np.float32)
@@ -59,7 +63,8 @@ def test_split_and_thread_kernels_bit_identical(name, kw, B, impl_env):
 
 
 @pytest.mark.parametrize("name,kw,B,T,ep", [("simple_spread", {}, 1500, 60, 25), ("simple_tag", {}, 700, 30, 7),
-                                            ("simple", {}, 300, 12, 0), ("simple_spread", {"num_agents": 4}, 200, 9, 4)])
+                                            ("simple", {}, 300, 12, 0), ("simple_spread", {"num_agents": 4}, 200, 9, 4),
+                                            ("simple_adversary", {}, 900, 30, 5), ("simple_push", {}, 500, 20, 4)])
 def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):
     seed, offset, step0 = 0xABCDEF0123, 4096, 50 if ep in (25, 0) else 14
     # --- stepwise: explicit reset / random_actions / step through the C ABI ----------------------
@@ -73,6 +78,7 @@ def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):
     lr = env_a.scenario.landmark_range
     start_pos = env_a.world.pos.clone()
     start_vel = env_a.world.vel.clone()
+    start_choice = env_a.world.choice_i32.clone() if env_a.world.choice_i32 is not None else None
     want_obs, want_rew = [], []
     b = env_a._sets[0].bufs
     for t in range(T):
@@ -89,6 +95,8 @@ def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):
     env_b.world.world_offset = offset
     env_b.world.pos.copy_(start_pos)
     env_b.world.vel.copy_(start_vel)
+    if start_choice is not None:
+        env_b.world.choice_i32.copy_(start_choice)
     roll = RandomRollout(env_b, episode_len=ep, pool=2, seed=seed)
     roll.t = step0
     traj = Trajectory(env_b, T)
@@ -100,11 +108,15 @@ def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):
         assert torch.equal(traj.rew[t], want_rew[t]), t
         assert not traj.done[t].any()
     assert torch.equal(env_b.world.pos, env_a.world.pos) and torch.equal(env_b.world.vel, env_a.world.vel)
+    if start_choice is not None:   # in-kernel resets re-drew the goals exactly as mpe_reset does
+        assert torch.equal(env_b.world.choice_i32, env_a.world.choice_i32)
     # --- overwrite mode leaves the last step's outputs in the env's buffers --------------------------
     env_c = mpe.make_env(name, batch_size=B, seed=seed, **kw)
     env_c.world.world_offset = offset
     env_c.world.pos.copy_(start_pos)
     env_c.world.vel.copy_(start_vel)
+    if start_choice is not None:
+        env_c.world.choice_i32.copy_(start_choice)
     roll_c = RandomRollout(env_c, episode_len=ep, pool=2, seed=seed)
     roll_c.t = step0
     out = roll_c.fused(T)

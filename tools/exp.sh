@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -12
+python -m pytest tests -m gpu -x -q 2>&1 | tail -25
