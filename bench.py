@@ -32,11 +32,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def algorithmic_bytes(A, L, obs_total, n_choices=0):
+def algorithmic_bytes(A, L, obs_total, n_choices=0, comm_floats=0):
     """Compulsory HBM bytes per env-step: read agent pos+vel, landmark pos, one-hot
     actions (+ the per-world goal index where the scenario has one); write agent pos+vel, obs, reward
     (fp32) + done (1 byte per agent)."""
-    reads = 4 * A + 2 * L + 5 * A + n_choices
+    reads = 4 * A + 2 * L + 5 * A + n_choices + comm_floats
     writes = 4 * A + obs_total + A
     return 4 * (reads + writes) + A
 
@@ -204,7 +204,8 @@ def main():
     rolls = [RandomRollout(e, episode_len=EP, pool=16) for e in envs]
     roll = StreamedRollout(rolls)
     obs_total = int(env._obs_off[-1])
-    bytes_step = algorithmic_bytes(A, Lm, obs_total, len(env.world.choice_pops))
+    speakers = sum(1 for a in env.world.agents if not a.silent)
+    bytes_step = algorithmic_bytes(A, Lm, obs_total, len(env.world.choice_pops), speakers * env.world.dim_c)
     can_fuse = A <= 6
     trajs = None
 

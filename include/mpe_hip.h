@@ -25,6 +25,7 @@
  *         exactly the [B, D_i] array obs_n[i] of the drop-in API        (environment.py:93)
  *   rew   [A][B]   done [A][B] (uint8, always 0: environment.py:132-135)
  *   info_* [A][B]  benchmark_data columns                                (simple_spread.py:47-63, simple_tag.py:57-66)
+ *   comm  [A][B][dim_c] communication action rows of the agents that speak (environment.py:183-190)
  *   choice [K][B]  int32 per-world picks of reset_world, e.g. the goal landmark index (simple_adversary.py:44)
  */
 #ifndef MPE_HIP_H_
@@ -37,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 2
+#define MPE_ABI_VERSION 3
 #define MPE_MAX_ENTITIES 512 /* agents + landmarks per world */
 #define MPE_ACTION_DIM 5     /* Discrete(dim_p*2+1), environment.py:45 */
 #define MPE_MAX_CHOICES 4    /* np.random.choice draws a reset_world makes before the positions */
@@ -54,7 +55,11 @@ enum MpeScenarioKind {
   MPE_SCN_SPREAD = 2,  /* multiagent/scenarios/simple_spread.py:47-100                         */
   MPE_SCN_TAG = 3,     /* multiagent/scenarios/simple_tag.py:57-147                            */
   MPE_SCN_ADVERSARY = 4, /* multiagent/scenarios/simple_adversary.py:76-139 (per-world goal landmark) */
-  MPE_SCN_PUSH = 5       /* multiagent/scenarios/simple_push.py:60-96      (per-world goal landmark) */
+  MPE_SCN_PUSH = 5,      /* multiagent/scenarios/simple_push.py:60-96      (per-world goal landmark) */
+  MPE_SCN_SPEAKER_LISTENER = 6, /* multiagent/scenarios/simple_speaker_listener.py:63-92 (comm, dim_c 3)   */
+  MPE_SCN_REFERENCE = 7,        /* multiagent/scenarios/simple_reference.py:57-83        (comm, dim_c 10)  */
+  MPE_SCN_CRYPTO = 8,           /* multiagent/scenarios/simple_crypto.py:97-169          (comm only, dim_c 4) */
+  MPE_SCN_WORLD_COMM = 9        /* multiagent/scenarios/simple_world_comm.py:143-289     (leader comm, dim_c 4) */
 };
 
 /*
@@ -100,6 +105,8 @@ typedef struct MpeBuffers {
   int32_t *info_occupied;   /* spread */
   float *force;             /* [A][2][B] scratch, only for the phase-level entry points        */
   const float *entity_table; /* device copy of mpe_fill_entity_table(); needed when A+L > 16   */
+  const float *comm;         /* [A][B][dim_c] communication action rows (Action.c, environment.py:183-190); an agent's
+                                row becomes its AgentState.c (core.py:171-177, no c_noise); rows of silent agents unused */
   int32_t *choice;           /* [n_choices][B] per-world picks (landmark indices): read by step/observe of the
                                 scenarios that have them, written by mpe_reset / in-kernel resets             */
 } MpeBuffers;

@@ -39,12 +39,22 @@ int check_desc(const MpeScenarioDesc *d, const char *what) {
   if (d->n_agents < 1 || d->n_landmarks < 0 || d->n_agents + d->n_landmarks > MPE_MAX_ENTITIES)
     return fail(MPE_EINVAL, "%s: need 1 <= A, 0 <= L, A+L <= %d (got A=%d L=%d)", what, MPE_MAX_ENTITIES,
                 d->n_agents, d->n_landmarks);
-  if (d->kind < MPE_SCN_GENERIC || d->kind > MPE_SCN_PUSH) return fail(MPE_EINVAL, "%s: bad kind %d", what, d->kind);
+  if (d->kind < MPE_SCN_GENERIC || d->kind > MPE_SCN_WORLD_COMM) return fail(MPE_EINVAL, "%s: bad kind %d", what, d->kind);
   for (int e = d->n_agents; e < d->n_agents + d->n_landmarks; ++e)
     if (d->movable[e]) return fail(MPE_EUNSUPPORTED, "%s: movable landmarks are not supported (entity %d)", what, e);
   for (int e = 0; e < d->n_agents; ++e)
     if (!(d->mass[e] > 0.f)) return fail(MPE_EINVAL, "%s: mass[%d] must be > 0", what, e);
-  const bool teams = d->kind == MPE_SCN_TAG || d->kind == MPE_SCN_ADVERSARY || d->kind == MPE_SCN_PUSH;
+  const bool teams = d->kind == MPE_SCN_TAG || d->kind == MPE_SCN_ADVERSARY || d->kind == MPE_SCN_PUSH ||
+                     d->kind == MPE_SCN_WORLD_COMM;
+  // the communication scenarios exist in the reference's shapes only
+  struct Shape { int kind, A, L, dim_c, n_choices, nadv; };
+  static const Shape kComm[] = {{MPE_SCN_SPEAKER_LISTENER, 2, 3, 3, 1, 0}, {MPE_SCN_REFERENCE, 2, 3, 10, 2, 0},
+                                {MPE_SCN_CRYPTO, 3, 2, 4, 2, 1}, {MPE_SCN_WORLD_COMM, 6, 5, 4, 0, 4}};
+  for (const Shape &sh : kComm)
+    if (d->kind == sh.kind && (d->n_agents != sh.A || d->n_landmarks != sh.L || d->dim_c != sh.dim_c ||
+                               d->n_choices != sh.n_choices || (sh.nadv && d->n_adversaries != sh.nadv)))
+      return fail(MPE_EUNSUPPORTED, "%s: kind %d is built for A=%d L=%d dim_c=%d n_choices=%d (got A=%d L=%d dim_c=%d n_choices=%d)",
+                  what, sh.kind, sh.A, sh.L, sh.dim_c, sh.n_choices, d->n_agents, d->n_landmarks, d->dim_c, d->n_choices);
   if (teams && (d->n_adversaries < 1 || d->n_adversaries >= d->n_agents))
     return fail(MPE_EINVAL, "%s: this scenario needs 1 <= n_adversaries < A", what);
   if ((d->kind == MPE_SCN_SPREAD || d->kind == MPE_SCN_TAG) && d->dim_c != 2)
@@ -165,6 +175,13 @@ int mpe_fill_obs_layout(MpeScenarioDesc *d) {
       case MPE_SCN_PUSH:                                                           // simple_push.py:78-96
         D = i < d->n_adversaries ? 2 + 2 * L + 2 * (A - 1) : 2 + 2 + 3 + 2 * L + 3 * L + 2 * (A - 1);
         break;
+      case MPE_SCN_SPEAKER_LISTENER: D = i == 0 ? 3 : 2 + 2 * L + d->dim_c; break;  // simple_speaker_listener.py:69-92
+      case MPE_SCN_REFERENCE: D = 2 + 2 * L + 3 + d->dim_c; break;                  // simple_reference.py:63-83
+      case MPE_SCN_CRYPTO: D = i == 0 ? d->dim_c : 2 * d->dim_c; break;             // simple_crypto.py:127-169
+      case MPE_SCN_WORLD_COMM:                                                      // simple_world_comm.py:231-289
+        D = i < d->n_adversaries ? 4 + 2 * L + 2 * (A - 1) + 2 * (A - d->n_adversaries) + 2 + d->dim_c
+                                 : 4 + 2 * L + 2 * (A - 1) + 2 + 2 * (A - d->n_adversaries - 1);
+        break;
       default: D = 0;
     }
     d->obs_off[i + 1] = d->obs_off[i] + D;
@@ -197,8 +214,10 @@ static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, 
     if (d->kind == MPE_SCN_GENERIC) return fail(MPE_EINVAL, "%s: kind GENERIC has no output stage", what);
     if (int rc = need(b->obs, what, "obs")) return rc;
     if (int rc = check_info(d, b, what)) return rc;
-    if (d->kind == MPE_SCN_ADVERSARY || d->kind == MPE_SCN_PUSH)
-      if (int rc = need(b->choice, what, "choice (the per-world goal landmark index)")) return rc;
+    if (d->n_choices > 0 && d->kind >= MPE_SCN_ADVERSARY)
+      if (int rc = need(b->choice, what, "choice (the per-world picks of reset_world)")) return rc;
+    if (d->kind >= MPE_SCN_SPEAKER_LISTENER)
+      if (int rc = need(b->comm, what, "comm (communication action rows / current comm state)")) return rc;
   }
   if (B == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -210,13 +229,16 @@ static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, 
     dd.kind = MPE_SCN_GENERIC;
     use = &dd;
   }
-  if (phys && out && d->n_agents + d->n_landmarks <= mpe::kNarrowMaxE && step_impl() != StepImpl::Thread &&
+  const bool comm_kind = kind >= MPE_SCN_SPEAKER_LISTENER;   // these exist as wave-per-agent kernels only
+  if (out && (phys || comm_kind) && d->n_agents + d->n_landmarks <= mpe::kNarrowMaxE &&
+      (comm_kind || step_impl() != StepImpl::Thread) &&
       mpe::split_supports(kind, d->n_agents, d->n_landmarks, d->n_adversaries)) {
     // the fused step: wave-per-agent / lane-per-world (mpe_split.hip)
     const mpe::NarrowDesc n = make_narrow(use, b, (size_t)B);
     mpe::RollArgs ra;
     std::memset(&ra, 0, sizeof(ra));
     ra.T = 1;
+    ra.observe_only = phys ? 0 : 1;
     return hip_result(mpe::launch_split(false, kind, d->n_agents, d->n_landmarks, d->n_adversaries, n, *b, (size_t)B,
                                         ra, s), what);
   }
@@ -301,8 +323,10 @@ int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
   if (int rc = check_state(b, B, what)) return rc;
   if (int rc = need(b->obs, what, "obs")) return rc;
   if (int rc = check_info(d, b, what)) return rc;
-  if (d->kind == MPE_SCN_ADVERSARY || d->kind == MPE_SCN_PUSH)
-    if (int rc = need(b->choice, what, "choice (the per-world goal landmark index)")) return rc;
+  if (d->n_choices > 0 && d->kind >= MPE_SCN_ADVERSARY)
+    if (int rc = need(b->choice, what, "choice (the per-world picks of reset_world)")) return rc;
+  if (d->kind >= MPE_SCN_SPEAKER_LISTENER)
+    return fail(MPE_EUNSUPPORTED, "%s: the random rollout draws moves only; communication scenarios step through mpe_step", what);
   if (T < 0 || episode_len < 0) return fail(MPE_EINVAL, "%s: T, episode_len must be >= 0", what);
   if (B == 0 || T == 0) return 0;
   if (d->n_agents + d->n_landmarks > mpe::kNarrowMaxE ||
@@ -310,6 +334,7 @@ int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
     return fail(MPE_EUNSUPPORTED, "%s: the fused rollout exists for the wave-per-agent shapes only", what);
   const mpe::NarrowDesc n = make_narrow(d, b, (size_t)B);
   mpe::RollArgs ra;
+  std::memset(&ra, 0, sizeof(ra));
   ra.T = T;
   ra.episode_len = episode_len;
   ra.trajectory = trajectory ? 1 : 0;

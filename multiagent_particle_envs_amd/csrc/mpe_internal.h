@@ -37,6 +37,7 @@ struct RollArgs {
   int32_t T;            // steps in this launch (ignored by the single-step kernel)
   int32_t episode_len;  // in-kernel reset every episode_len global steps; 0 = never
   int32_t trajectory;   // outputs of step t go to block t of the output buffers (else: overwrite block 0)
+  int32_t observe_only; // single-step kernel: skip World.step, emit the outputs of the current state (mpe_observe)
   float landmark_range;
   uint64_t seed, step0, world_offset;
 };

@@ -33,12 +33,24 @@ struct SplitShape {
   static constexpr int E = A + L;
   // floats an agent publishes per world: pos, vel, then squared distances to the landmarks the reward needs
   static constexpr int XW = KIND == MPE_SCN_SPREAD ? 4 + L
-                            : (KIND == MPE_SCN_SIMPLE || KIND == MPE_SCN_ADVERSARY || KIND == MPE_SCN_PUSH) ? 5 : 4;
+                            : (KIND == MPE_SCN_SIMPLE || KIND == MPE_SCN_ADVERSARY || KIND == MPE_SCN_PUSH ||
+                               KIND == MPE_SCN_SPEAKER_LISTENER || KIND == MPE_SCN_REFERENCE) ? 5
+                            : KIND == MPE_SCN_WORLD_COMM ? 6 : 4;
+  // World.dim_c of the communication scenarios (make_world of each)
+  static constexpr int DC = KIND == MPE_SCN_SPEAKER_LISTENER ? 3 : KIND == MPE_SCN_REFERENCE ? 10
+                            : (KIND == MPE_SCN_CRYPTO || KIND == MPE_SCN_WORLD_COMM) ? 4 : 2;
+  // per-world picks this kernel reads (MpeBuffers.choice rows)
+  static constexpr int NCH = (KIND == MPE_SCN_ADVERSARY || KIND == MPE_SCN_PUSH || KIND == MPE_SCN_SPEAKER_LISTENER) ? 1
+                             : (KIND == MPE_SCN_REFERENCE || KIND == MPE_SCN_CRYPTO) ? 2 : 0;
   static constexpr int DMAX = KIND == MPE_SCN_SIMPLE   ? 2 + 2 * L
                               : KIND == MPE_SCN_SPREAD ? 4 + 2 * L + 4 * (A - 1)
                               : KIND == MPE_SCN_TAG    ? 4 + 2 * L + 2 * (A - 1) + 2 * (A - NADV)
                               : KIND == MPE_SCN_ADVERSARY ? 2 + 2 * L + 2 * (A - 1)
                               : KIND == MPE_SCN_PUSH   ? 7 + 5 * L + 2 * (A - 1)
+                              : KIND == MPE_SCN_SPEAKER_LISTENER ? 2 + 2 * L + 3
+                              : KIND == MPE_SCN_REFERENCE ? 2 + 2 * L + 3 + 10
+                              : KIND == MPE_SCN_CRYPTO ? 8
+                              : KIND == MPE_SCN_WORLD_COMM ? 4 + 2 * L + 2 * (A - 1) + 2 * (A - NADV) + 2 + 4
                                                        : 1;
   static constexpr int TILE = kWave * (DMAX | 1);  // >= kWave * tile_stride<D>() of every row width used
   static constexpr int WAVES = A + 1;              // A agent waves + the reward wave
@@ -51,7 +63,8 @@ struct SplitShape {
 // X is the exchange block the agent waves filled: X[(a * XW + c) * 64 + lane], c = 0,1 pos, 2,3 vel, 4.. d2.
 template <int KIND, int A, int L, int NADV>
 __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffers &b, const float *X, int lane,
-                                            bool live, unsigned ln, size_t B, size_t ro /* uniform: row 0 of this step + w0 */) {
+                                            bool live, unsigned ln, size_t B, size_t w0 /* first world of the wave */,
+                                            size_t ro /* uniform: row 0 of this step + w0 */) {
   constexpr int XW = SplitShape<KIND, A, L, NADV>::XW;
   if (KIND == MPE_SCN_SIMPLE) {  // simple.py:41-43: -|pos - landmark 0|^2
     if (live) {
@@ -202,6 +215,117 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
       }
     }
   }
+  if constexpr (KIND == MPE_SCN_SPEAKER_LISTENER) {  // simple_speaker_listener.py:63-67: -|listener - goal landmark|^2 for both
+    if (live) {
+      const float r = -X[(1 * XW + 4) * kWave + lane];
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        const size_t o = ro + (size_t)a * B;
+        if (b.rew) (b.rew + wave_off(o))[ln] = d.collaborative ? r + r : r;
+        if (b.done) (b.done + wave_off(o))[ln] = 0;
+      }
+    }
+  }
+  if constexpr (KIND == MPE_SCN_REFERENCE) {  // simple_reference.py:57-61: agent i wants the OTHER agent at i's goal landmark
+    if (live) {
+      const float r0 = -X[(1 * XW + 4) * kWave + lane];   // |pos_1 - landmark goal_0|^2, published by agent 1
+      const float r1 = -X[(0 * XW + 4) * kWave + lane];
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        const size_t o = ro + (size_t)a * B;
+        if (b.rew) (b.rew + wave_off(o))[ln] = d.collaborative ? r0 + r1 : (a == 0 ? r0 : r1);
+        if (b.done) (b.done + wave_off(o))[ln] = 0;
+      }
+    }
+  }
+  if constexpr (KIND == MPE_SCN_CRYPTO) {  // simple_crypto.py:97-124: squared error of what Bob / Eve say against the goal one-hot
+    constexpr int DC = SplitShape<KIND, A, L, NADV>::DC;
+    if (live) {
+      const int g = (b.choice + wave_off(w0))[ln];
+      float err[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {   // a = 0: Eve (adversary), a = 1: Bob (good listener)
+        const float *c = b.comm + wave_off(((size_t)a * B + w0) * DC) + ln * DC;
+        float e = 0.f;
+        bool silent = true;
+#pragma unroll
+        for (int k = 0; k < DC; ++k) {
+          const float v = c[k], dv = v - (k == g ? 1.f : 0.f);
+          silent = silent && (v == 0.f);
+          e = e + dv * dv;
+        }
+        err[a] = silent ? 0.f : e;   // `continue` on an all-zero utterance (:107, :112, :122)
+      }
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        const float r = a == 0 ? 0.f - err[0] : (0.f + err[0]) + (0.f - err[1]);
+        const size_t o = ro + (size_t)a * B;
+        if (b.rew) (b.rew + wave_off(o))[ln] = r;
+        if (b.done) (b.done + wave_off(o))[ln] = 0;
+      }
+    }
+  }
+  if constexpr (KIND == MPE_SCN_WORLD_COMM) {  // simple_world_comm.py:143-203
+    constexpr int NG = A - NADV;
+    float px[A], py[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      px[a] = X[(a * XW + 0) * kWave + lane];
+      py[a] = X[(a * XW + 1) * kWave + lane];
+    }
+    bool hit[NG][NADV];
+    float dmin[NADV];   // adversary v: distance to the nearest good agent
+#pragma unroll
+    for (int v = 0; v < NADV; ++v) dmin[v] = INFINITY;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int v = 0; v < NADV; ++v) {
+        const float d2 = sq2d(px[NADV + g] - px[v], py[NADV + g] - py[v]);
+        hit[g][v] = sqrt_lt(d2, d.size[NADV + g] + d.size[v]);
+        dmin[v] = fminf(dmin[v], d2);
+      }
+    // food = landmarks 1, 2 (world.landmarks = [obstacle] + food + forests)
+    float fx[2], fy[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      fx[f] = (b.pos + wave_off((size_t)(2 * (A + 1 + f)) * B + w0))[ln];
+      fy[f] = (b.pos + wave_off((size_t)(2 * (A + 1 + f) + 1) * B + w0))[ln];
+    }
+    if (live) {
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        float r = 0.f;
+        if (a < NADV) {   // adversary_reward :188-203 (shape = True)
+          r = r - 0.1f * fast_sqrt(dmin[a < NADV ? a : 0]);
+          if ((d.collide >> a) & 1u) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+              for (int v = 0; v < NADV; ++v) r = r + (hit[g][v] ? 5.f : 0.f);
+          }
+        } else {          // agent_reward :156-186
+          if ((d.collide >> a) & 1u) {
+#pragma unroll
+            for (int v = 0; v < NADV; ++v) r = r - (hit[a >= NADV ? a - NADV : 0][v] ? 5.f : 0.f);
+          }
+          r = r - 2.f * tag_bound(fabsf(px[a]));
+          r = r - 2.f * tag_bound(fabsf(py[a]));
+          float m2 = INFINITY;
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const float d2 = sq2d(px[a] - fx[f], py[a] - fy[f]);
+            r = r + (sqrt_lt(d2, d.size[a] + d.size[A + 1 + f]) ? 2.f : 0.f);
+            m2 = fminf(m2, d2);
+          }
+          r = r + 0.05f * fast_sqrt(m2);
+        }
+        const size_t o = ro + (size_t)a * B;
+        if (b.rew) (b.rew + wave_off(o))[ln] = r;
+        if (b.done) (b.done + wave_off(o))[ln] = 0;
+      }
+    }
+  }
 }
 
 template <int KIND, int A, int L, int NADV, bool ROLL>
@@ -235,7 +359,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
     for (int t = 0; t < T; ++t) {
       const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
       __syncthreads();
-      reward_wave<KIND, A, L, NADV>(d, b, X, lane, live, ln, B, (size_t)t * row_stride + w0);
+      reward_wave<KIND, A, L, NADV>(d, b, X, lane, live, ln, B, w0, (size_t)t * row_stride + w0);
     }
     return;
   }
@@ -265,7 +389,11 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 
   const uint64_t gw = ra.world_offset + w;  // global world number (RNG streams)
   constexpr bool HAS_GOAL = KIND == MPE_SCN_ADVERSARY || KIND == MPE_SCN_PUSH;
-  int goal = HAS_GOAL ? (b.choice + wave_off(w0))[ln] : 0;   // this world's goal landmark (np.random.choice at reset)
+  constexpr int NCH = S::NCH, DC = S::DC;
+  // this world's picks of reset_world (np.random.choice: goal landmark, key ...)
+  int goal = NCH >= 1 ? (b.choice + wave_off(w0))[ln] : 0;
+  const int pick1 = NCH >= 2 ? (b.choice + wave_off(B + w0))[ln] : 0;
+  const bool step_world = ROLL || !ra.observe_only;   // mpe_observe: outputs of the current state only
 
   // resets fall on global steps that are multiples of episode_len: one 64-bit divide up front, then a
   // countdown (a per-step 64-bit modulo costs ~130 instructions on this ISA)
@@ -297,13 +425,16 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       const int m = action_draw(ra.seed, gw, gt, i);  // the one-hot row mpe_random_actions would write
       ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * accel_i;
       uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * accel_i;
-    } else {
+    } else if (step_world && movable_i) {
       fetch_action_wave(b, B, i, w0, ln, accel_i, ux, uy);
+    } else {
+      ux = 0.f;
+      uy = 0.f;
     }
 
     // ---- World.step for agent i (core.py:117-169): action force, contacts with every other entity
     //      in ascending order (Q9), integrate ------------------------------------------------------
-    if (movable_i) {
+    if (movable_i && step_world) {
       float fx = ux + 0.f, fy = uy + 0.f;
       if (collide_i) {
 #pragma unroll
@@ -337,9 +468,19 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
     }
     if (KIND == MPE_SCN_SIMPLE) X[(i * XW + 4) * kWave + lane] = sq2d(mx - px[A], my - py[A]);
     float gx = 0.f, gy = 0.f;
-    if (HAS_GOAL) {
+    if (HAS_GOAL || KIND == MPE_SCN_SPEAKER_LISTENER) {
       goal_pos<A, L>(px, py, goal, gx, gy);
       X[(i * XW + 4) * kWave + lane] = sq2d(mx - gx, my - gy);
+    }
+    if constexpr (KIND == MPE_SCN_REFERENCE) {   // what the OTHER agent's reward needs: my distance to its goal landmark
+      goal_pos<A, L>(px, py, i == 0 ? pick1 : goal, gx, gy);
+      X[(i * XW + 4) * kWave + lane] = sq2d(mx - gx, my - gy);
+    }
+    if constexpr (KIND == MPE_SCN_WORLD_COMM) {  // am I inside forest 0 / forest 1 (landmarks 3, 4)?  strict dist < size + size
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+        X[(i * XW + 4 + f) * kWave + lane] =
+            sqrt_lt(sq2d(mx - px[A + 3 + f], my - py[A + 3 + f]), size_i + d.size[A + 3 + f]) ? 1.f : -1.f;
     }
     __syncthreads();
 #pragma unroll
@@ -465,6 +606,99 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       if (adv) row(std::integral_constant<int, DA>{}, std::false_type{});
       else     row(std::integral_constant<int, DG>{}, std::true_type{});
     }
+    if constexpr (KIND == MPE_SCN_SPEAKER_LISTENER) {  // simple_speaker_listener.py:69-92
+      if (i == 0) {   // speaker: the goal landmark's colour (0.65 on channel goal, 0.15 elsewhere)
+        constexpr int D = 3, RS = tile_stride<D>();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put1<RS>(tile, lane, c, goal == c ? 0.65f : 0.15f);
+        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      } else {        // listener: vel, landmarks, what the speaker says
+        constexpr int D = 2 + 2 * L + DC, RS = tile_stride<D>();
+        put1<RS>(tile, lane, 0, mvx); put1<RS>(tile, lane, 1, mvy);
+#pragma unroll
+        for (int l = 0; l < L; ++l) { put1<RS>(tile, lane, 2 + 2 * l, px[A + l] - mx); put1<RS>(tile, lane, 3 + 2 * l, py[A + l] - my); }
+        const float *c0 = b.comm + wave_off(((size_t)0 * B + w0) * DC) + ln * DC;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, 2 + 2 * L + c, c0[c]);
+        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      }
+    }
+    if constexpr (KIND == MPE_SCN_REFERENCE) {  // simple_reference.py:63-83
+      constexpr int D = 2 + 2 * L + 3 + DC, RS = tile_stride<D>();
+      const int mine = i == 0 ? goal : pick1;   // agent.goal_b
+      put1<RS>(tile, lane, 0, mvx); put1<RS>(tile, lane, 1, mvy);
+#pragma unroll
+      for (int l = 0; l < L; ++l) { put1<RS>(tile, lane, 2 + 2 * l, px[A + l] - mx); put1<RS>(tile, lane, 3 + 2 * l, py[A + l] - my); }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) put1<RS>(tile, lane, 2 + 2 * L + c, mine == c ? 0.75f : 0.25f);   // goal_b.color
+      const float *co = b.comm + wave_off(((size_t)(1 - i) * B + w0) * DC) + ln * DC;
+#pragma unroll
+      for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, 5 + 2 * L + c, co[c]);
+      flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+    }
+    if constexpr (KIND == MPE_SCN_CRYPTO) {  // simple_crypto.py:127-169 (goal = pick 0, key = pick 1; colours are one-hots of width dim_c)
+      const float *cs = b.comm + wave_off(((size_t)2 * B + w0) * DC) + ln * DC;   // the speaker's utterance
+      if (i == 0) {          // Eve: what the speaker says
+        constexpr int D = DC, RS = tile_stride<D>();
+#pragma unroll
+        for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, c, cs[c]);
+        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      } else {
+        constexpr int D = 2 * DC, RS = tile_stride<D>();
+        if (i == 1) {        // Bob: key, utterance
+#pragma unroll
+          for (int c = 0; c < DC; ++c) { put1<RS>(tile, lane, c, pick1 == c ? 1.f : 0.f); put1<RS>(tile, lane, DC + c, cs[c]); }
+        } else {             // Alice: goal colour, key
+#pragma unroll
+          for (int c = 0; c < DC; ++c) { put1<RS>(tile, lane, c, goal == c ? 1.f : 0.f); put1<RS>(tile, lane, DC + c, pick1 == c ? 1.f : 0.f); }
+        }
+        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      }
+    }
+    if constexpr (KIND == MPE_SCN_WORLD_COMM) {  // simple_world_comm.py:231-289
+      constexpr int NG = A - NADV;
+      constexpr int DA = 4 + 2 * L + 2 * (A - 1) + 2 * NG + 2 + DC, DGd = 4 + 2 * L + 2 * (A - 1) + 2 + 2 * (NG - 1);
+      const bool f1 = X[(i * XW + 4) * kWave + lane] > 0.f, f2 = X[(i * XW + 5) * kWave + lane] > 0.f;
+      bool vis[A];   // may agent i see agent j: same forest, or both in the open; the leader sees everybody (:253)
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        const bool o1 = X[(j * XW + 4) * kWave + lane] > 0.f, o2 = X[(j * XW + 5) * kWave + lane] > 0.f;
+        vis[j] = i == 0 || (f1 && o1) || (f2 && o2) || (!f1 && !o1 && !f2 && !o2);
+      }
+      auto row = [&](auto dsel, auto advt) {
+        constexpr int D = decltype(dsel)::value, RS = tile_stride<D>();
+        constexpr bool ADV = decltype(advt)::value;
+        int k = 0;
+        put1<RS>(tile, lane, 0, mvx); put1<RS>(tile, lane, 1, mvy); put1<RS>(tile, lane, 2, mx); put1<RS>(tile, lane, 3, my);
+        k = 4;
+#pragma unroll
+        for (int l = 0; l < L; ++l) { put1<RS>(tile, lane, k, px[A + l] - mx); put1<RS>(tile, lane, k + 1, py[A + l] - my); k += 2; }
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+          if (j == i) continue;
+          put1<RS>(tile, lane, k, vis[j] ? px[j] - mx : 0.f);
+          put1<RS>(tile, lane, k + 1, vis[j] ? py[j] - my : 0.f);
+          k += 2;
+        }
+        if (!ADV) { put1<RS>(tile, lane, k, f1 ? 1.f : -1.f); put1<RS>(tile, lane, k + 1, f2 ? 1.f : -1.f); k += 2; }
+#pragma unroll
+        for (int j = NADV; j < A; ++j) {
+          if (j == i) continue;
+          put1<RS>(tile, lane, k, vis[j] ? X[(j * XW + 2) * kWave + lane] : 0.f);
+          put1<RS>(tile, lane, k + 1, vis[j] ? X[(j * XW + 3) * kWave + lane] : 0.f);
+          k += 2;
+        }
+        if (ADV) {
+          put1<RS>(tile, lane, k, f1 ? 1.f : -1.f); put1<RS>(tile, lane, k + 1, f2 ? 1.f : -1.f); k += 2;
+          const float *cl = b.comm + wave_off(((size_t)0 * B + w0) * DC) + ln * DC;   // world.agents[0].state.c
+#pragma unroll
+          for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, k + c, cl[c]);
+        }
+        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      };
+      if (i < NADV) row(std::integral_constant<int, DA>{}, std::true_type{});
+      else          row(std::integral_constant<int, DGd>{}, std::false_type{});
+    }
   }
   if (ROLL && HAS_GOAL && ra.episode_len > 0 && live && i == 0) (b.choice + wave_off(w0))[ln] = goal;
   if (ROLL && ra.episode_len > 0 && live) {
@@ -503,6 +737,8 @@ static const SplitEntry kSplitTable[] = {
     MPE_SPLIT_ENTRY(MPE_SCN_TAG, 4, 2, 3), MPE_SPLIT_ENTRY(MPE_SCN_TAG, 2, 1, 1),
     MPE_SPLIT_ENTRY(MPE_SCN_TAG, 6, 3, 4),
     MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 3, 2, 1), MPE_SPLIT_ENTRY(MPE_SCN_PUSH, 2, 2, 1),
+    MPE_SPLIT_ENTRY(MPE_SCN_SPEAKER_LISTENER, 2, 3, 0), MPE_SPLIT_ENTRY(MPE_SCN_REFERENCE, 2, 3, 0),
+    MPE_SPLIT_ENTRY(MPE_SCN_CRYPTO, 3, 2, 1), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 6, 5, 4),
 };
 
 static const SplitEntry *find_split(int kind, int A, int L, int nadv) {

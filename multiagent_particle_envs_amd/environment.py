@@ -65,6 +65,8 @@ class _OutputSet(object):
             b.entity_table = env._entity_table.data_ptr()
         if w.choice_i32 is not None:      # per-world picks (goal landmark ...): updated in place by resets
             b.choice = w.choice_i32.data_ptr()
+        if env._comm is not None:         # communication action rows = the agents' comm state
+            b.comm = env._comm.data_ptr()
         self.bufs = b
         self.reward_n = [self.rew[i] for i in range(A)]
         self.done_n = [self.done[i] for i in range(A)]
@@ -119,13 +121,14 @@ class MultiAgentEnv(object):
             (info_callback is None or (getattr(info_callback, "__self__", None) is sc and
                                        info_callback.__func__ is builtin.__dict__.get("benchmark_data"))) and \
             done_callback is None and len(world.scripted_agents) == 0 and \
-            all(a.silent and not a.u_noise for a in world.agents) and \
+            all((a.silent or (kind in _abi.COMM_KINDS and not a.c_noise)) and not a.u_noise for a in world.agents) and \
             not (info_callback is not None and kind in (_abi.MPE_SCN_ADVERSARY, _abi.MPE_SCN_PUSH))   # no fused benchmark_data there
         if fused is None:
             fused = own
         if fused and not own:
             raise _abi.MpeError("fused=True needs the unmodified callbacks of a built-in scenario")
         self.fused = bool(fused)
+        self._comm_kind = self.fused and kind in _abi.COMM_KINDS
         self._scenario = sc
         self._kind = kind if self.fused else _abi.MPE_SCN_GENERIC
         self._benchmark = self.fused and info_callback is not None
@@ -171,6 +174,7 @@ class MultiAgentEnv(object):
         self._flip = 0
         self._act = None
         self._ids = None
+        self._comm = None
         self._entity_table = None
         self.shared_viewer = shared_viewer
 
@@ -182,6 +186,8 @@ class MultiAgentEnv(object):
         w._require_device()
         A, B = len(w.agents), w.batch_size
         self._entity_table = w.entity_table(self._desc)   # read by the workgroup-per-world kernels only
+        if self._kind in _abi.COMM_KINDS:
+            self._comm = torch.zeros((A, B, w.dim_c), dtype=torch.float32, device=w.device)
         self._sets = [_OutputSet(self), _OutputSet(self)]
         self._act = torch.zeros((A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=w.device)
         self._ids = torch.zeros((A, B), dtype=torch.int32, device=w.device)
@@ -199,6 +205,8 @@ class MultiAgentEnv(object):
         """Bring the caller's actions into the [A,B,5] fp32 (or [A,B] int32) device layout; a tensor
         that already has it is used in place (zero copy)."""
         A, B = len(self.agents), self.batch_size
+        if self._comm is not None:
+            return self._stage_comm_actions(action_n), None
         if self.discrete_action_input:
             if torch.is_tensor(action_n) and action_n.shape == (A, B) and action_n.dtype == torch.int32 \
                     and action_n.is_cuda and action_n.is_contiguous():
@@ -221,11 +229,34 @@ class MultiAgentEnv(object):
             act = torch.zeros_like(act).scatter_(-1, idx, 1.0)
         return act, None
 
+    def _stage_comm_actions(self, action_n):
+        """Communication scenarios: agent i's action row is [move (5) if movable] + [utterance (dim_c) if not
+        silent] (Discrete / MultiDiscrete spaces, environment.py:148-155, 183-190).  The move part goes to
+        act [A,B,5], the utterance to comm [A,B,dim_c], which IS the agents' comm state after the step
+        (update_agent_state, core.py:171-177)."""
+        B, dc = self.batch_size, self.world.dim_c
+        for i, agent in enumerate(self.agents):
+            a = action_n[i]
+            a = a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), dtype=torch.float32)
+            a = a.to(self._act.device, torch.float32).reshape(-1, a.shape[-1]).expand(B, a.shape[-1])
+            k = 0
+            if agent.movable:
+                m = a[:, :_abi.MPE_ACTION_DIM]
+                if self.force_discrete_action:   # environment.py:169-172: argmax -> one-hot
+                    m = torch.zeros_like(m).scatter_(-1, m.argmax(dim=-1, keepdim=True), 1.0)
+                self._act[i].copy_(m)
+                k = _abi.MPE_ACTION_DIM
+            if not agent.silent:
+                self._comm[i].copy_(a[:, k:k + dc])
+                k += dc
+            assert k == a.shape[-1], "action row of agent %d has %d entries, expected %d" % (i, a.shape[-1], k)
+        return self._act
+
     # ------------------------------------------------------------------------------------------
     def step(self, action_n):
         """environment.py:80-104 for B worlds."""
         self.agents = self.world.policy_agents
-        if not self.fused:
+        if not self.fused or (self._comm_kind and self.discrete_action_input):
             return self._step_generic(action_n)
         self._ensure_buffers()
         act, ids = self._stage_actions(action_n)
@@ -235,6 +266,10 @@ class MultiAgentEnv(object):
         b.ids = ids.data_ptr() if ids is not None else None
         b.u = None
         _abi.check(_abi.lib().mpe_step(C.byref(self._desc), C.byref(b), self.batch_size, self._stream()), "mpe_step")
+        if self._comm is not None:   # update_agent_state (core.py:171-177): state.c = action.c for the agents that speak
+            for i, agent in enumerate(self.world.agents):
+                if not agent.silent:
+                    agent.state.c = self._comm[i]
         return self._deliver(out.obs_n, out.reward_n, out.done_n, out.info_n(self))
 
     def reset(self, seeds=None, mask=None):
@@ -252,6 +287,11 @@ class MultiAgentEnv(object):
             obs_n = [self._get_obs(agent) for agent in self.agents]
             return self._deliver(obs_n, None, None, None)[0]
         self._ensure_buffers()
+        if self._comm is not None:   # every reset_world zeroes the comm state (of the worlds it resets)
+            if mask is None:
+                self._comm.zero_()
+            else:
+                self._comm[:, torch.as_tensor(mask, device=self._comm.device).bool()] = 0.0
         out = self._next_set()
         b = out.bufs
         saved = (b.rew, b.done, b.info_rew, b.info_collisions, b.info_min_dists, b.info_occupied)

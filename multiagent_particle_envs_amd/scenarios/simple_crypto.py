@@ -3,6 +3,7 @@ moves (reference: multiagent/scenarios/simple_crypto.py).  Pure communication ga
 physics kernel has nothing to integrate: every agent is immovable)."""
 import torch
 
+from .. import _abi
 from ..core import World, Agent, Landmark, EntityChoice
 from ..scenario import BaseScenario
 from . import _util as U
@@ -15,6 +16,8 @@ class CryptoAgent(Agent):
 
 
 class Scenario(BaseScenario):
+    kind = _abi.MPE_SCN_CRYPTO   # fused kernel (wave-per-agent family)
+    num_adversaries = 1
     landmark_range = 1.0
 
     def make_world(self, batch_size=1, device=None):

@@ -2,12 +2,14 @@
 listener moves (reference: multiagent/scenarios/simple_speaker_listener.py).  Generic path."""
 import torch
 
+from .. import _abi
 from ..core import World, Agent, Landmark, EntityChoice
 from ..scenario import BaseScenario
 from . import _util as U
 
 
 class Scenario(BaseScenario):
+    kind = _abi.MPE_SCN_SPEAKER_LISTENER   # fused kernel (wave-per-agent family)
     landmark_range = 1.0
 
     def make_world(self, batch_size=1, device=None):

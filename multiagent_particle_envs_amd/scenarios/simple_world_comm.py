@@ -2,12 +2,15 @@
 a leader predator that can talk (reference: multiagent/scenarios/simple_world_comm.py).  Generic path."""
 import torch
 
+from .. import _abi
 from ..core import World, Agent, Landmark
 from ..scenario import BaseScenario
 from . import _util as U
 
 
 class Scenario(BaseScenario):
+    kind = _abi.MPE_SCN_WORLD_COMM   # fused kernel (wave-per-agent family)
+    num_adversaries = 4
     landmark_range = 0.9                           # simple_world_comm.py:104-113
 
     def make_world(self, batch_size=1, device=None):

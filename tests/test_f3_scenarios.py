@@ -121,7 +121,7 @@ def test_f3_spaces_match_the_reference():
             "simple_world_comm": ([34, 34, 34, 34, 28, 28], [(5, 4), 5, 5, 5, 5, 5])}
     for name, (obs_dims, acts) in want.items():
         env = mpe.make_env(name, batch_size=2, device="cpu")
-        assert env.fused == (name in ("simple_adversary", "simple_push"))   # these two have fused kernels
+        assert env.fused
         assert [sp.shape[0] for sp in env.observation_space] == obs_dims
         for sp, a in zip(env.action_space, acts):
             if isinstance(a, tuple):       # environment.py:58-61 MultiDiscrete([[0, n-1], ...])
@@ -130,7 +130,8 @@ def test_f3_spaces_match_the_reference():
                 assert sp.n == a
 
 
-FUSED = ["simple_adversary", "simple_push"]
+FUSED = list(NAMES)            # every one of them has a fused kernel (KIND specialisations of k_split)
+FUSED_ROLLOUT = ["simple_adversary", "simple_push"]
 
 
 @pytest.mark.gpu
@@ -163,6 +164,18 @@ def test_step_teacher_forced_against_reference_golden(name, fused, golden):
     print("max scaled err %s: %.3e" % (name, worst))
 
 
+def random_actions(env, rs, B):
+    acts = []
+    for agent in env.agents:
+        parts = []
+        if agent.movable:
+            parts.append(np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=B)])
+        if not agent.silent:
+            parts.append(rs.uniform(0, 1, size=(B, env.world.dim_c)).astype(np.float32))
+        acts.append(torch.as_tensor(np.concatenate(parts, axis=1)).cuda())
+    return acts
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", FUSED)
 def test_fused_kernel_equals_generic_path_at_size(name):
@@ -177,20 +190,22 @@ def test_fused_kernel_equals_generic_path_at_size(name):
     pos = rs.uniform(-1, 1, (B, E, 2)).astype(np.float32)
     pos[::3] *= 0.3
     vel = rs.uniform(-0.5, 0.5, (B, A, 2)).astype(np.float32)
-    goal = torch.as_tensor(rs.randint(0, len(ef.world.landmarks), size=B))
+    pops = ef.world.choice_pops
+    choice = np.stack([rs.randint(0, n, size=B) for n in pops], axis=1) if pops else np.zeros((B, 0), np.int64)
     for env in (ef, eg):
         env.world.set_state(pos, vel)
-        env.scenario.set_goal(env.world, goal)
-    act = torch.as_tensor(np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=(A, B))]).cuda()
+        set_choices(env, choice)
+    act = random_actions(ef, rs, B)
     of, rf, df, _ = ef.step(act)
-    og, rg, dg, _ = eg.step([act[i] for i in range(A)])
+    og, rg, dg, _ = eg.step(act)
     pf, vf = ef.world.get_state()
     pg, vg = eg.world.get_state()
     close(pf, pg, what="pos")
     close(vf, vg, what="vel")
     for i in range(A):
         close(np_(of[i]), np_(og[i]), what="obs%d" % i)
-        close(np_(rf[i]), np_(rg[i]), what="rew%d" % i)
+        close(np_(rf[i]) * np.ones(B), np_(rg[i]) * np.ones(B), what="rew%d" % i)
+        close(np_(ef.world.agents[i].state.c), np_(eg.world.agents[i].state.c), what="c%d" % i)
         assert not np_(df[i]).any()
     # reset(): the fused kernel's observe half against the torch observation()
     seeds = list(range(1000, 1000 + B))[:256]

@@ -55,7 +55,7 @@ def test_argument_validation_without_a_gpu():
     d.movable[4] = 1                                  # a movable landmark
     assert L.mpe_fill_obs_layout(C.byref(d)) == -2
     d.movable[4] = 0
-    d.kind = 9
+    d.kind = 99
     assert L.mpe_fill_obs_layout(C.byref(d)) == -1
     assert L.mpe_random_actions(None, None, 3, 8, 0, 0, 0, None) == -1
 
