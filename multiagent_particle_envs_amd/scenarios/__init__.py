@@ -17,6 +17,6 @@ def load(name):
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         return mod
-    raise FileNotFoundError("no scenario %r (built-in: the reference's nine: simple, simple_spread, simple_tag fused; "
+    raise FileNotFoundError("no scenario %r (built-in: the reference's nine -- simple, simple_spread, simple_tag, "
                             "simple_adversary, simple_push, simple_speaker_listener, simple_reference, simple_crypto, "
-                            "simple_world_comm on the generic path)" % name)
+                            "simple_world_comm; any other Scenario runs on the generic path)" % name)

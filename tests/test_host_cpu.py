@@ -145,7 +145,7 @@ def test_scenario_loader_and_generic_detection(tmp_path):
     assert mpe.scenarios.load("simple.py").Scenario.kind == _abi.MPE_SCN_SIMPLE
     with pytest.raises(FileNotFoundError):
         mpe.scenarios.load("simple_no_such_scenario.py")
-    assert not hasattr(mpe.scenarios.load("simple_crypto.py").Scenario, "kind")   # generic path: no fused kernel kind
+    assert mpe.scenarios.load("simple_crypto.py").Scenario.kind == _abi.MPE_SCN_CRYPTO
     # a subclass that overrides reward must NOT be routed to the fused kernel
     Base = mpe.scenarios.load("simple_spread.py").Scenario
 
