@@ -97,6 +97,17 @@ def cpu_baseline(scenario, okw, seconds, procs):
     return steps / wall, single[0] / single[1]
 
 
+def cpu_baseline_c(scenario, okw, seconds, threads):
+    """oracle/mpe_oracle.c -- the same algorithm in plain C (gcc -O2, OpenMP: one independent world per
+    thread): what compiled host code does with it.  Returns (aggregate, single-thread) env-steps/s or None."""
+    try:
+        from oracle import build_c, spec as ospec
+        spec = ospec.by_name(scenario, **okw)
+        return build_c.bench(spec, seconds, threads), build_c.bench(spec, min(seconds, 2.0), 1)
+    except Exception as e:  # the C restatement covers simple / simple_spread / simple_tag
+        return None
+
+
 def bench_generic(args, env, dev, rank, world, sharding):
     """Scenarios without a fused kernel: MultiAgentEnv.step() from Python -- torch
     _set_action, `mpe_world_step` (HIP), the scenario's torch observation/reward callbacks.  Host- and
@@ -357,6 +368,12 @@ def main():
                           "distribution, reset every 25 steps; 1 process alone: %.0f env-steps/s"
                           % (procs, args.cpu_seconds, single),
                 "single_core": single}
+            cp = cpu_baseline_c(args.scenario, okw, min(args.cpu_seconds, 4.0), procs)
+            if cp:
+                out["cpu_baseline"]["c_port"] = {
+                    "value": cp[0], "unit": "env-steps/s", "cores": procs, "single_core": cp[1],
+                    "sample": "oracle/mpe_oracle.c (the same algorithm in plain C, gcc -O2 -fopenmp, one world per "
+                              "thread, fp64), %d threads x %.0f s" % (procs, min(args.cpu_seconds, 4.0))}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -23,5 +23,6 @@ Modules
                   reference (Python loop + tiny NumPy ops per pair); the `cpu_baseline` "port"
   mpe_batched.py  the same arithmetic vectorised over B worlds, fp64 or fp32 -- the scalable truth
   philox.py       Philox4x32-10 + the uniform mapping used by the device reset / random actions
-  mpe_oracle.c    the fp64 step in plain C (threaded baseline; built by __graft_entry__.build)
+  mpe_oracle.c    the fp64 step in plain C (gcc; second checker + compiled-code CPU baseline; built by build_c.py)
+  build_c.py      gcc build + ctypes binding of mpe_oracle.c
 """

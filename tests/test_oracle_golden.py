@@ -136,3 +136,23 @@ def test_contact_kat():
         orc.set_state([[[0.0, 0.0], [d, 0.0]]], np.zeros((1, 2, 2)))
         f = orc.forces(orc.decode(np.zeros((2, 1, 5))))
         assert abs(f[0][0, 0] - fx) < 1e-9
+
+
+@pytest.mark.parametrize("name,spec,bench", CASES, ids=[c[0] for c in CASES])
+def test_c_restatement_matches_reference(name, spec, bench, golden):
+    """oracle/mpe_oracle.c (gcc, fp64) replayed from the reference's own states: same arithmetic in the
+    same order, so <= 1e-12; collision counts identical."""
+    from oracle import build_c
+    g = golden(name)
+    T, W, A = g["rew"].shape
+    for t in range(T):
+        p0 = g["pos0"] if t == 0 else g["pos"][t - 1]
+        v0 = g["vel0"] if t == 0 else g["vel"][t - 1]
+        pos, vel, obs, rew, col = build_c.step_batch(spec, p0, v0, g["act"][t], threads=2)
+        _close(pos, g["pos"][t])
+        _close(vel, g["vel"][t])
+        for i in range(A):
+            _close(obs[i], g["obs%d" % i][t])
+        _close(rew, g["rew"][t])
+        if "info_collisions" in g:
+            assert np.array_equal(col, g["info_collisions"][t])
