@@ -110,9 +110,6 @@ mpe::WideDesc make_wide(const MpeScenarioDesc *d) {
   w.dim_c = d->dim_c;
   w.collaborative = d->collaborative;
   w.D = d->obs_off[1] - d->obs_off[0];
-  w.obs_world_major = std::getenv("MPE_OBS_WORLD_MAJOR") ? 1 : 0;
-  w.obs_flat = std::getenv("MPE_WIDE_GENERIC_ROWS") ? 1 : 0;  // A/B switch: generic row emitter
-  w.stagger = std::getenv("MPE_WIDE_STAGGER") ? std::atoi(std::getenv("MPE_WIDE_STAGGER")) : 0;  // layout experiment switch
   w.dt = d->dt;
   w.damp = 1.0f - d->damping;
   w.cforce = d->contact_force;

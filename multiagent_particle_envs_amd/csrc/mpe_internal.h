@@ -17,9 +17,6 @@ int launch_phase(int phase, int A, int L, const NarrowDesc &d, const MpeBuffers 
 struct WideDesc {
   int32_t kind, A, L, dim_c, collaborative;
   int32_t D;  // obs width (spread: same for every agent)
-  int32_t stagger;          // experiment switch: start-up skew of co-resident workgroups (x ~4 us per round)
-  int32_t obs_flat;         // experiment switch: flat obs store order
-  int32_t obs_world_major;  // observation block laid out [B][A][D] instead of A blocks of [B][D]
   float dt, damp, cforce, cmargin, cmargin_inv;
 };
 constexpr int kEntityTableCols = 6;  // size, mass, accel, max_speed, movable, collide  -> [6][E] floats

@@ -27,7 +27,6 @@
 // ONE XCD (blockIdx % 8 selects the XCD), so that the line is fetched into one L2, not eight.
 // Per pair the arithmetic is mpe_device.h's, as in the small-N kernels; sums over landmarks / agents
 // are reduction trees (documented in DESIGN.md 4).
-#include <cstdlib>
 
 #include "mpe_internal.h"
 
@@ -394,12 +393,11 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
 
     if (OUT) {
       // ---- observation rows (simple_spread.py:84-100): issued first, they drain while the reward is computed
-      const bool world_major = d.obs_world_major != 0;
-      const size_t rowlen = world_major ? (size_t)D : (size_t)B * D;
-      float *const obs_w = b.obs + (world_major ? w * (size_t)A * D : w * (size_t)D);
-      const bool vec4 = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 &&
-                        (world_major || ((B * (size_t)D) & 3) == 0);
-      if (vec4 && D <= 8 * kWave && d.obs_flat == 0)
+      // agent i's rows form one [B][D] block (obs_n[i] of the drop-in API): the rows of one world are B*D floats apart
+      const size_t rowlen = (size_t)B * D;
+      float *const obs_w = b.obs + w * (size_t)D;
+      const bool vec4 = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && ((B * (size_t)D) & 3) == 0;
+      if (vec4 && D <= 8 * kWave)
         emit_rows_fast(Q, V, A, L, D, obs_w, rowlen, lane);
       else if (vec4)
         emit_rows<4>(Q, V, A, L, D, obs_w, rowlen, lane);
@@ -493,9 +491,8 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
   const size_t groups = (B + kWavesPerWg - 1) / kWavesPerWg;
   const size_t padded = (groups + 63) / 64 * 64;
   if (padded > 0xffffffffull) return MPE_EUNSUPPORTED;
-  int bpc = 8;
-  if (const char *e = std::getenv("MPE_WIDE_BPC")) bpc = std::atoi(e);  // tuning experiment switch
-  size_t cap = (size_t)n_cu * (size_t)(bpc > 0 ? bpc : 1) / 64 * 64;
+  constexpr int bpc = 8;
+  size_t cap = (size_t)n_cu * (size_t)bpc / 64 * 64;
   if (cap < 64) cap = 64;
   const dim3 grid((unsigned)(padded < cap ? padded : cap)), block(kWavesPerWg * kWave);
   const unsigned np = (unsigned)padded;
