@@ -230,3 +230,27 @@ def test_device_reset_draws_goal_landmarks_bit_exact():
         assert np.array_equal(np_(env.scenario.goal_index), want[0])
     frac = float(np_(env.world.choice_i32).mean())
     assert 0.45 < frac < 0.55
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_compat_mode_episode_like_a_reference_caller(name, golden):
+    """The drop-in usage, verbatim: make_env(name) -> one world, NumPy in / NumPy out, np.random-seeded reset,
+    per-agent action rows as the reference takes them; a free-running episode against the golden one
+    (free-running fp32 vs fp64: looser bound than the teacher-forced tests)."""
+    g = golden("f3_" + name)
+    env = mpe.make_env(name)
+    assert env.fused and env.batch_size == 1
+    w = 0
+    np.random.seed(int(g["seeds"][w]))
+    obs = env.reset()
+    for i in range(env.n):
+        assert isinstance(obs[i], np.ndarray) and obs[i].ndim == 1
+        close(obs[i], g["obs_reset%d" % i][w], what="reset obs%d" % i)
+    for t in range(g["rew"].shape[0]):
+        act = [g["act%d" % i][t, w] for i in range(env.n)]
+        obs, rew, done, info = env.step(act)
+        for i in range(env.n):
+            close(obs[i], g["obs%d" % i][t, w], tol=1e-4, what="t=%d obs%d" % (t, i))
+        close(np.array(rew), g["rew"][t, w], tol=1e-4, what="t=%d rew" % t)
+        assert done == [False] * env.n
