@@ -118,7 +118,7 @@ size_t mpe_sizeof_desc(void);
 size_t mpe_sizeof_buffers(void);
 /* Observation widths of the built-in scenarios: fills desc->obs_off[0..A]; returns D_total or <0. */
 int mpe_fill_obs_layout(MpeScenarioDesc *desc);
-/* Per-entity constants as one float table for the workgroup-per-world kernels:
+/* Per-entity constants as one float table for the wave-per-world (large N) kernel:
  * returns the number of floats; writes them to host_out when it is not NULL. */
 int mpe_fill_entity_table(const MpeScenarioDesc *desc, float *host_out);
 

@@ -369,7 +369,7 @@ class World(object):
         return d
 
     def entity_table(self, desc):
-        """Device copy of the per-entity constant table (workgroup-per-world kernels)."""
+        """Device copy of the per-entity constant table (the wave-per-world kernel for large N reads it)."""
         if self._entity_table is None:
             n = _abi.lib().mpe_fill_entity_table(C.byref(desc), None)
             host = (C.c_float * n)()

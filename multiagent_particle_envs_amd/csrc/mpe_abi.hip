@@ -245,7 +245,7 @@ static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, 
                                          d->n_landmarks, d->n_adversaries, n, *b, (size_t)B, s), what);
   }
   if (kind == MPE_SCN_GENERIC || kind == MPE_SCN_SPREAD) {
-    if (int rc = need(b->entity_table, what, "entity_table (required by the workgroup-per-world kernels)")) return rc;
+    if (int rc = need(b->entity_table, what, "entity_table (required by the wave-per-world kernel)")) return rc;
     mpe::WideDesc w = make_wide(use);
     w.kind = kind;
     return hip_result(mpe::launch_wide(phys, out, w, *b, (size_t)B, s), what);

@@ -13,7 +13,7 @@ int launch_narrow(NarrowOp op, int kind, int A, int L, int nadv, const NarrowDes
 int launch_phase(int phase, int A, int L, const NarrowDesc &d, const MpeBuffers &b, size_t B,
                  hipStream_t stream);
 
-// workgroup-per-world family (mpe_wide.hip)
+// wave-per-world family for large entity counts (mpe_wide.hip)
 struct WideDesc {
   int32_t kind, A, L, dim_c, collaborative;
   int32_t D;  // obs width (spread: same for every agent)

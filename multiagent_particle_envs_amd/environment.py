@@ -12,9 +12,9 @@ info_n = {'n': [...]}.  In reference-compatibility mode (`batch_size=None` in ma
 world, NumPy in / NumPy out, NumPy-global-RNG resets) the env is used exactly like the reference's.
 
 Two execution paths:
-  fused    built-in scenarios (simple, simple_spread, simple_tag): action decode, World.step and
-           every agent's observation/reward/done/info in one `mpe_step` launch (csrc/mpe_narrow.hip
-           thread-per-world, csrc/mpe_wide.hip workgroup-per-world for large N).
+  fused    the nine built-in scenarios (unmodified callbacks): action decode, World.step and every agent's
+           observation/reward/done/info in one `mpe_step` launch (csrc/mpe_split.hip wave-per-agent +
+           reward wave for up to 6 agents, csrc/mpe_wide.hip wave-per-world for large N).
   generic  any user Scenario: actions decoded with tensor ops (all of _set_action's modes,
            environment.py:144-192), physics by `mpe_world_step`, then the user's Python
            reward/observation callbacks on [B, .] tensor views.
@@ -185,7 +185,7 @@ class MultiAgentEnv(object):
         w = self.world
         w._require_device()
         A, B = len(w.agents), w.batch_size
-        self._entity_table = w.entity_table(self._desc)   # read by the workgroup-per-world kernels only
+        self._entity_table = w.entity_table(self._desc)   # read by the wave-per-world (large N) kernel only
         if self._kind in _abi.COMM_KINDS:
             self._comm = torch.zeros((A, B, w.dim_c), dtype=torch.float32, device=w.device)
         self._sets = [_OutputSet(self), _OutputSet(self)]

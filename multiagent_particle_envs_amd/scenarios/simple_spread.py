@@ -1,6 +1,6 @@
 """simple_spread: N agents cover N landmarks, shared reward with a collision penalty
 (reference: multiagent/scenarios/simple_spread.py; 3/3 hard-coded there, parameters here).
-Fused kernel kind MPE_SCN_SPREAD (thread-per-world for N <= 6, workgroup-per-world above)."""
+Fused kernel kind MPE_SCN_SPREAD (wave-per-agent + reward wave for N <= 6, wave-per-world above)."""
 import torch
 
 from .. import _abi
