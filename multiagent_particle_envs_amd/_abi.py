@@ -96,6 +96,18 @@ def lib():
     return _lib
 
 
+def raw_stream(device):
+    """The current HIP stream of `device` as a ctypes void* (what every entry point takes).  Uses torch's
+    raw-handle accessor when it exists: ~0.3 us instead of ~2.5 us for torch.cuda.current_stream(), which
+    matters when a step is a 6 us kernel."""
+    import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    get = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if get is not None:
+        return C.c_void_p(get(idx))
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = lib().mpe_last_error().decode("utf-8", "replace")

@@ -302,10 +302,9 @@ class World(object):
             if mask is not None:
                 mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
                 mptr = C.c_void_p(mask.data_ptr())
-            stream = torch.cuda.current_stream(self.device).cuda_stream
             _abi.check(_abi.lib().mpe_reset(C.byref(desc), C.byref(bufs), B, mptr, float(landmark_range),
                                             int(self.seed) & (2 ** 64 - 1), int(self._episode), int(self.world_offset),
-                                            C.c_void_p(stream)),
+                                            _abi.raw_stream(self.device)),
                        "mpe_reset")
             if choices:
                 idx = drawn.t().long()
@@ -406,8 +405,7 @@ class World(object):
         bufs = _abi.MpeBuffers()
         bufs.pos, bufs.vel, bufs.u = self.pos.data_ptr(), self.vel.data_ptr(), self._u.data_ptr()
         bufs.entity_table = self.entity_table(desc).data_ptr()
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        _abi.check(_abi.lib().mpe_world_step(C.byref(desc), C.byref(bufs), B, C.c_void_p(stream)), "mpe_world_step")
+        _abi.check(_abi.lib().mpe_world_step(C.byref(desc), C.byref(bufs), B, _abi.raw_stream(self.device)), "mpe_world_step")
         for agent in self.agents:  # update_agent_state (core.py:171-177)
             if agent.silent:
                 agent.state.c = torch.zeros((B, self.dim_c), dtype=torch.float32, device=self.device)

@@ -68,6 +68,7 @@ class _OutputSet(object):
         if env._comm is not None:         # communication action rows = the agents' comm state
             b.comm = env._comm.data_ptr()
         self.bufs = b
+        self.bufs_ref = C.byref(b)
         self.reward_n = [self.rew[i] for i in range(A)]
         self.done_n = [self.done[i] for i in range(A)]
 
@@ -186,6 +187,8 @@ class MultiAgentEnv(object):
         w._require_device()
         A, B = len(w.agents), w.batch_size
         self._entity_table = w.entity_table(self._desc)   # read by the wave-per-world (large N) kernel only
+        self._desc_ref = C.byref(self._desc)
+        self._mpe_step = _abi.lib().mpe_step
         if self._kind in _abi.COMM_KINDS:
             self._comm = torch.zeros((A, B, w.dim_c), dtype=torch.float32, device=w.device)
         self._sets = [_OutputSet(self), _OutputSet(self)]
@@ -193,7 +196,7 @@ class MultiAgentEnv(object):
         self._ids = torch.zeros((A, B), dtype=torch.int32, device=w.device)
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.world.device).cuda_stream)
+        return _abi.raw_stream(self.world.device)
 
     def _next_set(self):
         if self.fresh_outputs:
@@ -255,7 +258,8 @@ class MultiAgentEnv(object):
     # ------------------------------------------------------------------------------------------
     def step(self, action_n):
         """environment.py:80-104 for B worlds."""
-        self.agents = self.world.policy_agents
+        if len(self.agents) != len(self.world.agents):   # environment.py:85 re-reads world.policy_agents every step
+            self.agents = self.world.policy_agents
         if not self.fused or (self._comm_kind and self.discrete_action_input):
             return self._step_generic(action_n)
         self._ensure_buffers()
@@ -265,7 +269,9 @@ class MultiAgentEnv(object):
         b.act = act.data_ptr() if act is not None else None
         b.ids = ids.data_ptr() if ids is not None else None
         b.u = None
-        _abi.check(_abi.lib().mpe_step(C.byref(self._desc), C.byref(b), self.batch_size, self._stream()), "mpe_step")
+        rc = self._mpe_step(self._desc_ref, out.bufs_ref, self.batch_size, self._stream())
+        if rc:
+            _abi.check(rc, "mpe_step")
         if self._comm is not None:   # update_agent_state (core.py:171-177): state.c = action.c for the agents that speak
             for i, agent in enumerate(self.world.agents):
                 if not agent.silent:

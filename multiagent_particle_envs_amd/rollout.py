@@ -41,7 +41,7 @@ class RandomRollout(object):
         self._fill_pool()
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.world.device).cuda_stream)
+        return _abi.raw_stream(self.world.device)
 
     def _fill_pool(self):
         """Action tensor p holds the moves of global steps t with t % len(pool) == p, as drawn at
