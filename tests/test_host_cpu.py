@@ -158,3 +158,18 @@ def test_scenario_loader_and_generic_detection(tmp_path):
     assert not env.fused and env.observation_space[0].shape == (18,)
     with pytest.raises(_abi.MpeError):
         mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, fused=True)
+
+
+def test_header_is_plain_c_and_a_c_program_can_call_the_library(tmp_path):
+    """include/mpe_hip.h compiles as C (gcc -std=c99 -pedantic) and a C program links and calls libmpe_hip.so."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.dirname(_abi.LIB_PATH)
+    exe = str(tmp_path / "abi_smoke")
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+           os.path.join(root, "tests", "c", "abi_smoke.c"), "-o", exe, "-L", lib_dir, "-lmpe_hip",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout, r.stderr)
