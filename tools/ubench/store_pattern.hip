@@ -51,6 +51,25 @@ __global__ void __launch_bounds__(256) k_world(float *obs, size_t B, size_t rowl
     }
   }
 }
+// wave per world, per row 64+32 lanes, but the row ORDER is rotated: world w starts at row (w / GROUP) % A, so that at
+// any instant the waves are spread evenly over the A row windows (each window still sees contiguous GROUP-world runs)
+template <int GROUP>
+__global__ void __launch_bounds__(256) k_world_rot(float *obs, size_t B, size_t rowlen, size_t worldlen) {
+  const int lane = threadIdx.x & 63;
+  const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (w >= B) return;
+  float *base = obs + w * worldlen;
+  const float4 v = make_float4(1.f, 2.f, 3.f, (float)lane);
+  const int start = (int)((w / GROUP) % A);
+  for (int k = 0; k < A; ++k) {
+    int i = start + k;
+    if (i >= A) i -= A;
+    float4 *p = reinterpret_cast<float4 *>(base + (size_t)i * rowlen);
+    p[lane] = v;
+    if (lane < Dq - 64) p[64 + lane] = v;
+  }
+}
+
 // workgroup (256 threads) per world, flat: thread writes pieces tid, tid+256, ...
 __global__ void __launch_bounds__(256) k_wgworld(float *obs, size_t B, size_t rowlen, size_t worldlen) {
   const size_t w = blockIdx.x;
@@ -98,6 +117,9 @@ int main(int argc, char **argv) {
   rep("V6b grid-stride fill, 1024 x 256 threads", run([&] { hipLaunchKernelGGL(k_gridstride, dim3(1024), dim3(256), 0, s, (float4 *)obs, n4); }, s));
   rep("V2 wave/world, agent-major, 96 flat full stores", run([&] { hipLaunchKernelGGL((k_world<0, false, 1>), dim3(gw1), dim3(256), 0, s, obs, B, am_row, am_world); }, s));
   rep("V1 wave/world, agent-major, per row 64+32 lanes", run([&] { hipLaunchKernelGGL((k_world<1, false, 1>), dim3(gw1), dim3(256), 0, s, obs, B, am_row, am_world); }, s));
+  rep("V8 wave/world, agent-major, rows rotated per 64 worlds", run([&] { hipLaunchKernelGGL((k_world_rot<64>), dim3(gw1), dim3(256), 0, s, obs, B, am_row, am_world); }, s));
+  rep("V8b wave/world, agent-major, rows rotated per 4 worlds", run([&] { hipLaunchKernelGGL((k_world_rot<4>), dim3(gw1), dim3(256), 0, s, obs, B, am_row, am_world); }, s));
+  rep("V8c wave/world, agent-major, rows rotated per 512 worlds", run([&] { hipLaunchKernelGGL((k_world_rot<512>), dim3(gw1), dim3(256), 0, s, obs, B, am_row, am_world); }, s));
   rep("V3 wave/world, world-major, 96 flat full stores", run([&] { hipLaunchKernelGGL((k_world<0, false, 1>), dim3(gw1), dim3(256), 0, s, obs, B, wm_row, wm_world); }, s));
   rep("V4 wave/world, agent-major, flat, nontemporal", run([&] { hipLaunchKernelGGL((k_world<0, true, 1>), dim3(gw1), dim3(256), 0, s, obs, B, am_row, am_world); }, s));
   rep("V4b wave/world, world-major, flat, nontemporal", run([&] { hipLaunchKernelGGL((k_world<0, true, 1>), dim3(gw1), dim3(256), 0, s, obs, B, wm_row, wm_world); }, s));
