@@ -1,13 +1,28 @@
-"""Scenario plug-in protocol (reference: multiagent/scenario.py:4-10, README "Creating new
-environments").  A scenario builds a World and supplies reset/reward/observation callbacks; with
-`batch_size=B` every per-world scalar of the reference becomes a leading-B tensor."""
+"""Scenario plug-in protocol.
+
+The reference's contract (multiagent/scenario.py:4-10 and the README's "Creating new environments"): a
+scenario builds a World and supplies the reset / reward / observation callbacks that `make_env` hands to
+`MultiAgentEnv`.  Here every per-world scalar of the reference becomes a leading-B tensor:
+
+    make_world(batch_size, device, **kw) -> World      entities created, `world.allocate()` called
+    reset_world(world, mask=None, seeds=None)           initial conditions (all worlds, a masked subset, or
+                                                         reference-exact per-world NumPy seeds)
+    reward(agent, world) -> [B] tensor                   observation(agent, world) -> [B, D] tensor
+    benchmark_data(agent, world)  (optional)             what `make_env(..., benchmark=True)` returns as info
+
+A scenario whose class attribute `kind` names one of the `MPE_SCN_*` kernels, with its callbacks left
+unmodified, is stepped by one fused launch; anything else runs these callbacks over the HIP physics.
+"""
 
 
 class BaseScenario(object):
-    # create elements of the world
-    def make_world(self, batch_size=1, device=None):
-        raise NotImplementedError()
+    #: `_abi.MPE_SCN_*` of the fused kernel that implements this scenario's callbacks (None: generic path)
+    kind = None
 
-    # create initial conditions of the world
-    def reset_world(self, world):
-        raise NotImplementedError()
+    def make_world(self, batch_size=1, device=None):
+        """Create the World: agents, landmarks, their constants; end with `world.allocate()`."""
+        raise NotImplementedError("%s.make_world" % type(self).__name__)
+
+    def reset_world(self, world, mask=None, seeds=None):
+        """Draw initial conditions (`world.reset_uniform(...)` implements the reference's uniform placement)."""
+        raise NotImplementedError("%s.reset_world" % type(self).__name__)
