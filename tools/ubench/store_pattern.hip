@@ -21,6 +21,30 @@ __global__ void k_linear(float4 *o, size_t n4) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n4) o[t] = make_float4(1.f, 2.f, 3.f, 4.f);
 }
+// V9: linear order like V0, but every float4 is computed the way a two-kernel observation emitter would: thread t owns
+// piece q of row (agent i, world w) in MEMORY order, reads the world's positions from a world-major scratch copy
+// Qs [B][128] float2 (coalesced: consecutive pieces read consecutive entities) and its own position (broadcast).
+__global__ void __launch_bounds__(256) k_linear_rows(float4 *o, const float2 *__restrict__ Qs, unsigned Bw) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [A][B][Dq]
+  const unsigned per_agent = Bw * (unsigned)Dq;
+  const unsigned i = (unsigned)(t / per_agent);
+  const unsigned rem = (unsigned)(t - (size_t)i * per_agent);
+  const unsigned w = rem / (unsigned)Dq, q = rem - w * (unsigned)Dq;
+  if (i >= (unsigned)A) return;
+  const float2 *Qw = Qs + (size_t)w * 128;
+  const float2 me = Qw[64 + i];
+  const int idx0 = 2 * (int)q - 2, thr = 64 + (int)i;
+  int s0 = idx0 + (idx0 >= thr), s1 = idx0 + 1 + (idx0 + 1 >= thr);
+  s0 = s0 < 0 ? 0 : (s0 > 127 ? 127 : s0);
+  s1 = s1 < 0 ? 0 : (s1 > 127 ? 127 : s1);
+  const float2 p0 = Qw[s0], p1 = Qw[s1];
+  float4 v = make_float4(p0.x - me.x, p0.y - me.y, p1.x - me.x, p1.y - me.y);
+  if (2 * q >= 129) { v.x = 0.f; v.y = 0.f; }
+  if (2 * q + 1 >= 129) { v.z = 0.f; v.w = 0.f; }
+  if (q == 0) v = make_float4(me.x, me.y, me.x, me.y);
+  o[t] = v;
+}
+
 // V6: grid-stride fill with a small persistent grid
 __global__ void k_gridstride(float4 *o, size_t n4) {
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (size_t)gridDim.x * blockDim.x)
@@ -113,6 +137,8 @@ int main(int argc, char **argv) {
   const unsigned gw1 = (unsigned)((B * 64 + 255) / 256), gw4 = (unsigned)((B * 4 * 64 + 255) / 256);
   printf("B=%zu  block = %.1f MB\n", B, mb);
   rep("V0 linear, one float4 per thread", run([&] { hipLaunchKernelGGL(k_linear, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (float4 *)obs, n4); }, s));
+  float2 *Qs; CK(hipMalloc(&Qs, B * 128 * sizeof(float2))); CK(hipMemsetAsync(Qs, 0, B * 128 * sizeof(float2), s));
+  rep("V9 linear order, rows computed from a world-major scratch", run([&] { hipLaunchKernelGGL(k_linear_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (float4 *)obs, Qs, (unsigned)B); }, s));
   rep("V6 grid-stride fill, 2048 x 256 threads", run([&] { hipLaunchKernelGGL(k_gridstride, dim3(2048), dim3(256), 0, s, (float4 *)obs, n4); }, s));
   rep("V6b grid-stride fill, 1024 x 256 threads", run([&] { hipLaunchKernelGGL(k_gridstride, dim3(1024), dim3(256), 0, s, (float4 *)obs, n4); }, s));
   rep("V2 wave/world, agent-major, 96 flat full stores", run([&] { hipLaunchKernelGGL((k_world<0, false, 1>), dim3(gw1), dim3(256), 0, s, obs, B, am_row, am_world); }, s));
