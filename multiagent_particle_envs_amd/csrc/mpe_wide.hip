@@ -421,11 +421,22 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
             // every agent has the same size: the guard band of the strict `<` test is a per-lane constant
             const float m = ri + ri, mm = m * m, lo = mm * 0.9999996f, hi_ = mm * 1.0000004f;
             const bool has_band = mm > 1e-30f;
+            bool band = false;   // did any pair land in the guard band of the strict `<` (1e-6 wide: almost never)
 #pragma unroll 8
-            for (int a = 0; a < A; ++a) {  // uniform a: broadcast reads at compile-time offsets
+            for (int a = 0; a < A; ++a) {  // uniform a: broadcast reads at compile-time offsets; branch-free body
               const float2 pa = Q[L + a];
               m2 = fminf(m2, sq2d(pa.x - pl.x, pa.y - pl.y));
-              c += sqrt_lt_pre(sq2d(pa.x - pi.x, pa.y - pi.y), m, lo, hi_, has_band) ? 1 : 0;  // includes a == t
+              const float da = sq2d(pa.x - pi.x, pa.y - pi.y);
+              const bool below = da < lo;
+              c += below ? 1 : 0;                                  // includes a == t
+              band = band || (!below && !(da > hi_ && has_band));
+            }
+            if (band) {  // recount this lane's row with the exact test
+              c = 0;
+              for (int a = 0; a < A; ++a) {
+                const float2 pa = Q[L + a];
+                c += sqrt_lt_pre(sq2d(pa.x - pi.x, pa.y - pi.y), m, lo, hi_, has_band) ? 1 : 0;
+              }
             }
           } else {
 #pragma unroll 4
