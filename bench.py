@@ -217,7 +217,7 @@ def main():
     obs_total = int(env._obs_off[-1])
     speakers = sum(1 for a in env.world.agents if not a.silent)
     bytes_step = algorithmic_bytes(A, Lm, obs_total, len(env.world.choice_pops), speakers * env.world.dim_c)
-    can_fuse = A <= 6
+    can_fuse = A <= 6 or args.scenario == "simple_spread"
     trajs = None
 
     def fused_steps(n):
@@ -315,8 +315,8 @@ def main():
         dtf = timed("fused")
         kf = kernel_time_us("fused")
         extra["fused_rollout"] = {
-            "what": "mpe_rollout_random: one launch per %d-step episode, state in registers, moves drawn in-kernel, "
-                    "every step's obs/rew/done written to its own trajectory block" % (EP or 25),
+            "what": "mpe_rollout_random: one launch per %d-step episode, state kept on chip (registers / LDS), moves drawn "
+                    "in-kernel, every step's obs/rew/done written to its own trajectory block" % (EP or 25),
             "value": B * K * world / dtf, "unit": "env-steps/s", "ms_per_step": dtf * 1e3 / K,
             "kernel_us_per_step": kf,
             "achieved_GBps_at_411B_convention": bytes_step * B / (kf * 1e-6) / 1e9,

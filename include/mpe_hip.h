@@ -165,7 +165,7 @@ int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, ui
 /* mpe_rollout_random: T consecutive env steps in ONE launch, with in-kernel uniform random moves
  * (the rows mpe_random_actions(step0+t) would write) and an in-kernel reset whenever the global
  * step index step0+t is a multiple of `episode_len` (0 = never; episode = (step0+t)/episode_len,
- * as mpe_reset draws it).  State stays in registers between steps; pos/vel are written after the
+ * as mpe_reset draws it).  State stays on chip (registers / LDS) between steps; pos/vel are written after the
  * last step.  Every step's obs/rew/done/info ARE written: with trajectory != 0 the output buffers
  * hold T consecutive per-step blocks (obs: T x [B*obs_off[A]] floats; rew/done/info: T x [A][B]),
  * with trajectory == 0 step t overwrites the single block.

@@ -326,10 +326,6 @@ int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
     return fail(MPE_EUNSUPPORTED, "%s: the random rollout draws moves only; communication scenarios step through mpe_step", what);
   if (T < 0 || episode_len < 0) return fail(MPE_EINVAL, "%s: T, episode_len must be >= 0", what);
   if (B == 0 || T == 0) return 0;
-  if (d->n_agents + d->n_landmarks > mpe::kNarrowMaxE ||
-      !mpe::split_supports(d->kind, d->n_agents, d->n_landmarks, d->n_adversaries))
-    return fail(MPE_EUNSUPPORTED, "%s: the fused rollout exists for the wave-per-agent shapes only", what);
-  const mpe::NarrowDesc n = make_narrow(d, b, (size_t)B);
   mpe::RollArgs ra;
   std::memset(&ra, 0, sizeof(ra));
   ra.T = T;
@@ -339,8 +335,18 @@ int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
   ra.seed = seed;
   ra.step0 = step0;
   ra.world_offset = (uint64_t)world_offset;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d->n_agents + d->n_landmarks > mpe::kNarrowMaxE ||
+      !mpe::split_supports(d->kind, d->n_agents, d->n_landmarks, d->n_adversaries)) {
+    if (d->kind != MPE_SCN_SPREAD)
+      return fail(MPE_EUNSUPPORTED, "%s: the fused rollout exists for the wave-per-agent shapes and for simple_spread of any size", what);
+    if (int rc = need(b->entity_table, what, "entity_table (required by the wave-per-world kernel)")) return rc;
+    const mpe::WideDesc w = make_wide(d);
+    return hip_result(mpe::launch_wide(true, true, w, *b, (size_t)B, s, &ra), what);
+  }
+  const mpe::NarrowDesc n = make_narrow(d, b, (size_t)B);
   return hip_result(mpe::launch_split(true, d->kind, d->n_agents, d->n_landmarks, d->n_adversaries, n, *b, (size_t)B,
-                                      ra, static_cast<hipStream_t>(stream)), what);
+                                      ra, s), what);
 }
 
 }  // extern "C"

@@ -20,7 +20,9 @@ struct WideDesc {
   float dt, damp, cforce, cmargin, cmargin_inv;
 };
 constexpr int kEntityTableCols = 6;  // size, mass, accel, max_speed, movable, collide  -> [6][E] floats
-int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream);
+struct RollArgs;
+int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream,
+                const RollArgs *roll = nullptr);
 
 // reset / synthetic actions / fused rollout (mpe_rng.hip)
 int launch_reset(int A, int L, const MpeBuffers &b, size_t B, const uint8_t *mask, float landmark_range,

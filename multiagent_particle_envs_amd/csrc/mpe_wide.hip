@@ -28,6 +28,8 @@
 // Per pair the arithmetic is mpe_device.h's, as in the small-N kernels; sums over landmarks / agents
 // are reduction trees (documented in DESIGN.md 4).
 
+#include <cstring>
+
 #include "mpe_internal.h"
 
 namespace mpe {
@@ -240,9 +242,13 @@ __device__ __forceinline__ bool sqrt_lt_pre(float s2, float m, float lo, float h
   return r;
 }
 
-template <bool PHYS, bool OUT>
+// ROLL: the fused T-step rollout (mpe_rollout_random) -- the world stays in LDS across the steps, moves and resets
+// are drawn in-kernel (Philox, as mpe_random_actions / mpe_reset draw them), every step's rows / rewards are still
+// written.  A wave runs ahead into step t+1's contact phase while its step-t row stores drain, so the VALU-bound
+// phases that a single step cannot hide (every wave owns exactly one world at B = 4096) disappear under the stores.
+template <bool PHYS, bool OUT, bool ROLL>
 __global__ void __launch_bounds__(kWavesPerWg *kWave)
-k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_groups_padded) {
+k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_groups_padded, const RollArgs ra) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int A = d.A, L = d.L, E = A + L;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -332,13 +338,56 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
     }
     for (int i = lane; i < A; i += kWave) {
       V[i] = make_float2(b.vel[(size_t)(2 * i) * B + w], b.vel[(size_t)(2 * i + 1) * B + w]);
-      if (PHYS) {  // decode actions (environment.py:144-181)
+      if (PHYS && !ROLL) {  // decode actions (environment.py:144-181)
         float ux, uy;
         fetch_action(b, B, i, w, aconst[i].z, ux, uy);
         U[i] = make_float2(ux + 0.f, uy + 0.f);
       }
     }
     wave_sync();
+
+    // ---- the steps of this world (one, unless this is the rollout kernel) ---------------------------
+    const uint64_t gw = ra.world_offset + w;   // global world number (RNG streams)
+    const int T = ROLL ? ra.T : 1;
+    const size_t obs_stride = (ROLL && ra.trajectory) ? (size_t)A * D * B : 0;
+    const size_t row_stride = (ROLL && ra.trajectory) ? (size_t)A * B : 0;
+    int countdown = -1;    // resets fall on global steps that are multiples of episode_len
+    uint64_t ep = 0;
+    if (ROLL && ra.episode_len > 0) {
+      const uint64_t len = (uint64_t)ra.episode_len, r = ra.step0 % len;
+      countdown = r == 0 ? 0 : (int)(len - r);
+      ep = ra.step0 / len + (r ? 1 : 0);
+    }
+    for (int t = 0; t < T; ++t) {
+    if (ROLL) {
+      const uint64_t gt = ra.step0 + (uint64_t)t;
+      const bool reset_now = countdown == 0;
+      if (countdown >= 0) countdown = reset_now ? ra.episode_len - 1 : countdown - 1;
+      if (reset_now) {  // reset_world, as mpe_reset draws it for episode ep
+        for (int e = lane; e < E; e += kWave) {
+          float x, y;
+          reset_draw(ra.seed, gw, ep, e, e < A ? 1.0f : ra.landmark_range, x, y);
+          Q[e < A ? L + e : e - A] = make_float2(x, y);
+        }
+        for (int i = lane; i < A; i += kWave) V[i] = make_float2(0.f, 0.f);
+        ++ep;
+      }
+      for (int i = lane; i < A; i += kWave) {   // the one-hot row mpe_random_actions would write, decoded
+        const int m = action_draw(ra.seed, gw, gt, i);
+        const float sens = aconst[i].z;
+        const float ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * sens;
+        const float uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * sens;
+        U[i] = make_float2(ux + 0.f, uy + 0.f);
+      }
+      wave_sync();
+      if (!agents_only) {  // the partner list follows the positions
+        for (int e = lane; e < E; e += kWave) {
+          const int r = crank[e];
+          if (r >= 0) CPW[r] = Q[e < A ? L + e : e - A];
+        }
+        wave_sync();
+      }
+    }
 
     if (PHYS) {
       // ---- pairwise contact force (core.py:143-155,180-196) + integrate (core.py:158-169) -----------
@@ -376,10 +425,12 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
           integrate_one(p.x, p.y, v.x, v.y, ax, ay, ac.x, ac.y, d.damp, d.dt);
           QN[i] = p;
           V[i] = v;
-          b.pos[(size_t)(2 * i) * B + w] = p.x;
-          b.pos[(size_t)(2 * i + 1) * B + w] = p.y;
-          b.vel[(size_t)(2 * i) * B + w] = v.x;
-          b.vel[(size_t)(2 * i + 1) * B + w] = v.y;
+          if (!ROLL) {   // (the rollout writes the state back once, after its last step)
+            b.pos[(size_t)(2 * i) * B + w] = p.x;
+            b.pos[(size_t)(2 * i + 1) * B + w] = p.y;
+            b.vel[(size_t)(2 * i) * B + w] = v.x;
+            b.vel[(size_t)(2 * i + 1) * B + w] = v.y;
+          }
         } else if (have && A > kWave) {
           QN[i] = me;
         }
@@ -395,8 +446,9 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
       // ---- observation rows (simple_spread.py:84-100): issued first, they drain while the reward is computed
       // agent i's rows form one [B][D] block (obs_n[i] of the drop-in API): the rows of one world are B*D floats apart
       const size_t rowlen = (size_t)B * D;
-      float *const obs_w = b.obs + w * (size_t)D;
-      const bool vec4 = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && ((B * (size_t)D) & 3) == 0;
+      float *const obs_w = b.obs + (size_t)t * obs_stride + w * (size_t)D;
+      const bool vec4 = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && ((B * (size_t)D) & 3) == 0 &&
+                        ((obs_stride & 3) == 0);
       if (vec4 && D <= 8 * kWave)
         emit_rows_fast(Q, V, A, L, D, obs_w, rowlen, lane);
       else if (vec4)
@@ -464,26 +516,41 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
         for (int i = lane; i < A; i += kWave) {
           const int c = CNT[i];
           const float r = neg - (float)c;
-          if (b.rew) b.rew[(size_t)i * B + w] = d.collaborative ? tot : r;
-          if (b.done) b.done[(size_t)i * B + w] = 0;
+          const size_t o = (size_t)t * row_stride + (size_t)i * B + w;
+          if (b.rew) b.rew[o] = d.collaborative ? tot : r;
+          if (b.done) b.done[o] = 0;
           if (b.info_rew) {
-            b.info_rew[(size_t)i * B + w] = r;
-            b.info_collisions[(size_t)i * B + w] = c;
-            b.info_min_dists[(size_t)i * B + w] = -neg;
-            b.info_occupied[(size_t)i * B + w] = occ;
+            b.info_rew[o] = r;
+            b.info_collisions[o] = c;
+            b.info_min_dists[o] = -neg;
+            b.info_occupied[o] = occ;
           }
         }
       } else if (b.done) {
-        for (int i = lane; i < A; i += kWave) b.done[(size_t)i * B + w] = 0;
+        for (int i = lane; i < A; i += kWave) b.done[(size_t)t * row_stride + (size_t)i * B + w] = 0;
       }
     }
-    wave_sync();  // every LDS read of this world is done before the next one is staged
+    wave_sync();  // every LDS read of this step is done before the next step / world overwrites the block
+    }  // steps
+    if (ROLL) {   // hand the state back: every entity (in-kernel resets move the landmarks too)
+      for (int e = lane; e < E; e += kWave) {
+        const float2 p = Q[e < A ? L + e : e - A];
+        b.pos[(size_t)(2 * e) * B + w] = p.x;
+        b.pos[(size_t)(2 * e + 1) * B + w] = p.y;
+      }
+      for (int i = lane; i < A; i += kWave) {
+        b.vel[(size_t)(2 * i) * B + w] = V[i].x;
+        b.vel[(size_t)(2 * i + 1) * B + w] = V[i].y;
+      }
+      wave_sync();
+    }
   }
 }
 
 }  // namespace
 
-int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream) {
+int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream,
+                const RollArgs *roll) {
   if (out && d.kind != MPE_SCN_SPREAD) return MPE_EUNSUPPORTED;
   if (out && (d.dim_c != 2 || (d.D & 1))) return MPE_EUNSUPPORTED;
   const Carve cv = carve(d.A, d.L);
@@ -507,9 +574,14 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
   if (cap < 64) cap = 64;
   const dim3 grid((unsigned)(padded < cap ? padded : cap)), block(kWavesPerWg * kWave);
   const unsigned np = (unsigned)padded;
-  if (phys && out) hipLaunchKernelGGL((k_wave<true, true>), grid, block, lds, stream, d, b, B, np);
-  else if (phys) hipLaunchKernelGGL((k_wave<true, false>), grid, block, lds, stream, d, b, B, np);
-  else hipLaunchKernelGGL((k_wave<false, true>), grid, block, lds, stream, d, b, B, np);
+  RollArgs ra;
+  std::memset(&ra, 0, sizeof(ra));
+  if (roll) {
+    if (!(phys && out)) return MPE_EUNSUPPORTED;
+    hipLaunchKernelGGL((k_wave<true, true, true>), grid, block, lds, stream, d, b, B, np, *roll);
+  } else if (phys && out) hipLaunchKernelGGL((k_wave<true, true, false>), grid, block, lds, stream, d, b, B, np, ra);
+  else if (phys) hipLaunchKernelGGL((k_wave<true, false, false>), grid, block, lds, stream, d, b, B, np, ra);
+  else hipLaunchKernelGGL((k_wave<false, true, false>), grid, block, lds, stream, d, b, B, np, ra);
   return (int)hipGetLastError();
 }
 

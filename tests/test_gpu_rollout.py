@@ -64,7 +64,10 @@ def test_split_and_thread_kernels_bit_identical(name, kw, B, impl_env):
 
 @pytest.mark.parametrize("name,kw,B,T,ep", [("simple_spread", {}, 1500, 60, 25), ("simple_tag", {}, 700, 30, 7),
                                             ("simple", {}, 300, 12, 0), ("simple_spread", {"num_agents": 4}, 200, 9, 4),
-                                            ("simple_adversary", {}, 900, 30, 5), ("simple_push", {}, 500, 20, 4)])
+                                            ("simple_adversary", {}, 900, 30, 5), ("simple_push", {}, 500, 20, 4),
+                                            ("simple_spread", {"num_agents": 8}, 130, 11, 4),            # wave-per-world kernel
+                                            ("simple_spread", {"num_agents": 20, "num_landmarks": 12}, 70, 7, 3),
+                                            ("simple_spread", {"num_agents": 64}, 37, 6, 5)])
 def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):
     seed, offset, step0 = 0xABCDEF0123, 4096, 50 if ep in (25, 0) else 14
     # --- stepwise: explicit reset / random_actions / step through the C ABI ----------------------

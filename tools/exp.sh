@@ -1,7 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-for rep in 1 2 3; do
-for v in base new; do
-  if [ $v = new ]; then unset MPE_HIP_LIB; else export MPE_HIP_LIB=$PWD/tools/ubench/ablate/libmpe_base.so; fi
-  echo "== $v"; python tools/probe_wide.py 64 4096 2>&1 | grep "full step\|observe only"
-done; done
+python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+python bench.py --no-cpu-baseline --agents 64 --batch 4096 --steps 100 --repeats 3 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('n64 per-step %.2f us, frac %.3f; fused'%(r['kernel_us_per_launch'], r['frac']), d.get('extra',{}).get('fused_rollout'))"
