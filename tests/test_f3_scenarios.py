@@ -254,3 +254,34 @@ def test_compat_mode_episode_like_a_reference_caller(name, golden):
             close(obs[i], g["obs%d" % i][t, w], tol=1e-4, what="t=%d obs%d" % (t, i))
         close(np.array(rew), g["rew"][t, w], tol=1e-4, what="t=%d rew" % t)
         assert done == [False] * env.n
+
+
+@pytest.mark.gpu
+def test_discrete_action_input_on_a_comm_scenario_matches_one_hot_rows():
+    """environment.py:161-167 / :183-186: integer actions (note the opposite x/y sign convention of the integer
+    form).  For the scenarios that speak the env routes this mode through the generic path; it
+    must agree with the fused kernel fed the equivalent one-hot rows."""
+    B = 512
+    rs = np.random.RandomState(4)
+    ef = mpe.make_env("simple_reference", batch_size=B)
+    ei = mpe.make_env("simple_reference", batch_size=B)
+    ei.discrete_action_input = True
+    E, A = len(ef.world.entities), 2
+    pos = rs.uniform(-1, 1, (B, E, 2)).astype(np.float32)
+    vel = rs.uniform(-0.5, 0.5, (B, A, 2)).astype(np.float32)
+    choice = np.stack([rs.randint(0, 3, size=B) for _ in range(2)], axis=1)
+    for env in (ef, ei):
+        env.world.set_state(pos, vel)
+        set_choices(env, choice)
+    move = rs.randint(0, 5, size=(A, B))
+    say = rs.randint(0, 10, size=(A, B))
+    # integer id 1 means -x, one-hot index 1 means +x (and likewise 3/4 for y): swap to get the same force
+    swap = np.array([0, 2, 1, 4, 3])
+    rows = [torch.as_tensor(np.concatenate([np.eye(5, dtype=np.float32)[swap[move[i]]],
+                                            np.eye(10, dtype=np.float32)[say[i]]], axis=1)).cuda() for i in range(A)]
+    ids = [torch.as_tensor(np.stack([move[i], say[i]], axis=1)).cuda() for i in range(A)]
+    of, rf, _, _ = ef.step(rows)
+    oi, ri, _, _ = ei.step(ids)
+    for i in range(A):
+        close(np_(oi[i]), np_(of[i]), what="obs%d" % i)
+        close(np_(ri[i]) * np.ones(B), np_(rf[i]) * np.ones(B), what="rew%d" % i)
