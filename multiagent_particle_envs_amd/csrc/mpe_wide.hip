@@ -547,6 +547,268 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
   }
 }
 
+// ---- several worlds per wave: the mid-size regime (7 <= A, L <= 32) ------------------------------------------
+// With a world per wave, a 16-agent world leaves three quarters of the lanes idle in every phase and its 384-byte
+// rows fill a sixth of a wave store.  Here a wave owns WPW = 64 / AP consecutive worlds (AP = 8, 16 or 32 lanes per
+// world slot, the power of two covering max(A, L)): lane = (slot, a) is agent a -- and landmark a -- of world slot.
+// The phases are k_wave's, with per-slot LDS blocks instead of wave-uniform ones and SEGMENTED shuffle reductions
+// (xor offsets below AP); row stores are flat over (slot, piece), so the WPW adjacent rows of one agent index form
+// one contiguous WPW * D * 4-byte run.  Same per-pair arithmetic, same accumulation order (action, then partners
+// ascending) as every other kernel.
+template <bool PHYS, bool OUT>
+__global__ void __launch_bounds__(kWavesPerWg *kWave)
+k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_groups_padded, const int AP) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int A = d.A, L = d.L, E = A + L;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int WPW = kWave / AP;
+  const int slot = lane / AP, a = lane - slot * AP;
+  const Carve cv = carve(A, L);
+  float *const sizeq = reinterpret_cast<float *>(smem + cv.sizeq);
+  int *const crank = reinterpret_cast<int *>(smem + cv.crank);
+  float *const csz = reinterpret_cast<float *>(smem + cv.csz);
+  float4 *const aconst = reinterpret_cast<float4 *>(smem + cv.aconst);
+  // per wave: WPW blocks of {Q [E], V [A], U [A], CPW [E]} float2
+  const int blk = 2 * E + 2 * A;   // float2 per slot
+  float2 *const wbase = reinterpret_cast<float2 *>(smem + cv.shared_bytes) + (size_t)wave * WPW * blk;
+  auto Qs = [&](int sl) { return wbase + sl * blk; };
+  auto Vs = [&](int sl) { return wbase + sl * blk + E; };
+  auto Us = [&](int sl) { return wbase + sl * blk + E + A; };
+  auto Cs = [&](int sl) { return wbase + sl * blk + E + 2 * A; };
+  float2 *const Q = Qs(slot), *const V = Vs(slot), *const U = Us(slot);
+
+  // ---- per-entity constants (as k_wave) -----------------------------------------------------------------------
+  const float *tab = b.entity_table;
+  for (int e = tid; e < E; e += blockDim.x) sizeq[e < A ? L + e : e - A] = tab[0 * E + e];
+  for (int i = tid; i < A; i += blockDim.x) {
+    const int fl = (tab[4 * E + i] != 0.f ? kMovable : 0) | (tab[5 * E + i] != 0.f ? kCollide : 0);
+    aconst[i] = make_float4(1.0f / tab[1 * E + i], tab[3 * E + i], tab[2 * E + i], __int_as_float(fl));
+  }
+  int nC = 0;
+  bool agents_only = true;
+  if (tid < kWave) {   // E <= 64: one pass
+    const bool c = lane < E && tab[5 * E + lane] != 0.f;
+    const unsigned long long m = __ballot(c);
+    if (lane < E) {
+      const int kq = __popcll(m & ((1ull << lane) - 1ull));
+      crank[lane] = c ? kq : -1;
+      if (c) csz[kq] = tab[0 * E + lane];
+    }
+  }
+  {
+    const bool in = lane < E;
+    const bool c = in && tab[5 * E + lane] != 0.f;
+    nC = __popcll(__ballot(c));
+    agents_only = !__any(in && (c != (lane < A)));
+  }
+  nC = __builtin_amdgcn_readfirstlane(nC);
+  float2 *const CPW = agents_only ? Q + L : Cs(slot);
+  __syncthreads();
+
+  const float far = kFarX * d.cmargin;
+  const int D = d.D;
+  const bool vec4 = OUT && (D & 3) == 0 && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && ((B * (size_t)D) & 3) == 0;
+  const int P = vec4 ? D >> 2 : D >> 1;       // pieces (16 or 8 bytes) per row
+  const int npc = WPW * P;                    // pieces per row index over the wave's slots
+  const int kpz = 2 + L + (A - 1);
+
+  const size_t per_wg = (size_t)kWavesPerWg * WPW;
+  for (unsigned x = blockIdx.x; x < n_groups_padded; x += gridDim.x) {
+    const unsigned xcd = x & 7u, sl8 = x >> 3;
+    const unsigned g = ((sl8 >> 3) << 6) | (xcd << 3) | (sl8 & 7u);
+    const size_t wb = (size_t)g * per_wg + (size_t)wave * WPW;   // first world of this wave
+    if (wb >= B) continue;                                       // wave-uniform
+    const size_t w = wb + slot;
+    const bool ok = w < B;                                       // this lane's slot holds a world
+
+    // ---- stage -------------------------------------------------------------------------------------------
+    if (ok) {
+      if (a < A) {
+        const float2 p = make_float2(b.pos[(size_t)(2 * a) * B + w], b.pos[(size_t)(2 * a + 1) * B + w]);
+        Q[L + a] = p;
+        if (PHYS && !agents_only) { const int r = crank[a]; if (r >= 0) CPW[r] = p; }
+        V[a] = make_float2(b.vel[(size_t)(2 * a) * B + w], b.vel[(size_t)(2 * a + 1) * B + w]);
+        if (PHYS) {
+          float ux, uy;
+          fetch_action(b, B, a, w, aconst[a].z, ux, uy);
+          U[a] = make_float2(ux + 0.f, uy + 0.f);
+        }
+      }
+      if (a < L) {
+        const int e = A + a;
+        const float2 p = make_float2(b.pos[(size_t)(2 * e) * B + w], b.pos[(size_t)(2 * e + 1) * B + w]);
+        Q[a] = p;
+        if (PHYS && !agents_only) { const int r = crank[e]; if (r >= 0) CPW[r] = p; }
+      }
+    }
+    wave_sync();
+
+    const bool have = ok && a < A;
+    if (PHYS) {
+      // ---- contacts + integrate (core.py:143-169), lane = (slot, agent a) -------------------------------------
+      const float4 ac = aconst[a < A ? a : 0];
+      const int fi = have ? __float_as_int(ac.w) : 0;
+      const float2 me = Q[L + (a < A ? a : 0)];
+      const float ri = sizeq[L + (a < A ? a : 0)];
+      const float2 u = U[a < A ? a : 0];
+      float ax = u.x, ay = u.y;
+      const bool pushes = (fi & kCollide) && (fi & kMovable);
+      const int self_rank = pushes ? crank[a] : -1;
+      const float rfar = ri + far;
+      for (int kb = 0; kb < nC; kb += 32) {
+        const int n = min(nC - kb, 32);
+        unsigned near = near_mask32<false>(CPW, csz, kb, n, me, rfar, 0.f);
+        if (self_rank >= kb && self_rank < kb + 32) near &= ~(0x80000000u >> (self_rank - kb));
+        if (!pushes) near = 0u;
+        while (near) {
+          const int j = __clz((int)near);
+          near &= ~(0x80000000u >> j);
+          const float2 pj = CPW[kb + j];
+          float gx, gy;
+          contact_force(me.x - pj.x, me.y - pj.y, ri + csz[kb + j], d.cforce, d.cmargin, d.cmargin_inv, gx, gy);
+          ax = gx + ax;
+          ay = gy + ay;
+        }
+      }
+      wave_sync();   // every lane has read the old positions
+      if (have && (fi & kMovable)) {
+        float2 p = me, v = V[a];
+        integrate_one(p.x, p.y, v.x, v.y, ax, ay, ac.x, ac.y, d.damp, d.dt);
+        Q[L + a] = p;
+        V[a] = v;
+        b.pos[(size_t)(2 * a) * B + w] = p.x;
+        b.pos[(size_t)(2 * a + 1) * B + w] = p.y;
+        b.vel[(size_t)(2 * a) * B + w] = v.x;
+        b.vel[(size_t)(2 * a + 1) * B + w] = v.y;
+      }
+      wave_sync();
+    }
+
+    if (OUT) {
+      // ---- observation rows: for each agent index i, the rows of the wave's WPW worlds are adjacent in HBM --------
+      const int nvalid = (B - wb) < (size_t)WPW ? (int)(B - wb) : WPW;   // slots that hold a world
+      if (vec4 && npc <= 3 * kWave) {
+        // fast form: this lane's (slot, piece) for its up to three pieces per row index, and both candidate sources
+        // of both pairs of each piece (without / with the self-skip), are row-invariant: fetched once per batch of
+        // worlds.  A row then costs one broadcast-ish read of (pos_i, vel_i) per piece, selects, subtractions, a store.
+        int psl[3], ppc[3];
+        bool pok[3];
+        float2 ca[3][2], cb[3][2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int idx = lane + kWave * k;
+          psl[k] = idx / P;
+          ppc[k] = idx - psl[k] * P;
+          pok[k] = idx < npc && psl[k] < nvalid;
+          if (!pok[k]) psl[k] = 0;
+          const float2 *const Qx = Qs(psl[k]);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int id = 2 * ppc[k] + h - 2;
+            ca[k][h] = Qx[min(max(id, 0), E - 1)];
+            cb[k][h] = Qx[min(max(id + 1, 0), E - 1)];
+          }
+        }
+        for (int i = 0; i < A; ++i) {
+          float *const rows = b.obs + ((size_t)i * B + wb) * D;   // wave-uniform: WPW rows of D floats, contiguous
+          const int thr = L + i;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            if (kWave * k >= npc) break;   // uniform
+            const float2 mi = Qs(psl[k])[L + i];
+            const float2 vi = Vs(psl[k])[i];
+            float o[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int kp = 2 * ppc[k] + h, id = kp - 2;
+              const float2 pj = id >= thr ? cb[k][h] : ca[k][h];
+              float2 v = make_float2(pj.x - mi.x, pj.y - mi.y);
+              v = kp >= kpz ? make_float2(0.f, 0.f) : v;
+              v = kp == 0 ? vi : v;
+              v = kp == 1 ? mi : v;
+              o[2 * h] = v.x;
+              o[2 * h + 1] = v.y;
+            }
+            if (pok[k]) *reinterpret_cast<float4 *>(rows + 4 * (lane + kWave * k)) = make_float4(o[0], o[1], o[2], o[3]);
+          }
+        }
+      } else
+      for (int i = 0; i < A; ++i) {   // generic form (8-byte pieces, or more than three pieces per lane)
+        float *const rows = b.obs + ((size_t)i * B + wb) * D;   // wave-uniform: WPW rows of D floats, contiguous
+        for (int idx = lane; idx < npc; idx += kWave) {
+          const int sl = idx / P, pc = idx - sl * P;
+          if (sl >= nvalid) continue;
+          const float2 *const Qx = Qs(sl);
+          const float2 mi = Qx[L + i];
+          if (vec4) {
+            float o[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int kp = 2 * pc + h, id = kp - 2;
+              const float2 pj = Qx[min(max(id + (id >= L + i ? 1 : 0), 0), E - 1)];
+              float2 v = make_float2(pj.x - mi.x, pj.y - mi.y);
+              if (kp >= kpz) v = make_float2(0.f, 0.f);
+              if (kp == 0) v = Vs(sl)[i];
+              if (kp == 1) v = mi;
+              o[2 * h] = v.x;
+              o[2 * h + 1] = v.y;
+            }
+            *reinterpret_cast<float4 *>(rows + 4 * idx) = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+            const int kp = pc, id = kp - 2;
+            const float2 pj = Qx[min(max(id + (id >= L + i ? 1 : 0), 0), E - 1)];
+            float2 v = make_float2(pj.x - mi.x, pj.y - mi.y);
+            if (kp >= kpz) v = make_float2(0.f, 0.f);
+            if (kp == 0) v = Vs(sl)[i];
+            if (kp == 1) v = mi;
+            *reinterpret_cast<float2 *>(rows + 2 * idx) = v;
+          }
+        }
+      }
+
+      // ---- reward (simple_spread.py:72-82) + benchmark_data: lane (slot, a) = landmark a and agent a ----------------
+      if (b.rew || b.info_rew) {
+        const bool hl = ok && a < L, hi = have;
+        const float2 pl = Q[a < L ? a : 0];
+        const float2 pi = Q[L + (a < A ? a : 0)];
+        const float ri = sizeq[L + (a < A ? a : 0)];
+        float m2 = INFINITY;
+        int c = 0;
+        for (int j = 0; j < A; ++j) {
+          const float2 pa = Q[L + j];
+          m2 = fminf(m2, sq2d(pa.x - pl.x, pa.y - pl.y));
+          c += sqrt_lt(sq2d(pa.x - pi.x, pa.y - pi.y), sizeq[L + j] + ri) ? 1 : 0;   // includes j == a
+        }
+        float neg = hl ? -fast_sqrt(m2) : 0.f;
+        int occ = (hl && sqrt_lt(m2, 0.1f)) ? 1 : 0;
+        c = (hi && (__float_as_int(aconst[a < A ? a : 0].w) & kCollide)) ? c : 0;
+        float csum = (float)c;
+        for (int o = AP >> 1; o > 0; o >>= 1) {   // segmented: xor offsets stay inside the slot
+          neg += __shfl_xor(neg, o, kWave);
+          occ += __shfl_xor(occ, o, kWave);
+          csum += __shfl_xor(csum, o, kWave);
+        }
+        if (hi) {
+          const float tot = (float)A * neg - csum;   // environment.py:100-102
+          const float r = neg - (float)c;
+          if (b.rew) b.rew[(size_t)a * B + w] = d.collaborative ? tot : r;
+          if (b.done) b.done[(size_t)a * B + w] = 0;
+          if (b.info_rew) {
+            b.info_rew[(size_t)a * B + w] = r;
+            b.info_collisions[(size_t)a * B + w] = c;
+            b.info_min_dists[(size_t)a * B + w] = -neg;
+            b.info_occupied[(size_t)a * B + w] = occ;
+          }
+        }
+      } else if (b.done && have) {
+        b.done[(size_t)a * B + w] = 0;
+      }
+    }
+    wave_sync();
+  }
+}
+
 }  // namespace
 
 int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream,
@@ -576,6 +838,21 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
   const unsigned np = (unsigned)padded;
   RollArgs ra;
   std::memset(&ra, 0, sizeof(ra));
+  const int amax = d.A > d.L ? d.A : d.L;
+  if (!roll && amax <= 32 && d.A + d.L <= kWave) {
+    // several worlds per wave (k_multi): AP lanes per world slot
+    const int AP = amax <= 8 ? 8 : amax <= 16 ? 16 : 32, WPW = kWave / AP;
+    const size_t mlds = cv.shared_bytes + (size_t)kWavesPerWg * WPW * (2 * (d.A + d.L) + 2 * d.A) * sizeof(float2);
+    if (mlds <= 64 * 1024) {
+      const size_t mg = (B + (size_t)kWavesPerWg * WPW - 1) / ((size_t)kWavesPerWg * WPW);
+      const size_t mp = (mg + 63) / 64 * 64;
+      const dim3 mgrid((unsigned)(mp < cap ? mp : cap));
+      if (phys && out) hipLaunchKernelGGL((k_multi<true, true>), mgrid, block, mlds, stream, d, b, B, (unsigned)mp, AP);
+      else if (phys) hipLaunchKernelGGL((k_multi<true, false>), mgrid, block, mlds, stream, d, b, B, (unsigned)mp, AP);
+      else hipLaunchKernelGGL((k_multi<false, true>), mgrid, block, mlds, stream, d, b, B, (unsigned)mp, AP);
+      return (int)hipGetLastError();
+    }
+  }
   if (roll) {
     if (!(phys && out)) return MPE_EUNSUPPORTED;
     hipLaunchKernelGGL((k_wave<true, true, true>), grid, block, lds, stream, d, b, B, np, *roll);
