@@ -137,6 +137,12 @@ CONFIGS = [
     ("simple_spread", lambda: ospec.simple_spread(8), {"num_agents": 8}, 512, 3),       # wide kernel, small N
     ("simple_spread", lambda: ospec.simple_spread(20, 12), {"num_agents": 20, "num_landmarks": 12}, 256, 2),
     ("simple_spread", lambda: ospec.simple_spread(64), {"num_agents": 64}, 96, 2),      # configs[3] arithmetic
+    # several worlds per wave (k_multi): 8 / 4 / 2 worlds per wave, ragged last waves, D % 4 != 0 (8-byte pieces)
+    ("simple_spread", lambda: ospec.simple_spread(7), {"num_agents": 7}, 1001, 2),
+    ("simple_spread", lambda: ospec.simple_spread(16), {"num_agents": 16}, 333, 2),
+    ("simple_spread", lambda: ospec.simple_spread(32), {"num_agents": 32}, 131, 2),
+    ("simple_spread", lambda: ospec.simple_spread(5, 9), {"num_agents": 5, "num_landmarks": 9}, 257, 2),
+    ("simple_spread", lambda: ospec.simple_spread(12, 3), {"num_agents": 12, "num_landmarks": 3}, 100, 2),
 ]
 
 
