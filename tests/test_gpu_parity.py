@@ -406,3 +406,47 @@ def test_batch_multi_agent_env_concatenates_per_agent_lists():
     act = [torch.zeros((8, 5), device="cuda") for _ in range(7)]
     obs, rew, done, info = both.step(act, 0)
     assert len(obs) == len(rew) == len(done) == 7 and info == {"n": []}
+
+
+@pytest.mark.parametrize("N,B", [(16, 300), (40, 90)])
+def test_large_worlds_other_entry_paths(N, B):
+    """The large-N kernels (several worlds per wave for N=16, a wave per world for N=40) through their other
+    doors: integer action ids (discrete_action_input; opposite sign convention), and World.step alone
+    (mpe_world_step) under a user scenario whose callbacks stay in Python -- against the fused step."""
+    rs = np.random.RandomState(N)
+    pos = rs.uniform(-1, 1, (B, 2 * N, 2)).astype(np.float32)
+    pos[::2] *= 0.5
+    vel = rs.uniform(-0.4, 0.4, (B, N, 2)).astype(np.float32)
+    ids = rs.randint(0, 5, size=(N, B))
+    swap = np.array([0, 2, 1, 4, 3])                       # id 1 = -x, one-hot index 1 = +x
+    rows = torch.as_tensor(np.eye(5, dtype=np.float32)[swap[ids]]).cuda()
+    ref = mpe.make_env("simple_spread", batch_size=B, num_agents=N)
+    ref.world.set_state(pos, vel)
+    o_ref, r_ref, _, _ = ref.step(rows)
+    p_ref, v_ref = ref.world.get_state()
+    # integer ids
+    e_id = mpe.make_env("simple_spread", batch_size=B, num_agents=N)
+    e_id.discrete_action_input = True
+    e_id.world.set_state(pos, vel)
+    o_id, r_id, _, _ = e_id.step(torch.as_tensor(ids.astype(np.int32)).cuda())
+    p_id, v_id = e_id.world.get_state()
+    assert np.array_equal(p_id, p_ref) and np.array_equal(v_id, v_ref)
+    for i in (0, N // 2, N - 1):
+        assert torch.equal(o_id[i], o_ref[i]) and torch.equal(r_id[i], r_ref[i])
+    # generic path: the same scenario class with an overridden (equivalent) reward -> torch callbacks + mpe_world_step
+    Base = mpe.scenarios.load("simple_spread.py").Scenario
+
+    class Mine(Base):
+        def reward(self, agent, world):
+            return Base.reward(self, agent, world)
+    sc = Mine()
+    w = sc.make_world(batch_size=B, num_agents=N)
+    e_gen = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation)
+    assert not e_gen.fused
+    w.set_state(pos, vel)
+    o_g, r_g, _, _ = e_gen.step([rows[i] for i in range(N)])
+    p_g, v_g = w.get_state()
+    assert np.array_equal(p_g, p_ref) and np.array_equal(v_g, v_ref)     # the same physics kernel arithmetic
+    for i in (0, N - 1):
+        close(np_(o_g[i]), np_(o_ref[i]))
+        close(np_(r_g[i]), np_(r_ref[i]))
