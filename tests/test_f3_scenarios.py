@@ -285,3 +285,65 @@ def test_discrete_action_input_on_a_comm_scenario_matches_one_hot_rows():
     for i in range(A):
         close(np_(oi[i]), np_(of[i]), what="obs%d" % i)
         close(np_(ri[i]) * np.ones(B), np_(rf[i]) * np.ones(B), what="rew%d" % i)
+
+
+@pytest.mark.gpu
+def test_action_noise_and_scripted_agents_on_the_generic_path():
+    """core.py:119-120,138,176 (u_noise / c_noise: Gaussian noise on the applied force and the emitted word) and
+    core.py:112-114,119-120 (agents with an action_callback are scripted: not policy agents, stepped by the world).
+    No shipped scenario sets them; they force the generic path, where the noise comes from torch's
+    generator, so the check re-draws the same normals from the same seed."""
+    B = 257
+    Base = mpe.scenarios.load("simple_speaker_listener.py").Scenario
+    sc = Base()
+    w = sc.make_world(batch_size=B)
+    w.agents[1].u_noise = 0.5                  # the listener moves
+    w.agents[0].c_noise = 0.25                 # the speaker speaks
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation)
+    assert not env.fused
+    env.reset(seeds=np.arange(B) + 3)
+    pos0, vel0 = w.get_state()
+    rs = np.random.RandomState(0)
+    word = np.eye(3, dtype=np.float32)[rs.randint(0, 3, B)]
+    move = np.eye(5, dtype=np.float32)[rs.randint(0, 5, B)]
+    torch.manual_seed(11)
+    obs, _, _, _ = env.step([torch.as_tensor(word).cuda(), torch.as_tensor(move).cuda()])
+    torch.manual_seed(11)
+    nu = torch.randn(B, 2, device="cuda").cpu().numpy() * 0.5       # World.step draws u noise first (agents in order)
+    nc = torch.randn(B, 3, device="cuda").cpu().numpy() * 0.25      # then update_agent_state draws c noise
+    u = np.stack([move[:, 1] - move[:, 2], move[:, 3] - move[:, 4]], 1) * 5.0 + nu
+    v = vel0[:, 1] * 0.75 + u * 0.1            # no contacts in this scenario (nothing collides)
+    p = pos0[:, 1] + v * 0.1
+    pos1, vel1 = w.get_state()
+    close(vel1[:, 1], v, what="noisy velocity")
+    close(pos1[:, 1], p, what="noisy position")
+    close(np_(w.agents[0].state.c), word + nc, what="noisy word")
+    close(np_(obs[1])[:, -3:], word + nc, what="listener hears the noisy word")
+
+    # scripted agent: the prey of simple_tag runs away along +x by itself
+    sc = mpe.scenarios.load("simple_tag.py").Scenario()
+    w = sc.make_world(batch_size=B)
+
+    def flee(agent, world):
+        act = mpe.core.Action()
+        act.u = torch.zeros((world.batch_size, 2), device=world.device)
+        act.u[:, 0] = agent.accel
+        act.c = torch.zeros((world.batch_size, world.dim_c), device=world.device)
+        return act
+    w.agents[3].action_callback = flee
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation)
+    assert env.n == 3 and not env.fused and len(w.scripted_agents) == 1
+    env.reset(seeds=np.arange(B) + 5)
+    ref = mpe.make_env("simple_tag", batch_size=B)
+    ref.reset(seeds=np.arange(B) + 5)
+    assert np.array_equal(ref.world.get_state()[0], w.get_state()[0])
+    acts = rs.randint(0, 5, (3, B))
+    rows = [torch.as_tensor(np.eye(5, dtype=np.float32)[acts[i]]).cuda() for i in range(3)]
+    plus_x = torch.zeros(B, 5, device="cuda"); plus_x[:, 1] = 1.0
+    o_s, r_s, _, _ = env.step(rows)
+    o_r, r_r, _, _ = ref.step(rows + [plus_x])
+    assert np.array_equal(ref.world.get_state()[0], w.get_state()[0])
+    assert len(o_s) == 3
+    for i in range(3):
+        close(np_(o_s[i]), np_(o_r[i]))
+        close(np_(r_s[i]), np_(r_r[i]))
