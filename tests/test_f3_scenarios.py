@@ -347,3 +347,70 @@ def test_action_noise_and_scripted_agents_on_the_generic_path():
     for i in range(3):
         close(np_(o_s[i]), np_(o_r[i]))
         close(np_(r_s[i]), np_(r_r[i]))
+
+
+def _mirror_case(name, B, kw):
+    rs = np.random.RandomState(B % 9973)
+    env = mpe.make_env(name, batch_size=B, **kw)
+    assert env.fused
+    A, E = len(env.world.agents), len(env.world.entities)
+    pos = rs.uniform(-1, 1, (B, E, 2)).astype(np.float32)
+    pos[::3] *= 0.3
+    vel = rs.uniform(-0.7, 0.7, (B, A, 2)).astype(np.float32)
+    pops = env.world.choice_pops
+    choice = np.stack([rs.randint(0, n, size=B) for n in pops], axis=1) if pops else np.zeros((B, 0), np.int64)
+    act = random_actions(env, rs, B)
+
+    def run(p, v, a):
+        env.world.set_state(p, v)
+        set_choices(env, choice)
+        o, r, _, _ = env.step(a)
+        ps, vs = env.world.get_state()
+        return [np_(x).copy() for x in o], [np_(x).copy() * np.ones(B, np.float32) for x in r], ps, vs
+    o0, r0, p0, v0 = run(pos, vel, act)
+    return env, (pos, vel, act), (o0, r0, p0, v0), run
+
+
+MIRROR_CASES = [(n, 16384, {}) for n in ("simple", "simple_tag", "simple_adversary", "simple_push",
+                                         "simple_speaker_listener", "simple_reference", "simple_crypto",
+                                         "simple_world_comm")] + \
+               [("simple_spread", 524288, {}), ("simple_spread", 8192, {"num_agents": 16}),
+                ("simple_spread", 4096, {"num_agents": 64})]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B,kw", MIRROR_CASES, ids=["%s-%d" % (c[0], c[1]) for c in MIRROR_CASES])
+def test_mirror_and_transpose_symmetry_at_full_size(name, B, kw):
+    """Size-independent, bit-exact properties of the step (every kernel family, BASELINE sizes and the 8-GPU total
+    of 524 288 worlds on one device): reflecting the world in the y axis (x -> -x, moves +x <-> -x) negates the
+    x components of the state and of every geometric observation column and leaves every other output bit-identical
+    (IEEE negation commutes with every operation on the path; distances use dx*dx + dy*dy).  Swapping the axes
+    (x <-> y, moves accordingly) swaps the state components bit-exactly as well (fp addition commutes); rewards then
+    agree to rounding only where a scenario sums per-axis terms in a fixed order (simple_tag's boundary penalty)."""
+    env, (pos, vel, act), (o0, r0, p0, v0), run = _mirror_case(name, B, kw)
+    sx = np.array([-1.0, 1.0], np.float32)
+
+    def swap_moves(a, perm):
+        out = []
+        for agent, x in zip(env.agents, a):
+            x = x.clone()
+            if agent.movable:
+                x[:, :5] = x[:, perm]
+            out.append(x)
+        return out
+    om, rm, pm, vm = run(pos * sx, vel * sx, swap_moves(act, [0, 2, 1, 3, 4]))
+    assert np.array_equal(pm, p0 * sx) and np.array_equal(vm, v0 * sx)
+    n_geo = 0
+    for i in range(len(o0)):
+        assert np.array_equal(rm[i], r0[i]), "reward of agent %d changed under reflection" % i
+        same = (om[i] == o0[i]).all(axis=0)
+        neg = (om[i] == -o0[i]).all(axis=0)
+        assert (same | neg).all(), "agent %d: columns %s neither kept nor negated" % (i, np.nonzero(~(same | neg))[0])
+        n_geo += int((neg & ~same).sum())
+    movers = sum(1 for a in env.agents if a.movable)
+    assert n_geo >= movers                                # at least the x velocity column of every mover flips
+    ot, rt, pt, vt = run(pos[..., ::-1].copy(), vel[..., ::-1].copy(), swap_moves(act, [0, 3, 4, 1, 2]))
+    assert np.array_equal(pt, p0[..., ::-1]) and np.array_equal(vt, v0[..., ::-1])
+    for i in range(len(o0)):
+        close(rt[i], r0[i], what="reward under axis swap")
+        assert np.array_equal(np.sort(np.abs(ot[i]), axis=1), np.sort(np.abs(o0[i]), axis=1))
