@@ -323,6 +323,26 @@ def main():
             "compulsory_bytes_per_env_step": 4 * (obs_total + A) + A,
             "achieved_GBps_compulsory": (4 * (obs_total + A) + A) * B / (kf * 1e-6) / 1e9}
 
+    if not args.no_extra and args.mode == "graph" and S == 1:
+        # SURVEY 8d's "regenerate every step": `value` steps on moves already resident in HBM (the policy's output);
+        # here each step also draws its fresh moves on the device first
+        for how in ("inline",):
+            rr = RandomRollout(env, episode_len=EP, pool=16, regenerate=True)
+            gr = rr.capture(K)
+            gr.replay()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                sharding.barrier(dev)
+                t0 = time.perf_counter()
+                gr.replay()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            dtr = sharding.reduce_max(sorted(ts)[1], dev)
+            extra["moves_regenerated_every_step"] = {
+                "what": "graph of K x (mpe_random_actions -> mpe_step), resets every %d steps" % EP,
+                "value": B * K * world / dtr, "unit": "env-steps/s", "ms_per_step": dtr * 1e3 / K}
+
     if rank == 0:
         achieved = bytes_step * B / (k_us * 1e-6) / 1e9
         kname = ("mpe::k_split" if os.environ.get("MPE_STEP_IMPL") != "thread" else "mpe::k_narrow") if A <= 6 \

@@ -19,7 +19,11 @@ from . import _abi
 
 
 class RandomRollout(object):
-    def __init__(self, env, episode_len=25, pool=16, seed=None):
+    def __init__(self, env, episode_len=25, pool=16, seed=None, regenerate=False):
+        """regenerate: False -- the pool's tensors are drawn once and cycled (the policy's output is already resident
+        in HBM when the step is launched); True -- every step first draws its own fresh moves (`mpe_random_actions`
+        for global step t) on the same stream.  (Drawing them one step ahead on a side stream was measured too: the
+        fork/join per step costs more inside a HIP graph than the 2.8 us launch it hides -- 13.0 vs 9.4 us per step.)"""
         if not env.fused:
             raise _abi.MpeError("RandomRollout drives the fused built-in scenarios")
         self.env = env
@@ -32,6 +36,7 @@ class RandomRollout(object):
         self.pool = [torch.empty((A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=self.world.device)
                      for _ in range(pool)]
         self.t = 0          # global step counter (also indexes the Philox action stream)
+        self.regenerate = bool(regenerate)
         self._L = _abi.lib()
         self._lr = float(getattr(env._scenario, "landmark_range", 1.0))
         self._gen_desc = self.world.scenario_desc(_abi.MPE_SCN_GENERIC)
@@ -50,12 +55,18 @@ class RandomRollout(object):
             _abi.check(self._L.mpe_random_actions(act.data_ptr(), None, self.A, self.B, self.seed, p,
                                                   int(self.world.world_offset), self._stream()), "mpe_random_actions")
 
+    def _draw(self, t, stream):
+        _abi.check(self._L.mpe_random_actions(self.pool[t % len(self.pool)].data_ptr(), None, self.A, self.B, self.seed,
+                                              t, int(self.world.world_offset), stream), "mpe_random_actions")
+
     def enqueue(self, steps):
         """Enqueue `steps` env steps (and the resets that fall among them) on the current stream."""
         env, w = self.env, self.world
         L, desc, B = self._L, self._desc, self.B
         st = self._stream()
         for _ in range(steps):
+            if self.regenerate:
+                self._draw(self.t, st)
             if self.episode_len and self.t % self.episode_len == 0:
                 b = env._sets[0].bufs
                 _abi.check(L.mpe_reset(C.byref(self._gen_desc), C.byref(b), B, None, self._lr, self.seed,

@@ -141,6 +141,25 @@ def test_graph_replay_matches_eager():
         assert torch.equal(envs[0]._sets[s].obs, envs[1]._sets[s].obs)
 
 
+def test_regenerated_moves_match_the_fused_rollout():
+    """Fresh moves every step, drawn by `mpe_random_actions` in front of each step on the step's
+    stream, eager and as a captured graph: the same trajectory as the fused
+    rollout, which draws its moves in-kernel (more steps than the pool has tensors, so cycling would differ)."""
+    B, T = 4096, 60
+    envs = [mpe.make_env("simple_spread", batch_size=B, seed=5) for _ in range(3)]
+    fused = RandomRollout(envs[0], episode_len=25, pool=2)
+    fused.fused(T)
+    eager = RandomRollout(envs[1], episode_len=25, pool=4, regenerate=True)
+    eager.enqueue(T)
+    graph = RandomRollout(envs[2], episode_len=25, pool=4, regenerate=True)
+    g = graph.capture(T)
+    g.replay()
+    torch.cuda.synchronize()
+    for e in envs[1:]:
+        assert torch.equal(e.world.pos, envs[0].world.pos) and torch.equal(e.world.vel, envs[0].world.vel)
+        assert torch.equal(e._sets[(T - 1) & 1].obs, envs[0]._sets[0].obs)
+
+
 def test_rollout_outputs_against_oracle():
     """A free-running fused rollout is still the reference's physics: replay its first steps in the
     fp64 oracle from the trajectory's own observations (positions are in the observation)."""
