@@ -162,6 +162,15 @@ int mpe_reset(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, co
 int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed,
                        uint64_t step, int64_t world_offset, void *stream);
 
+/* Episode bookkeeping -- NEW API, no reference counterpart: `done` is always False in the reference
+ * (environment.py:132-135, make_env.py:41-43: no done_callback) and the caller counts steps itself
+ * (bin/interactive.py, MADDPG's 25-step episodes).  After a step: episode_step[w] += 1 for every
+ * world; worlds that reach max_episode_steps (> 0) get done[a][w] = 1 for all n_agents rows (other
+ * entries are left as the step / the done_callback wrote them); with clear_finished != 0 their
+ * counter restarts at 0 (the caller resets them next: mpe_reset with mask = a done row).          */
+int mpe_episode_tick(int32_t *episode_step, uint8_t *done, int32_t n_agents, int64_t B,
+                     int32_t max_episode_steps, int32_t clear_finished, void *stream);
+
 /* mpe_rollout_random: T consecutive env steps in ONE launch, with in-kernel uniform random moves
  * (the rows mpe_random_actions(step0+t) would write) and an in-kernel reset whenever the global
  * step index step0+t is a multiple of `episode_len` (0 = never; episode = (step0+t)/episode_len,

@@ -269,8 +269,8 @@ class World(object):
         A, E, B = len(self.agents), len(self.entities), self.batch_size
         choices = list(choices or [])
         idx = None
-        m = None if mask is None else torch.as_tensor(mask).cpu().numpy().astype(bool)
         if seeds is not None or self.rng_mode == "numpy":
+            m = None if mask is None else torch.as_tensor(mask).cpu().numpy().astype(bool)
             if seeds is not None:
                 assert len(seeds) == B
             pos, vel = self.get_state() if m is not None else (np.zeros((B, E, 2), np.float64), np.zeros((B, A, 2)))

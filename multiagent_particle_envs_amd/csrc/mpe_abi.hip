@@ -312,6 +312,16 @@ int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, ui
                                                static_cast<hipStream_t>(stream)), what);
 }
 
+int mpe_episode_tick(int32_t *episode_step, uint8_t *done, int32_t n_agents, int64_t B, int32_t max_episode_steps,
+                     int32_t clear_finished, void *stream) {
+  const char *what = "mpe_episode_tick";
+  if (!episode_step || !done) return fail(MPE_EINVAL, "%s: episode_step and done must be device pointers", what);
+  if (n_agents < 1 || B < 0 || max_episode_steps < 0) return fail(MPE_EINVAL, "%s: bad n_agents/B/max_episode_steps", what);
+  if (B == 0) return 0;
+  return hip_result(mpe::launch_episode_tick(episode_step, done, n_agents, (size_t)B, max_episode_steps,
+                                             clear_finished, static_cast<hipStream_t>(stream)), what);
+}
+
 int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, int32_t T, int32_t episode_len,
                        float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
                        int32_t trajectory, void *stream) {

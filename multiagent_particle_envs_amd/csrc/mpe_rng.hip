@@ -49,6 +49,28 @@ k_random_actions(float *__restrict__ act, int32_t *__restrict__ ids, size_t B, u
   }
 }
 
+// Episode bookkeeping (new API, SURVEY 8 f1: the reference never ends an episode, environment.py:132-135): one
+// thread per world bumps the world's step counter, ORs "horizon reached" into the A done rows the step kernel (zeros)
+// or the done_callback wrote, and clears the counter of a finished world when its reset follows (auto-reset).
+__global__ void __launch_bounds__(kBlock)
+k_episode_tick(int32_t *__restrict__ episode_step, uint8_t *__restrict__ done, size_t B, int A, int max_steps,
+               int clear_finished) {
+  const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= B) return;
+  const int c = episode_step[w] + 1;
+  const bool over = max_steps > 0 && c >= max_steps;
+  episode_step[w] = (over && clear_finished) ? 0 : c;
+  if (over)
+    for (int a = 0; a < A; ++a) done[(size_t)a * B + w] = 1;
+}
+
+int launch_episode_tick(int32_t *episode_step, uint8_t *done, int A, size_t B, int max_steps, int clear_finished,
+                        hipStream_t stream) {
+  hipLaunchKernelGGL(k_episode_tick, dim3((unsigned)((B + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, episode_step,
+                     done, B, A, max_steps, clear_finished);
+  return (int)hipGetLastError();
+}
+
 int launch_reset(int A, int L, const MpeBuffers &b, size_t B, const uint8_t *mask, float landmark_range,
                  uint64_t seed, uint64_t episode, uint64_t world_offset, int n_choices, const int32_t *pop,
                  hipStream_t stream) {

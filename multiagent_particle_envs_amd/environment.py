@@ -90,7 +90,7 @@ class MultiAgentEnv(object):
 
     def __init__(self, world, reset_callback=None, reward_callback=None, observation_callback=None,
                  info_callback=None, done_callback=None, shared_viewer=True,
-                 numpy_io=False, fresh_outputs=False, fused=None):
+                 numpy_io=False, fresh_outputs=False, fused=None, max_episode_steps=None, auto_reset=False):
         self.world = world
         self.agents = self.world.policy_agents
         self.n = len(world.policy_agents)
@@ -106,6 +106,15 @@ class MultiAgentEnv(object):
         self.force_discrete_action = world.discrete_action if hasattr(world, 'discrete_action') else False
         self.shared_reward = world.collaborative if hasattr(world, 'collaborative') else False
         self.time = 0
+        # episode bookkeeping -- new API: the reference never ends an episode (environment.py:132-135,
+        # done_callback is None in make_env.py:41-43) and leaves counting to the caller.  Off by default (parity).
+        self.max_episode_steps = int(max_episode_steps) if max_episode_steps else 0
+        self.auto_reset = bool(auto_reset)
+        if self.auto_reset and not self.max_episode_steps:
+            raise _abi.MpeError("auto_reset needs max_episode_steps")
+        self.episode_step = None      # int32 [B] on the device: steps since each world's last reset
+        self._steps_taken = 0         # env steps since construction
+        self._may_finish = set()      # values of _steps_taken at which some world can reach the horizon
         self.numpy_io = bool(numpy_io)
         self.fresh_outputs = bool(fresh_outputs)
 
@@ -276,7 +285,59 @@ class MultiAgentEnv(object):
             for i, agent in enumerate(self.world.agents):
                 if not agent.silent:
                     agent.state.c = self._comm[i]
+        if self.max_episode_steps and self._episode_tick(out.done):
+            self._observe_into(out)         # worlds that finished were reset: their rows are the new episode's first
         return self._deliver(out.obs_n, out.reward_n, out.done_n, out.info_n(self))
+
+    def _episode_tick(self, done):
+        """After a step: count it for every world, mark the worlds that reached max_episode_steps done (all agents),
+        and -- auto_reset -- start their next episode (reset_callback with mask = the done row).  `done` is the
+        [A,B] bool tensor the step wrote.  Returns True when a reset was issued (observations must be refreshed).
+        No host synchronisation: which worlds finish is decided on the device; the host only tracks at which step
+        counts some world CAN finish (max_episode_steps after every full, masked or automatic reset) to skip the
+        reset launches everywhere else."""
+        w = self.world
+        if self.episode_step is None:
+            self.episode_step = torch.zeros(self.batch_size, dtype=torch.int32, device=w.device)
+            self._may_finish.add(self._steps_taken + self.max_episode_steps)
+        self._steps_taken += 1
+        _abi.check(_abi.lib().mpe_episode_tick(self.episode_step.data_ptr(), done.data_ptr(), done.shape[0],
+                                               self.batch_size, self.max_episode_steps, 1 if self.auto_reset else 0,
+                                               self._stream()), "mpe_episode_tick")
+        if self._steps_taken not in self._may_finish:
+            return False
+        self._may_finish.discard(self._steps_taken)
+        if not self.auto_reset:
+            return False
+        self.reset_callback(w, mask=done[0])
+        if self._comm is not None:
+            self._comm.masked_fill_(done[0][None, :, None], 0.0)
+        self._may_finish.add(self._steps_taken + self.max_episode_steps)
+        return True
+
+    def _note_reset(self, mask):
+        if not self.max_episode_steps:
+            return
+        if self.episode_step is not None:
+            if mask is None:
+                self.episode_step.zero_()
+            else:
+                self.episode_step.masked_fill_(torch.as_tensor(mask, device=self.world.device).bool(), 0)
+        if mask is None:
+            self._may_finish.clear()
+        self._may_finish.add(self._steps_taken + self.max_episode_steps)
+
+    def _observe_into(self, out):
+        """Rewrite the observation rows of `out` from the current state (mpe_observe); rewards, dones, info stay."""
+        b = out.bufs
+        saved = (b.rew, b.done, b.info_rew, b.info_collisions, b.info_min_dists, b.info_occupied, b.act, b.ids, b.u)
+        b.rew = b.done = b.info_rew = b.info_collisions = b.info_min_dists = b.info_occupied = None
+        b.act = b.ids = b.u = None
+        try:
+            _abi.check(_abi.lib().mpe_observe(C.byref(self._desc), C.byref(b), self.batch_size, self._stream()),
+                       "mpe_observe")
+        finally:
+            (b.rew, b.done, b.info_rew, b.info_collisions, b.info_min_dists, b.info_occupied, b.act, b.ids, b.u) = saved
 
     def reset(self, seeds=None, mask=None):
         """environment.py:106-116.  `seeds` (one per world) gives reference-exact initial states
@@ -288,6 +349,7 @@ class MultiAgentEnv(object):
         if mask is not None:
             kw["mask"] = mask
         self.reset_callback(world, **kw)
+        self._note_reset(mask)
         self.agents = world.policy_agents
         if not self.fused:
             obs_n = [self._get_obs(agent) for agent in self.agents]
@@ -299,15 +361,7 @@ class MultiAgentEnv(object):
             else:
                 self._comm[:, torch.as_tensor(mask, device=self._comm.device).bool()] = 0.0
         out = self._next_set()
-        b = out.bufs
-        saved = (b.rew, b.done, b.info_rew, b.info_collisions, b.info_min_dists, b.info_occupied)
-        b.rew = b.done = b.info_rew = b.info_collisions = b.info_min_dists = b.info_occupied = None
-        b.act = b.ids = b.u = None
-        try:
-            _abi.check(_abi.lib().mpe_observe(C.byref(self._desc), C.byref(b), self.batch_size, self._stream()),
-                       "mpe_observe")
-        finally:
-            b.rew, b.done, b.info_rew, b.info_collisions, b.info_min_dists, b.info_occupied = saved
+        self._observe_into(out)
         return self._deliver(out.obs_n, None, None, None)[0]
 
     def _deliver(self, obs_n, reward_n, done_n, info_n):
@@ -415,6 +469,12 @@ class MultiAgentEnv(object):
         if self.shared_reward:  # environment.py:100-102: every agent gets the sum
             total = torch.stack([torch.as_tensor(r, device=self.world.device) for r in reward_n]).sum(dim=0)
             reward_n = [total] * self.n
+        if self.max_episode_steps:
+            done = torch.stack([torch.as_tensor(d, device=self.world.device).bool().expand(self.batch_size)
+                                for d in done_n]).contiguous()
+            if self._episode_tick(done):
+                obs_n = [self._get_obs(agent) for agent in self.agents]
+            done_n = [done[i] for i in range(len(done_n))]
         return self._deliver(obs_n, reward_n, done_n, info_n)
 
     # rendering is a GUI concern of the reference (environment.py:200-263) and is not provided

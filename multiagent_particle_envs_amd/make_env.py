@@ -5,12 +5,15 @@
     env = make_env('simple_spread', batch_size=65536)        # B worlds, torch tensors on the GPU
     env = make_env('simple_spread', batch_size=4096, num_agents=64)   # scenario kwargs pass through
 
+    env = make_env('simple_tag', batch_size=16384, max_episode_steps=25, auto_reset=True)
+                                                             # new: done at the horizon + device-side auto-reset
+
 Everything on the step path runs in libmpe_hip.so on a HIP device; there is no CPU fallback.
 """
 
 
 def make_env(scenario_name, benchmark=False, batch_size=None, device=None, seed=0, fresh_outputs=False,
-             fused=None, **scenario_kwargs):
+             fused=None, max_episode_steps=None, auto_reset=False, **scenario_kwargs):
     from .environment import MultiAgentEnv
     from . import scenarios
 
@@ -25,6 +28,7 @@ def make_env(scenario_name, benchmark=False, batch_size=None, device=None, seed=
         scenario.reset_world(world)
     info_cb = getattr(scenario, "benchmark_data", None) if benchmark else None
     env = MultiAgentEnv(world, scenario.reset_world, scenario.reward, scenario.observation, info_cb,
-                        numpy_io=compat, fresh_outputs=fresh_outputs or compat, fused=fused)
+                        numpy_io=compat, fresh_outputs=fresh_outputs or compat, fused=fused,
+                        max_episode_steps=max_episode_steps, auto_reset=auto_reset)
     env.scenario = scenario
     return env

@@ -414,3 +414,57 @@ def test_mirror_and_transpose_symmetry_at_full_size(name, B, kw):
     for i in range(len(o0)):
         close(rt[i], r0[i], what="reward under axis swap")
         assert np.array_equal(np.sort(np.abs(ot[i]), axis=1), np.sort(np.abs(o0[i]), axis=1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,fused", [("simple_tag", True), ("simple_tag", False), ("simple_adversary", True),
+                                        ("simple_adversary", False), ("simple_reference", True)])
+def test_episode_horizon_and_device_side_auto_reset(name, fused):
+    """New API (the reference never ends an episode, environment.py:132-135): with max_episode_steps the
+    env counts steps per world on the device and reports done at the horizon; with auto_reset the finished worlds
+    start their next episode inside step() (masked `mpe_reset`, no host synchronisation) and the returned
+    observation rows are the new episode's first.  Mirrored here by a plain env that is reset by hand with the same
+    masks at the same moments: states, goals, observations and rewards must stay bit-identical throughout."""
+    B, H = 300, 5
+    env = mpe.make_env(name, batch_size=B, seed=3, fused=fused, max_episode_steps=H, auto_reset=True)
+    ref = mpe.make_env(name, batch_size=B, seed=3, fused=fused)
+    assert env.fused == fused
+    A = env.n
+    rs = np.random.RandomState(1)
+    half = torch.as_tensor(rs.rand(B) < 0.5).cuda()
+    o_e, o_r = env.reset(), ref.reset()
+    finishing = {5: None, 10: ~half, 12: half, 15: ~half}      # step -> worlds that reach the horizon (None = all)
+    for t in range(1, 17):
+        act = random_actions(env, rs, B)
+        o_e, r_e, d_e, _ = env.step(act)
+        o_r, r_r, d_r, _ = ref.step(act)
+        m = finishing.get(t, False)
+        want_done = torch.zeros(B, dtype=torch.bool, device="cuda") if m is False else \
+            (torch.ones(B, dtype=torch.bool, device="cuda") if m is None else m)
+        for i in range(A):
+            assert torch.equal(d_e[i].bool(), want_done), (t, i)
+            assert not d_r[i].any()
+            assert torch.equal(r_e[i] * torch.ones(B, device="cuda"), r_r[i] * torch.ones(B, device="cuda")), (t, i)
+        if m is not False:
+            o_r = ref.reset(mask=m) if m is not None else ref.reset()
+        if t == 7:                                                # a manual masked reset in the middle of an episode
+            o_e, o_r = env.reset(mask=half), ref.reset(mask=half)
+        assert np.array_equal(env.world.get_state()[0], ref.world.get_state()[0]), t
+        assert np.array_equal(env.world.get_state()[1], ref.world.get_state()[1]), t
+        if env.world.choice_i32 is not None:
+            assert torch.equal(env.world.choice_i32, ref.world.choice_i32), t
+        for i in range(A):
+            assert torch.equal(o_e[i], o_r[i]), (t, i)
+    want = torch.where(half, torch.tensor(4, device="cuda"), torch.tensor(1, device="cuda")).int()
+    assert torch.equal(env.episode_step, want)                   # half finished at 12, the rest at 15; now t = 16
+
+    # without auto_reset: done stays up until the caller resets
+    env2 = mpe.make_env(name, batch_size=B, seed=3, fused=fused, max_episode_steps=3)
+    env2.reset()
+    seen = []
+    for t in range(1, 8):
+        _, _, d, _ = env2.step(random_actions(env2, rs, B))
+        seen.append(bool(d[0].all()) if d[0].any() else False)
+        if t == 5:
+            env2.reset()
+    assert seen == [False, False, True, True, True, False, False]
