@@ -143,6 +143,25 @@ def bench_generic(args, env, dev, rank, world, sharding):
         walls.append(time.perf_counter() - t0)
         sharding.barrier(dev)
     dt = sharding.reduce_max(sorted(walls)[len(walls) // 2], dev)
+    # the same step captured once into a HIP graph (GraphedStep): one replay per step instead of ~100 launches
+    from multiagent_particle_envs_amd import GraphedStep
+    gs = GraphedStep(env, pool[0])
+
+    def run_graphed(n):
+        for k in range(n):
+            if EP and k % EP == 0:
+                env.reset()
+            gs.step(pool[k % len(pool)])
+    run_graphed(W)
+    walls = []
+    for _ in range(args.repeats):
+        sharding.barrier(dev)
+        t0 = time.perf_counter()
+        run_graphed(K)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+        sharding.barrier(dev)
+    dtg = sharding.reduce_max(sorted(walls)[len(walls) // 2], dev)
     if rank == 0:
         A, Lm = len(env.world.agents), len(env.world.landmarks)
         print(json.dumps({
@@ -153,6 +172,9 @@ def bench_generic(args, env, dev, rank, world, sharding):
             "config": {"workload": "%s A=%d L=%d, %d worlds/GPU, generic path (torch callbacks + mpe_world_step), "
                                    "random one-hot actions, reset every %d steps" % (args.scenario, A, Lm, B, EP),
                        "batch_per_gpu": B, "global_batch": B * world, "mode": "api-generic", "repeats": args.repeats},
+            "extra": {"graphed_step": {"what": "GraphedStep: the same env.step captured into a HIP graph, replayed per step "
+                                               "(actions copied into the graph's static inputs every step)",
+                                       "value": B * K * world / dtg, "unit": "env-steps/s", "ms_per_step": dtg * 1e3 / K}},
             "roofline": {"bound": "host", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                          "traffic": None, "note": "no fused kernel for this scenario: the step is ~100 small torch "
                                                   "launches + one HIP physics launch, bound by the Python host"},
@@ -175,6 +197,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (fused-rollout) measurement")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--generic", action="store_true",
+                    help="step through the generic path (torch callbacks + mpe_world_step) although a fused kernel exists")
     ap.add_argument("--streams", type=int, default=1,
                     help="cut the per-GPU batch into this many independent sub-batches, one HIP stream each")
     args = ap.parse_args()
@@ -205,7 +229,7 @@ def main():
     assert B % S == 0, "--batch must be a multiple of --streams"
     envs = []
     for s_ in range(S):                        # S sub-batches of B/S worlds, one HIP stream each
-        e = mpe.make_env(args.scenario, batch_size=B // S, seed=args.seed, **kw)
+        e = mpe.make_env(args.scenario, batch_size=B // S, seed=args.seed, fused=False if args.generic else None, **kw)
         e.world.world_offset = rank * B + s_ * (B // S)   # global world numbering: no shared RNG streams
         envs.append(e)
     env = envs[0]

@@ -127,7 +127,8 @@ class Agent(Entity):
 class EntityChoice(object):
     """A per-world pick among `entities` -- what the reference writes as
     `agent.goal_a = np.random.choice(world.landmarks)` (simple_adversary.py:44, simple_push.py:41, ...).
-    `index` is a [B] long tensor; attribute access gathers from the picked entity of every world, so
+    `index` is a [B] integer tensor -- pass a VIEW of persistent storage (`world.choice_i32[k]`) so that resets, which
+    rewrite it in place, are seen by a captured graph; attribute access gathers from the picked entity of every world, so
     reference-style scenario code (`agent.goal_a.state.p_pos`, `agent.goal_b.color`) runs unchanged."""
 
     def __init__(self, world, entities, index):
@@ -138,7 +139,7 @@ class EntityChoice(object):
     def _gather(self, per_entity):
         stack = torch.stack(per_entity, dim=0)                      # [K, B, w]
         ar = torch.arange(stack.shape[1], device=stack.device)
-        return stack[self.index.to(stack.device), ar]
+        return stack[self.index.to(stack.device).long(), ar]
 
     @property
     def state(self):
@@ -162,7 +163,7 @@ class EntityChoice(object):
         sizes = [e.size for e in self.entities]
         if all(x == sizes[0] for x in sizes):
             return sizes[0]
-        return torch.tensor(sizes, dtype=torch.float32, device=self.index.device)[self.index]
+        return self._world.constant(sizes)[self.index.long()]
 
 
 class World(object):
@@ -228,8 +229,20 @@ class World(object):
         self._desc = None
         return self
 
+    def constant(self, values):
+        """A small host constant (a colour, a list of sizes) as a cached fp32 device tensor: uploaded once, so
+        callbacks neither pay a host-to-device copy per step nor break HIP-graph capture (GraphedStep)."""
+        import numpy as np
+        arr = np.asarray(values, dtype=np.float32)
+        key = (arr.shape, arr.tobytes())
+        cache = self.__dict__.setdefault("_constants", {})
+        t = cache.get(key)
+        if t is None or t.device != torch.device(self.device):
+            t = cache[key] = torch.as_tensor(arr).to(self.device)
+        return t
+
     def _as_batch(self, value, width):
-        t = torch.as_tensor(value, dtype=torch.float32, device=self.device)
+        t = value.to(dtype=torch.float32, device=self.device) if torch.is_tensor(value) else self.constant(value)
         if t.dim() == 1:
             t = t.unsqueeze(0)
         return t.expand(self.batch_size, width)

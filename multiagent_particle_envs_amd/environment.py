@@ -482,6 +482,66 @@ class MultiAgentEnv(object):
         raise NotImplementedError("rendering is out of scope of the MI355X hot-path build (see DESIGN.md)")
 
 
+class GraphedStep(object):
+    """`env.step` captured once into a HIP graph and replayed: the host leaves the per-step loop.
+
+    The generic path (a user Scenario's torch callbacks around `mpe_world_step`) is a hundred small launches per
+    step, each costing the Python host microseconds; replaying them as one graph costs one launch call.  Nothing is
+    traced or compiled: the same kernels run in the same order on the same buffers.
+
+        g = GraphedStep(env, example_action_n)      # captures env.step(example)
+        obs_n, rew_n, done_n, info_n = g.step(action_n)       # copies action_n into g.action_n, replays
+        g.action_n[i].copy_(policy_output_i); g.step()        # or write the static inputs yourself
+
+    The returned tensors are the graph's static outputs (overwritten by the next replay).  Callbacks must be
+    capturable: no .item()/.cpu()/host branches on device data.  Episode bookkeeping (max_episode_steps) decides
+    on the host when to launch resets, so it is not captured: reset between replays with env.reset(...)."""
+
+    def __init__(self, env, action_n, warmup=3):
+        if env.numpy_io:
+            raise _abi.MpeError("GraphedStep works on device tensors (make_env(..., batch_size=B))")
+        if env.max_episode_steps:
+            raise _abi.MpeError("GraphedStep does not capture episode bookkeeping; count steps outside or use auto-reset eagerly")
+        self.env = env
+        dev = env.world.device
+        as_list = not torch.is_tensor(action_n)
+        self.action_n = [torch.as_tensor(a, device=dev).clone() for a in action_n] if as_list else action_n.clone()
+        fresh, env.fresh_outputs = env.fresh_outputs, True     # the graph owns its outputs
+        pos, vel = env.world.pos.clone(), env.world.vel.clone()
+        comm = [a.state.c.clone() if torch.is_tensor(a.state.c) else a.state.c for a in env.world.agents]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(warmup):            # allocator / code-object warm-up outside the capture
+                    env.step(self.action_n)
+                torch.cuda.synchronize(dev)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=side):
+                    self.outputs = env.step(self.action_n)
+        finally:
+            env.fresh_outputs = fresh
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self._comm_state = [a.state.c for a in env.world.agents]   # the tensors the graph writes (resets re-point state.c)
+        env.world.pos.copy_(pos)                   # the warm-up steps did not happen
+        env.world.vel.copy_(vel)
+        for a, c in zip(env.world.agents, comm):
+            if torch.is_tensor(c) and torch.is_tensor(a.state.c):
+                a.state.c.copy_(c)
+
+    def step(self, action_n=None):
+        if action_n is not None:
+            if torch.is_tensor(self.action_n):
+                self.action_n.copy_(action_n)
+            else:
+                for dst, src in zip(self.action_n, action_n):
+                    dst.copy_(torch.as_tensor(src, device=dst.device))
+        self.graph.replay()
+        for a, c in zip(self.env.world.agents, self._comm_state):
+            a.state.c = c
+        return self.outputs
+
+
 class BatchMultiAgentEnv(object):
     """The reference's list-of-envs wrapper (environment.py:288-335): per-agent lists of several envs
     concatenated, `n` = total number of agents.  Each member may itself be a batched env (the batch

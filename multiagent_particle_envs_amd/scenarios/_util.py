@@ -21,8 +21,20 @@ def is_collision(a, b):
 
 def const(world, values):
     """A per-entity constant vector (a colour) as a [B, w] tensor."""
-    t = torch.tensor(values, dtype=torch.float32, device=world.device)
+    t = world.constant(values)
     return t.unsqueeze(0).expand(world.batch_size, t.shape[0])
+
+
+def assign(obj, name, value):
+    """obj.name = value for a per-world tensor that a reset recomputes (a goal-dependent colour, a key): written IN
+    PLACE when obj.name already is a private tensor of that shape, so its address survives resets -- a captured HIP
+    graph (GraphedStep) keeps reading the live values."""
+    old = getattr(obj, name, None)
+    if torch.is_tensor(old) and old._base is None and old.shape == value.shape and old.dtype == value.dtype \
+            and old.device == value.device:
+        old.copy_(value)
+    else:
+        setattr(obj, name, value.clone() if value._base is not None else value)
 
 
 def zeros(world, w=None):

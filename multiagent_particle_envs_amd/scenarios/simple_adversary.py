@@ -58,8 +58,8 @@ class Scenario(BaseScenario):
             world.agents[i].color = U.const(world, [0.35, 0.35, 0.85])
         for i, landmark in enumerate(world.landmarks):   # goal landmark green, the others grey (:41-46)
             is_goal = (self.goal_index == i).unsqueeze(1)
-            landmark.color = torch.where(is_goal, U.const(world, [0.15, 0.65, 0.15]), U.const(world, [0.15, 0.15, 0.15]))
-        goal = EntityChoice(world, world.landmarks, self.goal_index)
+            U.assign(landmark, "color", torch.where(is_goal, U.const(world, [0.15, 0.65, 0.15]), U.const(world, [0.15, 0.15, 0.15])))
+        goal = EntityChoice(world, world.landmarks, world.choice_i32[0])
         for agent in world.agents:
             agent.goal_a = goal
 

@@ -59,14 +59,15 @@ class Scenario(BaseScenario):
 
     def _apply(self, world):
         for agent in world.agents:
-            agent.color = U.const(world, [0.75, 0.25, 0.25] if agent.adversary else [0.25, 0.25, 0.25])
+            if agent is not world.agents[1]:       # (agents[1] takes the goal's colour below, :67)
+                agent.color = U.const(world, [0.75, 0.25, 0.25] if agent.adversary else [0.25, 0.25, 0.25])
         for i, landmark in enumerate(world.landmarks):   # :56-61: landmark i's "colour" is the one-hot e_i of width dim_c
             c = [0.0] * world.dim_c
             c[i] += 1
             landmark.color = U.const(world, c)
-        goal = EntityChoice(world, world.landmarks, self.choice_index[:, 0])
-        world.agents[1].color = goal.color
-        world.agents[2].key = EntityChoice(world, world.landmarks, self.choice_index[:, 1]).color
+        goal = EntityChoice(world, world.landmarks, world.choice_i32[0])
+        U.assign(world.agents[1], "color", goal.color)
+        U.assign(world.agents[2], "key", EntityChoice(world, world.landmarks, world.choice_i32[1]).color)
         for agent in world.agents:
             agent.goal_a = goal
 

@@ -52,13 +52,13 @@ class Scenario(BaseScenario):
             c = [0.1, 0.1, 0.1]
             c[i + 1] += 0.8
             landmark.color = U.const(world, c)
-        goal = EntityChoice(world, world.landmarks, self.goal_index)
+        goal = EntityChoice(world, world.landmarks, world.choice_i32[0])
         for agent in world.agents:                        # :41-49
             agent.goal_a = goal
             if agent.adversary:
                 agent.color = U.const(world, [0.75, 0.25, 0.25])
             else:                                          # channel goal.index + 1 += 0.5
-                agent.color = U.const(world, [0.25, 0.25, 0.25]) + U.one_hot_rows(world, self.goal_index + 1, 3, 0.5)
+                U.assign(agent, "color", U.const(world, [0.25, 0.25, 0.25]) + U.one_hot_rows(world, self.goal_index + 1, 3, 0.5))
 
     def reward(self, agent, world):                # simple_push.py:60-62
         return self.adversary_reward(agent, world) if agent.adversary else self.agent_reward(agent, world)

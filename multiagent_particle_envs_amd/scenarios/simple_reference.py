@@ -52,10 +52,10 @@ class Scenario(BaseScenario):
         world.landmarks[1].color = U.const(world, [0.25, 0.75, 0.25])
         world.landmarks[2].color = U.const(world, [0.25, 0.25, 0.75])
         a0, a1 = world.agents
-        a0.goal_a, a0.goal_b = a1, EntityChoice(world, world.landmarks, self.goal_index[:, 0])
-        a1.goal_a, a1.goal_b = a0, EntityChoice(world, world.landmarks, self.goal_index[:, 1])
-        a1.color = a0.goal_b.color   # :43-44 (goal_a.color = goal_b.color; rendering only)
-        a0.color = a1.goal_b.color
+        a0.goal_a, a0.goal_b = a1, EntityChoice(world, world.landmarks, world.choice_i32[0])
+        a1.goal_a, a1.goal_b = a0, EntityChoice(world, world.landmarks, world.choice_i32[1])
+        U.assign(a1, "color", a0.goal_b.color)   # :43-44 (goal_a.color = goal_b.color; rendering only)
+        U.assign(a0, "color", a1.goal_b.color)
 
     def reward(self, agent, world):                # simple_reference.py:57-61
         if agent.goal_a is None or agent.goal_b is None:

@@ -52,13 +52,14 @@ class Scenario(BaseScenario):
         for agent in world.agents:
             agent.goal_a = None
             agent.goal_b = None
-            agent.color = U.const(world, [0.25, 0.25, 0.25])
+            if agent is not world.agents[1]:       # (the listener takes the goal's colour + 0.45 below, :52)
+                agent.color = U.const(world, [0.25, 0.25, 0.25])
         world.landmarks[0].color = U.const(world, [0.65, 0.15, 0.15])
         world.landmarks[1].color = U.const(world, [0.15, 0.65, 0.15])
         world.landmarks[2].color = U.const(world, [0.15, 0.15, 0.65])
         world.agents[0].goal_a = world.agents[1]                                     # the listener ...
-        world.agents[0].goal_b = EntityChoice(world, world.landmarks, self.goal_index)   # ... should reach this landmark
-        world.agents[1].color = world.agents[0].goal_b.color + 0.45                  # :52 (rendering only)
+        world.agents[0].goal_b = EntityChoice(world, world.landmarks, world.choice_i32[0])   # ... should reach this landmark
+        U.assign(world.agents[1], "color", world.agents[0].goal_b.color + 0.45)                  # :52 (rendering only)
 
     def benchmark_data(self, agent, world):
         # the reference's body (`self.reward(agent, reward)`, :61) raises NameError; this is what it means

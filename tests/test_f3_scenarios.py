@@ -468,3 +468,32 @@ def test_episode_horizon_and_device_side_auto_reset(name, fused):
         if t == 5:
             env2.reset()
     assert seen == [False, False, True, True, True, False, False]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,fused", [("simple_adversary", False), ("simple_reference", False),
+                                        ("simple_world_comm", False), ("simple_tag", True)])
+def test_graphed_step_replays_the_eager_step(name, fused):
+    """GraphedStep: env.step captured once into a HIP graph (the generic path's ~100 launches become one replay).
+    Same kernels on the same buffers, so a replay must reproduce the eager step bit-for-bit, across resets too."""
+    B = 513
+    rs = np.random.RandomState(4)
+    env_g = mpe.make_env(name, batch_size=B, seed=8, fused=fused)
+    env_e = mpe.make_env(name, batch_size=B, seed=8, fused=fused)
+    o_g, o_e = env_g.reset(), env_e.reset()
+    gs = mpe.GraphedStep(env_g, random_actions(env_g, rs, B))
+    assert np.array_equal(env_g.world.get_state()[0], env_e.world.get_state()[0])     # capture left the state alone
+    for t in range(7):
+        act = random_actions(env_e, rs, B)
+        o_g, r_g, d_g, _ = gs.step(act)
+        o_e, r_e, d_e, _ = env_e.step(act)
+        for i in range(env_e.n):
+            assert torch.equal(o_g[i], o_e[i]), (t, i)
+            assert torch.equal(r_g[i] * torch.ones(B, device="cuda"), r_e[i] * torch.ones(B, device="cuda")), (t, i)
+            assert torch.equal(d_g[i].bool(), d_e[i].bool())
+            c_g, c_e = env_g.world.agents[i].state.c, env_e.world.agents[i].state.c
+            assert torch.equal(c_g, c_e), (t, i)
+        assert np.array_equal(env_g.world.get_state()[0], env_e.world.get_state()[0]), t
+        if t == 3:
+            env_g.reset()
+            env_e.reset()
