@@ -370,7 +370,7 @@ def main():
     if rank == 0:
         achieved = bytes_step * B / (k_us * 1e-6) / 1e9
         kname = ("mpe::k_split" if os.environ.get("MPE_STEP_IMPL") != "thread" else "mpe::k_narrow") if A <= 6 \
-            else "mpe::k_wave"
+            else ("mpe::k_multi" if max(A, Lm) <= 32 and A + Lm <= 64 else "mpe::k_wave")
         tkey = "%s_A%d_L%d_B%d" % (args.scenario, A, Lm, B)
         tr = pmc_traffic(tkey) if S == 1 and args.mode in ("graph", "eager") else None
         copy_gbs = copy_ceiling_gbs()
