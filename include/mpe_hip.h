@@ -162,6 +162,12 @@ int mpe_reset(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, co
 int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed,
                        uint64_t step, int64_t world_offset, void *stream);
 
+/* 1 when mpe_step / mpe_observe have a fused kernel for this descriptor (kind, agent / landmark /
+ * adversary counts, dim_c), 0 when the caller must keep Scenario.observation / reward itself and
+ * use mpe_world_step (e.g. simple_tag with other team sizes than simple_tag.py:10-12), < 0 on an
+ * invalid descriptor.  simple_spread is fused at every size up to MPE_MAX_ENTITIES.             */
+int mpe_step_supported(const MpeScenarioDesc *desc);
+
 /* Episode bookkeeping -- NEW API, no reference counterpart: `done` is always False in the reference
  * (environment.py:132-135, make_env.py:41-43: no done_callback) and the caller counts steps itself
  * (bin/interactive.py, MADDPG's 25-step episodes).  After a step: episode_step[w] += 1 for every

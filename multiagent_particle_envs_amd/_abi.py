@@ -50,6 +50,7 @@ EXPORTS = {
     "mpe_sizeof_buffers": (C.c_size_t, []),
     "mpe_fill_obs_layout": (C.c_int, [C.POINTER(MpeScenarioDesc)]),
     "mpe_fill_entity_table": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(C.c_float)]),
+    "mpe_step_supported": (C.c_int, [C.POINTER(MpeScenarioDesc)]),
     "mpe_step": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
     "mpe_observe": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
     "mpe_world_step": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),

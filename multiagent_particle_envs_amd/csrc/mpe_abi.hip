@@ -254,6 +254,19 @@ static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, 
               d->n_landmarks, d->n_adversaries);
 }
 
+int mpe_step_supported(const MpeScenarioDesc *d) {
+  if (int rc = check_desc(d, "mpe_step_supported")) return rc;
+  if (d->kind == MPE_SCN_GENERIC) return 0;   // World.step only (mpe_world_step); callbacks stay with the caller
+  const int A = d->n_agents, L = d->n_landmarks;
+  if (A + L <= mpe::kNarrowMaxE && mpe::split_supports(d->kind, A, L, d->n_adversaries)) return 1;
+  if (d->kind >= MPE_SCN_SPEAKER_LISTENER) return 0;
+  if (use_narrow(d)) return 1;
+  if (d->kind != MPE_SCN_SPREAD) return 0;
+  mpe::WideDesc w = make_wide(d);
+  w.kind = d->kind;
+  return mpe::wide_supports(w, true) ? 1 : 0;
+}
+
 int mpe_step(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, void *stream) {
   return run("mpe_step", true, true, d, b, B, stream);
 }

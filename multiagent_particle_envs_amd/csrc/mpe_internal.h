@@ -21,6 +21,7 @@ struct WideDesc {
 };
 constexpr int kEntityTableCols = 6;  // size, mass, accel, max_speed, movable, collide  -> [6][E] floats
 struct RollArgs;
+bool wide_supports(const WideDesc &d, bool out);
 int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream,
                 const RollArgs *roll = nullptr);
 

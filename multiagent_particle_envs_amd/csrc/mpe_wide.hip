@@ -64,6 +64,7 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t
 // Private to each wave: the world.  Positions sit in OBSERVATION order
 //   Q = [ landmark 0 .. L-1 | agent 0 .. A-1 ]
 // so that the observation row of agent i is  Q[idx + (idx >= L+i)] - Q[L+i]  for idx = 0 .. L+A-2.
+constexpr size_t kMaxLds = 160 * 1024;   // LDS of one gfx950 CU
 struct Carve {
   size_t sizeq, crank, csz, aconst, shared_bytes;  // shared block offsets
   size_t q, v, u, qn, cpw, wave_bytes;             // per-wave block offsets (relative to the wave's base)
@@ -811,13 +812,19 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
 
 }  // namespace
 
+bool wide_supports(const WideDesc &d, bool out) {
+  if (out && (d.kind != MPE_SCN_SPREAD || d.dim_c != 2 || (d.D & 1))) return false;
+  const Carve cv = carve(d.A, d.L);
+  return cv.shared_bytes + kWavesPerWg * cv.wave_bytes <= kMaxLds;
+}
+
 int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream,
                 const RollArgs *roll) {
   if (out && d.kind != MPE_SCN_SPREAD) return MPE_EUNSUPPORTED;
   if (out && (d.dim_c != 2 || (d.D & 1))) return MPE_EUNSUPPORTED;
   const Carve cv = carve(d.A, d.L);
   const size_t lds = cv.shared_bytes + kWavesPerWg * cv.wave_bytes;
-  if (lds > 64 * 1024) return MPE_EUNSUPPORTED;
+  if (lds > kMaxLds) return MPE_EUNSUPPORTED;
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0, v = 0;
@@ -851,6 +858,15 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
       else if (phys) hipLaunchKernelGGL((k_multi<true, false>), mgrid, block, mlds, stream, d, b, B, (unsigned)mp, AP);
       else hipLaunchKernelGGL((k_multi<false, true>), mgrid, block, mlds, stream, d, b, B, (unsigned)mp, AP);
       return (int)hipGetLastError();
+    }
+  }
+  if (lds > 64 * 1024) {  // beyond the default dynamic-LDS window: ask for it (a workgroup may own all 160 KiB of a gfx950 CU)
+    const void *fn = roll ? (const void *)k_wave<true, true, true>
+                          : phys && out ? (const void *)k_wave<true, true, false>
+                                        : phys ? (const void *)k_wave<true, false, false> : (const void *)k_wave<false, true, false>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return MPE_EUNSUPPORTED;
     }
   }
   if (roll) {

@@ -133,10 +133,13 @@ class MultiAgentEnv(object):
             done_callback is None and len(world.scripted_agents) == 0 and \
             all((a.silent or (kind in _abi.COMM_KINDS and not a.c_noise)) and not a.u_noise for a in world.agents) and \
             not (info_callback is not None and kind in (_abi.MPE_SCN_ADVERSARY, _abi.MPE_SCN_PUSH))   # no fused benchmark_data there
+        if own:   # ... and a kernel for this shape (the f3 scenarios are fused at the reference's team sizes)
+            own = _abi.lib().mpe_step_supported(C.byref(world.scenario_desc(kind, getattr(sc, "num_adversaries", 0)))) == 1
         if fused is None:
             fused = own
         if fused and not own:
-            raise _abi.MpeError("fused=True needs the unmodified callbacks of a built-in scenario")
+            raise _abi.MpeError("fused=True needs the unmodified callbacks of a built-in scenario at a shape libmpe_hip.so has a "
+                                "kernel for (mpe_step_supported)")
         self.fused = bool(fused)
         self._comm_kind = self.fused and kind in _abi.COMM_KINDS
         self._scenario = sc

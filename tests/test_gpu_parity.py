@@ -143,6 +143,12 @@ CONFIGS = [
     ("simple_spread", lambda: ospec.simple_spread(32), {"num_agents": 32}, 131, 2),
     ("simple_spread", lambda: ospec.simple_spread(5, 9), {"num_agents": 5, "num_landmarks": 9}, 257, 2),
     ("simple_spread", lambda: ospec.simple_spread(12, 3), {"num_agents": 12, "num_landmarks": 3}, 100, 2),
+    # more than one wave of agents per world (batched contact phase, rows longer than two wave stores), up to the
+    # ABI's entity limit MPE_MAX_ENTITIES = 512
+    ("simple_spread", lambda: ospec.simple_spread(100), {"num_agents": 100}, 37, 2),
+    ("simple_spread", lambda: ospec.simple_spread(70, 3), {"num_agents": 70, "num_landmarks": 3}, 50, 2),
+    ("simple_spread", lambda: ospec.simple_spread(3, 90), {"num_agents": 3, "num_landmarks": 90}, 50, 2),
+    ("simple_spread", lambda: ospec.simple_spread(256), {"num_agents": 256}, 5, 2),
 ]
 
 
@@ -450,3 +456,56 @@ def test_large_worlds_other_entry_paths(N, B):
     for i in (0, N - 1):
         close(np_(o_g[i]), np_(o_ref[i]))
         close(np_(r_g[i]), np_(r_ref[i]))
+
+
+def test_large_all_colliding_world_against_oracle():
+    """A 90-entity simple_tag (40 predators, 30 prey, 20 obstacles): every entity collides, three different sizes,
+    speed clamps -- the wave-per-world physics with a ranked partner list that is NOT the agent block, more than
+    one wave of agents, non-uniform reach.  Whatever path the env takes for this shape must match the oracle."""
+    B = 64
+    spec = ospec.simple_tag(40, 30, 20)
+    env = mpe.make_env("simple_tag", batch_size=B, num_adversaries=40, num_good_agents=30, num_landmarks=20)
+    A = spec.n_agents
+    rs = np.random.RandomState(2)
+    pos = rs.uniform(-1, 1, (B, spec.n_entities, 2))
+    pos[::2] *= 0.4                                            # crowded worlds: many simultaneous contacts
+    vel = rs.uniform(-1.2, 1.2, (B, A, 2))
+    o64 = BatchedOracle(spec, B)
+    p32, v32 = pos.astype(np.float32), vel.astype(np.float32)
+    o64.set_state(p32, v32)
+    env.world.set_state(p32, v32)
+    act = np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=(A, B))]
+    obs64, rew64, _, _ = o64.step(act)
+    obs_n, rew_n, done_n, _ = env.step(torch.as_tensor(act).cuda())
+    gp, gv = env.world.get_state()
+    scale = max(1.0, np.abs(o64.vel).max())
+    assert np.abs(gp - o64.pos).max() < 2e-5 * scale and np.abs(gv - o64.vel).max() < 2e-4 * scale
+    ok = guard_ok(spec, o64.pos)
+    for i in (0, 39, 40, 69):
+        assert np.abs(np_(obs_n[i]) - obs64[i]).max() < 2e-4 * scale
+        assert np.abs(np_(rew_n[i])[ok] - rew64[i][ok]).max() < 1e-3
+
+
+def test_world_step_at_the_entity_limit():
+    """MPE_MAX_ENTITIES = 512 entities, all colliding, three sizes, speed clamps (a 200 + 112 + 200 simple_tag):
+    `World.step` alone (mpe_world_step -> the wave-per-world kernel with > 64 KiB of LDS per workgroup)."""
+    B = 6
+    spec = ospec.simple_tag(200, 112, 200)
+    sc = mpe.scenarios.load("simple_tag.py").Scenario()
+    w = sc.make_world(batch_size=B, num_adversaries=200, num_good_agents=112, num_landmarks=200)
+    A = spec.n_agents
+    rs = np.random.RandomState(3)
+    pos = rs.uniform(-1, 1, (B, spec.n_entities, 2)).astype(np.float32)
+    vel = rs.uniform(-1.2, 1.2, (B, A, 2)).astype(np.float32)
+    o64 = BatchedOracle(spec, B)
+    o64.set_state(pos, vel)
+    w.set_state(pos, vel)
+    act = np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=(A, B))]
+    o64.integrate(o64.forces(o64.decode(act)))            # World.step of the oracle (no outputs)
+    for i, agent in enumerate(w.agents):
+        a = torch.as_tensor(act[i]).cuda()
+        agent.action.u = torch.stack([a[:, 1] - a[:, 2], a[:, 3] - a[:, 4]], dim=1) * agent.accel
+    w.step()
+    gp, gv = w.get_state()
+    scale = max(1.0, np.abs(o64.vel).max())
+    assert np.abs(gp - o64.pos).max() < 2e-5 * scale and np.abs(gv - o64.vel).max() < 2e-4 * scale

@@ -160,6 +160,29 @@ def test_scenario_loader_and_generic_detection(tmp_path):
         mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, fused=True)
 
 
+def test_fused_kernels_cover_the_reference_shapes_and_other_shapes_fall_back():
+    """mpe_step_supported: the nine scenarios at the reference's team sizes and simple_spread at every size have a fused
+    kernel; other shapes of the f3 scenarios keep their torch callbacks around mpe_world_step (the env says so up
+    front instead of failing at the first step)."""
+    def env_of(name, **kw):
+        sc = mpe.scenarios.load(name + ".py").Scenario()
+        w = sc.make_world(batch_size=2, device="cpu", **kw)
+        return mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation)
+    for name in ("simple", "simple_spread", "simple_tag", "simple_adversary", "simple_push", "simple_speaker_listener",
+                 "simple_reference", "simple_crypto", "simple_world_comm"):
+        assert env_of(name).fused, name
+    for n in (2, 6, 7, 16, 33, 64, 100, 256):
+        assert env_of("simple_spread", num_agents=n).fused, n
+    big = env_of("simple_tag", num_adversaries=40, num_good_agents=30, num_landmarks=20)
+    assert not big.fused and big.observation_space[0].shape == (4 + 40 + 138 + 60,)
+    assert not env_of("simple_tag", num_adversaries=2).fused
+    d = big.world.scenario_desc(_abi.MPE_SCN_GENERIC)
+    assert _abi.lib().mpe_step_supported(C.byref(d)) == 0
+    d = _abi.MpeScenarioDesc()
+    d.kind, d.n_agents = 99, 1
+    assert _abi.lib().mpe_step_supported(C.byref(d)) < 0
+
+
 def test_header_is_plain_c_and_a_c_program_can_call_the_library(tmp_path):
     """include/mpe_hip.h compiles as C (gcc -std=c99 -pedantic) and a C program links and calls libmpe_hip.so."""
     import subprocess
