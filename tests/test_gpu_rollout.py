@@ -67,7 +67,9 @@ def test_split_and_thread_kernels_bit_identical(name, kw, B, impl_env):
                                             ("simple_adversary", {}, 900, 30, 5), ("simple_push", {}, 500, 20, 4),
                                             ("simple_spread", {"num_agents": 8}, 130, 11, 4),            # wave-per-world kernel
                                             ("simple_spread", {"num_agents": 20, "num_landmarks": 12}, 70, 7, 3),
-                                            ("simple_spread", {"num_agents": 64}, 37, 6, 5)])
+                                            ("simple_spread", {"num_agents": 64}, 37, 6, 5),
+                                            ("simple_spread", {"num_agents": 100}, 9, 5, 2),             # > one wave of agents
+                                            ("simple_spread", {"num_agents": 3, "num_landmarks": 90}, 21, 5, 3)])
 def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):
     seed, offset, step0 = 0xABCDEF0123, 4096, 50 if ep in (25, 0) else 14
     # --- stepwise: explicit reset / random_actions / step through the C ABI ----------------------
