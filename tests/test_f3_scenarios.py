@@ -497,3 +497,63 @@ def test_graphed_step_replays_the_eager_step(name, fused):
         if t == 3:
             env_g.reset()
             env_e.reset()
+
+
+CUSTOM = [("simple_spread", {}), ("simple_spread", {"num_agents": 8}), ("simple_spread", {"num_agents": 40, "num_landmarks": 7}),
+          ("simple_tag", {}), ("simple_adversary", {}), ("simple_push", {}), ("simple_world_comm", {}), ("simple", {})]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", CUSTOM, ids=["%s%s" % (n, "-".join(map(str, k.values()))) for n, k in CUSTOM])
+@pytest.mark.parametrize("trial", [0, 1])
+def test_customised_entity_constants_fused_equals_generic(name, kw, trial):
+    """The kernels read sizes, masses, collide flags, speed limits and action gains from the descriptor at run time
+    (the reference keeps them as plain attributes anyone may change after make_world, core.py:27-51).  Randomise
+    them on a built-in scenario and hold the fused kernel to the generic path (torch callbacks written from the
+    reference + mpe_world_step) on crowded random worlds."""
+    B = 2048
+    rs = np.random.RandomState(100 * trial + len(name))
+
+    def build(fused):
+        sc = mpe.scenarios.load(name + ".py").Scenario()
+        w = sc.make_world(batch_size=B, **kw)
+        r = np.random.RandomState(7 + trial)                    # the same customisation for both envs
+        for e in w.entities:
+            e.size = float(r.uniform(0.03, 0.2))
+            e.initial_mass = float(r.uniform(0.5, 2.0))
+            if r.rand() < 0.3:
+                e.collide = not e.collide
+        for a in w.agents:
+            a.max_speed = None if r.rand() < 0.4 else float(r.uniform(0.4, 1.5))
+            a.accel = None if r.rand() < 0.4 else float(r.uniform(2.0, 6.0))
+        w.seed = 5
+        w.rng_mode = "device"
+        sc.reset_world(w)
+        env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, fused=fused)
+        env.scenario = sc
+        return env
+    ef, eg = build(True), build(False)
+    A, E = len(ef.world.agents), len(ef.world.entities)
+    pos = rs.uniform(-1, 1, (B, E, 2)).astype(np.float32)
+    pos[::2] *= 0.35
+    vel = rs.uniform(-0.8, 0.8, (B, A, 2)).astype(np.float32)
+    pops = ef.world.choice_pops
+    choice = np.stack([rs.randint(0, n, size=B) for n in pops], axis=1) if pops else np.zeros((B, 0), np.int64)
+    for env in (ef, eg):
+        env.world.set_state(pos, vel)
+        set_choices(env, choice)
+    act = random_actions(ef, rs, B)
+    of, rf, _, _ = ef.step(act)
+    og, rg, _, _ = eg.step(act)
+    pf, vf = ef.world.get_state()
+    pg, vg = eg.world.get_state()
+    close(pf, pg, what="pos")
+    close(vf, vg, what="vel")
+    near = np.zeros(B, bool)                                     # worlds with a pair within 1e-5 of touching: the strict
+    for a_ in range(E):                                          # `<` of the collision counts may flip between fp32 paths
+        for b_ in range(a_ + 1, E):
+            dist = np.linalg.norm(pf[:, a_] - pf[:, b_], axis=1)
+            near |= np.abs(dist - (ef.world.entities[a_].size + ef.world.entities[b_].size)) < 1e-5
+    for i in range(A):
+        close(np_(of[i]), np_(og[i]), what="obs%d" % i)
+        close((np_(rf[i]) * np.ones(B))[~near], (np_(rg[i]) * np.ones(B))[~near], what="rew%d" % i)
