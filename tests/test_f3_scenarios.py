@@ -526,6 +526,9 @@ def test_customised_entity_constants_fused_equals_generic(name, kw, trial):
         for a in w.agents:
             a.max_speed = None if r.rand() < 0.4 else float(r.uniform(0.4, 1.5))
             a.accel = None if r.rand() < 0.4 else float(r.uniform(2.0, 6.0))
+        if trial == 1:                                           # World constants too (core.py:94-99)
+            w.dt, w.damping = 0.05, 0.4
+            w.contact_force, w.contact_margin = 250.0, 4e-3
         w.seed = 5
         w.rng_mode = "device"
         sc.reset_world(w)
