@@ -59,7 +59,7 @@ def c_spec(spec):
     s.collaborative = 1 if spec.collaborative else 0
     s.dt, s.damping, s.contact_force, s.contact_margin = spec.dt, spec.damping, spec.contact_force, spec.contact_margin
     for e in range(spec.n_entities):
-        s.size[e], s.mass[e] = spec.size[e], 1.0
+        s.size[e], s.mass[e] = spec.size[e], spec.mass_of(e)
         s.movable[e], s.collide[e] = int(spec.movable[e]), int(spec.collide[e])
     for i in range(spec.n_agents):
         s.accel[i] = 5.0 if spec.accel[i] is None else spec.accel[i]

@@ -97,7 +97,7 @@ class BatchedOracle(object):
                 continue
             v = self.vel[:, i] * one_minus
             if f[i] is not None:
-                v = v + (f[i] / self.dt_.type(1.0)) * dt
+                v = v + (f[i] / self.dt_.type(s.mass_of(i))) * dt            # core.py:162
             if s.max_speed[i] is not None:
                 ms = self.dt_.type(s.max_speed[i])
                 speed = np.sqrt(np.square(v[:, 0]) + np.square(v[:, 1]))
@@ -149,6 +149,9 @@ class BatchedOracle(object):
             dmin = self.size[ag][:, None] + self.size[ag][None, :]
             hit = daa < dmin[None]                            # includes a == i (Q1)
             counts = hit.sum(axis=1).astype(np.int32)         # [B, A]
+            for i in range(A):                                # `if agent.collide:` simple_spread.py:78 (reward), :58 (benchmark_data)
+                if not s.collide[i]:
+                    counts[:, i] = 0
             lm_term = np.zeros(B, self.dt_)
             for l in range(len(lms)):                         # rew -= min(dists), landmark order
                 lm_term = lm_term - mins[:, l]
@@ -180,12 +183,13 @@ class BatchedOracle(object):
                     adv_rew = adv_rew + np.where(hit[:, g, a], 10, 0).astype(self.dt_)
             coll = np.zeros((A, B), np.int32)
             for vi, j in enumerate(advs):
-                rew[j] = adv_rew
-                coll[j] = hit[:, :, vi].sum(axis=1)
+                rew[j] = adv_rew if s.collide[j] else 0.0     # `if agent.collide:` simple_tag.py:124
+                coll[j] = hit[:, :, vi].sum(axis=1)           # benchmark_data :57-66 has no such gate
             for gi, j in enumerate(good):
                 r = np.zeros(B, self.dt_)
                 for a in range(len(advs)):
-                    r = r - np.where(hit[:, gi, a], 10, 0).astype(self.dt_)
+                    if s.collide[j]:                          # simple_tag.py:97
+                        r = r - np.where(hit[:, gi, a], 10, 0).astype(self.dt_)
                 for p in range(2):
                     x = np.abs(self.pos[:, j, p])
                     with np.errstate(over="ignore"):

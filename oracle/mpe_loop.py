@@ -81,7 +81,7 @@ class LoopEnv(object):
                 continue
             v = self.vel[e] * (1 - s.damping)
             if force[e] is not None:
-                v += (force[e] / 1.0) * s.dt
+                v += (force[e] / s.mass_of(e)) * s.dt
             ms = s.max_speed[e] if e < s.n_agents else None
             if ms is not None:
                 speed = np.sqrt(np.square(v[0]) + np.square(v[1]))
@@ -144,14 +144,16 @@ class LoopEnv(object):
             good = [j for j in range(A) if not s.adversary[j]]
             rew = 0
             if s.adversary[i]:
-                for g in good:
-                    for a in advs:
-                        if self._touch(g, a):
-                            rew += 10
+                if s.collide[i]:                       # simple_tag.py:124
+                    for g in good:
+                        for a in advs:
+                            if self._touch(g, a):
+                                rew += 10
                 return rew
-            for a in advs:
-                if self._touch(a, i):
-                    rew -= 10
+            if s.collide[i]:                           # simple_tag.py:97
+                for a in advs:
+                    if self._touch(a, i):
+                        rew -= 10
             for p in range(2):
                 x = abs(self.pos[i][p])
                 if x < 0.9:

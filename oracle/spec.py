@@ -25,12 +25,16 @@ class Spec:
     accel: List[Optional[float]]         # per agent; None -> sensitivity 5.0 (environment.py:178-181)
     max_speed: List[Optional[float]]     # per agent; None -> no clamp (core.py:164)
     adversary: List[bool] = field(default_factory=list)
+    mass: Optional[List[float]] = None   # per entity: Entity.mass = initial_mass (core.py:47-51); None -> 1.0 everywhere
     collaborative: bool = False          # shared reward = sum over agents (environment.py:100-102)
     landmark_range: float = 1.0          # reset: uniform(-r, +r) for landmarks
     dt: float = 0.1
     damping: float = 0.25
     contact_force: float = 1e2
     contact_margin: float = 1e-3
+
+    def mass_of(self, e):
+        return 1.0 if self.mass is None else self.mass[e]
 
     @property
     def n_entities(self):

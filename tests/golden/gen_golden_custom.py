@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Golden vectors for CUSTOMISED entity / world constants, recorded from the unmodified reference
+(runs only in the build container, like gen_golden.py).
+
+    python tests/golden/gen_golden_custom.py     # writes tests/golden/custom_simple_tag.npz, custom_simple_spread.npz
+
+The reference keeps sizes, masses, collide flags, speed limits, action gains and the integration constants as plain
+attributes (core.py:27-51, 94-99) that a user may change after make_world; the step must honour them.  The
+constants used are stored in the .npz next to the trajectories."""
+import os
+import numpy as np
+
+import gen_golden as G   # sets up the import path / gym stub, provides record()
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def customise(env, seed, world_consts):
+    r = np.random.RandomState(seed)
+    w = env.world
+    consts = {"size": [], "mass": [], "collide": [], "max_speed": [], "accel": []}
+    for e in w.entities:
+        e.size = float(r.uniform(0.03, 0.2))
+        e.initial_mass = float(r.uniform(0.5, 2.0))
+        if r.rand() < 0.3:
+            e.collide = not e.collide
+        consts["size"].append(e.size)
+        consts["mass"].append(e.mass)
+        consts["collide"].append(bool(e.collide))
+    for a in w.agents:
+        a.max_speed = None if r.rand() < 0.4 else float(r.uniform(0.4, 1.5))
+        a.accel = None if r.rand() < 0.4 else float(r.uniform(2.0, 6.0))
+        consts["max_speed"].append(-1.0 if a.max_speed is None else a.max_speed)    # -1 encodes None
+        consts["accel"].append(-1.0 if a.accel is None else a.accel)
+    w.dt, w.damping, w.contact_force, w.contact_margin = world_consts
+    out = {"c_" + k: np.array(v) for k, v in consts.items()}
+    out["c_world"] = np.array(world_consts, dtype=np.float64)
+    return out
+
+
+def main():
+    for name, seed, wc in (("simple_tag", 11, (0.05, 0.4, 250.0, 4e-3)), ("simple_spread", 12, (0.1, 0.25, 1e2, 1e-3))):
+        env = G.make_env(name, benchmark=True)
+        consts = customise(env, seed, wc)
+        data = G.record(name, env, list(range(300, 324)), 12, squeeze_every=2, squeeze=0.3)
+        data.update(consts)
+        path = os.path.join(HERE, "custom_%s.npz" % name)
+        np.savez_compressed(path, **data)
+        print("%-28s %8.1f KiB" % (os.path.basename(path), os.path.getsize(path) / 1024.0))
+
+
+if __name__ == "__main__":
+    main()

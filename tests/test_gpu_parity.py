@@ -509,3 +509,41 @@ def test_world_step_at_the_entity_limit():
     gp, gv = w.get_state()
     scale = max(1.0, np.abs(o64.vel).max())
     assert np.abs(gp - o64.pos).max() < 2e-5 * scale and np.abs(gv - o64.vel).max() < 2e-4 * scale
+
+
+@pytest.mark.parametrize("name", ["simple_tag", "simple_spread"])
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "generic"])
+def test_customised_constants_against_reference_golden(name, fused, golden):
+    """tests/golden/custom_*.npz: the reference stepped after its entity / world attributes were changed (sizes, masses,
+    collide flags, speed limits, action gains, dt, damping, contact force and margin: core.py:27-51, 94-99).  The same
+    attribute assignments on this package's world, teacher-forced from the reference's fp64 states -- through the fused
+    kernel (run-time descriptor constants, `if agent.collide` reward gates) and through the generic path."""
+    from test_oracle_golden import custom_spec
+    g = golden("custom_" + name)
+    spec = custom_spec(name, g)
+    T, W, A = g["rew"].shape
+    sc = mpe.scenarios.load(name + ".py").Scenario()
+    w = sc.make_world(batch_size=W)
+    for k, e in enumerate(w.entities):
+        e.size, e.initial_mass, e.collide = float(g["c_size"][k]), float(g["c_mass"][k]), bool(g["c_collide"][k])
+    for k, a in enumerate(w.agents):
+        a.max_speed = None if g["c_max_speed"][k] < 0 else float(g["c_max_speed"][k])
+        a.accel = None if g["c_accel"][k] < 0 else float(g["c_accel"][k])
+    w.dt, w.damping, w.contact_force, w.contact_margin = [float(x) for x in g["c_world"]]
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, sc.benchmark_data, fused=fused)
+    for t in range(T):
+        prev_pos = g["pos0"] if t == 0 else g["pos"][t - 1]
+        prev_vel = g["vel0"] if t == 0 else g["vel"][t - 1]
+        w.set_state(prev_pos, prev_vel)
+        act = torch.as_tensor(np.transpose(g["act"][t], (1, 0, 2)), dtype=torch.float32).cuda().contiguous()
+        obs_n, rew_n, _, info = env.step(act if fused else [act[i] for i in range(A)])
+        pos, vel = w.get_state()
+        close(pos, g["pos"][t], what="pos t=%d" % t)
+        close(vel, g["vel"][t], what="vel t=%d" % t)
+        ok = guard_ok(spec, g["pos"][t])
+        for i in range(A):
+            close(np_(obs_n[i]), g["obs%d" % i][t], what="obs%d t=%d" % (i, t))
+            close((np_(rew_n[i]) * np.ones(W))[ok], g["rew"][t][:, i][ok], what="rew%d t=%d" % (i, t))
+        cols = [x[1] if isinstance(x, tuple) else x for x in info["n"]]       # a plain 0 where `agent.collide` is off
+        got = np.stack([np.asarray(np_(c) if torch.is_tensor(c) else c) * np.ones(W, np.int64) for c in cols], axis=1)
+        assert np.array_equal(got[ok], g["info_collisions"][t][ok])

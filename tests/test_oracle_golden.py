@@ -156,3 +156,53 @@ def test_c_restatement_matches_reference(name, spec, bench, golden):
         _close(rew, g["rew"][t])
         if "info_collisions" in g:
             assert np.array_equal(col, g["info_collisions"][t])
+
+
+def custom_spec(name, g):
+    """The customised constants a custom_*.npz golden was recorded with (tests/golden/gen_golden_custom.py)."""
+    import dataclasses
+    base = ospec.by_name(name)
+    dt, damping, cforce, cmargin = [float(x) for x in g["c_world"]]
+    opt = lambda v: None if v < 0 else float(v)
+    return dataclasses.replace(base, size=[float(x) for x in g["c_size"]], mass=[float(x) for x in g["c_mass"]],
+                               collide=[bool(x) for x in g["c_collide"]], max_speed=[opt(x) for x in g["c_max_speed"]],
+                               accel=[opt(x) for x in g["c_accel"]], dt=dt, damping=damping, contact_force=cforce,
+                               contact_margin=cmargin)
+
+
+@pytest.mark.parametrize("name", ["simple_tag", "simple_spread"])
+def test_oracles_honour_customised_constants(name, golden):
+    """Sizes, masses, collide flags, speed limits, action gains, dt / damping / contact constants changed after
+    make_world (plain attributes in the reference, core.py:27-51, 94-99): both restatements against the reference."""
+    g = golden("custom_" + name)
+    spec = custom_spec(name, g)
+    T, W, A = g["rew"].shape
+    orc = BatchedOracle(spec, W, np.float64, benchmark=True)
+    orc.set_state(g["pos0"], g["vel0"])
+    for t in range(T):
+        obs, rew, done, info = orc.step(np.transpose(g["act"][t], (1, 0, 2)))
+        _close(orc.pos, g["pos"][t])
+        _close(orc.vel, g["vel"][t])
+        for i in range(A):
+            _close(obs[i], g["obs%d" % i][t])
+        _close(rew.T, g["rew"][t])
+        assert np.array_equal(info["collisions"].T, g["info_collisions"][t])
+    from oracle import build_c                       # ... and the plain-C restatement
+    for t in range(T):
+        p0 = g["pos0"] if t == 0 else g["pos"][t - 1]
+        v0 = g["vel0"] if t == 0 else g["vel"][t - 1]
+        pos, vel, obs, rew, col = build_c.step_batch(spec, p0, v0, g["act"][t], threads=2)
+        _close(pos, g["pos"][t])
+        _close(vel, g["vel"][t])
+        for i in range(A):
+            _close(obs[i], g["obs%d" % i][t])
+        _close(rew, g["rew"][t])
+        assert np.array_equal(col, g["info_collisions"][t])
+    env = LoopEnv(spec, benchmark=True)
+    for w in range(4):
+        env.set_state(g["pos0"][w], g["vel0"][w])
+        for t in range(T):
+            obs, rew, done, info = env.step([g["act"][t, w, i] for i in range(A)])
+            for i in range(A):
+                _close(obs[i], g["obs%d" % i][t, w])
+            _close(np.array(rew, dtype=np.float64), g["rew"][t, w])
