@@ -104,7 +104,7 @@ class MultiAgentEnv(object):
         self.discrete_action_space = True
         self.discrete_action_input = False
         self.force_discrete_action = world.discrete_action if hasattr(world, 'discrete_action') else False
-        self.shared_reward = world.collaborative if hasattr(world, 'collaborative') else False
+        self._shared_reward = bool(world.collaborative) if hasattr(world, 'collaborative') else False
         self.time = 0
         # episode bookkeeping -- new API: the reference never ends an episode (environment.py:132-135,
         # done_callback is None in make_env.py:41-43) and leaves counting to the caller.  Off by default (parity).
@@ -190,6 +190,21 @@ class MultiAgentEnv(object):
         self._comm = None
         self._entity_table = None
         self.shared_viewer = shared_viewer
+
+    @property
+    def shared_reward(self):
+        """environment.py:36: every agent receives the sum of all rewards.  Read at every step by the reference, so it
+        may be flipped on a live env: the fused kernels implement the scenario's own setting (world.collaborative), any
+        other value sends the env to the generic path."""
+        return self._shared_reward
+
+    @shared_reward.setter
+    def shared_reward(self, value):
+        value = bool(value)
+        if value != self._shared_reward and getattr(self, "fused", False):
+            self.fused = False
+            self._comm_kind = False
+        self._shared_reward = value
 
     # ------------------------------------------------------------------------------------------
     def _ensure_buffers(self):

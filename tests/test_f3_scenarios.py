@@ -560,3 +560,31 @@ def test_customised_entity_constants_fused_equals_generic(name, kw, trial):
     for i in range(A):
         close(np_(of[i]), np_(og[i]), what="obs%d" % i)
         close((np_(rf[i]) * np.ones(B))[~near], (np_(rg[i]) * np.ones(B))[~near], what="rew%d" % i)
+
+
+@pytest.mark.gpu
+def test_shared_reward_can_be_flipped_on_a_live_env():
+    """environment.py:100-102 reads self.shared_reward at every step: flipping it changes what step() returns.  The
+    fused kernels implement the scenario's own setting; the other one is served by the generic path."""
+    B = 500
+    rs = np.random.RandomState(0)
+    tag, twin = mpe.make_env("simple_tag", batch_size=B, seed=1), mpe.make_env("simple_tag", batch_size=B, seed=1)
+    tag.reset(), twin.reset()
+    pos, vel = twin.world.get_state()
+    pos[::2] *= 0.2
+    tag.world.set_state(pos, vel), twin.world.set_state(pos, vel)
+    tag.shared_reward = True
+    assert not tag.fused and twin.fused
+    act = random_actions(twin, rs, B)
+    _, r_sum, _, _ = tag.step(act)
+    _, r_own, _, _ = twin.step(act)
+    total = sum(np_(r).astype(np.float64) for r in r_own)
+    assert np.abs(total).max() > 0
+    for r in r_sum:
+        close(np_(r), total)
+    spread = mpe.make_env("simple_spread", batch_size=B, seed=1)
+    twin = mpe.make_env("simple_spread", batch_size=B, seed=1)
+    spread.shared_reward = False
+    _, r_ind, _, _ = spread.step(random_actions(twin, np.random.RandomState(3), B))
+    _, r_sh, _, _ = twin.step(random_actions(twin, np.random.RandomState(3), B))
+    close(sum(np_(r).astype(np.float64) for r in r_ind), np_(r_sh[0]))
