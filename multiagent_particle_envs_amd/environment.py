@@ -191,6 +191,22 @@ class MultiAgentEnv(object):
         self._entity_table = None
         self.shared_viewer = shared_viewer
 
+    def refresh_constants(self):
+        """Re-read the entity / world constants (size, mass, collide, movable, max_speed, accel, dt, damping, contact
+        force / margin) from the Python objects.  The reference reads them at every step; here they are snapshotted
+        into the kernels' descriptor when the env is built, so call this after changing any of them on a live env
+        (and rebuild RandomRollout / GraphedStep objects made from it)."""
+        w = self.world
+        w._desc = None
+        w._entity_table = None
+        if self.fused:
+            self._desc = w.scenario_desc(self._kind, getattr(self._scenario, "num_adversaries", 0))
+            if self._sets is not None:
+                self._entity_table = w.entity_table(self._desc)
+                self._desc_ref = C.byref(self._desc)
+                for out in self._sets:
+                    out.bufs.entity_table = self._entity_table.data_ptr()
+
     @property
     def shared_reward(self):
         """environment.py:36: every agent receives the sum of all rewards.  Read at every step by the reference, so it

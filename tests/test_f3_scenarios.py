@@ -588,3 +588,28 @@ def test_shared_reward_can_be_flipped_on_a_live_env():
     _, r_ind, _, _ = spread.step(random_actions(twin, np.random.RandomState(3), B))
     _, r_sh, _, _ = twin.step(random_actions(twin, np.random.RandomState(3), B))
     close(sum(np_(r).astype(np.float64) for r in r_ind), np_(r_sh[0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [{}, {"num_agents": 20}], ids=["n3", "n20"])
+def test_refresh_constants_on_a_live_env(kw):
+    """Constants are snapshotted into the kernel descriptor when the env is built; refresh_constants() re-reads them."""
+    B = 300
+    rs = np.random.RandomState(0)
+    env = mpe.make_env("simple_spread", batch_size=B, seed=2, **kw)
+    gen = mpe.make_env("simple_spread", batch_size=B, seed=2, fused=False, **kw)
+    act = random_actions(env, rs, B)
+    env.step(act), gen.step(act)                      # buffers exist, descriptor in use
+    for e in (env, gen):
+        for k, a in enumerate(e.world.agents):
+            a.size = 0.05 + 0.01 * (k % 5)
+            a.max_speed = 0.7
+        e.world.damping = 0.5
+        e.refresh_constants()
+        e.world.set_state(*env.world.get_state())
+    o1, r1, _, _ = env.step(act)
+    o2, r2, _, _ = gen.step(act)
+    assert np.abs(env.world.get_state()[1]).max() <= 0.7 * (1 + 1e-5)
+    close(env.world.get_state()[0], gen.world.get_state()[0])
+    close(np_(o1[0]), np_(o2[0]))
+    close(np_(r1[0]), np_(r2[0]) * np.ones(B))
