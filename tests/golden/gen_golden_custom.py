@@ -2,7 +2,8 @@
 """Golden vectors for CUSTOMISED entity / world constants, recorded from the unmodified reference
 (runs only in the build container, like gen_golden.py).
 
-    python tests/golden/gen_golden_custom.py     # writes tests/golden/custom_simple_tag.npz, custom_simple_spread.npz
+    python tests/golden/gen_golden_custom.py        # writes tests/golden/custom_simple_tag.npz, custom_simple_spread.npz
+    python tests/golden/gen_golden_custom.py --f3   # writes tests/golden/f3c_<scenario>.npz for the six other scenarios
 
 The reference keeps sizes, masses, collide flags, speed limits, action gains and the integration constants as plain
 attributes (core.py:27-51, 94-99) that a user may change after make_world; the step must honour them.  The
@@ -49,5 +50,19 @@ def main():
         print("%-28s %8.1f KiB" % (os.path.basename(path), os.path.getsize(path) / 1024.0))
 
 
+def main_f3():
+    """The six other scenarios with customised constants: tests/golden/f3c_<scenario>.npz."""
+    import gen_golden_scenarios as S
+    for k, name in enumerate(("simple_adversary", "simple_push", "simple_speaker_listener", "simple_reference",
+                              "simple_crypto", "simple_world_comm")):
+        wc = (0.05, 0.4, 250.0, 4e-3) if k % 2 else (0.1, 0.25, 1e2, 1e-3)
+        data = S.record(name, list(range(500, 516)), 8, squeeze_every=2, squeeze=0.3,
+                        customise=lambda env, k=k, wc=wc: customise(env, 20 + k, wc))
+        path = os.path.join(HERE, "f3c_%s.npz" % name)
+        np.savez_compressed(path, **data)
+        print("%-28s %8.1f KiB" % (os.path.basename(path), os.path.getsize(path) / 1024.0))
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    main_f3() if "--f3" in sys.argv else main()

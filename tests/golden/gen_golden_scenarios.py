@@ -64,9 +64,10 @@ def draw_action(agent, world, rng, soft):
     return np.concatenate(parts)
 
 
-def record(name, seeds, T, squeeze_every=0, squeeze=0.3):
+def record(name, seeds, T, squeeze_every=0, squeeze=0.3, customise=None):
     env = make_env(name)
     world = env.world
+    consts = customise(env) if customise else {}     # gen_golden_custom.py: entity / world constants changed after make_world
     A, W, E = env.n, len(seeds), len(world.entities)
     rng = np.random.RandomState(4321)
     dims = [env.observation_space[i].shape[0] for i in range(A)]
@@ -108,6 +109,7 @@ def record(name, seeds, T, squeeze_every=0, squeeze=0.3):
             out["rew"][t, w] = np.array(rew, dtype=np.float64)
             out["pos"][t, w] = np.array([e.state.p_pos for e in world.entities])
             out["vel"][t, w] = np.array([a.state.p_vel for a in world.agents])
+    out.update(consts)
     return out
 
 

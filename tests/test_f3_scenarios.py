@@ -613,3 +613,48 @@ def test_refresh_constants_on_a_live_env(kw):
     close(env.world.get_state()[0], gen.world.get_state()[0])
     close(np_(o1[0]), np_(o2[0]))
     close(np_(r1[0]), np_(r2[0]) * np.ones(B))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,fused", [(n, False) for n in NAMES] + [(n, True) for n in FUSED],
+                         ids=[n + "-generic" for n in NAMES] + [n + "-fused" for n in FUSED])
+def test_customised_constants_against_reference_golden(name, fused, golden):
+    """tests/golden/f3c_*.npz: the reference stepped after its sizes, masses, collide flags, speed limits, action gains
+    and dt / damping / contact constants were changed (gen_golden_custom.py --f3).  Same assignments here, both paths."""
+    g = golden("f3c_" + name)
+    W, T = len(g["seeds"]), g["rew"].shape[0]
+    sc = mpe.scenarios.load(name + ".py").Scenario()
+    w = sc.make_world(batch_size=W)
+    for k, e in enumerate(w.entities):
+        e.size, e.initial_mass, e.collide = float(g["c_size"][k]), float(g["c_mass"][k]), bool(g["c_collide"][k])
+    for k, a in enumerate(w.agents):
+        a.max_speed = None if g["c_max_speed"][k] < 0 else float(g["c_max_speed"][k])
+        a.accel = None if g["c_accel"][k] < 0 else float(g["c_accel"][k])
+    w.dt, w.damping, w.contact_force, w.contact_margin = [float(x) for x in g["c_world"]]
+    w.rng_mode = "device"
+    sc.reset_world(w)
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, fused=fused)
+    env.scenario = sc
+    assert env.fused == fused
+    A = env.n
+    set_choices(env, g["choice"])
+    # worlds where a pair sits within 1e-6 of touching: collision-count rewards may flip between fp32 and fp64
+    sizes = np.array([e.size for e in w.entities])
+    for t in range(T):
+        if t == 0:
+            w.set_state(g["pos0"], g["vel0"])
+            set_comm(env, g, -1)
+        else:
+            w.set_state(g["pos"][t - 1], g["vel"][t - 1])
+            set_comm(env, g, t - 1)
+        act = [torch.as_tensor(g["act%d" % i][t], dtype=torch.float32).cuda() for i in range(A)]
+        obs_n, rew_n, _, _ = env.step(act)
+        pos, vel = w.get_state()
+        close(pos, g["pos"][t], what="t=%d pos" % t)
+        close(vel, g["vel"][t], what="t=%d vel" % t)
+        d = np.linalg.norm(g["pos"][t][:, :, None, :] - g["pos"][t][:, None, :, :], axis=-1)
+        ok = ~(np.abs(d - (sizes[:, None] + sizes[None, :])[None]) < 1e-6).any(axis=(1, 2))
+        for i in range(A):
+            close(np_(obs_n[i]), g["obs%d" % i][t], what="t=%d obs%d" % (t, i))
+            close((np_(rew_n[i]) * np.ones(W))[ok], g["rew"][t][:, i][ok], what="t=%d rew%d" % (t, i))
+            close(np_(w.agents[i].state.c), g["c%d" % i][t], what="t=%d c%d" % (t, i))
