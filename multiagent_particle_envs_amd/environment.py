@@ -303,8 +303,8 @@ class MultiAgentEnv(object):
         """environment.py:80-104 for B worlds."""
         if len(self.agents) != len(self.world.agents):   # environment.py:85 re-reads world.policy_agents every step
             self.agents = self.world.policy_agents
-        if not self.fused or (self._comm_kind and self.discrete_action_input):
-            return self._step_generic(action_n)
+        if not self.fused or (self._comm_kind and self.discrete_action_input) or not self.discrete_action_space:
+            return self._step_generic(action_n)      # (the kernels decode 5-wide move rows / integer ids only)
         self._ensure_buffers()
         act, ids = self._stage_actions(action_n)
         out = self._next_set()

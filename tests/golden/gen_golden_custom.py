@@ -4,6 +4,7 @@
 
     python tests/golden/gen_golden_custom.py        # writes tests/golden/custom_simple_tag.npz, custom_simple_spread.npz
     python tests/golden/gen_golden_custom.py --f3   # writes tests/golden/f3c_<scenario>.npz for the six other scenarios
+    python tests/golden/gen_golden_custom.py --modes   # mode_force_discrete.npz, mode_continuous.npz (_set_action modes)
 
 The reference keeps sizes, masses, collide flags, speed limits, action gains and the integration constants as plain
 attributes (core.py:27-51, 94-99) that a user may change after make_world; the step must honour them.  The
@@ -63,6 +64,40 @@ def main_f3():
         print("%-28s %8.1f KiB" % (os.path.basename(path), os.path.getsize(path) / 1024.0))
 
 
+def main_modes():
+    """_set_action modes not covered elsewhere: force_discrete_action (environment.py:169-172, argmax -> one-hot, the
+    caller's rows are soft) and a continuous action space (environment.py:176-177: u = action itself, 2 numbers)."""
+    env = G.make_env("simple_spread", benchmark=True)
+    env.force_discrete_action = True
+    data = G.record("simple_spread", env, list(range(700, 716)), 8, squeeze_every=2, squeeze=0.3, soft_every=1)
+    np.savez_compressed(os.path.join(HERE, "mode_force_discrete.npz"), **data)
+    env = G.make_env("simple_tag")
+    env.discrete_action_space = False
+    W, T, A = 16, 8, env.n
+    rng = np.random.RandomState(77)
+    out = {"pos0": np.zeros((W, 6, 2)), "vel0": np.zeros((W, A, 2)), "act2": np.zeros((T, W, A, 2)),
+           "pos": np.zeros((T, W, 6, 2)), "vel": np.zeros((T, W, A, 2)), "rew": np.zeros((T, W, A))}
+    for i in range(A):
+        out["obs%d" % i] = np.zeros((T, W, env.observation_space[i].shape[0]))
+    for w in range(W):
+        np.random.seed(800 + w)
+        env.reset()
+        if w % 2:
+            for ent in env.world.entities:
+                ent.state.p_pos = ent.state.p_pos * 0.3
+        out["pos0"][w], out["vel0"][w] = G.state_of(env)
+        for t in range(T):
+            act = rng.uniform(-1, 1, (A, 2))
+            out["act2"][t, w] = act
+            obs, rew, done, info = env.step([a.copy() for a in act])
+            out["pos"][t, w], out["vel"][t, w] = G.state_of(env)
+            out["rew"][t, w] = rew
+            for i in range(A):
+                out["obs%d" % i][t, w] = obs[i]
+    np.savez_compressed(os.path.join(HERE, "mode_continuous.npz"), **out)
+    print("mode_force_discrete.npz, mode_continuous.npz written")
+
+
 if __name__ == "__main__":
     import sys
-    main_f3() if "--f3" in sys.argv else main()
+    main_modes() if "--modes" in sys.argv else main_f3() if "--f3" in sys.argv else main()

@@ -547,3 +547,37 @@ def test_customised_constants_against_reference_golden(name, fused, golden):
         cols = [x[1] if isinstance(x, tuple) else x for x in info["n"]]       # a plain 0 where `agent.collide` is off
         got = np.stack([np.asarray(np_(c) if torch.is_tensor(c) else c) * np.ones(W, np.int64) for c in cols], axis=1)
         assert np.array_equal(got[ok], g["info_collisions"][t][ok])
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "generic"])
+def test_force_discrete_and_continuous_action_modes_against_reference_golden(fused, golden):
+    """environment.py:169-172 (force_discrete_action: the soft row becomes the one-hot of its argmax) and :176-177
+    (discrete_action_space = False: the action IS the force direction, two numbers) -- recorded from the reference
+    (tests/golden/gen_golden_custom.py --modes), teacher-forced here."""
+    g = golden("mode_force_discrete")
+    T, W, A = g["rew"].shape
+    env = mpe.make_env("simple_spread", batch_size=W, fused=fused)
+    env.force_discrete_action = True
+    for t in range(T):
+        env.world.set_state(g["pos0"] if t == 0 else g["pos"][t - 1], g["vel0"] if t == 0 else g["vel"][t - 1])
+        act = torch.as_tensor(np.transpose(g["act"][t], (1, 0, 2)), dtype=torch.float32).cuda().contiguous()
+        keep = act.clone()
+        obs_n, rew_n, _, _ = env.step(act if fused else [act[i] for i in range(A)])
+        pos, vel = env.world.get_state()
+        close(pos, g["pos"][t], what="pos t=%d" % t)
+        close(vel, g["vel"][t], what="vel t=%d" % t)
+        for i in range(A):
+            close(np_(obs_n[i]), g["obs%d" % i][t], what="obs%d" % i)
+    g = golden("mode_continuous")
+    T, W, A = g["rew"].shape
+    env = mpe.make_env("simple_tag", batch_size=W, fused=fused)
+    env.discrete_action_space = False
+    for t in range(T):
+        env.world.set_state(g["pos0"] if t == 0 else g["pos"][t - 1], g["vel0"] if t == 0 else g["vel"][t - 1])
+        act = [torch.as_tensor(g["act2"][t][:, i], dtype=torch.float32).cuda() for i in range(A)]
+        obs_n, rew_n, _, _ = env.step(act)
+        pos, vel = env.world.get_state()
+        close(pos, g["pos"][t], what="continuous pos t=%d" % t)
+        close(vel, g["vel"][t], what="continuous vel t=%d" % t)
+        for i in range(A):
+            close(np_(obs_n[i]), g["obs%d" % i][t], what="continuous obs%d" % i)
