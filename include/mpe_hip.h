@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 3
+#define MPE_ABI_VERSION 3 /* layout of the two structs below + meaning of existing entry points; new entry points are additive */
 #define MPE_MAX_ENTITIES 512 /* agents + landmarks per world */
 #define MPE_ACTION_DIM 5     /* Discrete(dim_p*2+1), environment.py:45 */
 #define MPE_MAX_CHOICES 4    /* np.random.choice draws a reset_world makes before the positions */
