@@ -150,3 +150,20 @@ def test_error_reporting():
     b2 = _abi.MpeBuffers()
     b2.pos, b2.vel, b2.obs, b2.act = envt.world.pos.data_ptr(), envt.world.vel.data_ptr(), obs.data_ptr(), act.data_ptr()
     assert L.mpe_step(C.byref(dt), C.byref(b2), 8, None) == -2 and b"no kernel" in L.mpe_last_error()
+
+
+def test_a_c_program_steps_the_reference_kat_on_the_gpu(tmp_path):
+    """tests/c/abi_gpu.c: hipMalloc + mpe_step from C, no Python / torch in the process -- the library is the product,
+    PyTorch is plumbing.  Checks the reference's recorded known-answer step."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.dirname(_abi.LIB_PATH)
+    exe = str(tmp_path / "abi_gpu")
+    cmd = ["gcc", "-std=c99", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(root, "include"),
+           os.path.join(root, "tests", "c", "abi_gpu.c"), "-o", exe, "-L", lib_dir, "-lmpe_hip", "-L/opt/rocm/lib",
+           "-lamdhip64", "-lm", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr[-500:])
