@@ -5,22 +5,33 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json metric config): simple_spread, 3 agents / 3 landmarks, 65536 worlds PER GPU
-(weak scaling: rank r owns worlds [r*B, (r+1)*B); no collective on the step path), fp32,
-uniform random one-hot moves, device-side reset every 25 steps (MADDPG episode length).
-One "step" = every world of the batch advanced once with all agents' obs/reward/done written.
+Headline workload (BASELINE.json metric config, C5): simple_spread, 3 agents / 3 landmarks, 65536 worlds PER GPU
+(weak scaling: rank r owns worlds [r*B, (r+1)*B); no collective on the step path), fp32.
+Protocol: uniform random one-hot moves `[A][B][5]` that are FRESH for every step -- one
+`mpe_random_actions_block` launch per 25-step episode draws the episode's moves, inside the timed region --, a
+device-side `mpe_reset` every 25 steps (MADDPG episode length), one `mpe_step` launch per step that reads its moves
+from HBM and writes every agent's obs / reward / done.  One "step" = every world of the batch advanced once.
 
-Timed region: barrier + synchronize, K steps, synchronize + barrier; max over ranks; rank 0 prints
-ONE JSON line.  Modes:
-  graph  (default, `value`)  K `mpe_step` launches (+ resets) replayed from a HIP graph; every launch
-         reads its one-hot action tensor from HBM (pool of pre-generated tensors) and writes all outputs
-  eager  the same launches issued from Python through the C ABI
-  api    through MultiAgentEnv.step()/reset() (the drop-in API, Python in the loop)
-  fused  `mpe_rollout_random`: one launch per 25-step episode, state in registers, moves drawn in-kernel,
-         every step's outputs written to its own trajectory block (reported under "extra" by default)
+Timed region: barrier + synchronize, the K-step HIP graph replayed R times back to back (R = 1 when K steps already
+take >= 20 ms; a 20-step region is 0.15 ms, shorter than one graph launch is accurate to), synchronize + barrier;
+max over ranks; `value` = B * K * R * ranks / that time.  Rank 0 prints ONE JSON line.
+
+Besides the headline the line carries (N=1 only):
+  roofline             the step kernel's HIP-event time over back-to-back launches -> algorithmic GB/s vs 8 TB/s.
+                       At B=65536 the working set (27 MB/launch + the 98 MB move pool) sits in the 256 MiB Infinity
+                       Cache: the limit there is launch + latency, and the line says so.
+  extra.hbm_resident   the same kernel and protocol at B=1048576 (431 MB per launch: beyond the Infinity Cache)
+  extra.configs        BASELINE.json's other single-GPU configs: C2 spread N=3 B=4096, C3 simple_tag B=16384,
+                       C4 spread N=64 B=4096 -- each with its own roofline entry
+  extra.fused_rollout  `mpe_rollout_random`: one launch per episode, state on chip, moves drawn in-kernel
+  extra.moves_resident the round-1 headline: moves read from a resident ring that is never redrawn
+  cpu_baseline         oracle/mpe_loop.py on the host cores (+ the C port), with the unmodified reference's own
+                       numbers from the build container (profiles/cpu_reference.json) quoted beside it
 """
 import argparse
+import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -29,7 +40,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~5.3-6.3 TB/s is the measured copy ceiling
+L3_BYTES = 256 * 1024 * 1024   # Infinity Cache
+MIN_REGION_MS = 20.0
 
 
 def algorithmic_bytes(A, L, obs_total, n_choices=0, comm_floats=0):
@@ -104,7 +117,23 @@ def cpu_baseline_c(scenario, okw, seconds, threads):
         from oracle import build_c, spec as ospec
         spec = ospec.by_name(scenario, **okw)
         return build_c.bench(spec, seconds, threads), build_c.bench(spec, min(seconds, 2.0), 1)
-    except Exception as e:  # the C restatement covers simple / simple_spread / simple_tag
+    except Exception:  # the C restatement covers simple / simple_spread / simple_tag
+        return None
+
+
+def cpu_reference_record(key):
+    """The unmodified reference timed in the build container (tools/time_reference.py -> profiles/cpu_reference.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "cpu_reference.json")) as f:
+            d = json.load(f)
+        row = d["configs"][key]
+        return {"source": "profiles/cpu_reference.json (tools/time_reference.py: the unmodified /root/reference, build container)",
+                "cpu_model": d["cpu_model"], "cores": d["usable_cores"],
+                "env_steps_per_s_1_process": row["reference"]["env_steps_per_s_1_process"],
+                "env_steps_per_s_all_cores": row["reference"]["env_steps_per_s_all_cores"],
+                "port_over_reference_1_process": row["port_over_reference_1_process"],
+                "port_over_reference_all_cores": row["port_over_reference_all_cores"]}
+    except Exception:
         return None
 
 
@@ -182,6 +211,202 @@ def bench_generic(args, env, dev, rank, world, sharding):
     return None
 
 
+class Leg(object):
+    """One workload (scenario, sizes, batch) on this rank's GPU: env(s), rollout driver, measurements."""
+
+    def __init__(self, mpe, scenario, agents, B, EP, rank, streams=1, seed=0, generic=False):
+        from multiagent_particle_envs_amd.rollout import RandomRollout, StreamedRollout
+        self.kw, self.okw = {}, {}
+        if scenario == "simple_spread" and agents != 3:
+            self.kw["num_agents"] = agents
+            self.okw["n"] = agents
+        self.scenario, self.B, self.EP, self.S = scenario, B, EP, max(1, streams)
+        assert B % self.S == 0, "--batch must be a multiple of --streams"
+        self.envs = []
+        for s_ in range(self.S):                        # S sub-batches of B/S worlds, one HIP stream each
+            e = mpe.make_env(scenario, batch_size=B // self.S, seed=seed, fused=False if generic else None, **self.kw)
+            e.world.world_offset = rank * B + s_ * (B // self.S)   # global world numbering: no shared RNG streams
+            self.envs.append(e)
+        self.env = self.envs[0]
+        self.A, self.Lm = len(self.env.world.agents), len(self.env.world.landmarks)
+        self._RR, self._SR = RandomRollout, StreamedRollout
+        self.rolls = {}
+        self.trajs = None
+
+    def roll(self, protocol):
+        """protocol 'fresh': every step consumes moves nobody used before (block redraw per episode, in the timed
+        region); 'resident': a ring of 16 move tensors drawn once."""
+        if protocol not in self.rolls:
+            P = (self.EP or 16) if protocol == "fresh" else 16
+            rs = [self._RR(e, episode_len=self.EP, pool=P, regenerate=(protocol == "fresh")) for e in self.envs]
+            self.rolls[protocol] = self._SR(rs)
+        return self.rolls[protocol]
+
+    def geometry(self):
+        env = self.env
+        obs_total = int(env._obs_off[-1])
+        speakers = sum(1 for a in env.world.agents if not a.silent)
+        bytes_step = algorithmic_bytes(self.A, self.Lm, obs_total, len(env.world.choice_pops), speakers * env.world.dim_c)
+        compulsory_roll = 4 * (obs_total + self.A) + self.A    # a fused rollout keeps state on chip and draws moves in-kernel
+        A, Lm = self.A, self.Lm
+        kname = "mpe::k_split" if A + Lm <= 16 else ("mpe::k_multi" if max(A, Lm) <= 32 and A + Lm <= 64 else "mpe::k_wave")
+        return obs_total, bytes_step, compulsory_roll, kname
+
+    def fused_steps(self, roll, n):
+        from multiagent_particle_envs_amd.rollout import Trajectory
+        T = self.EP if self.EP else 25
+        if self.trajs is None:
+            self.trajs = [Trajectory(e, T) for e in self.envs]
+        done = 0
+        while done < n:
+            k = min(T, n - done)
+            roll.fused(k, self.trajs)
+            done += k
+
+    def body(self, mode, protocol, n):
+        roll = self.roll(protocol)
+        if mode == "graph":
+            return roll.capture(n).replay
+        if mode == "eager":
+            return lambda: roll.enqueue(n)
+        if mode == "fused":
+            return lambda: self.fused_steps(roll, n)
+        env, r0, EP = self.env, roll.rollouts[0], self.EP
+        assert self.S == 1, "--mode api drives one env"
+
+        def api():
+            for k in range(n):
+                if EP and k % EP == 0:
+                    env.reset()
+                env.step(r0.pool[k % len(r0.pool)])
+        return api
+
+    def timed(self, torch, sharding, dev, mode, protocol, K, W, repeats):
+        """-> (seconds for K*R steps: median over repeats, max over ranks; R; HIP-event ms of the median repeat)."""
+        roll = self.roll(protocol)
+        body = self.body(mode, protocol, K)
+        if mode == "fused":
+            self.fused_steps(roll, W)
+        else:
+            roll.enqueue(W)
+        body()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()     # size the region: R replays of the K-step body >= MIN_REGION_MS
+        body()
+        torch.cuda.synchronize()
+        once = max(time.perf_counter() - t0, 1e-6)
+        R = max(1, int(math.ceil(MIN_REGION_MS * 1e-3 / once))) if mode in ("graph", "fused") else 1
+        R = int(sharding.reduce_max(R, dev))
+        walls, evs = [], []
+        for _ in range(repeats):
+            sharding.barrier(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _r in range(R):
+                body()
+            e1.record()
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)   # this rank's K*R steps, from the common start to its own completion
+            sharding.barrier(dev)                      # (the MAX over ranks below is the job's time)
+            evs.append(e0.elapsed_time(e1))
+        order = sorted(range(len(walls)), key=lambda i: walls[i])
+        med = order[len(order) // 2]
+        return sharding.reduce_max(walls[med], dev), R, evs[med]
+
+    def kernel_time_us(self, torch, mode, n=400):
+        """The dominant kernel's time per env step, from HIP events on the launch stream around n back-to-back
+        dependent launches with nothing else in between (no resets, no redraws): graph replay / fused launches."""
+        roll = self.roll("resident")
+        roll.set_episode_len(0)
+        try:
+            body = self.body("fused" if mode == "fused" else "graph", "resident", n)
+            body()
+            torch.cuda.synchronize()
+            best = None
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                body()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / n
+                best = us if best is None else min(best, us)
+            return best
+        finally:
+            roll.set_episode_len(self.EP)
+
+    def release(self):
+        self.rolls.clear()
+        self.trajs = None
+        self.envs = []
+        self.env = None
+
+
+def launch_floor_us(torch, dev, n=400):
+    """Empty-ish dependent launch: `mpe_episode_tick` on 64 worlds, n launches captured in a HIP graph."""
+    from multiagent_particle_envs_amd import _abi
+    L = _abi.lib()
+    cnt = torch.zeros(64, dtype=torch.int32, device=dev)
+    done = torch.zeros((1, 64), dtype=torch.bool, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        L.mpe_episode_tick(cnt.data_ptr(), done.data_ptr(), 1, 64, 0, 0, _abi.raw_stream(dev))
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(n):
+                L.mpe_episode_tick(cnt.data_ptr(), done.data_ptr(), 1, 64, 0, 0, _abi.raw_stream(dev))
+    torch.cuda.current_stream(dev).wait_stream(s)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+def copy_ceiling_gbs(torch, dev):
+    """Device-to-device copy of 1 GiB (read + write counted; beyond the Infinity Cache): the streaming ceiling of this box."""
+    n = 256 * 1024 * 1024
+    a = torch.empty(n, dtype=torch.float32, device=dev)
+    b_ = torch.empty_like(a)
+    a.fill_(1.0)
+    b_.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b_.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def roofline_entry(leg, k_us, B, mode, floor_us):
+    obs_total, bytes_step, compulsory_roll, kname = leg.geometry()
+    per_launch = bytes_step * B
+    achieved = per_launch / (k_us * 1e-6) / 1e9
+    tr = pmc_traffic("%s_A%d_L%d_B%d" % (leg.scenario, leg.A, leg.Lm, B)) if mode in ("graph", "eager") else None
+    moves_pool = 25 * leg.A * B * 20
+    resident = per_launch + moves_pool < L3_BYTES
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": tr["traffic_bytes_per_launch"] if tr else None,
+            "traffic_source": tr["source"] if tr else None,
+            "regime": ("working set (%.0f MB per launch + %.0f MB of moves) fits the 256 MiB Infinity Cache: the PMC "
+                       "'traffic' is fabric requests, largely L3 hits; the launch is launch/latency-limited, not HBM-limited"
+                       % (per_launch / 1e6, moves_pool / 1e6)) if resident else
+                      ("working set (%.0f MB per launch) exceeds the 256 MiB Infinity Cache: HBM-resident" % (per_launch / 1e6)),
+            "l3_resident": resident,
+            "algorithmic_bytes_per_env_step": bytes_step, "algorithmic_bytes_per_launch": per_launch,
+            "kernel": kname, "kernel_us_per_launch": k_us, "env_steps_per_launch": B,
+            "launch_floor_us": floor_us,
+            "frac_excluding_launch_floor": (per_launch / max((k_us - floor_us), 1e-3) / 1e3 / HBM_PEAK_GBS) if floor_us else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,11 +417,20 @@ def main():
     ap.add_argument("--agents", type=int, default=3)
     ap.add_argument("--episode-len", type=int, default=25)
     ap.add_argument("--mode", default="graph", choices=["graph", "eager", "api", "fused"])
+    ap.add_argument("--protocol", default="fresh", choices=["fresh", "resident"],
+                    help="fresh: every step's moves are newly drawn (one block draw per episode, timed); resident: a ring of "
+                         "16 move tensors drawn once (round-1 headline)")
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (fused-rollout) measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other configs, 1M leg, fused rollout)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--backend", default=None, help="torch.distributed backend for N>1 (default nccl = RCCL; gloo for the "
+                                                     "one-GPU rehearsal test)")
+    ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--dump-state", default=None, metavar="DIR",
+                    help="before timing: run the rollout's episode-0 reset + step 0 and save this rank's pos / vel / obs / "
+                         "rew to DIR/rank<r>.npz (the multi-rank rehearsal test compares them with one big batch)")
     ap.add_argument("--generic", action="store_true",
                     help="step through the generic path (torch callbacks + mpe_world_step) although a fused kernel exists")
     ap.add_argument("--streams", type=int, default=1,
@@ -207,212 +441,161 @@ def main():
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.all_ranks_on_gpu0 else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the step path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = args.backend or "nccl"
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    rdev = dev if (world == 1 or (args.backend or "nccl") == "nccl") else torch.device("cpu")   # where the bookkeeping reductions live
 
     import multiagent_particle_envs_amd as mpe
     from multiagent_particle_envs_amd import sharding
-    from multiagent_particle_envs_amd.rollout import RandomRollout, StreamedRollout, Trajectory
-    kw, okw = {}, {}
-    if args.scenario == "simple_spread" and args.agents != 3:
-        kw["num_agents"] = args.agents
-        okw["n"] = args.agents
+
+    class _Sh(object):   # barrier on the GPU, reductions on the backend's device
+        @staticmethod
+        def barrier(d):
+            sharding.barrier(d)
+
+        @staticmethod
+        def reduce_max(v, d):
+            return sharding.reduce_max(v, rdev)
     B, K, W, EP = args.batch, args.steps, args.warmup, args.episode_len
-    S = max(1, args.streams)
-    assert B % S == 0, "--batch must be a multiple of --streams"
-    envs = []
-    for s_ in range(S):                        # S sub-batches of B/S worlds, one HIP stream each
-        e = mpe.make_env(args.scenario, batch_size=B // S, seed=args.seed, fused=False if args.generic else None, **kw)
-        e.world.world_offset = rank * B + s_ * (B // S)   # global world numbering: no shared RNG streams
-        envs.append(e)
-    env = envs[0]
-    A, Lm = len(env.world.agents), len(env.world.landmarks)
-    if not env.fused:
-        return bench_generic(args, env, dev, rank, world, sharding)
-    rolls = [RandomRollout(e, episode_len=EP, pool=16) for e in envs]
-    roll = StreamedRollout(rolls)
-    obs_total = int(env._obs_off[-1])
-    speakers = sum(1 for a in env.world.agents if not a.silent)
-    bytes_step = algorithmic_bytes(A, Lm, obs_total, len(env.world.choice_pops), speakers * env.world.dim_c)
-    can_fuse = A <= 6 or args.scenario == "simple_spread"
-    trajs = None
+    leg = Leg(mpe, args.scenario, args.agents, B, EP, rank, args.streams, args.seed, args.generic)
+    if not leg.env.fused:
+        return bench_generic(args, leg.env, dev, rank, world, _Sh)
+    A, Lm = leg.A, leg.Lm
+    obs_total, bytes_step, compulsory_roll, kname = leg.geometry()
+    can_fuse = A + Lm <= 16 and leg.env._kind not in (6, 7, 8, 9) or args.scenario == "simple_spread"
 
-    def fused_steps(n):
-        nonlocal trajs
-        T = EP if EP else 25
-        if trajs is None:
-            trajs = [Trajectory(e, T) for e in envs]
-        done = 0
-        while done < n:
-            k = min(T, n - done)
-            roll.fused(k, trajs)
-            done += k
-
-    def make_body(mode, n):
-        if mode == "graph":
-            g = roll.capture(n)
-            return g.replay
-        if mode == "eager":
-            return lambda: roll.enqueue(n)
-        if mode == "fused":
-            return lambda: fused_steps(n)
-
-        def api():
-            assert S == 1, "--mode api drives one env"
-            for k in range(n):
-                if EP and k % EP == 0:
-                    env.reset()
-                env.step(rolls[0].pool[k % len(rolls[0].pool)])
-        return api
-
-    def timed(mode):
-        """median over repeats of the wall time of exactly K steps, max over ranks"""
-        body = make_body(mode, K)
-        if mode == "fused":
-            fused_steps(W)
-        else:
-            roll.enqueue(W)
-        sharding.barrier(dev)
-        walls = []
-        evs = []
-        for _ in range(args.repeats):
-            sharding.barrier(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0 = time.perf_counter()
-            e0.record()
-            body()
-            e1.record()
-            torch.cuda.synchronize()
-            walls.append(time.perf_counter() - t0)   # this rank's K steps, from the common start to its own completion
-            sharding.barrier(dev)                      # (the MAX over ranks below is the job's time)
-            evs.append(e0.elapsed_time(e1))
-        if mode == args.mode:
-            region_ms[:] = evs
-        return sharding.reduce_max(sorted(walls)[len(walls) // 2], dev)
-
-    region_ms = []      # HIP-event time of each timed repeat (events on the launch stream)
-
-    def kernel_time_us(mode, n=400):
-        """The dominant kernel's time per env step, from HIP events on the launch stream around n
-        back-to-back steps with no resets in between (graph replay / fused launches)."""
-        roll.set_episode_len(0)
-        try:
-            body = make_body("fused" if mode == "fused" else "graph", n)
-            body()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            body()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) * 1e3 / n
-        finally:
-            roll.set_episode_len(EP)
-
-    def copy_ceiling_gbs():
-        """Device-to-device copy of 256 MiB (read + write counted), the practical streaming ceiling of this box."""
-        n = 64 * 1024 * 1024
-        a = torch.empty(n, dtype=torch.float32, device=dev)
-        b_ = torch.empty_like(a)
-        a.fill_(1.0)
-        b_.copy_(a)
+    if args.dump_state:
+        import numpy as np
+        r0 = leg.roll(args.protocol).rollouts[0]
+        assert r0.t == 0
+        out0 = r0.enqueue(1)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            b_.copy_(a)
-        e1.record()
-        torch.cuda.synchronize()
-        return 10 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        os.makedirs(args.dump_state, exist_ok=True)
+        np.savez(os.path.join(args.dump_state, "rank%d.npz" % rank), pos=leg.env.world.pos.cpu().numpy(),
+                 vel=leg.env.world.vel.cpu().numpy(), obs=out0.obs.cpu().numpy(), rew=out0.rew.cpu().numpy(),
+                 world_offset=np.int64(leg.env.world.world_offset))
 
-    dt = timed(args.mode)
-    k_us = kernel_time_us(args.mode)
+    dt, R, ev_ms = leg.timed(torch, _Sh, dev, args.mode, args.protocol, K, W, args.repeats)
+    k_us = leg.kernel_time_us(torch, args.mode)
+    floor_us = launch_floor_us(torch, dev)
     extra = {}
-    if not args.no_extra and can_fuse and args.mode != "fused":
-        dtf = timed("fused")
-        kf = kernel_time_us("fused")
+    solo = world == 1 and not args.no_extra and args.streams == 1
+
+    if solo and can_fuse and args.mode != "fused":
+        dtf, Rf, _ = leg.timed(torch, _Sh, dev, "fused", "resident", K, W, 3)
+        kf = leg.kernel_time_us(torch, "fused")
         extra["fused_rollout"] = {
             "what": "mpe_rollout_random: one launch per %d-step episode, state kept on chip (registers / LDS), moves drawn "
                     "in-kernel, every step's obs/rew/done written to its own trajectory block" % (EP or 25),
-            "value": B * K * world / dtf, "unit": "env-steps/s", "ms_per_step": dtf * 1e3 / K,
+            "value": B * K * Rf / dtf, "unit": "env-steps/s", "ms_per_step": dtf * 1e3 / (K * Rf),
             "kernel_us_per_step": kf,
-            "achieved_GBps_at_411B_convention": bytes_step * B / (kf * 1e-6) / 1e9,
-            "compulsory_bytes_per_env_step": 4 * (obs_total + A) + A,
-            "achieved_GBps_compulsory": (4 * (obs_total + A) + A) * B / (kf * 1e-6) / 1e9}
+            "compulsory_bytes_per_env_step": compulsory_roll,
+            "achieved_GBps_compulsory": compulsory_roll * B / (kf * 1e-6) / 1e9,
+            "frac_compulsory": compulsory_roll * B / (kf * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "achieved_GBps_at_per_step_convention": bytes_step * B / (kf * 1e-6) / 1e9,
+            "per_step_convention_bytes": bytes_step}
+    if solo and args.mode == "graph" and args.protocol == "fresh":
+        dtr, Rr, _ = leg.timed(torch, _Sh, dev, "graph", "resident", K, W, 3)
+        extra["moves_resident"] = {
+            "what": "the same K-step graph with the moves read from a resident ring of 16 tensors drawn once (no redraw "
+                    "launches in the timed region): the step as a policy-driven caller sees it",
+            "value": B * K * Rr / dtr, "unit": "env-steps/s", "ms_per_step": dtr * 1e3 / (K * Rr)}
 
-    if not args.no_extra and args.mode == "graph" and S == 1:
-        # SURVEY 8d's "regenerate every step": `value` steps on moves already resident in HBM (the policy's output);
-        # here each step also draws its fresh moves on the device first
-        for how in ("inline",):
-            rr = RandomRollout(env, episode_len=EP, pool=16, regenerate=True)
-            gr = rr.capture(K)
-            gr.replay()
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(3):
-                sharding.barrier(dev)
-                t0 = time.perf_counter()
-                gr.replay()
-                torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t0)
-            dtr = sharding.reduce_max(sorted(ts)[1], dev)
-            extra["moves_regenerated_every_step"] = {
-                "what": "graph of K x (mpe_random_actions -> mpe_step), resets every %d steps" % EP,
-                "value": B * K * world / dtr, "unit": "env-steps/s", "ms_per_step": dtr * 1e3 / K}
+    headline_roof = roofline_entry(leg, k_us, B, args.mode, floor_us)
+    default_line = solo and args.scenario == "simple_spread" and args.agents == 3 and B == 65536
+    if default_line:
+        leg.release()
+        torch.cuda.empty_cache()
+        # ---- the same kernel and protocol where the working set cannot sit in the Infinity Cache ----------------
+        big = Leg(mpe, "simple_spread", 3, 1 << 20, EP, rank, 1, args.seed)
+        dtb, Rb, _ = big.timed(torch, _Sh, dev, "graph", "fresh", 25, 5, 3)
+        kb = big.kernel_time_us(torch, "graph", n=100)
+        rb = roofline_entry(big, kb, 1 << 20, "graph", floor_us)
+        extra["hbm_resident"] = {"what": "simple_spread N=3 at 1048576 worlds (431 MB per launch, 2 GB of moves per episode): "
+                                         "same kernel, same protocol, HBM-resident",
+                                 "value": (1 << 20) * 25 * Rb / dtb, "unit": "env-steps/s",
+                                 "ms_per_step": dtb * 1e3 / (25 * Rb), "roofline": rb}
+        big.release()
+        del big
+        torch.cuda.empty_cache()
+        # ---- BASELINE.json's other single-GPU configs ------------------------------------------------------------
+        cfgs = {}
+        for key, scn, ag, bb, kk in (("C2_spread_n3_B4096", "simple_spread", 3, 4096, 200),
+                                     ("C3_tag_B16384", "simple_tag", 3, 16384, 200),
+                                     ("C4_spread_n64_B4096", "simple_spread", 64, 4096, 50)):
+            lg = Leg(mpe, scn, ag, bb, EP, rank, 1, args.seed)
+            d1, R1, _ = lg.timed(torch, _Sh, dev, "graph", "fresh", kk, 10, 3)
+            k1 = lg.kernel_time_us(torch, "graph", n=200 if bb * ag < 100000 else 100)
+            ent = {"value": bb * kk * R1 / d1, "unit": "env-steps/s", "ms_per_step": d1 * 1e3 / (kk * R1),
+                   "workload": "%s A=%d L=%d, %d worlds" % (scn, lg.A, lg.Lm, bb), "roofline": roofline_entry(lg, k1, bb, "graph", floor_us)}
+            d2, R2, _ = lg.timed(torch, _Sh, dev, "fused", "resident", kk, 10, 3)
+            k2 = lg.kernel_time_us(torch, "fused", n=200 if bb * ag < 100000 else 100)
+            comp = lg.geometry()[2]
+            ent["fused_rollout"] = {"value": bb * kk * R2 / d2, "unit": "env-steps/s", "kernel_us_per_step": k2,
+                                    "compulsory_bytes_per_env_step": comp,
+                                    "frac_compulsory": comp * bb / (k2 * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            cfgs[key] = ent
+            lg.release()
+            del lg
+            torch.cuda.empty_cache()
+        extra["configs"] = cfgs
 
     if rank == 0:
-        achieved = bytes_step * B / (k_us * 1e-6) / 1e9
-        kname = ("mpe::k_split" if os.environ.get("MPE_STEP_IMPL") != "thread" else "mpe::k_narrow") if A <= 6 \
-            else ("mpe::k_multi" if max(A, Lm) <= 32 and A + Lm <= 64 else "mpe::k_wave")
-        tkey = "%s_A%d_L%d_B%d" % (args.scenario, A, Lm, B)
-        tr = pmc_traffic(tkey) if S == 1 and args.mode in ("graph", "eager") else None
-        copy_gbs = copy_ceiling_gbs()
+        copy_gbs = copy_ceiling_gbs(torch, dev)
+        headline_roof.update({
+            "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": headline_roof["achieved"] / copy_gbs,
+            "timed_region_us_per_step": ev_ms * 1e3 / (K * R),
+            "note": "achieved = algorithmic bytes per launch / kernel_us_per_launch; kernel_us_per_launch = HIP-event time "
+                    "(launch stream) of 400 back-to-back dependent step launches / 400, best of 3 (the rocprofv3 kernel-trace "
+                    "average of the same command is under profiles/); launch_floor_us = the same for a 64-world bookkeeping "
+                    "kernel; timed_region_us_per_step = HIP-event time of the timed region / (steps x graph_replays) and "
+                    "includes the per-episode reset and move-draw launches"})
         out = {
             "metric": "env steps/sec (whole node), %s N=%d, batch=%d per GPU" % (args.scenario, A, B),
-            "value": B * K * world / dt, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": B * K * R * world / dt, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt * 1e3 / (K * R), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s A=%d L=%d, %d worlds/GPU, one-hot random moves in HBM, reset every %d steps"
-                                   % (args.scenario, A, Lm, B, EP),
-                       "batch_per_gpu": B, "global_batch": B * world, "mode": args.mode,
-                       "repeats": args.repeats, "streams_per_gpu": S,
+            "config": {"workload": "%s A=%d L=%d, %d worlds/GPU, one-hot random moves (%s), device reset every %d steps"
+                                   % (args.scenario, A, Lm, B,
+                                      "fresh for every step: one block draw per episode inside the timed region"
+                                      if args.protocol == "fresh" else "resident ring of 16 tensors", EP),
+                       "protocol": args.protocol, "batch_per_gpu": B, "global_batch": B * world, "mode": args.mode,
+                       "graph_replays_in_timed_region": R, "timed_steps": K * R,
+                       "repeats": args.repeats, "streams_per_gpu": args.streams,
                        "sharding": "worlds by batch index, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": tr["traffic_bytes_per_launch"] if tr else None,
-                         "traffic_source": tr["source"] if tr else None,
-                         "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
-                         "algorithmic_bytes_per_env_step": bytes_step,
-                         "algorithmic_bytes_per_launch": bytes_step * B,
-                         "kernel": kname,
-                         "kernel_us_per_launch": k_us, "env_steps_per_launch": B,
-                         "timed_region_us_per_step": (sorted(region_ms)[len(region_ms) // 2] * 1e3 / K) if region_ms else None,
-                         "note": "achieved = algorithmic bytes per launch / kernel_us_per_launch; kernel_us_per_launch = HIP-event "
-                                 "time (launch stream) of 400 back-to-back dependent step launches / 400 (agrees with the rocprofv3 "
-                                 "kernel-trace average under profiles/); timed_region_us_per_step = HIP-event time of the timed "
-                                 "region / steps (includes the reset launches every episode); with S>1 streams the S sub-batch "
-                                 "launches of one step overlap, so both are times per full-batch step"},
+            "roofline": headline_roof,
         }
         if extra:
             out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             procs = usable_cores()
-            agg, single = cpu_baseline(args.scenario, okw, args.cpu_seconds, procs)
+            agg, single = cpu_baseline(args.scenario, leg.okw, args.cpu_seconds, procs)
+            refkey = {"simple": "simple", "simple_tag": "simple_tag"}.get(
+                args.scenario, "simple_spread_n%d" % A if args.scenario == "simple_spread" else None)
+            ref = cpu_reference_record(refkey) if refkey else None
             out["cpu_baseline"] = {
                 "value": agg, "unit": "env-steps/s", "cores": procs, "kind": "port",
                 "sample": "oracle/mpe_loop.py (the reference's per-object fp64 Python/NumPy loop restated; "
                           "/root/reference is absent on the GPU box), %d processes x %.0f s each, same move "
-                          "distribution, reset every 25 steps; 1 process alone: %.0f env-steps/s"
+                          "distribution, reset every 25 steps; 1 process alone: %.0f env-steps/s.  The unmodified "
+                          "reference itself, same protocol, in the build container: see `reference_build_container`"
                           % (procs, args.cpu_seconds, single),
                 "single_core": single}
-            cp = cpu_baseline_c(args.scenario, okw, min(args.cpu_seconds, 4.0), procs)
+            if ref:
+                out["cpu_baseline"]["reference_build_container"] = ref
+                out["cpu_baseline"]["value_in_reference_terms"] = agg / ref["port_over_reference_all_cores"]
+            cp = cpu_baseline_c(args.scenario, leg.okw, min(args.cpu_seconds, 4.0), procs)
             if cp:
                 out["cpu_baseline"]["c_port"] = {
                     "value": cp[0], "unit": "env-steps/s", "cores": procs, "single_core": cp[1],

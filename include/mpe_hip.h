@@ -131,6 +131,12 @@ int mpe_fill_entity_table(const MpeScenarioDesc *desc, float *host_out);
  *   (environment.py:100-102).  Reads pos, vel, act|ids; writes pos, vel, obs, rew, done, info_*. */
 int mpe_step(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, void *stream);
 
+/* mpe_step_thread: the same step, same arguments, bit-identical results, on the thread-per-world kernel
+ * family (one lane owns one world) instead of the wave-per-agent one -- the independent second
+ * implementation the parity tests hold mpe_step to.  Shapes without a thread-per-world kernel (the
+ * communication scenarios, A + L > 16) run the kernel mpe_step runs.                                  */
+int mpe_step_thread(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, void *stream);
+
 /* mpe_observe: the output half only (used by reset(): environment.py:106-116 -> _get_obs, and by
  * the phase-level tests): obs (+ rew/done/info when those pointers are set) from the current state. */
 int mpe_observe(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, void *stream);
@@ -161,6 +167,12 @@ int mpe_reset(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, co
 /* Uniform random moves: one-hot rows into act [A][B][5] and/or ids [A][B] (either may be NULL). */
 int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed,
                        uint64_t step, int64_t world_offset, void *stream);
+/* The same for T consecutive global steps step0 .. step0+T-1 in one launch: act holds T consecutive
+ * [A][B][5] tensors, ids T consecutive [A][B] tensors; tensor s is exactly what
+ * mpe_random_actions(step0 + s) writes.  (A rollout that wants fresh moves for every step draws one
+ * episode's worth per launch instead of paying a launch per step.)                               */
+int mpe_random_actions_block(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed,
+                             uint64_t step0, int32_t T, int64_t world_offset, void *stream);
 
 /* 1 when mpe_step / mpe_observe have a fused kernel for this descriptor (kind, agent / landmark /
  * adversary counts, dim_c), 0 when the caller must keep Scenario.observation / reward itself and

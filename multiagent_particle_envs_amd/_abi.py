@@ -52,6 +52,7 @@ EXPORTS = {
     "mpe_fill_entity_table": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(C.c_float)]),
     "mpe_step_supported": (C.c_int, [C.POINTER(MpeScenarioDesc)]),
     "mpe_step": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
+    "mpe_step_thread": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
     "mpe_observe": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
     "mpe_world_step": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
     "mpe_apply_action_force": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
@@ -61,6 +62,8 @@ EXPORTS = {
                             C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]),
     "mpe_random_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64,
                                      C.c_int64, C.c_void_p]),
+    "mpe_random_actions_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64,
+                                           C.c_int32, C.c_int64, C.c_void_p]),
     "mpe_episode_tick": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "mpe_rollout_random": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_int32,
                                      C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32,

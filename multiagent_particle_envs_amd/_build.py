@@ -23,6 +23,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function"]
 
 
+STRESS_VARIANTS = {"stress": ["-DMPE_STRESS_DELAY_WAVE=1"],
+                   "stress_racy": ["-DMPE_STRESS_DELAY_WAVE=1", "-DMPE_STRESS_STORE_BEFORE_BARRIER"]}
+
+
+def variant_lib(tag):
+    return os.path.join(LIBDIR, "libmpe_hip_%s.so" % tag)
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -43,8 +51,8 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    if not force and not _stale(LIB, srcs + hdrs):
-        return LIB  # the shipped .so is newer than every source: nothing to do (GPU box)
+    if not force and not any(_stale(l, srcs + hdrs) for l in [LIB] + [variant_lib(t) for t in STRESS_VARIANTS]):
+        return LIB  # the shipped .so files are newer than every source: nothing to do (GPU box)
     jobs = []
     objs = []
     for src in SOURCES:
@@ -62,10 +70,25 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-8000:]))
         if verbose and r.stderr.strip():
             print(r.stderr[-4000:])
+    # test-only variants of the wave-per-agent kernels (tests/test_gpu_race.py): one agent wave of every workgroup
+    # is held back ~30 us before its first load (MPE_STRESS_DELAY_WAVE); "_racy" additionally restores the
+    # store-before-barrier ordering the round-1 kernel had, as the negative control that shows the test can fail
+    variants = []
+    split_src = os.path.join(CSRC, "mpe_split.hip")
+    for tag, defs in STRESS_VARIANTS.items():
+        o = os.path.join(OBJ, "mpe_split_%s.o" % tag)
+        variants.append((tag, o))
+        if force or _stale(o, [split_src] + hdrs):
+            jobs.append([hipcc] + FLAGS + defs + ["-c", split_src, "-o", o])
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    for tag, o in variants:
+        vlib = os.path.join(LIBDIR, "libmpe_hip_%s.so" % tag)
+        vobjs = [o if x.endswith("mpe_split.o") else x for x in objs]
+        if force or _stale(vlib, vobjs):
+            run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", vlib] + vobjs)
     return LIB
 
 

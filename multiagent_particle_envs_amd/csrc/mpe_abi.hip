@@ -25,14 +25,10 @@ int hip_result(int rc, const char *what) {
   return fail(rc, "%s: %s", what, hipGetErrorString((hipError_t)rc));
 }
 
-// Which kernel family serves mpe_step for the small-entity shapes.  Default: wave-per-agent
-// (mpe_split.hip).  MPE_STEP_IMPL=thread selects the thread-per-world kernel (mpe_narrow.hip) --
-// a tuning / A-B switch read at call time, not a behavioural one: both give bit-identical results.
+// Which kernel family serves a step on the small-entity shapes: wave-per-agent (mpe_split.hip) is what
+// mpe_step launches; thread-per-world (mpe_narrow.hip) is reachable through its own entry point
+// mpe_step_thread -- an explicit argument of the call, not process state.  Both give bit-identical results.
 enum class StepImpl { Split, Thread };
-StepImpl step_impl() {
-  const char *e = std::getenv("MPE_STEP_IMPL");
-  return (e && std::strcmp(e, "thread") == 0) ? StepImpl::Thread : StepImpl::Split;
-}
 
 int check_desc(const MpeScenarioDesc *d, const char *what) {
   if (!d) return fail(MPE_EINVAL, "%s: desc is NULL", what);
@@ -203,7 +199,7 @@ int mpe_fill_entity_table(const MpeScenarioDesc *d, float *out) {
 }
 
 static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
-               void *stream) {
+               void *stream, StepImpl impl = StepImpl::Split) {
   if (int rc = check_desc(d, what)) return rc;
   if (int rc = check_state(b, B, what)) return rc;
   if (phys) if (int rc = check_actions(b, what)) return rc;
@@ -228,7 +224,7 @@ static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, 
   }
   const bool comm_kind = kind >= MPE_SCN_SPEAKER_LISTENER;   // these exist as wave-per-agent kernels only
   if (out && (phys || comm_kind) && d->n_agents + d->n_landmarks <= mpe::kNarrowMaxE &&
-      (comm_kind || step_impl() != StepImpl::Thread) &&
+      (comm_kind || impl != StepImpl::Thread) &&
       mpe::split_supports(kind, d->n_agents, d->n_landmarks, d->n_adversaries)) {
     // the fused step: wave-per-agent / lane-per-world (mpe_split.hip)
     const mpe::NarrowDesc n = make_narrow(use, b, (size_t)B);
@@ -269,6 +265,9 @@ int mpe_step_supported(const MpeScenarioDesc *d) {
 
 int mpe_step(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, void *stream) {
   return run("mpe_step", true, true, d, b, B, stream);
+}
+int mpe_step_thread(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, void *stream) {
+  return run("mpe_step_thread", true, true, d, b, B, stream, StepImpl::Thread);
 }
 int mpe_observe(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, void *stream) {
   return run("mpe_observe", false, true, d, b, B, stream);
@@ -315,14 +314,19 @@ int mpe_reset(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, const ui
                                       static_cast<hipStream_t>(stream)), what);
 }
 
+int mpe_random_actions_block(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed, uint64_t step0,
+                             int32_t T, int64_t world_offset, void *stream) {
+  const char *what = "mpe_random_actions_block";
+  if (!act && !ids) return fail(MPE_EINVAL, "%s: act and ids are both NULL", what);
+  if (n_agents < 1 || B < 0 || T < 0 || T > 65535) return fail(MPE_EINVAL, "%s: bad n_agents/B/T", what);
+  if (B == 0 || T == 0) return 0;
+  return hip_result(mpe::launch_random_actions(act, ids, n_agents, (size_t)B, seed, step0, T, (uint64_t)world_offset,
+                                               static_cast<hipStream_t>(stream)), what);
+}
+
 int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed, uint64_t step,
                        int64_t world_offset, void *stream) {
-  const char *what = "mpe_random_actions";
-  if (!act && !ids) return fail(MPE_EINVAL, "%s: act and ids are both NULL", what);
-  if (n_agents < 1 || B < 0) return fail(MPE_EINVAL, "%s: bad n_agents/B", what);
-  if (B == 0) return 0;
-  return hip_result(mpe::launch_random_actions(act, ids, n_agents, (size_t)B, seed, step, (uint64_t)world_offset,
-                                               static_cast<hipStream_t>(stream)), what);
+  return mpe_random_actions_block(act, ids, n_agents, B, seed, step, 1, world_offset, stream);
 }
 
 int mpe_episode_tick(int32_t *episode_step, uint8_t *done, int32_t n_agents, int64_t B, int32_t max_episode_steps,

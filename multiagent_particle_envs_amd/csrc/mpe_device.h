@@ -240,14 +240,39 @@ __host__ __device__ inline int action_draw(uint64_t seed, uint64_t b, uint64_t t
 // store would be stride-D scattered.  Each wave parks its 64 rows in its own LDS tile and streams
 // the tile out as 16-byte stores over the contiguous 256*D-byte segment it owns.  No workgroup
 // barrier is involved.
-// Row stride S of the tile:
-//   D/2 odd (D = 18, 14, 30 ...)  S = D: the tile IS the output segment, the flush is one
-//       ds_read_b128 + one 16-byte store per lane with no index arithmetic, and rows written as
-//       float2 (8-byte) pieces are bank-conflict-free (stride D/2 odd in 8-byte units);
-//   otherwise                      S = D|1 (odd => conflict-free 4-byte column writes) and the flush
+// Row stride S of the tile and how a lane writes its row (bank = dword address mod 32 for every ds_write;
+// ds_write_b64 is serviced in contiguous 16-lane groups, ds_write_b128 in contiguous 8-lane groups):
+//   D % 4 == 2 (D = 18, 14, 10, 34 ...)   S = D, rows written as float2 pieces: stride D/2 is odd in 8-byte
+//       units, so the 16 lanes of a group land on 16 different bank pairs.  The tile IS the output segment:
+//       the flush is one ds_read_b128 + one 16-byte store per lane with no index arithmetic;
+//   D % 4 == 0, D/4 odd (D = 4, 12, 20, 28)   S = D, rows written as float4 pieces: the 8 lanes of a group
+//       land on 8 different 4-bank slots; the tile is the output segment as above;
+//   D % 4 == 0, D/4 in {2, 4, 8} (D = 8, 16, 32)   S = D, float4 pieces with the piece index XOR-swizzled by
+//       the row (swz4): un-swizzled, the lanes of a group would pile onto 4 / 2 / 1 slots (2- / 4- / 8-way
+//       conflicts).  The flush reads logical piece q from its swizzled place -- a permutation inside the row,
+//       so its ds_read_b128 (64 banks, 16-lane groups) stays conflict-free;
+//   otherwise (odd D, D = 24, 40 ...)      S = D|1 (odd => conflict-free 4-byte column writes) and the flush
 //       gathers each 16-byte piece with a divide-by-constant per element.
 template <int D>
+constexpr bool row_vec4() {
+  return (D % 4) == 0 && ((((D / 4) & 1) == 1) || D == 8 || D == 16 || D == 32);
+}
+// rows built by RowPairs (every column written as part of an (x, y) pair): the rules above
+template <int D>
+constexpr int pair_stride() { return (row_vec4<D>() || ((D % 2) == 0 && ((D / 2) % 2) == 1)) ? D : (D | 1); }
+// rows built column by column with put1 / put2 (the communication scenarios' mixed rows): float2 pieces where
+// D % 4 == 2, an odd stride with 4-byte writes otherwise; never swizzled
+template <int D>
 constexpr int tile_stride() { return ((D % 2) == 0 && ((D / 2) % 2) == 1) ? D : (D | 1); }
+
+// piece-index swizzle of row `l` for NS = D/4 pieces per row (0 when NS is odd: no swizzle needed)
+template <int NS>
+__device__ __forceinline__ int swz4(int l) {
+  if constexpr (NS == 2) return (l >> 2) & 1;
+  else if constexpr (NS == 4) return (l >> 1) & 3;
+  else if constexpr (NS == 8) return l & 7;
+  else return 0;
+}
 
 // columns c, c+1 (c even) of this lane's row
 template <int S>
@@ -263,22 +288,44 @@ __device__ __forceinline__ void put2(float *tile, int lane, int c, float x, floa
 template <int S>
 __device__ __forceinline__ void put1(float *tile, int lane, int c, float x) { tile[lane * S + c] = x; }
 
-// flush_rows: the tile (row stride tile_stride<D>(), rows = lanes) already holds the wave's 64 rows.
+// Writer of one lane's row of D floats handed over as (x, y) pairs at even columns in ascending order
+// (every built-in observation row is a list of 2-vectors): picks the piece width of tile_stride<D>().
 template <int D>
+struct RowPairs {
+  static constexpr int S = pair_stride<D>();
+  float *tile;
+  int lane;
+  float h0 = 0.f, h1 = 0.f;   // first half of a 16-byte piece
+  __device__ __forceinline__ RowPairs(float *t, int l) : tile(t), lane(l) {}
+  __device__ __forceinline__ void put(int c, float x, float y) {
+    if constexpr (row_vec4<D>()) {
+      if ((c & 3) == 0) { h0 = x; h1 = y; }
+      else *reinterpret_cast<float4 *>(tile + lane * D + 4 * ((c >> 2) ^ swz4<D / 4>(lane))) = make_float4(h0, h1, x, y);
+    } else {
+      put2<S>(tile, lane, c, x, y);
+    }
+  }
+};
+
+// flush_rows: the tile (row stride tile_stride<D>(), rows = lanes) already holds the wave's 64 rows.
+// PAIRS: the rows were written by RowPairs (pair_stride, possibly swizzled); otherwise by put1 / put2 (tile_stride).
+template <int D, bool PAIRS = false>
 __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict__ g, int nvalid, int lane,
                                            bool vec4) {
-  constexpr int S = tile_stride<D>();
+  constexpr int S = PAIRS ? pair_stride<D>() : tile_stride<D>();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int nfl = nvalid * D;
   constexpr int NQ = 16 * D;  // float4 slots in a full tile
+  constexpr int NSW = (PAIRS && row_vec4<D>() && ((D / 4) & 1) == 0) ? D / 4 : 0;   // pieces per row when the tile is swizzled
   if (S == D && vec4 && nvalid == kWave) {
     // the common case -- a full wave of worlds, aligned rows: straight 16-byte copies, no bounds tests
 #pragma unroll
     for (int it = 0; it < (NQ + kWave - 1) / kWave; ++it) {
       const int q = lane + kWave * it;
+      const int qs = NSW ? (q ^ swz4<NSW>(q / (NSW ? NSW : 1))) : q;   // NSW is a power of two: q / NSW is the row
       if ((it + 1) * kWave <= NQ || q < NQ)
-        *reinterpret_cast<float4 *>(g + 4 * q) = *reinterpret_cast<const float4 *>(tile + 4 * q);
+        *reinterpret_cast<float4 *>(g + 4 * q) = *reinterpret_cast<const float4 *>(tile + 4 * qs);
     }
   } else {
 #pragma unroll
@@ -288,7 +335,8 @@ __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict_
     if (q < NQ && j < nfl) {
       float v[4];
       if constexpr (S == D) {
-        const float4 t = *reinterpret_cast<const float4 *>(tile + j);
+        const int qs = NSW ? (q ^ swz4<NSW>(q / (NSW ? NSW : 1))) : q;
+        const float4 t = *reinterpret_cast<const float4 *>(tile + 4 * qs);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
       } else {
 #pragma unroll
@@ -315,18 +363,20 @@ __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict_
 template <int D>
 __device__ __forceinline__ void store_rows(float *tile, const float (&row)[D], float *__restrict__ g,
                                            int nvalid, int lane, bool vec4) {
-  constexpr int S = tile_stride<D>();
-  if constexpr ((S & 1) == 0) {
+  if constexpr ((D & 1) == 0) {
+    RowPairs<D> r(tile, lane);
 #pragma unroll
-    for (int c = 0; c < D; c += 2) put2<S>(tile, lane, c, row[c], row[c + 1]);
+    for (int c = 0; c < D; c += 2) r.put(c, row[c], row[c + 1]);
+    flush_rows<D, true>(tile, g, nvalid, lane, vec4);
   } else {
+    constexpr int S = tile_stride<D>();
 #pragma unroll
     for (int c = 0; c < D; ++c) tile[lane * S + c] = row[c];
+    flush_rows<D, false>(tile, g, nvalid, lane, vec4);
   }
-  flush_rows<D>(tile, g, nvalid, lane, vec4);
 }
 
 template <int D>
-constexpr int tile_floats() { return kWave * tile_stride<D>(); }
+constexpr int tile_floats() { return kWave * (D | 1); }   // >= either stride rule
 
 }  // namespace mpe

@@ -34,18 +34,46 @@ k_reset(float *__restrict__ pos, float *__restrict__ vel, const uint8_t *__restr
   }
 }
 
+// Uniform random moves for T consecutive global steps (the moves a policy would hand over; bench / rollout
+// workloads).  A wave owns 64 consecutive worlds of one agent QUAD at one step: one Philox block per lane
+// yields the moves of agents 4q .. 4q+3 of that lane's world (action_draw's counter layout), and the
+// one-hot rows [64 worlds][5] of an agent -- 1280 contiguous bytes of act [A][B][5] -- leave as five
+// 256-byte wave stores, lane f of store k writing float 64k + f of the run (the move of world (64k+f)/5
+// arrives by a wave shuffle).  Step s writes the s-th consecutive [A][B][5] / [A][B] tensor.
 __global__ void __launch_bounds__(kBlock)
-k_random_actions(float *__restrict__ act, int32_t *__restrict__ ids, size_t B, uint64_t seed, uint64_t step,
+k_random_actions(float *__restrict__ act, int32_t *__restrict__ ids, size_t B, int A, uint64_t seed, uint64_t step0,
                  uint64_t world_offset) {
-  const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = blockIdx.y;
-  if (w >= B) return;
-  const int m = action_draw(seed, world_offset + w, step, i);
-  if (ids) ids[(size_t)i * B + w] = m;
-  if (act) {
-    float *row = act + ((size_t)i * B + w) * MPE_ACTION_DIM;
+  const int lane = threadIdx.x & (kWave - 1);
+  const size_t w0 = ((size_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * kWave;   // wave-uniform
+  if (w0 >= B) return;
+  const int q = blockIdx.y;
+  const uint64_t step = step0 + blockIdx.z;
+  const int nvalid = (B - w0) < (size_t)kWave ? (int)(B - w0) : kWave;
+  const size_t w = w0 + (size_t)(lane < nvalid ? lane : nvalid - 1);
+  const uint64_t gw = world_offset + w;
+  U4 c;
+  c.x = (uint32_t)gw;
+  c.y = (uint32_t)(gw >> 32) ^ (uint32_t)(step >> 32);
+  c.z = (uint32_t)q;
+  c.w = kStreamAction ^ (uint32_t)step;
+  const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t word[4] = {o.x, o.y, o.z, o.w};
+  const size_t sblk = (size_t)blockIdx.z * (size_t)A * B;   // this step's tensor
 #pragma unroll
-    for (int k = 0; k < MPE_ACTION_DIM; ++k) row[k] = (k == m) ? 1.f : 0.f;
+  for (int k4 = 0; k4 < 4; ++k4) {
+    const int i = 4 * q + k4;
+    if (i >= A) break;   // uniform
+    const int m = (int)(((uint64_t)word[k4] * 5u) >> 32);
+    if (ids && lane < nvalid) ids[sblk + (size_t)i * B + w] = m;
+    if (act) {
+      float *const run = act + (sblk + (size_t)i * B + w0) * MPE_ACTION_DIM;   // wave-uniform: 64 rows of 5 floats
+#pragma unroll
+      for (int k = 0; k < MPE_ACTION_DIM; ++k) {
+        const int f = kWave * k + lane, wl = f / MPE_ACTION_DIM, comp = f - wl * MPE_ACTION_DIM;
+        const int ms = __shfl(m, wl, kWave);
+        if (wl < nvalid) run[f] = (comp == ms) ? 1.f : 0.f;
+      }
+    }
   }
 }
 
@@ -80,10 +108,11 @@ int launch_reset(int A, int L, const MpeBuffers &b, size_t B, const uint8_t *mas
   return (int)hipGetLastError();
 }
 
-int launch_random_actions(float *act, int32_t *ids, int A, size_t B, uint64_t seed, uint64_t step,
+int launch_random_actions(float *act, int32_t *ids, int A, size_t B, uint64_t seed, uint64_t step0, int T,
                           uint64_t world_offset, hipStream_t stream) {
-  const dim3 grid((unsigned)((B + kBlock - 1) / kBlock), (unsigned)A);
-  hipLaunchKernelGGL(k_random_actions, grid, dim3(kBlock), 0, stream, act, ids, B, seed, step, world_offset);
+  const size_t per_block = (size_t)(kBlock / kWave) * kWave;
+  const dim3 grid((unsigned)((B + per_block - 1) / per_block), (unsigned)((A + 3) / 4), (unsigned)T);
+  hipLaunchKernelGGL(k_random_actions, grid, dim3(kBlock), 0, stream, act, ids, B, A, seed, step0, world_offset);
   return (int)hipGetLastError();
 }
 

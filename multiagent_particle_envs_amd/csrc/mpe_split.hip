@@ -5,9 +5,10 @@
 // instructions, so the step is latency-bound at ~10 us although its 27 MB would stream in ~4 us.
 // Here a workgroup is (A + 1) waves x 64 lanes: lane = world, and the waves split the work of those
 // 64 worlds by ROLE:
-//   wave i < A   AGENT i: loads the world, its contacts and its integration (core.py:117-169), stores
-//                its new state, publishes (pos_i, vel_i[, |pos_i - landmark_l|^2]) in LDS, and after
-//                ONE __syncthreads assembles and stores agent i's observation rows;
+//   wave i < A   AGENT i: loads the world, its contacts and its integration (core.py:117-169), publishes
+//                (pos_i, vel_i[, |pos_i - landmark_l|^2]) in LDS, and after ONE __syncthreads stores its
+//                new state (behind the barrier: a sibling wave may still be loading the pre-step
+//                positions before it) and assembles and stores agent i's observation rows;
 //   wave A       REWARD: touches no global input at all -- behind the same barrier it reads what the
 //                agents published and computes every agent's reward / done / benchmark_data once
 //                (the reference recomputes the shared terms per agent: O(A^2 L) -> O(A L)).
@@ -328,6 +329,14 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
   }
 }
 
+__device__ __forceinline__ void store_state(const MpeBuffers &b, size_t B, int i, size_t w0, unsigned ln, float mx,
+                                            float my, float mvx, float mvy) {
+  (b.pos + wave_off((size_t)(2 * i) * B + w0))[ln] = mx;
+  (b.pos + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = my;
+  (b.vel + wave_off((size_t)(2 * i) * B + w0))[ln] = mvx;
+  (b.vel + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = mvy;
+}
+
 template <int KIND, int A, int L, int NADV, bool ROLL>
 __global__ void __launch_bounds__((A + 1) * kWave)
 k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs ra) {
@@ -340,6 +349,13 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   const int i = is_agent ? role : 0;
   const size_t w0 = (size_t)blockIdx.x * kWave;
   if (w0 >= B) return;  // workgroup-uniform
+#ifdef MPE_STRESS_DELAY_WAVE
+  // test build only (libmpe_hip_stress.so, tests/test_gpu_race.py): hold one agent wave back for ~30 us before
+  // its first load, so that every sibling wave has long finished its World.step when this one starts -- any
+  // ordering bug between the state stores and the sibling loads then shows as a wrong contact force
+  if (role == (MPE_STRESS_DELAY_WAVE) % A)
+    for (int k = 0; k < 10; ++k) __builtin_amdgcn_s_sleep(127);   // 10 x 8128 clocks
+#endif
   const int nvalid = (B - w0) < (size_t)kWave ? (int)(B - w0) : kWave;
   const bool live = lane < nvalid;
   // dead lanes of a ragged last wave shadow its last live world (their stores are masked).  Every
@@ -448,12 +464,9 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         }
       }
       integrate_one(mx, my, mvx, mvy, fx, fy, mass_i, maxspd_i, d.damp, d.dt);
-      if (live && (!ROLL || t == T - 1)) {
-        (b.pos + wave_off((size_t)(2 * i) * B + w0))[ln] = mx;
-        (b.pos + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = my;
-        (b.vel + wave_off((size_t)(2 * i) * B + w0))[ln] = mvx;
-        (b.vel + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = mvy;
-      }
+#ifdef MPE_STRESS_STORE_BEFORE_BARRIER   // negative control of tests/test_gpu_race.py: the ordering that races
+      if (live && (!ROLL || t == T - 1)) store_state(b, B, i, w0, ln, mx, my, mvx, mvy);
+#endif
     }
 
     // ---- publish this agent's new state; read the other agents' ------------------------------------
@@ -483,6 +496,13 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
             sqrt_lt(sq2d(mx - px[A + 3 + f], my - py[A + 3 + f]), size_i + d.size[A + 3 + f]) ? 1.f : -1.f;
     }
     __syncthreads();
+    // The new state goes back to HBM only BEHIND the barrier: every sibling wave loaded this agent's
+    // pre-step position at kernel entry and consumed it in its contact loop, which lies before its own
+    // arrival at this barrier -- so no wave can observe a post-step position in World.step, whatever
+    // the dispatch order or timing of the waves (core.py:117-131: forces from the pre-step positions).
+#ifndef MPE_STRESS_STORE_BEFORE_BARRIER
+    if (movable_i && step_world && live && (!ROLL || t == T - 1)) store_state(b, B, i, w0, ln, mx, my, mvx, mvy);
+#endif
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       if (a == i) { px[a] = mx; py[a] = my; continue; }  // uniform
@@ -493,53 +513,56 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
     // ---- observation row of agent i for this step -------------------------------------------------
     float *const obs_t = b.obs + (size_t)t * obs_stride;
     if (KIND == MPE_SCN_SIMPLE) {  // simple.py:45-50
-      constexpr int D = 2 + 2 * L, RS = tile_stride<D>();
-      put2<RS>(tile, lane, 0, mvx, mvy);
+      constexpr int D = 2 + 2 * L;
+      RowPairs<D> r(tile, lane);
+      r.put(0, mvx, mvy);
 #pragma unroll
-      for (int l = 0; l < L; ++l) put2<RS>(tile, lane, 2 + 2 * l, px[A + l] - mx, py[A + l] - my);
-      flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      for (int l = 0; l < L; ++l) r.put(2 + 2 * l, px[A + l] - mx, py[A + l] - my);
+      flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
     }
     if (KIND == MPE_SCN_SPREAD) {  // simple_spread.py:84-100
-      constexpr int D = 4 + 2 * L + 4 * (A - 1), RS = tile_stride<D>();
-      put2<RS>(tile, lane, 0, mvx, mvy);
-      put2<RS>(tile, lane, 2, mx, my);
+      constexpr int D = 4 + 2 * L + 4 * (A - 1);
+      RowPairs<D> r(tile, lane);
+      r.put(0, mvx, mvy);
+      r.put(2, mx, my);
 #pragma unroll
-      for (int l = 0; l < L; ++l) put2<RS>(tile, lane, 4 + 2 * l, px[A + l] - mx, py[A + l] - my);
+      for (int l = 0; l < L; ++l) r.put(4 + 2 * l, px[A + l] - mx, py[A + l] - my);
       int k = 4 + 2 * L;  // uniform running column
 #pragma unroll
       for (int j = 0; j < A; ++j) {
         if (j == i) continue;
-        put2<RS>(tile, lane, k, px[j] - mx, py[j] - my);
+        r.put(k, px[j] - mx, py[j] - my);
         k += 2;
       }
 #pragma unroll
-      for (int z = 0; z < 2 * (A - 1); z += 2) put2<RS>(tile, lane, k + z, 0.f, 0.f);  // silent agents' comm
-      flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      for (int z = 0; z < 2 * (A - 1); z += 2) r.put(k + z, 0.f, 0.f);  // silent agents' comm
+      flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
     }
     if (KIND == MPE_SCN_TAG) {  // simple_tag.py:131-147
       constexpr int NG = A - NADV;
       constexpr int DA = 4 + 2 * L + 2 * (A - 1) + 2 * NG, DG = DA - 2;
       const bool adv = i < NADV;
       auto row = [&](auto dsel) {  // one observation row of width D (adversaries DA, good agents DG)
-        constexpr int D = decltype(dsel)::value, RS = tile_stride<D>();
-        put2<RS>(tile, lane, 0, mvx, mvy);
-        put2<RS>(tile, lane, 2, mx, my);
+        constexpr int D = decltype(dsel)::value;
+        RowPairs<D> r(tile, lane);
+        r.put(0, mvx, mvy);
+        r.put(2, mx, my);
 #pragma unroll
-        for (int l = 0; l < L; ++l) put2<RS>(tile, lane, 4 + 2 * l, px[A + l] - mx, py[A + l] - my);
+        for (int l = 0; l < L; ++l) r.put(4 + 2 * l, px[A + l] - mx, py[A + l] - my);
         int k = 4 + 2 * L;
 #pragma unroll
         for (int j = 0; j < A; ++j) {
           if (j == i) continue;
-          put2<RS>(tile, lane, k, px[j] - mx, py[j] - my);
+          r.put(k, px[j] - mx, py[j] - my);
           k += 2;
         }
 #pragma unroll
         for (int j = NADV; j < A; ++j) {
           if (j == i) continue;
-          put2<RS>(tile, lane, k, X[(j * XW + 2) * kWave + lane], X[(j * XW + 3) * kWave + lane]);
+          r.put(k, X[(j * XW + 2) * kWave + lane], X[(j * XW + 3) * kWave + lane]);
           k += 2;
         }
-        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       };
       if (adv) row(std::integral_constant<int, DA>{});
       else     row(std::integral_constant<int, DG>{});
@@ -548,18 +571,19 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       constexpr int DG = 2 + 2 * L + 2 * (A - 1), DA = DG - 2;
       const bool adv = i < NADV;
       auto row = [&](auto dsel, auto good) {
-        constexpr int D = decltype(dsel)::value, RS = tile_stride<D>();
+        constexpr int D = decltype(dsel)::value;
+        RowPairs<D> r(tile, lane);
         int k = 0;
-        if (decltype(good)::value) { put2<RS>(tile, lane, k, gx - mx, gy - my); k += 2; }
+        if (decltype(good)::value) { r.put(k, gx - mx, gy - my); k += 2; }
 #pragma unroll
-        for (int l = 0; l < L; ++l) { put2<RS>(tile, lane, k, px[A + l] - mx, py[A + l] - my); k += 2; }
+        for (int l = 0; l < L; ++l) { r.put(k, px[A + l] - mx, py[A + l] - my); k += 2; }
 #pragma unroll
         for (int j = 0; j < A; ++j) {
           if (j == i) continue;
-          put2<RS>(tile, lane, k, px[j] - mx, py[j] - my);
+          r.put(k, px[j] - mx, py[j] - my);
           k += 2;
         }
-        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       };
       if (adv) row(std::integral_constant<int, DA>{}, std::false_type{});
       else     row(std::integral_constant<int, DG>{}, std::true_type{});

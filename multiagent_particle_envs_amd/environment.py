@@ -117,6 +117,7 @@ class MultiAgentEnv(object):
         self._may_finish = set()      # values of _steps_taken at which some world can reach the horizon
         self.numpy_io = bool(numpy_io)
         self.fresh_outputs = bool(fresh_outputs)
+        self._step_impl = "split"
 
         # ---- can the whole step run as one fused kernel? ---------------------------------------------
         sc = getattr(observation_callback, "__self__", None)
@@ -208,6 +209,21 @@ class MultiAgentEnv(object):
                     out.bufs.entity_table = self._entity_table.data_ptr()
 
     @property
+    def step_impl(self):
+        """Which kernel family the fused step launches: 'split' (wave-per-agent, `mpe_step`, the default) or
+        'thread' (thread-per-world, `mpe_step_thread`: the independent second implementation the parity tests
+        compare against -- bit-identical results)."""
+        return self._step_impl
+
+    @step_impl.setter
+    def step_impl(self, value):
+        if value not in ("split", "thread"):
+            raise _abi.MpeError("step_impl is 'split' or 'thread'")
+        self._step_impl = value
+        if self._sets is not None:
+            self._mpe_step = _abi.lib().mpe_step_thread if value == "thread" else _abi.lib().mpe_step
+
+    @property
     def shared_reward(self):
         """environment.py:36: every agent receives the sum of all rewards.  Read at every step by the reference, so it
         may be flipped on a live env: the fused kernels implement the scenario's own setting (world.collaborative), any
@@ -231,7 +247,7 @@ class MultiAgentEnv(object):
         A, B = len(w.agents), w.batch_size
         self._entity_table = w.entity_table(self._desc)   # read by the wave-per-world (large N) kernel only
         self._desc_ref = C.byref(self._desc)
-        self._mpe_step = _abi.lib().mpe_step
+        self._mpe_step = _abi.lib().mpe_step_thread if self.step_impl == "thread" else _abi.lib().mpe_step
         if self._kind in _abi.COMM_KINDS:
             self._comm = torch.zeros((A, B, w.dim_c), dtype=torch.float32, device=w.device)
         self._sets = [_OutputSet(self), _OutputSet(self)]

@@ -21,9 +21,11 @@ from . import _abi
 class RandomRollout(object):
     def __init__(self, env, episode_len=25, pool=16, seed=None, regenerate=False):
         """regenerate: False -- the pool's tensors are drawn once and cycled (the policy's output is already resident
-        in HBM when the step is launched); True -- every step first draws its own fresh moves (`mpe_random_actions`
-        for global step t) on the same stream.  (Drawing them one step ahead on a side stream was measured too: the
-        fork/join per step costs more inside a HIP graph than the 2.8 us launch it hides -- 13.0 vs 9.4 us per step.)"""
+        in HBM when the step is launched); True -- every step consumes moves nobody has used before: whenever the pool
+        is exhausted (every `pool` steps; use pool = episode_len) ONE `mpe_random_actions_block` launch redraws all of
+        it for the next `pool` global steps, on the same stream.  (Per-step redraws cost a second 2.8 us launch per
+        step; drawing one step ahead on a side stream costs a fork/join per step inside a HIP graph, which was
+        measured slower still: 13.0 vs 9.4 us per step.  The block draw is one 98 MB-write launch per 25 steps.)"""
         if not env.fused:
             raise _abi.MpeError("RandomRollout drives the fused built-in scenarios")
         self.env = env
@@ -33,8 +35,8 @@ class RandomRollout(object):
         env._ensure_buffers()
         A, B = len(self.world.agents), self.world.batch_size
         self.A, self.B = A, B
-        self.pool = [torch.empty((A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=self.world.device)
-                     for _ in range(pool)]
+        self.pool_t = torch.empty((int(pool), A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=self.world.device)
+        self.pool = [self.pool_t[p] for p in range(int(pool))]
         self.t = 0          # global step counter (also indexes the Philox action stream)
         self.regenerate = bool(regenerate)
         self._L = _abi.lib()
@@ -48,16 +50,14 @@ class RandomRollout(object):
     def _stream(self):
         return _abi.raw_stream(self.world.device)
 
-    def _fill_pool(self):
-        """Action tensor p holds the moves of global steps t with t % len(pool) == p, as drawn at
-        step index p (the pool is cycled; the fused kernel draws fresh moves every step)."""
-        for p, act in enumerate(self.pool):
-            _abi.check(self._L.mpe_random_actions(act.data_ptr(), None, self.A, self.B, self.seed, p,
-                                                  int(self.world.world_offset), self._stream()), "mpe_random_actions")
-
-    def _draw(self, t, stream):
-        _abi.check(self._L.mpe_random_actions(self.pool[t % len(self.pool)].data_ptr(), None, self.A, self.B, self.seed,
-                                              t, int(self.world.world_offset), stream), "mpe_random_actions")
+    def _fill_pool(self, t0=0, stream=None):
+        """Action tensor p holds the moves of global steps t with t % len(pool) == p -- those of steps
+        t0 .. t0 + len(pool) - 1 after this call (t0 a multiple of len(pool)); without `regenerate` the pool is
+        drawn once and cycled (the fused kernel draws fresh moves every step)."""
+        _abi.check(self._L.mpe_random_actions_block(self.pool_t.data_ptr(), None, self.A, self.B, self.seed, int(t0),
+                                                    len(self.pool), int(self.world.world_offset),
+                                                    stream if stream is not None else self._stream()),
+                   "mpe_random_actions_block")
 
     def enqueue(self, steps):
         """Enqueue `steps` env steps (and the resets that fall among them) on the current stream."""
@@ -65,8 +65,8 @@ class RandomRollout(object):
         L, desc, B = self._L, self._desc, self.B
         st = self._stream()
         for _ in range(steps):
-            if self.regenerate:
-                self._draw(self.t, st)
+            if self.regenerate and self.t % len(self.pool) == 0:
+                self._fill_pool(self.t, st)
             if self.episode_len and self.t % self.episode_len == 0:
                 b = env._sets[0].bufs
                 _abi.check(L.mpe_reset(C.byref(self._gen_desc), C.byref(b), B, None, self._lr, self.seed,

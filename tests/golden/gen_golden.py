@@ -142,6 +142,10 @@ def record(name, env, seeds, T, squeeze_every=0, squeeze=0.3, soft_every=4, ids=
 
 def main():
     t0 = time.time()
+    only = sys.argv[1:]          # e.g. `gen_golden.py simple_spread_n64`: rewrite just that file
+    if only == ["simple_spread_n64"]:
+        jobs = [("simple_spread_n64", record_n64())]
+        return write(jobs, t0)
     jobs = []
     # C1: simple, 100 random-action steps (BASELINE.json configs[0]) -- plumbing check
     jobs.append(("simple", record("simple", make_env("simple"), list(range(16)), 100)))
@@ -156,12 +160,20 @@ def main():
     env.discrete_action_input = True
     jobs.append(("simple_spread_ids", record("simple_spread_ids", env, list(range(100, 116)), 10,
                                              squeeze_every=2, ids=True)))
-    # simple_spread N=64 (configs[3]); 0.9 s per reference step, so few worlds / steps
-    jobs.append(("simple_spread_n64", record("simple_spread_n64", spread_n(64), [7, 8], 3,
-                                             squeeze_every=0)))
+    jobs.append(("simple_spread_n64", record_n64()))
     # a mid-size N to pin the N-generic code (N=5)
     jobs.append(("simple_spread_n5", record("simple_spread_n5", spread_n(5), list(range(200, 212)), 12,
                                             squeeze_every=2, squeeze=0.4)))
+    write(jobs, t0)
+
+
+def record_n64():
+    """simple_spread N=64 (configs[3]); 0.9 s per reference step: 8 worlds x 3 steps, every other world squeezed so
+    that dozens of agents overlap (the contact path at N=64, not just the far field)."""
+    return record("simple_spread_n64", spread_n(64), [7, 8, 9, 10, 11, 12, 13, 14], 3, squeeze_every=2, squeeze=0.5)
+
+
+def write(jobs, t0):
     for name, data in jobs:
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **data)

@@ -254,6 +254,16 @@ def test_compat_mode_episode_like_a_reference_caller(name, golden):
             close(obs[i], g["obs%d" % i][t, w], tol=1e-4, what="t=%d obs%d" % (t, i))
         close(np.array(rew), g["rew"][t, w], tol=1e-4, what="t=%d rew" % t)
         assert done == [False] * env.n
+    # the same episode teacher-forced (state put back on the reference's fp64 trajectory before every step): the
+    # per-step bar of 1e-5 through the same NumPy-in / NumPy-out calls
+    np.random.seed(int(g["seeds"][w]))
+    env.reset()
+    for t in range(g["rew"].shape[0]):
+        env.world.set_state((g["pos0"] if t == 0 else g["pos"][t - 1])[w][None], (g["vel0"] if t == 0 else g["vel"][t - 1])[w][None])
+        obs, rew, done, info = env.step([g["act%d" % i][t, w] for i in range(env.n)])
+        for i in range(env.n):
+            close(obs[i], g["obs%d" % i][t, w], what="teacher-forced t=%d obs%d" % (t, i))
+        close(np.array(rew), g["rew"][t, w], what="teacher-forced t=%d rew" % t)
 
 
 @pytest.mark.gpu

@@ -130,6 +130,21 @@ def test_random_actions_bit_exact_and_uniform():
     assert np.abs(counts - 0.2).max() < 0.01
 
 
+def test_random_actions_block_equals_per_step_draws():
+    """mpe_random_actions_block: tensor s of the block is exactly mpe_random_actions(step0 + s); ragged batch, A not a
+    multiple of the four agents one Philox block serves."""
+    L = _abi.lib()
+    for A, B, T, step0, off in ((3, 1000, 25, 50, 0), (6, 65, 4, 2 ** 32 - 2, 123456789), (1, 64, 3, 0, 5)):
+        blk = torch.full((T, A, B, 5), -1.0, device="cuda")
+        bid = torch.full((T, A, B), -1, dtype=torch.int32, device="cuda")
+        _abi.check(L.mpe_random_actions_block(blk.data_ptr(), bid.data_ptr(), A, B, 9, step0, T, off, stream()))
+        for s in range(T):
+            want = philox.action_ids(9, B, step0 + s, A, world_offset=off)
+            assert np.array_equal(bid[s].cpu().numpy(), want)
+            assert np.array_equal(blk[s].cpu().numpy(), philox.one_hot(want))
+    assert L.mpe_random_actions_block(None, None, 3, 8, 0, 0, 1, 0, None) == -1
+
+
 def test_error_reporting():
     L = _abi.lib()
     env = make_env("simple_spread", batch_size=64)

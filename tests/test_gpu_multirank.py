@@ -1,0 +1,71 @@
+"""Rehearsal of bench.py's N>1 path on ONE GPU: two ranks launched exactly as the driver launches
+them (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`), both on cuda:0, bookkeeping
+collectives over gloo instead of RCCL.  Checks the line rank 0 prints (whole-job value, global batch) and that rank
+r's worlds are worlds [r*B, (r+1)*B) of one big batch bit for bit (reset draws and moves are keyed by the global
+world number: no collective on the step path, nothing shared between ranks)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import multiagent_particle_envs_amd as mpe
+from multiagent_particle_envs_amd.rollout import RandomRollout
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_one_gpu(tmp_path):
+    B = 4096
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--batch", str(B),
+           "--backend", "gloo", "--all-ranks-on-gpu0", "--no-cpu-baseline", "--dump-state", str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0) expected, got %d" % len(lines)
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5
+    assert out["config"]["batch_per_gpu"] == B and out["config"]["global_batch"] == 2 * B
+    assert out["scaling"] == "weak" and out["unit"] == "env-steps/s"
+    # whole-job value = both ranks' worlds over the slowest rank's time
+    assert abs(out["value"] - 2 * B / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
+    assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
+
+    # one process, one batch of 2B worlds: the same episode-0 reset + step 0
+    big = mpe.make_env("simple_spread", batch_size=2 * B, seed=0)
+    rr = RandomRollout(big, episode_len=25, pool=25, regenerate=True)
+    o = rr.enqueue(1)
+    torch.cuda.synchronize()
+    ref = {"pos": big.world.pos.cpu().numpy(), "vel": big.world.vel.cpu().numpy(), "rew": o.rew.cpu().numpy()}
+    obs = [x.cpu().numpy() for x in o.obs_n]
+    for rank in (0, 1):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        assert int(d["world_offset"]) == rank * B
+        sl = slice(rank * B, (rank + 1) * B)
+        assert np.array_equal(d["pos"], ref["pos"][:, :, sl])
+        assert np.array_equal(d["vel"], ref["vel"][:, :, sl])
+        assert np.array_equal(d["rew"], ref["rew"][:, sl])
+        off = 0
+        for i in range(3):   # agent i's [B, 18] block of the rank's obs buffer
+            blk = d["obs"][off * B:(off + 18) * B].reshape(B, 18)
+            assert np.array_equal(blk, obs[i][sl])
+            off += 18
+    assert not np.array_equal(ref["pos"][:, :, :B], ref["pos"][:, :, B:])   # the two shards are different worlds

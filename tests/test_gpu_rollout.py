@@ -20,25 +20,15 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-@pytest.fixture
-def impl_env():
-    old = os.environ.get("MPE_STEP_IMPL")
-    yield
-    if old is None:
-        os.environ.pop("MPE_STEP_IMPL", None)
-    else:
-        os.environ["MPE_STEP_IMPL"] = old
-
-
 @pytest.mark.parametrize("name,kw,B", [("simple", {}, 3000), ("simple_spread", {}, 5000), ("simple_tag", {}, 4097),
                                        ("simple_spread", {"num_agents": 5}, 777),
                                        ("simple_adversary", {}, 2000), ("simple_push", {}, 1111)])
-def test_split_and_thread_kernels_bit_identical(name, kw, B, impl_env):
+def test_split_and_thread_kernels_bit_identical(name, kw, B):
     rs = np.random.RandomState(1)
     outs = {}
     for impl in ("split", "thread"):
-        os.environ["MPE_STEP_IMPL"] = impl
         env = mpe.make_env(name, benchmark=name not in ("simple_adversary", "simple_push"), batch_size=B, **kw)
+        env.step_impl = impl
         assert env.fused
         A, E = len(env.world.agents), len(env.world.entities)
         rs = np.random.RandomState(1)

@@ -10,6 +10,6 @@ mkdir -p $R/gpurun_out/pmc_$TAG
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD"; do
   name=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$TAG/$name -o x -- \
-      python $R/bench.py --mode eager --steps 40 --warmup 5 --repeats 1 --no-cpu-baseline --no-extra "$@" > $R/gpurun_out/pmc_$TAG/$name.log 2>&1
+      python $R/bench.py --mode eager --protocol resident --steps 40 --warmup 5 --repeats 1 --no-cpu-baseline --no-extra "$@" > $R/gpurun_out/pmc_$TAG/$name.log 2>&1
 done
 find $R/gpurun_out/pmc_$TAG -name "*.csv" | head -20
