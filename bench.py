@@ -297,13 +297,21 @@ class Leg(object):
         once = max(time.perf_counter() - t0, 1e-6)
         R = max(1, int(math.ceil(MIN_REGION_MS * 1e-3 / once))) if mode in ("graph", "fused") else 1
         R = int(sharding.reduce_max(R, dev))
+        reps = R
+        if R > 1 and K * R <= 8000:
+            # one body of K*R CONSECUTIVE steps (resets and move draws fall every episode_len steps of the long run,
+            # whatever K is) instead of R replays of a K-step episode fragment
+            body = self.body(mode, protocol, K * R)
+            body()
+            torch.cuda.synchronize()
+            reps = 1
         walls, evs = [], []
         for _ in range(repeats):
             sharding.barrier(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
             e0.record()
-            for _r in range(R):
+            for _r in range(reps):
                 body()
             e1.record()
             torch.cuda.synchronize()

@@ -104,6 +104,7 @@ mpe::WideDesc make_wide(const MpeScenarioDesc *d) {
   w.A = d->n_agents;
   w.L = d->n_landmarks;
   w.dim_c = d->dim_c;
+  w.nadv = d->n_adversaries;
   w.collaborative = d->collaborative;
   w.D = d->obs_off[1] - d->obs_off[0];
   w.dt = d->dt;
@@ -111,6 +112,18 @@ mpe::WideDesc make_wide(const MpeScenarioDesc *d) {
   w.cforce = d->contact_force;
   w.cmargin = d->contact_margin;
   w.cmargin_inv = 1.0f / d->contact_margin;
+  const int A = d->n_agents, E = d->n_agents + d->n_landmarks;
+  bool homo = true;
+  for (int i = 1; i < A; ++i)
+    homo = homo && d->size[i] == d->size[0] && d->mass[i] == d->mass[0] && d->accel[i] == d->accel[0] &&
+           d->max_speed[i] == d->max_speed[0] && d->movable[i] == d->movable[0] && d->collide[i] == d->collide[0];
+  for (int e = A; e < E; ++e) homo = homo && !d->collide[e];
+  w.homo = homo ? 1 : 0;
+  w.a_flags = (d->movable[0] ? 1 : 0) | (d->collide[0] ? 2 : 0);
+  w.a_size = d->size[0];
+  w.a_inv_mass = 1.0f / d->mass[0];
+  w.a_accel = d->accel[0];
+  w.a_max_speed = d->max_speed[0];
   return w;
 }
 
@@ -240,7 +253,7 @@ static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, 
     return hip_result(mpe::launch_narrow(phys ? mpe::NarrowOp::Step : mpe::NarrowOp::Observe, kind, d->n_agents,
                                          d->n_landmarks, d->n_adversaries, n, *b, (size_t)B, s), what);
   }
-  if (kind == MPE_SCN_GENERIC || kind == MPE_SCN_SPREAD) {
+  if (kind == MPE_SCN_GENERIC || kind == MPE_SCN_SPREAD || kind == MPE_SCN_TAG) {
     if (int rc = need(b->entity_table, what, "entity_table (required by the wave-per-world kernel)")) return rc;
     mpe::WideDesc w = make_wide(use);
     w.kind = kind;
@@ -257,7 +270,7 @@ int mpe_step_supported(const MpeScenarioDesc *d) {
   if (A + L <= mpe::kNarrowMaxE && mpe::split_supports(d->kind, A, L, d->n_adversaries)) return 1;
   if (d->kind >= MPE_SCN_SPEAKER_LISTENER) return 0;
   if (use_narrow(d)) return 1;
-  if (d->kind != MPE_SCN_SPREAD) return 0;
+  if (d->kind != MPE_SCN_SPREAD && d->kind != MPE_SCN_TAG) return 0;   // the wave-per-world kernel: any team sizes
   mpe::WideDesc w = make_wide(d);
   w.kind = d->kind;
   return mpe::wide_supports(w, true) ? 1 : 0;
@@ -365,8 +378,8 @@ int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d->n_agents + d->n_landmarks > mpe::kNarrowMaxE ||
       !mpe::split_supports(d->kind, d->n_agents, d->n_landmarks, d->n_adversaries)) {
-    if (d->kind != MPE_SCN_SPREAD)
-      return fail(MPE_EUNSUPPORTED, "%s: the fused rollout exists for the wave-per-agent shapes and for simple_spread of any size", what);
+    if (d->kind != MPE_SCN_SPREAD && d->kind != MPE_SCN_TAG)
+      return fail(MPE_EUNSUPPORTED, "%s: the fused rollout exists for the wave-per-agent shapes and for simple_spread / simple_tag of any size", what);
     if (int rc = need(b->entity_table, what, "entity_table (required by the wave-per-world kernel)")) return rc;
     const mpe::WideDesc w = make_wide(d);
     return hip_result(mpe::launch_wide(true, true, w, *b, (size_t)B, s, &ra), what);

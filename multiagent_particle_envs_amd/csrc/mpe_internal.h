@@ -16,8 +16,13 @@ int launch_phase(int phase, int A, int L, const NarrowDesc &d, const MpeBuffers 
 // wave-per-world family for large entity counts (mpe_wide.hip)
 struct WideDesc {
   int32_t kind, A, L, dim_c, collaborative;
+  int32_t nadv;  // simple_tag: agents [0, nadv) are adversaries
   int32_t D;  // obs width (spread: same for every agent)
   float dt, damp, cforce, cmargin, cmargin_inv;
+  // homo: every agent has the same constants (below) and no landmark collides -- the shipped simple_spread at any N;
+  // kernels specialised for it take the constants from here instead of the device table
+  int32_t homo, a_flags /* 1 movable | 2 collide */;
+  float a_size, a_inv_mass, a_accel, a_max_speed;
 };
 constexpr int kEntityTableCols = 6;  // size, mass, accel, max_speed, movable, collide  -> [6][E] floats
 struct RollArgs;

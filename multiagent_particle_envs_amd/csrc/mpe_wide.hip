@@ -32,6 +32,15 @@
 
 #include "mpe_internal.h"
 
+// tuning knobs of k_duo (A/B builds override them with -D): share of the rows wave 0 emits, and an off switch
+#ifndef MPE_DUO_SPLIT_NUM
+#define MPE_DUO_SPLIT_NUM 5
+#define MPE_DUO_SPLIT_DEN 8
+#endif
+#ifndef MPE_DUO_ENABLE
+#define MPE_DUO_ENABLE 1
+#endif
+
 namespace mpe {
 
 namespace {
@@ -59,6 +68,11 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+// floats of one step's observation block of simple_tag (all agents' rows of all worlds)
+__host__ __device__ inline size_t obs_stride_tag(int A, int L, int nadv, size_t B) {
+  const int NG = A - nadv, DA = 4 + 2 * L + 2 * (A - 1) + 2 * NG;
+  return B * ((size_t)nadv * DA + (size_t)NG * (DA - 2));
+}
 
 // LDS carve-up.  Shared by the workgroup (constants, staged once): sizeq, crank/csz, agent constants.
 // Private to each wave: the world.  Positions sit in OBSERVATION order
@@ -157,7 +171,8 @@ __device__ __forceinline__ void emit_rows(const float2 *Q, const float2 *V, int 
 // against the uniform threshold L+i, two selects and two subtractions -- no LDS traffic and no address
 // arithmetic in the row loop beyond the broadcast read of (pos_i, vel_i) for the next row.
 __device__ __forceinline__ void emit_rows_fast(const float2 *Q, const float2 *V, int A, int L, int D,
-                                               float *obs_w, size_t rowlen, int lane) {
+                                               float *obs_w, size_t rowlen, int lane, int i_begin = 0, int i_end = -1) {
+  if (i_end < 0) i_end = A;
   const int E = A + L;
   const int P = D >> 2;             // 16-byte pieces per row, <= 128
   const int kpz = 2 + L + (A - 1);  // first all-zero pair
@@ -177,8 +192,8 @@ __device__ __forceinline__ void emit_rows_fast(const float2 *Q, const float2 *V,
     }
   const bool st0 = lane < P, st1 = lane + kWave < P;
   const bool tail0 = 2 * kWave > kpz;  // uniform: the first wave store already reaches the zero tail
-  float2 me = Q[L], vel = V[0];
-  for (int i = 0; i < A; ++i) {
+  float2 me = Q[L + min(i_begin, A - 1)], vel = V[min(i_begin, A - 1)];
+  for (int i = i_begin; i < i_end; ++i) {
     const int thr = L + i;
     float *const row = obs_w + (size_t)i * rowlen;  // wave-uniform
     const int inext = min(i + 1, A - 1);
@@ -208,6 +223,41 @@ __device__ __forceinline__ void emit_rows_fast(const float2 *Q, const float2 *V,
     }
     me = me_n;
     vel = vel_n;
+  }
+}
+
+// One world's simple_tag observation rows (simple_tag.py:131-147), any team sizes:
+//   row i = [vel_i | pos_i | landmark_l - pos_i ... | pos_j - pos_i (j != i, ascending) ... | vel_g of the good
+//            agents g != i, ascending]                 -- adversaries i < nadv see NG velocities, good agents NG - 1
+// i.e. spread's row with the zero tail replaced by raw velocities, and ragged widths DA / DA - 2: agent i's
+// [B][D_i] block starts at float offset B * (i * DA) for adversaries, B * (nadv * DA + (i - nadv) * DG) for the
+// good agents.  8-byte pieces (D_i is even, never both widths a multiple of 4): lane -> pair kp, 512 B per wave store.
+__device__ __forceinline__ void emit_rows_tag(const float2 *Q, const float2 *V, int A, int L, int nadv, float *obs,
+                                              size_t B, size_t w, int lane) {
+  const int NG = A - nadv, DA = 4 + 2 * L + 2 * (A - 1) + 2 * NG, DG = DA - 2;
+  const int kpz = 2 + L + (A - 1);   // first velocity pair
+  for (int i = 0; i < A; ++i) {
+    const bool adv = i < nadv;       // uniform
+    const int Di = adv ? DA : DG;
+    const size_t off = adv ? (size_t)i * DA : (size_t)nadv * DA + (size_t)(i - nadv) * DG;
+    float *const row = obs + B * off + w * (size_t)Di;   // wave-uniform
+    const float2 me = Q[L + i], vel = V[i];
+    const int thr = L + i, P = Di >> 1;
+    for (int kp = lane; kp < P; kp += kWave) {
+      float2 o;
+      if (kp >= kpz) {
+        int g = kp - kpz;
+        if (!adv) g += (g >= i - nadv) ? 1 : 0;
+        o = V[nadv + g];
+      } else if (kp >= 2) {
+        const int idx = kp - 2;
+        const float2 pj = Q[idx + (idx >= thr ? 1 : 0)];
+        o = make_float2(pj.x - me.x, pj.y - me.y);
+      } else {
+        o = kp == 0 ? vel : me;
+      }
+      *reinterpret_cast<float2 *>(row + 2 * kp) = o;
+    }
   }
 }
 
@@ -443,7 +493,51 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
       }
     }
 
-    if (OUT) {
+    if (OUT && d.kind == MPE_SCN_TAG) {
+      // ---- simple_tag, any team sizes: rows (:131-147), rewards (:84-129), benchmark_data (:57-66) ------------
+      const int nadv = d.nadv;
+      emit_rows_tag(Q, V, A, L, nadv, b.obs + (size_t)t * (ROLL && ra.trajectory ? obs_stride_tag(A, L, nadv, B) : 0), B, w, lane);
+      if (b.rew || b.info_collisions) {
+        float hits = 0.f;   // all (good, adversary) contacts of the world, counted on the adversary lanes
+        for (int t0 = 0; t0 < A; t0 += kWave) {
+          const int tt = t0 + lane;
+          const bool hi = tt < A, is_adv = tt < nadv;
+          const float2 pi = Q[L + (hi ? tt : 0)];
+          const float ri = sizeq[L + (hi ? tt : 0)];
+          int c = 0;
+          for (int j = 0; j < A; ++j) {   // uniform j; a lane counts the agents of the OTHER team it touches
+            const float2 pj = Q[L + j];
+            const bool other = (j < nadv) != is_adv;
+            c += (other && sqrt_lt(sq2d(pj.x - pi.x, pj.y - pi.y), sizeq[L + j] + ri)) ? 1 : 0;
+          }
+          if (hi) CNT[tt] = c;
+          hits += (hi && is_adv) ? (float)c : 0.f;
+        }
+        hits = wave_sum(hits);
+        const float adv_rew = 10.f * hits;   // adversary_reward :115-129: +10 per contact, the same for every adversary
+        wave_sync();
+        for (int i = lane; i < A; i += kWave) {
+          const int c = CNT[i];
+          const bool coll = __float_as_int(aconst[i].w) & kCollide;
+          float r;
+          if (i < nadv) {
+            r = coll ? adv_rew : 0.f;
+          } else {                            // agent_reward :89-113
+            const float2 p = Q[L + i];
+            r = coll ? 0.f - 10.f * (float)c : 0.f;
+            r -= tag_bound(fabsf(p.x));
+            r -= tag_bound(fabsf(p.y));
+          }
+          const size_t o = (size_t)t * row_stride + (size_t)i * B + w;
+          if (b.rew) b.rew[o] = r;
+          if (b.done) b.done[o] = 0;
+          if (b.info_collisions) b.info_collisions[o] = i < nadv ? c : 0;   // benchmark_data :57-66
+        }
+      } else if (b.done) {
+        for (int i = lane; i < A; i += kWave) b.done[(size_t)t * row_stride + (size_t)i * B + w] = 0;
+      }
+    }
+    if (OUT && d.kind == MPE_SCN_SPREAD) {
       // ---- observation rows (simple_spread.py:84-100): issued first, they drain while the reward is computed
       // agent i's rows form one [B][D] block (obs_n[i] of the drop-in API): the rows of one world are B*D floats apart
       const size_t rowlen = (size_t)B * D;
@@ -546,6 +640,145 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
       wave_sync();
     }
   }
+}
+
+// ---- two waves per world: the headline large-N shape (simple_spread, 32 < N <= 64, identical agents) ----------
+// k_wave gives a world to ONE wave, so at B = 4096 every wave runs load -> contacts -> 128 row stores -> reward
+// once, all of them in step: ~8 us in which no store is in flight, then the 403 MB of rows at the store rate,
+// then the reward (~1600 VALU per wave) of the last waves exposed at the end -- 88 us where a plain fill of the
+// same bytes takes 60.  Here a workgroup is one world and two waves with different ROLES:
+//   wave 0   loads the world, runs World.step (lane = agent), publishes the new state in LDS, stores it,
+//            and after the workgroup's one barrier emits observation rows [0, split);
+//   wave 1   sleeps at the barrier (no VALU, no LDS), then computes the reward / benchmark_data of the world
+//            and emits rows [split, A).
+// The reward's arithmetic therefore runs on other waves than half of the row stores and overlaps them; twice as
+// many waves are in flight, and workgroups of later worlds start their load / contact phase while earlier ones
+// stream rows, so the memory pipe sees stores from ~3 us on.  Scenario constants are kernel arguments (the
+// agents are identical, landmarks do not collide): no constant table, no staging pass, no second barrier.
+// Per-pair arithmetic, accumulation order (action first, partners ascending: Q9) and the reward's reduction
+// trees are k_wave's: results are bit-identical to it (tests/test_gpu_parity.py).
+constexpr int kDuoSplitNum = MPE_DUO_SPLIT_NUM, kDuoSplitDen = MPE_DUO_SPLIT_DEN;   // wave 0 emits rows [0, A * num / den)
+
+__global__ void __launch_bounds__(2 * kWave)
+k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int A = d.A, L = d.L, E = A + L, D = d.D;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float2 *const Q = reinterpret_cast<float2 *>(smem);                       // [landmarks | agents]: observation order
+  float2 *const V = reinterpret_cast<float2 *>(smem + align16(sizeof(float2) * E));
+  // world of this workgroup: XCD = blockIdx % 8 (hardware round-robin); 32 consecutive slots of one XCD own 32
+  // consecutive worlds = one 128-byte line of every state row, fetched into ONE L2
+  const unsigned x = blockIdx.x, xcd = x & 7u, slot = x >> 3;
+  const size_t w = (size_t)(((slot >> 5) << 8) | (xcd << 5) | (slot & 31u));
+  if (w >= B) return;   // workgroup-uniform
+  const int split = (A * kDuoSplitNum) / kDuoSplitDen;
+  const bool movable = d.a_flags & kMovable, collide = d.a_flags & kCollide;
+
+  if (wave == 0) {
+    // ---- stage + World.step (core.py:117-169) --------------------------------------------------------------
+    const bool have = lane < A;
+    const int i = have ? lane : 0;
+    float2 me = make_float2(b.pos[(size_t)(2 * i) * B + w], b.pos[(size_t)(2 * i + 1) * B + w]);
+    float2 v = make_float2(b.vel[(size_t)(2 * i) * B + w], b.vel[(size_t)(2 * i + 1) * B + w]);
+    float ux, uy;
+    fetch_action(b, B, i, w, d.a_accel, ux, uy);
+    if (lane < L) {
+      const int e = A + lane;
+      Q[lane] = make_float2(b.pos[(size_t)(2 * e) * B + w], b.pos[(size_t)(2 * e + 1) * B + w]);
+    }
+    if (have) Q[L + i] = me;
+    wave_sync();
+    if (movable) {
+      float ax = ux + 0.f, ay = uy + 0.f;   // action force first, then the partners in ascending order (Q9)
+      if (collide) {
+        const float ri = d.a_size, rfar = ri + kFarX * d.cmargin, reach = rfar + ri;
+        const float2 *const CPW = Q + L;
+        for (int kb = 0; kb < A; kb += 32) {
+          const int n = min(A - kb, 32);
+          unsigned near = near_mask32<true>(CPW, nullptr, kb, n, me, rfar, reach * reach);
+          if (i >= kb && i < kb + 32) near &= ~(0x80000000u >> (i - kb));   // not against itself
+          if (!have) near = 0u;
+          while (near) {   // pass 2: the partners within reach only, ascending
+            const int j = __clz((int)near);
+            near &= ~(0x80000000u >> j);
+            const float2 pj = CPW[kb + j];
+            float gx, gy;
+            contact_force(me.x - pj.x, me.y - pj.y, ri + ri, d.cforce, d.cmargin, d.cmargin_inv, gx, gy);
+            ax = gx + ax;
+            ay = gy + ay;
+          }
+        }
+      }
+      integrate_one(me.x, me.y, v.x, v.y, ax, ay, d.a_inv_mass, d.a_max_speed, d.damp, d.dt);
+    }
+    wave_sync();   // every lane has read the old positions
+    if (have) {
+      Q[L + i] = me;
+      V[i] = v;
+    }
+    __syncthreads();
+    if (have && movable) {   // behind the barrier, like k_split: nothing reads the old state from HBM after it
+      b.pos[(size_t)(2 * i) * B + w] = me.x;
+      b.pos[(size_t)(2 * i + 1) * B + w] = me.y;
+      b.vel[(size_t)(2 * i) * B + w] = v.x;
+      b.vel[(size_t)(2 * i + 1) * B + w] = v.y;
+    }
+    emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
+    return;
+  }
+
+  // ---- wave 1: reward (simple_spread.py:72-82) + benchmark_data (:47-63), then the other rows ---------------
+  __syncthreads();
+  if (b.rew || b.info_rew) {
+    const bool hl = lane < L, hi = lane < A;
+    const float2 pl = Q[hl ? lane : 0];          // landmark `lane`
+    const float2 pi = Q[L + (hi ? lane : 0)];    // agent `lane`
+    const float m = d.a_size + d.a_size, mm = m * m, lo = mm * 0.9999996f, hi_ = mm * 1.0000004f;
+    const bool has_band = mm > 1e-30f;
+    float m2 = INFINITY;
+    int c = 0;
+    bool band = false;   // did any pair land in the guard band of the strict `<` (1e-6 wide: almost never)
+#pragma unroll 8
+    for (int a = 0; a < A; ++a) {  // uniform a: broadcast reads at compile-time offsets; branch-free body
+      const float2 pa = Q[L + a];
+      m2 = fminf(m2, sq2d(pa.x - pl.x, pa.y - pl.y));
+      const float da = sq2d(pa.x - pi.x, pa.y - pi.y);
+      const bool below = da < lo;
+      c += below ? 1 : 0;                                  // includes a == lane
+      band = band || (!below && !(da > hi_ && has_band));
+    }
+    if (band) {  // recount this lane's row with the exact test
+      c = 0;
+      for (int a = 0; a < A; ++a) {
+        const float2 pa = Q[L + a];
+        c += sqrt_lt_pre(sq2d(pa.x - pi.x, pa.y - pi.y), m, lo, hi_, has_band) ? 1 : 0;
+      }
+    }
+    float neg = hl ? 0.f - fast_sqrt(m2) : 0.f;
+    int occ = (hl && sqrt_lt(m2, 0.1f)) ? 1 : 0;
+    c = (hi && collide) ? c : 0;
+    float csum = (float)c;
+    neg = wave_sum(neg);
+    occ = wave_sum_i(occ);
+    csum = wave_sum(csum);
+    const float tot = (float)A * neg - csum;  // environment.py:100-102: sum over agents of (neg - count_i)
+    if (hi) {
+      const float r = neg - (float)c;
+      const size_t o = (size_t)lane * B + w;
+      if (b.rew) b.rew[o] = d.collaborative ? tot : r;
+      if (b.done) b.done[o] = 0;
+      if (b.info_rew) {
+        b.info_rew[o] = r;
+        b.info_collisions[o] = c;
+        b.info_min_dists[o] = -neg;
+        b.info_occupied[o] = occ;
+      }
+    }
+  } else if (b.done && lane < A) {
+    b.done[(size_t)lane * B + w] = 0;
+  }
+  emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
 }
 
 // ---- several worlds per wave: the mid-size regime (7 <= A, L <= 32) ------------------------------------------
@@ -812,15 +1045,23 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
 
 }  // namespace
 
+// k_duo serves the fused spread step of 33..64 identical agents with 16-byte-aligned rows of at most 128 pieces
+static bool duo_eligible(const WideDesc &d, const MpeBuffers &b, size_t B, bool phys, bool out, bool roll) {
+  const int amax = d.A > d.L ? d.A : d.L;
+  return phys && out && !roll && d.kind == MPE_SCN_SPREAD && d.homo && d.dim_c == 2 && amax > 32 && d.A <= kWave &&
+         d.L <= kWave && (d.D & 3) == 0 && d.D <= 8 * kWave && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 &&
+         ((B * (size_t)d.D) & 3) == 0 && MPE_DUO_ENABLE;
+}
+
 bool wide_supports(const WideDesc &d, bool out) {
-  if (out && (d.kind != MPE_SCN_SPREAD || d.dim_c != 2 || (d.D & 1))) return false;
+  if (out && ((d.kind != MPE_SCN_SPREAD && d.kind != MPE_SCN_TAG) || d.dim_c != 2 || (d.D & 1))) return false;
   const Carve cv = carve(d.A, d.L);
   return cv.shared_bytes + kWavesPerWg * cv.wave_bytes <= kMaxLds;
 }
 
 int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream,
                 const RollArgs *roll) {
-  if (out && d.kind != MPE_SCN_SPREAD) return MPE_EUNSUPPORTED;
+  if (out && d.kind != MPE_SCN_SPREAD && d.kind != MPE_SCN_TAG) return MPE_EUNSUPPORTED;
   if (out && (d.dim_c != 2 || (d.D & 1))) return MPE_EUNSUPPORTED;
   const Carve cv = carve(d.A, d.L);
   const size_t lds = cv.shared_bytes + kWavesPerWg * cv.wave_bytes;
@@ -846,7 +1087,16 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
   RollArgs ra;
   std::memset(&ra, 0, sizeof(ra));
   const int amax = d.A > d.L ? d.A : d.L;
-  if (!roll && amax <= 32 && d.A + d.L <= kWave) {
+  if (duo_eligible(d, b, B, phys, out, roll != nullptr)) {
+    // two waves per world (k_duo): one workgroup per world, worlds padded to whole 256-world blocks of the XCD map
+    const size_t padded_w = (B + 255) / 256 * 256;
+    if (padded_w <= 0x7fffffffull) {
+      const size_t dlds = align16(sizeof(float2) * (d.A + d.L)) + align16(sizeof(float2) * d.A);
+      hipLaunchKernelGGL(k_duo, dim3((unsigned)padded_w), dim3(2 * kWave), dlds, stream, d, b, B);
+      return (int)hipGetLastError();
+    }
+  }
+  if (!roll && amax <= 32 && d.A + d.L <= kWave && !(out && d.kind != MPE_SCN_SPREAD)) {
     // several worlds per wave (k_multi): AP lanes per world slot
     const int AP = amax <= 8 ? 8 : amax <= 16 ? 16 : 32, WPW = kWave / AP;
     const size_t mlds = cv.shared_bytes + (size_t)kWavesPerWg * WPW * (2 * (d.A + d.L) + 2 * d.A) * sizeof(float2);

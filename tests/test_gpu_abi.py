@@ -154,17 +154,22 @@ def test_error_reporting():
     assert L.mpe_step(C.byref(desc), C.byref(b), 64, None) == -1 and b"pos" in L.mpe_last_error()
     b.pos, b.vel = env.world.pos.data_ptr(), env.world.vel.data_ptr()
     assert L.mpe_step(C.byref(desc), C.byref(b), 64, None) == -1 and b"act" in L.mpe_last_error()
-    # a tag shape no kernel was built for: the C ABI says so (mpe_step_supported 0, mpe_step MPE_EUNSUPPORTED) and the
-    # env keeps the scenario's torch callbacks around mpe_world_step instead
-    envt = make_env("simple_tag", batch_size=8, num_adversaries=5, num_good_agents=2, num_landmarks=1)
-    assert not envt.fused and len(envt.reset()) == 7
-    dt = envt.world.scenario_desc(_abi.MPE_SCN_TAG, 5)
-    assert L.mpe_step_supported(C.byref(dt)) == 0
-    obs = torch.zeros(8 * int(dt.obs_off[7]), device="cuda")
-    act = torch.zeros((7, 8, 5), device="cuda")
+    # a shape no kernel was built for (simple_adversary away from the reference's team sizes): the C ABI says so
+    # (mpe_step_supported 0, mpe_step MPE_EUNSUPPORTED) and the env keeps the scenario's torch callbacks around
+    # mpe_world_step instead
+    enva = make_env("simple_adversary", batch_size=8, num_agents=5, num_adversaries=2)
+    assert not enva.fused and len(enva.reset()) == 5
+    da = enva.world.scenario_desc(_abi.MPE_SCN_ADVERSARY, 2)
+    assert L.mpe_step_supported(C.byref(da)) == 0
+    obs = torch.zeros(8 * int(da.obs_off[5]), device="cuda")
+    act = torch.zeros((5, 8, 5), device="cuda")
     b2 = _abi.MpeBuffers()
-    b2.pos, b2.vel, b2.obs, b2.act = envt.world.pos.data_ptr(), envt.world.vel.data_ptr(), obs.data_ptr(), act.data_ptr()
-    assert L.mpe_step(C.byref(dt), C.byref(b2), 8, None) == -2 and b"no kernel" in L.mpe_last_error()
+    b2.pos, b2.vel, b2.obs, b2.act = enva.world.pos.data_ptr(), enva.world.vel.data_ptr(), obs.data_ptr(), act.data_ptr()
+    b2.choice = enva.world.choice_i32.data_ptr()
+    assert L.mpe_step(C.byref(da), C.byref(b2), 8, None) == -2 and b"no kernel" in L.mpe_last_error()
+    # simple_tag is fused at ANY team sizes (wave-per-world kernel)
+    envt = make_env("simple_tag", batch_size=8, num_adversaries=5, num_good_agents=2, num_landmarks=1)
+    assert envt.fused and L.mpe_step_supported(C.byref(envt.world.scenario_desc(_abi.MPE_SCN_TAG, 5))) == 1
 
 
 def test_a_c_program_steps_the_reference_kat_on_the_gpu(tmp_path):

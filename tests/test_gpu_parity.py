@@ -581,3 +581,95 @@ def test_force_discrete_and_continuous_action_modes_against_reference_golden(fus
         close(vel, g["vel"][t], what="continuous vel t=%d" % t)
         for i in range(A):
             close(np_(obs_n[i]), g["obs%d" % i][t], what="continuous obs%d" % i)
+
+
+@pytest.mark.parametrize("teams,B", [((5, 2, 1), 2048), ((2, 2, 3), 1000), ((40, 30, 20), 64), ((70, 10, 5), 33),
+                                     ((1, 6, 1), 500)])
+def test_simple_tag_any_team_sizes_fused_against_oracle(teams, B):
+    """simple_tag.py:84-147 are N-generic; only make_world hard-codes 3 / 1 / 2.  Every other split runs the
+    wave-per-world kernel's tag stage (ragged rows, team rewards, benchmark counts): per-element bar vs the oracle."""
+    nadv, ngood, nl = teams
+    spec = ospec.simple_tag(nadv, ngood, nl)
+    env = mpe.make_env("simple_tag", benchmark=True, batch_size=B, num_adversaries=nadv, num_good_agents=ngood,
+                       num_landmarks=nl)
+    assert env.fused
+    A = spec.n_agents
+    rs = np.random.RandomState(nadv * 100 + ngood)
+    pos = rs.uniform(-1.1, 1.1, (B, spec.n_entities, 2))      # some prey beyond the +-0.9 / +-1 boundary penalties
+    pos[::3] *= 0.35
+    vel = rs.uniform(-1.2, 1.2, (B, A, 2))
+    p32, v32 = pos.astype(np.float32), vel.astype(np.float32)
+    o64 = BatchedOracle(spec, B, benchmark=True)
+    o64.set_state(p32, v32)
+    env.world.set_state(p32, v32)
+    for t in range(2):
+        act = np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=(A, B))]
+        st_p, st_v = o64.pos.copy(), o64.vel.copy()
+        env.world.set_state(st_p.astype(np.float32), st_v.astype(np.float32))     # teacher-forced
+        o64.set_state(st_p.astype(np.float32), st_v.astype(np.float32))
+        obs64, rew64, _, info64 = o64.step(act)
+        obs_n, rew_n, done_n, info = env.step(torch.as_tensor(act).cuda())
+        gp, gv = env.world.get_state()
+        close(gp, o64.pos, what="pos")
+        close(gv, o64.vel, what="vel")
+        ok = guard_ok(spec, o64.pos)
+        for i in range(A):
+            assert obs_n[i].shape == (B, obs64[i].shape[1])
+            close(np_(obs_n[i]), obs64[i], what="obs%d" % i)
+            close(np_(rew_n[i])[ok], rew64[i][ok], what="rew%d" % i)
+            assert not np_(done_n[i]).any()
+        got = np.stack([np_(x) for x in info["n"]], axis=1)          # [B, A] benchmark_data collision counts
+        assert np.array_equal(got[ok], info64["collisions"].T[ok])
+
+
+def test_simple_tag_fused_equals_generic_at_65536_worlds():
+    """The wave-per-world tag stage against the scenario's own torch callbacks (generic path: same physics kernel)."""
+    B, kw = 65536, dict(num_adversaries=5, num_good_agents=2, num_landmarks=1)
+    ef = mpe.make_env("simple_tag", batch_size=B, seed=3, **kw)
+    eg = mpe.make_env("simple_tag", batch_size=B, seed=3, fused=False, **kw)
+    assert ef.fused and not eg.fused
+    eg.world.pos.copy_(ef.world.pos)
+    eg.world.vel.copy_(ef.world.vel)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for t in range(3):
+        act = torch.nn.functional.one_hot(torch.randint(0, 5, (7, B), device="cuda", generator=g), 5).float()
+        of, rf, _, _ = ef.step(act)
+        og, rg, _, _ = eg.step([act[i] for i in range(7)])
+        assert torch.equal(ef.world.pos, eg.world.pos) and torch.equal(ef.world.vel, eg.world.vel)
+        for i in range(7):
+            close(np_(of[i]), np_(og[i]), what="obs%d" % i)
+            close(np_(rf[i]), np_(rg[i]), what="rew%d" % i)
+
+
+def test_two_waves_per_world_kernel_is_bit_identical_to_the_wave_per_world_kernel():
+    """`mpe_step` on 33..64 identical agents runs k_duo (one workgroup of two waves per world); `mpe_world_step` followed
+    by `mpe_observe` runs k_wave's physics and output stages on the same state.  Same arithmetic, same order: equal bits.
+    B is not a multiple of the 256-world blocks of k_duo's XCD map; N = 40 has dead lanes, N = 64 none."""
+    import ctypes as C
+    from multiagent_particle_envs_amd import _abi
+    L_ = _abi.lib()
+    for N, B in ((64, 300), (40, 77), (33, 1000)):
+        rs = np.random.RandomState(N)
+        pos = rs.uniform(-1, 1, (B, 2 * N, 2)).astype(np.float32)
+        pos[::2] *= 0.5
+        vel = rs.uniform(-1, 1, (B, N, 2)).astype(np.float32)
+        act = torch.as_tensor(rs.uniform(-1, 1, (N, B, 5)).astype(np.float32)).cuda()
+        e1 = mpe.make_env("simple_spread", benchmark=True, batch_size=B, num_agents=N)
+        e2 = mpe.make_env("simple_spread", benchmark=True, batch_size=B, num_agents=N)
+        for e in (e1, e2):
+            e.world.set_state(pos, vel)
+            e._ensure_buffers()
+        o1, r1, _, i1 = e1.step(act)
+        out = e2._sets[0]
+        b = out.bufs
+        b.act, b.ids, b.u = act.data_ptr(), None, None
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _abi.check(L_.mpe_world_step(C.byref(e2._desc), C.byref(b), B, st), "mpe_world_step")
+        b.act = None
+        _abi.check(L_.mpe_observe(C.byref(e2._desc), C.byref(b), B, st), "mpe_observe")
+        assert torch.equal(e1.world.pos, e2.world.pos) and torch.equal(e1.world.vel, e2.world.vel)
+        for i in range(N):
+            assert torch.equal(o1[i], out.obs_n[i]), (N, i)
+            assert torch.equal(r1[i], out.reward_n[i]), (N, i)
+        for k in ("rew", "collisions", "min_dists", "occupied_landmarks"):
+            assert torch.equal(e1._sets[e1._flip].info[k], out.info[k]), k

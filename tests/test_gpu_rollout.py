@@ -59,7 +59,10 @@ def test_split_and_thread_kernels_bit_identical(name, kw, B):
                                             ("simple_spread", {"num_agents": 20, "num_landmarks": 12}, 70, 7, 3),
                                             ("simple_spread", {"num_agents": 64}, 37, 6, 5),
                                             ("simple_spread", {"num_agents": 100}, 9, 5, 2),             # > one wave of agents
-                                            ("simple_spread", {"num_agents": 3, "num_landmarks": 90}, 21, 5, 3)])
+                                            ("simple_spread", {"num_agents": 3, "num_landmarks": 90}, 21, 5, 3),
+                                            # simple_tag at team sizes the reference does not ship: wave-per-world kernel
+                                            ("simple_tag", {"num_adversaries": 5, "num_good_agents": 2, "num_landmarks": 1}, 100, 9, 4),
+                                            ("simple_tag", {"num_adversaries": 40, "num_good_agents": 30, "num_landmarks": 20}, 10, 5, 2)])
 def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):
     seed, offset, step0 = 0xABCDEF0123, 4096, 50 if ep in (25, 0) else 14
     # --- stepwise: explicit reset / random_actions / step through the C ABI ----------------------

@@ -173,9 +173,11 @@ def test_fused_kernels_cover_the_reference_shapes_and_other_shapes_fall_back():
         assert env_of(name).fused, name
     for n in (2, 6, 7, 16, 33, 64, 100, 256):
         assert env_of("simple_spread", num_agents=n).fused, n
-    big = env_of("simple_tag", num_adversaries=40, num_good_agents=30, num_landmarks=20)
-    assert not big.fused and big.observation_space[0].shape == (4 + 40 + 138 + 60,)
-    assert not env_of("simple_tag", num_adversaries=2).fused
+    big = env_of("simple_tag", num_adversaries=40, num_good_agents=30, num_landmarks=20)   # any team sizes: wave-per-world kernel
+    assert big.fused and big.observation_space[0].shape == (4 + 40 + 138 + 60,)
+    assert big.observation_space[69].shape == (4 + 40 + 138 + 58,)
+    assert env_of("simple_tag", num_adversaries=2).fused
+    assert not env_of("simple_adversary", num_agents=5, num_adversaries=2).fused        # reference team sizes only
     d = big.world.scenario_desc(_abi.MPE_SCN_GENERIC)
     assert _abi.lib().mpe_step_supported(C.byref(d)) == 0
     d = _abi.MpeScenarioDesc()
