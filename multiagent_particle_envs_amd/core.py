@@ -83,8 +83,22 @@ class Action(object):
         self.c = None
 
 
+# attributes the kernels' descriptor snapshots (MpeScenarioDesc): assigning any of them on a bound entity / world
+# marks the snapshot stale, and the next step re-reads them -- the reference reads them live on every step
+_ENTITY_CONSTANTS = frozenset(["size", "movable", "collide", "max_speed", "accel", "initial_mass", "u_noise", "c_noise",
+                               "silent"])
+_WORLD_CONSTANTS = frozenset(["dt", "damping", "contact_force", "contact_margin", "collaborative", "dim_c"])
+
+
 class Entity(object):
     """Per-entity constants, identical across the B worlds (reference: core.py:27-51)."""
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        if name in _ENTITY_CONSTANTS:
+            w = getattr(self.__dict__.get("state"), "_world", None)
+            if w is not None:
+                w._constants_version += 1
 
     def __init__(self):
         self.name = ''
@@ -169,7 +183,16 @@ class EntityChoice(object):
 class World(object):
     """B particle worlds stepped in lock-step (reference: core.py:82-196 for one world)."""
 
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        if name in _WORLD_CONSTANTS and "_constants_version" in self.__dict__:
+            self.__dict__["_constants_version"] += 1
+            self.__dict__["_desc"] = None
+            self.__dict__["_entity_table"] = None
+
     def __init__(self, batch_size=1, device=None):
+        self._constants_version = 0   # bumped by every assignment to a constant the kernel descriptor snapshots
+        self._desc_version = -1
         self.agents = []
         self.landmarks = []
         self.dim_c = 0
@@ -349,6 +372,10 @@ class World(object):
         objects exactly where the reference reads them (size/movable/collide/accel/max_speed/mass,
         core.py:27-51; accel -> sensitivity default 5.0, environment.py:178-181)."""
         key = (kind, n_adversaries)
+        if self._desc_version != self._constants_version:   # an entity / world constant was assigned since the snapshot
+            self._desc = None
+            self._entity_table = None
+            self._desc_version = self._constants_version
         if self._desc is None:
             self._desc = {}
         if key in self._desc:
@@ -396,6 +423,23 @@ class World(object):
             raise _abi.MpeError("the step path runs on a HIP device only (world tensors are on %s); "
                                 "there is no CPU fallback" % self.pos.device)
 
+    def _randn(self, shape):
+        """Standard-normal noise for u_noise / c_noise (core.py:138,176).  rng_mode 'numpy' (reference-compatibility):
+        drawn from the process-global np.random in the reference's order (agents in order: the u draws before the
+        physics, the c draws after), so `np.random.seed(s)` reproduces the reference's noisy trajectories and leaves
+        the stream where the reference leaves it for the next reset.  rng_mode 'device': a torch generator keyed by
+        (world.seed, world.world_offset) -- reproducible per shard, independent of torch's global generator."""
+        if self.rng_mode == "numpy":
+            import numpy as np
+            return torch.as_tensor(np.random.randn(*shape), dtype=torch.float32).to(self.device)
+        g = self.__dict__.get("_noise_gen")
+        key = (int(self.seed), int(self.world_offset), str(self.device))
+        if g is None or self.__dict__.get("_noise_key") != key:
+            g = torch.Generator(device=self.device)
+            g.manual_seed((int(self.seed) * 0x9E3779B97F4A7C15 + int(self.world_offset) + 0x5EED) & (2 ** 63 - 1))
+            self.__dict__["_noise_gen"], self.__dict__["_noise_key"] = g, key
+        return torch.randn(tuple(shape), generator=g, dtype=torch.float32, device=self.device)
+
     # ---- World.step (core.py:117-131) -----------------------------------------------------------
     def step(self):
         """Advance all B worlds using each agent's `action.u` ([B,2] tensors), physics only:
@@ -409,8 +453,8 @@ class World(object):
         for i, agent in enumerate(self.agents):
             if agent.movable and agent.action.u is not None:
                 u = self._as_batch(agent.action.u, 2)
-                if agent.u_noise:
-                    u = u + torch.randn_like(u) * agent.u_noise
+                if agent.u_noise:   # core.py:138: np.random.randn(*agent.action.u.shape) * agent.u_noise
+                    u = u + self._randn(u.shape) * agent.u_noise
                 self._u[i].t().copy_(u)
             else:
                 self._u[i].zero_()
@@ -424,6 +468,6 @@ class World(object):
                 agent.state.c = torch.zeros((B, self.dim_c), dtype=torch.float32, device=self.device)
             else:
                 c = agent.action.c
-                if c is not None and agent.c_noise:
-                    c = c + torch.randn_like(c) * agent.c_noise
+                if c is not None and agent.c_noise:   # core.py:176
+                    c = c + self._randn(c.shape) * agent.c_noise
                 agent.state.c = c

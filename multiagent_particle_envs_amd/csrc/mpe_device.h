@@ -327,6 +327,16 @@ __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict_
       if ((it + 1) * kWave <= NQ || q < NQ)
         *reinterpret_cast<float4 *>(g + 4 * q) = *reinterpret_cast<const float4 *>(tile + 4 * qs);
     }
+  } else if (S == D && vec4 && ((nvalid * D) & 3) == 0) {
+    // a narrower workgroup (32 / 16 worlds) or an even ragged tail: the same copies, bounded by the rows present
+    const int nq = (nvalid * D) >> 2;
+#pragma unroll
+    for (int it = 0; it < (NQ + kWave - 1) / kWave; ++it) {
+      const int q = lane + kWave * it;
+      if (kWave * it >= nq) break;   // uniform
+      const int qs = NSW ? (q ^ swz4<NSW>(q / (NSW ? NSW : 1))) : q;
+      if (q < nq) *reinterpret_cast<float4 *>(g + 4 * q) = *reinterpret_cast<const float4 *>(tile + 4 * qs);
+    }
   } else {
 #pragma unroll
   for (int it = 0; it < (NQ + kWave - 1) / kWave; ++it) {

@@ -45,6 +45,7 @@ struct RollArgs {
   int32_t episode_len;  // in-kernel reset every episode_len global steps; 0 = never
   int32_t trajectory;   // outputs of step t go to block t of the output buffers (else: overwrite block 0)
   int32_t observe_only; // single-step kernel: skip World.step, emit the outputs of the current state (mpe_observe)
+  int32_t wpw;          // worlds per workgroup of the wave-per-agent kernels (set by launch_split)
   float landmark_range;
   uint64_t seed, step0, world_offset;
 };

@@ -347,7 +347,10 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // uniform: agent index, or A = reward
   const bool is_agent = role < A;
   const int i = is_agent ? role : 0;
-  const size_t w0 = (size_t)blockIdx.x * kWave;
+  // worlds of this workgroup: ra.wpw (64, 32 or 16) consecutive ones, lane = world; with fewer than 64 the upper
+  // lanes idle, which buys more workgroups -- more waves per SIMD to hide latency -- when the batch is small
+  const int wpw = ra.wpw;
+  const size_t w0 = (size_t)blockIdx.x * (size_t)wpw;
   if (w0 >= B) return;  // workgroup-uniform
 #ifdef MPE_STRESS_DELAY_WAVE
   // test build only (libmpe_hip_stress.so, tests/test_gpu_race.py): hold one agent wave back for ~30 us before
@@ -356,7 +359,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   if (role == (MPE_STRESS_DELAY_WAVE) % A)
     for (int k = 0; k < 10; ++k) __builtin_amdgcn_s_sleep(127);   // 10 x 8128 clocks
 #endif
-  const int nvalid = (B - w0) < (size_t)kWave ? (int)(B - w0) : kWave;
+  const int nvalid = (B - w0) < (size_t)wpw ? (int)(B - w0) : wpw;
   const bool live = lane < nvalid;
   // dead lanes of a ragged last wave shadow its last live world (their stores are masked).  Every
   // global address below is "wave-uniform base (SGPRs) + ln": scalar-base addressing, no per-lane
@@ -743,6 +746,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 }
 
 // ---- dispatch -----------------------------------------------------------------------------------
+
 using SplitFn = void (*)(const NarrowDesc, const MpeBuffers, const size_t, const RollArgs);
 struct SplitEntry {
   int kind, A, L, nadv;
@@ -777,9 +781,17 @@ int launch_split(bool roll, int kind, int A, int L, int nadv, const NarrowDesc &
                  const RollArgs &ra, hipStream_t stream) {
   const SplitEntry *e = find_split(kind, A, L, nadv);
   if (!e) return MPE_EUNSUPPORTED;
-  const unsigned grid = (unsigned)((B + kWave - 1) / kWave);
+  // worlds per workgroup: full waves.  Narrower workgroups (more of them, idle upper lanes) were tried for the
+  // small-batch configs, hoping for more waves per SIMD to hide latency: they lose --
+  RollArgs r2 = ra;
+#ifdef MPE_SPLIT_WPW
+  r2.wpw = MPE_SPLIT_WPW;
+#else
+  r2.wpw = kWave;   // measured (tools/ab_run.sh, MPE_SPLIT_WPW builds): 64 wins at every batch -- tag B=16384 4.1 / 4.5 / 5.7 us at 64 / 32 / 16
+#endif
+  const unsigned grid = (unsigned)((B + r2.wpw - 1) / r2.wpw);
   hipLaunchKernelGGL(roll ? e->roll : e->step, dim3(grid), dim3((A + 1) * kWave), roll ? e->lds_roll : e->lds_step, stream,
-                     d, b, B, ra);
+                     d, b, B, r2);
   return (int)hipGetLastError();
 }
 

@@ -40,6 +40,17 @@
 #ifndef MPE_DUO_ENABLE
 #define MPE_DUO_ENABLE 1
 #endif
+#ifndef MPE_DUO_G
+#define MPE_DUO_G 4   // worlds per workgroup of k_duo (1, 2, 4 or 8)
+#endif
+// ablation builds (tools/ab_build.sh): bit 0 skip the reward, bit 1 skip the contact loop, bit 2 skip the row stores
+#ifndef MPE_DUO_ABLATE
+#define MPE_DUO_ABLATE 0
+#endif
+// row-store flavour: 0 plain, 1 nontemporal (nt), 2 write-through (sc1)
+#ifndef MPE_ROW_STORE
+#define MPE_ROW_STORE 0
+#endif
 
 namespace mpe {
 
@@ -100,6 +111,20 @@ __host__ __device__ inline Carve carve(int A, int L) {
   c.cpw = o; o += align16(sizeof(float2) * E);         // positions of the collidable entities, by rank (the contact partner list)
   c.wave_bytes = o;
   return c;
+}
+
+__device__ __forceinline__ void row_store4(float *p, float4 o) {
+#if MPE_ROW_STORE == 1
+  typedef float vf4 __attribute__((ext_vector_type(4)));
+  vf4 t = {o.x, o.y, o.z, o.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<vf4 *>(p));
+#elif MPE_ROW_STORE == 2
+  typedef float vf4 __attribute__((ext_vector_type(4)));
+  vf4 t = {o.x, o.y, o.z, o.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+#else
+  *reinterpret_cast<float4 *>(p) = o;
+#endif
 }
 
 // One world's observation rows (simple_spread.py:84-100), row by row:
@@ -209,7 +234,7 @@ __device__ __forceinline__ void emit_rows_fast(const float2 *Q, const float2 *V,
         if (!live[0][1]) { o.z = 0.f; o.w = 0.f; }
       }
       if (lane == 0) o = make_float4(vel.x, vel.y, me.x, me.y);  // the row's header
-      if (st0) *reinterpret_cast<float4 *>(row + (unsigned)(4 * lane)) = o;
+      if (st0) row_store4(row + (unsigned)(4 * lane), o);
     }
     if (two) {
       float4 o;
@@ -219,7 +244,7 @@ __device__ __forceinline__ void emit_rows_fast(const float2 *Q, const float2 *V,
       o.z = s1.x - me.x; o.w = s1.y - me.y;
       if (!live[1][0]) { o.x = 0.f; o.y = 0.f; }
       if (!live[1][1]) { o.z = 0.f; o.w = 0.f; }
-      if (st1) *reinterpret_cast<float4 *>(row + (unsigned)(4 * (lane + kWave))) = o;
+      if (st1) row_store4(row + (unsigned)(4 * (lane + kWave)), o);
     }
     me = me_n;
     vel = vel_n;
@@ -642,98 +667,164 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
   }
 }
 
-// ---- two waves per world: the headline large-N shape (simple_spread, 32 < N <= 64, identical agents) ----------
-// k_wave gives a world to ONE wave, so at B = 4096 every wave runs load -> contacts -> 128 row stores -> reward
-// once, all of them in step: ~8 us in which no store is in flight, then the 403 MB of rows at the store rate,
-// then the reward (~1600 VALU per wave) of the last waves exposed at the end -- 88 us where a plain fill of the
-// same bytes takes 60.  Here a workgroup is one world and two waves with different ROLES:
-//   wave 0   loads the world, runs World.step (lane = agent), publishes the new state in LDS, stores it,
-//            and after the workgroup's one barrier emits observation rows [0, split);
-//   wave 1   sleeps at the barrier (no VALU, no LDS), then computes the reward / benchmark_data of the world
-//            and emits rows [split, A).
-// The reward's arithmetic therefore runs on other waves than half of the row stores and overlaps them; twice as
-// many waves are in flight, and workgroups of later worlds start their load / contact phase while earlier ones
-// stream rows, so the memory pipe sees stores from ~3 us on.  Scenario constants are kernel arguments (the
-// agents are identical, landmarks do not collide): no constant table, no staging pass, no second barrier.
-// Per-pair arithmetic, accumulation order (action first, partners ascending: Q9) and the reward's reduction
-// trees are k_wave's: results are bit-identical to it (tests/test_gpu_parity.py).
-constexpr int kDuoSplitNum = MPE_DUO_SPLIT_NUM, kDuoSplitDen = MPE_DUO_SPLIT_DEN;   // wave 0 emits rows [0, A * num / den)
+// ---- two waves per world, G worlds per workgroup: the headline large-N shape (simple_spread, 32 < N <= 64) ------
+// What k_wave costs at B = 4096, N = 64 (88 us; ablations in DESIGN.md 6): the rows stream at the HBM write rate
+// (60-73 us), but before them every world pays ~13 us of STATE I/O that nothing overlaps -- with a wave per world,
+// lane = agent, every 4-byte state / action access of a wave touches 64 different 128-byte lines (the SoA layout is
+// batch-innermost), ~1000 L2 requests per world, 4.2 M per launch: more requests than the 403 MB of rows.  And the
+// reward (~1600 VALU per wave) of the last waves is exposed at the end.  Here
+//   * a workgroup owns G consecutive worlds and stages their state COOPERATIVELY: thread -> (row, world), so the G
+//     worlds of a row are G*4 contiguous bytes of one line -- ~5x fewer L2 requests at G = 4; the new state leaves
+//     the same way (staged in LDS, stored by rows);
+//   * each world has two waves with different ROLES: wave 2g runs World.step (lane = agent) and, after the
+//     workgroup's second barrier, emits observation rows [0, split); wave 2g+1 stores the new state, computes the
+//     reward / benchmark_data and emits rows [split, A) -- the reward's arithmetic overlaps other waves' row stores.
+// Scenario constants are kernel arguments (identical agents, landmarks do not collide): no constant table.  Per-pair
+// arithmetic, accumulation order (action first, partners ascending: Q9) and the reward's reduction trees are
+// k_wave's: results are bit-identical to it (tests/test_gpu_parity.py).
+constexpr int kDuoSplitNum = MPE_DUO_SPLIT_NUM, kDuoSplitDen = MPE_DUO_SPLIT_DEN;   // wave 2g emits rows [0, A * num / den)
 
-__global__ void __launch_bounds__(2 * kWave)
+struct DuoCarve { size_t q, v, u, araw, slot_bytes; };
+__host__ __device__ inline DuoCarve duo_carve(int A, int L) {
+  DuoCarve c;
+  size_t o = 0;
+  c.q = o;    o += align16(sizeof(float2) * (A + L));   // positions, observation order [landmarks | agents]
+  c.v = o;    o += align16(sizeof(float2) * A);
+  c.u = o;    o += align16(sizeof(float2) * A);         // decoded action force
+  c.araw = o; o += align16(sizeof(float) * MPE_ACTION_DIM * A);   // the world's raw action rows [A][5]
+  c.slot_bytes = o;
+  return c;
+}
+
+template <int G>
+__global__ void __launch_bounds__(2 * G * kWave)
 k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = 2 * G * kWave;
   const int A = d.A, L = d.L, E = A + L, D = d.D;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  float2 *const Q = reinterpret_cast<float2 *>(smem);                       // [landmarks | agents]: observation order
-  float2 *const V = reinterpret_cast<float2 *>(smem + align16(sizeof(float2) * E));
-  // world of this workgroup: XCD = blockIdx % 8 (hardware round-robin); 32 consecutive slots of one XCD own 32
-  // consecutive worlds = one 128-byte line of every state row, fetched into ONE L2
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 1, role = wave & 1;
+  const DuoCarve cv = duo_carve(A, L);
+  auto Qs = [&](int sl) { return reinterpret_cast<float2 *>(smem + (size_t)sl * cv.slot_bytes + cv.q); };
+  auto Vs = [&](int sl) { return reinterpret_cast<float2 *>(smem + (size_t)sl * cv.slot_bytes + cv.v); };
+  auto Us = [&](int sl) { return reinterpret_cast<float2 *>(smem + (size_t)sl * cv.slot_bytes + cv.u); };
+  auto Rs = [&](int sl) { return reinterpret_cast<float *>(smem + (size_t)sl * cv.slot_bytes + cv.araw); };
+  // worlds of this workgroup: G consecutive ones; XCD = blockIdx % 8 (hardware round-robin), and the 32 / G groups
+  // that share a 128-byte line of every state row (32 consecutive worlds) sit on ONE XCD
+  constexpr unsigned GPL = 32 / G;
   const unsigned x = blockIdx.x, xcd = x & 7u, slot = x >> 3;
-  const size_t w = (size_t)(((slot >> 5) << 8) | (xcd << 5) | (slot & 31u));
-  if (w >= B) return;   // workgroup-uniform
-  const int split = (A * kDuoSplitNum) / kDuoSplitDen;
+  const size_t w0 = (size_t)(((slot / GPL) * 8u + xcd) * GPL + (slot % GPL)) * G;
+  if (w0 >= B) return;   // workgroup-uniform
+  const int nvalid = (B - w0) < (size_t)G ? (int)(B - w0) : G;
   const bool movable = d.a_flags & kMovable, collide = d.a_flags & kCollide;
 
-  if (wave == 0) {
-    // ---- stage + World.step (core.py:117-169) --------------------------------------------------------------
+  // ---- cooperative stage: thread -> (row, world slot); the slots of a row are adjacent lanes and adjacent bytes ----
+  {
+    const int gg = tid % G, r0 = tid / G;
+    if (gg < nvalid) {
+      const size_t wg = w0 + gg;
+      float *const Qf = reinterpret_cast<float *>(Qs(gg));
+      for (int r = r0; r < 2 * E; r += NT / G) {
+        const int e = r >> 1;
+        Qf[2 * (e < A ? L + e : e - A) + (r & 1)] = b.pos[(size_t)r * B + wg];
+      }
+      float *const Vf = reinterpret_cast<float *>(Vs(gg));
+      for (int r = r0; r < 2 * A; r += NT / G) Vf[r] = b.vel[(size_t)r * B + wg];
+      if (b.ids) {
+        for (int i = r0; i < A; i += NT / G) {
+          float ux, uy;
+          decode_id(b.ids[(size_t)i * B + wg], d.a_accel, ux, uy);
+          Us(gg)[i] = make_float2(ux + 0.f, uy + 0.f);
+        }
+      } else if (b.u) {
+        float *const Uf = reinterpret_cast<float *>(Us(gg));
+        for (int r = r0; r < 2 * A; r += NT / G) Uf[r] = b.u[(size_t)r * B + wg] + 0.f;
+      }
+    }
+    if (b.act) {   // agent i's rows of the G worlds are 5 G contiguous floats of act [A][B][5]
+      constexpr int RW = MPE_ACTION_DIM * G;
+      for (int t = tid; t < A * RW; t += NT) {
+        const int i = t / RW, k = t - i * RW, sl = k / MPE_ACTION_DIM, c = k - sl * MPE_ACTION_DIM;
+        if (sl < nvalid) Rs(sl)[i * MPE_ACTION_DIM + c] = b.act[((size_t)i * B + w0) * MPE_ACTION_DIM + k];
+      }
+    }
+  }
+  __syncthreads();
+
+  const bool wok = g < nvalid;
+  const size_t w = w0 + (wok ? g : 0);
+  float2 *const Q = Qs(g), *const V = Vs(g);
+  const int split = (A * kDuoSplitNum) / kDuoSplitDen;
+
+  if (role == 0 && wok && movable) {
+    // ---- World.step (core.py:117-169), lane = agent ------------------------------------------------------------
     const bool have = lane < A;
     const int i = have ? lane : 0;
-    float2 me = make_float2(b.pos[(size_t)(2 * i) * B + w], b.pos[(size_t)(2 * i + 1) * B + w]);
-    float2 v = make_float2(b.vel[(size_t)(2 * i) * B + w], b.vel[(size_t)(2 * i + 1) * B + w]);
+    float2 me = Q[L + i], v = V[i];
     float ux, uy;
-    fetch_action(b, B, i, w, d.a_accel, ux, uy);
-    if (lane < L) {
-      const int e = A + lane;
-      Q[lane] = make_float2(b.pos[(size_t)(2 * e) * B + w], b.pos[(size_t)(2 * e + 1) * B + w]);
+    if (b.act) {
+      decode_row(Rs(g) + i * MPE_ACTION_DIM, d.a_accel, ux, uy);
+      ux = ux + 0.f;
+      uy = uy + 0.f;
+    } else {
+      const float2 u = Us(g)[i];
+      ux = u.x;
+      uy = u.y;
     }
-    if (have) Q[L + i] = me;
-    wave_sync();
-    if (movable) {
-      float ax = ux + 0.f, ay = uy + 0.f;   // action force first, then the partners in ascending order (Q9)
-      if (collide) {
-        const float ri = d.a_size, rfar = ri + kFarX * d.cmargin, reach = rfar + ri;
-        const float2 *const CPW = Q + L;
-        for (int kb = 0; kb < A; kb += 32) {
-          const int n = min(A - kb, 32);
-          unsigned near = near_mask32<true>(CPW, nullptr, kb, n, me, rfar, reach * reach);
-          if (i >= kb && i < kb + 32) near &= ~(0x80000000u >> (i - kb));   // not against itself
-          if (!have) near = 0u;
-          while (near) {   // pass 2: the partners within reach only, ascending
-            const int j = __clz((int)near);
-            near &= ~(0x80000000u >> j);
-            const float2 pj = CPW[kb + j];
-            float gx, gy;
-            contact_force(me.x - pj.x, me.y - pj.y, ri + ri, d.cforce, d.cmargin, d.cmargin_inv, gx, gy);
-            ax = gx + ax;
-            ay = gy + ay;
-          }
+    float ax = ux, ay = uy;   // action force first, then the partners in ascending order (Q9)
+    if (collide && !(MPE_DUO_ABLATE & 2)) {
+      const float ri = d.a_size, rfar = ri + kFarX * d.cmargin, reach = rfar + ri;
+      const float2 *const CPW = Q + L;
+      for (int kb = 0; kb < A; kb += 32) {
+        const int n = min(A - kb, 32);
+        unsigned near = near_mask32<true>(CPW, nullptr, kb, n, me, rfar, reach * reach);
+        if (i >= kb && i < kb + 32) near &= ~(0x80000000u >> (i - kb));   // not against itself
+        if (!have) near = 0u;
+        while (near) {   // pass 2: the partners within reach only, ascending
+          const int j = __clz((int)near);
+          near &= ~(0x80000000u >> j);
+          const float2 pj = CPW[kb + j];
+          float gx, gy;
+          contact_force(me.x - pj.x, me.y - pj.y, ri + ri, d.cforce, d.cmargin, d.cmargin_inv, gx, gy);
+          ax = gx + ax;
+          ay = gy + ay;
         }
       }
-      integrate_one(me.x, me.y, v.x, v.y, ax, ay, d.a_inv_mass, d.a_max_speed, d.damp, d.dt);
     }
+    integrate_one(me.x, me.y, v.x, v.y, ax, ay, d.a_inv_mass, d.a_max_speed, d.damp, d.dt);
     wave_sync();   // every lane has read the old positions
     if (have) {
       Q[L + i] = me;
       V[i] = v;
     }
-    __syncthreads();
-    if (have && movable) {   // behind the barrier, like k_split: nothing reads the old state from HBM after it
-      b.pos[(size_t)(2 * i) * B + w] = me.x;
-      b.pos[(size_t)(2 * i + 1) * B + w] = me.y;
-      b.vel[(size_t)(2 * i) * B + w] = v.x;
-      b.vel[(size_t)(2 * i + 1) * B + w] = v.y;
-    }
-    emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
+  }
+  __syncthreads();
+
+  if (role == 0) {
+    if (wok && !(MPE_DUO_ABLATE & 4)) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
     return;
   }
 
-  // ---- wave 1: reward (simple_spread.py:72-82) + benchmark_data (:47-63), then the other rows ---------------
-  __syncthreads();
-  if (b.rew || b.info_rew) {
+  // ---- odd waves: the new state back to HBM by rows (thread -> (row, world slot)), reward, the other rows --------
+  if (movable) {
+    const int t1 = g * kWave + lane;   // 0 .. 64 G - 1 over the G odd waves
+    const int gg = t1 % G;
+    if (gg < nvalid) {
+      const float *const Qa = reinterpret_cast<const float *>(Qs(gg) + L);
+      const float *const Vf = reinterpret_cast<const float *>(Vs(gg));
+      for (int r = t1 / G; r < 2 * A; r += kWave) {
+        b.pos[(size_t)r * B + w0 + gg] = Qa[r];
+        b.vel[(size_t)r * B + w0 + gg] = Vf[r];
+      }
+    }
+  }
+  if (!wok) return;
+  if ((b.rew || b.info_rew) && !(MPE_DUO_ABLATE & 1)) {
+    // reward (simple_spread.py:72-82) + benchmark_data (:47-63): lane = landmark `lane` and agent `lane`
     const bool hl = lane < L, hi = lane < A;
-    const float2 pl = Q[hl ? lane : 0];          // landmark `lane`
-    const float2 pi = Q[L + (hi ? lane : 0)];    // agent `lane`
+    const float2 pl = Q[hl ? lane : 0];
+    const float2 pi = Q[L + (hi ? lane : 0)];
     const float m = d.a_size + d.a_size, mm = m * m, lo = mm * 0.9999996f, hi_ = mm * 1.0000004f;
     const bool has_band = mm > 1e-30f;
     float m2 = INFINITY;
@@ -778,7 +869,7 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   } else if (b.done && lane < A) {
     b.done[(size_t)lane * B + w] = 0;
   }
-  emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
+  if (!(MPE_DUO_ABLATE & 4)) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
 }
 
 // ---- several worlds per wave: the mid-size regime (7 <= A, L <= 32) ------------------------------------------
@@ -1089,10 +1180,11 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
   const int amax = d.A > d.L ? d.A : d.L;
   if (duo_eligible(d, b, B, phys, out, roll != nullptr)) {
     // two waves per world (k_duo): one workgroup per world, worlds padded to whole 256-world blocks of the XCD map
-    const size_t padded_w = (B + 255) / 256 * 256;
+    constexpr int G = MPE_DUO_G;
+    const size_t padded_w = (B + 255) / 256 * 256;   // whole 256-world blocks of the XCD map
     if (padded_w <= 0x7fffffffull) {
-      const size_t dlds = align16(sizeof(float2) * (d.A + d.L)) + align16(sizeof(float2) * d.A);
-      hipLaunchKernelGGL(k_duo, dim3((unsigned)padded_w), dim3(2 * kWave), dlds, stream, d, b, B);
+      const size_t dlds = (size_t)G * duo_carve(d.A, d.L).slot_bytes;
+      hipLaunchKernelGGL(k_duo<G>, dim3((unsigned)(padded_w / G)), dim3(2 * G * kWave), dlds, stream, d, b, B);
       return (int)hipGetLastError();
     }
   }

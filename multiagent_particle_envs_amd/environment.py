@@ -118,6 +118,8 @@ class MultiAgentEnv(object):
         self.numpy_io = bool(numpy_io)
         self.fresh_outputs = bool(fresh_outputs)
         self._step_impl = "split"
+        self._constants_seen = world._constants_version
+        self._scenario_state_stale = False   # set by device-side rollouts (RandomRollout): Scenario._apply pending
 
         # ---- can the whole step run as one fused kernel? ---------------------------------------------
         sc = getattr(observation_callback, "__self__", None)
@@ -200,6 +202,10 @@ class MultiAgentEnv(object):
         w = self.world
         w._desc = None
         w._entity_table = None
+        self._constants_seen = w._constants_version
+        if self.fused and any(a.u_noise or (a.c_noise and not a.silent) for a in w.agents):
+            self.fused = False          # the fused kernels draw no action / communication noise (core.py:138,176): generic path
+            self._comm_kind = False
         if self.fused:
             self._desc = w.scenario_desc(self._kind, getattr(self._scenario, "num_adversaries", 0))
             if self._sets is not None:
@@ -315,10 +321,28 @@ class MultiAgentEnv(object):
         return self._act
 
     # ------------------------------------------------------------------------------------------
+    def sync_from_device(self):
+        """Re-derive the scenario's Python-side per-world state (goal-dependent colours, `agent.goal_a` views, comm
+        state, keys ...) from the device tensors.  Device-side rollouts (`RandomRollout`, `mpe_rollout_random`) reset
+        worlds with `mpe_reset` / in-kernel resets without going through `Scenario.reset_world`; they flag the env and
+        this runs before the next `step()` / `reset()` / `benchmark_data` through the Python API."""
+        self._scenario_state_stale = False
+        sc, w = self._scenario if self._scenario is not None else getattr(self, "scenario", None), self.world
+        if sc is not None and hasattr(sc, "_apply"):
+            sc._apply(w)
+        for agent in w.agents:   # every reset_world leaves state.c = 0; the random rollouts never speak
+            agent.state.c = torch.zeros((self.batch_size, w.dim_c), dtype=torch.float32, device=w.device)
+        if self._comm is not None:
+            self._comm.zero_()
+
     def step(self, action_n):
         """environment.py:80-104 for B worlds."""
+        if self._scenario_state_stale:
+            self.sync_from_device()
         if len(self.agents) != len(self.world.agents):   # environment.py:85 re-reads world.policy_agents every step
             self.agents = self.world.policy_agents
+        if self._constants_seen != self.world._constants_version:   # an entity / world constant was assigned: re-snapshot
+            self.refresh_constants()
         if not self.fused or (self._comm_kind and self.discrete_action_input) or not self.discrete_action_space:
             return self._step_generic(action_n)      # (the kernels decode 5-wide move rows / integer ids only)
         self._ensure_buffers()
@@ -354,6 +378,15 @@ class MultiAgentEnv(object):
         _abi.check(_abi.lib().mpe_episode_tick(self.episode_step.data_ptr(), done.data_ptr(), done.shape[0],
                                                self.batch_size, self.max_episode_steps, 1 if self.auto_reset else 0,
                                                self._stream()), "mpe_episode_tick")
+        if self.done_callback is not None and self.auto_reset:
+            # a done_callback can end a world at ANY step: restart every world some agent (or the horizon) flagged,
+            # at every step, and restart its step counter too (the tick only clears it at the horizon)
+            finished = done.any(dim=0)
+            self.episode_step.masked_fill_(finished, 0)
+            self.reset_callback(w, mask=finished)
+            if self._comm is not None:
+                self._comm.masked_fill_(finished[None, :, None], 0.0)
+            return True
         if self._steps_taken not in self._may_finish:
             return False
         self._may_finish.discard(self._steps_taken)
@@ -392,6 +425,8 @@ class MultiAgentEnv(object):
     def reset(self, seeds=None, mask=None):
         """environment.py:106-116.  `seeds` (one per world) gives reference-exact initial states
         (`np.random.seed(s); env.reset()` per world, drawn on the host); `mask` resets a subset."""
+        if self._scenario_state_stale:
+            self.sync_from_device()
         world = self.world
         kw = {}
         if seeds is not None:

@@ -78,7 +78,17 @@ class RandomRollout(object):
             b.u = None
             _abi.check(L.mpe_step(C.byref(desc), C.byref(b), B, st), "mpe_step")
             self.t += 1
+        self._mark_stale()
         return env._sets[(self.t - 1) & 1]
+
+    def _mark_stale(self):
+        """Device-side resets bypass Scenario.reset_world: the env re-derives the scenario's Python-side per-world
+        state (MultiAgentEnv.sync_from_device) before its next step() / reset() through the Python API; the env's
+        per-world step counters follow the rollout's episode clock."""
+        env = self.env
+        env._scenario_state_stale = True
+        if env.episode_step is not None and self.episode_len:
+            env.episode_step.fill_(self.t % self.episode_len)
 
     def capture(self, steps):
         """Capture `steps` env steps into a HIP graph (torch.cuda.CUDAGraph); replay() re-runs them.
@@ -113,6 +123,7 @@ class RandomRollout(object):
                                               1 if trajectory is not None else 0, self._stream()),
                    "mpe_rollout_random")
         self.t += steps
+        self._mark_stale()
         return ret
 
 

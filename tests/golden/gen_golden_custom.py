@@ -98,6 +98,57 @@ def main_modes():
     print("mode_force_discrete.npz, mode_continuous.npz written")
 
 
+def main_noise():
+    """Agent.u_noise / Agent.c_noise (core.py:138, :176): Gaussian noise drawn from the process-global np.random inside
+    World.step -- the u draws (movable agents, in order) before the physics, the c draws (speaking agents) after.  Each
+    world: np.random.seed(s); env.reset(); T steps; the noise and the next reset come out of that one stream."""
+    import gen_golden_scenarios as S   # noqa: F401  (import path for the comm scenarios' action rows)
+    for name, setup in (("simple_spread", lambda env: [setattr(a, "u_noise", 0.3) for a in env.world.agents]),
+                        ("simple_reference", lambda env: [setattr(env.world.agents[0], "u_noise", 0.1)] +
+                                                         [setattr(a, "c_noise", 0.2) for a in env.world.agents])):
+        env = G.make_env(name)
+        setup(env)
+        W, T, A = 6, 6, env.n
+        E = len(env.world.entities)
+        rng = np.random.RandomState(31)
+        widths = [env.action_space[i].n if hasattr(env.action_space[i], "n") else
+                  int(sum(env.action_space[i].high - env.action_space[i].low + 1)) for i in range(A)]
+        out = {"seeds": np.arange(900, 900 + W), "pos0": np.zeros((W, E, 2)), "vel0": np.zeros((W, A, 2)),
+               "pos": np.zeros((T, W, E, 2)), "vel": np.zeros((T, W, A, 2)), "rew": np.zeros((T, W, A)),
+               "u_noise": np.array([a.u_noise or 0.0 for a in env.world.agents]),
+               "c_noise": np.array([a.c_noise or 0.0 for a in env.world.agents])}
+        for i in range(A):
+            out["act%d" % i] = np.zeros((T, W, widths[i]))
+            out["obs%d" % i] = np.zeros((T, W, env.observation_space[i].shape[0]))
+            out["c%d" % i] = np.zeros((T, W, env.world.dim_c))
+        for w in range(W):
+            np.random.seed(int(out["seeds"][w]))
+            env.reset()
+            out["pos0"][w], out["vel0"][w] = G.state_of(env)
+            for t in range(T):
+                acts = []
+                for i in range(A):
+                    a = np.zeros(widths[i])
+                    k = 0
+                    if env.world.agents[i].movable:
+                        a[rng.randint(0, 5)] = 1.0
+                        k = 5
+                    if not env.world.agents[i].silent:
+                        a[k + rng.randint(0, env.world.dim_c)] = 1.0
+                    acts.append(a)
+                    out["act%d" % i][t, w] = a
+                obs, rew, done, info = env.step([a.copy() for a in acts])
+                out["pos"][t, w], out["vel"][t, w] = G.state_of(env)
+                out["rew"][t, w] = rew
+                for i in range(A):
+                    out["obs%d" % i][t, w] = obs[i]
+                    out["c%d" % i][t, w] = env.world.agents[i].state.c
+        path = os.path.join(HERE, "noise_%s.npz" % name)
+        np.savez_compressed(path, **out)
+        print("%-28s %8.1f KiB" % (os.path.basename(path), os.path.getsize(path) / 1024.0))
+
+
 if __name__ == "__main__":
     import sys
-    main_modes() if "--modes" in sys.argv else main_f3() if "--f3" in sys.argv else main()
+    (main_noise() if "--noise" in sys.argv else main_modes() if "--modes" in sys.argv else
+     main_f3() if "--f3" in sys.argv else main())

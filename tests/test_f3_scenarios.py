@@ -668,3 +668,73 @@ def test_customised_constants_against_reference_golden(name, fused, golden):
             close(np_(obs_n[i]), g["obs%d" % i][t], what="t=%d obs%d" % (t, i))
             close((np_(rew_n[i]) * np.ones(W))[ok], g["rew"][t][:, i][ok], what="t=%d rew%d" % (t, i))
             close(np_(w.agents[i].state.c), g["c%d" % i][t], what="t=%d c%d" % (t, i))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["simple_spread", "simple_reference"])
+def test_action_and_comm_noise_follow_the_reference_numpy_stream(name, golden):
+    """Agent.u_noise / c_noise (core.py:138,176) are drawn from the process-global np.random inside World.step.  In
+    reference-compatibility mode `np.random.seed(s); env.reset(); env.step(...)` must reproduce the reference's noisy
+    trajectory (tests/golden/noise_*.npz, recorded from the reference) -- and leave the stream where the reference
+    leaves it: every world's reset below comes out of the same stream the previous episode's noise came from."""
+    g = golden("noise_" + name)
+    env = mpe.make_env(name)
+    assert env.fused
+    for a, un, cn in zip(env.world.agents, g["u_noise"], g["c_noise"]):   # set after make_env, as a reference user would
+        a.u_noise = float(un) if un else None
+        a.c_noise = float(cn) if cn else None
+    T, W, A = g["rew"].shape
+    for w in range(W):
+        np.random.seed(int(g["seeds"][w]))
+        env.reset()
+        assert not env.fused or w == 0       # the first step notices the noise and leaves the fused path
+        pos, vel = env.world.get_state()
+        close(pos[0], g["pos0"][w], what="reset pos")
+        for t in range(T):
+            if t:   # teacher-forced; the noise stream runs on
+                env.world.set_state(g["pos"][t - 1, w][None], g["vel"][t - 1, w][None])
+            obs, rew, done, info = env.step([g["act%d" % i][t, w] for i in range(A)])
+            assert not env.fused
+            pos, vel = env.world.get_state()
+            close(pos[0], g["pos"][t, w], what="w=%d t=%d pos" % (w, t))
+            close(vel[0], g["vel"][t, w], what="w=%d t=%d vel" % (w, t))
+            for i in range(A):
+                close(obs[i], g["obs%d" % i][t, w], what="w=%d t=%d obs%d" % (w, t, i))
+                close(np_(env.world.agents[i].state.c)[0], g["c%d" % i][t, w], what="w=%d t=%d c%d" % (w, t, i))
+            close(np.array(rew), g["rew"][t, w], what="w=%d t=%d rew" % (w, t))
+
+
+@pytest.mark.gpu
+def test_constants_assigned_on_a_live_env_are_honoured_without_a_refresh_call():
+    """The reference reads sizes, masses, speed limits, dt ... on every step (core.py:117-196), so assigning one on a
+    live env takes effect at the next step.  Here the kernels' descriptor is a snapshot; assignments bump a version the
+    step compares, so the same holds -- fused and generic paths."""
+    B = 512
+    rs = np.random.RandomState(4)
+    pos = (rs.uniform(-1, 1, (B, 6, 2)) * 0.3).astype(np.float32)
+    vel = rs.uniform(-1, 1, (B, 3, 2)).astype(np.float32)
+    act = torch.as_tensor(np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=(3, B))]).cuda()
+
+    def edit(env):
+        env.world.agents[1].size = 0.21
+        env.world.agents[2].max_speed = 0.3
+        env.world.agents[0].initial_mass = 2.5
+        env.world.damping = 0.4
+    for fused in (True, False):
+        live = mpe.make_env("simple_spread", batch_size=B, fused=fused)
+        live.world.set_state(pos, vel)
+        live.step(act if fused else [act[i] for i in range(3)])      # descriptor snapshotted with the default constants
+        edit(live)
+        live.world.set_state(pos, vel)
+        o1, r1, _, _ = live.step(act if fused else [act[i] for i in range(3)])
+        fresh = mpe.make_env("simple_spread", batch_size=B, fused=fused)
+        edit(fresh)
+        fresh.world.set_state(pos, vel)
+        o2, r2, _, _ = fresh.step(act if fused else [act[i] for i in range(3)])
+        assert torch.equal(live.world.pos, fresh.world.pos) and torch.equal(live.world.vel, fresh.world.vel)
+        for i in range(3):
+            assert torch.equal(o1[i], o2[i]) and torch.equal(r1[i], r2[i])
+        untouched = mpe.make_env("simple_spread", batch_size=B, fused=fused)
+        untouched.world.set_state(pos, vel)
+        untouched.step(act if fused else [act[i] for i in range(3)])
+        assert not torch.equal(untouched.world.vel, fresh.world.vel)     # the edits do change the physics

@@ -143,6 +143,19 @@ int main(int argc, char **argv) {
   rep("V6b grid-stride fill, 1024 x 256 threads", run([&] { hipLaunchKernelGGL(k_gridstride, dim3(1024), dim3(256), 0, s, (float4 *)obs, n4); }, s));
   rep("V2 wave/world, agent-major, 96 flat full stores", run([&] { hipLaunchKernelGGL((k_world<0, false, 1>), dim3(gw1), dim3(256), 0, s, obs, B, am_row, am_world); }, s));
   rep("V1 wave/world, agent-major, per row 64+32 lanes", run([&] { hipLaunchKernelGGL((k_world<1, false, 1>), dim3(gw1), dim3(256), 0, s, obs, B, am_row, am_world); }, s));
+  // the same wave-per-world row pattern with the agent blocks PADDED apart: rows of one world are then no longer an
+  // exact multiple of 2 MiB apart (B*D*4 = 6 MiB at B=4096) -- does the per-process bimodality (60 vs 73 us) follow
+  // the power-of-two stride between the concurrently written streams?
+  {
+    float *big; CK(hipMalloc(&big, (nfl + (size_t)A * (1 << 20)) * 4));
+    for (size_t pad : {(size_t)64, (size_t)1024, (size_t)(8192 + 64), (size_t)(1 << 18) + 64}) {
+      char nm[96]; snprintf(nm, sizeof nm, "V1p wave/world, agent-major, block stride + %zu floats", pad);
+      rep(nm, run([&] { hipLaunchKernelGGL((k_world<1, false, 1>), dim3(gw1), dim3(256), 0, s, big, B, am_row + pad, am_world); }, s));
+    }
+    rep("V1  (same buffer, unpadded)", run([&] { hipLaunchKernelGGL((k_world<1, false, 1>), dim3(gw1), dim3(256), 0, s, big, B, am_row, am_world); }, s));
+    rep("V0  linear fill of the same buffer", run([&] { hipLaunchKernelGGL(k_linear, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (float4 *)big, n4); }, s));
+    CK(hipFree(big));
+  }
   rep("V8 wave/world, agent-major, rows rotated per 64 worlds", run([&] { hipLaunchKernelGGL((k_world_rot<64>), dim3(gw1), dim3(256), 0, s, obs, B, am_row, am_world); }, s));
   rep("V8b wave/world, agent-major, rows rotated per 4 worlds", run([&] { hipLaunchKernelGGL((k_world_rot<4>), dim3(gw1), dim3(256), 0, s, obs, B, am_row, am_world); }, s));
   rep("V8c wave/world, agent-major, rows rotated per 512 worlds", run([&] { hipLaunchKernelGGL((k_world_rot<512>), dim3(gw1), dim3(256), 0, s, obs, B, am_row, am_world); }, s));
