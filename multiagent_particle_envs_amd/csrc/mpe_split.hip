@@ -665,21 +665,25 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
     }
     if constexpr (KIND == MPE_SCN_CRYPTO) {  // simple_crypto.py:127-169 (goal = pick 0, key = pick 1; colours are one-hots of width dim_c)
       const float *cs = b.comm + wave_off(((size_t)2 * B + w0) * DC) + ln * DC;   // the speaker's utterance
+      static_assert((DC & 1) == 0, "crypto rows are written as pairs");
       if (i == 0) {          // Eve: what the speaker says
-        constexpr int D = DC, RS = tile_stride<D>();
+        constexpr int D = DC;
+        RowPairs<D> r(tile, lane);
 #pragma unroll
-        for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, c, cs[c]);
-        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        for (int c = 0; c < DC; c += 2) r.put(c, cs[c], cs[c + 1]);
+        flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       } else {
-        constexpr int D = 2 * DC, RS = tile_stride<D>();
-        if (i == 1) {        // Bob: key, utterance
+        constexpr int D = 2 * DC;
+        RowPairs<D> r(tile, lane);
+        const int first = i == 1 ? pick1 : goal;   // Bob: key, utterance;  Alice: goal colour, key
 #pragma unroll
-          for (int c = 0; c < DC; ++c) { put1<RS>(tile, lane, c, pick1 == c ? 1.f : 0.f); put1<RS>(tile, lane, DC + c, cs[c]); }
-        } else {             // Alice: goal colour, key
+        for (int c = 0; c < DC; c += 2) r.put(c, first == c ? 1.f : 0.f, first == c + 1 ? 1.f : 0.f);
 #pragma unroll
-          for (int c = 0; c < DC; ++c) { put1<RS>(tile, lane, c, goal == c ? 1.f : 0.f); put1<RS>(tile, lane, DC + c, pick1 == c ? 1.f : 0.f); }
+        for (int c = 0; c < DC; c += 2) {
+          if (i == 1) r.put(DC + c, cs[c], cs[c + 1]);
+          else        r.put(DC + c, pick1 == c ? 1.f : 0.f, pick1 == c + 1 ? 1.f : 0.f);
         }
-        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       }
     }
     if constexpr (KIND == MPE_SCN_WORLD_COMM) {  // simple_world_comm.py:231-289
@@ -693,35 +697,35 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         vis[j] = i == 0 || (f1 && o1) || (f2 && o2) || (!f1 && !o1 && !f2 && !o2);
       }
       auto row = [&](auto dsel, auto advt) {
-        constexpr int D = decltype(dsel)::value, RS = tile_stride<D>();
+        constexpr int D = decltype(dsel)::value;
         constexpr bool ADV = decltype(advt)::value;
-        int k = 0;
-        put1<RS>(tile, lane, 0, mvx); put1<RS>(tile, lane, 1, mvy); put1<RS>(tile, lane, 2, mx); put1<RS>(tile, lane, 3, my);
-        k = 4;
+        RowPairs<D> r(tile, lane);   // every field of the row is a 2-vector (the 4-wide utterance: two of them)
+        r.put(0, mvx, mvy);
+        r.put(2, mx, my);
+        int k = 4;
 #pragma unroll
-        for (int l = 0; l < L; ++l) { put1<RS>(tile, lane, k, px[A + l] - mx); put1<RS>(tile, lane, k + 1, py[A + l] - my); k += 2; }
+        for (int l = 0; l < L; ++l) { r.put(k, px[A + l] - mx, py[A + l] - my); k += 2; }
 #pragma unroll
         for (int j = 0; j < A; ++j) {
           if (j == i) continue;
-          put1<RS>(tile, lane, k, vis[j] ? px[j] - mx : 0.f);
-          put1<RS>(tile, lane, k + 1, vis[j] ? py[j] - my : 0.f);
+          r.put(k, vis[j] ? px[j] - mx : 0.f, vis[j] ? py[j] - my : 0.f);
           k += 2;
         }
-        if (!ADV) { put1<RS>(tile, lane, k, f1 ? 1.f : -1.f); put1<RS>(tile, lane, k + 1, f2 ? 1.f : -1.f); k += 2; }
+        if (!ADV) { r.put(k, f1 ? 1.f : -1.f, f2 ? 1.f : -1.f); k += 2; }
 #pragma unroll
         for (int j = NADV; j < A; ++j) {
           if (j == i) continue;
-          put1<RS>(tile, lane, k, vis[j] ? X[(j * XW + 2) * kWave + lane] : 0.f);
-          put1<RS>(tile, lane, k + 1, vis[j] ? X[(j * XW + 3) * kWave + lane] : 0.f);
+          r.put(k, vis[j] ? X[(j * XW + 2) * kWave + lane] : 0.f, vis[j] ? X[(j * XW + 3) * kWave + lane] : 0.f);
           k += 2;
         }
         if (ADV) {
-          put1<RS>(tile, lane, k, f1 ? 1.f : -1.f); put1<RS>(tile, lane, k + 1, f2 ? 1.f : -1.f); k += 2;
+          r.put(k, f1 ? 1.f : -1.f, f2 ? 1.f : -1.f);
+          k += 2;
           const float *cl = b.comm + wave_off(((size_t)0 * B + w0) * DC) + ln * DC;   // world.agents[0].state.c
 #pragma unroll
-          for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, k + c, cl[c]);
+          for (int c = 0; c < DC; c += 2) r.put(k + c, cl[c], cl[c + 1]);
         }
-        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       };
       if (i < NADV) row(std::integral_constant<int, DA>{}, std::true_type{});
       else          row(std::integral_constant<int, DGd>{}, std::false_type{});

@@ -106,6 +106,79 @@ class RandomRollout(object):
         torch.cuda.current_stream(self.world.device).wait_stream(s)
         return g
 
+    @property
+    def can_pipeline(self):
+        """True when `mpe_step` has a staged form for this env (a scratch area was allocated: mpe_scratch_floats > 0)."""
+        return self.env._scratch is not None
+
+    def enqueue_pipelined(self, steps, streams=None):
+        """The same `steps` env steps with the two halves of CONSECUTIVE steps overlapped (`mpe_step_stage`): stream W
+        runs reset / move draw / World.step + rewards of step t+1 while stream R still writes the observation rows of
+        step t from that step's scratch copy (two scratch areas, alternating).  Legal because the moves of a random
+        rollout do not depend on the observations; every step's outputs are what the sequential form writes, only
+        their completion order across streams differs.  Call inside a graph capture or eagerly; joins on the
+        current stream before returning."""
+        env, w = self.env, self.world
+        if not self.can_pipeline:
+            return self.enqueue(steps)
+        L, desc, B, dev = self._L, self._desc, self.B, w.device
+        if getattr(self, "_scratch2", None) is None:
+            self._scratch2 = torch.empty_like(env._scratch)
+            self._pipe_streams = streams or (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        sW, sR = self._pipe_streams
+        cur = torch.cuda.current_stream(dev)
+        sW.wait_stream(cur)
+        sR.wait_stream(cur)
+        scr = (env._scratch, self._scratch2)
+        rows_done = [None, None]     # event after the ROWS stage that last read scratch k
+        for _ in range(steps):
+            k = self.t & 1
+            out = env._sets[k]
+            b = out.bufs
+            with torch.cuda.stream(sW):
+                st = _abi.raw_stream(dev)
+                if self.regenerate and self.t % len(self.pool) == 0:
+                    self._fill_pool(self.t, st)
+                if self.episode_len and self.t % self.episode_len == 0:
+                    _abi.check(L.mpe_reset(C.byref(self._gen_desc), C.byref(env._sets[0].bufs), B, None, self._lr, self.seed,
+                                           self.t // self.episode_len, int(w.world_offset), st), "mpe_reset")
+                if rows_done[k] is not None:
+                    sW.wait_event(rows_done[k])          # scratch k (and output set k) are free again
+                b.act = self.pool[self.t % len(self.pool)].data_ptr()
+                b.ids = b.u = None
+                b.scratch = scr[k].data_ptr()
+                _abi.check(L.mpe_step_stage(C.byref(desc), C.byref(b), B, _abi.MPE_STAGE_WORLD, st), "mpe_step_stage")
+                world_done = torch.cuda.Event()
+                world_done.record(sW)
+            with torch.cuda.stream(sR):
+                sR.wait_event(world_done)
+                _abi.check(L.mpe_step_stage(C.byref(desc), C.byref(b), B, _abi.MPE_STAGE_ROWS, _abi.raw_stream(dev)),
+                           "mpe_step_stage")
+                rows_done[k] = torch.cuda.Event()
+                rows_done[k].record(sR)
+            self.t += 1
+        for out in env._sets:
+            out.bufs.scratch = env._scratch.data_ptr()
+        cur.wait_stream(sW)
+        cur.wait_stream(sR)
+        self._mark_stale()
+        return env._sets[(self.t - 1) & 1]
+
+    def capture_pipelined(self, steps):
+        """`enqueue_pipelined(steps)` captured into a HIP graph (two-stream fork / join inside the graph)."""
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(device=self.world.device)
+        s.wait_stream(torch.cuda.current_stream(self.world.device))
+        t0 = self.t
+        with torch.cuda.stream(s):
+            self.enqueue_pipelined(2)          # warm the code objects / create the side streams outside capture
+            self.t = t0
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                self.enqueue_pipelined(steps)
+        torch.cuda.current_stream(self.world.device).wait_stream(s)
+        return g
+
     def fused(self, steps, trajectory=None):
         """One `mpe_rollout_random` launch covering `steps` env steps.  With `trajectory` (a
         Trajectory of at least `steps` blocks) every step's outputs land in their own block;
@@ -207,6 +280,8 @@ class Trajectory(object):
             b.entity_table = env._entity_table.data_ptr()
         if w.choice_i32 is not None:
             b.choice = w.choice_i32.data_ptr()
+        if env._scratch is not None:
+            b.scratch = env._scratch.data_ptr()
         self.bufs = b
 
 

@@ -301,8 +301,9 @@ def test_discrete_action_input_on_a_comm_scenario_matches_one_hot_rows():
 def test_action_noise_and_scripted_agents_on_the_generic_path():
     """core.py:119-120,138,176 (u_noise / c_noise: Gaussian noise on the applied force and the emitted word) and
     core.py:112-114,119-120 (agents with an action_callback are scripted: not policy agents, stepped by the world).
-    No shipped scenario sets them; they force the generic path, where the noise comes from torch's
-    generator, so the check re-draws the same normals from the same seed."""
+    No shipped scenario sets them; they force the generic path.  In device mode the noise comes from a
+    generator keyed by (world.seed, world.world_offset) -- not torch's global one -- so a second world with the same
+    key re-draws the same normals, and torch.manual_seed does not move them."""
     B = 257
     Base = mpe.scenarios.load("simple_speaker_listener.py").Scenario
     sc = Base()
@@ -316,11 +317,17 @@ def test_action_noise_and_scripted_agents_on_the_generic_path():
     rs = np.random.RandomState(0)
     word = np.eye(3, dtype=np.float32)[rs.randint(0, 3, B)]
     move = np.eye(5, dtype=np.float32)[rs.randint(0, 5, B)]
+    w.seed = 77
     torch.manual_seed(11)
     obs, _, _, _ = env.step([torch.as_tensor(word).cuda(), torch.as_tensor(move).cuda()])
-    torch.manual_seed(11)
-    nu = torch.randn(B, 2, device="cuda").cpu().numpy() * 0.5       # World.step draws u noise first (agents in order)
-    nc = torch.randn(B, 3, device="cuda").cpu().numpy() * 0.25      # then update_agent_state draws c noise
+    torch.manual_seed(12345)                                         # irrelevant by construction
+    twin = Base().make_world(batch_size=B)
+    twin.seed = 77
+    nu = twin._randn((B, 2)).cpu().numpy() * 0.5                     # World.step draws u noise first (agents in order)
+    nc = twin._randn((B, 3)).cpu().numpy() * 0.25                    # then update_agent_state draws c noise
+    other = Base().make_world(batch_size=B)
+    other.seed, other.world_offset = 77, B                           # another shard of the same job: another stream
+    assert not torch.equal(other._randn((B, 2)), torch.as_tensor(nu / 0.5).cuda())
     u = np.stack([move[:, 1] - move[:, 2], move[:, 3] - move[:, 4]], 1) * 5.0 + nu
     v = vel0[:, 1] * 0.75 + u * 0.1            # no contacts in this scenario (nothing collides)
     p = pos0[:, 1] + v * 0.1

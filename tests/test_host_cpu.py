@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "mpe_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|size_t|const char \*)\s*\**\s*(mpe_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|size_t|const char \*)\s*\**\s*(mpe_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 15
     assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
     raw = C.CDLL(_abi.LIB_PATH)
