@@ -304,7 +304,7 @@ class Leg(object):
         R = max(1, int(math.ceil(MIN_REGION_MS * 1e-3 / once))) if mode in ("graph", "fused", "pipelined") else 1
         R = int(sharding.reduce_max(R, dev))
         reps = R
-        if R > 1 and K * R <= 8000:
+        if R > 1 and K * R <= 8000 and mode != "pipelined":   # (a two-stream graph of thousands of nodes crashed the HIP runtime)
             # one body of K*R CONSECUTIVE steps (resets and move draws fall every episode_len steps of the long run,
             # whatever K is) instead of R replays of a K-step episode fragment
             body = self.body(mode, protocol, K * R)

@@ -888,9 +888,9 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   if (ROWS && !(MPE_DUO_ABLATE & 4)) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
 }
 
-// The observation block of simple_spread written in MEMORY order (second launch of the staged step): thread t of
-// agent block i owns 16-byte piece q = t % P of world w = t / P, i.e. float4 number t of obs_n[i] -- consecutive
-// threads, waves and workgroups write consecutive addresses, blocks in dispatch order, exactly like a fill.  Why:
+// The observation block of simple_spread written in MEMORY order (second launch of the staged step): within agent
+// block i, wave r writes row r -- consecutive waves and workgroups write consecutive addresses, blocks in dispatch
+// order, like a fill.  Why:
 // a fill of these 403 MB (B = 4096, N = 64) takes 59-60 us in every process, the same bytes written as one 1.5 KB
 // row per wave, 4096 waves at 64 places each (k_wave, k_duo<ROWS>) take 60 OR 73 us depending on where the
 // process's buffers landed physically (tools/ubench/store_pattern.hip; padding the blocks apart does not help).
@@ -899,36 +899,41 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
 // Same subtraction on the same values as emit_rows_fast: bit-identical rows.
 __global__ void __launch_bounds__(256)
 k_rows(const float *__restrict__ scratch, float *__restrict__ obs, const unsigned B, const int A, const int L, const int D) {
+  // a wave per row: wave r of agent block i (= blockIdx.y) writes row w = r -- consecutive waves and workgroups write
+  // consecutive 4 D-byte rows; lane -> pieces lane, lane + 64 (P <= 128): no index arithmetic beyond the row number
   const int E = A + L, P = D >> 2, kpz = 2 + L + (A - 1);
-  const unsigned t = blockIdx.x * 256u + threadIdx.x;
-  const unsigned total = B * (unsigned)P;
-  if (t >= total) return;
-  const int i = blockIdx.y;
-  const unsigned w = t / (unsigned)P;
-  const int q = (int)(t - w * (unsigned)P);
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned w = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (w >= B) return;   // wave-uniform
+  const int i = blockIdx.y, thr = L + i;
   const float2 *const S = reinterpret_cast<const float2 *>(scratch + (size_t)w * scratch_stride(A, L));
-  const float2 me = S[L + i];
-  const int thr = L + i;
-  float4 o;
-  {
-    const int kp = 2 * q, idx = kp - 2;
-    const float2 pj = S[min(max(idx + (idx >= thr ? 1 : 0), 0), E - 1)];
-    o.x = pj.x - me.x;
-    o.y = pj.y - me.y;
-    if (kp >= kpz) { o.x = 0.f; o.y = 0.f; }
+  const float2 me = S[thr];
+  float *const row = obs + ((size_t)i * B + w) * (size_t)D;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int q = lane + kWave * k;
+    if (kWave * k >= P) break;   // uniform
+    float4 o;
+    {
+      const int kp = 2 * q, idx = kp - 2;
+      const float2 pj = S[min(max(idx + (idx >= thr ? 1 : 0), 0), E - 1)];
+      o.x = pj.x - me.x;
+      o.y = pj.y - me.y;
+      if (kp >= kpz) { o.x = 0.f; o.y = 0.f; }
+    }
+    {
+      const int kp = 2 * q + 1, idx = kp - 2;
+      const float2 pj = S[min(max(idx + (idx >= thr ? 1 : 0), 0), E - 1)];
+      o.z = pj.x - me.x;
+      o.w = pj.y - me.y;
+      if (kp >= kpz) { o.z = 0.f; o.w = 0.f; }
+    }
+    if (q == 0) {   // the row's header
+      const float2 vel = S[E + i];
+      o = make_float4(vel.x, vel.y, me.x, me.y);
+    }
+    if (q < P) *reinterpret_cast<float4 *>(row + 4 * q) = o;
   }
-  {
-    const int kp = 2 * q + 1, idx = kp - 2;
-    const float2 pj = S[min(max(idx + (idx >= thr ? 1 : 0), 0), E - 1)];
-    o.z = pj.x - me.x;
-    o.w = pj.y - me.y;
-    if (kp >= kpz) { o.z = 0.f; o.w = 0.f; }
-  }
-  if (q == 0) {   // the row's header
-    const float2 vel = S[E + i];
-    o = make_float4(vel.x, vel.y, me.x, me.y);
-  }
-  reinterpret_cast<float4 *>(obs + (size_t)i * B * (size_t)D)[t] = o;
 }
 
 // ---- several worlds per wave: the mid-size regime (7 <= A, L <= 32) ------------------------------------------
@@ -1260,7 +1265,7 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
         // staged: World.step + reward + a world-major copy of the new world, then the rows in memory order
         if (stage != kStageRows) hipLaunchKernelGGL((k_duo<G, false>), dgrid, dblock, dlds, stream, d, b, B);
         if (stage != kStageWorld)
-          hipLaunchKernelGGL(k_rows, dim3((unsigned)((pieces + 255) / 256), (unsigned)d.A), dim3(256), 0, stream, b.scratch,
+          hipLaunchKernelGGL(k_rows, dim3((unsigned)((B + 3) / 4), (unsigned)d.A), dim3(256), 0, stream, b.scratch,
                              b.obs, (unsigned)B, d.A, d.L, d.D);
         return (int)hipGetLastError();
       }
