@@ -249,10 +249,15 @@ class Leg(object):
         bytes_step = algorithmic_bytes(self.A, self.Lm, obs_total, len(env.world.choice_pops), speakers * env.world.dim_c)
         compulsory_roll = 4 * (obs_total + self.A) + self.A    # a fused rollout keeps state on chip and draws moves in-kernel
         A, Lm = self.A, self.Lm
-        kname = "mpe::k_split" if A + Lm <= 16 else ("mpe::k_multi" if max(A, Lm) <= 32 and A + Lm <= 64 else
-                                                      "mpe::k_duo<4,false> + mpe::k_rows (staged step: two launches; kernel_us_per_launch "
-                                                      "is the pair, per step)" if max(A, Lm) <= 64 and env._scratch is not None
-                                                      else "mpe::k_wave")
+        if A + Lm <= 16:
+            kname = "mpe::k_split"
+        elif max(A, Lm) <= 32 and A + Lm <= 64:
+            kname = "mpe::k_multi"
+        elif self.scenario == "simple_spread" and max(A, Lm) <= 64 and obs_total // A % 4 == 0:
+            kname = ("mpe::k_duo<4,false> + mpe::k_rows (staged step: two launches; kernel_us_per_launch is the pair)"
+                     if env._scratch is not None else "mpe::k_duo<4,true>")
+        else:
+            kname = "mpe::k_wave"
         return obs_total, bytes_step, compulsory_roll, kname
 
     def fused_steps(self, roll, n):

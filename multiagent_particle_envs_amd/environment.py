@@ -195,9 +195,12 @@ class MultiAgentEnv(object):
         self._comm = None
         self._entity_table = None
         self._scratch = None
-        self.staged_step = True   # hand the library its optional scratch area (mpe_scratch_floats): 33..64-agent
-        #                           simple_spread then steps as World.step + memory-order rows (two launches);
-        #                           set False before the first step to keep the single-launch kernel
+        self.staged_step = False  # True (before the first step): hand the library its optional scratch area
+        #                           (mpe_scratch_floats): 33..64-agent simple_spread then steps as World.step + rewards,
+        #                           then memory-order rows (two launches) instead of the single-launch kernel.  Measured
+        #                           (DESIGN.md 6): back to back on one stream the pair is 1-4 us SLOWER than the single
+        #                           launch (its reward arithmetic no longer hides under row stores); it pays when the two
+        #                           halves of consecutive steps overlap (RandomRollout.enqueue_pipelined)
         self.shared_viewer = shared_viewer
 
     def refresh_constants(self):

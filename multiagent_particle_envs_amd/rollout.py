@@ -108,13 +108,15 @@ class RandomRollout(object):
 
     @property
     def can_pipeline(self):
-        """True when `mpe_step` has a staged form for this env (a scratch area was allocated: mpe_scratch_floats > 0)."""
-        return self.env._scratch is not None
+        """True when `mpe_step` has a staged form for this env's shape (mpe_scratch_floats > 0)."""
+        if getattr(self, "_scratch_floats", None) is None:
+            self._scratch_floats = int(self._L.mpe_scratch_floats(C.byref(self._desc), self.B))
+        return self._scratch_floats > 0
 
     def enqueue_pipelined(self, steps, streams=None):
-        """The same `steps` env steps with the two halves of CONSECUTIVE steps overlapped (`mpe_step_stage`): stream W
-        runs reset / move draw / World.step + rewards of step t+1 while stream R still writes the observation rows of
-        step t from that step's scratch copy (two scratch areas, alternating).  Legal because the moves of a random
+        """The same `steps` env steps with the two halves of CONSECUTIVE steps overlapped (`mpe_step_stage`): the current
+        stream runs reset / move draw / World.step + rewards of step t+1 while a side stream still writes the observation
+        rows of step t from that step's scratch copy (two scratch areas, alternating).  Legal because the moves of a random
         rollout do not depend on the observations; every step's outputs are what the sequential form writes, only
         their completion order across streams differs.  Call inside a graph capture or eagerly; joins on the
         current stream before returning."""
@@ -122,45 +124,44 @@ class RandomRollout(object):
         if not self.can_pipeline:
             return self.enqueue(steps)
         L, desc, B, dev = self._L, self._desc, self.B, w.device
-        if getattr(self, "_scratch2", None) is None:
-            self._scratch2 = torch.empty_like(env._scratch)
-            self._pipe_streams = streams or (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-        sW, sR = self._pipe_streams
+        if getattr(self, "_pipe_scratch", None) is None:    # two scratch areas of the rollout's own, alternating by step
+            self._pipe_scratch = tuple(torch.empty(self._scratch_floats, dtype=torch.float32, device=dev) for _ in range(2))
+            self._row_stream = streams or torch.cuda.Stream(device=dev)
+        sR = self._row_stream
         cur = torch.cuda.current_stream(dev)
-        sW.wait_stream(cur)
-        sR.wait_stream(cur)
-        scr = (env._scratch, self._scratch2)
-        rows_done = [None, None]     # event after the ROWS stage that last read scratch k
-        for _ in range(steps):
-            k = self.t & 1
-            out = env._sets[k]
-            b = out.bufs
-            with torch.cuda.stream(sW):
-                st = _abi.raw_stream(dev)
-                if self.regenerate and self.t % len(self.pool) == 0:
-                    self._fill_pool(self.t, st)
-                if self.episode_len and self.t % self.episode_len == 0:
-                    _abi.check(L.mpe_reset(C.byref(self._gen_desc), C.byref(env._sets[0].bufs), B, None, self._lr, self.seed,
-                                           self.t // self.episode_len, int(w.world_offset), st), "mpe_reset")
-                if rows_done[k] is not None:
-                    sW.wait_event(rows_done[k])          # scratch k (and output set k) are free again
-                b.act = self.pool[self.t % len(self.pool)].data_ptr()
-                b.ids = b.u = None
-                b.scratch = scr[k].data_ptr()
-                _abi.check(L.mpe_step_stage(C.byref(desc), C.byref(b), B, _abi.MPE_STAGE_WORLD, st), "mpe_step_stage")
-                world_done = torch.cuda.Event()
-                world_done.record(sW)
+        scr = self._pipe_scratch
+
+        def world_stage(t):      # on the current stream: reset / move draw / World.step + rewards of global step t
+            st = self._stream()
+            if self.regenerate and t % len(self.pool) == 0:
+                self._fill_pool(t, st)
+            if self.episode_len and t % self.episode_len == 0:
+                _abi.check(L.mpe_reset(C.byref(self._gen_desc), C.byref(env._sets[0].bufs), B, None, self._lr, self.seed,
+                                       t // self.episode_len, int(w.world_offset), st), "mpe_reset")
+            b = env._sets[t & 1].bufs
+            b.act = self.pool[t % len(self.pool)].data_ptr()
+            b.ids = b.u = None
+            b.scratch = scr[t & 1].data_ptr()
+            _abi.check(L.mpe_step_stage(C.byref(desc), C.byref(b), B, _abi.MPE_STAGE_WORLD, st), "mpe_step_stage")
+
+        # fork / join only (the shape HIP-graph capture digests): rows of step t on the side stream while the current
+        # stream already runs the world stage of step t+1; the join at the end of the iteration orders rows(t) before
+        # world(t+2), which reuses its scratch area and output set
+        t0, t1 = self.t, self.t + steps
+        world_stage(t0)
+        for t in range(t0, t1):
+            sR.wait_stream(cur)
             with torch.cuda.stream(sR):
-                sR.wait_event(world_done)
+                b = env._sets[t & 1].bufs
+                b.scratch = scr[t & 1].data_ptr()
                 _abi.check(L.mpe_step_stage(C.byref(desc), C.byref(b), B, _abi.MPE_STAGE_ROWS, _abi.raw_stream(dev)),
                            "mpe_step_stage")
-                rows_done[k] = torch.cuda.Event()
-                rows_done[k].record(sR)
-            self.t += 1
-        for out in env._sets:
-            out.bufs.scratch = env._scratch.data_ptr()
-        cur.wait_stream(sW)
-        cur.wait_stream(sR)
+            if t + 1 < t1:
+                world_stage(t + 1)
+            cur.wait_stream(sR)
+        self.t = t1
+        for out in env._sets:      # back to the env's own choice (staged_step) for its sequential steps
+            out.bufs.scratch = env._scratch.data_ptr() if env._scratch is not None else None
         self._mark_stale()
         return env._sets[(self.t - 1) & 1]
 

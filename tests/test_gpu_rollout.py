@@ -185,7 +185,7 @@ def test_pipelined_rollout_equals_sequential(N, B):
     K = 23
     envs = [mpe.make_env("simple_spread", batch_size=B, num_agents=N, seed=4) for _ in range(3)]
     rolls = [RandomRollout(e, episode_len=5, pool=5, regenerate=True) for e in envs]
-    assert rolls[0].can_pipeline
+    assert rolls[0].can_pipeline and envs[1]._scratch is None        # the pipelined rollout brings its own scratch areas
     last = [rolls[0].enqueue(K), rolls[1].enqueue_pipelined(K)]
     g = rolls[2].capture_pipelined(K)
     g.replay()
