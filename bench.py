@@ -249,15 +249,7 @@ class Leg(object):
         bytes_step = algorithmic_bytes(self.A, self.Lm, obs_total, len(env.world.choice_pops), speakers * env.world.dim_c)
         compulsory_roll = 4 * (obs_total + self.A) + self.A    # a fused rollout keeps state on chip and draws moves in-kernel
         A, Lm = self.A, self.Lm
-        if A + Lm <= 16:
-            kname = "mpe::k_split"
-        elif max(A, Lm) <= 32 and A + Lm <= 64:
-            kname = "mpe::k_multi"
-        elif self.scenario == "simple_spread" and max(A, Lm) <= 64 and obs_total // A % 4 == 0:
-            kname = ("mpe::k_duo<4,false> + mpe::k_rows (staged step: two launches; kernel_us_per_launch is the pair)"
-                     if env._scratch is not None else "mpe::k_duo<4,true>")
-        else:
-            kname = "mpe::k_wave"
+        kname = "mpe::k_split" if A + Lm <= 16 else ("mpe::k_multi" if max(A, Lm) <= 32 and A + Lm <= 64 else "mpe::k_wave")
         return obs_total, bytes_step, compulsory_roll, kname
 
     def fused_steps(self, roll, n):
@@ -279,9 +271,6 @@ class Leg(object):
             return lambda: roll.enqueue(n)
         if mode == "fused":
             return lambda: self.fused_steps(roll, n)
-        if mode == "pipelined":
-            assert self.S == 1
-            return roll.rollouts[0].capture_pipelined(n).replay
         env, r0, EP = self.env, roll.rollouts[0], self.EP
         assert self.S == 1, "--mode api drives one env"
 
@@ -306,10 +295,10 @@ class Leg(object):
         body()
         torch.cuda.synchronize()
         once = max(time.perf_counter() - t0, 1e-6)
-        R = max(1, int(math.ceil(MIN_REGION_MS * 1e-3 / once))) if mode in ("graph", "fused", "pipelined") else 1
+        R = max(1, int(math.ceil(MIN_REGION_MS * 1e-3 / once))) if mode in ("graph", "fused") else 1
         R = int(sharding.reduce_max(R, dev))
         reps = R
-        if R > 1 and K * R <= 8000 and mode != "pipelined":   # (a two-stream graph of thousands of nodes crashed the HIP runtime)
+        if R > 1 and K * R <= 8000:
             # one body of K*R CONSECUTIVE steps (resets and move draws fall every episode_len steps of the long run,
             # whatever K is) instead of R replays of a K-step episode fragment
             body = self.body(mode, protocol, K * R)
@@ -435,7 +424,7 @@ def main():
     ap.add_argument("--scenario", default="simple_spread")
     ap.add_argument("--agents", type=int, default=3)
     ap.add_argument("--episode-len", type=int, default=25)
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "api", "fused", "pipelined"])
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "api", "fused"])
     ap.add_argument("--protocol", default="fresh", choices=["fresh", "resident"],
                     help="fresh: every step's moves are newly drawn (one block draw per episode, timed); resident: a ring of "
                          "16 move tensors drawn once (round-1 headline)")
@@ -564,14 +553,6 @@ def main():
             ent["fused_rollout"] = {"value": bb * kk * R2 / d2, "unit": "env-steps/s", "kernel_us_per_step": k2,
                                     "compulsory_bytes_per_env_step": comp,
                                     "frac_compulsory": comp * bb / (k2 * 1e-6) / 1e9 / HBM_PEAK_GBS}
-            if lg.roll("fresh").rollouts[0].can_pipeline:
-                d3, R3, _ = lg.timed(torch, _Sh, dev, "pipelined", "fresh", kk, 10, 3)
-                ent["pipelined"] = {
-                    "what": "the same steps with World.step + rewards of step t+1 overlapping the observation rows of step t "
-                            "on a second stream (mpe_step_stage; legal for a rollout whose moves do not depend on the "
-                            "observations); `value` above is the sequential, policy-in-the-loop form",
-                    "value": bb * kk * R3 / d3, "unit": "env-steps/s", "ms_per_step": d3 * 1e3 / (kk * R3),
-                    "frac": lg.geometry()[1] * bb / (d3 / (kk * R3)) / 1e9 / HBM_PEAK_GBS}
             cfgs[key] = ent
             lg.release()
             del lg

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 4 /* layout of the two structs below + meaning of existing entry points; new entry points are additive */
+#define MPE_ABI_VERSION 3 /* layout of the two structs below + meaning of existing entry points; new entry points are additive */
 #define MPE_MAX_ENTITIES 512 /* agents + landmarks per world */
 #define MPE_ACTION_DIM 5     /* Discrete(dim_p*2+1), environment.py:45 */
 #define MPE_MAX_CHOICES 4    /* np.random.choice draws a reset_world makes before the positions */
@@ -109,10 +109,6 @@ typedef struct MpeBuffers {
                                 row becomes its AgentState.c (core.py:171-177, no c_noise); rows of silent agents unused */
   int32_t *choice;           /* [n_choices][B] per-world picks (landmark indices): read by step/observe of the
                                 scenarios that have them, written by mpe_reset / in-kernel resets             */
-  float *scratch;            /* optional work area of mpe_scratch_floats(desc, B) floats, contents meaningless to the
-                                caller: with it the large-N step (simple_spread, 33..64 agents) runs as two launches --
-                                World.step + reward leave a world-major copy of the new world here, then the
-                                observation block is written in memory order -- instead of one; NULL = one launch */
 } MpeBuffers;
 
 /* ---- library / binding sanity -------------------------------------------------------------- */
@@ -134,23 +130,6 @@ int mpe_fill_entity_table(const MpeScenarioDesc *desc, float *host_out);
  *   (environment.py:92-97 -> Scenario.observation/reward/benchmark_data) -> shared-reward sum
  *   (environment.py:100-102).  Reads pos, vel, act|ids; writes pos, vel, obs, rew, done, info_*. */
 int mpe_step(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, void *stream);
-
-/* Floats of MpeBuffers.scratch that make mpe_step take its staged (two-launch) form for this shape and batch;
- * 0 when the shape steps in one launch anyway (then scratch is ignored), < 0 on an invalid descriptor.        */
-int64_t mpe_scratch_floats(const MpeScenarioDesc *desc, int64_t B);
-
-/* mpe_step_stage: mpe_step cut at its internal seam, for callers that overlap the two halves of CONSECUTIVE steps
- * on two streams (a rollout whose moves do not depend on the observations: World.step of step t+1 needs the
- * state of step t, not its observation rows):
- *   MPE_STAGE_ALL    = mpe_step
- *   MPE_STAGE_WORLD  _set_action + World.step + reward / done / info of every agent (+ the scratch copy)
- *   MPE_STAGE_ROWS   the observation rows, from the scratch copy the WORLD stage left
- * WORLD followed by ROWS (same bufs->scratch) writes exactly what mpe_step writes.  Shapes without a staged form
- * (mpe_scratch_floats == 0, or scratch == NULL) do everything in WORLD; ROWS is then a no-op.               */
-#define MPE_STAGE_ALL 0
-#define MPE_STAGE_WORLD 1
-#define MPE_STAGE_ROWS 2
-int mpe_step_stage(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, int32_t stage, void *stream);
 
 /* mpe_step_thread: the same step, same arguments, bit-identical results, on the thread-per-world kernel
  * family (one lane owns one world) instead of the wave-per-agent one -- the independent second

@@ -6,14 +6,13 @@ library handle (`lib()`), and every compute entry point needs device pointers.
 import ctypes as C
 import os
 
-MPE_ABI_VERSION = 4
+MPE_ABI_VERSION = 3
 MPE_MAX_ENTITIES = 512
 MPE_ACTION_DIM = 5
 MPE_SCN_GENERIC, MPE_SCN_SIMPLE, MPE_SCN_SPREAD, MPE_SCN_TAG, MPE_SCN_ADVERSARY, MPE_SCN_PUSH = 0, 1, 2, 3, 4, 5
 MPE_SCN_SPEAKER_LISTENER, MPE_SCN_REFERENCE, MPE_SCN_CRYPTO, MPE_SCN_WORLD_COMM = 6, 7, 8, 9
 COMM_KINDS = (MPE_SCN_SPEAKER_LISTENER, MPE_SCN_REFERENCE, MPE_SCN_CRYPTO, MPE_SCN_WORLD_COMM)   # agents speak: MpeBuffers.comm
 MPE_MAX_CHOICES = 4
-MPE_STAGE_ALL, MPE_STAGE_WORLD, MPE_STAGE_ROWS = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPE_HIP_LIB") or os.path.join(_HERE, "lib", "libmpe_hip.so")  # override: A/B builds
@@ -39,7 +38,7 @@ class MpeBuffers(C.Structure):
         ("obs", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p),
         ("info_rew", C.c_void_p), ("info_collisions", C.c_void_p), ("info_min_dists", C.c_void_p),
         ("info_occupied", C.c_void_p), ("force", C.c_void_p), ("entity_table", C.c_void_p),
-        ("comm", C.c_void_p), ("choice", C.c_void_p), ("scratch", C.c_void_p),
+        ("comm", C.c_void_p), ("choice", C.c_void_p),
     ]
 
 
@@ -53,8 +52,6 @@ EXPORTS = {
     "mpe_fill_entity_table": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(C.c_float)]),
     "mpe_step_supported": (C.c_int, [C.POINTER(MpeScenarioDesc)]),
     "mpe_step": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
-    "mpe_step_stage": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_int32, C.c_void_p]),
-    "mpe_scratch_floats": (C.c_int64, [C.POINTER(MpeScenarioDesc), C.c_int64]),
     "mpe_step_thread": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
     "mpe_observe": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
     "mpe_world_step": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),

@@ -212,7 +212,7 @@ int mpe_fill_entity_table(const MpeScenarioDesc *d, float *out) {
 }
 
 static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
-               void *stream, StepImpl impl = StepImpl::Split, int stage = mpe::kStageAll) {
+               void *stream, StepImpl impl = StepImpl::Split) {
   if (int rc = check_desc(d, what)) return rc;
   if (int rc = check_state(b, B, what)) return rc;
   if (phys) if (int rc = check_actions(b, what)) return rc;
@@ -235,8 +235,6 @@ static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, 
     dd.kind = MPE_SCN_GENERIC;
     use = &dd;
   }
-  const bool staged_shape = out && phys && d->kind == MPE_SCN_SPREAD && b->scratch && d->n_agents + d->n_landmarks > mpe::kNarrowMaxE;
-  if (stage == mpe::kStageRows && !staged_shape) return 0;   // one-launch shapes did everything in the WORLD stage
   const bool comm_kind = kind >= MPE_SCN_SPEAKER_LISTENER;   // these exist as wave-per-agent kernels only
   if (out && (phys || comm_kind) && d->n_agents + d->n_landmarks <= mpe::kNarrowMaxE &&
       (comm_kind || impl != StepImpl::Thread) &&
@@ -259,7 +257,7 @@ static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, 
     if (int rc = need(b->entity_table, what, "entity_table (required by the wave-per-world kernel)")) return rc;
     mpe::WideDesc w = make_wide(use);
     w.kind = kind;
-    return hip_result(mpe::launch_wide(phys, out, w, *b, (size_t)B, s, nullptr, stage), what);
+    return hip_result(mpe::launch_wide(phys, out, w, *b, (size_t)B, s), what);
   }
   return fail(MPE_EUNSUPPORTED, "%s: no kernel for kind=%d A=%d L=%d n_adv=%d", what, d->kind, d->n_agents,
               d->n_landmarks, d->n_adversaries);
@@ -280,17 +278,6 @@ int mpe_step_supported(const MpeScenarioDesc *d) {
 
 int mpe_step(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, void *stream) {
   return run("mpe_step", true, true, d, b, B, stream);
-}
-int mpe_step_stage(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, int32_t stage, void *stream) {
-  if (stage < MPE_STAGE_ALL || stage > MPE_STAGE_ROWS) return fail(MPE_EINVAL, "mpe_step_stage: bad stage %d", stage);
-  return run("mpe_step_stage", true, true, d, b, B, stream, StepImpl::Split, stage);
-}
-int64_t mpe_scratch_floats(const MpeScenarioDesc *d, int64_t B) {
-  if (int rc = check_desc(d, "mpe_scratch_floats")) return rc;
-  if (B < 0) return fail(MPE_EINVAL, "mpe_scratch_floats: B < 0");
-  if (d->kind != MPE_SCN_SPREAD || d->n_agents + d->n_landmarks <= mpe::kNarrowMaxE) return 0;
-  mpe::WideDesc w = make_wide(d);
-  return (int64_t)mpe::wide_scratch_floats(w, (size_t)B);
 }
 int mpe_step_thread(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, void *stream) {
   return run("mpe_step_thread", true, true, d, b, B, stream, StepImpl::Thread);

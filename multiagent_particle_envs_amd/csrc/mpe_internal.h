@@ -27,10 +27,8 @@ struct WideDesc {
 constexpr int kEntityTableCols = 6;  // size, mass, accel, max_speed, movable, collide  -> [6][E] floats
 struct RollArgs;
 bool wide_supports(const WideDesc &d, bool out);
-constexpr int kStageAll = 0, kStageWorld = 1, kStageRows = 2;   // mpe_step_stage
 int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream,
-                const RollArgs *roll = nullptr, int stage = kStageAll);
-size_t wide_scratch_floats(const WideDesc &d, size_t B);   // 0: this shape steps in one launch
+                const RollArgs *roll = nullptr);
 
 // reset / synthetic actions / fused rollout (mpe_rng.hip)
 int launch_reset(int A, int L, const MpeBuffers &b, size_t B, const uint8_t *mask, float landmark_range,

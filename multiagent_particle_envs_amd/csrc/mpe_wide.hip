@@ -43,9 +43,6 @@
 #ifndef MPE_DUO_G
 #define MPE_DUO_G 4   // worlds per workgroup of k_duo (1, 2, 4 or 8)
 #endif
-#ifndef MPE_DUO_STAGED
-#define MPE_DUO_STAGED 1   // with MpeBuffers.scratch: two launches (world + memory-order rows) instead of one
-#endif
 // ablation builds (tools/ab_build.sh): bit 0 skip the reward, bit 1 skip the contact loop, bit 2 skip the row stores
 #ifndef MPE_DUO_ABLATE
 #define MPE_DUO_ABLATE 0
@@ -699,13 +696,7 @@ __host__ __device__ inline DuoCarve duo_carve(int A, int L) {
   return c;
 }
 
-// floats per world of the scratch block: Q [E] float2 in observation order, then V [A] float2 (16-byte multiple)
-__host__ __device__ inline size_t scratch_stride(int A, int L) { return 2 * (size_t)((A + L + A + 1) & ~1); }
-
-// ROWS = false is the first of TWO launches (mpe_step with MpeBuffers.scratch set): instead of emitting rows the even
-// waves leave a world-major copy of the post-step world in the scratch block, and k_rows (below) writes the
-// observation block in MEMORY order from it.
-template <int G, bool ROWS>
+template <int G>
 __global__ void __launch_bounds__(2 * G * kWave)
 k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -811,14 +802,7 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   __syncthreads();
 
   if (role == 0) {
-    if (!wok) return;
-    if (ROWS) {
-      if (!(MPE_DUO_ABLATE & 4)) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
-    } else {   // the world, as the row kernel wants it: one contiguous block, 8-byte pieces, 512 B per wave store
-      float2 *const S = reinterpret_cast<float2 *>(b.scratch + w * scratch_stride(A, L));
-      for (int e = lane; e < E; e += kWave) S[e] = Q[e];
-      if (lane < A) S[E + lane] = V[lane];
-    }
+    if (wok && !(MPE_DUO_ABLATE & 4)) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
     return;
   }
 
@@ -885,55 +869,7 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   } else if (b.done && lane < A) {
     b.done[(size_t)lane * B + w] = 0;
   }
-  if (ROWS && !(MPE_DUO_ABLATE & 4)) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
-}
-
-// The observation block of simple_spread written in MEMORY order (second launch of the staged step): within agent
-// block i, wave r writes row r -- consecutive waves and workgroups write consecutive addresses, blocks in dispatch
-// order, like a fill.  Why:
-// a fill of these 403 MB (B = 4096, N = 64) takes 59-60 us in every process, the same bytes written as one 1.5 KB
-// row per wave, 4096 waves at 64 places each (k_wave, k_duo<ROWS>) take 60 OR 73 us depending on where the
-// process's buffers landed physically (tools/ubench/store_pattern.hip; padding the blocks apart does not help).
-// Inputs come from the world-major scratch copy the first launch left (1.5 KB per world, L2 / Infinity-Cache
-// resident): pos_i and vel_i are broadcast within a row, the two operands of a piece are adjacent entities.
-// Same subtraction on the same values as emit_rows_fast: bit-identical rows.
-__global__ void __launch_bounds__(256)
-k_rows(const float *__restrict__ scratch, float *__restrict__ obs, const unsigned B, const int A, const int L, const int D) {
-  // a wave per row: wave r of agent block i (= blockIdx.y) writes row w = r -- consecutive waves and workgroups write
-  // consecutive 4 D-byte rows; lane -> pieces lane, lane + 64 (P <= 128): no index arithmetic beyond the row number
-  const int E = A + L, P = D >> 2, kpz = 2 + L + (A - 1);
-  const int lane = threadIdx.x & (kWave - 1);
-  const unsigned w = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (w >= B) return;   // wave-uniform
-  const int i = blockIdx.y, thr = L + i;
-  const float2 *const S = reinterpret_cast<const float2 *>(scratch + (size_t)w * scratch_stride(A, L));
-  const float2 me = S[thr];
-  float *const row = obs + ((size_t)i * B + w) * (size_t)D;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int q = lane + kWave * k;
-    if (kWave * k >= P) break;   // uniform
-    float4 o;
-    {
-      const int kp = 2 * q, idx = kp - 2;
-      const float2 pj = S[min(max(idx + (idx >= thr ? 1 : 0), 0), E - 1)];
-      o.x = pj.x - me.x;
-      o.y = pj.y - me.y;
-      if (kp >= kpz) { o.x = 0.f; o.y = 0.f; }
-    }
-    {
-      const int kp = 2 * q + 1, idx = kp - 2;
-      const float2 pj = S[min(max(idx + (idx >= thr ? 1 : 0), 0), E - 1)];
-      o.z = pj.x - me.x;
-      o.w = pj.y - me.y;
-      if (kp >= kpz) { o.z = 0.f; o.w = 0.f; }
-    }
-    if (q == 0) {   // the row's header
-      const float2 vel = S[E + i];
-      o = make_float4(vel.x, vel.y, me.x, me.y);
-    }
-    if (q < P) *reinterpret_cast<float4 *>(row + 4 * q) = o;
-  }
+  if (!(MPE_DUO_ABLATE & 4)) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
 }
 
 // ---- several worlds per wave: the mid-size regime (7 <= A, L <= 32) ------------------------------------------
@@ -1214,19 +1150,8 @@ bool wide_supports(const WideDesc &d, bool out) {
   return cv.shared_bytes + kWavesPerWg * cv.wave_bytes <= kMaxLds;
 }
 
-size_t wide_scratch_floats(const WideDesc &d, size_t B) {
-  MpeBuffers probe;
-  std::memset(&probe, 0, sizeof(probe));   // alignment of obs is checked at launch; the shape decides here
-  const int amax = d.A > d.L ? d.A : d.L;
-  const bool shape = d.kind == MPE_SCN_SPREAD && d.homo && d.dim_c == 2 && amax > 32 && d.A <= kWave && d.L <= kWave &&
-                     (d.D & 3) == 0 && d.D <= 8 * kWave && MPE_DUO_ENABLE && MPE_DUO_STAGED;
-  return shape ? B * scratch_stride(d.A, d.L) : 0;
-}
-
 int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream,
-                const RollArgs *roll, int stage) {
-  if (stage == kStageRows && !(phys && out && !roll && b.scratch && duo_eligible(d, b, B, phys, out, false)))
-    return 0;   // shapes that step in one launch did everything in the first stage
+                const RollArgs *roll) {
   if (out && d.kind != MPE_SCN_SPREAD && d.kind != MPE_SCN_TAG) return MPE_EUNSUPPORTED;
   if (out && (d.dim_c != 2 || (d.D & 1))) return MPE_EUNSUPPORTED;
   const Carve cv = carve(d.A, d.L);
@@ -1259,17 +1184,7 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
     const size_t padded_w = (B + 255) / 256 * 256;   // whole 256-world blocks of the XCD map
     if (padded_w <= 0x7fffffffull) {
       const size_t dlds = (size_t)G * duo_carve(d.A, d.L).slot_bytes;
-      const dim3 dgrid((unsigned)(padded_w / G)), dblock(2 * G * kWave);
-      const size_t pieces = B * (size_t)(d.D >> 2);
-      if (b.scratch && pieces < 0x7fffffffull && MPE_DUO_STAGED) {
-        // staged: World.step + reward + a world-major copy of the new world, then the rows in memory order
-        if (stage != kStageRows) hipLaunchKernelGGL((k_duo<G, false>), dgrid, dblock, dlds, stream, d, b, B);
-        if (stage != kStageWorld)
-          hipLaunchKernelGGL(k_rows, dim3((unsigned)((B + 3) / 4), (unsigned)d.A), dim3(256), 0, stream, b.scratch,
-                             b.obs, (unsigned)B, d.A, d.L, d.D);
-        return (int)hipGetLastError();
-      }
-      if (stage != kStageRows) hipLaunchKernelGGL((k_duo<G, true>), dgrid, dblock, dlds, stream, d, b, B);
+      hipLaunchKernelGGL(k_duo<G>, dim3((unsigned)(padded_w / G)), dim3(2 * G * kWave), dlds, stream, d, b, B);
       return (int)hipGetLastError();
     }
   }

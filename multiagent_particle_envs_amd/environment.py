@@ -67,8 +67,6 @@ class _OutputSet(object):
             b.choice = w.choice_i32.data_ptr()
         if env._comm is not None:         # communication action rows = the agents' comm state
             b.comm = env._comm.data_ptr()
-        if env._scratch is not None:      # work area of the staged (two-launch) large-N step
-            b.scratch = env._scratch.data_ptr()
         self.bufs = b
         self.bufs_ref = C.byref(b)
         self.reward_n = [self.rew[i] for i in range(A)]
@@ -194,13 +192,6 @@ class MultiAgentEnv(object):
         self._ids = None
         self._comm = None
         self._entity_table = None
-        self._scratch = None
-        self.staged_step = False  # True (before the first step): hand the library its optional scratch area
-        #                           (mpe_scratch_floats): 33..64-agent simple_spread then steps as World.step + rewards,
-        #                           then memory-order rows (two launches) instead of the single-launch kernel.  Measured
-        #                           (DESIGN.md 6): back to back on one stream the pair is 1-4 us SLOWER than the single
-        #                           launch (its reward arithmetic no longer hides under row stores); it pays when the two
-        #                           halves of consecutive steps overlap (RandomRollout.enqueue_pipelined)
         self.shared_viewer = shared_viewer
 
     def refresh_constants(self):
@@ -265,8 +256,6 @@ class MultiAgentEnv(object):
         self._mpe_step = _abi.lib().mpe_step_thread if self.step_impl == "thread" else _abi.lib().mpe_step
         if self._kind in _abi.COMM_KINDS:
             self._comm = torch.zeros((A, B, w.dim_c), dtype=torch.float32, device=w.device)
-        n_scratch = int(_abi.lib().mpe_scratch_floats(self._desc_ref, B)) if self.staged_step else 0
-        self._scratch = torch.empty(n_scratch, dtype=torch.float32, device=w.device) if n_scratch > 0 else None
         self._sets = [_OutputSet(self), _OutputSet(self)]
         self._act = torch.zeros((A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=w.device)
         self._ids = torch.zeros((A, B), dtype=torch.int32, device=w.device)

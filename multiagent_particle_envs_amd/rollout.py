@@ -106,80 +106,6 @@ class RandomRollout(object):
         torch.cuda.current_stream(self.world.device).wait_stream(s)
         return g
 
-    @property
-    def can_pipeline(self):
-        """True when `mpe_step` has a staged form for this env's shape (mpe_scratch_floats > 0)."""
-        if getattr(self, "_scratch_floats", None) is None:
-            self._scratch_floats = int(self._L.mpe_scratch_floats(C.byref(self._desc), self.B))
-        return self._scratch_floats > 0
-
-    def enqueue_pipelined(self, steps, streams=None):
-        """The same `steps` env steps with the two halves of CONSECUTIVE steps overlapped (`mpe_step_stage`): the current
-        stream runs reset / move draw / World.step + rewards of step t+1 while a side stream still writes the observation
-        rows of step t from that step's scratch copy (two scratch areas, alternating).  Legal because the moves of a random
-        rollout do not depend on the observations; every step's outputs are what the sequential form writes, only
-        their completion order across streams differs.  Call inside a graph capture or eagerly; joins on the
-        current stream before returning."""
-        env, w = self.env, self.world
-        if not self.can_pipeline:
-            return self.enqueue(steps)
-        L, desc, B, dev = self._L, self._desc, self.B, w.device
-        if getattr(self, "_pipe_scratch", None) is None:    # two scratch areas of the rollout's own, alternating by step
-            self._pipe_scratch = tuple(torch.empty(self._scratch_floats, dtype=torch.float32, device=dev) for _ in range(2))
-            self._row_stream = streams or torch.cuda.Stream(device=dev)
-        sR = self._row_stream
-        cur = torch.cuda.current_stream(dev)
-        scr = self._pipe_scratch
-
-        def world_stage(t):      # on the current stream: reset / move draw / World.step + rewards of global step t
-            st = self._stream()
-            if self.regenerate and t % len(self.pool) == 0:
-                self._fill_pool(t, st)
-            if self.episode_len and t % self.episode_len == 0:
-                _abi.check(L.mpe_reset(C.byref(self._gen_desc), C.byref(env._sets[0].bufs), B, None, self._lr, self.seed,
-                                       t // self.episode_len, int(w.world_offset), st), "mpe_reset")
-            b = env._sets[t & 1].bufs
-            b.act = self.pool[t % len(self.pool)].data_ptr()
-            b.ids = b.u = None
-            b.scratch = scr[t & 1].data_ptr()
-            _abi.check(L.mpe_step_stage(C.byref(desc), C.byref(b), B, _abi.MPE_STAGE_WORLD, st), "mpe_step_stage")
-
-        # fork / join only (the shape HIP-graph capture digests): rows of step t on the side stream while the current
-        # stream already runs the world stage of step t+1; the join at the end of the iteration orders rows(t) before
-        # world(t+2), which reuses its scratch area and output set
-        t0, t1 = self.t, self.t + steps
-        world_stage(t0)
-        for t in range(t0, t1):
-            sR.wait_stream(cur)
-            with torch.cuda.stream(sR):
-                b = env._sets[t & 1].bufs
-                b.scratch = scr[t & 1].data_ptr()
-                _abi.check(L.mpe_step_stage(C.byref(desc), C.byref(b), B, _abi.MPE_STAGE_ROWS, _abi.raw_stream(dev)),
-                           "mpe_step_stage")
-            if t + 1 < t1:
-                world_stage(t + 1)
-            cur.wait_stream(sR)
-        self.t = t1
-        for out in env._sets:      # back to the env's own choice (staged_step) for its sequential steps
-            out.bufs.scratch = env._scratch.data_ptr() if env._scratch is not None else None
-        self._mark_stale()
-        return env._sets[(self.t - 1) & 1]
-
-    def capture_pipelined(self, steps):
-        """`enqueue_pipelined(steps)` captured into a HIP graph (two-stream fork / join inside the graph)."""
-        g = torch.cuda.CUDAGraph()
-        s = torch.cuda.Stream(device=self.world.device)
-        s.wait_stream(torch.cuda.current_stream(self.world.device))
-        t0 = self.t
-        with torch.cuda.stream(s):
-            self.enqueue_pipelined(2)          # warm the code objects / create the side streams outside capture
-            self.t = t0
-            torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=s):
-                self.enqueue_pipelined(steps)
-        torch.cuda.current_stream(self.world.device).wait_stream(s)
-        return g
-
     def fused(self, steps, trajectory=None):
         """One `mpe_rollout_random` launch covering `steps` env steps.  With `trajectory` (a
         Trajectory of at least `steps` blocks) every step's outputs land in their own block;
@@ -281,8 +207,6 @@ class Trajectory(object):
             b.entity_table = env._entity_table.data_ptr()
         if w.choice_i32 is not None:
             b.choice = w.choice_i32.data_ptr()
-        if env._scratch is not None:
-            b.scratch = env._scratch.data_ptr()
         self.bufs = b
 
 

@@ -648,7 +648,7 @@ def test_two_waves_per_world_kernel_is_bit_identical_to_the_wave_per_world_kerne
     import ctypes as C
     from multiagent_particle_envs_amd import _abi
     L_ = _abi.lib()
-    for N, B, staged in ((64, 300, True), (64, 300, False), (40, 77, True), (40, 77, False), (33, 1000, True)):
+    for N, B in ((64, 300), (40, 77), (33, 1000)):
         rs = np.random.RandomState(N)
         pos = rs.uniform(-1, 1, (B, 2 * N, 2)).astype(np.float32)
         pos[::2] *= 0.5
@@ -656,11 +656,9 @@ def test_two_waves_per_world_kernel_is_bit_identical_to_the_wave_per_world_kerne
         act = torch.as_tensor(rs.uniform(-1, 1, (N, B, 5)).astype(np.float32)).cuda()
         e1 = mpe.make_env("simple_spread", benchmark=True, batch_size=B, num_agents=N)
         e2 = mpe.make_env("simple_spread", benchmark=True, batch_size=B, num_agents=N)
-        e1.staged_step = staged      # True: k_duo<no rows> + k_rows (two launches);  False: k_duo emitting its own rows
         for e in (e1, e2):
             e.world.set_state(pos, vel)
             e._ensure_buffers()
-        assert (e1._scratch is not None) == (staged and (4 + 6 * N - 4) % 4 == 0)   # N = 33: rows of 198 floats, k_wave
         o1, r1, _, i1 = e1.step(act)
         out = e2._sets[0]
         b = out.bufs
@@ -675,43 +673,3 @@ def test_two_waves_per_world_kernel_is_bit_identical_to_the_wave_per_world_kerne
             assert torch.equal(r1[i], out.reward_n[i]), (N, i)
         for k in ("rew", "collisions", "min_dists", "occupied_landmarks"):
             assert torch.equal(e1._sets[e1._flip].info[k], out.info[k]), k
-
-
-def test_step_stages_compose_to_the_step():
-    """mpe_step_stage: WORLD followed by ROWS writes what mpe_step writes (N = 64: the staged shape); for a shape that
-    steps in one launch WORLD is the whole step and ROWS a no-op; mpe_scratch_floats tells which is which."""
-    import ctypes as C
-    from multiagent_particle_envs_amd import _abi
-    L_ = _abi.lib()
-    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for N, B in ((64, 129), (3, 500)):
-        rs = np.random.RandomState(7)
-        pos = (rs.uniform(-1, 1, (B, 2 * N, 2)) * 0.6).astype(np.float32)
-        vel = rs.uniform(-1, 1, (B, N, 2)).astype(np.float32)
-        act = torch.as_tensor(rs.uniform(-1, 1, (N, B, 5)).astype(np.float32)).cuda()
-        envs = [mpe.make_env("simple_spread", batch_size=B, num_agents=N) for _ in range(2)]
-        for e in envs:
-            e.staged_step = True
-            e.world.set_state(pos, vel)
-            e._ensure_buffers()
-        assert (envs[0]._scratch is not None) == (N == 64)
-        n = L_.mpe_scratch_floats(C.byref(envs[0].world.scenario_desc(_abi.MPE_SCN_SPREAD)), B)
-        if n:
-            assert envs[0]._scratch.numel() == n
-        outs = []
-        for e, stages in zip(envs, ((_abi.MPE_STAGE_ALL,), (_abi.MPE_STAGE_WORLD, _abi.MPE_STAGE_ROWS))):
-            out = e._sets[0]
-            out.obs.fill_(-7.0)
-            b = out.bufs
-            b.act, b.ids, b.u = act.data_ptr(), None, None
-            for k, stage in enumerate(stages):
-                _abi.check(L_.mpe_step_stage(C.byref(e._desc), C.byref(b), B, stage, st()), "mpe_step_stage")
-                if N == 64 and stage == _abi.MPE_STAGE_WORLD:
-                    torch.cuda.synchronize()
-                    assert float(out.obs.max()) == -7.0          # no observation row before the ROWS stage ...
-                    assert not torch.equal(e.world.pos, torch.as_tensor(pos).permute(1, 2, 0).cuda())   # ... the state has moved
-            outs.append(out)
-        assert torch.equal(envs[0].world.pos, envs[1].world.pos) and torch.equal(envs[0].world.vel, envs[1].world.vel)
-        assert torch.equal(outs[0].obs, outs[1].obs) and torch.equal(outs[0].rew, outs[1].rew)
-        assert not bool((outs[0].obs == -7.0).any())     # every float of the block was written
-    assert L_.mpe_step_stage(C.byref(envs[0]._desc), C.byref(outs[0].bufs), 1, 3, None) == -1

@@ -175,26 +175,3 @@ def test_rollout_outputs_against_oracle():
             got = traj.obs[t][i].cpu().numpy()
             assert np.abs(got - obs64[i]).max() < 2e-5          # free-running, 3 steps
         assert np.abs(traj.rew[t].cpu().numpy() - rew64).max() < 1e-4
-
-
-@pytest.mark.parametrize("N,B", [(64, 300), (40, 64)])
-def test_pipelined_rollout_equals_sequential(N, B):
-    """RandomRollout.enqueue_pipelined / capture_pipelined: World.step of step t+1 overlaps the observation rows of step
-    t on a second stream (mpe_step_stage, two alternating scratch areas).  Every output must be what the sequential
-    rollout writes -- checked with fresh moves every step and a reset cadence that is not a multiple of 2."""
-    K = 23
-    envs = [mpe.make_env("simple_spread", batch_size=B, num_agents=N, seed=4) for _ in range(3)]
-    rolls = [RandomRollout(e, episode_len=5, pool=5, regenerate=True) for e in envs]
-    assert rolls[0].can_pipeline and envs[1]._scratch is None        # the pipelined rollout brings its own scratch areas
-    last = [rolls[0].enqueue(K), rolls[1].enqueue_pipelined(K)]
-    g = rolls[2].capture_pipelined(K)
-    g.replay()
-    torch.cuda.synchronize()
-    last.append(envs[2]._sets[(K - 1) & 1])
-    for e in envs[1:]:
-        assert torch.equal(e.world.pos, envs[0].world.pos) and torch.equal(e.world.vel, envs[0].world.vel)
-        for s_ in range(2):      # both ping-pong sets: steps K-1 and K-2
-            assert torch.equal(e._sets[s_].obs, envs[0]._sets[s_].obs)
-            assert torch.equal(e._sets[s_].rew, envs[0]._sets[s_].rew)
-    small = RandomRollout(mpe.make_env("simple_spread", batch_size=64), episode_len=5)
-    assert not small.can_pipeline and small.enqueue_pipelined(3) is not None      # falls back to the sequential form
