@@ -249,7 +249,14 @@ class Leg(object):
         bytes_step = algorithmic_bytes(self.A, self.Lm, obs_total, len(env.world.choice_pops), speakers * env.world.dim_c)
         compulsory_roll = 4 * (obs_total + self.A) + self.A    # a fused rollout keeps state on chip and draws moves in-kernel
         A, Lm = self.A, self.Lm
-        kname = "mpe::k_split" if A + Lm <= 16 else ("mpe::k_multi" if max(A, Lm) <= 32 and A + Lm <= 64 else "mpe::k_wave")
+        if A + Lm <= 16:
+            kname = "mpe::k_split"
+        elif max(A, Lm) <= 32 and A + Lm <= 64 and self.scenario == "simple_spread":
+            kname = "mpe::k_multi"
+        elif self.scenario == "simple_spread" and max(A, Lm) <= 64 and (obs_total // A) % 4 == 0:
+            kname = "mpe::k_duo<4>"
+        else:
+            kname = "mpe::k_wave"
         return obs_total, bytes_step, compulsory_roll, kname
 
     def fused_steps(self, roll, n):
@@ -481,7 +488,7 @@ def main():
         return bench_generic(args, leg.env, dev, rank, world, _Sh)
     A, Lm = leg.A, leg.Lm
     obs_total, bytes_step, compulsory_roll, kname = leg.geometry()
-    can_fuse = A + Lm <= 16 and leg.env._kind not in (6, 7, 8, 9) or args.scenario == "simple_spread"
+    can_fuse = leg.env._kind not in (6, 7, 8, 9) and (A + Lm <= 16 or args.scenario in ("simple_spread", "simple_tag"))
 
     if args.dump_state:
         import numpy as np
