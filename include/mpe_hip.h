@@ -174,6 +174,12 @@ int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, ui
 int mpe_random_actions_block(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed,
                              uint64_t step0, int32_t T, int64_t world_offset, void *stream);
 
+/* Uniform random WORDS for the communication scenarios: one-hot rows into comm [A][B][dim_c] for the agents whose
+ * bit is set in `speakers` (bit a = agent a; rows of the others are left alone) -- the communication half of a
+ * random action (environment.py:183-190), keyed by (seed, global world, step, agent) like the moves.           */
+int mpe_random_comm(float *comm, int32_t n_agents, int64_t B, int32_t dim_c, uint32_t speakers, uint64_t seed,
+                    uint64_t step, int64_t world_offset, void *stream);
+
 /* 1 when mpe_step / mpe_observe have a fused kernel for this descriptor (kind, agent / landmark /
  * adversary counts, dim_c), 0 when the caller must keep Scenario.observation / reward itself and
  * use mpe_world_step (e.g. simple_tag with other team sizes than simple_tag.py:10-12), < 0 on an
@@ -196,7 +202,11 @@ int mpe_episode_tick(int32_t *episode_step, uint8_t *done, int32_t n_agents, int
  * last step.  Every step's obs/rew/done/info ARE written: with trajectory != 0 the output buffers
  * hold T consecutive per-step blocks (obs: T x [B*obs_off[A]] floats; rew/done/info: T x [A][B]),
  * with trajectory == 0 step t overwrites the single block.
- * Bit-identical to T x { [mpe_reset]; mpe_random_actions(step0+t); mpe_step }.                  */
+ * Bit-identical to T x { [mpe_reset]; mpe_random_actions(step0+t); mpe_step }.
+ * Communication scenarios (kinds 6-9): the speaking agents' words are drawn in-kernel too (the rows
+ * mpe_random_comm(step0+t) writes: speaker_listener agent 0, reference agents 0-1, crypto agents 0-2, world_comm
+ * agent 0), per-world picks are re-drawn by the in-kernel resets, and bufs->comm receives the words of the LAST
+ * step (the agents' comm state afterwards) -- this one entry point writes through the `comm` pointer.          */
 int mpe_rollout_random(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, int32_t T,
                        int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0,
                        int64_t world_offset, int32_t trajectory, void *stream);

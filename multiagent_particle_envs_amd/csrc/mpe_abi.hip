@@ -342,6 +342,16 @@ int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, ui
   return mpe_random_actions_block(act, ids, n_agents, B, seed, step, 1, world_offset, stream);
 }
 
+int mpe_random_comm(float *comm, int32_t n_agents, int64_t B, int32_t dim_c, uint32_t speakers, uint64_t seed,
+                    uint64_t step, int64_t world_offset, void *stream) {
+  const char *what = "mpe_random_comm";
+  if (!comm) return fail(MPE_EINVAL, "%s: comm is NULL", what);
+  if (n_agents < 1 || n_agents > 32 || B < 0 || dim_c < 1) return fail(MPE_EINVAL, "%s: bad n_agents/B/dim_c", what);
+  if (B == 0 || speakers == 0) return 0;
+  return hip_result(mpe::launch_random_comm(comm, n_agents, (size_t)B, dim_c, speakers, seed, step, (uint64_t)world_offset,
+                                            static_cast<hipStream_t>(stream)), what);
+}
+
 int mpe_episode_tick(int32_t *episode_step, uint8_t *done, int32_t n_agents, int64_t B, int32_t max_episode_steps,
                      int32_t clear_finished, void *stream) {
   const char *what = "mpe_episode_tick";
@@ -362,8 +372,8 @@ int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
   if (int rc = check_info(d, b, what)) return rc;
   if (d->n_choices > 0 && d->kind >= MPE_SCN_ADVERSARY)
     if (int rc = need(b->choice, what, "choice (the per-world picks of reset_world)")) return rc;
-  if (d->kind >= MPE_SCN_SPEAKER_LISTENER)
-    return fail(MPE_EUNSUPPORTED, "%s: the random rollout draws moves only; communication scenarios step through mpe_step", what);
+  if (d->kind >= MPE_SCN_SPEAKER_LISTENER)   // the speaking agents' words are drawn in-kernel; their last words are left in comm
+    if (int rc = need(b->comm, what, "comm (receives the agents' comm state after the last step)")) return rc;
   if (T < 0 || episode_len < 0) return fail(MPE_EINVAL, "%s: T, episode_len must be >= 0", what);
   if (B == 0 || T == 0) return 0;
   mpe::RollArgs ra;

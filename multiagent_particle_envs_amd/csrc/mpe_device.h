@@ -198,6 +198,7 @@ __host__ __device__ inline float uniform_pm(uint32_t bits, float r) {
 constexpr uint32_t kStreamReset = 0x52455345u;   // "RESE"
 constexpr uint32_t kStreamAction = 0x41435449u;  // "ACTI"
 constexpr uint32_t kStreamChoice = 0x43484f49u;  // "CHOI"
+constexpr uint32_t kStreamComm = 0x434f4d4du;    // "COMM"
 
 // Position pair of entity e in world b for episode `ep`.
 __host__ __device__ inline void reset_draw(uint64_t seed, uint64_t b, uint64_t ep, int e, float r,
@@ -233,6 +234,18 @@ __host__ __device__ inline int action_draw(uint64_t seed, uint64_t b, uint64_t t
   const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   const uint32_t w = (i & 3) == 0 ? o.x : (i & 3) == 1 ? o.y : (i & 3) == 2 ? o.z : o.w;
   return (int)(((uint64_t)w * 5u) >> 32);
+}
+
+// Uniform word in {0..n-1} agent i of world b says at global step `t` (one-hot communication action, environment.py:183-190).
+__host__ __device__ inline int comm_draw(uint64_t seed, uint64_t b, uint64_t t, int i, int n) {
+  U4 c;
+  c.x = (uint32_t)b;
+  c.y = (uint32_t)(b >> 32) ^ (uint32_t)(t >> 32);
+  c.z = (uint32_t)(i >> 2);
+  c.w = kStreamComm ^ (uint32_t)t;
+  const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t w = (i & 3) == 0 ? o.x : (i & 3) == 1 ? o.y : (i & 3) == 2 ? o.z : o.w;
+  return (int)(((uint64_t)w * (uint32_t)n) >> 32);
 }
 
 // ---- wave-private LDS transpose: 64 per-lane rows of D floats -> one contiguous 64*D-float run ----

@@ -77,6 +77,26 @@ k_random_actions(float *__restrict__ act, int32_t *__restrict__ ids, size_t B, i
   }
 }
 
+// Uniform random words of the agents that speak: one-hot rows into comm [A][B][dim_c] (communication scenarios'
+// synthetic workload; the rows the fused rollout recomputes in-kernel).  One thread per (world, agent).
+__global__ void __launch_bounds__(kBlock)
+k_random_comm(float *__restrict__ comm, size_t B, int dim_c, unsigned speakers, uint64_t seed, uint64_t step,
+              uint64_t world_offset) {
+  const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (w >= B || !((speakers >> i) & 1u)) return;
+  const int id = comm_draw(seed, world_offset + w, step, i, dim_c);
+  float *row = comm + ((size_t)i * B + w) * dim_c;
+  for (int c = 0; c < dim_c; ++c) row[c] = c == id ? 1.f : 0.f;
+}
+
+int launch_random_comm(float *comm, int A, size_t B, int dim_c, unsigned speakers, uint64_t seed, uint64_t step,
+                       uint64_t world_offset, hipStream_t stream) {
+  const dim3 grid((unsigned)((B + kBlock - 1) / kBlock), (unsigned)A);
+  hipLaunchKernelGGL(k_random_comm, grid, dim3(kBlock), 0, stream, comm, B, dim_c, speakers, seed, step, world_offset);
+  return (int)hipGetLastError();
+}
+
 // Episode bookkeeping (new API, SURVEY 8 f1: the reference never ends an episode, environment.py:132-135): one
 // thread per world bumps the world's step counter, ORs "horizon reached" into the A done rows the step kernel (zeros)
 // or the done_callback wrote, and clears the counter of a finished world when its reset follows (auto-reset).

@@ -60,12 +60,36 @@ struct SplitShape {
   }
 };
 
+// Which agents speak in the communication scenarios (their make_world: `agent.silent = False`), bit a = agent a.
+template <int KIND>
+constexpr unsigned speakers_of() {
+  return KIND == MPE_SCN_SPEAKER_LISTENER ? 0x1u : KIND == MPE_SCN_REFERENCE ? 0x3u : KIND == MPE_SCN_CRYPTO ? 0x7u
+         : KIND == MPE_SCN_WORLD_COMM ? 0x1u : 0u;
+}
+// The utterance of one agent in one world at this step: a row of MpeBuffers.comm (what the caller passed), or -- in
+// the fused rollout -- the one-hot of the word mpe_random_comm draws for (world, step, agent), recomputed where used.
+template <bool ROLL>
+struct Word {
+  const float *row;
+  int id;
+  __device__ __forceinline__ float operator[](int c) const { return ROLL ? (c == id ? 1.f : 0.f) : row[c]; }
+};
+template <int DC, bool ROLL>
+__device__ __forceinline__ Word<ROLL> word_of(const MpeBuffers &b, size_t B, size_t w0, unsigned ln, int j, uint64_t seed,
+                                              uint64_t gw, uint64_t gt) {
+  Word<ROLL> wd;
+  wd.row = ROLL ? nullptr : b.comm + wave_off(((size_t)j * B + w0) * DC) + ln * DC;
+  wd.id = ROLL ? comm_draw(seed, gw, gt, j, DC) : 0;
+  return wd;
+}
+
 // ---- the reward wave: Scenario.reward / benchmark_data / done for all A agents of 64 worlds --------
 // X is the exchange block the agent waves filled: X[(a * XW + c) * 64 + lane], c = 0,1 pos, 2,3 vel, 4.. d2.
-template <int KIND, int A, int L, int NADV>
+template <int KIND, int A, int L, int NADV, bool ROLL>
 __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffers &b, const float *X, int lane,
                                             bool live, unsigned ln, size_t B, size_t w0 /* first world of the wave */,
-                                            size_t ro /* uniform: row 0 of this step + w0 */) {
+                                            size_t ro /* uniform: row 0 of this step + w0 */, uint64_t seed, uint64_t gw,
+                                            uint64_t gt, int goal_roll /* rollout: this world's pick 0 */) {
   constexpr int XW = SplitShape<KIND, A, L, NADV>::XW;
   if (KIND == MPE_SCN_SIMPLE) {  // simple.py:41-43: -|pos - landmark 0|^2
     if (live) {
@@ -242,11 +266,11 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
   if constexpr (KIND == MPE_SCN_CRYPTO) {  // simple_crypto.py:97-124: squared error of what Bob / Eve say against the goal one-hot
     constexpr int DC = SplitShape<KIND, A, L, NADV>::DC;
     if (live) {
-      const int g = (b.choice + wave_off(w0))[ln];
+      const int g = ROLL ? goal_roll : (b.choice + wave_off(w0))[ln];
       float err[2];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {   // a = 0: Eve (adversary), a = 1: Bob (good listener)
-        const float *c = b.comm + wave_off(((size_t)a * B + w0) * DC) + ln * DC;
+        const Word<ROLL> c = word_of<DC, ROLL>(b, B, w0, ln, a, seed, gw, gt);
         float e = 0.f;
         bool silent = true;
 #pragma unroll
@@ -375,10 +399,26 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 
   if (!is_agent) {
     // ---- the reward wave --------------------------------------------------------------------------
+    // (simple_crypto's reward needs the world's goal pick: in the rollout it follows the in-kernel resets with the
+    //  same countdown the agent waves run)
+    const uint64_t gw_r = ra.world_offset + w;
+    int goal_r = (ROLL && KIND == MPE_SCN_CRYPTO) ? (b.choice + wave_off(w0))[ln] : 0;
+    int cd = -1;
+    uint64_t ep_r = 0;
+    if (ROLL && KIND == MPE_SCN_CRYPTO && ra.episode_len > 0) {
+      const uint64_t len = (uint64_t)ra.episode_len, r = ra.step0 % len;
+      cd = r == 0 ? 0 : (int)(len - r);
+      ep_r = ra.step0 / len + (r ? 1 : 0);
+    }
     for (int t = 0; t < T; ++t) {
+      if (ROLL && KIND == MPE_SCN_CRYPTO && cd >= 0) {
+        if (cd == 0) { goal_r = choice_draw(ra.seed, gw_r, ep_r, 0, d.choice_pop[0]); ++ep_r; cd = ra.episode_len - 1; }
+        else --cd;
+      }
       const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
       __syncthreads();
-      reward_wave<KIND, A, L, NADV>(d, b, X, lane, live, ln, B, w0, (size_t)t * row_stride + w0);
+      reward_wave<KIND, A, L, NADV, ROLL>(d, b, X, lane, live, ln, B, w0, (size_t)t * row_stride + w0, ra.seed, gw_r,
+                                          ra.step0 + (uint64_t)t, goal_r);
     }
     return;
   }
@@ -411,7 +451,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   constexpr int NCH = S::NCH, DC = S::DC;
   // this world's picks of reset_world (np.random.choice: goal landmark, key ...)
   int goal = NCH >= 1 ? (b.choice + wave_off(w0))[ln] : 0;
-  const int pick1 = NCH >= 2 ? (b.choice + wave_off(B + w0))[ln] : 0;
+  int pick1 = NCH >= 2 ? (b.choice + wave_off(B + w0))[ln] : 0;
   const bool step_world = ROLL || !ra.observe_only;   // mpe_observe: outputs of the current state only
 
   // resets fall on global steps that are multiples of episode_len: one 64-bit divide up front, then a
@@ -426,8 +466,8 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 
   for (int t = 0; t < T; ++t) {
     float ux, uy;
+    const uint64_t gt = ra.step0 + (uint64_t)t;   // global step: indexes the move / word streams of the rollout
     if (ROLL) {
-      const uint64_t gt = ra.step0 + (uint64_t)t;
       const bool reset_now = countdown == 0;
       if (countdown >= 0) countdown = reset_now ? ra.episode_len - 1 : countdown - 1;
       if (reset_now) {  // reset_world, as mpe_reset does it for episode ep = gt / episode_len
@@ -438,7 +478,8 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
           if (a == i) { mx = px[a]; my = py[a]; }
         mvx = 0.f;
         mvy = 0.f;
-        if (HAS_GOAL) goal = choice_draw(ra.seed, gw, ep, 0, d.choice_pop[0]);
+        if (NCH >= 1) goal = choice_draw(ra.seed, gw, ep, 0, d.choice_pop[0]);
+        if (NCH >= 2) pick1 = choice_draw(ra.seed, gw, ep, 1, d.choice_pop[1]);
         ++ep;
       }
       const int m = action_draw(ra.seed, gw, gt, i);  // the one-hot row mpe_random_actions would write
@@ -644,7 +685,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         put1<RS>(tile, lane, 0, mvx); put1<RS>(tile, lane, 1, mvy);
 #pragma unroll
         for (int l = 0; l < L; ++l) { put1<RS>(tile, lane, 2 + 2 * l, px[A + l] - mx); put1<RS>(tile, lane, 3 + 2 * l, py[A + l] - my); }
-        const float *c0 = b.comm + wave_off(((size_t)0 * B + w0) * DC) + ln * DC;
+        const Word<ROLL> c0 = word_of<DC, ROLL>(b, B, w0, ln, 0, ra.seed, gw, gt);
 #pragma unroll
         for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, 2 + 2 * L + c, c0[c]);
         flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
@@ -658,13 +699,13 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       for (int l = 0; l < L; ++l) { put1<RS>(tile, lane, 2 + 2 * l, px[A + l] - mx); put1<RS>(tile, lane, 3 + 2 * l, py[A + l] - my); }
 #pragma unroll
       for (int c = 0; c < 3; ++c) put1<RS>(tile, lane, 2 + 2 * L + c, mine == c ? 0.75f : 0.25f);   // goal_b.color
-      const float *co = b.comm + wave_off(((size_t)(1 - i) * B + w0) * DC) + ln * DC;
+      const Word<ROLL> co = word_of<DC, ROLL>(b, B, w0, ln, 1 - i, ra.seed, gw, gt);
 #pragma unroll
       for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, 5 + 2 * L + c, co[c]);
       flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
     }
     if constexpr (KIND == MPE_SCN_CRYPTO) {  // simple_crypto.py:127-169 (goal = pick 0, key = pick 1; colours are one-hots of width dim_c)
-      const float *cs = b.comm + wave_off(((size_t)2 * B + w0) * DC) + ln * DC;   // the speaker's utterance
+      const Word<ROLL> cs = word_of<DC, ROLL>(b, B, w0, ln, 2, ra.seed, gw, gt);   // the speaker's utterance
       static_assert((DC & 1) == 0, "crypto rows are written as pairs");
       if (i == 0) {          // Eve: what the speaker says
         constexpr int D = DC;
@@ -721,7 +762,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         if (ADV) {
           r.put(k, f1 ? 1.f : -1.f, f2 ? 1.f : -1.f);
           k += 2;
-          const float *cl = b.comm + wave_off(((size_t)0 * B + w0) * DC) + ln * DC;   // world.agents[0].state.c
+          const Word<ROLL> cl = word_of<DC, ROLL>(b, B, w0, ln, 0, ra.seed, gw, gt);   // world.agents[0].state.c
 #pragma unroll
           for (int c = 0; c < DC; c += 2) r.put(k + c, cl[c], cl[c + 1]);
         }
@@ -731,7 +772,17 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       else          row(std::integral_constant<int, DGd>{}, std::false_type{});
     }
   }
-  if (ROLL && HAS_GOAL && ra.episode_len > 0 && live && i == 0) (b.choice + wave_off(w0))[ln] = goal;
+  if (ROLL && NCH >= 1 && ra.episode_len > 0 && live && i == 0) {   // the picks of the last in-kernel reset
+    (b.choice + wave_off(w0))[ln] = goal;
+    if (NCH >= 2) (b.choice + wave_off(B + w0))[ln] = pick1;
+  }
+  if (ROLL && ((speakers_of<KIND>() >> i) & 1u) && live && T > 0) {
+    // update_agent_state (core.py:171-177): what agent i said at the last step is its comm state afterwards
+    float *const mine = const_cast<float *>(b.comm) + wave_off(((size_t)i * B + w0) * DC) + ln * DC;
+    const int id = comm_draw(ra.seed, gw, ra.step0 + (uint64_t)(T - 1), i, DC);
+#pragma unroll
+    for (int c = 0; c < DC; ++c) mine[c] = c == id ? 1.f : 0.f;
+  }
   if (ROLL && ra.episode_len > 0 && live) {
     // in-kernel resets moved the landmarks: hand their positions back (wave i writes landmarks l = i mod A)
 #pragma unroll

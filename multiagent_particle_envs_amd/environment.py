@@ -330,10 +330,11 @@ class MultiAgentEnv(object):
         sc, w = self._scenario if self._scenario is not None else getattr(self, "scenario", None), self.world
         if sc is not None and hasattr(sc, "_apply"):
             sc._apply(w)
-        for agent in w.agents:   # every reset_world leaves state.c = 0; the random rollouts never speak
-            agent.state.c = torch.zeros((self.batch_size, w.dim_c), dtype=torch.float32, device=w.device)
-        if self._comm is not None:
-            self._comm.zero_()
+        for i, agent in enumerate(w.agents):   # update_agent_state: silent agents 0, the others their last words
+            if self._comm is not None and not agent.silent:
+                agent.state.c = self._comm[i]
+            else:
+                agent.state.c = torch.zeros((self.batch_size, w.dim_c), dtype=torch.float32, device=w.device)
 
     def step(self, action_n):
         """environment.py:80-104 for B worlds."""

@@ -37,6 +37,15 @@ class RandomRollout(object):
         self.A, self.B = A, B
         self.pool_t = torch.empty((int(pool), A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=self.world.device)
         self.pool = [self.pool_t[p] for p in range(int(pool))]
+        # communication scenarios: the agents that speak say a uniform random word per step (`mpe_random_comm`), pooled
+        # like the moves; comm tensor p holds the words of the global steps t with t % len(pool) == p
+        self.speakers = 0
+        self.pool_c = None
+        if env._comm is not None:
+            for i, agent in enumerate(self.world.agents):
+                if not agent.silent:
+                    self.speakers |= 1 << i
+            self.pool_c = torch.zeros((int(pool), A, B, int(self.world.dim_c)), dtype=torch.float32, device=self.world.device)
         self.t = 0          # global step counter (also indexes the Philox action stream)
         self.regenerate = bool(regenerate)
         self._L = _abi.lib()
@@ -58,6 +67,11 @@ class RandomRollout(object):
                                                     len(self.pool), int(self.world.world_offset),
                                                     stream if stream is not None else self._stream()),
                    "mpe_random_actions_block")
+        if self.pool_c is not None:
+            for p in range(len(self.pool)):
+                _abi.check(self._L.mpe_random_comm(self.pool_c[p].data_ptr(), self.A, self.B, int(self.world.dim_c),
+                                                   self.speakers, self.seed, int(t0) + p, int(self.world.world_offset),
+                                                   stream if stream is not None else self._stream()), "mpe_random_comm")
 
     def enqueue(self, steps):
         """Enqueue `steps` env steps (and the resets that fall among them) on the current stream."""
@@ -76,8 +90,14 @@ class RandomRollout(object):
             b.act = self.pool[self.t % len(self.pool)].data_ptr()
             b.ids = None
             b.u = None
+            if self.pool_c is not None:
+                b.comm = self.pool_c[self.t % len(self.pool)].data_ptr()
             _abi.check(L.mpe_step(C.byref(desc), C.byref(b), B, st), "mpe_step")
             self.t += 1
+        if self.pool_c is not None and steps > 0:   # the agents' comm state after the last step = their last words
+            env._comm.copy_(self.pool_c[(self.t - 1) % len(self.pool)])
+            for out in env._sets:
+                out.bufs.comm = env._comm.data_ptr()
         self._mark_stale()
         return env._sets[(self.t - 1) & 1]
 
@@ -207,6 +227,8 @@ class Trajectory(object):
             b.entity_table = env._entity_table.data_ptr()
         if w.choice_i32 is not None:
             b.choice = w.choice_i32.data_ptr()
+        if env._comm is not None:
+            b.comm = env._comm.data_ptr()
         self.bufs = b
 
 

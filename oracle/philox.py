@@ -13,6 +13,7 @@ W0, W1 = 0x9E3779B9, 0xBB67AE85
 STREAM_RESET = 0x52455345
 STREAM_ACTION = 0x41435449
 STREAM_CHOICE = 0x43484F49   # "CHOI"
+STREAM_COMM = 0x434F4D4D     # "COMM"
 MASK = np.uint64(0xFFFFFFFF)
 
 
@@ -96,5 +97,23 @@ def action_ids(seed, batch, step, n_agents, world_offset=0):
     return ids
 
 
-def one_hot(ids):
-    return np.eye(5, dtype=np.float32)[ids]
+def comm_ids(seed, batch, step, n_agents, dim_c, world_offset=0):
+    """words [A, B] int32 in {0..dim_c-1} as mpe_random_comm draws them at global step `step` (csrc/mpe_device.h comm_draw)."""
+    b = np.arange(batch, dtype=np.uint64) + np.uint64(world_offset)
+    ids = np.zeros((n_agents, batch), np.int32)
+    for quad in range((n_agents + 3) // 4):
+        c0 = b & MASK
+        c1 = ((b >> np.uint64(32)) ^ np.uint64((step >> 32) & 0xFFFFFFFF)) & MASK
+        c2 = np.full(batch, quad, np.uint64)
+        c3 = np.full(batch, (STREAM_COMM ^ (step & 0xFFFFFFFF)) & 0xFFFFFFFF, np.uint64)
+        o = philox4x32_10(c0, c1, c2, c3, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        for k in range(4):
+            i = 4 * quad + k
+            if i >= n_agents:
+                break
+            ids[i] = ((o[k].astype(np.uint64) * np.uint64(dim_c)) >> np.uint64(32)).astype(np.int32)
+    return ids
+
+
+def one_hot(ids, n=5):
+    return np.eye(n, dtype=np.float32)[ids]

@@ -62,7 +62,10 @@ def test_split_and_thread_kernels_bit_identical(name, kw, B):
                                             ("simple_spread", {"num_agents": 3, "num_landmarks": 90}, 21, 5, 3),
                                             # simple_tag at team sizes the reference does not ship: wave-per-world kernel
                                             ("simple_tag", {"num_adversaries": 5, "num_good_agents": 2, "num_landmarks": 1}, 100, 9, 4),
-                                            ("simple_tag", {"num_adversaries": 40, "num_good_agents": 30, "num_landmarks": 20}, 10, 5, 2)])
+                                            ("simple_tag", {"num_adversaries": 40, "num_good_agents": 30, "num_landmarks": 20}, 10, 5, 2),
+                                            # the communication scenarios: words drawn in-kernel, picks re-drawn by in-kernel resets
+                                            ("simple_speaker_listener", {}, 700, 13, 4), ("simple_reference", {}, 333, 11, 3),
+                                            ("simple_crypto", {}, 200, 9, 4), ("simple_world_comm", {}, 129, 10, 5)])
 def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):
     seed, offset, step0 = 0xABCDEF0123, 4096, 50 if ep in (25, 0) else 14
     # --- stepwise: explicit reset / random_actions / step through the C ABI ----------------------
@@ -73,6 +76,8 @@ def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):
     L = _abi.lib()
     gen = env_a.world.scenario_desc(_abi.MPE_SCN_GENERIC)
     act = torch.zeros((A, B, 5), device="cuda")
+    speakers = sum(1 << i for i, a in enumerate(env_a.world.agents) if not a.silent) if env_a._comm is not None else 0
+    dim_c = int(env_a.world.dim_c)
     lr = env_a.scenario.landmark_range
     start_pos = env_a.world.pos.clone()
     start_vel = env_a.world.vel.clone()
@@ -84,6 +89,8 @@ def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):
         if ep and gt % ep == 0:
             _abi.check(L.mpe_reset(C.byref(gen), C.byref(b), B, None, lr, seed, gt // ep, offset, stream()))
         _abi.check(L.mpe_random_actions(act.data_ptr(), None, A, B, seed, gt, offset, stream()))
+        if speakers:   # the agents that speak say a uniform random word: rows of comm [A][B][dim_c]
+            _abi.check(L.mpe_random_comm(env_a._comm.data_ptr(), A, B, dim_c, speakers, seed, gt, offset, stream()))
         b.act, b.ids, b.u = act.data_ptr(), None, None
         _abi.check(L.mpe_step(C.byref(env_a._desc), C.byref(b), B, stream()))
         want_obs.append([o.clone() for o in env_a._sets[0].obs_n])
@@ -108,6 +115,16 @@ def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):
     assert torch.equal(env_b.world.pos, env_a.world.pos) and torch.equal(env_b.world.vel, env_a.world.vel)
     if start_choice is not None:   # in-kernel resets re-drew the goals exactly as mpe_reset does
         assert torch.equal(env_b.world.choice_i32, env_a.world.choice_i32)
+    if speakers:                   # the agents' comm state after the rollout = their last words
+        assert torch.equal(env_b._comm, env_a._comm) and float(env_b._comm.sum()) == B * bin(speakers).count("1")
+        sample = RandomRollout(env_a, episode_len=ep, pool=3, seed=seed)   # the pooled stepwise driver draws the same words
+        from oracle import philox
+        want = philox.one_hot(philox.comm_ids(seed, B, 2, A, dim_c, world_offset=offset), dim_c)
+        for i in range(A):
+            if (speakers >> i) & 1:
+                assert np.array_equal(sample.pool_c[2][i].cpu().numpy(), want[i])
+            else:
+                assert not sample.pool_c[2][i].any()
     # --- overwrite mode leaves the last step's outputs in the env's buffers --------------------------
     env_c = mpe.make_env(name, batch_size=B, seed=seed, **kw)
     env_c.world.world_offset = offset
