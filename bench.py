@@ -488,7 +488,7 @@ def main():
         return bench_generic(args, leg.env, dev, rank, world, _Sh)
     A, Lm = leg.A, leg.Lm
     obs_total, bytes_step, compulsory_roll, kname = leg.geometry()
-    can_fuse = leg.env._kind not in (6, 7, 8, 9) and (A + Lm <= 16 or args.scenario in ("simple_spread", "simple_tag"))
+    can_fuse = A + Lm <= 16 or args.scenario in ("simple_spread", "simple_tag")
 
     if args.dump_state:
         import numpy as np

@@ -89,7 +89,8 @@ template <int KIND, int A, int L, int NADV, bool ROLL>
 __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffers &b, const float *X, int lane,
                                             bool live, unsigned ln, size_t B, size_t w0 /* first world of the wave */,
                                             size_t ro /* uniform: row 0 of this step + w0 */, uint64_t seed, uint64_t gw,
-                                            uint64_t gt, int goal_roll /* rollout: this world's pick 0 */) {
+                                            uint64_t gt, int goal_roll /* rollout: this world's pick 0 */,
+                                            const float (&food_roll)[4] /* rollout, world_comm: food x0 y0 x1 y1 */) {
   constexpr int XW = SplitShape<KIND, A, L, NADV>::XW;
   if (KIND == MPE_SCN_SIMPLE) {  // simple.py:41-43: -|pos - landmark 0|^2
     if (live) {
@@ -313,9 +314,9 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
     // food = landmarks 1, 2 (world.landmarks = [obstacle] + food + forests)
     float fx[2], fy[2];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      fx[f] = (b.pos + wave_off((size_t)(2 * (A + 1 + f)) * B + w0))[ln];
-      fy[f] = (b.pos + wave_off((size_t)(2 * (A + 1 + f) + 1) * B + w0))[ln];
+    for (int f = 0; f < 2; ++f) {   // (the rollout's in-kernel resets move the landmarks: HBM holds them only at the end)
+      fx[f] = ROLL ? food_roll[2 * f] : (b.pos + wave_off((size_t)(2 * (A + 1 + f)) * B + w0))[ln];
+      fy[f] = ROLL ? food_roll[2 * f + 1] : (b.pos + wave_off((size_t)(2 * (A + 1 + f) + 1) * B + w0))[ln];
     }
     if (live) {
 #pragma unroll
@@ -399,26 +400,44 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 
   if (!is_agent) {
     // ---- the reward wave --------------------------------------------------------------------------
-    // (simple_crypto's reward needs the world's goal pick: in the rollout it follows the in-kernel resets with the
-    //  same countdown the agent waves run)
+    // (what the reward needs besides the agents' published state follows the in-kernel resets of the rollout with the
+    //  same countdown the agent waves run: simple_crypto's goal pick, simple_world_comm's food positions)
+    constexpr bool TRACK = ROLL && (KIND == MPE_SCN_CRYPTO || KIND == MPE_SCN_WORLD_COMM);
     const uint64_t gw_r = ra.world_offset + w;
     int goal_r = (ROLL && KIND == MPE_SCN_CRYPTO) ? (b.choice + wave_off(w0))[ln] : 0;
+    float food[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ROLL && KIND == MPE_SCN_WORLD_COMM) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        food[2 * f] = (b.pos + wave_off((size_t)(2 * (A + 1 + f)) * B + w0))[ln];
+        food[2 * f + 1] = (b.pos + wave_off((size_t)(2 * (A + 1 + f) + 1) * B + w0))[ln];
+      }
+    }
     int cd = -1;
     uint64_t ep_r = 0;
-    if (ROLL && KIND == MPE_SCN_CRYPTO && ra.episode_len > 0) {
+    if (TRACK && ra.episode_len > 0) {
       const uint64_t len = (uint64_t)ra.episode_len, r = ra.step0 % len;
       cd = r == 0 ? 0 : (int)(len - r);
       ep_r = ra.step0 / len + (r ? 1 : 0);
     }
     for (int t = 0; t < T; ++t) {
-      if (ROLL && KIND == MPE_SCN_CRYPTO && cd >= 0) {
-        if (cd == 0) { goal_r = choice_draw(ra.seed, gw_r, ep_r, 0, d.choice_pop[0]); ++ep_r; cd = ra.episode_len - 1; }
-        else --cd;
+      if (TRACK && cd >= 0) {
+        if (cd == 0) {
+          if (KIND == MPE_SCN_CRYPTO) goal_r = choice_draw(ra.seed, gw_r, ep_r, 0, d.choice_pop[0]);
+          if (KIND == MPE_SCN_WORLD_COMM) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f) reset_draw(ra.seed, gw_r, ep_r, A + 1 + f, ra.landmark_range, food[2 * f], food[2 * f + 1]);
+          }
+          ++ep_r;
+          cd = ra.episode_len - 1;
+        } else {
+          --cd;
+        }
       }
       const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
       __syncthreads();
       reward_wave<KIND, A, L, NADV, ROLL>(d, b, X, lane, live, ln, B, w0, (size_t)t * row_stride + w0, ra.seed, gw_r,
-                                          ra.step0 + (uint64_t)t, goal_r);
+                                          ra.step0 + (uint64_t)t, goal_r, food);
     }
     return;
   }
@@ -737,36 +756,38 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         const bool o1 = X[(j * XW + 4) * kWave + lane] > 0.f, o2 = X[(j * XW + 5) * kWave + lane] > 0.f;
         vis[j] = i == 0 || (f1 && o1) || (f2 && o2) || (!f1 && !o1 && !f2 && !o2);
       }
+      // (column-by-column 4-byte writes: building these rows from (x, y) pairs -- RowPairs, as the other scenarios do --
+      //  measured 1.5 us SLOWER here, 20.0 vs 18.6 us at B = 65536, same box)
       auto row = [&](auto dsel, auto advt) {
-        constexpr int D = decltype(dsel)::value;
+        constexpr int D = decltype(dsel)::value, RS = tile_stride<D>();
         constexpr bool ADV = decltype(advt)::value;
-        RowPairs<D> r(tile, lane);   // every field of the row is a 2-vector (the 4-wide utterance: two of them)
-        r.put(0, mvx, mvy);
-        r.put(2, mx, my);
-        int k = 4;
+        int k = 0;
+        put1<RS>(tile, lane, 0, mvx); put1<RS>(tile, lane, 1, mvy); put1<RS>(tile, lane, 2, mx); put1<RS>(tile, lane, 3, my);
+        k = 4;
 #pragma unroll
-        for (int l = 0; l < L; ++l) { r.put(k, px[A + l] - mx, py[A + l] - my); k += 2; }
+        for (int l = 0; l < L; ++l) { put1<RS>(tile, lane, k, px[A + l] - mx); put1<RS>(tile, lane, k + 1, py[A + l] - my); k += 2; }
 #pragma unroll
         for (int j = 0; j < A; ++j) {
           if (j == i) continue;
-          r.put(k, vis[j] ? px[j] - mx : 0.f, vis[j] ? py[j] - my : 0.f);
+          put1<RS>(tile, lane, k, vis[j] ? px[j] - mx : 0.f);
+          put1<RS>(tile, lane, k + 1, vis[j] ? py[j] - my : 0.f);
           k += 2;
         }
-        if (!ADV) { r.put(k, f1 ? 1.f : -1.f, f2 ? 1.f : -1.f); k += 2; }
+        if (!ADV) { put1<RS>(tile, lane, k, f1 ? 1.f : -1.f); put1<RS>(tile, lane, k + 1, f2 ? 1.f : -1.f); k += 2; }
 #pragma unroll
         for (int j = NADV; j < A; ++j) {
           if (j == i) continue;
-          r.put(k, vis[j] ? X[(j * XW + 2) * kWave + lane] : 0.f, vis[j] ? X[(j * XW + 3) * kWave + lane] : 0.f);
+          put1<RS>(tile, lane, k, vis[j] ? X[(j * XW + 2) * kWave + lane] : 0.f);
+          put1<RS>(tile, lane, k + 1, vis[j] ? X[(j * XW + 3) * kWave + lane] : 0.f);
           k += 2;
         }
         if (ADV) {
-          r.put(k, f1 ? 1.f : -1.f, f2 ? 1.f : -1.f);
-          k += 2;
+          put1<RS>(tile, lane, k, f1 ? 1.f : -1.f); put1<RS>(tile, lane, k + 1, f2 ? 1.f : -1.f); k += 2;
           const Word<ROLL> cl = word_of<DC, ROLL>(b, B, w0, ln, 0, ra.seed, gw, gt);   // world.agents[0].state.c
 #pragma unroll
-          for (int c = 0; c < DC; c += 2) r.put(k + c, cl[c], cl[c + 1]);
+          for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, k + c, cl[c]);
         }
-        flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       };
       if (i < NADV) row(std::integral_constant<int, DA>{}, std::true_type{});
       else          row(std::integral_constant<int, DGd>{}, std::false_type{});
