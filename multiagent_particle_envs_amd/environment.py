@@ -126,28 +126,34 @@ class MultiAgentEnv(object):
         kind = getattr(sc, "kind", None)
         pkg = __name__.rsplit(".", 1)[0] + ".scenarios."
         builtin = next((c for c in type(sc).__mro__ if c.__module__.startswith(pkg)), None) if sc is not None else None
+        def is_builtin(cb, name):
+            return getattr(cb, "__self__", None) is sc and getattr(cb, "__func__", None) is builtin.__dict__.get(name)
+        # the kernel side of a step (action decode, World.step, observation rows) needs the built-in observation, a
+        # reset_world of the same scenario object, no scripted agents, no action / communication noise, and a kernel
+        # for this shape; reward / benchmark_data / done may each be the built-in (computed in the same launch) or
+        # ANY Python callback (evaluated on the post-step world after the launch: "partial fusion")
         own = builtin is not None and kind is not None and \
-            getattr(reward_callback, "__self__", None) is sc and \
-            getattr(reset_callback, "__self__", None) is sc and \
-            getattr(reward_callback, "__func__", None) is builtin.__dict__.get("reward") and \
-            getattr(observation_callback, "__func__", None) is builtin.__dict__.get("observation") and \
-            (info_callback is None or (getattr(info_callback, "__self__", None) is sc and
-                                       info_callback.__func__ is builtin.__dict__.get("benchmark_data"))) and \
-            done_callback is None and len(world.scripted_agents) == 0 and \
-            all((a.silent or (kind in _abi.COMM_KINDS and not a.c_noise)) and not a.u_noise for a in world.agents) and \
-            not (info_callback is not None and kind in (_abi.MPE_SCN_ADVERSARY, _abi.MPE_SCN_PUSH))   # no fused benchmark_data there
+            getattr(reset_callback, "__self__", None) is sc and is_builtin(observation_callback, "observation") and \
+            len(world.scripted_agents) == 0 and \
+            all((a.silent or (kind in _abi.COMM_KINDS and not a.c_noise)) and not a.u_noise for a in world.agents)
         if own:   # ... and a kernel for this shape (the f3 scenarios are fused at the reference's team sizes)
             own = _abi.lib().mpe_step_supported(C.byref(world.scenario_desc(kind, getattr(sc, "num_adversaries", 0)))) == 1
+        self._py_reward = own and not is_builtin(reward_callback, "reward")
+        self._py_info = own and info_callback is not None and not (
+            is_builtin(info_callback, "benchmark_data") and kind in (_abi.MPE_SCN_SPREAD, _abi.MPE_SCN_TAG))
+        self._py_done = own and done_callback is not None
         if fused is None:
             fused = own
         if fused and not own:
-            raise _abi.MpeError("fused=True needs the unmodified callbacks of a built-in scenario at a shape libmpe_hip.so has a "
-                                "kernel for (mpe_step_supported)")
+            raise _abi.MpeError("fused=True needs the unmodified observation callback of a built-in scenario at a shape "
+                                "libmpe_hip.so has a kernel for (mpe_step_supported), without scripted agents or noise")
         self.fused = bool(fused)
         self._comm_kind = self.fused and kind in _abi.COMM_KINDS
         self._scenario = sc
         self._kind = kind if self.fused else _abi.MPE_SCN_GENERIC
-        self._benchmark = self.fused and info_callback is not None
+        self._benchmark = self.fused and info_callback is not None and not self._py_info
+        if not self.fused:
+            self._py_reward = self._py_info = self._py_done = False
 
         # ---- spaces (environment.py:38-70) -------------------------------------------------------------
         self.action_space = []
@@ -353,6 +359,8 @@ class MultiAgentEnv(object):
         b.act = act.data_ptr() if act is not None else None
         b.ids = ids.data_ptr() if ids is not None else None
         b.u = None
+        if self._py_reward:          # the reward is a Python callback: the launch skips its reward stage
+            b.rew = None
         rc = self._mpe_step(self._desc_ref, out.bufs_ref, self.batch_size, self._stream())
         if rc:
             _abi.check(rc, "mpe_step")
@@ -360,9 +368,26 @@ class MultiAgentEnv(object):
             for i, agent in enumerate(self.world.agents):
                 if not agent.silent:
                     agent.state.c = self._comm[i]
-        if self.max_episode_steps and self._episode_tick(out.done):
+        reward_n, done_n, info_n, done = out.reward_n, out.done_n, None, out.done
+        if self._py_reward or self._py_done or self._py_info:
+            # partial fusion: the user's reward / done / benchmark_data callbacks on the post-step world (environment.py:92-102)
+            if self._py_reward:
+                b.rew = out.rew.data_ptr()
+                reward_n = [torch.as_tensor(self._get_reward(a), device=self.world.device) for a in self.agents]
+                if self.shared_reward:
+                    total = torch.stack([r.expand(self.batch_size) for r in reward_n]).sum(dim=0)
+                    reward_n = [total] * self.n
+            if self._py_done:
+                done = torch.stack([torch.as_tensor(self._get_done(a), device=self.world.device).bool().expand(self.batch_size)
+                                    for a in self.agents]).contiguous()
+                done_n = [done[i] for i in range(self.n)]
+            if self._py_info:
+                info_n = {'n': [self._get_info(a) for a in self.agents]}
+        if info_n is None:
+            info_n = out.info_n(self)
+        if self.max_episode_steps and self._episode_tick(done):
             self._observe_into(out)         # worlds that finished were reset: their rows are the new episode's first
-        return self._deliver(out.obs_n, out.reward_n, out.done_n, out.info_n(self))
+        return self._deliver(out.obs_n, reward_n, done_n, info_n)
 
     def _episode_tick(self, done):
         """After a step: count it for every world, mark the worlds that reached max_episode_steps done (all agents),

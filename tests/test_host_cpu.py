@@ -146,16 +146,28 @@ def test_scenario_loader_and_generic_detection(tmp_path):
     with pytest.raises(FileNotFoundError):
         mpe.scenarios.load("simple_no_such_scenario.py")
     assert mpe.scenarios.load("simple_crypto.py").Scenario.kind == _abi.MPE_SCN_CRYPTO
-    # a subclass that overrides reward must NOT be routed to the fused kernel
+    # a subclass that overrides REWARD keeps the kernel for action decode + World.step + observation rows and gets its
+    # own reward evaluated in Python on the post-step world (partial fusion); overriding OBSERVATION leaves the kernel
     Base = mpe.scenarios.load("simple_spread.py").Scenario
 
-    class Mine(Base):
+    class MyReward(Base):
         def reward(self, agent, world):
             return -agent.state.p_pos.abs().sum(dim=1)
-    sc = Mine()
+
+    class MyObs(Base):
+        def observation(self, agent, world):
+            return Base.observation(self, agent, world)
+    sc = MyReward()
     w = sc.make_world(batch_size=3, device="cpu")
     env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation)
-    assert not env.fused and env.observation_space[0].shape == (18,)
+    assert env.fused and env._py_reward and not env._py_done and not env._py_info
+    assert env.observation_space[0].shape == (18,)
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, done_callback=lambda agent, world: False)
+    assert env.fused and env._py_done
+    sc = MyObs()
+    w = sc.make_world(batch_size=3, device="cpu")
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation)
+    assert not env.fused and not env._py_reward and env.observation_space[0].shape == (18,)
     with pytest.raises(_abi.MpeError):
         mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, fused=True)
 
