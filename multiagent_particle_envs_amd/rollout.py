@@ -209,6 +209,9 @@ class StreamedRollout(object):
         return sum(r.B for r in self.rollouts)
 
     def _fan(self, fn):
+        if len(self.rollouts) == 1:      # nothing to fan out: stay on the caller's stream (a rollout that draws ahead
+            fn(self.rollouts[0])         # forks its own side stream, and HIP-graph capture does not digest nested forks)
+            return
         cur = torch.cuda.current_stream(self.device)
         for r, s in zip(self.rollouts, self.streams):
             s.wait_stream(cur)
