@@ -237,10 +237,8 @@ class Leg(object):
         """protocol 'fresh': every step consumes moves nobody used before (block redraw per episode, in the timed
         region); 'resident': a ring of 16 move tensors drawn once."""
         if protocol not in self.rolls:
-            fresh = protocol.startswith("fresh")
-            P = (self.EP or 16) if fresh else 16
-            rs = [self._RR(e, episode_len=self.EP, pool=P, regenerate=fresh, draw_ahead=(protocol == "fresh"))
-                  for e in self.envs]
+            P = (self.EP or 16) if protocol == "fresh" else 16
+            rs = [self._RR(e, episode_len=self.EP, pool=P, regenerate=(protocol == "fresh")) for e in self.envs]
             self.rolls[protocol] = self._SR(rs)
         return self.rolls[protocol]
 
@@ -287,7 +285,7 @@ class Leg(object):
             for k in range(n):
                 if EP and k % EP == 0:
                     env.reset()
-                env.step(r0.pool[k % len(r0.pool)])      # (moves of the first block, cycled)
+                env.step(r0.pool[k % len(r0.pool)])
         return api
 
     def timed(self, torch, sharding, dev, mode, protocol, K, W, repeats):
@@ -434,7 +432,7 @@ def main():
     ap.add_argument("--agents", type=int, default=3)
     ap.add_argument("--episode-len", type=int, default=25)
     ap.add_argument("--mode", default="graph", choices=["graph", "eager", "api", "fused"])
-    ap.add_argument("--protocol", default="fresh", choices=["fresh", "fresh-inline", "resident"],
+    ap.add_argument("--protocol", default="fresh", choices=["fresh", "resident"],
                     help="fresh: every step's moves are newly drawn (one block draw per episode, timed); resident: a ring of "
                          "16 move tensors drawn once (round-1 headline)")
     ap.add_argument("--repeats", type=int, default=5)
@@ -585,10 +583,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s A=%d L=%d, %d worlds/GPU, one-hot random moves (%s), device reset every %d steps"
                                    % (args.scenario, A, Lm, B,
-                                      "fresh for every step: one block draw per episode inside the timed region, on a side stream "
-                                      "one episode ahead" if args.protocol == "fresh" else
-                                      "fresh for every step: one block draw per episode inside the timed region, in line"
-                                      if args.protocol == "fresh-inline" else "resident ring of 16 tensors", EP),
+                                      "fresh for every step: one block draw per episode inside the timed region"
+                                      if args.protocol == "fresh" else "resident ring of 16 tensors", EP),
                        "protocol": args.protocol, "batch_per_gpu": B, "global_batch": B * world, "mode": args.mode,
                        "graph_replays_in_timed_region": R, "timed_steps": K * R,
                        "repeats": args.repeats, "streams_per_gpu": args.streams,

@@ -19,14 +19,13 @@ from . import _abi
 
 
 class RandomRollout(object):
-    def __init__(self, env, episode_len=25, pool=16, seed=None, regenerate=False, draw_ahead=False):
+    def __init__(self, env, episode_len=25, pool=16, seed=None, regenerate=False):
         """regenerate: False -- the pool's tensors are drawn once and cycled (the policy's output is already resident
-        in HBM when the step is launched); True -- every step consumes moves nobody has used before: the pool is one
-        BLOCK of `pool` consecutive global steps (use pool = episode_len) drawn by ONE `mpe_random_actions_block`
-        launch when the rollout enters the block.  draw_ahead (with regenerate): two blocks alternate and the NEXT
-        block is drawn on a side stream while the current block's steps run (one fork / join per block, which HIP
-        graphs digest; per-STEP redraws on a side stream were measured slower than inline: 13.0 vs 9.4 us per step).
-        Block b holds exactly the tensors mpe_random_actions(step) would write for its steps, whichever way it is drawn."""
+        in HBM when the step is launched); True -- every step consumes moves nobody has used before: whenever the pool
+        is exhausted (every `pool` steps; use pool = episode_len) ONE `mpe_random_actions_block` launch redraws all of
+        it for the next `pool` global steps, on the same stream.  (Per-step redraws cost a second 2.8 us launch per
+        step; drawing one step ahead on a side stream costs a fork/join per step inside a HIP graph, which was
+        measured slower still: 13.0 vs 9.4 us per step.  The block draw is one 98 MB-write launch per 25 steps.)"""
         if not env.fused:
             raise _abi.MpeError("RandomRollout drives the fused built-in scenarios")
         self.env = env
@@ -34,29 +33,21 @@ class RandomRollout(object):
         self.episode_len = int(episode_len)
         self.seed = int(env.world.seed if seed is None else seed) & (2 ** 64 - 1)
         env._ensure_buffers()
-        A, B, dev = len(self.world.agents), self.world.batch_size, self.world.device
+        A, B = len(self.world.agents), self.world.batch_size
         self.A, self.B = A, B
-        self.regenerate = bool(regenerate)
-        self.draw_ahead = bool(draw_ahead) and self.regenerate
-        P, H = int(pool), (2 if self.draw_ahead else 1)
-        self._halves = [torch.empty((P, A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=dev) for _ in range(H)]
-        self.pool_t = self._halves[0]
-        self.pool = [self.pool_t[p] for p in range(P)]
+        self.pool_t = torch.empty((int(pool), A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=self.world.device)
+        self.pool = [self.pool_t[p] for p in range(int(pool))]
         # communication scenarios: the agents that speak say a uniform random word per step (`mpe_random_comm`), pooled
-        # like the moves
+        # like the moves; comm tensor p holds the words of the global steps t with t % len(pool) == p
         self.speakers = 0
         self.pool_c = None
-        self._halves_c = None
         if env._comm is not None:
             for i, agent in enumerate(self.world.agents):
                 if not agent.silent:
                     self.speakers |= 1 << i
-            self._halves_c = [torch.zeros((P, A, B, int(self.world.dim_c)), dtype=torch.float32, device=dev) for _ in range(H)]
-            self.pool_c = self._halves_c[0]
-        self._held = [None] * H        # which block (t // P) each half holds
-        self._side = torch.cuda.Stream(device=dev) if self.draw_ahead else None
-        self._ahead_pending = False
+            self.pool_c = torch.zeros((int(pool), A, B, int(self.world.dim_c)), dtype=torch.float32, device=self.world.device)
         self.t = 0          # global step counter (also indexes the Philox action stream)
+        self.regenerate = bool(regenerate)
         self._L = _abi.lib()
         self._lr = float(getattr(env._scenario, "landmark_range", 1.0))
         self._gen_desc = self.world.scenario_desc(_abi.MPE_SCN_GENERIC)
@@ -68,72 +59,43 @@ class RandomRollout(object):
     def _stream(self):
         return _abi.raw_stream(self.world.device)
 
-    def _fill_pool(self, t0=0, stream=None, half=0):
-        """Draw the block of len(pool) consecutive global steps starting at t0 (a multiple of len(pool)) into `half`:
-        tensor p = the moves (and words) of step t0 + p.  Without `regenerate` the pool is drawn once and cycled."""
-        st = stream if stream is not None else self._stream()
-        P = len(self.pool)
-        _abi.check(self._L.mpe_random_actions_block(self._halves[half].data_ptr(), None, self.A, self.B, self.seed, int(t0),
-                                                    P, int(self.world.world_offset), st), "mpe_random_actions_block")
-        if self._halves_c is not None:
-            for p in range(P):
-                _abi.check(self._L.mpe_random_comm(self._halves_c[half][p].data_ptr(), self.A, self.B, int(self.world.dim_c),
-                                                   self.speakers, self.seed, int(t0) + p, int(self.world.world_offset), st),
-                           "mpe_random_comm")
-        self._held[half] = int(t0) // P
-
-    def _block_for(self, t, st):
-        """-> the half that holds step t's block (regenerate mode), drawing / joining / forking as needed."""
-        P = len(self.pool)
-        blk = t // P
-        h = blk & 1 if self.draw_ahead else 0
-        dev = self.world.device
-        if self._ahead_pending and (self._held[h] == blk or t % P == 0):
-            torch.cuda.current_stream(dev).wait_stream(self._side)     # join: the block drawn ahead is complete
-            self._ahead_pending = False
-        if self._held[h] != blk:
-            self._fill_pool(blk * P, st, h)                             # not drawn ahead: draw it here, on this stream
-        if self.draw_ahead and t % P == 0 and self._held[h ^ 1] != blk + 1 and not self._ahead_pending:
-            self._side.wait_stream(torch.cuda.current_stream(dev))      # fork: every step that read the other half is enqueued
-            with torch.cuda.stream(self._side):
-                self._fill_pool((blk + 1) * P, _abi.raw_stream(dev), h ^ 1)
-            self._ahead_pending = True
-        return h
-
-    def moves(self, t):
-        """The [A, B, 5] move tensor step t reads (its block must be the one held: see enqueue)."""
-        P = len(self.pool)
-        h = ((t // P) & 1) if self.draw_ahead else 0
-        return self._halves[h][t % P]
+    def _fill_pool(self, t0=0, stream=None):
+        """Action tensor p holds the moves of global steps t with t % len(pool) == p -- those of steps
+        t0 .. t0 + len(pool) - 1 after this call (t0 a multiple of len(pool)); without `regenerate` the pool is
+        drawn once and cycled (the fused kernel draws fresh moves every step)."""
+        _abi.check(self._L.mpe_random_actions_block(self.pool_t.data_ptr(), None, self.A, self.B, self.seed, int(t0),
+                                                    len(self.pool), int(self.world.world_offset),
+                                                    stream if stream is not None else self._stream()),
+                   "mpe_random_actions_block")
+        if self.pool_c is not None:
+            for p in range(len(self.pool)):
+                _abi.check(self._L.mpe_random_comm(self.pool_c[p].data_ptr(), self.A, self.B, int(self.world.dim_c),
+                                                   self.speakers, self.seed, int(t0) + p, int(self.world.world_offset),
+                                                   stream if stream is not None else self._stream()), "mpe_random_comm")
 
     def enqueue(self, steps):
         """Enqueue `steps` env steps (and the resets that fall among them) on the current stream."""
         env, w = self.env, self.world
         L, desc, B = self._L, self._desc, self.B
         st = self._stream()
-        P = len(self.pool)
-        h = 0
         for _ in range(steps):
-            if self.regenerate:
-                h = self._block_for(self.t, st)
+            if self.regenerate and self.t % len(self.pool) == 0:
+                self._fill_pool(self.t, st)
             if self.episode_len and self.t % self.episode_len == 0:
                 b = env._sets[0].bufs
                 _abi.check(L.mpe_reset(C.byref(self._gen_desc), C.byref(b), B, None, self._lr, self.seed,
                                        self.t // self.episode_len, int(w.world_offset), st), "mpe_reset")
             out = env._sets[self.t & 1]
             b = out.bufs
-            b.act = self._halves[h][self.t % P].data_ptr()
+            b.act = self.pool[self.t % len(self.pool)].data_ptr()
             b.ids = None
             b.u = None
-            if self._halves_c is not None:
-                b.comm = self._halves_c[h][self.t % P].data_ptr()
+            if self.pool_c is not None:
+                b.comm = self.pool_c[self.t % len(self.pool)].data_ptr()
             _abi.check(L.mpe_step(C.byref(desc), C.byref(b), B, st), "mpe_step")
             self.t += 1
-        if self._ahead_pending:          # join the side stream before handing the stream back (a block drawn ahead stays held)
-            torch.cuda.current_stream(w.device).wait_stream(self._side)
-            self._ahead_pending = False
-        if self._halves_c is not None and steps > 0:   # the agents' comm state after the last step = their last words
-            env._comm.copy_(self._halves_c[h][(self.t - 1) % P])
+        if self.pool_c is not None and steps > 0:   # the agents' comm state after the last step = their last words
+            env._comm.copy_(self.pool_c[(self.t - 1) % len(self.pool)])
             for out in env._sets:
                 out.bufs.comm = env._comm.data_ptr()
         self._mark_stale()
@@ -159,8 +121,6 @@ class RandomRollout(object):
             self.enqueue(2)          # warm the code objects outside capture
             self.t = t0
             torch.cuda.synchronize()
-            if self.regenerate:
-                self._held = [None] * len(self._held)     # every block draw of the captured steps is part of the graph
             with torch.cuda.graph(g, stream=s):
                 self.enqueue(steps)
         torch.cuda.current_stream(self.world.device).wait_stream(s)
@@ -236,8 +196,6 @@ class StreamedRollout(object):
             self.enqueue(2)                      # load code objects outside capture
             for r, t in zip(self.rollouts, t0):
                 r.t = t
-                if r.regenerate:
-                    r._held = [None] * len(r._held)       # every block draw of the captured steps is part of the graph
             torch.cuda.synchronize()
             with torch.cuda.graph(g, stream=main):
                 self.enqueue(steps)

@@ -192,27 +192,3 @@ def test_rollout_outputs_against_oracle():
             got = traj.obs[t][i].cpu().numpy()
             assert np.abs(got - obs64[i]).max() < 2e-5          # free-running, 3 steps
         assert np.abs(traj.rew[t].cpu().numpy() - rew64).max() < 1e-4
-
-
-def test_block_draws_ahead_on_a_side_stream_change_nothing():
-    """RandomRollout(regenerate=True, draw_ahead=True): the next block of moves is drawn on a side stream while the current
-    block's steps run (two alternating halves, one fork / join per block).  Same moves, same results as drawing every
-    block in line -- eager, across enqueue calls that end mid-block, and captured into a graph."""
-    B, K = 3000, 37
-    envs = [mpe.make_env("simple_tag", batch_size=B, seed=6) for _ in range(3)]
-    inline = RandomRollout(envs[0], episode_len=5, pool=5, regenerate=True)
-    ahead = RandomRollout(envs[1], episode_len=5, pool=5, regenerate=True, draw_ahead=True)
-    graph = RandomRollout(envs[2], episode_len=5, pool=5, regenerate=True, draw_ahead=True)
-    inline.enqueue(K)
-    for n in (3, 9, 25):          # calls that end inside a block
-        ahead.enqueue(n)
-    g = graph.capture(K)
-    g.replay()
-    torch.cuda.synchronize()
-    for e in envs[1:]:
-        assert torch.equal(e.world.pos, envs[0].world.pos) and torch.equal(e.world.vel, envs[0].world.vel)
-        for s_ in range(2):
-            assert torch.equal(e._sets[s_].obs, envs[0]._sets[s_].obs) and torch.equal(e._sets[s_].rew, envs[0]._sets[s_].rew)
-    from oracle import philox
-    t = K - 1
-    assert np.array_equal(ahead.moves(t).cpu().numpy(), philox.one_hot(philox.action_ids(6, B, t, 4)))
