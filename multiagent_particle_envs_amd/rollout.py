@@ -25,7 +25,9 @@ class RandomRollout(object):
         is exhausted (every `pool` steps; use pool = episode_len) ONE `mpe_random_actions_block` launch redraws all of
         it for the next `pool` global steps, on the same stream.  (Per-step redraws cost a second 2.8 us launch per
         step; drawing one step ahead on a side stream costs a fork/join per step inside a HIP graph, which was
-        measured slower still: 13.0 vs 9.4 us per step.  The block draw is one 98 MB-write launch per 25 steps.)"""
+        measured slower still: 13.0 vs 9.4 us per step; drawing the next BLOCK on a side stream, one fork/join per
+        episode (commit d24e237), is slower too: 8.2-8.3 vs 7.3 us per step at B = 65536, 92.9 vs 85.2 at B = 1M --
+        concurrent kernels do not overlap usefully on this stack.  The block draw is one 98 MB-write launch per 25 steps.)"""
         if not env.fused:
             raise _abi.MpeError("RandomRollout drives the fused built-in scenarios")
         self.env = env
@@ -169,8 +171,8 @@ class StreamedRollout(object):
         return sum(r.B for r in self.rollouts)
 
     def _fan(self, fn):
-        if len(self.rollouts) == 1:      # nothing to fan out: stay on the caller's stream (a rollout that draws ahead
-            fn(self.rollouts[0])         # forks its own side stream, and HIP-graph capture does not digest nested forks)
+        if len(self.rollouts) == 1:      # nothing to fan out: stay on the caller's stream
+            fn(self.rollouts[0])
             return
         cur = torch.cuda.current_stream(self.device)
         for r, s in zip(self.rollouts, self.streams):
