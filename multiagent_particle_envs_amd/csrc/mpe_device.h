@@ -116,9 +116,19 @@ __device__ __forceinline__ void integrate_one(float &px, float &py, float &vx, f
 
 // _set_action (environment.py:161-181): one action row -> u = (a1-a2, a3-a4) * sensitivity, or the
 // integer form 1:-x 2:+x 3:-y 4:+y (the reference's opposite sign convention).
+// The four floats a[1..4] of a 20-byte action row as ONE 16-byte load at 4-byte alignment (global memory takes
+// unaligned dwordx4): a wave's 64 rows span 10 cache lines, and four separate dword loads would request each of them
+// four times -- in the N=3 step kernel the action rows were 40 of a wave's 68 line requests.
+typedef float float4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ void decode_row(const float *__restrict__ a, float sens, float &ux, float &uy) {
+#ifdef MPE_ACT_DWORD_LOADS   // A/B: the four separate dword loads
   ux = (a[1] - a[2]) * sens;
   uy = (a[3] - a[4]) * sens;
+#else
+  const float4_a4 m = *reinterpret_cast<const float4_a4 *>(a + 1);
+  ux = (m.x - m.y) * sens;
+  uy = (m.z - m.w) * sens;
+#endif
 }
 __device__ __forceinline__ void decode_id(int id, float sens, float &ux, float &uy) {
   ux = (id == 1 ? -1.f : (id == 2 ? 1.f : 0.f)) * sens;

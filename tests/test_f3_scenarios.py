@@ -745,3 +745,36 @@ def test_constants_assigned_on_a_live_env_are_honoured_without_a_refresh_call():
         untouched.world.set_state(pos, vel)
         untouched.step(act if fused else [act[i] for i in range(3)])
         assert not torch.equal(untouched.world.vel, fresh.world.vel)     # the edits do change the physics
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["simple_adversary", "simple_crypto", "simple_world_comm"])
+def test_benchmark_data_of_the_f3_scenarios_rides_on_the_fused_step(name):
+    """make_env(name, benchmark=True): the kernels have no benchmark_data stage for these scenarios; the env keeps the fused
+    launch for physics + observations + rewards and evaluates the scenario's own benchmark_data in Python on the
+    post-step world (partial fusion) -- same info as the all-Python generic path."""
+    B = 500
+    ef = mpe.make_env(name, benchmark=True, batch_size=B, seed=2)
+    eg = mpe.make_env(name, benchmark=True, batch_size=B, seed=2, fused=False)
+    if not hasattr(ef.scenario, "benchmark_data"):
+        pytest.skip("no benchmark_data in this scenario")
+    assert ef.fused and ef._py_info and not ef._py_reward and not eg.fused
+    eg.world.pos.copy_(ef.world.pos)
+    eg.world.vel.copy_(ef.world.vel)
+    if ef.world.choice_i32 is not None:
+        eg.world.choice_i32.copy_(ef.world.choice_i32)
+        eg.scenario._apply(eg.world)
+    rs = np.random.RandomState(0)
+    for t in range(3):
+        acts = random_actions(ef, rs, B)
+        of, rf, _, inf_f = ef.step(acts)
+        og, rg, _, inf_g = eg.step(acts)
+        for i in range(ef.n):
+            close(np_(of[i]), np_(og[i]), what="obs%d" % i)
+            close(np_(rf[i]) * np.ones(B), np_(rg[i]) * np.ones(B), what="rew%d" % i)
+            a, b = inf_f["n"][i], inf_g["n"][i]
+            a = a if isinstance(a, (tuple, list)) else (a,)
+            b = b if isinstance(b, (tuple, list)) else (b,)
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                close(np_(x) * np.ones(B), np_(y) * np.ones(B), what="info%d" % i)
