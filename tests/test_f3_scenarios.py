@@ -777,4 +777,5 @@ def test_benchmark_data_of_the_f3_scenarios_rides_on_the_fused_step(name):
             b = b if isinstance(b, (tuple, list)) else (b,)
             assert len(a) == len(b)
             for x, y in zip(a, b):
-                close(np_(x) * np.ones(B), np_(y) * np.ones(B), what="info%d" % i)
+                x, y = np_(x).astype(np.float64), np_(y).astype(np.float64)
+                close(np.broadcast_to(x, np.broadcast(x, y).shape), np.broadcast_to(y, np.broadcast(x, y).shape), what="info%d" % i)
