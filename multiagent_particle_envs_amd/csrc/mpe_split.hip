@@ -27,6 +27,12 @@
 
 #include "mpe_internal.h"
 
+// ablation builds (tools/ab_build.sh): bit 0 skip the contact loop, bit 1 skip the reward stage, bit 2 skip the
+// observation rows, bit 3 skip the state stores -- what each stage of the step costs
+#ifndef MPE_SPLIT_ABLATE
+#define MPE_SPLIT_ABLATE 0
+#endif
+
 namespace mpe {
 
 template <int KIND, int A, int L, int NADV>
@@ -436,6 +442,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       }
       const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
       __syncthreads();
+      if (!(MPE_SPLIT_ABLATE & 2))
       reward_wave<KIND, A, L, NADV, ROLL>(d, b, X, lane, live, ln, B, w0, (size_t)t * row_stride + w0, ra.seed, gw_r,
                                           ra.step0 + (uint64_t)t, goal_r, food);
     }
@@ -515,7 +522,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
     //      in ascending order (Q9), integrate ------------------------------------------------------
     if (movable_i && step_world) {
       float fx = ux + 0.f, fy = uy + 0.f;
-      if (collide_i) {
+      if (collide_i && !(MPE_SPLIT_ABLATE & 1)) {
 #pragma unroll
         for (int j = 0; j < E; ++j) {
           if (j == i) continue;                        // uniform
@@ -564,8 +571,10 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
     // arrival at this barrier -- so no wave can observe a post-step position in World.step, whatever
     // the dispatch order or timing of the waves (core.py:117-131: forces from the pre-step positions).
 #ifndef MPE_STRESS_STORE_BEFORE_BARRIER
-    if (movable_i && step_world && live && (!ROLL || t == T - 1)) store_state(b, B, i, w0, ln, mx, my, mvx, mvy);
+    if (movable_i && step_world && live && (!ROLL || t == T - 1) && !(MPE_SPLIT_ABLATE & 8))
+      store_state(b, B, i, w0, ln, mx, my, mvx, mvy);
 #endif
+    if (MPE_SPLIT_ABLATE & 4) continue;   // (no observation rows)
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       if (a == i) { px[a] = mx; py[a] = my; continue; }  // uniform
