@@ -234,16 +234,21 @@ __host__ __device__ inline int choice_draw(uint64_t seed, uint64_t b, uint64_t e
   const uint32_t w = (k & 3) == 0 ? o.x : (k & 3) == 1 ? o.y : (k & 3) == 2 ? o.z : o.w;
   return (int)(((uint64_t)w * (uint32_t)n) >> 32);
 }
-// Uniform move in {0..4} for agent i of world b at global step `t`.
-__host__ __device__ inline int action_draw(uint64_t seed, uint64_t b, uint64_t t, int i) {
+// The Philox block that holds the moves of agents 4q .. 4q+3 of world b at global step `t` (one word each).
+__host__ __device__ inline U4 action_block(uint64_t seed, uint64_t b, uint64_t t, int q) {
   U4 c;
   c.x = (uint32_t)b;
   c.y = (uint32_t)(b >> 32) ^ (uint32_t)(t >> 32);
-  c.z = (uint32_t)(i >> 2);
+  c.z = (uint32_t)q;
   c.w = kStreamAction ^ (uint32_t)t;
-  const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__host__ __device__ inline int move_of(uint32_t word) { return (int)(((uint64_t)word * 5u) >> 32); }
+// Uniform move in {0..4} for agent i of world b at global step `t`.
+__host__ __device__ inline int action_draw(uint64_t seed, uint64_t b, uint64_t t, int i) {
+  const U4 o = action_block(seed, b, t, i >> 2);
   const uint32_t w = (i & 3) == 0 ? o.x : (i & 3) == 1 ? o.y : (i & 3) == 2 ? o.z : o.w;
-  return (int)(((uint64_t)w * 5u) >> 32);
+  return move_of(w);
 }
 
 // Uniform word in {0..n-1} agent i of world b says at global step `t` (one-hot communication action, environment.py:183-190).

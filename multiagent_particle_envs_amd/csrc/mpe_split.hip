@@ -61,8 +61,9 @@ struct SplitShape {
                                                        : 1;
   static constexpr int TILE = kWave * (DMAX | 1);  // >= kWave * tile_stride<D>() of every row width used
   static constexpr int WAVES = A + 1;              // A agent waves + the reward wave
+  // rollout: + the moves of the next step, drawn by the reward wave for all agents (two buffers by step parity)
   static constexpr size_t lds_bytes(bool roll) {
-    return sizeof(float) * ((roll ? 2 : 1) * A * XW * kWave + A * TILE);
+    return sizeof(float) * ((roll ? 2 : 1) * A * XW * kWave + A * TILE + (roll ? 2 * A * kWave : 0));
   }
 };
 
@@ -399,6 +400,10 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   const size_t w = w0 + (size_t)ln;
   float *const xch = smem;
   float *const tile = smem + (ROLL ? 2 : 1) * A * XW * kWave + i * S::TILE;
+  // rollout: mv[(t & 1)][a][lane] = the move of agent a at step t.  The agent waves of a world would each run the
+  // SAME Philox block (one block serves four agents) at the head of their per-step dependency chain; instead the
+  // reward wave, which idles until the barrier, draws the NEXT step's moves for everybody while the agents step.
+  int *const mv = reinterpret_cast<int *>(smem + (ROLL ? 2 : 1) * A * XW * kWave + A * S::TILE);
 
   const int T = ROLL ? ra.T : 1;
   const size_t obs_stride = ra.trajectory ? (size_t)d.obs_off[A] * B : 0;
@@ -438,6 +443,17 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
           cd = ra.episode_len - 1;
         } else {
           --cd;
+        }
+      }
+      if (ROLL && t + 1 < T) {   // the moves of step t + 1: read by the agent waves behind this step's barrier
+        const uint64_t gt1 = ra.step0 + (uint64_t)t + 1;
+#pragma unroll
+        for (int q = 0; q < (A + 3) / 4; ++q) {
+          const U4 o = action_block(ra.seed, gw_r, gt1, q);
+          const uint32_t word[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (4 * q + k < A) mv[(((t + 1) & 1) * A + 4 * q + k) * kWave + lane] = move_of(word[k]);
         }
       }
       const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
@@ -508,7 +524,8 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         if (NCH >= 2) pick1 = choice_draw(ra.seed, gw, ep, 1, d.choice_pop[1]);
         ++ep;
       }
-      const int m = action_draw(ra.seed, gw, gt, i);  // the one-hot row mpe_random_actions would write
+      // the one-hot row mpe_random_actions would write: drawn here at the first step, by the reward wave afterwards
+      const int m = t == 0 ? action_draw(ra.seed, gw, gt, i) : mv[((t & 1) * A + i) * kWave + lane];
       ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * accel_i;
       uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * accel_i;
     } else if (step_world && movable_i) {
