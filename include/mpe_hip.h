@@ -174,11 +174,12 @@ int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, ui
 int mpe_random_actions_block(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed,
                              uint64_t step0, int32_t T, int64_t world_offset, void *stream);
 
-/* Uniform random WORDS for the communication scenarios: one-hot rows into comm [A][B][dim_c] for the agents whose
- * bit is set in `speakers` (bit a = agent a; rows of the others are left alone) -- the communication half of a
- * random action (environment.py:183-190), keyed by (seed, global world, step, agent) like the moves.           */
+/* Uniform random WORDS for the communication scenarios, for T consecutive global steps step0 .. step0+T-1: comm holds
+ * T consecutive [A][B][dim_c] tensors; one-hot rows for the agents whose bit is set in `speakers` (bit a = agent a;
+ * rows of the others are left alone) -- the communication half of a random action (environment.py:183-190), keyed
+ * by (seed, global world, step, agent) like the moves.                                                        */
 int mpe_random_comm(float *comm, int32_t n_agents, int64_t B, int32_t dim_c, uint32_t speakers, uint64_t seed,
-                    uint64_t step, int64_t world_offset, void *stream);
+                    uint64_t step0, int32_t T, int64_t world_offset, void *stream);
 
 /* 1 when mpe_step / mpe_observe have a fused kernel for this descriptor (kind, agent / landmark /
  * adversary counts, dim_c), 0 when the caller must keep Scenario.observation / reward itself and

@@ -65,7 +65,7 @@ EXPORTS = {
     "mpe_random_actions_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64,
                                            C.c_int32, C.c_int64, C.c_void_p]),
     "mpe_random_comm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_uint32, C.c_uint64, C.c_uint64,
-                                  C.c_int64, C.c_void_p]),
+                                  C.c_int32, C.c_int64, C.c_void_p]),
     "mpe_episode_tick": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "mpe_rollout_random": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_int32,
                                      C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32,

@@ -343,13 +343,14 @@ int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, ui
 }
 
 int mpe_random_comm(float *comm, int32_t n_agents, int64_t B, int32_t dim_c, uint32_t speakers, uint64_t seed,
-                    uint64_t step, int64_t world_offset, void *stream) {
+                    uint64_t step0, int32_t T, int64_t world_offset, void *stream) {
   const char *what = "mpe_random_comm";
   if (!comm) return fail(MPE_EINVAL, "%s: comm is NULL", what);
-  if (n_agents < 1 || n_agents > 32 || B < 0 || dim_c < 1) return fail(MPE_EINVAL, "%s: bad n_agents/B/dim_c", what);
-  if (B == 0 || speakers == 0) return 0;
-  return hip_result(mpe::launch_random_comm(comm, n_agents, (size_t)B, dim_c, speakers, seed, step, (uint64_t)world_offset,
-                                            static_cast<hipStream_t>(stream)), what);
+  if (n_agents < 1 || n_agents > 32 || B < 0 || dim_c < 1 || T < 0 || T > 65535)
+    return fail(MPE_EINVAL, "%s: bad n_agents/B/dim_c/T", what);
+  if (B == 0 || speakers == 0 || T == 0) return 0;
+  return hip_result(mpe::launch_random_comm(comm, n_agents, (size_t)B, dim_c, speakers, seed, step0, T,
+                                            (uint64_t)world_offset, static_cast<hipStream_t>(stream)), what);
 }
 
 int mpe_episode_tick(int32_t *episode_step, uint8_t *done, int32_t n_agents, int64_t B, int32_t max_episode_steps,

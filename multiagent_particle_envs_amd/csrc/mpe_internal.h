@@ -39,7 +39,7 @@ int launch_episode_tick(int32_t *episode_step, uint8_t *done, int A, size_t B, i
 int launch_random_actions(float *act, int32_t *ids, int A, size_t B, uint64_t seed, uint64_t step0, int T,
                           uint64_t world_offset, hipStream_t stream);
 
-int launch_random_comm(float *comm, int A, size_t B, int dim_c, unsigned speakers, uint64_t seed, uint64_t step,
+int launch_random_comm(float *comm, int A, size_t B, int dim_c, unsigned speakers, uint64_t seed, uint64_t step0, int T,
                        uint64_t world_offset, hipStream_t stream);
 
 // wave-per-agent / lane-per-world family (mpe_split.hip): fused step and fused T-step rollout

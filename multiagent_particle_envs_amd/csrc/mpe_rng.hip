@@ -80,20 +80,20 @@ k_random_actions(float *__restrict__ act, int32_t *__restrict__ ids, size_t B, i
 // Uniform random words of the agents that speak: one-hot rows into comm [A][B][dim_c] (communication scenarios'
 // synthetic workload; the rows the fused rollout recomputes in-kernel).  One thread per (world, agent).
 __global__ void __launch_bounds__(kBlock)
-k_random_comm(float *__restrict__ comm, size_t B, int dim_c, unsigned speakers, uint64_t seed, uint64_t step,
+k_random_comm(float *__restrict__ comm, size_t B, int A, int dim_c, unsigned speakers, uint64_t seed, uint64_t step0,
               uint64_t world_offset) {
   const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int i = blockIdx.y;
   if (w >= B || !((speakers >> i) & 1u)) return;
-  const int id = comm_draw(seed, world_offset + w, step, i, dim_c);
-  float *row = comm + ((size_t)i * B + w) * dim_c;
+  const int id = comm_draw(seed, world_offset + w, step0 + blockIdx.z, i, dim_c);
+  float *row = comm + (((size_t)blockIdx.z * A + i) * B + w) * dim_c;   // step s: the s-th consecutive [A][B][dim_c] tensor
   for (int c = 0; c < dim_c; ++c) row[c] = c == id ? 1.f : 0.f;
 }
 
-int launch_random_comm(float *comm, int A, size_t B, int dim_c, unsigned speakers, uint64_t seed, uint64_t step,
+int launch_random_comm(float *comm, int A, size_t B, int dim_c, unsigned speakers, uint64_t seed, uint64_t step0, int T,
                        uint64_t world_offset, hipStream_t stream) {
-  const dim3 grid((unsigned)((B + kBlock - 1) / kBlock), (unsigned)A);
-  hipLaunchKernelGGL(k_random_comm, grid, dim3(kBlock), 0, stream, comm, B, dim_c, speakers, seed, step, world_offset);
+  const dim3 grid((unsigned)((B + kBlock - 1) / kBlock), (unsigned)A, (unsigned)T);
+  hipLaunchKernelGGL(k_random_comm, grid, dim3(kBlock), 0, stream, comm, B, A, dim_c, speakers, seed, step0, world_offset);
   return (int)hipGetLastError();
 }
 

@@ -70,10 +70,9 @@ class RandomRollout(object):
                                                     stream if stream is not None else self._stream()),
                    "mpe_random_actions_block")
         if self.pool_c is not None:
-            for p in range(len(self.pool)):
-                _abi.check(self._L.mpe_random_comm(self.pool_c[p].data_ptr(), self.A, self.B, int(self.world.dim_c),
-                                                   self.speakers, self.seed, int(t0) + p, int(self.world.world_offset),
-                                                   stream if stream is not None else self._stream()), "mpe_random_comm")
+            _abi.check(self._L.mpe_random_comm(self.pool_c.data_ptr(), self.A, self.B, int(self.world.dim_c),
+                                               self.speakers, self.seed, int(t0), len(self.pool), int(self.world.world_offset),
+                                               stream if stream is not None else self._stream()), "mpe_random_comm")
 
     def enqueue(self, steps):
         """Enqueue `steps` env steps (and the resets that fall among them) on the current stream."""

@@ -90,7 +90,7 @@ def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):
             _abi.check(L.mpe_reset(C.byref(gen), C.byref(b), B, None, lr, seed, gt // ep, offset, stream()))
         _abi.check(L.mpe_random_actions(act.data_ptr(), None, A, B, seed, gt, offset, stream()))
         if speakers:   # the agents that speak say a uniform random word: rows of comm [A][B][dim_c]
-            _abi.check(L.mpe_random_comm(env_a._comm.data_ptr(), A, B, dim_c, speakers, seed, gt, offset, stream()))
+            _abi.check(L.mpe_random_comm(env_a._comm.data_ptr(), A, B, dim_c, speakers, seed, gt, 1, offset, stream()))
         b.act, b.ids, b.u = act.data_ptr(), None, None
         _abi.check(L.mpe_step(C.byref(env_a._desc), C.byref(b), B, stream()))
         want_obs.append([o.clone() for o in env_a._sets[0].obs_n])
