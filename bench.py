@@ -527,6 +527,14 @@ def main():
                     "launches in the timed region): the step as a policy-driven caller sees it",
             "value": B * K * Rr / dtr, "unit": "env-steps/s", "ms_per_step": dtr * 1e3 / (K * Rr)}
 
+    if solo and args.mode == "graph":
+        # the drop-in API itself: env.reset() / env.step() called from Python, one launch per call, moves from a resident ring
+        dta, _, _ = leg.timed(torch, _Sh, dev, "api", "resident", max(K, 500), W, 3)
+        extra["python_api"] = {
+            "what": "MultiAgentEnv.step() / reset() called from Python (the drop-in API; host in the loop, no graph): "
+                    "%d steps, reset every %d" % (max(K, 500), EP),
+            "value": B * max(K, 500) / dta, "unit": "env-steps/s", "ms_per_step": dta * 1e3 / max(K, 500)}
+
     headline_roof = roofline_entry(leg, k_us, B, args.mode, floor_us)
     default_line = solo and args.scenario == "simple_spread" and args.agents == 3 and B == 65536
     if default_line:

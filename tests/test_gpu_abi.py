@@ -145,6 +145,25 @@ def test_random_actions_block_equals_per_step_draws():
     assert L.mpe_random_actions_block(None, None, 3, 8, 0, 0, 1, 0, None) == -1
 
 
+def test_random_comm_blocks_bit_exact():
+    """mpe_random_comm: one-hot words of the speaking agents for T consecutive steps, bit-exact against oracle/philox.py;
+    silent agents' rows are left alone."""
+    L = _abi.lib()
+    A, B, dim_c, T, seed, step0, off = 6, 1000, 4, 7, 99, 2 ** 32 - 3, 5000
+    speakers = 0b100101
+    comm = torch.full((T, A, B, dim_c), -1.0, device="cuda")
+    _abi.check(L.mpe_random_comm(comm.data_ptr(), A, B, dim_c, speakers, seed, step0, T, off, stream()))
+    got = comm.cpu().numpy()
+    for s_ in range(T):
+        want = philox.one_hot(philox.comm_ids(seed, B, step0 + s_, A, dim_c, world_offset=off), dim_c)
+        for i in range(A):
+            if (speakers >> i) & 1:
+                assert np.array_equal(got[s_, i], want[i])
+            else:
+                assert (got[s_, i] == -1.0).all()
+    assert L.mpe_random_comm(None, A, B, dim_c, speakers, seed, 0, 1, 0, None) == -1
+
+
 def test_error_reporting():
     L = _abi.lib()
     env = make_env("simple_spread", batch_size=64)
