@@ -253,7 +253,7 @@ class Leg(object):
             kname = "mpe::k_split"
         elif max(A, Lm) <= 32 and A + Lm <= 64 and self.scenario == "simple_spread":
             kname = "mpe::k_multi"
-        elif self.scenario == "simple_spread" and max(A, Lm) <= 64 and (obs_total // A) % 4 == 0:
+        elif self.scenario == "simple_spread" and max(A, Lm) <= 64:
             kname = "mpe::k_duo<4>"
         else:
             kname = "mpe::k_wave"

@@ -137,14 +137,15 @@ __device__ __forceinline__ void row_store4(float *p, float4 o) {
 // wave store.  Wave-pieces that lie entirely in the zero tail skip the LDS reads.
 template <int VEC>
 __device__ __forceinline__ void emit_rows(const float2 *Q, const float2 *V, int A, int L, int D,
-                                          float *obs_w, size_t rowlen, int lane) {
+                                          float *obs_w, size_t rowlen, int lane, int i_begin = 0, int i_end = -1) {
   constexpr int PP = VEC / 2;       // (x, y) pairs per piece
   const int E = A + L;
   const int P = D / VEC;            // pieces per row
   const int kpz = 2 + L + (A - 1);  // first all-zero pair
   const int K = (P + kWave - 1) / kWave;
-  float2 me = Q[L], vel = V[0];
-  for (int i = 0; i < A; ++i) {
+  if (i_end < 0) i_end = A;
+  float2 me = Q[L + min(i_begin, A - 1)], vel = V[min(i_begin, A - 1)];
+  for (int i = i_begin; i < i_end; ++i) {
     const int thr = L + i;
     float *const row = obs_w + (size_t)i * rowlen;  // wave-uniform
     const int inext = min(i + 1, A - 1);
@@ -803,8 +804,13 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   }
   __syncthreads();
 
+  // rows of D = 6 N floats: 16-byte pieces when N is even, 8-byte pieces when N is odd (rows then start 8 bytes off)
+  const bool rows16 = (D & 3) == 0 && ((B * (size_t)D) & 3) == 0;
   if (role == 0) {
-    if (wok && !(MPE_DUO_ABLATE & 4)) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
+    if (wok && !(MPE_DUO_ABLATE & 4)) {
+      if (rows16) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
+      else        emit_rows<2>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
+    }
     return;
   }
 
@@ -871,7 +877,10 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   } else if (b.done && lane < A) {
     b.done[(size_t)lane * B + w] = 0;
   }
-  if (!(MPE_DUO_ABLATE & 4)) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
+  if (!(MPE_DUO_ABLATE & 4)) {
+    if (rows16) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
+    else        emit_rows<2>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
+  }
 }
 
 // ---- several worlds per wave: the mid-size regime (7 <= A, L <= 32) ------------------------------------------
@@ -1138,12 +1147,11 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
 
 }  // namespace
 
-// k_duo serves the fused spread step of 33..64 identical agents with 16-byte-aligned rows of at most 128 pieces
+// k_duo serves the fused spread step of 33..64 identical agents (rows of at most 512 floats)
 static bool duo_eligible(const WideDesc &d, const MpeBuffers &b, size_t B, bool phys, bool out, bool roll) {
   const int amax = d.A > d.L ? d.A : d.L;
   return phys && out && !roll && d.kind == MPE_SCN_SPREAD && d.homo && d.dim_c == 2 && amax > 32 && d.A <= kWave &&
-         d.L <= kWave && (d.D & 3) == 0 && d.D <= 8 * kWave && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 &&
-         ((B * (size_t)d.D) & 3) == 0 && MPE_DUO_ENABLE;
+         d.L <= kWave && (d.D & 1) == 0 && d.D <= 8 * kWave && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && MPE_DUO_ENABLE;
 }
 
 bool wide_supports(const WideDesc &d, bool out) {
