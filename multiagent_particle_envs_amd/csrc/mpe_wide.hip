@@ -40,6 +40,9 @@
 #ifndef MPE_DUO_ENABLE
 #define MPE_DUO_ENABLE 1
 #endif
+#ifndef MPE_MULTI_ABLATE   // k_multi ablation builds: bit 0 skip the reward, bit 1 the contact loop, bit 2 the rows
+#define MPE_MULTI_ABLATE 0
+#endif
 #ifndef MPE_DUO_G
 #define MPE_DUO_G 4   // worlds per workgroup of k_duo (1, 2, 4 or 8)
 #endif
@@ -992,7 +995,7 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
       const bool pushes = (fi & kCollide) && (fi & kMovable);
       const int self_rank = pushes ? crank[a] : -1;
       const float rfar = ri + far;
-      for (int kb = 0; kb < nC; kb += 32) {
+      for (int kb = 0; kb < nC && !(MPE_MULTI_ABLATE & 2); kb += 32) {
         const int n = min(nC - kb, 32);
         unsigned near = near_mask32<false>(CPW, csz, kb, n, me, rfar, 0.f);
         if (self_rank >= kb && self_rank < kb + 32) near &= ~(0x80000000u >> (self_rank - kb));
@@ -1024,7 +1027,8 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
     if (OUT) {
       // ---- observation rows: for each agent index i, the rows of the wave's WPW worlds are adjacent in HBM --------
       const int nvalid = (B - wb) < (size_t)WPW ? (int)(B - wb) : WPW;   // slots that hold a world
-      if (vec4 && npc <= 3 * kWave) {
+      if (MPE_MULTI_ABLATE & 4) {
+      } else if (vec4 && npc <= 3 * kWave) {
         // fast form: this lane's (slot, piece) for its up to three pieces per row index, and both candidate sources
         // of both pairs of each piece (without / with the self-skip), are row-invariant: fetched once per batch of
         // worlds.  A row then costs one broadcast-ish read of (pos_i, vel_i) per piece, selects, subtractions, a store.
@@ -1104,7 +1108,7 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
       }
 
       // ---- reward (simple_spread.py:72-82) + benchmark_data: lane (slot, a) = landmark a and agent a ----------------
-      if (b.rew || b.info_rew) {
+      if ((b.rew || b.info_rew) && !(MPE_MULTI_ABLATE & 1)) {
         const bool hl = ok && a < L, hi = have;
         const float2 pl = Q[a < L ? a : 0];
         const float2 pi = Q[L + (a < A ? a : 0)];
