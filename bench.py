@@ -29,7 +29,6 @@ Besides the headline the line carries (N=1 only):
                        numbers from the build container (profiles/cpu_reference.json) quoted beside it
 """
 import argparse
-import ctypes as C
 import json
 import math
 import os
