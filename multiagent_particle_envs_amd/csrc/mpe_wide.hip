@@ -43,6 +43,9 @@
 #ifndef MPE_MULTI_ABLATE   // k_multi ablation builds: bit 0 skip the reward, bit 1 the contact loop, bit 2 the rows
 #define MPE_MULTI_ABLATE 0
 #endif
+#ifndef MPE_DUO_ROLL
+#define MPE_DUO_ROLL 1    // 0: the rollout of 33..64-agent spread stays on k_wave<ROLL>
+#endif
 #ifndef MPE_DUO_G
 #define MPE_DUO_G 4   // worlds per workgroup of k_duo (1, 2, 4 or 8)
 #endif
@@ -715,6 +718,60 @@ __host__ __device__ inline DuoCarve duo_carve(int A, int L) {
   return c;
 }
 
+// Reward (simple_spread.py:72-82) + benchmark_data (:47-63) of one world by one wave, identical agents: lane = landmark
+// `lane` and agent `lane`; o = this lane's element of the [A][B] output rows (+ the step's block in a trajectory).
+__device__ __forceinline__ void duo_reward(const WideDesc &d, const MpeBuffers &b, const float2 *Q, int A, int L, size_t B,
+                                           size_t w, size_t o, int lane, bool collide) {
+  if (b.rew || b.info_rew) {
+    // reward (simple_spread.py:72-82) + benchmark_data (:47-63): lane = landmark `lane` and agent `lane`
+    const bool hl = lane < L, hi = lane < A;
+    const float2 pl = Q[hl ? lane : 0];
+    const float2 pi = Q[L + (hi ? lane : 0)];
+    const float m = d.a_size + d.a_size, mm = m * m, lo = mm * 0.9999996f, hi_ = mm * 1.0000004f;
+    const bool has_band = mm > 1e-30f;
+    float m2 = INFINITY;
+    int c = 0;
+    bool band = false;   // did any pair land in the guard band of the strict `<` (1e-6 wide: almost never)
+#pragma unroll 8
+    for (int a = 0; a < A; ++a) {  // uniform a: broadcast reads at compile-time offsets; branch-free body
+      const float2 pa = Q[L + a];
+      m2 = fminf(m2, sq2d(pa.x - pl.x, pa.y - pl.y));
+      const float da = sq2d(pa.x - pi.x, pa.y - pi.y);
+      const bool below = da < lo;
+      c += below ? 1 : 0;                                  // includes a == lane (SURVEY Q1)
+      band = band || (!below && !(da > hi_ && has_band));
+    }
+    if (band) {  // recount this lane's row with the exact test
+      c = 0;
+      for (int a = 0; a < A; ++a) {
+        const float2 pa = Q[L + a];
+        c += sqrt_lt_pre(sq2d(pa.x - pi.x, pa.y - pi.y), m, lo, hi_, has_band) ? 1 : 0;
+      }
+    }
+    float neg = hl ? 0.f - fast_sqrt(m2) : 0.f;
+    int occ = (hl && sqrt_lt(m2, 0.1f)) ? 1 : 0;
+    c = (hi && collide) ? c : 0;
+    float csum = (float)c;
+    neg = wave_sum(neg);
+    occ = wave_sum_i(occ);
+    csum = wave_sum(csum);
+    const float tot = (float)A * neg - csum;  // environment.py:100-102: sum over agents of (neg - count_i)
+    if (hi) {
+      const float r = neg - (float)c;
+      if (b.rew) b.rew[o] = d.collaborative ? tot : r;
+      if (b.done) b.done[o] = 0;
+      if (b.info_rew) {
+        b.info_rew[o] = r;
+        b.info_collisions[o] = c;
+        b.info_min_dists[o] = -neg;
+        b.info_occupied[o] = occ;
+      }
+    }
+  } else if (b.done && lane < A) {
+    b.done[o] = 0;
+  }
+}
+
 // (register budget: 71 VGPRs = 3 workgroups per CU; forcing 8 or 4 waves per SIMD with amdgpu_waves_per_eu measured
 //  85.6-86.5 / 87.5-88.3 vs 84.5-85.0 us in the same box)
 template <int G>
@@ -846,58 +903,177 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
     }
   }
   if (!wok) return;
-  if ((b.rew || b.info_rew) && !(MPE_DUO_ABLATE & 1)) {
-    // reward (simple_spread.py:72-82) + benchmark_data (:47-63): lane = landmark `lane` and agent `lane`
-    const bool hl = lane < L, hi = lane < A;
-    const float2 pl = Q[hl ? lane : 0];
-    const float2 pi = Q[L + (hi ? lane : 0)];
-    const float m = d.a_size + d.a_size, mm = m * m, lo = mm * 0.9999996f, hi_ = mm * 1.0000004f;
-    const bool has_band = mm > 1e-30f;
-    float m2 = INFINITY;
-    int c = 0;
-    bool band = false;   // did any pair land in the guard band of the strict `<` (1e-6 wide: almost never)
-#pragma unroll 8
-    for (int a = 0; a < A; ++a) {  // uniform a: broadcast reads at compile-time offsets; branch-free body
-      const float2 pa = Q[L + a];
-      m2 = fminf(m2, sq2d(pa.x - pl.x, pa.y - pl.y));
-      const float da = sq2d(pa.x - pi.x, pa.y - pi.y);
-      const bool below = da < lo;
-      c += below ? 1 : 0;                                  // includes a == lane (SURVEY Q1)
-      band = band || (!below && !(da > hi_ && has_band));
-    }
-    if (band) {  // recount this lane's row with the exact test
-      c = 0;
-      for (int a = 0; a < A; ++a) {
-        const float2 pa = Q[L + a];
-        c += sqrt_lt_pre(sq2d(pa.x - pi.x, pa.y - pi.y), m, lo, hi_, has_band) ? 1 : 0;
-      }
-    }
-    float neg = hl ? 0.f - fast_sqrt(m2) : 0.f;
-    int occ = (hl && sqrt_lt(m2, 0.1f)) ? 1 : 0;
-    c = (hi && collide) ? c : 0;
-    float csum = (float)c;
-    neg = wave_sum(neg);
-    occ = wave_sum_i(occ);
-    csum = wave_sum(csum);
-    const float tot = (float)A * neg - csum;  // environment.py:100-102: sum over agents of (neg - count_i)
-    if (hi) {
-      const float r = neg - (float)c;
-      const size_t o = (size_t)lane * B + w;
-      if (b.rew) b.rew[o] = d.collaborative ? tot : r;
-      if (b.done) b.done[o] = 0;
-      if (b.info_rew) {
-        b.info_rew[o] = r;
-        b.info_collisions[o] = c;
-        b.info_min_dists[o] = -neg;
-        b.info_occupied[o] = occ;
-      }
-    }
-  } else if (b.done && lane < A) {
-    b.done[(size_t)lane * B + w] = 0;
-  }
+  if (!(MPE_DUO_ABLATE & 1)) duo_reward(d, b, Q, A, L, B, w, (size_t)lane * B + w, lane, collide);
   if (!(MPE_DUO_ABLATE & 4)) {
     if (rows16) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
     else        emit_rows<2>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
+  }
+}
+
+// ---- the fused T-step rollout on k_duo's plan (mpe_rollout_random, spread 32 < N <= 64, identical agents) ---------
+// The worlds of the workgroup stay in LDS for all T steps, so the per-step state I/O of the stepwise kernel is gone;
+// positions and velocities are DOUBLE-buffered by step parity: step t's World.step (wave 2g) reads P(t-1) from buffer
+// t & 1 and writes P(t) into the other one.  One workgroup barrier per step closes step t's World.step; behind it wave
+// 2g emits rows [0, split) of step t and goes straight on to step t+1's moves and contacts -- which only read P(t) and
+// write the buffer nobody reads any more -- while wave 2g+1 computes step t's reward and emits the remaining rows.  In-kernel resets (mpe_reset's draws) overwrite the
+// buffer the previous step's rows are read from: they sit behind one more barrier, on reset steps only.  Moves are
+// drawn per agent lane (action_draw: the rows mpe_random_actions would write).  Bit-identical to
+// T x { [mpe_reset]; mpe_random_actions; mpe_step } (tests/test_gpu_rollout.py).
+struct DuoRollCarve { size_t q[2], v[2], slot_bytes; };
+__host__ __device__ inline DuoRollCarve duo_roll_carve(int A, int L) {
+  DuoRollCarve c;
+  size_t o = 0;
+  for (int k = 0; k < 2; ++k) { c.q[k] = o; o += align16(sizeof(float2) * (A + L)); }
+  for (int k = 0; k < 2; ++k) { c.v[k] = o; o += align16(sizeof(float2) * A); }
+  c.slot_bytes = o;
+  return c;
+}
+
+template <int G>
+__global__ void __launch_bounds__(2 * G * kWave)
+k_duo_roll(const WideDesc d, const MpeBuffers b, const size_t B, const RollArgs ra) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = 2 * G * kWave;
+  const int A = d.A, L = d.L, E = A + L, D = d.D;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 1, role = wave & 1;
+  const DuoRollCarve cv = duo_roll_carve(A, L);
+  auto Qs = [&](int sl, int k) { return reinterpret_cast<float2 *>(smem + (size_t)sl * cv.slot_bytes + cv.q[k]); };
+  auto Vs = [&](int sl, int k) { return reinterpret_cast<float2 *>(smem + (size_t)sl * cv.slot_bytes + cv.v[k]); };
+  constexpr unsigned GPL = 32 / G;
+  const unsigned x = blockIdx.x, xcd = x & 7u, slot = x >> 3;
+  const size_t w0 = (size_t)(((slot / GPL) * 8u + xcd) * GPL + (slot % GPL)) * G;
+  if (w0 >= B) return;   // workgroup-uniform
+  const int nvalid = (B - w0) < (size_t)G ? (int)(B - w0) : G;
+  const bool movable = d.a_flags & kMovable, collide = d.a_flags & kCollide;
+
+  // ---- stage P(-1) into buffer 0 (landmarks into both buffers), cooperatively: thread -> (row, world slot) ----------
+  {
+    const int gg = tid % G, r0 = tid / G;
+    if (gg < nvalid) {
+      const size_t wg = w0 + gg;
+      float *const Q0 = reinterpret_cast<float *>(Qs(gg, 0)), *const Q1 = reinterpret_cast<float *>(Qs(gg, 1));
+      for (int r = r0; r < 2 * E; r += NT / G) {
+        const int e = r >> 1, qi = 2 * (e < A ? L + e : e - A) + (r & 1);
+        const float val = b.pos[(size_t)r * B + wg];
+        Q0[qi] = val;
+        if (e >= A) Q1[qi] = val;
+      }
+      float *const V0 = reinterpret_cast<float *>(Vs(gg, 0));
+      for (int r = r0; r < 2 * A; r += NT / G) V0[r] = b.vel[(size_t)r * B + wg];
+    }
+  }
+  __syncthreads();
+
+  const bool wok = g < nvalid;
+  const size_t w = w0 + (wok ? g : 0);
+  const uint64_t gw = ra.world_offset + w;   // global world number (RNG streams)
+  const int split = (A * kDuoSplitNum) / kDuoSplitDen;
+  const int T = ra.T;
+  const size_t obs_stride = ra.trajectory ? (size_t)A * D * B : 0;
+  const size_t row_stride = ra.trajectory ? (size_t)A * B : 0;
+  const bool rows16 = (D & 3) == 0 && ((B * (size_t)D) & 3) == 0 && ((obs_stride & 3) == 0);
+  int countdown = -1;    // resets fall on global steps that are multiples of episode_len
+  uint64_t ep = 0;
+  if (ra.episode_len > 0) {
+    const uint64_t len = (uint64_t)ra.episode_len, r = ra.step0 % len;
+    countdown = r == 0 ? 0 : (int)(len - r);
+    ep = ra.step0 / len + (r ? 1 : 0);
+  }
+
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1, nxt = cur ^ 1;            // P(t-1) in buffer cur, P(t) goes to buffer nxt
+    const uint64_t gt = ra.step0 + (uint64_t)t;
+    const bool reset_now = countdown == 0;           // uniform over the grid
+    if (countdown >= 0) countdown = reset_now ? ra.episode_len - 1 : countdown - 1;
+    if (reset_now) {
+      __syncthreads();   // the rows of step t-1 (read from buffer cur by both waves) are out
+      if (role == 0 && wok) {   // reset_world, as mpe_reset draws it for episode ep
+        if (lane < A) {
+          float px, py;
+          reset_draw(ra.seed, gw, ep, lane, 1.0f, px, py);
+          Qs(g, cur)[L + lane] = make_float2(px, py);
+          Vs(g, cur)[lane] = make_float2(0.f, 0.f);
+        }
+        if (lane < L) {
+          float px, py;
+          reset_draw(ra.seed, gw, ep, A + lane, ra.landmark_range, px, py);
+          Qs(g, cur)[lane] = make_float2(px, py);
+          Qs(g, nxt)[lane] = make_float2(px, py);
+        }
+        wave_sync();
+      }
+      ++ep;
+    }
+    if (role == 0 && wok) {
+      // ---- World.step (core.py:117-169), lane = agent: P(t-1) -> P(t) -----------------------------------------
+      const float2 *const Qc = Qs(g, cur);
+      const bool have = lane < A;
+      const int i = have ? lane : 0;
+      float2 me = Qc[L + i], v = Vs(g, cur)[i];
+      if (movable) {
+        const int m = action_draw(ra.seed, gw, gt, i);   // the one-hot row mpe_random_actions would write, decoded
+        const float ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * d.a_accel;
+        const float uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * d.a_accel;
+        float ax = ux + 0.f, ay = uy + 0.f;   // action force first, then the partners in ascending order (Q9)
+        if (collide) {
+          const float ri = d.a_size, rfar = ri + kFarX * d.cmargin, reach = rfar + ri;
+          const float2 *const CPW = Qc + L;
+          for (int kb = 0; kb < A; kb += 32) {
+            const int n = min(A - kb, 32);
+            unsigned near = near_mask32<true>(CPW, nullptr, kb, n, me, rfar, reach * reach);
+            if (i >= kb && i < kb + 32) near &= ~(0x80000000u >> (i - kb));   // not against itself
+            if (!have) near = 0u;
+            while (near) {   // pass 2: the partners within reach only, ascending
+              const int j = __clz((int)near);
+              near &= ~(0x80000000u >> j);
+              const float2 pj = CPW[kb + j];
+              float gx, gy;
+              contact_force(me.x - pj.x, me.y - pj.y, ri + ri, d.cforce, d.cmargin, d.cmargin_inv, gx, gy);
+              ax = gx + ax;
+              ay = gy + ay;
+            }
+          }
+        }
+        integrate_one(me.x, me.y, v.x, v.y, ax, ay, d.a_inv_mass, d.a_max_speed, d.damp, d.dt);
+      }
+      if (have) {   // the other buffer: nobody reads it before the barrier below
+        Qs(g, nxt)[L + i] = me;
+        Vs(g, nxt)[i] = v;
+      }
+    }
+    __syncthreads();   // P(t) is complete; every read of buffer nxt's previous contents (rows of step t-2 ...) is long over
+
+    const float2 *const Q = Qs(g, nxt), *const V = Vs(g, nxt);
+    float *const obs_w = b.obs + (size_t)t * obs_stride + w * (size_t)D;
+    if (role == 0) {
+      if (wok) {
+        if (rows16) emit_rows_fast(Q, V, A, L, D, obs_w, (size_t)B * D, lane, 0, split);
+        else        emit_rows<2>(Q, V, A, L, D, obs_w, (size_t)B * D, lane, 0, split);
+      }
+    } else if (wok) {
+      duo_reward(d, b, Q, A, L, B, w, (size_t)t * row_stride + (size_t)lane * B + w, lane, collide);
+      if (rows16) emit_rows_fast(Q, V, A, L, D, obs_w, (size_t)B * D, lane, split, A);
+      else        emit_rows<2>(Q, V, A, L, D, obs_w, (size_t)B * D, lane, split, A);
+    }
+  }
+
+  // ---- hand the state back: P(T-1) sits in buffer T & 1; every entity (in-kernel resets move the landmarks too) -------
+  __syncthreads();
+  {
+    const int fin = T & 1;
+    const int gg = tid % G, r0 = tid / G;
+    if (gg < nvalid) {
+      const size_t wg = w0 + gg;
+      const float *const Qf = reinterpret_cast<const float *>(Qs(gg, fin));
+      const float *const Vf = reinterpret_cast<const float *>(Vs(gg, fin));
+      for (int r = r0; r < 2 * E; r += NT / G) {
+        const int e = r >> 1;
+        b.pos[(size_t)r * B + wg] = Qf[2 * (e < A ? L + e : e - A) + (r & 1)];
+      }
+      for (int r = r0; r < 2 * A; r += NT / G) b.vel[(size_t)r * B + wg] = Vf[r];
+    }
   }
 }
 
@@ -1221,6 +1397,15 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
   RollArgs ra;
   std::memset(&ra, 0, sizeof(ra));
   const int amax = d.A > d.L ? d.A : d.L;
+  if (roll && duo_eligible(d, b, B, phys, out, false) && MPE_DUO_ROLL) {
+    constexpr int G = MPE_DUO_G;
+    const size_t padded_w = (B + 255) / 256 * 256;
+    if (padded_w <= 0x7fffffffull) {
+      const size_t dlds = (size_t)G * duo_roll_carve(d.A, d.L).slot_bytes;
+      hipLaunchKernelGGL(k_duo_roll<G>, dim3((unsigned)(padded_w / G)), dim3(2 * G * kWave), dlds, stream, d, b, B, *roll);
+      return (int)hipGetLastError();
+    }
+  }
   if (duo_eligible(d, b, B, phys, out, roll != nullptr)) {
     // two waves per world (k_duo): one workgroup per world, worlds padded to whole 256-world blocks of the XCD map
     constexpr int G = MPE_DUO_G;

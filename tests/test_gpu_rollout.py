@@ -57,7 +57,10 @@ def test_split_and_thread_kernels_bit_identical(name, kw, B):
                                             ("simple_adversary", {}, 900, 30, 5), ("simple_push", {}, 500, 20, 4),
                                             ("simple_spread", {"num_agents": 8}, 130, 11, 4),            # wave-per-world kernel
                                             ("simple_spread", {"num_agents": 20, "num_landmarks": 12}, 70, 7, 3),
-                                            ("simple_spread", {"num_agents": 64}, 37, 6, 5),
+                                            ("simple_spread", {"num_agents": 64}, 37, 6, 5),               # k_duo_roll (two waves per world)
+                                            ("simple_spread", {"num_agents": 40}, 130, 9, 3),
+                                            ("simple_spread", {"num_agents": 33}, 6, 5, 0),               # odd N: 8-byte row pieces
+                                            ("simple_spread", {"num_agents": 64}, 260, 3, 1),             # a reset at every step
                                             ("simple_spread", {"num_agents": 100}, 9, 5, 2),             # > one wave of agents
                                             ("simple_spread", {"num_agents": 3, "num_landmarks": 90}, 21, 5, 3),
                                             # simple_tag at team sizes the reference does not ship: wave-per-world kernel
