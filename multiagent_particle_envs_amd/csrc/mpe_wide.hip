@@ -43,6 +43,9 @@
 #ifndef MPE_MULTI_ABLATE   // k_multi ablation builds: bit 0 skip the reward, bit 1 the contact loop, bit 2 the rows
 #define MPE_MULTI_ABLATE 0
 #endif
+#ifndef MPE_DUO_MIN_N
+#define MPE_DUO_MIN_N 32   // k_duo serves max(A, L) above this (below: k_multi, several worlds per wave)
+#endif
 #ifndef MPE_DUO_ROLL
 #define MPE_DUO_ROLL 1    // 0: the rollout of 33..64-agent spread stays on k_wave<ROLL>
 #endif
@@ -1359,7 +1362,7 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
 // k_duo serves the fused spread step of 33..64 identical agents (rows of at most 512 floats)
 static bool duo_eligible(const WideDesc &d, const MpeBuffers &b, size_t B, bool phys, bool out, bool roll) {
   const int amax = d.A > d.L ? d.A : d.L;
-  return phys && out && !roll && d.kind == MPE_SCN_SPREAD && d.homo && d.dim_c == 2 && amax > 32 && d.A <= kWave &&
+  return phys && out && !roll && d.kind == MPE_SCN_SPREAD && d.homo && d.dim_c == 2 && amax > MPE_DUO_MIN_N && d.A <= kWave &&
          d.L <= kWave && (d.D & 1) == 0 && d.D <= 8 * kWave && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && MPE_DUO_ENABLE;
 }
 
