@@ -648,7 +648,7 @@ def test_two_waves_per_world_kernel_is_bit_identical_to_the_wave_per_world_kerne
     import ctypes as C
     from multiagent_particle_envs_amd import _abi
     L_ = _abi.lib()
-    for N, B in ((64, 300), (40, 77), (33, 1000), (63, 41), (64, 1), (48, 5)):   # odd N: rows leave as 8-byte pieces; B < 4: ragged groups
+    for N, B in ((64, 300), (40, 77), (33, 1000), (63, 41), (64, 1), (48, 5), (64, 4096)):   # odd N: 8-byte row pieces; B < 4: ragged groups; (64, 4096) = BASELINE config C4 at full size
         rs = np.random.RandomState(N)
         pos = rs.uniform(-1, 1, (B, 2 * N, 2)).astype(np.float32)
         pos[::2] *= 0.5
