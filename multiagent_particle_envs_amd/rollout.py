@@ -73,6 +73,7 @@ class RandomRollout(object):
             _abi.check(self._L.mpe_random_comm(self.pool_c.data_ptr(), self.A, self.B, int(self.world.dim_c),
                                                self.speakers, self.seed, int(t0), len(self.pool), int(self.world.world_offset),
                                                stream if stream is not None else self._stream()), "mpe_random_comm")
+        self._pool_block = int(t0) // len(self.pool)     # which block of global steps the pool holds
 
     def enqueue(self, steps):
         """Enqueue `steps` env steps (and the resets that fall among them) on the current stream."""
@@ -80,8 +81,8 @@ class RandomRollout(object):
         L, desc, B = self._L, self._desc, self.B
         st = self._stream()
         for _ in range(steps):
-            if self.regenerate and self.t % len(self.pool) == 0:
-                self._fill_pool(self.t, st)
+            if self.regenerate and self.t // len(self.pool) != self._pool_block:   # entering a block the pool does not hold
+                self._fill_pool(self.t // len(self.pool) * len(self.pool), st)
             if self.episode_len and self.t % self.episode_len == 0:
                 b = env._sets[0].bufs
                 _abi.check(L.mpe_reset(C.byref(self._gen_desc), C.byref(b), B, None, self._lr, self.seed,
@@ -122,6 +123,8 @@ class RandomRollout(object):
             self.enqueue(2)          # warm the code objects outside capture
             self.t = t0
             torch.cuda.synchronize()
+            if self.regenerate:
+                self._pool_block = None      # every block draw of the captured steps is part of the graph
             with torch.cuda.graph(g, stream=s):
                 self.enqueue(steps)
         torch.cuda.current_stream(self.world.device).wait_stream(s)
@@ -197,6 +200,8 @@ class StreamedRollout(object):
             self.enqueue(2)                      # load code objects outside capture
             for r, t in zip(self.rollouts, t0):
                 r.t = t
+                if r.regenerate:
+                    r._pool_block = None     # every block draw of the captured steps is part of the graph
             torch.cuda.synchronize()
             with torch.cuda.graph(g, stream=main):
                 self.enqueue(steps)

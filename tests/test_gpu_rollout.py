@@ -195,3 +195,23 @@ def test_rollout_outputs_against_oracle():
             got = traj.obs[t][i].cpu().numpy()
             assert np.abs(got - obs64[i]).max() < 2e-5          # free-running, 3 steps
         assert np.abs(traj.rew[t].cpu().numpy() - rew64).max() < 1e-4
+
+
+def test_fresh_moves_rollout_started_mid_block_reads_the_right_moves():
+    """RandomRollout(regenerate=True): the pool is one block of `pool` consecutive global steps; a rollout whose step
+    counter is moved (here: into the middle of block 3) must redraw that block, not read stale tensors -- every step's
+    moves are exactly mpe_random_actions(step)."""
+    B, P = 512, 5
+    env = mpe.make_env("simple_spread", batch_size=B, seed=8)
+    roll = RandomRollout(env, episode_len=0, pool=P, regenerate=True)
+    roll.t = 17
+    ref = mpe.make_env("simple_spread", batch_size=B, seed=8)
+    ref.world.pos.copy_(env.world.pos)
+    ref.world.vel.copy_(env.world.vel)
+    act = torch.zeros((3, B, 5), device="cuda")
+    for t in range(17, 24):          # crosses from block 3 into block 4
+        _abi.check(_abi.lib().mpe_random_actions(act.data_ptr(), None, 3, B, 8, t, 0, stream()))
+        ref.step(act)
+    roll.enqueue(7)
+    torch.cuda.synchronize()
+    assert torch.equal(env.world.pos, ref.world.pos) and torch.equal(env.world.vel, ref.world.vel)
