@@ -59,11 +59,16 @@ struct SplitShape {
                               : KIND == MPE_SCN_CRYPTO ? 8
                               : KIND == MPE_SCN_WORLD_COMM ? 4 + 2 * L + 2 * (A - 1) + 2 * (A - NADV) + 2 + 4
                                                        : 1;
-  static constexpr int TILE = kWave * (DMAX | 1);  // >= kWave * tile_stride<D>() of every row width used
+  // rows a wave's LDS tile holds: 64, except in simple_world_comm's ROLLOUT (six agent waves, 34-float rows, two exchange
+  // blocks: 72 KB per workgroup with 64-row tiles = two workgroups per CU).  With 32-row tiles (the wave's rows leave in
+  // two halves) it is 45 KB: three per CU -- measured 10.8 vs 13.4 us per step; the single step is NOT faster that way
+  // (19.4-19.7 vs 18.3-18.8 us) and keeps 64 rows.
+  static constexpr int trows(bool roll) { return (KIND == MPE_SCN_WORLD_COMM && roll) ? 32 : kWave; }
+  static constexpr int tile_floats(bool roll) { return trows(roll) * (DMAX | 1); }  // >= trows * tile_stride<D>() of every row width
   static constexpr int WAVES = A + 1;              // A agent waves + the reward wave
   // rollout: + the moves of the next step, drawn by the reward wave for all agents (two buffers by step parity)
   static constexpr size_t lds_bytes(bool roll) {
-    return sizeof(float) * ((roll ? 2 : 1) * A * XW * kWave + A * TILE + (roll ? 2 * A * kWave : 0));
+    return sizeof(float) * ((roll ? 2 : 1) * A * XW * kWave + A * tile_floats(roll) + (roll ? 2 * A * kWave : 0));
   }
 };
 
@@ -399,11 +404,11 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   const unsigned ln = (unsigned)(live ? lane : nvalid - 1) & 63u;
   const size_t w = w0 + (size_t)ln;
   float *const xch = smem;
-  float *const tile = smem + (ROLL ? 2 : 1) * A * XW * kWave + i * S::TILE;
+  float *const tile = smem + (ROLL ? 2 : 1) * A * XW * kWave + i * S::tile_floats(ROLL);
   // rollout: mv[(t & 1)][a][lane] = the move of agent a at step t.  The agent waves of a world would each run the
   // SAME Philox block (one block serves four agents) at the head of their per-step dependency chain; instead the
   // reward wave, which idles until the barrier, draws the NEXT step's moves for everybody while the agents step.
-  int *const mv = reinterpret_cast<int *>(smem + (ROLL ? 2 : 1) * A * XW * kWave + A * S::TILE);
+  int *const mv = reinterpret_cast<int *>(smem + (ROLL ? 2 : 1) * A * XW * kWave + A * S::tile_floats(ROLL));
 
   const int T = ROLL ? ra.T : 1;
   const size_t obs_stride = ra.trajectory ? (size_t)d.obs_off[A] * B : 0;
@@ -787,33 +792,41 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       auto row = [&](auto dsel, auto advt) {
         constexpr int D = decltype(dsel)::value, RS = tile_stride<D>();
         constexpr bool ADV = decltype(advt)::value;
+        constexpr bool HALF = S::trows(ROLL) == 32;   // 32-row tile: rows of worlds 0..31, then of worlds 32..63
+#pragma unroll
+        for (int h = 0; h < (HALF ? 2 : 1); ++h) {
+        const int r = HALF ? (lane & 31) : lane;
+        if (!HALF || (lane >> 5) == h) {
         int k = 0;
-        put1<RS>(tile, lane, 0, mvx); put1<RS>(tile, lane, 1, mvy); put1<RS>(tile, lane, 2, mx); put1<RS>(tile, lane, 3, my);
+        put1<RS>(tile, r, 0, mvx); put1<RS>(tile, r, 1, mvy); put1<RS>(tile, r, 2, mx); put1<RS>(tile, r, 3, my);
         k = 4;
 #pragma unroll
-        for (int l = 0; l < L; ++l) { put1<RS>(tile, lane, k, px[A + l] - mx); put1<RS>(tile, lane, k + 1, py[A + l] - my); k += 2; }
+        for (int l = 0; l < L; ++l) { put1<RS>(tile, r, k, px[A + l] - mx); put1<RS>(tile, r, k + 1, py[A + l] - my); k += 2; }
 #pragma unroll
         for (int j = 0; j < A; ++j) {
           if (j == i) continue;
-          put1<RS>(tile, lane, k, vis[j] ? px[j] - mx : 0.f);
-          put1<RS>(tile, lane, k + 1, vis[j] ? py[j] - my : 0.f);
+          put1<RS>(tile, r, k, vis[j] ? px[j] - mx : 0.f);
+          put1<RS>(tile, r, k + 1, vis[j] ? py[j] - my : 0.f);
           k += 2;
         }
-        if (!ADV) { put1<RS>(tile, lane, k, f1 ? 1.f : -1.f); put1<RS>(tile, lane, k + 1, f2 ? 1.f : -1.f); k += 2; }
+        if (!ADV) { put1<RS>(tile, r, k, f1 ? 1.f : -1.f); put1<RS>(tile, r, k + 1, f2 ? 1.f : -1.f); k += 2; }
 #pragma unroll
         for (int j = NADV; j < A; ++j) {
           if (j == i) continue;
-          put1<RS>(tile, lane, k, vis[j] ? X[(j * XW + 2) * kWave + lane] : 0.f);
-          put1<RS>(tile, lane, k + 1, vis[j] ? X[(j * XW + 3) * kWave + lane] : 0.f);
+          put1<RS>(tile, r, k, vis[j] ? X[(j * XW + 2) * kWave + lane] : 0.f);
+          put1<RS>(tile, r, k + 1, vis[j] ? X[(j * XW + 3) * kWave + lane] : 0.f);
           k += 2;
         }
         if (ADV) {
-          put1<RS>(tile, lane, k, f1 ? 1.f : -1.f); put1<RS>(tile, lane, k + 1, f2 ? 1.f : -1.f); k += 2;
+          put1<RS>(tile, r, k, f1 ? 1.f : -1.f); put1<RS>(tile, r, k + 1, f2 ? 1.f : -1.f); k += 2;
           const Word<ROLL> cl = word_of<DC, ROLL>(b, B, w0, ln, 0, ra.seed, gw, gt);   // world.agents[0].state.c
 #pragma unroll
-          for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, k + c, cl[c]);
+          for (int c = 0; c < DC; ++c) put1<RS>(tile, r, k + c, cl[c]);
         }
-        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        }
+        const int nv = HALF ? min(max(nvalid - 32 * h, 0), 32) : nvalid;   // uniform
+        if (nv > 0) flush_rows<D>(tile, obs_t + B * obs_off_i + (w0 + (HALF ? 32 * h : 0)) * D, nv, lane, d.vec4);
+        }
       };
       if (i < NADV) row(std::integral_constant<int, DA>{}, std::true_type{});
       else          row(std::integral_constant<int, DGd>{}, std::false_type{});
