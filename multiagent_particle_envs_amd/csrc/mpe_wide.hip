@@ -922,16 +922,18 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
 // buffer the previous step's rows are read from: they sit behind one more barrier, on reset steps only.  Moves are
 // drawn per agent lane (action_draw: the rows mpe_random_actions would write).  Bit-identical to
 // T x { [mpe_reset]; mpe_random_actions; mpe_step } (tests/test_gpu_rollout.py).
-struct DuoRollCarve { size_t q[2], v[2], slot_bytes; };
+struct DuoRollCarve { size_t q_bytes, v_bytes, v0, slot_bytes; };   // per slot: Q buffer 0, Q buffer 1, V buffer 0, V buffer 1
 __host__ __device__ inline DuoRollCarve duo_roll_carve(int A, int L) {
   DuoRollCarve c;
-  size_t o = 0;
-  for (int k = 0; k < 2; ++k) { c.q[k] = o; o += align16(sizeof(float2) * (A + L)); }
-  for (int k = 0; k < 2; ++k) { c.v[k] = o; o += align16(sizeof(float2) * A); }
-  c.slot_bytes = o;
+  c.q_bytes = align16(sizeof(float2) * (A + L));
+  c.v_bytes = align16(sizeof(float2) * A);
+  c.v0 = 2 * c.q_bytes;
+  c.slot_bytes = 2 * c.q_bytes + 2 * c.v_bytes;
   return c;
 }
 
+// (128 VGPRs, no scratch; forcing the budget of 5 / 6 / 8 waves per SIMD measured 71.1-72.3 / 72.6-73.2 / 74.5-75.7 vs
+//  70.5-72.3 us per step in the same box)
 template <int G>
 __global__ void __launch_bounds__(2 * G * kWave)
 k_duo_roll(const WideDesc d, const MpeBuffers b, const size_t B, const RollArgs ra) {
@@ -942,8 +944,9 @@ k_duo_roll(const WideDesc d, const MpeBuffers b, const size_t B, const RollArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = wave >> 1, role = wave & 1;
   const DuoRollCarve cv = duo_roll_carve(A, L);
-  auto Qs = [&](int sl, int k) { return reinterpret_cast<float2 *>(smem + (size_t)sl * cv.slot_bytes + cv.q[k]); };
-  auto Vs = [&](int sl, int k) { return reinterpret_cast<float2 *>(smem + (size_t)sl * cv.slot_bytes + cv.v[k]); };
+  // (offsets by arithmetic, not by indexing an array with the step parity: that would live in scratch memory)
+  auto Qs = [&](int sl, int k) { return reinterpret_cast<float2 *>(smem + (size_t)sl * cv.slot_bytes + (size_t)k * cv.q_bytes); };
+  auto Vs = [&](int sl, int k) { return reinterpret_cast<float2 *>(smem + (size_t)sl * cv.slot_bytes + cv.v0 + (size_t)k * cv.v_bytes); };
   constexpr unsigned GPL = 32 / G;
   const unsigned x = blockIdx.x, xcd = x & 7u, slot = x >> 3;
   const size_t w0 = (size_t)(((slot / GPL) * 8u + xcd) * GPL + (slot % GPL)) * G;
