@@ -775,8 +775,9 @@ __device__ __forceinline__ void duo_reward(const WideDesc &d, const MpeBuffers &
   }
 }
 
-// (register budget: 71 VGPRs = 3 workgroups per CU; forcing 8 or 4 waves per SIMD with amdgpu_waves_per_eu measured
-//  85.6-86.5 / 87.5-88.3 vs 84.5-85.0 us in the same box)
+// (register budget: the occupancy caps that were tried -- amdgpu_waves_per_eu forcing 8 or 4 waves per SIMD at 71 VGPRs:
+//  85.6-86.5 / 87.5-88.3 vs 84.5-85.0 us; capping at 6 or 4 at today's 46 VGPRs: 76.8-80.3 / 76.3-83.0 vs 76.1-80.2 --
+//  are inside the run-to-run spread of the row stream)
 template <int G>
 __global__ void __launch_bounds__(2 * G * kWave)
 k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
