@@ -280,11 +280,18 @@ class Leg(object):
         env, r0, EP = self.env, roll.rollouts[0], self.EP
         assert self.S == 1, "--mode api drives one env"
 
+        import torch
+        if r0.pool_c is None:
+            acts = [r0.pool[p] for p in range(len(r0.pool))]            # one [A, B, 5] tensor per step
+        else:   # communication scenarios: agent i's row = [move (5) if it moves] + [word (dim_c) if it speaks]
+            acts = [[torch.cat(([r0.pool[p][i]] if a.movable else []) + ([r0.pool_c[p][i]] if not a.silent else []), dim=1)
+                     for i, a in enumerate(env.agents)] for p in range(len(r0.pool))]
+
         def api():
             for k in range(n):
                 if EP and k % EP == 0:
                     env.reset()
-                env.step(r0.pool[k % len(r0.pool)])
+                env.step(acts[k % len(acts)])      # (the first block's moves, cycled)
         return api
 
     def timed(self, torch, sharding, dev, mode, protocol, K, W, repeats):
