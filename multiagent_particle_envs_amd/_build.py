@@ -23,6 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function"]
 
 
+STRESS_SOURCES = ("split", "wide")
 STRESS_VARIANTS = {"stress": ["-DMPE_STRESS_DELAY_WAVE=1"],
                    "stress_racy": ["-DMPE_STRESS_DELAY_WAVE=1", "-DMPE_STRESS_STORE_BEFORE_BARRIER"]}
 
@@ -70,23 +71,27 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-8000:]))
         if verbose and r.stderr.strip():
             print(r.stderr[-4000:])
-    # test-only variants of the wave-per-agent kernels (tests/test_gpu_race.py): one agent wave of every workgroup
-    # is held back ~30 us before its first load (MPE_STRESS_DELAY_WAVE); "_racy" additionally restores the
-    # store-before-barrier ordering the round-1 kernel had, as the negative control that shows the test can fail
+    # test-only variants of the role-split kernels (tests/test_gpu_race.py): one wave of every workgroup is held back
+    # (MPE_STRESS_DELAY_WAVE: ~30 us before its first load in k_split / k_duo, a few us at every step of k_duo_roll);
+    # "_racy" additionally restores the store-before-barrier ordering the round-1 k_split had, as the negative control
+    # that shows the test can fail
     variants = []
-    split_src = os.path.join(CSRC, "mpe_split.hip")
     for tag, defs in STRESS_VARIANTS.items():
-        o = os.path.join(OBJ, "mpe_split_%s.o" % tag)
-        variants.append((tag, o))
-        if force or _stale(o, [split_src] + hdrs):
-            jobs.append([hipcc] + FLAGS + defs + ["-c", split_src, "-o", o])
+        vo = {}
+        for stem in STRESS_SOURCES:      # the kernel files that carry MPE_STRESS_* hooks
+            src = os.path.join(CSRC, "mpe_%s.hip" % stem)
+            o = os.path.join(OBJ, "mpe_%s_%s.o" % (stem, tag))
+            vo["mpe_%s.o" % stem] = o
+            if force or _stale(o, [src] + hdrs):
+                jobs.append([hipcc] + FLAGS + defs + ["-c", src, "-o", o])
+        variants.append((tag, vo))
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    for tag, o in variants:
+    for tag, vo in variants:
         vlib = os.path.join(LIBDIR, "libmpe_hip_%s.so" % tag)
-        vobjs = [o if x.endswith("mpe_split.o") else x for x in objs]
+        vobjs = [vo.get(os.path.basename(x), x) for x in objs]
         if force or _stale(vlib, vobjs):
             run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", vlib] + vobjs)
     return LIB

@@ -800,6 +800,10 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   if (w0 >= B) return;   // workgroup-uniform
   const int nvalid = (B - w0) < (size_t)G ? (int)(B - w0) : G;
   const bool movable = d.a_flags & kMovable, collide = d.a_flags & kCollide;
+#ifdef MPE_STRESS_DELAY_WAVE   // test build (libmpe_hip_stress.so): one wave of every workgroup starts ~30 us late
+  if (wave == 1)
+    for (int k = 0; k < 10; ++k) __builtin_amdgcn_s_sleep(127);
+#endif
 
   // ---- cooperative stage: thread -> (row, world slot); the slots of a row are adjacent lanes and adjacent bytes ----
   {
@@ -990,6 +994,10 @@ k_duo_roll(const WideDesc d, const MpeBuffers b, const size_t B, const RollArgs 
   }
 
   for (int t = 0; t < T; ++t) {
+#ifdef MPE_STRESS_DELAY_WAVE   // test build: every step one wave lags ~7 us -- alternately a row/reward wave and a physics wave --
+    if (wave == 1 + (t & 1))   // so that its partners run ahead into the next step's buffer as far as the barriers allow
+      for (int k = 0; k < 2; ++k) __builtin_amdgcn_s_sleep(127);
+#endif
     const int cur = t & 1, nxt = cur ^ 1;            // P(t-1) in buffer cur, P(t) goes to buffer nxt
     const uint64_t gt = ra.step0 + (uint64_t)t;
     const bool reset_now = countdown == 0;           // uniform over the grid

@@ -78,13 +78,15 @@ def test_split_vs_thread_bit_identity_1M_worlds_100_steps():
 def test_rollout_and_scenario_suites_pass_under_the_delayed_wave_build():
     """The fused rollouts double-buffer their LDS exchange blocks (and the moves the reward wave draws ahead) by step
     parity, with one barrier per step: exactly the kind of protocol a late wave would break.  Run the rollout and
-    scenario suites -- bit-identity of rollout vs stepwise for all nine scenarios, fused vs generic, goldens -- in a
-    subprocess against libmpe_hip_stress.so (one agent wave of every workgroup ~30 us late)."""
+    scenario and parity suites -- bit-identity of rollout vs stepwise for all nine scenarios and for k_duo_roll, k_duo vs
+    k_wave, fused vs generic, goldens -- in a subprocess against libmpe_hip_stress.so (one wave of every workgroup of
+    k_split / k_duo ~30 us late; in k_duo_roll a different wave lags at every step)."""
     env = dict(os.environ)
     env["MPE_HIP_LIB"] = _build.variant_lib("stress")
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_rollout.py"),
-                        os.path.join(ROOT, "tests", "test_f3_scenarios.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
+                        os.path.join(ROOT, "tests", "test_f3_scenarios.py"), os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
                        capture_output=True, text=True, env=env, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
