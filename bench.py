@@ -248,11 +248,14 @@ class Leg(object):
         bytes_step = algorithmic_bytes(self.A, self.Lm, obs_total, len(env.world.choice_pops), speakers * env.world.dim_c)
         compulsory_roll = 4 * (obs_total + self.A) + self.A    # a fused rollout keeps state on chip and draws moves in-kernel
         A, Lm = self.A, self.Lm
-        if A + Lm <= 16:
+        # which kernel family mpe_step dispatches this shape to (csrc/mpe_abi.hip: the k_split table, else mpe_wide.hip)
+        spread = self.scenario == "simple_spread"
+        if (spread and A == Lm and A <= 6) or (self.scenario == "simple_tag" and (A, Lm) in ((4, 2), (2, 1), (6, 3))) or \
+                self.scenario not in ("simple_spread", "simple_tag"):
             kname = "mpe::k_split"
-        elif max(A, Lm) <= 32 and A + Lm <= 64 and self.scenario == "simple_spread":
+        elif spread and max(A, Lm) <= 32 and A + Lm <= 64:
             kname = "mpe::k_multi"
-        elif self.scenario == "simple_spread" and max(A, Lm) <= 64:
+        elif spread and max(A, Lm) <= 64:
             kname = "mpe::k_duo<4>"
         else:
             kname = "mpe::k_wave"

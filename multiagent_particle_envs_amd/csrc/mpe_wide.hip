@@ -49,6 +49,9 @@
 #ifndef MPE_DUO_ROLL
 #define MPE_DUO_ROLL 1    // 0: the rollout of 33..64-agent spread stays on k_wave<ROLL>
 #endif
+#ifndef MPE_MULTI_ROLL_MAX_N
+#define MPE_MULTI_ROLL_MAX_N 24   // the rollout runs on k_multi<ROLL> up to this max(A, L), on k_wave<ROLL> above (measured)
+#endif
 #ifndef MPE_DUO_G
 #define MPE_DUO_G 4   // worlds per workgroup of k_duo (1, 2, 4 or 8)
 #endif
@@ -1100,9 +1103,13 @@ k_duo_roll(const WideDesc d, const MpeBuffers b, const size_t B, const RollArgs 
 // (xor offsets below AP); row stores are flat over (slot, piece), so the WPW adjacent rows of one agent index form
 // one contiguous WPW * D * 4-byte run.  Same per-pair arithmetic, same accumulation order (action, then partners
 // ascending) as every other kernel.
-template <bool PHYS, bool OUT>
+// ROLL: the fused T-step rollout on the same plan (mpe_rollout_random for these sizes): the wave's worlds stay in
+// their LDS blocks for all T steps, moves and resets are drawn in-kernel exactly as k_wave<ROLL> draws them, every
+// step's rows / rewards are written, the state goes back to HBM once.  (k_wave<ROLL> served these sizes before: a
+// world per wave at N = 8 is 113 us per step at B = 65 536 against 30 us for a launch per step on this kernel.)
+template <bool PHYS, bool OUT, bool ROLL>
 __global__ void __launch_bounds__(kWavesPerWg *kWave)
-k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_groups_padded, const int AP) {
+k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_groups_padded, const int AP, const RollArgs ra) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int A = d.A, L = d.L, E = A + L;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -1167,7 +1174,11 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
 
   const float far = kFarX * d.cmargin;
   const int D = d.D;
-  const bool vec4 = OUT && (D & 3) == 0 && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && ((B * (size_t)D) & 3) == 0;
+  const int T = ROLL ? ra.T : 1;
+  const size_t obs_stride = (ROLL && ra.trajectory) ? (size_t)A * D * B : 0;   // per-step output blocks of a trajectory
+  const size_t row_stride = (ROLL && ra.trajectory) ? (size_t)A * B : 0;
+  const bool vec4 = OUT && (D & 3) == 0 && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && ((B * (size_t)D) & 3) == 0 &&
+                    (obs_stride & 3) == 0;
   const int P = vec4 ? D >> 2 : D >> 1;       // pieces (16 or 8 bytes) per row
   const int npc = WPW * P;                    // pieces per row index over the wave's slots
   const int kpz = 2 + L + (A - 1);
@@ -1188,7 +1199,7 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
         Q[L + a] = p;
         if (PHYS && !agents_only) { const int r = crank[a]; if (r >= 0) CPW[r] = p; }
         V[a] = make_float2(b.vel[(size_t)(2 * a) * B + w], b.vel[(size_t)(2 * a + 1) * B + w]);
-        if (PHYS) {
+        if (PHYS && !ROLL) {
           float ux, uy;
           fetch_action(b, B, a, w, aconst[a].z, ux, uy);
           U[a] = make_float2(ux + 0.f, uy + 0.f);
@@ -1204,6 +1215,47 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
     wave_sync();
 
     const bool have = ok && a < A;
+    const uint64_t gw = ra.world_offset + w;   // global world number (RNG streams)
+    int countdown = -1;    // resets fall on global steps that are multiples of episode_len (as in k_wave<ROLL>)
+    uint64_t ep = 0;
+    if (ROLL && ra.episode_len > 0) {
+      const uint64_t len = (uint64_t)ra.episode_len, r = ra.step0 % len;
+      countdown = r == 0 ? 0 : (int)(len - r);
+      ep = ra.step0 / len + (r ? 1 : 0);
+    }
+    for (int t = 0; t < T; ++t) {
+    if (ROLL) {
+      const uint64_t gt = ra.step0 + (uint64_t)t;
+      const bool reset_now = countdown == 0;   // wave-uniform
+      if (countdown >= 0) countdown = reset_now ? ra.episode_len - 1 : countdown - 1;
+      if (reset_now) {  // reset_world, as mpe_reset draws it for episode ep
+        if (ok && a < A) {
+          float x, y;
+          reset_draw(ra.seed, gw, ep, a, 1.0f, x, y);
+          Q[L + a] = make_float2(x, y);
+          V[a] = make_float2(0.f, 0.f);
+        }
+        if (ok && a < L) {
+          float x, y;
+          reset_draw(ra.seed, gw, ep, A + a, ra.landmark_range, x, y);
+          Q[a] = make_float2(x, y);
+        }
+        ++ep;
+      }
+      if (have) {   // the one-hot row mpe_random_actions would write, decoded
+        const int m = action_draw(ra.seed, gw, gt, a);
+        const float sens = aconst[a].z;
+        const float ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * sens;
+        const float uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * sens;
+        U[a] = make_float2(ux + 0.f, uy + 0.f);
+      }
+      wave_sync();
+      if (!agents_only) {  // the partner list follows the positions
+        if (ok && a < A) { const int r = crank[a]; if (r >= 0) CPW[r] = Q[L + a]; }
+        if (ok && a < L) { const int r = crank[A + a]; if (r >= 0) CPW[r] = Q[a]; }
+        wave_sync();
+      }
+    }
     if (PHYS) {
       // ---- contacts + integrate (core.py:143-169), lane = (slot, agent a) -------------------------------------
       const float4 ac = aconst[a < A ? a : 0];
@@ -1236,10 +1288,12 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
         integrate_one(p.x, p.y, v.x, v.y, ax, ay, ac.x, ac.y, d.damp, d.dt);
         Q[L + a] = p;
         V[a] = v;
-        b.pos[(size_t)(2 * a) * B + w] = p.x;
-        b.pos[(size_t)(2 * a + 1) * B + w] = p.y;
-        b.vel[(size_t)(2 * a) * B + w] = v.x;
-        b.vel[(size_t)(2 * a + 1) * B + w] = v.y;
+        if (!ROLL) {   // (the rollout writes the state back once, after its last step)
+          b.pos[(size_t)(2 * a) * B + w] = p.x;
+          b.pos[(size_t)(2 * a + 1) * B + w] = p.y;
+          b.vel[(size_t)(2 * a) * B + w] = v.x;
+          b.vel[(size_t)(2 * a + 1) * B + w] = v.y;
+        }
       }
       wave_sync();
     }
@@ -1271,7 +1325,7 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
           }
         }
         for (int i = 0; i < A; ++i) {
-          float *const rows = b.obs + ((size_t)i * B + wb) * D;   // wave-uniform: WPW rows of D floats, contiguous
+          float *const rows = b.obs + (size_t)t * obs_stride + ((size_t)i * B + wb) * D;   // wave-uniform: WPW rows of D floats, contiguous
           const int thr = L + i;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
@@ -1295,7 +1349,7 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
         }
       } else
       for (int i = 0; i < A; ++i) {   // generic form (8-byte pieces, or more than three pieces per lane)
-        float *const rows = b.obs + ((size_t)i * B + wb) * D;   // wave-uniform: WPW rows of D floats, contiguous
+        float *const rows = b.obs + (size_t)t * obs_stride + ((size_t)i * B + wb) * D;   // wave-uniform: WPW rows of D floats, contiguous
         for (int idx = lane; idx < npc; idx += kWave) {
           const int sl = idx / P, pc = idx - sl * P;
           if (sl >= nvalid) continue;
@@ -1352,20 +1406,37 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
         if (hi) {
           const float tot = (float)A * neg - csum;   // environment.py:100-102
           const float r = neg - (float)c;
-          if (b.rew) b.rew[(size_t)a * B + w] = d.collaborative ? tot : r;
-          if (b.done) b.done[(size_t)a * B + w] = 0;
+          const size_t o = (size_t)t * row_stride + (size_t)a * B + w;
+          if (b.rew) b.rew[o] = d.collaborative ? tot : r;
+          if (b.done) b.done[o] = 0;
           if (b.info_rew) {
-            b.info_rew[(size_t)a * B + w] = r;
-            b.info_collisions[(size_t)a * B + w] = c;
-            b.info_min_dists[(size_t)a * B + w] = -neg;
-            b.info_occupied[(size_t)a * B + w] = occ;
+            b.info_rew[o] = r;
+            b.info_collisions[o] = c;
+            b.info_min_dists[o] = -neg;
+            b.info_occupied[o] = occ;
           }
         }
       } else if (b.done && have) {
-        b.done[(size_t)a * B + w] = 0;
+        b.done[(size_t)t * row_stride + (size_t)a * B + w] = 0;
       }
     }
-    wave_sync();
+    wave_sync();   // every LDS read of this step is done before the next step / batch of worlds overwrites the blocks
+    }  // steps
+    if (ROLL) {   // hand the state back: every entity (in-kernel resets move the landmarks too)
+      if (have) {
+        const float2 p = Q[L + a], v = V[a];
+        b.pos[(size_t)(2 * a) * B + w] = p.x;
+        b.pos[(size_t)(2 * a + 1) * B + w] = p.y;
+        b.vel[(size_t)(2 * a) * B + w] = v.x;
+        b.vel[(size_t)(2 * a + 1) * B + w] = v.y;
+      }
+      if (ok && a < L) {
+        const float2 p = Q[a];
+        b.pos[(size_t)(2 * (A + a)) * B + w] = p.x;
+        b.pos[(size_t)(2 * (A + a) + 1) * B + w] = p.y;
+      }
+      wave_sync();
+    }
   }
 }
 
@@ -1431,7 +1502,7 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
       return (int)hipGetLastError();
     }
   }
-  if (!roll && amax <= 32 && d.A + d.L <= kWave && !(out && d.kind != MPE_SCN_SPREAD)) {
+  if ((!roll || (phys && out && amax <= MPE_MULTI_ROLL_MAX_N)) && amax <= 32 && d.A + d.L <= kWave && !(out && d.kind != MPE_SCN_SPREAD)) {
     // several worlds per wave (k_multi): AP lanes per world slot
     const int AP = amax <= 8 ? 8 : amax <= 16 ? 16 : 32, WPW = kWave / AP;
     const size_t mlds = cv.shared_bytes + (size_t)kWavesPerWg * WPW * (2 * (d.A + d.L) + 2 * d.A) * sizeof(float2);
@@ -1439,9 +1510,10 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
       const size_t mg = (B + (size_t)kWavesPerWg * WPW - 1) / ((size_t)kWavesPerWg * WPW);
       const size_t mp = (mg + 63) / 64 * 64;
       const dim3 mgrid((unsigned)(mp < cap ? mp : cap));
-      if (phys && out) hipLaunchKernelGGL((k_multi<true, true>), mgrid, block, mlds, stream, d, b, B, (unsigned)mp, AP);
-      else if (phys) hipLaunchKernelGGL((k_multi<true, false>), mgrid, block, mlds, stream, d, b, B, (unsigned)mp, AP);
-      else hipLaunchKernelGGL((k_multi<false, true>), mgrid, block, mlds, stream, d, b, B, (unsigned)mp, AP);
+      if (roll) hipLaunchKernelGGL((k_multi<true, true, true>), mgrid, block, mlds, stream, d, b, B, (unsigned)mp, AP, *roll);
+      else if (phys && out) hipLaunchKernelGGL((k_multi<true, true, false>), mgrid, block, mlds, stream, d, b, B, (unsigned)mp, AP, ra);
+      else if (phys) hipLaunchKernelGGL((k_multi<true, false, false>), mgrid, block, mlds, stream, d, b, B, (unsigned)mp, AP, ra);
+      else hipLaunchKernelGGL((k_multi<false, true, false>), mgrid, block, mlds, stream, d, b, B, (unsigned)mp, AP, ra);
       return (int)hipGetLastError();
     }
   }

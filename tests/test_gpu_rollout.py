@@ -55,8 +55,13 @@ def test_split_and_thread_kernels_bit_identical(name, kw, B):
 @pytest.mark.parametrize("name,kw,B,T,ep", [("simple_spread", {}, 1500, 60, 25), ("simple_tag", {}, 700, 30, 7),
                                             ("simple", {}, 300, 12, 0), ("simple_spread", {"num_agents": 4}, 200, 9, 4),
                                             ("simple_adversary", {}, 900, 30, 5), ("simple_push", {}, 500, 20, 4),
-                                            ("simple_spread", {"num_agents": 8}, 130, 11, 4),            # wave-per-world kernel
+                                            ("simple_spread", {"num_agents": 8}, 130, 11, 4),            # k_multi<ROLL>: several worlds per wave
                                             ("simple_spread", {"num_agents": 20, "num_landmarks": 12}, 70, 7, 3),
+                                            ("simple_spread", {"num_agents": 16}, 1000, 8, 3),
+                                            ("simple_spread", {"num_agents": 32}, 77, 6, 2),
+                                            ("simple_spread", {"num_agents": 7}, 515, 7, 25),             # 8-byte row pieces
+                                            ("simple_spread", {"num_agents": 9, "num_landmarks": 22}, 41, 5, 1),
+                                            ("simple_spread", {"num_agents": 8}, 70000, 3, 2),            # more groups than the persistent grid
                                             ("simple_spread", {"num_agents": 64}, 37, 6, 5),               # k_duo_roll (two waves per world)
                                             ("simple_spread", {"num_agents": 40}, 130, 9, 3),
                                             ("simple_spread", {"num_agents": 33}, 6, 5, 0),               # odd N: 8-byte row pieces
