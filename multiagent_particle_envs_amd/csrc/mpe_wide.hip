@@ -1462,13 +1462,13 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
   const Carve cv = carve(d.A, d.L);
   const size_t lds = cv.shared_bytes + kWavesPerWg * cv.wave_bytes;
   if (lds > kMaxLds) return MPE_EUNSUPPORTED;
-  static int n_cu = 0;
-  if (n_cu == 0) {
+  static const int n_cu = [] {   // (a C++11 magic static: concurrent first calls from several host threads are fine)
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
-    else n_cu = 256;
-  }
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
+    (void)hipGetLastError();
+    return 256;
+  }();
   // groups of kWavesPerWg worlds, padded to whole 64-group blocks so that the XCD-aware permutation
   // inside the kernel is a bijection; persistent grid of up to 8 workgroups per CU (a multiple of 64,
   // hence of 8: a workgroup's later iterations stay on its XCD's share of the worlds)

@@ -191,6 +191,64 @@ def test_error_reporting():
     assert envt.fused and L.mpe_step_supported(C.byref(envt.world.scenario_desc(_abi.MPE_SCN_TAG, 5))) == 1
 
 
+def test_concurrent_host_threads_each_on_its_own_stream():
+    """include/mpe_hip.h: "re-entrant and thread-safe for distinct buffers", errors in a thread-local string.  Four host
+    threads step four envs (one per kernel family) at the same time, each on its own HIP stream (ctypes drops the GIL
+    around every call), and a fifth provokes errors meanwhile: every env ends bit-identical to the same run done alone,
+    and the failing thread's message never shows up in the others."""
+    import threading
+    shapes = [("simple_spread", {}, 4096), ("simple_tag", {}, 3000), ("simple_spread", {"num_agents": 16}, 512),
+              ("simple_spread", {"num_agents": 40}, 64)]
+    T = 60
+
+    def episode(name, kw, B, own_stream):
+        env = make_env(name, batch_size=B, seed=11, **kw)
+        A = len(env.world.agents)
+        acts = torch.as_tensor(np.random.RandomState(B).uniform(-1, 1, (T, A, B, 5)).astype(np.float32)).cuda()
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream() if own_stream else torch.cuda.current_stream()
+        with torch.cuda.stream(s):
+            env.reset()
+            for t in range(T):
+                obs, rew, _, _ = env.step(acts[t])
+            out = [o.clone() for o in obs] + [r.clone() for r in rew] + [env.world.pos.clone(), env.world.vel.clone()]
+            assert not own_stream or _abi.lib().mpe_last_error() == b""   # (a fresh thread: nothing has failed in it)
+        s.synchronize()
+        return out
+
+    alone = [episode(n, kw, B, False) for n, kw, B in shapes]
+    got, errs, stop = [None] * len(shapes), [], threading.Event()
+
+    def worker(k):
+        try:
+            got[k] = episode(*shapes[k], True)
+        except BaseException as e:   # noqa: BLE001 -- reported by the main thread
+            errs.append((k, repr(e)))
+
+    def troublemaker():
+        L, b = _abi.lib(), _abi.MpeBuffers()
+        try:
+            while not stop.is_set():
+                assert L.mpe_step(None, C.byref(b), 64, None) == -1 and L.mpe_last_error() != b""
+        except BaseException as e:   # noqa: BLE001
+            errs.append(("troublemaker", repr(e)))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(len(shapes))]
+    bad = threading.Thread(target=troublemaker)
+    bad.start()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    stop.set()
+    bad.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for k in range(len(shapes)):
+        for a, b_ in zip(alone[k], got[k]):
+            assert torch.equal(a, b_), shapes[k]
+
+
 def test_a_c_program_steps_the_reference_kat_on_the_gpu(tmp_path):
     """tests/c/abi_gpu.c: hipMalloc + mpe_step from C, no Python / torch in the process -- the library is the product,
     PyTorch is plumbing.  Checks the reference's recorded known-answer step."""
