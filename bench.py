@@ -295,7 +295,31 @@ class Leg(object):
                 if EP and k % EP == 0:
                     env.reset()
                 env.step(acts[k % len(acts)])      # (the first block's moves, cycled)
-        return api
+        if mode == "api":
+            return api
+
+        # mode "host": a caller whose policy lives on the host, as the reference's callers do -- one-hot moves arrive in
+        # (pinned) host memory, observations and rewards go back to host memory, and the caller waits for them every step
+        assert r0.pool_c is None, "--mode host: scenarios without a communication action"
+        h_acts = [a.cpu().pin_memory() for a in acts[:min(len(acts), 4)]]
+        d_act = torch.empty_like(acts[0])
+        obs0 = env.reset()
+        h_obs = [torch.empty(o.shape, dtype=o.dtype).pin_memory() for o in obs0]
+        h_rew = [torch.empty(o.shape[:1], dtype=torch.float32).pin_memory() for o in obs0]
+
+        def host():
+            for k in range(n):
+                if EP and k % EP == 0:
+                    for h, o in zip(h_obs, env.reset()):
+                        h.copy_(o, non_blocking=True)
+                d_act.copy_(h_acts[k % len(h_acts)], non_blocking=True)
+                obs, rew, _, _ = env.step(d_act)
+                for h, o in zip(h_obs, obs):
+                    h.copy_(o, non_blocking=True)
+                for h, r in zip(h_rew, rew):
+                    h.copy_(r, non_blocking=True)
+                torch.cuda.synchronize()
+        return host
 
     def timed(self, torch, sharding, dev, mode, protocol, K, W, repeats):
         """-> (seconds for K*R steps: median over repeats, max over ranks; R; HIP-event ms of the median repeat)."""
@@ -365,6 +389,11 @@ class Leg(object):
         self.trajs = None
         self.envs = []
         self.env = None
+
+
+def _abi_action_dim():
+    from multiagent_particle_envs_amd import _abi
+    return _abi.MPE_ACTION_DIM
 
 
 def launch_floor_us(torch, dev, n=400):
@@ -440,7 +469,7 @@ def main():
     ap.add_argument("--scenario", default="simple_spread")
     ap.add_argument("--agents", type=int, default=3)
     ap.add_argument("--episode-len", type=int, default=25)
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "api", "fused"])
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "api", "host", "fused"])
     ap.add_argument("--protocol", default="fresh", choices=["fresh", "resident"],
                     help="fresh: every step's moves are newly drawn (one block draw per episode, timed); resident: a ring of "
                          "16 move tensors drawn once (round-1 headline)")
@@ -543,6 +572,18 @@ def main():
             "what": "MultiAgentEnv.step() / reset() called from Python (the drop-in API; host in the loop, no graph): "
                     "%d steps, reset every %d" % (max(K, 500), EP),
             "value": B * max(K, 500) / dta, "unit": "env-steps/s", "ms_per_step": dta * 1e3 / max(K, 500)}
+
+    if solo and args.mode == "graph" and leg.roll("resident").rollouts[0].pool_c is None:
+        # the same API with the caller's buffers in HOST memory (PCIe both ways, a synchronisation every step): never `value`
+        nh = 100
+        dth, _, _ = leg.timed(torch, _Sh, dev, "host", "resident", nh, 10, 3)
+        io_bytes = 4 * (A * _abi_action_dim() + obs_total + A)
+        extra["host_buffers"] = {
+            "what": "MultiAgentEnv.step() with one-hot moves coming from pinned host memory and observations + rewards copied "
+                    "back to pinned host memory, the caller waiting for them every step (a host-side policy, as in the reference's "
+                    "callers): PCIe-inclusive, %d steps" % nh,
+            "value": B * nh / dth, "unit": "env-steps/s", "ms_per_step": dth * 1e3 / nh,
+            "pcie_bytes_per_env_step": io_bytes, "pcie_GBps": B * nh * io_bytes / dth / 1e9}
 
     headline_roof = roofline_entry(leg, k_us, B, args.mode, floor_us)
     default_line = solo and args.scenario == "simple_spread" and args.agents == 3 and B == 65536
