@@ -236,8 +236,9 @@ class Leg(object):
         """protocol 'fresh': every step consumes moves nobody used before (block redraw per episode, in the timed
         region); 'resident': a ring of 16 move tensors drawn once."""
         if protocol not in self.rolls:
-            P = (self.EP or 16) if protocol == "fresh" else 16
-            rs = [self._RR(e, episode_len=self.EP, pool=P, regenerate=(protocol == "fresh")) for e in self.envs]
+            fresh, ids = protocol.startswith("fresh"), protocol.endswith("_ids")   # "..._ids": int32 move ids instead of one-hot rows
+            P = (self.EP or 16) if fresh else 16
+            rs = [self._RR(e, episode_len=self.EP, pool=P, regenerate=fresh, action_ids=ids) for e in self.envs]
             self.rolls[protocol] = self._SR(rs)
         return self.rolls[protocol]
 
@@ -362,13 +363,13 @@ class Leg(object):
         med = order[len(order) // 2]
         return sharding.reduce_max(walls[med], dev), R, evs[med]
 
-    def kernel_time_us(self, torch, mode, n=400):
+    def kernel_time_us(self, torch, mode, n=400, protocol="resident"):
         """The dominant kernel's time per env step, from HIP events on the launch stream around n back-to-back
         dependent launches with nothing else in between (no resets, no redraws): graph replay / fused launches."""
-        roll = self.roll("resident")
+        roll = self.roll(protocol)
         roll.set_episode_len(0)
         try:
-            body = self.body("fused" if mode == "fused" else "graph", "resident", n)
+            body = self.body("fused" if mode == "fused" else "graph", protocol, n)
             body()
             torch.cuda.synchronize()
             best = None
@@ -564,6 +565,20 @@ def main():
             "what": "the same K-step graph with the moves read from a resident ring of 16 tensors drawn once (no redraw "
                     "launches in the timed region): the step as a policy-driven caller sees it",
             "value": B * K * Rr / dtr, "unit": "env-steps/s", "ms_per_step": dtr * 1e3 / (K * Rr)}
+
+    if solo and args.mode == "graph" and args.protocol == "fresh" and leg.roll("resident").rollouts[0].pool_c is None:
+        # the reference's other action format (`discrete_action_input`, environment.py:161-167): int32 ids, 4 bytes per agent
+        dti, Ri, _ = leg.timed(torch, _Sh, dev, "graph", "fresh_ids", K, W, 3)
+        ki = leg.kernel_time_us(torch, "graph", protocol="resident_ids")
+        bytes_ids = bytes_step - 4 * A * (_abi_action_dim() - 1)
+        extra["int_action_ids"] = {
+            "what": "the headline protocol with the moves handed over as int32 ids [A][B] (discrete_action_input; SURVEY 8d: "
+                    "subtract 5A*4 B, add A*4 B) instead of one-hot fp32 rows: fresh ids for every step, reset every %d" % EP,
+            "value": B * K * Ri / dti, "unit": "env-steps/s", "ms_per_step": dti * 1e3 / (K * Ri),
+            "kernel_us_per_launch": ki, "algorithmic_bytes_per_env_step": bytes_ids,
+            "achieved_GBps": B * bytes_ids / ki / 1e3, "frac": B * bytes_ids / ki / 1e3 / HBM_PEAK_GBS}
+        leg.rolls.pop("fresh_ids", None)
+        leg.rolls.pop("resident_ids", None)
 
     if solo and args.mode == "graph":
         # the drop-in API itself: env.reset() / env.step() called from Python, one launch per call, moves from a resident ring

@@ -19,8 +19,11 @@ from . import _abi
 
 
 class RandomRollout(object):
-    def __init__(self, env, episode_len=25, pool=16, seed=None, regenerate=False):
-        """regenerate: False -- the pool's tensors are drawn once and cycled (the policy's output is already resident
+    def __init__(self, env, episode_len=25, pool=16, seed=None, regenerate=False, action_ids=False):
+        """action_ids: the moves are handed to mpe_step as int32 ids [A][B] (the reference's `discrete_action_input`
+        format, environment.py:161-167: 4 bytes per agent instead of a 20-byte one-hot row; mind its opposite sign
+        convention) instead of one-hot rows -- only for the eager / graph drivers.
+        regenerate: False -- the pool's tensors are drawn once and cycled (the policy's output is already resident
         in HBM when the step is launched); True -- every step consumes moves nobody has used before: whenever the pool
         is exhausted (every `pool` steps; use pool = episode_len) ONE `mpe_random_actions_block` launch redraws all of
         it for the next `pool` global steps, on the same stream.  (Per-step redraws cost a second 2.8 us launch per
@@ -37,7 +40,11 @@ class RandomRollout(object):
         env._ensure_buffers()
         A, B = len(self.world.agents), self.world.batch_size
         self.A, self.B = A, B
-        self.pool_t = torch.empty((int(pool), A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=self.world.device)
+        self.action_ids = bool(action_ids)
+        if self.action_ids:
+            self.pool_t = torch.empty((int(pool), A, B), dtype=torch.int32, device=self.world.device)
+        else:
+            self.pool_t = torch.empty((int(pool), A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=self.world.device)
         self.pool = [self.pool_t[p] for p in range(int(pool))]
         # communication scenarios: the agents that speak say a uniform random word per step (`mpe_random_comm`), pooled
         # like the moves; comm tensor p holds the words of the global steps t with t % len(pool) == p
@@ -65,7 +72,9 @@ class RandomRollout(object):
         """Action tensor p holds the moves of global steps t with t % len(pool) == p -- those of steps
         t0 .. t0 + len(pool) - 1 after this call (t0 a multiple of len(pool)); without `regenerate` the pool is
         drawn once and cycled (the fused kernel draws fresh moves every step)."""
-        _abi.check(self._L.mpe_random_actions_block(self.pool_t.data_ptr(), None, self.A, self.B, self.seed, int(t0),
+        _abi.check(self._L.mpe_random_actions_block(None if self.action_ids else self.pool_t.data_ptr(),
+                                                    self.pool_t.data_ptr() if self.action_ids else None,
+                                                    self.A, self.B, self.seed, int(t0),
                                                     len(self.pool), int(self.world.world_offset),
                                                     stream if stream is not None else self._stream()),
                    "mpe_random_actions_block")
@@ -89,8 +98,8 @@ class RandomRollout(object):
                                        self.t // self.episode_len, int(w.world_offset), st), "mpe_reset")
             out = env._sets[self.t & 1]
             b = out.bufs
-            b.act = self.pool[self.t % len(self.pool)].data_ptr()
-            b.ids = None
+            move = self.pool[self.t % len(self.pool)].data_ptr()
+            b.act, b.ids = (None, move) if self.action_ids else (move, None)
             b.u = None
             if self.pool_c is not None:
                 b.comm = self.pool_c[self.t % len(self.pool)].data_ptr()
@@ -114,7 +123,9 @@ class RandomRollout(object):
 
     def capture(self, steps):
         """Capture `steps` env steps into a HIP graph (torch.cuda.CUDAGraph); replay() re-runs them.
-        `steps` should be a multiple of lcm(episode_len, pool, 2) for the replay to be periodic."""
+        `steps` should be a multiple of lcm(episode_len, pool, 2) for the replay to be periodic.  The two warm-up steps
+        in front of the capture really run (the world moves on by two steps; the step counter does not): begin the
+        captured steps at a reset (self.t a multiple of episode_len) when the trajectory has to be a known one."""
         g = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream(device=self.world.device)
         s.wait_stream(torch.cuda.current_stream(self.world.device))

@@ -220,3 +220,36 @@ def test_fresh_moves_rollout_started_mid_block_reads_the_right_moves():
     roll.enqueue(7)
     torch.cuda.synchronize()
     assert torch.equal(env.world.pos, ref.world.pos) and torch.equal(env.world.vel, ref.world.vel)
+
+
+def test_rollout_with_integer_action_ids_equals_env_steps_with_those_ids():
+    """RandomRollout(action_ids=True): the moves reach mpe_step as int32 ids [A][B] (`discrete_action_input`,
+    environment.py:161-167) -- eager and as a captured graph the same trajectory as env.step() fed the ids
+    mpe_random_actions writes, which are the NumPy Philox restatement's; and NOT the one-hot trajectory (Q3: id 1 is -x)."""
+    from oracle import philox
+    B, T, P, EP = 1000, 11, 4, 7
+    envs = [mpe.make_env("simple_tag", batch_size=B, seed=21) for _ in range(4)]
+    ref = envs[0]
+    ref.discrete_action_input = True
+    ref._ensure_buffers()
+    gen = ref.world.scenario_desc(_abi.MPE_SCN_GENERIC)
+    ids = torch.zeros((4, B), dtype=torch.int32, device="cuda")
+    for t in range(T):
+        if t % EP == 0:
+            _abi.check(_abi.lib().mpe_reset(C.byref(gen), C.byref(ref._sets[0].bufs), B, None, ref.scenario.landmark_range,
+                                            21, t // EP, 0, stream()))
+        _abi.check(_abi.lib().mpe_random_actions(None, ids.data_ptr(), 4, B, 21, t, 0, stream()))
+        assert np.array_equal(ids.cpu().numpy(), philox.action_ids(21, B, t, 4))
+        ref_obs, ref_rew, _, _ = ref.step([ids[i] for i in range(4)])
+    eager = RandomRollout(envs[1], episode_len=EP, pool=P, regenerate=True, action_ids=True)
+    out_e = eager.enqueue(T)
+    graph = RandomRollout(envs[2], episode_len=EP, pool=P, regenerate=True, action_ids=True)
+    graph.capture(T).replay()
+    onehot = RandomRollout(envs[3], episode_len=EP, pool=P, regenerate=True)
+    onehot.enqueue(T)
+    torch.cuda.synchronize()
+    for e in envs[1:3]:
+        assert torch.equal(e.world.pos, ref.world.pos) and torch.equal(e.world.vel, ref.world.vel)
+    for i in range(4):
+        assert torch.equal(out_e.obs_n[i], ref_obs[i]) and torch.equal(out_e.rew[i], ref_rew[i])
+    assert not torch.equal(envs[3].world.pos, ref.world.pos)
