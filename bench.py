@@ -440,6 +440,20 @@ def copy_ceiling_gbs(torch, dev):
     return 5 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def fill_ceiling_gbs(torch, dev):
+    """Linear fill of 1 GiB (writes only): what an output-dominated launch (N = 64: 96 % of its bytes are rows) can stream at."""
+    a = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev)
+    a.fill_(1.0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        a.fill_(2.0)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def roofline_entry(leg, k_us, B, mode, floor_us):
     obs_total, bytes_step, compulsory_roll, kname = leg.geometry()
     per_launch = bytes_step * B
@@ -641,8 +655,13 @@ def main():
 
     if rank == 0:
         copy_gbs = copy_ceiling_gbs(torch, dev)
+        fill_gbs = fill_ceiling_gbs(torch, dev)
+        for ent in extra.get("configs", {}).values():   # the other configs against this box's measured streaming rates
+            ent["roofline"].update({"measured_copy_GBps": copy_gbs, "measured_fill_GBps": fill_gbs,
+                                    "frac_of_measured_fill": ent["roofline"]["achieved"] / fill_gbs})
         headline_roof.update({
             "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": headline_roof["achieved"] / copy_gbs,
+            "measured_fill_GBps": fill_gbs,
             "timed_region_us_per_step": ev_ms * 1e3 / (K * R),
             "note": "achieved = algorithmic bytes per launch / kernel_us_per_launch; kernel_us_per_launch = HIP-event time "
                     "(launch stream) of 400 back-to-back dependent step launches / 400, best of 3 (the rocprofv3 kernel-trace "
