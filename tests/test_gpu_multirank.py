@@ -69,3 +69,29 @@ def test_bench_two_ranks_one_gpu(tmp_path):
             assert np.array_equal(blk, obs[i][sl])
             off += 18
     assert not np.array_equal(ref["pos"][:, :, :B], ref["pos"][:, :, B:])   # the two shards are different worlds
+
+
+def test_bench_single_gpu_line_carries_the_contract():
+    """`python bench.py --steps K --warmup W` (N = 1, as the driver runs it): ONE JSON line with the contract's keys, the
+    HBM roofline object and the CPU baseline object; value == worlds x steps / time."""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-extra",
+                        "--cpu-seconds", "1", "--repeats", "3"], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 10 and out["warmup"] == 3 and out["higher_is_better"] is True
+    assert out["unit"] == "env-steps/s" and out["dtype"] == "f32" and out["data"] == "synthetic" and out["vs_baseline"] is None
+    assert "workload" in out["config"] and "model" not in out["config"] and out["config"]["batch_per_gpu"] == 65536
+    assert abs(out["value"] - 65536 / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
+    roof = out["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0.2 < roof["frac"] < 1.0
+    assert roof["algorithmic_bytes_per_env_step"] == 411 and (roof["traffic"] is None or roof["traffic"] > 2e7)
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] in ("port", "reference") and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["unit"] == "env-steps/s" and cpu["sample"]
