@@ -119,6 +119,7 @@ mpe::WideDesc make_wide(const MpeScenarioDesc *d) {
            d->max_speed[i] == d->max_speed[0] && d->movable[i] == d->movable[0] && d->collide[i] == d->collide[0];
   for (int e = A; e < E; ++e) homo = homo && !d->collide[e];
   w.homo = homo ? 1 : 0;
+  w.rows_nt = 0;   // launch_wide decides (it knows the buffers)
   w.a_flags = (d->movable[0] ? 1 : 0) | (d->collide[0] ? 2 : 0);
   w.a_size = d->size[0];
   w.a_inv_mass = 1.0f / d->mass[0];

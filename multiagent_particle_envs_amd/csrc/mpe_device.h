@@ -335,9 +335,55 @@ struct RowPairs {
   }
 };
 
+// Stores of observation rows: written once, read by nobody on the GPU before the launch ends, and -- the rule every
+// emitter obeys -- a wave store is a whole-line, contiguous, in-order run.  Their cache policy is worth 5-15 % of a launch
+// (same-box A/B, profiles/r2_ab_logs.txt session 40):
+//   kRowsNt   nontemporal ("nt": the line is not kept): best when a launch writes tens of MB -- spread N=3 at 65 536
+//             worlds 6.38 -> 5.52 us, at 1 M worlds 72 -> 69 us, N=64 78-85 -> 74.8 us (and no more bimodality)
+//   kRowsSc1  agent scope ("sc1": written through the XCD's L2): best for the small launches, whose end-of-kernel
+//             write-back of dirty lines is otherwise exposed -- tag at 16 384 worlds 4.14 -> 3.75 us (nt 3.98)
+//   kRowsPlain  rows that share lines between waves (a row that is not a whole number of lines, N=100): either hint
+//             evicts the half-written line before its other half arrives -- 115 -> 145-158 us.
+// The asm form carries no "memory" clobber on purpose (nothing in the kernel reads a row back), so the compiler keeps
+// scheduling LDS reads and arithmetic across it as it does across ordinary stores.  -DMPE_ROW_STORE=<n> forces one policy.
+enum { kRowsPlain = 0, kRowsNt = 1, kRowsSc1 = 2 };
+#ifdef MPE_ROW_STORE
+#define MPE_ROW_POLICY(P) (MPE_ROW_STORE)
+#else
+#define MPE_ROW_POLICY(P) (P)
+#endif
+template <int POLICY>
+__device__ __forceinline__ void store_row4(float *p, float4 o) {
+  typedef float vf4 __attribute__((ext_vector_type(4)));
+  constexpr int F = MPE_ROW_POLICY(POLICY);
+  if constexpr (F == kRowsNt) {
+    vf4 t = {o.x, o.y, o.z, o.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<vf4 *>(p));
+  } else if constexpr (F == kRowsSc1) {
+    vf4 t = {o.x, o.y, o.z, o.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t));
+  } else {
+    *reinterpret_cast<float4 *>(p) = o;
+  }
+}
+template <int POLICY>
+__device__ __forceinline__ void store_row2(float *p, float2 o) {
+  typedef float vf2 __attribute__((ext_vector_type(2)));
+  constexpr int F = MPE_ROW_POLICY(POLICY);
+  if constexpr (F == kRowsNt) {
+    vf2 t = {o.x, o.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<vf2 *>(p));
+  } else if constexpr (F == kRowsSc1) {
+    vf2 t = {o.x, o.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(t));
+  } else {
+    *reinterpret_cast<float2 *>(p) = o;
+  }
+}
+
 // flush_rows: the tile (row stride tile_stride<D>(), rows = lanes) already holds the wave's 64 rows.
 // PAIRS: the rows were written by RowPairs (pair_stride, possibly swizzled); otherwise by put1 / put2 (tile_stride).
-template <int D, bool PAIRS = false>
+template <int D, bool PAIRS = false, int RP = kRowsNt>
 __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict__ g, int nvalid, int lane,
                                            bool vec4) {
   constexpr int S = PAIRS ? pair_stride<D>() : tile_stride<D>();
@@ -353,7 +399,7 @@ __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict_
       const int q = lane + kWave * it;
       const int qs = NSW ? (q ^ swz4<NSW>(q / (NSW ? NSW : 1))) : q;   // NSW is a power of two: q / NSW is the row
       if ((it + 1) * kWave <= NQ || q < NQ)
-        *reinterpret_cast<float4 *>(g + 4 * q) = *reinterpret_cast<const float4 *>(tile + 4 * qs);
+        store_row4<RP>(g + 4 * q, *reinterpret_cast<const float4 *>(tile + 4 * qs));
     }
   } else if (S == D && vec4 && ((nvalid * D) & 3) == 0) {
     // a narrower workgroup (32 / 16 worlds) or an even ragged tail: the same copies, bounded by the rows present
@@ -363,7 +409,7 @@ __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict_
       const int q = lane + kWave * it;
       if (kWave * it >= nq) break;   // uniform
       const int qs = NSW ? (q ^ swz4<NSW>(q / (NSW ? NSW : 1))) : q;
-      if (q < nq) *reinterpret_cast<float4 *>(g + 4 * q) = *reinterpret_cast<const float4 *>(tile + 4 * qs);
+      if (q < nq) store_row4<RP>(g + 4 * q, *reinterpret_cast<const float4 *>(tile + 4 * qs));
     }
   } else {
 #pragma unroll
@@ -385,7 +431,7 @@ __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict_
         }
       }
       if (vec4 && j + 3 < nfl) {
-        *reinterpret_cast<float4 *>(g + j) = make_float4(v[0], v[1], v[2], v[3]);
+        store_row4<RP>(g + j, make_float4(v[0], v[1], v[2], v[3]));
       } else {
 #pragma unroll
         for (int m = 0; m < 4; ++m)

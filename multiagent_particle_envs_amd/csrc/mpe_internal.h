@@ -23,6 +23,7 @@ struct WideDesc {
   // kernels specialised for it take the constants from here instead of the device table
   int32_t homo, a_flags /* 1 movable | 2 collide */;
   float a_size, a_inv_mass, a_accel, a_max_speed;
+  int32_t rows_nt;  // set by launch_wide: every wave store of rows is a whole number of 128-byte lines -> nontemporal stores
 };
 constexpr int kEntityTableCols = 6;  // size, mass, accel, max_speed, movable, collide  -> [6][E] floats
 struct RollArgs;

@@ -374,7 +374,7 @@ __device__ __forceinline__ void store_state(const MpeBuffers &b, size_t B, int i
   (b.vel + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = mvy;
 }
 
-template <int KIND, int A, int L, int NADV, bool ROLL>
+template <int KIND, int A, int L, int NADV, bool ROLL, int RP /* row-store policy: kRowsNt / kRowsSc1 (mpe_device.h) */>
 __global__ void __launch_bounds__((A + 1) * kWave)
 k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs ra) {
   using S = SplitShape<KIND, A, L, NADV>;
@@ -612,7 +612,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       r.put(0, mvx, mvy);
 #pragma unroll
       for (int l = 0; l < L; ++l) r.put(2 + 2 * l, px[A + l] - mx, py[A + l] - my);
-      flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
     }
     if (KIND == MPE_SCN_SPREAD) {  // simple_spread.py:84-100
       constexpr int D = 4 + 2 * L + 4 * (A - 1);
@@ -630,7 +630,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       }
 #pragma unroll
       for (int z = 0; z < 2 * (A - 1); z += 2) r.put(k + z, 0.f, 0.f);  // silent agents' comm
-      flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
     }
     if (KIND == MPE_SCN_TAG) {  // simple_tag.py:131-147
       constexpr int NG = A - NADV;
@@ -656,7 +656,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
           r.put(k, X[(j * XW + 2) * kWave + lane], X[(j * XW + 3) * kWave + lane]);
           k += 2;
         }
-        flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       };
       if (adv) row(std::integral_constant<int, DA>{});
       else     row(std::integral_constant<int, DG>{});
@@ -677,7 +677,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
           r.put(k, px[j] - mx, py[j] - my);
           k += 2;
         }
-        flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       };
       if (adv) row(std::integral_constant<int, DA>{}, std::false_type{});
       else     row(std::integral_constant<int, DG>{}, std::true_type{});
@@ -719,7 +719,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
           else put2<RS>(tile, lane, k, px[j] - mx, py[j] - my);
           k += 2;
         }
-        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D, false, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       };
       if (adv) row(std::integral_constant<int, DA>{}, std::false_type{});
       else     row(std::integral_constant<int, DG>{}, std::true_type{});
@@ -729,7 +729,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         constexpr int D = 3, RS = tile_stride<D>();
 #pragma unroll
         for (int c = 0; c < 3; ++c) put1<RS>(tile, lane, c, goal == c ? 0.65f : 0.15f);
-        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D, false, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       } else {        // listener: vel, landmarks, what the speaker says
         constexpr int D = 2 + 2 * L + DC, RS = tile_stride<D>();
         put1<RS>(tile, lane, 0, mvx); put1<RS>(tile, lane, 1, mvy);
@@ -738,7 +738,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         const Word<ROLL> c0 = word_of<DC, ROLL>(b, B, w0, ln, 0, ra.seed, gw, gt);
 #pragma unroll
         for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, 2 + 2 * L + c, c0[c]);
-        flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D, false, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       }
     }
     if constexpr (KIND == MPE_SCN_REFERENCE) {  // simple_reference.py:63-83
@@ -752,7 +752,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       const Word<ROLL> co = word_of<DC, ROLL>(b, B, w0, ln, 1 - i, ra.seed, gw, gt);
 #pragma unroll
       for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, 5 + 2 * L + c, co[c]);
-      flush_rows<D>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      flush_rows<D, false, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
     }
     if constexpr (KIND == MPE_SCN_CRYPTO) {  // simple_crypto.py:127-169 (goal = pick 0, key = pick 1; colours are one-hots of width dim_c)
       const Word<ROLL> cs = word_of<DC, ROLL>(b, B, w0, ln, 2, ra.seed, gw, gt);   // the speaker's utterance
@@ -762,7 +762,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         RowPairs<D> r(tile, lane);
 #pragma unroll
         for (int c = 0; c < DC; c += 2) r.put(c, cs[c], cs[c + 1]);
-        flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       } else {
         constexpr int D = 2 * DC;
         RowPairs<D> r(tile, lane);
@@ -774,7 +774,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
           if (i == 1) r.put(DC + c, cs[c], cs[c + 1]);
           else        r.put(DC + c, pick1 == c ? 1.f : 0.f, pick1 == c + 1 ? 1.f : 0.f);
         }
-        flush_rows<D, true>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       }
     }
     if constexpr (KIND == MPE_SCN_WORLD_COMM) {  // simple_world_comm.py:231-289
@@ -825,7 +825,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         }
         }
         const int nv = HALF ? min(max(nvalid - 32 * h, 0), 32) : nvalid;   // uniform
-        if (nv > 0) flush_rows<D>(tile, obs_t + B * obs_off_i + (w0 + (HALF ? 32 * h : 0)) * D, nv, lane, d.vec4);
+        if (nv > 0) flush_rows<D, false, RP>(tile, obs_t + B * obs_off_i + (w0 + (HALF ? 32 * h : 0)) * D, nv, lane, d.vec4);
         }
       };
       if (i < NADV) row(std::integral_constant<int, DA>{}, std::true_type{});
@@ -862,14 +862,16 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 
 // ---- dispatch -----------------------------------------------------------------------------------
 
+constexpr size_t kRowsNtFromBytes = 8u << 20;
 using SplitFn = void (*)(const NarrowDesc, const MpeBuffers, const size_t, const RollArgs);
 struct SplitEntry {
   int kind, A, L, nadv;
-  SplitFn step, roll;
+  SplitFn step, step_small, roll;   // step: rows stored nontemporal; step_small: at agent scope (launches that write little)
   size_t lds_step, lds_roll;
 };
-#define MPE_SPLIT_ENTRY(KIND, A, L, NADV)                                                     \
-  { KIND, A, L, NADV, k_split<KIND, A, L, NADV, false>, k_split<KIND, A, L, NADV, true>,       \
+#define MPE_SPLIT_ENTRY(KIND, A, L, NADV)                                                                         \
+  { KIND, A, L, NADV, k_split<KIND, A, L, NADV, false, kRowsNt>, k_split<KIND, A, L, NADV, false, kRowsSc1>,       \
+    k_split<KIND, A, L, NADV, true, kRowsNt>,                                                                      \
     SplitShape<KIND, A, L, NADV>::lds_bytes(false), SplitShape<KIND, A, L, NADV>::lds_bytes(true) }
 
 static const SplitEntry kSplitTable[] = {
@@ -905,7 +907,11 @@ int launch_split(bool roll, int kind, int A, int L, int nadv, const NarrowDesc &
   r2.wpw = kWave;   // measured (tools/ab_run.sh, MPE_SPLIT_WPW builds): 64 wins at every batch -- tag B=16384 4.1 / 4.5 / 5.7 us at 64 / 32 / 16
 #endif
   const unsigned grid = (unsigned)((B + r2.wpw - 1) / r2.wpw);
-  hipLaunchKernelGGL(roll ? e->roll : e->step, dim3(grid), dim3((A + 1) * kWave), roll ? e->lds_roll : e->lds_step, stream,
+  // row-store policy (mpe_device.h): nontemporal from ~8 MB of rows per launch, agent scope below (measured: spread N=3 at
+  // 65 536 worlds (14 MB) 5.54 vs 5.70 us, simple_reference (11 MB) 5.05 vs 5.21, simple_adversary (7 MB) 4.67 vs 4.63,
+  // simple_tag at 16 384 worlds (4 MB) 3.98 vs 3.75, spread N=3 at 4096 worlds (0.9 MB) 3.10 vs 2.98)
+  const bool small = (size_t)d.obs_off[A] * sizeof(float) * B < kRowsNtFromBytes;
+  hipLaunchKernelGGL(roll ? e->roll : small ? e->step_small : e->step, dim3(grid), dim3((A + 1) * kWave), roll ? e->lds_roll : e->lds_step, stream,
                      d, b, B, r2);
   return (int)hipGetLastError();
 }

@@ -59,11 +59,6 @@
 #ifndef MPE_DUO_ABLATE
 #define MPE_DUO_ABLATE 0
 #endif
-// row-store flavour: 0 plain, 1 nontemporal (nt), 2 write-through (sc1)
-#ifndef MPE_ROW_STORE
-#define MPE_ROW_STORE 0
-#endif
-
 namespace mpe {
 
 namespace {
@@ -123,20 +118,6 @@ __host__ __device__ inline Carve carve(int A, int L) {
   c.cpw = o; o += align16(sizeof(float2) * E);         // positions of the collidable entities, by rank (the contact partner list)
   c.wave_bytes = o;
   return c;
-}
-
-__device__ __forceinline__ void row_store4(float *p, float4 o) {
-#if MPE_ROW_STORE == 1
-  typedef float vf4 __attribute__((ext_vector_type(4)));
-  vf4 t = {o.x, o.y, o.z, o.w};
-  __builtin_nontemporal_store(t, reinterpret_cast<vf4 *>(p));
-#elif MPE_ROW_STORE == 2
-  typedef float vf4 __attribute__((ext_vector_type(4)));
-  vf4 t = {o.x, o.y, o.z, o.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
-#else
-  *reinterpret_cast<float4 *>(p) = o;
-#endif
 }
 
 // One world's observation rows (simple_spread.py:84-100), row by row:
@@ -208,6 +189,7 @@ __device__ __forceinline__ void emit_rows(const float2 *Q, const float2 *V, int 
 // pieces are fetched ONCE per world into registers (16 VGPRs); a row is then, per pair, one compare
 // against the uniform threshold L+i, two selects and two subtractions -- no LDS traffic and no address
 // arithmetic in the row loop beyond the broadcast read of (pos_i, vel_i) for the next row.
+template <int RP /* row-store policy (mpe_device.h): kRowsNt when a row is a whole number of lines, else kRowsPlain */>
 __device__ __forceinline__ void emit_rows_fast(const float2 *Q, const float2 *V, int A, int L, int D,
                                                float *obs_w, size_t rowlen, int lane, int i_begin = 0, int i_end = -1) {
   if (i_end < 0) i_end = A;
@@ -247,7 +229,7 @@ __device__ __forceinline__ void emit_rows_fast(const float2 *Q, const float2 *V,
         if (!live[0][1]) { o.z = 0.f; o.w = 0.f; }
       }
       if (lane == 0) o = make_float4(vel.x, vel.y, me.x, me.y);  // the row's header
-      if (st0) row_store4(row + (unsigned)(4 * lane), o);
+      if (st0) store_row4<RP>(row + (unsigned)(4 * lane), o);
     }
     if (two) {
       float4 o;
@@ -257,7 +239,7 @@ __device__ __forceinline__ void emit_rows_fast(const float2 *Q, const float2 *V,
       o.z = s1.x - me.x; o.w = s1.y - me.y;
       if (!live[1][0]) { o.x = 0.f; o.y = 0.f; }
       if (!live[1][1]) { o.z = 0.f; o.w = 0.f; }
-      if (st1) row_store4(row + (unsigned)(4 * (lane + kWave)), o);
+      if (st1) store_row4<RP>(row + (unsigned)(4 * (lane + kWave)), o);
     }
     me = me_n;
     vel = vel_n;
@@ -598,7 +580,8 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
       const bool vec4 = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && ((B * (size_t)D) & 3) == 0 &&
                         ((obs_stride & 3) == 0);
       if (vec4 && D <= 8 * kWave)
-        emit_rows_fast(Q, V, A, L, D, obs_w, rowlen, lane);
+        if (d.rows_nt) emit_rows_fast<kRowsNt>(Q, V, A, L, D, obs_w, rowlen, lane);
+        else           emit_rows_fast<kRowsPlain>(Q, V, A, L, D, obs_w, rowlen, lane);
       else if (vec4)
         emit_rows<4>(Q, V, A, L, D, obs_w, rowlen, lane);
       else
@@ -894,7 +877,8 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   const bool rows16 = (D & 3) == 0 && ((B * (size_t)D) & 3) == 0;
   if (role == 0) {
     if (wok && !(MPE_DUO_ABLATE & 4)) {
-      if (rows16) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
+      if (rows16 && d.rows_nt) emit_rows_fast<kRowsNt>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
+      else if (rows16) emit_rows_fast<kRowsPlain>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
       else        emit_rows<2>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
     }
     return;
@@ -916,7 +900,8 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   if (!wok) return;
   if (!(MPE_DUO_ABLATE & 1)) duo_reward(d, b, Q, A, L, B, w, (size_t)lane * B + w, lane, collide);
   if (!(MPE_DUO_ABLATE & 4)) {
-    if (rows16) emit_rows_fast(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
+    if (rows16 && d.rows_nt) emit_rows_fast<kRowsNt>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
+    else if (rows16) emit_rows_fast<kRowsPlain>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
     else        emit_rows<2>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
   }
 }
@@ -1067,12 +1052,14 @@ k_duo_roll(const WideDesc d, const MpeBuffers b, const size_t B, const RollArgs 
     float *const obs_w = b.obs + (size_t)t * obs_stride + w * (size_t)D;
     if (role == 0) {
       if (wok) {
-        if (rows16) emit_rows_fast(Q, V, A, L, D, obs_w, (size_t)B * D, lane, 0, split);
+        if (rows16 && d.rows_nt) emit_rows_fast<kRowsNt>(Q, V, A, L, D, obs_w, (size_t)B * D, lane, 0, split);
+        else if (rows16) emit_rows_fast<kRowsPlain>(Q, V, A, L, D, obs_w, (size_t)B * D, lane, 0, split);
         else        emit_rows<2>(Q, V, A, L, D, obs_w, (size_t)B * D, lane, 0, split);
       }
     } else if (wok) {
       duo_reward(d, b, Q, A, L, B, w, (size_t)t * row_stride + (size_t)lane * B + w, lane, collide);
-      if (rows16) emit_rows_fast(Q, V, A, L, D, obs_w, (size_t)B * D, lane, split, A);
+      if (rows16 && d.rows_nt) emit_rows_fast<kRowsNt>(Q, V, A, L, D, obs_w, (size_t)B * D, lane, split, A);
+      else if (rows16) emit_rows_fast<kRowsPlain>(Q, V, A, L, D, obs_w, (size_t)B * D, lane, split, A);
       else        emit_rows<2>(Q, V, A, L, D, obs_w, (size_t)B * D, lane, split, A);
     }
   }
@@ -1344,7 +1331,10 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
               o[2 * h] = v.x;
               o[2 * h + 1] = v.y;
             }
-            if (pok[k]) *reinterpret_cast<float4 *>(rows + 4 * (lane + kWave * k)) = make_float4(o[0], o[1], o[2], o[3]);
+            if (pok[k]) {
+              if (d.rows_nt) store_row4<kRowsNt>(rows + 4 * (lane + kWave * k), make_float4(o[0], o[1], o[2], o[3]));
+              else           store_row4<kRowsPlain>(rows + 4 * (lane + kWave * k), make_float4(o[0], o[1], o[2], o[3]));
+            }
           }
         }
       } else
@@ -1455,8 +1445,14 @@ bool wide_supports(const WideDesc &d, bool out) {
   return cv.shared_bytes + kWavesPerWg * cv.wave_bytes <= kMaxLds;
 }
 
-int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, size_t B, hipStream_t stream,
+int launch_wide(bool phys, bool out, const WideDesc &d_in, const MpeBuffers &b, size_t B, hipStream_t stream,
                 const RollArgs *roll) {
+  WideDesc d = d_in;
+  // rows may go out nontemporal when no 128-byte line is shared between two wave stores (mpe_device.h): a row (k_wave /
+  // k_duo) resp. the rows of a wave's worlds for one agent index (k_multi, set below) is a whole number of lines
+  const bool lines = out && d.kind == MPE_SCN_SPREAD && (reinterpret_cast<uintptr_t>(b.obs) & 127) == 0 &&
+                     (((size_t)B * d.D * sizeof(float)) & 127) == 0;
+  d.rows_nt = lines && ((d.D * sizeof(float)) & 127) == 0;
   if (out && d.kind != MPE_SCN_SPREAD && d.kind != MPE_SCN_TAG) return MPE_EUNSUPPORTED;
   if (out && (d.dim_c != 2 || (d.D & 1))) return MPE_EUNSUPPORTED;
   const Carve cv = carve(d.A, d.L);
@@ -1505,6 +1501,7 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
   if ((!roll || (phys && out && amax <= MPE_MULTI_ROLL_MAX_N)) && amax <= 32 && d.A + d.L <= kWave && !(out && d.kind != MPE_SCN_SPREAD)) {
     // several worlds per wave (k_multi): AP lanes per world slot
     const int AP = amax <= 8 ? 8 : amax <= 16 ? 16 : 32, WPW = kWave / AP;
+    d.rows_nt = lines && (((size_t)WPW * d.D * sizeof(float)) & 127) == 0;
     const size_t mlds = cv.shared_bytes + (size_t)kWavesPerWg * WPW * (2 * (d.A + d.L) + 2 * d.A) * sizeof(float2);
     if (mlds <= 64 * 1024) {
       const size_t mg = (B + (size_t)kWavesPerWg * WPW - 1) / ((size_t)kWavesPerWg * WPW);
