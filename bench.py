@@ -685,7 +685,11 @@ def main():
         }
         if extra:
             out["extra"] = extra
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.scenario not in ("simple", "simple_spread", "simple_tag"):
+            out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
+                                   "sample": "none: the per-object CPU restatement (oracle/mpe_loop.py) covers simple / simple_spread / "
+                                             "simple_tag; the batched oracle of the other scenarios is test infrastructure only"}
+        elif not args.no_cpu_baseline and world == 1:
             procs = usable_cores()
             agg, single = cpu_baseline(args.scenario, leg.okw, args.cpu_seconds, procs)
             refkey = {"simple": "simple", "simple_tag": "simple_tag"}.get(

@@ -341,7 +341,8 @@ struct RowPairs {
 //   kRowsNt   nontemporal ("nt": the line is not kept): best when a launch writes tens of MB -- spread N=3 at 65 536
 //             worlds 6.38 -> 5.52 us, at 1 M worlds 72 -> 69 us, N=64 78-85 -> 74.8 us (and no more bimodality)
 //   kRowsSc1  agent scope ("sc1": written through the XCD's L2): best for the small launches, whose end-of-kernel
-//             write-back of dirty lines is otherwise exposed -- tag at 16 384 worlds 4.14 -> 3.75 us (nt 3.98)
+//             write-back of dirty lines is otherwise exposed -- tag at 16 384 worlds 4.14 -> 3.75 us (nt 3.98) -- and for
+//             the k_split rollouts, where nt can lose (simple_adversary 1.47 -> 1.73 us per step, sc1 1.39)
 //   kRowsPlain  rows that share lines between waves (a row that is not a whole number of lines, N=100): either hint
 //             evicts the half-written line before its other half arrives -- 115 -> 145-158 us.
 // The asm form carries no "memory" clobber on purpose (nothing in the kernel reads a row back), so the compiler keeps

@@ -862,16 +862,16 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 
 // ---- dispatch -----------------------------------------------------------------------------------
 
-constexpr size_t kRowsNtFromBytes = 8u << 20;
+constexpr size_t kRowsNtFromBytes = 8u << 20, kRollNtFromBytes = 16u << 20;   // bytes of rows per launch / per rollout step
 using SplitFn = void (*)(const NarrowDesc, const MpeBuffers, const size_t, const RollArgs);
 struct SplitEntry {
   int kind, A, L, nadv;
-  SplitFn step, step_small, roll;   // step: rows stored nontemporal; step_small: at agent scope (launches that write little)
+  SplitFn step, step_small, roll, roll_small;   // rows stored nontemporal; *_small: at agent scope (mpe_device.h)
   size_t lds_step, lds_roll;
 };
 #define MPE_SPLIT_ENTRY(KIND, A, L, NADV)                                                                         \
   { KIND, A, L, NADV, k_split<KIND, A, L, NADV, false, kRowsNt>, k_split<KIND, A, L, NADV, false, kRowsSc1>,       \
-    k_split<KIND, A, L, NADV, true, kRowsNt>,                                                                      \
+    k_split<KIND, A, L, NADV, true, kRowsNt>, k_split<KIND, A, L, NADV, true, kRowsSc1>,                           \
     SplitShape<KIND, A, L, NADV>::lds_bytes(false), SplitShape<KIND, A, L, NADV>::lds_bytes(true) }
 
 static const SplitEntry kSplitTable[] = {
@@ -910,8 +910,12 @@ int launch_split(bool roll, int kind, int A, int L, int nadv, const NarrowDesc &
   // row-store policy (mpe_device.h): nontemporal from ~8 MB of rows per launch, agent scope below (measured: spread N=3 at
   // 65 536 worlds (14 MB) 5.54 vs 5.70 us, simple_reference (11 MB) 5.05 vs 5.21, simple_adversary (7 MB) 4.67 vs 4.63,
   // simple_tag at 16 384 worlds (4 MB) 3.98 vs 3.75, spread N=3 at 4096 worlds (0.9 MB) 3.10 vs 2.98)
-  const bool small = (size_t)d.obs_off[A] * sizeof(float) * B < kRowsNtFromBytes;
-  hipLaunchKernelGGL(roll ? e->roll : small ? e->step_small : e->step, dim3(grid), dim3((A + 1) * kWave), roll ? e->lds_roll : e->lds_step, stream,
+  // The rollouts want the agent-scope form up to larger steps (nt LOSES there: simple_adversary 1.47 -> 1.73 us per step with nt,
+  // 1.39 with sc1; simple_reference 1.97 / 2.29 / 1.88) and nt only for the big rows of simple_world_comm (50 MB per step:
+  // 10.8 plain / 10.7 nt / 16.5 sc1).
+  const size_t row_bytes = (size_t)d.obs_off[A] * sizeof(float) * B;
+  const bool small = row_bytes < (roll ? kRollNtFromBytes : kRowsNtFromBytes);
+  hipLaunchKernelGGL(roll ? (small ? e->roll_small : e->roll) : small ? e->step_small : e->step, dim3(grid), dim3((A + 1) * kWave), roll ? e->lds_roll : e->lds_step, stream,
                      d, b, B, r2);
   return (int)hipGetLastError();
 }
