@@ -862,7 +862,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 
 // ---- dispatch -----------------------------------------------------------------------------------
 
-constexpr size_t kRowsNtFromBytes = 8u << 20, kRollNtFromBytes = 16u << 20;   // bytes of rows per launch / per rollout step
+constexpr size_t kRowsNtFromBytes = 8u << 20, kRollNtFromBytes = 12u << 20;   // bytes of rows per launch / per rollout step
 using SplitFn = void (*)(const NarrowDesc, const MpeBuffers, const size_t, const RollArgs);
 struct SplitEntry {
   int kind, A, L, nadv;
