@@ -73,7 +73,9 @@ def test_split_and_thread_kernels_bit_identical(name, kw, B):
                                             ("simple_tag", {"num_adversaries": 40, "num_good_agents": 30, "num_landmarks": 20}, 10, 5, 2),
                                             # the communication scenarios: words drawn in-kernel, picks re-drawn by in-kernel resets
                                             ("simple_speaker_listener", {}, 700, 13, 4), ("simple_reference", {}, 333, 11, 3),
-                                            ("simple_crypto", {}, 200, 9, 4), ("simple_world_comm", {}, 129, 10, 5)])
+                                            ("simple_crypto", {}, 200, 9, 4), ("simple_world_comm", {}, 129, 10, 5),
+                                            # >= 12 MB of rows per step: the rollout kernels built with nontemporal row stores
+                                            ("simple_spread", {}, 65536, 3, 2), ("simple_world_comm", {}, 20000, 3, 2)])
 def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):
     seed, offset, step0 = 0xABCDEF0123, 4096, 50 if ep in (25, 0) else 14
     # --- stepwise: explicit reset / random_actions / step through the C ABI ----------------------
