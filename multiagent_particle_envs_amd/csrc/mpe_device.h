@@ -382,6 +382,30 @@ __device__ __forceinline__ void store_row2(float *p, float2 o) {
   }
 }
 
+// The step's other outputs -- new state, rewards, dones, benchmark counts -- are 4- and 1-byte lane stores.  POLICY kRowsSc1
+// writes them through the L2 as well (measured per scenario, see aux_policy<KIND>() in mpe_split.hip); -DMPE_AUX_STORE=<n> forces one.
+template <int POLICY, typename T> struct aux_value { typedef T type; };
+template <int POLICY, typename T>
+__device__ __forceinline__ void store_aux(T *p, typename aux_value<POLICY, T>::type v) {
+#ifdef MPE_AUX_STORE
+  constexpr int F = MPE_AUX_STORE;
+#else
+  constexpr int F = POLICY;
+#endif
+  if constexpr (F == kRowsSc1) {
+    if constexpr (sizeof(T) == 4) {
+      asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v));
+    } else {
+      const int vv = (int)v;
+      asm volatile("global_store_byte %0, %1, off sc1" ::"v"(p), "v"(vv));
+    }
+  } else if constexpr (F == kRowsNt) {
+    __builtin_nontemporal_store(v, p);
+  } else {
+    *p = v;
+  }
+}
+
 // flush_rows: the tile (row stride tile_stride<D>(), rows = lanes) already holds the wave's 64 rows.
 // PAIRS: the rows were written by RowPairs (pair_stride, possibly swizzled); otherwise by put1 / put2 (tile_stride).
 template <int D, bool PAIRS = false, int RP = kRowsNt>

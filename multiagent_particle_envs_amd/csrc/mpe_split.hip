@@ -97,7 +97,14 @@ __device__ __forceinline__ Word<ROLL> word_of(const MpeBuffers &b, size_t B, siz
 
 // ---- the reward wave: Scenario.reward / benchmark_data / done for all A agents of 64 worlds --------
 // X is the exchange block the agent waves filled: X[(a * XW + c) * 64 + lane], c = 0,1 pos, 2,3 vel, 4.. d2.
-template <int KIND, int A, int L, int NADV, bool ROLL>
+// Cache policy of the 4- / 1-byte outputs (state, rewards, dones, counts): agent scope for simple_tag's SMALL launches (the
+// kernels built with agent-scope rows), ordinary stores everywhere else.  Measured (profiles/r2_ab_logs.txt session 40): tag at
+// 16 384 worlds 3.78 -> 3.47 us per step, 1.29 -> 1.25 per rollout step, at 4096 worlds 3.24 -> 3.18 -- but at 65 536 worlds
+// 6.52 -> 6.95, and simple_spread loses at both 4096 (2.98 -> 3.11) and 65 536 worlds (5.55 -> 5.94).
+template <int KIND, int RP>
+constexpr int aux_policy() { return (KIND == MPE_SCN_TAG && RP == kRowsSc1) ? kRowsSc1 : kRowsPlain; }
+
+template <int KIND, int A, int L, int NADV, bool ROLL, int AUX>
 __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffers &b, const float *X, int lane,
                                             bool live, unsigned ln, size_t B, size_t w0 /* first world of the wave */,
                                             size_t ro /* uniform: row 0 of this step + w0 */, uint64_t seed, uint64_t gw,
@@ -108,8 +115,8 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
     if (live) {
 #pragma unroll
       for (int a = 0; a < A; ++a) {
-        if (b.rew) (b.rew + wave_off(ro + (size_t)a * B))[ln] = -X[(a * XW + 4) * kWave + lane];
-        if (b.done) (b.done + wave_off(ro + (size_t)a * B))[ln] = 0;
+        if (b.rew) store_aux<AUX>(b.rew + wave_off(ro + (size_t)a * B) + ln, -X[(a * XW + 4) * kWave + lane]);
+        if (b.done) store_aux<AUX>(b.done + wave_off(ro + (size_t)a * B) + ln, 0);
       }
     }
   }
@@ -166,19 +173,19 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
 #pragma unroll
         for (int a = 0; a < A; ++a) {
           const size_t o = ro + (size_t)a * B;
-          if (b.rew) (b.rew + wave_off(o))[ln] = d.collaborative ? total : r[a];
+          if (b.rew) store_aux<AUX>(b.rew + wave_off(o) + ln, d.collaborative ? total : r[a]);
           if (b.info_rew) {
-            (b.info_rew + wave_off(o))[ln] = r[a];
-            (b.info_collisions + wave_off(o))[ln] = cnt[a];
-            (b.info_min_dists + wave_off(o))[ln] = md;
-            (b.info_occupied + wave_off(o))[ln] = occupied;
+            store_aux<AUX>(b.info_rew + wave_off(o) + ln, r[a]);
+            store_aux<AUX>(b.info_collisions + wave_off(o) + ln, cnt[a]);
+            store_aux<AUX>(b.info_min_dists + wave_off(o) + ln, md);
+            store_aux<AUX>(b.info_occupied + wave_off(o) + ln, occupied);
           }
         }
       }
     }
     if (b.done && live) {
 #pragma unroll
-      for (int a = 0; a < A; ++a) (b.done + wave_off(ro + (size_t)a * B))[ln] = 0;
+      for (int a = 0; a < A; ++a) store_aux<AUX>(b.done + wave_off(ro + (size_t)a * B) + ln, 0);
     }
   }
   if (KIND == MPE_SCN_TAG) {  // simple_tag.py:84-129, :57-66
@@ -220,14 +227,14 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
             r -= tag_bound(fabsf(py[a]));
           }
           const size_t o = ro + (size_t)a * B;
-          if (b.rew) (b.rew + wave_off(o))[ln] = r;
-          if (b.info_collisions) (b.info_collisions + wave_off(o))[ln] = c;  // benchmark_data :57-66
+          if (b.rew) store_aux<AUX>(b.rew + wave_off(o) + ln, r);
+          if (b.info_collisions) store_aux<AUX>(b.info_collisions + wave_off(o) + ln, c);  // benchmark_data :57-66
         }
       }
     }
     if (b.done && live) {
 #pragma unroll
-      for (int a = 0; a < A; ++a) (b.done + wave_off(ro + (size_t)a * B))[ln] = 0;
+      for (int a = 0; a < A; ++a) store_aux<AUX>(b.done + wave_off(ro + (size_t)a * B) + ln, 0);
     }
   }
   if (KIND == MPE_SCN_ADVERSARY || KIND == MPE_SCN_PUSH) {
@@ -248,8 +255,8 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
         if (KIND == MPE_SCN_ADVERSARY) r = a < NADV ? -d2g[a] : -fast_sqrt(m2) + adv_sum;            // :113 / :100-107
         else                           r = a < NADV ? fast_sqrt(m2) - fast_sqrt(d2g[a]) : -fast_sqrt(d2g[a]);  // simple_push.py:68-76 / :64-66
         const size_t o = ro + (size_t)a * B;
-        if (b.rew) (b.rew + wave_off(o))[ln] = r;
-        if (b.done) (b.done + wave_off(o))[ln] = 0;
+        if (b.rew) store_aux<AUX>(b.rew + wave_off(o) + ln, r);
+        if (b.done) store_aux<AUX>(b.done + wave_off(o) + ln, 0);
       }
     }
   }
@@ -259,8 +266,8 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
 #pragma unroll
       for (int a = 0; a < A; ++a) {
         const size_t o = ro + (size_t)a * B;
-        if (b.rew) (b.rew + wave_off(o))[ln] = d.collaborative ? r + r : r;
-        if (b.done) (b.done + wave_off(o))[ln] = 0;
+        if (b.rew) store_aux<AUX>(b.rew + wave_off(o) + ln, d.collaborative ? r + r : r);
+        if (b.done) store_aux<AUX>(b.done + wave_off(o) + ln, 0);
       }
     }
   }
@@ -271,8 +278,8 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
 #pragma unroll
       for (int a = 0; a < A; ++a) {
         const size_t o = ro + (size_t)a * B;
-        if (b.rew) (b.rew + wave_off(o))[ln] = d.collaborative ? r0 + r1 : (a == 0 ? r0 : r1);
-        if (b.done) (b.done + wave_off(o))[ln] = 0;
+        if (b.rew) store_aux<AUX>(b.rew + wave_off(o) + ln, d.collaborative ? r0 + r1 : (a == 0 ? r0 : r1));
+        if (b.done) store_aux<AUX>(b.done + wave_off(o) + ln, 0);
       }
     }
   }
@@ -298,8 +305,8 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
       for (int a = 0; a < A; ++a) {
         const float r = a == 0 ? 0.f - err[0] : (0.f + err[0]) + (0.f - err[1]);
         const size_t o = ro + (size_t)a * B;
-        if (b.rew) (b.rew + wave_off(o))[ln] = r;
-        if (b.done) (b.done + wave_off(o))[ln] = 0;
+        if (b.rew) store_aux<AUX>(b.rew + wave_off(o) + ln, r);
+        if (b.done) store_aux<AUX>(b.done + wave_off(o) + ln, 0);
       }
     }
   }
@@ -359,19 +366,20 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
           r = r + 0.05f * fast_sqrt(m2);
         }
         const size_t o = ro + (size_t)a * B;
-        if (b.rew) (b.rew + wave_off(o))[ln] = r;
-        if (b.done) (b.done + wave_off(o))[ln] = 0;
+        if (b.rew) store_aux<AUX>(b.rew + wave_off(o) + ln, r);
+        if (b.done) store_aux<AUX>(b.done + wave_off(o) + ln, 0);
       }
     }
   }
 }
 
+template <int AUX>
 __device__ __forceinline__ void store_state(const MpeBuffers &b, size_t B, int i, size_t w0, unsigned ln, float mx,
                                             float my, float mvx, float mvy) {
-  (b.pos + wave_off((size_t)(2 * i) * B + w0))[ln] = mx;
-  (b.pos + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = my;
-  (b.vel + wave_off((size_t)(2 * i) * B + w0))[ln] = mvx;
-  (b.vel + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = mvy;
+  store_aux<AUX>(b.pos + wave_off((size_t)(2 * i) * B + w0) + ln, mx);
+  store_aux<AUX>(b.pos + wave_off((size_t)(2 * i + 1) * B + w0) + ln, my);
+  store_aux<AUX>(b.vel + wave_off((size_t)(2 * i) * B + w0) + ln, mvx);
+  store_aux<AUX>(b.vel + wave_off((size_t)(2 * i + 1) * B + w0) + ln, mvy);
 }
 
 template <int KIND, int A, int L, int NADV, bool ROLL, int RP /* row-store policy: kRowsNt / kRowsSc1 (mpe_device.h) */>
@@ -379,6 +387,7 @@ __global__ void __launch_bounds__((A + 1) * kWave)
 k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs ra) {
   using S = SplitShape<KIND, A, L, NADV>;
   constexpr int E = A + L, XW = S::XW;
+  constexpr int AUX = aux_policy<KIND, RP>();
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & (kWave - 1);
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // uniform: agent index, or A = reward
@@ -464,7 +473,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
       __syncthreads();
       if (!(MPE_SPLIT_ABLATE & 2))
-      reward_wave<KIND, A, L, NADV, ROLL>(d, b, X, lane, live, ln, B, w0, (size_t)t * row_stride + w0, ra.seed, gw_r,
+      reward_wave<KIND, A, L, NADV, ROLL, AUX>(d, b, X, lane, live, ln, B, w0, (size_t)t * row_stride + w0, ra.seed, gw_r,
                                           ra.step0 + (uint64_t)t, goal_r, food);
     }
     return;
@@ -557,7 +566,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       }
       integrate_one(mx, my, mvx, mvy, fx, fy, mass_i, maxspd_i, d.damp, d.dt);
 #ifdef MPE_STRESS_STORE_BEFORE_BARRIER   // negative control of tests/test_gpu_race.py: the ordering that races
-      if (live && (!ROLL || t == T - 1)) store_state(b, B, i, w0, ln, mx, my, mvx, mvy);
+      if (live && (!ROLL || t == T - 1)) store_state<AUX>(b, B, i, w0, ln, mx, my, mvx, mvy);
 #endif
     }
 
@@ -594,7 +603,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
     // the dispatch order or timing of the waves (core.py:117-131: forces from the pre-step positions).
 #ifndef MPE_STRESS_STORE_BEFORE_BARRIER
     if (movable_i && step_world && live && (!ROLL || t == T - 1) && !(MPE_SPLIT_ABLATE & 8))
-      store_state(b, B, i, w0, ln, mx, my, mvx, mvy);
+      store_state<AUX>(b, B, i, w0, ln, mx, my, mvx, mvy);
 #endif
     if (MPE_SPLIT_ABLATE & 4) continue;   // (no observation rows)
 #pragma unroll
@@ -833,8 +842,8 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
     }
   }
   if (ROLL && NCH >= 1 && ra.episode_len > 0 && live && i == 0) {   // the picks of the last in-kernel reset
-    (b.choice + wave_off(w0))[ln] = goal;
-    if (NCH >= 2) (b.choice + wave_off(B + w0))[ln] = pick1;
+    store_aux<AUX>(b.choice + wave_off(w0) + ln, goal);
+    if (NCH >= 2) store_aux<AUX>(b.choice + wave_off(B + w0) + ln, pick1);
   }
   if (ROLL && ((speakers_of<KIND>() >> i) & 1u) && live && T > 0) {
     // update_agent_state (core.py:171-177): what agent i said at the last step is its comm state afterwards
@@ -852,10 +861,10 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         (b.pos + wave_off((size_t)(2 * (A + l) + 1) * B + w0))[ln] = py[A + l];
       }
     if (!movable_i) {  // an immovable agent is never integrated, but a reset did place it
-      (b.pos + wave_off((size_t)(2 * i) * B + w0))[ln] = mx;
-      (b.pos + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = my;
-      (b.vel + wave_off((size_t)(2 * i) * B + w0))[ln] = mvx;
-      (b.vel + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = mvy;
+      store_aux<AUX>(b.pos + wave_off((size_t)(2 * i) * B + w0) + ln, mx);
+      store_aux<AUX>(b.pos + wave_off((size_t)(2 * i + 1) * B + w0) + ln, my);
+      store_aux<AUX>(b.vel + wave_off((size_t)(2 * i) * B + w0) + ln, mvx);
+      store_aux<AUX>(b.vel + wave_off((size_t)(2 * i + 1) * B + w0) + ln, mvy);
     }
   }
 }
