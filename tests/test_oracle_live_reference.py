@@ -111,3 +111,34 @@ def test_loop_port_replays_fresh_reference_worlds(fresh):
                 for i in range(A):
                     _close(obs[i], g["obs%d" % i][t, w])
                 _close(np.array(rew, dtype=np.float64), g["rew"][t, w])
+
+
+# ---- the six other scenarios: the product's own reset_world / observation / reward (torch, on the CPU) against the
+#      reference run live -- the check tests/test_f3_scenarios.py makes against the committed f3_*.npz, on fresh seeds ----------
+RECORDER_F3 = r"""
+import sys, numpy as np
+sys.path.insert(0, %(golden)r)
+import gen_golden_scenarios as gs
+base = int(sys.argv[1])
+for k, (name, sq) in enumerate([("simple_adversary", 0), ("simple_push", 2), ("simple_speaker_listener", 0), ("simple_reference", 0),
+                                ("simple_crypto", 0), ("simple_world_comm", 2)]):
+    data = gs.record(name, [base + 100 * k + j for j in range(8)], 6, squeeze_every=sq)
+    np.savez(sys.argv[2] + "/f3_" + name + ".npz", **data)
+"""
+
+
+@pytest.fixture(scope="module")
+def fresh_f3(tmp_path_factory):
+    out = tmp_path_factory.mktemp("live_reference_f3")
+    base = int(datetime.date.today().strftime("%y%m%d")) * 1000 + 7
+    env = dict(os.environ, SUPPRESS_MA_PROMPT="1", PYTHONDONTWRITEBYTECODE="1", PYTHONWARNINGS="ignore")
+    r = subprocess.run([sys.executable, "-c", RECORDER_F3 % {"golden": os.path.join(ROOT, "tests", "golden")}, str(base), str(out)],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=str(out))
+    assert r.returncode == 0, r.stderr[-3000:]
+    return lambda name: dict(np.load(os.path.join(str(out), name + ".npz")))
+
+
+def test_host_callbacks_of_the_other_six_scenarios_on_fresh_reference_worlds(fresh_f3):
+    import test_f3_scenarios as f3
+    for name in f3.NAMES:
+        f3.test_reset_and_callbacks_match_reference_on_cpu(name, fresh_f3)
