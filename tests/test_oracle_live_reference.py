@@ -88,6 +88,25 @@ def test_batched_oracle_replays_fresh_reference_worlds(name, spec, bench, fresh)
             _close(info["min_dists"].T, g["info_min_dists"][t])
 
 
+@pytest.mark.parametrize("name,spec,bench", CASES, ids=[c[0] for c in CASES])
+def test_c_restatement_replays_fresh_reference_worlds(name, spec, bench, fresh):
+    """oracle/mpe_oracle.c (bench.py's `c_port`), teacher-forced from the reference's own states."""
+    from oracle import build_c
+    g = fresh(name)
+    T, W, A = g["rew"].shape
+    for t in range(T):
+        p0 = g["pos0"] if t == 0 else g["pos"][t - 1]
+        v0 = g["vel0"] if t == 0 else g["vel"][t - 1]
+        pos, vel, obs, rew, col = build_c.step_batch(spec, p0, v0, g["act"][t], threads=2)
+        _close(pos, g["pos"][t])
+        _close(vel, g["vel"][t])
+        for i in range(A):
+            _close(obs[i], g["obs%d" % i][t])
+        _close(rew, g["rew"][t])
+        if "info_collisions" in g:
+            assert np.array_equal(col, g["info_collisions"][t])
+
+
 def test_seeded_resets_of_fresh_worlds(fresh):
     """reset_world consumes the global MT19937 stream in the reference's order: the un-squeezed worlds' initial
     states follow from their seeds alone."""
