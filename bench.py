@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps 1000 --warmup 50
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          # no launcher: bench.py starts the N ranks itself (one per GPU)
 
 Headline workload (BASELINE.json metric config, C5): simple_spread, 3 agents / 3 landmarks, 65536 worlds PER GPU
 (weak scaling: rank r owns worlds [r*B, (r+1)*B); no collective on the step path), fp32.
@@ -12,9 +13,15 @@ Protocol: uniform random one-hot moves `[A][B][5]` that are FRESH
 device-side `mpe_reset` every 25 steps (MADDPG episode length), one `mpe_step` launch per step that reads its moves
 from HBM and writes every agent's obs / reward / done.  One "step" = every world of the batch advanced once.
 
-Timed region: barrier + synchronize, the K-step HIP graph replayed R times back to back (R = 1 when K steps already
-take >= 20 ms; a 20-step region is 0.15 ms, shorter than one graph launch is accurate to), synchronize + barrier;
-max over ranks; `value` = B * K * R * ranks / that time.  Rank 0 prints ONE JSON line.
+Timed region: barrier + synchronize, a HIP graph of up to 8000 CONSECUTIVE steps replayed back to back until the region
+holds >= 2 s of GPU work (whatever --steps is: `--steps 20` and `--steps 1000` time the same graph), synchronize +
+barrier; median of 5 repeats, max over ranks; `value` = B * timed steps * ranks / that time.  Rank 0 prints ONE JSON line.
+
+N > 1 never measures fewer GPUs than asked for: with WORLD_SIZE unset `--gpus N` starts N ranks itself and fails when
+the node has fewer GPUs or a rank fails; with a launcher, WORLD_SIZE must equal --gpus.  The barrier travels over RCCL
+when every rank can bring it up and over gloo otherwise (`config.barrier_backend`; the step path has no collective, so
+the measured work is the same); `config.ranks` lists each rank's GPU, its own rate and kernel time; `roofline` is per
+GPU (slowest rank's kernel) and `cpu_baseline` is emitted on every line.
 
 Besides the headline the line carries (N=1 only):
   roofline             the step kernel's HIP-event time over back-to-back launches -> algorithmic GB/s vs 8 TB/s.
@@ -22,11 +29,12 @@ Besides the headline the line carries (N=1 only):
                        Cache: the limit there is launch + latency, and the line says so.
   extra.hbm_resident   the same kernel and protocol at B=1048576 (431 MB per launch: beyond the Infinity Cache)
   extra.configs        BASELINE.json's other single-GPU configs: C2 spread N=3 B=4096, C3 simple_tag B=16384,
-                       C4 spread N=64 B=4096 -- each with its own roofline entry
+                       C4 spread N=64 B=4096 -- each with its own roofline entry and min / median / max over 5 repeats
   extra.fused_rollout  `mpe_rollout_random`: one launch per episode, state on chip, moves drawn in-kernel
   extra.moves_resident the round-1 headline: moves read from a resident ring that is never redrawn
-  cpu_baseline         oracle/mpe_loop.py on the host cores (+ the C port), with the unmodified reference's own
-                       numbers from the build container (profiles/cpu_reference.json) quoted beside it
+  extra.box            which GPU / clocks / power cap / partition modes / driver this line was measured on
+  cpu_baseline         oracle/mpe_loop.py on the host cores (+ the C port), timed AFTER the GPU legs, with the unmodified
+                       reference's own numbers from the build container (profiles/cpu_reference.json) quoted beside it
 """
 import argparse
 import json
@@ -41,7 +49,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~5.3-6.3 TB/s is the measured copy ceiling
 L3_BYTES = 256 * 1024 * 1024   # Infinity Cache
-MIN_REGION_MS = 20.0
+MIN_REGION_MS = 2000.0      # the headline's timed region: >= 2 s of back-to-back GPU work per repeat
+SIDE_REGION_MS = 300.0      # the secondary legs'
+MAX_GRAPH_STEPS = 8000      # consecutive steps captured into one HIP graph (replayed to fill the region)
 
 
 def algorithmic_bytes(A, L, obs_total, n_choices=0, comm_floats=0):
@@ -136,7 +146,7 @@ def cpu_reference_record(key):
         return None
 
 
-def bench_generic(args, env, dev, rank, world, sharding):
+def bench_generic(args, env, dev, rank, world, rv):
     """Scenarios without a fused kernel: MultiAgentEnv.step() from Python -- torch
     _set_action, `mpe_world_step` (HIP), the scenario's torch observation/reward callbacks.  Host- and
     launch-bound by construction; reported as throughput only (no roofline claim)."""
@@ -164,13 +174,13 @@ def bench_generic(args, env, dev, rank, world, sharding):
     run(W)
     walls = []
     for _ in range(args.repeats):
-        sharding.barrier(dev)
+        rv.barrier()
         t0 = time.perf_counter()
         run(K)
         torch.cuda.synchronize()
         walls.append(time.perf_counter() - t0)
-        sharding.barrier(dev)
-    dt = sharding.reduce_max(sorted(walls)[len(walls) // 2], dev)
+        rv.barrier()
+    dt = rv.reduce_max(sorted(walls)[len(walls) // 2])
     # the same step captured once into a HIP graph (GraphedStep): one replay per step instead of ~100 launches
     from multiagent_particle_envs_amd import GraphedStep
     gs = GraphedStep(env, pool[0])
@@ -183,13 +193,13 @@ def bench_generic(args, env, dev, rank, world, sharding):
     run_graphed(W)
     walls = []
     for _ in range(args.repeats):
-        sharding.barrier(dev)
+        rv.barrier()
         t0 = time.perf_counter()
         run_graphed(K)
         torch.cuda.synchronize()
         walls.append(time.perf_counter() - t0)
-        sharding.barrier(dev)
-    dtg = sharding.reduce_max(sorted(walls)[len(walls) // 2], dev)
+        rv.barrier()
+    dtg = rv.reduce_max(sorted(walls)[len(walls) // 2])
     if rank == 0:
         A, Lm = len(env.world.agents), len(env.world.landmarks)
         print(json.dumps({
@@ -322,8 +332,13 @@ class Leg(object):
                 torch.cuda.synchronize()
         return host
 
-    def timed(self, torch, sharding, dev, mode, protocol, K, W, repeats):
-        """-> (seconds for K*R steps: median over repeats, max over ranks; R; HIP-event ms of the median repeat)."""
+    def timed(self, torch, rv, dev, mode, protocol, K, W, repeats, region_ms=None):
+        """-> (seconds for the timed steps: median over repeats, max over ranks; R = timed steps / K; HIP-event ms of
+        the median repeat; [min, median, max] env-steps/s of this rank over the repeats).
+        The timed region is >= region_ms of back-to-back GPU work: a HIP graph of G = K*r1 CONSECUTIVE steps (resets
+        and move draws fall every episode_len steps of the long run, whatever K is; G <= MAX_GRAPH_STEPS) replayed
+        `reps` times with nothing in between."""
+        region_ms = MIN_REGION_MS if region_ms is None else region_ms
         roll = self.roll(protocol)
         body = self.body(mode, protocol, K)
         if mode == "fused":
@@ -332,23 +347,22 @@ class Leg(object):
             roll.enqueue(W)
         body()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()     # size the region: R replays of the K-step body >= MIN_REGION_MS
+        t0 = time.perf_counter()     # size the region
         body()
         torch.cuda.synchronize()
         once = max(time.perf_counter() - t0, 1e-6)
-        R = max(1, int(math.ceil(MIN_REGION_MS * 1e-3 / once))) if mode in ("graph", "fused") else 1
-        R = int(sharding.reduce_max(R, dev))
-        reps = R
-        if R > 1 and K * R <= 8000:
-            # one body of K*R CONSECUTIVE steps (resets and move draws fall every episode_len steps of the long run,
-            # whatever K is) instead of R replays of a K-step episode fragment
-            body = self.body(mode, protocol, K * R)
+        R = max(1, int(math.ceil(region_ms * 1e-3 / once))) if mode in ("graph", "fused") else 1
+        R = int(rv.reduce_max(R))
+        r1 = max(1, min(R, MAX_GRAPH_STEPS // max(K, 1)))
+        reps = int(math.ceil(R / float(r1)))
+        R = r1 * reps
+        if r1 > 1:
+            body = self.body(mode, protocol, K * r1)
             body()
             torch.cuda.synchronize()
-            reps = 1
         walls, evs = [], []
         for _ in range(repeats):
-            sharding.barrier(dev)
+            rv.barrier()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
             e0.record()
@@ -357,11 +371,12 @@ class Leg(object):
             e1.record()
             torch.cuda.synchronize()
             walls.append(time.perf_counter() - t0)   # this rank's K*R steps, from the common start to its own completion
-            sharding.barrier(dev)                      # (the MAX over ranks below is the job's time)
+            rv.barrier()                               # (the MAX over ranks below is the job's time)
             evs.append(e0.elapsed_time(e1))
         order = sorted(range(len(walls)), key=lambda i: walls[i])
         med = order[len(order) // 2]
-        return sharding.reduce_max(walls[med], dev), R, evs[med]
+        rate = [self.B * K * R / walls[i] for i in (order[-1], med, order[0])]
+        return rv.reduce_max(walls[med]), R, evs[med], rate
 
     def kernel_time_us(self, torch, mode, n=400, protocol="resident"):
         """The dominant kernel's time per env step, from HIP events on the launch stream around n back-to-back
@@ -475,7 +490,36 @@ def roofline_entry(leg, k_us, B, mode, floor_us):
             "frac_excluding_launch_floor": (per_launch / max((k_us - floor_us), 1e-3) / 1e3 / HBM_PEAK_GBS) if floor_us else None}
 
 
-def main():
+def box_fingerprint(torch, dev):
+    """What this rank's GPU is and how the box is set up: device properties from the runtime, clocks / power cap /
+    partition modes / driver from rocm-smi when it answers (C4's 20 % box-to-box spread, DESIGN 2.7, needs a label)."""
+    fp = {}
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        fp.update({"name": pr.name, "arch": getattr(pr, "gcnArchName", None), "cus": pr.multi_processor_count,
+                   "hbm_bytes": pr.total_memory, "uuid": str(getattr(pr, "uuid", "")) or None,
+                   "clock_rate_khz": getattr(pr, "clock_rate", None), "memory_clock_rate_khz": getattr(pr, "memory_clock_rate", None),
+                   "l2_bytes": getattr(pr, "L2_cache_size", None)})
+        fp["hip"] = torch.version.hip
+    except Exception as e:
+        fp["error"] = repr(e)
+    try:
+        import subprocess
+        r = subprocess.run(["rocm-smi", "-d", str(dev.index), "--showclocks", "--showpower", "--showmaxpower", "--showmemorypartition",
+                            "--showcomputepartition", "--showdriverversion", "--showperflevel", "--json"],
+                           capture_output=True, text=True, timeout=30)
+        d = json.loads(r.stdout[r.stdout.index("{"):])
+        smi = {}
+        for card, kv in d.items():
+            for k, v in kv.items():
+                smi["%s/%s" % (card, k)] = v
+        fp["rocm_smi"] = smi
+    except Exception as e:
+        fp["rocm_smi"] = "unavailable: %s" % type(e).__name__
+    return fp
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -489,12 +533,15 @@ def main():
                     help="fresh: every step's moves are newly drawn (one block draw per episode, timed); resident: a ring of "
                          "16 move tensors drawn once (round-1 headline)")
     ap.add_argument("--repeats", type=int, default=5)
+    ap.add_argument("--region-ms", type=float, default=MIN_REGION_MS,
+                    help="minimum back-to-back GPU work per timed repeat of the headline leg")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other configs, 1M leg, fused rollout)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--backend", default=None, help="torch.distributed backend for N>1 (default nccl = RCCL; gloo for the "
-                                                     "one-GPU rehearsal test)")
+    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"],
+                    help="what carries the N>1 barrier: auto = RCCL when every rank can bring it up, else gloo (the step "
+                         "path has no collective either way)")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--dump-state", default=None, metavar="DIR",
                     help="before timing: run the rollout's episode-0 reset + step 0 and save this rank's pos / vel / obs / "
@@ -503,42 +550,68 @@ def main():
                     help="step through the generic path (torch callbacks + mpe_world_step) although a fused kernel exists")
     ap.add_argument("--streams", type=int, default=1,
                     help="cut the per-GPU batch into this many independent sub-batches, one HIP stream each")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one per GPU), relay rank 0's
+    line.  Never measures fewer GPUs than were asked for: too few visible GPUs, a failed rank or a line whose n_gpus is
+    not N is a non-zero exit, not a mislabelled record."""
+    import torch
+    from multiagent_particle_envs_amd import sharding
+    n = args.gpus
+    seen = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if seen < (1 if args.all_ranks_on_gpu0 else n):
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this node -- refusing to measure fewer GPUs "
+                         "than requested (run with --gpus <= %d, or --all-ranks-on-gpu0 for the one-GPU rehearsal)\n"
+                         % (n, seen, max(seen, 1)))
+        return 2
+    sys.stderr.write("bench.py: --gpus %d without a launcher (WORLD_SIZE unset): starting %d ranks, one per GPU\n" % (n, n))
+    rc, out = sharding.spawn_local_ranks([os.path.abspath(__file__)] + sys.argv[1:], n, one_device=args.all_ranks_on_gpu0)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if rc != 0 or len(lines) != 1:
+        sys.stderr.write("bench.py: the %d-rank job failed (exit %s, %d JSON lines)\n%s\n" % (n, rc, len(lines), out[-2000:]))
+        return rc or 1
+    line = json.loads(lines[0])
+    if line.get("n_gpus") != n:
+        sys.stderr.write("bench.py: ranks reported n_gpus=%r for --gpus %d\n" % (line.get("n_gpus"), n))
+        return 1
+    line["config"]["launcher"] = "self-spawned (bench.py started the ranks)"
+    print(json.dumps(line))
+    return 0
+
+
+def main():
+    args = parse_args()
+    env_world = int(os.environ.get("WORLD_SIZE", "1") or "1")
+    if args.gpus > 1 and env_world == 1:
+        sys.exit(launch_ranks(args))
 
     import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = env_world
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d: launch with --nproc-per-node == --gpus (or drop the launcher: "
+                         "`python bench.py --gpus N` starts its own ranks)" % (world, args.gpus))
     local = 0 if args.all_ranks_on_gpu0 else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the step path has no CPU fallback)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants cuda:%d, %d GPU(s) visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = args.backend or "nccl"
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
-    rdev = dev if (world == 1 or (args.backend or "nccl") == "nccl") else torch.device("cpu")   # where the bookkeeping reductions live
 
     import multiagent_particle_envs_amd as mpe
     from multiagent_particle_envs_amd import sharding
+    rv = sharding.Rendezvous(rank, world, dev, backend=args.backend)
+    if rv.note and rank == 0:
+        sys.stderr.write("bench.py: %s\n" % rv.note)
 
-    class _Sh(object):   # barrier on the GPU, reductions on the backend's device
-        @staticmethod
-        def barrier(d):
-            sharding.barrier(d)
-
-        @staticmethod
-        def reduce_max(v, d):
-            return sharding.reduce_max(v, rdev)
     B, K, W, EP = args.batch, args.steps, args.warmup, args.episode_len
     leg = Leg(mpe, args.scenario, args.agents, B, EP, rank, args.streams, args.seed, args.generic)
     if not leg.env.fused:
-        return bench_generic(args, leg.env, dev, rank, world, _Sh)
+        bench_generic(args, leg.env, dev, rank, world, rv)
+        return rv.close()
     A, Lm = leg.A, leg.Lm
     obs_total, bytes_step, compulsory_roll, kname = leg.geometry()
     can_fuse = A + Lm <= 16 or args.scenario in ("simple_spread", "simple_tag")
@@ -554,19 +627,23 @@ def main():
                  vel=leg.env.world.vel.cpu().numpy(), obs=out0.obs.cpu().numpy(), rew=out0.rew.cpu().numpy(),
                  world_offset=np.int64(leg.env.world.world_offset))
 
-    dt, R, ev_ms = leg.timed(torch, _Sh, dev, args.mode, args.protocol, K, W, args.repeats)
+    def stats(rate):
+        return {"min": rate[0], "median": rate[1], "max": rate[2], "unit": "env-steps/s per GPU"}
+
+    dt, R, ev_ms, rate = leg.timed(torch, rv, dev, args.mode, args.protocol, K, W, args.repeats, args.region_ms)
     k_us = leg.kernel_time_us(torch, args.mode)
     floor_us = launch_floor_us(torch, dev)
     extra = {}
     solo = world == 1 and not args.no_extra and args.streams == 1
+    SR = SIDE_REGION_MS
 
     if solo and can_fuse and args.mode != "fused":
-        dtf, Rf, _ = leg.timed(torch, _Sh, dev, "fused", "resident", K, W, 3)
+        dtf, Rf, _, rf = leg.timed(torch, rv, dev, "fused", "resident", K, W, 3, SR)
         kf = leg.kernel_time_us(torch, "fused")
         extra["fused_rollout"] = {
             "what": "mpe_rollout_random: one launch per %d-step episode, state kept on chip (registers / LDS), moves drawn "
                     "in-kernel, every step's obs/rew/done written to its own trajectory block" % (EP or 25),
-            "value": B * K * Rf / dtf, "unit": "env-steps/s", "ms_per_step": dtf * 1e3 / (K * Rf),
+            "value": B * K * Rf / dtf, "unit": "env-steps/s", "ms_per_step": dtf * 1e3 / (K * Rf), "repeats": stats(rf),
             "kernel_us_per_step": kf,
             "compulsory_bytes_per_env_step": compulsory_roll,
             "achieved_GBps_compulsory": compulsory_roll * B / (kf * 1e-6) / 1e9,
@@ -574,21 +651,21 @@ def main():
             "achieved_GBps_at_per_step_convention": bytes_step * B / (kf * 1e-6) / 1e9,
             "per_step_convention_bytes": bytes_step}
     if solo and args.mode == "graph" and args.protocol == "fresh":
-        dtr, Rr, _ = leg.timed(torch, _Sh, dev, "graph", "resident", K, W, 3)
+        dtr, Rr, _, rr = leg.timed(torch, rv, dev, "graph", "resident", K, W, 3, SR)
         extra["moves_resident"] = {
             "what": "the same K-step graph with the moves read from a resident ring of 16 tensors drawn once (no redraw "
                     "launches in the timed region): the step as a policy-driven caller sees it",
-            "value": B * K * Rr / dtr, "unit": "env-steps/s", "ms_per_step": dtr * 1e3 / (K * Rr)}
+            "value": B * K * Rr / dtr, "unit": "env-steps/s", "ms_per_step": dtr * 1e3 / (K * Rr), "repeats": stats(rr)}
 
     if solo and args.mode == "graph" and args.protocol == "fresh" and leg.roll("resident").rollouts[0].pool_c is None:
         # the reference's other action format (`discrete_action_input`, environment.py:161-167): int32 ids, 4 bytes per agent
-        dti, Ri, _ = leg.timed(torch, _Sh, dev, "graph", "fresh_ids", K, W, 3)
+        dti, Ri, _, ri = leg.timed(torch, rv, dev, "graph", "fresh_ids", K, W, 3, SR)
         ki = leg.kernel_time_us(torch, "graph", protocol="resident_ids")
         bytes_ids = bytes_step - 4 * A * (_abi_action_dim() - 1)
         extra["int_action_ids"] = {
             "what": "the headline protocol with the moves handed over as int32 ids [A][B] (discrete_action_input; SURVEY 8d: "
                     "subtract 5A*4 B, add A*4 B) instead of one-hot fp32 rows: fresh ids for every step, reset every %d" % EP,
-            "value": B * K * Ri / dti, "unit": "env-steps/s", "ms_per_step": dti * 1e3 / (K * Ri),
+            "value": B * K * Ri / dti, "unit": "env-steps/s", "ms_per_step": dti * 1e3 / (K * Ri), "repeats": stats(ri),
             "kernel_us_per_launch": ki, "algorithmic_bytes_per_env_step": bytes_ids,
             "achieved_GBps": B * bytes_ids / ki / 1e3, "frac": B * bytes_ids / ki / 1e3 / HBM_PEAK_GBS}
         leg.rolls.pop("fresh_ids", None)
@@ -596,16 +673,17 @@ def main():
 
     if solo and args.mode == "graph":
         # the drop-in API itself: env.reset() / env.step() called from Python, one launch per call, moves from a resident ring
-        dta, _, _ = leg.timed(torch, _Sh, dev, "api", "resident", max(K, 500), W, 3)
+        na = max(K, 20000)
+        dta, _, _, ra = leg.timed(torch, rv, dev, "api", "resident", na, W, 3)
         extra["python_api"] = {
             "what": "MultiAgentEnv.step() / reset() called from Python (the drop-in API; host in the loop, no graph): "
-                    "%d steps, reset every %d" % (max(K, 500), EP),
-            "value": B * max(K, 500) / dta, "unit": "env-steps/s", "ms_per_step": dta * 1e3 / max(K, 500)}
+                    "%d steps, reset every %d" % (na, EP),
+            "value": B * na / dta, "unit": "env-steps/s", "ms_per_step": dta * 1e3 / na, "repeats": stats(ra)}
 
     if solo and args.mode == "graph" and leg.roll("resident").rollouts[0].pool_c is None:
         # the same API with the caller's buffers in HOST memory (PCIe both ways, a synchronisation every step): never `value`
-        nh = 100
-        dth, _, _ = leg.timed(torch, _Sh, dev, "host", "resident", nh, 10, 3)
+        nh = 200
+        dth, _, _, rh = leg.timed(torch, rv, dev, "host", "resident", nh, 10, 3)
         io_bytes = 4 * (A * _abi_action_dim() + obs_total + A)
         extra["host_buffers"] = {
             "what": "MultiAgentEnv.step() with one-hot moves coming from pinned host memory and observations + rewards copied "
@@ -621,12 +699,12 @@ def main():
         torch.cuda.empty_cache()
         # ---- the same kernel and protocol where the working set cannot sit in the Infinity Cache ----------------
         big = Leg(mpe, "simple_spread", 3, 1 << 20, EP, rank, 1, args.seed)
-        dtb, Rb, _ = big.timed(torch, _Sh, dev, "graph", "fresh", 25, 5, 3)
+        dtb, Rb, _, rb_ = big.timed(torch, rv, dev, "graph", "fresh", 25, 5, 5, 2 * SR)
         kb = big.kernel_time_us(torch, "graph", n=100)
         rb = roofline_entry(big, kb, 1 << 20, "graph", floor_us)
         extra["hbm_resident"] = {"what": "simple_spread N=3 at 1048576 worlds (431 MB per launch, 2 GB of moves per episode): "
                                          "same kernel, same protocol, HBM-resident",
-                                 "value": (1 << 20) * 25 * Rb / dtb, "unit": "env-steps/s",
+                                 "value": (1 << 20) * 25 * Rb / dtb, "unit": "env-steps/s", "repeats": stats(rb_),
                                  "ms_per_step": dtb * 1e3 / (25 * Rb), "roofline": rb}
         big.release()
         del big
@@ -637,14 +715,15 @@ def main():
                                      ("C3_tag_B16384", "simple_tag", 3, 16384, 200),
                                      ("C4_spread_n64_B4096", "simple_spread", 64, 4096, 50)):
             lg = Leg(mpe, scn, ag, bb, EP, rank, 1, args.seed)
-            d1, R1, _ = lg.timed(torch, _Sh, dev, "graph", "fresh", kk, 10, 3)
+            d1, R1, _, r1_ = lg.timed(torch, rv, dev, "graph", "fresh", kk, 10, 5, 2 * SR)
             k1 = lg.kernel_time_us(torch, "graph", n=200 if bb * ag < 100000 else 100)
-            ent = {"value": bb * kk * R1 / d1, "unit": "env-steps/s", "ms_per_step": d1 * 1e3 / (kk * R1),
+            ent = {"value": bb * kk * R1 / d1, "unit": "env-steps/s", "ms_per_step": d1 * 1e3 / (kk * R1), "repeats": stats(r1_),
+                   "timed_steps": kk * R1,
                    "workload": "%s A=%d L=%d, %d worlds" % (scn, lg.A, lg.Lm, bb), "roofline": roofline_entry(lg, k1, bb, "graph", floor_us)}
-            d2, R2, _ = lg.timed(torch, _Sh, dev, "fused", "resident", kk, 10, 3)
+            d2, R2, _, r2_ = lg.timed(torch, rv, dev, "fused", "resident", kk, 10, 5, SR)
             k2 = lg.kernel_time_us(torch, "fused", n=200 if bb * ag < 100000 else 100)
             comp = lg.geometry()[2]
-            ent["fused_rollout"] = {"value": bb * kk * R2 / d2, "unit": "env-steps/s", "kernel_us_per_step": k2,
+            ent["fused_rollout"] = {"value": bb * kk * R2 / d2, "unit": "env-steps/s", "kernel_us_per_step": k2, "repeats": stats(r2_),
                                     "compulsory_bytes_per_env_step": comp,
                                     "frac_compulsory": comp * bb / (k2 * 1e-6) / 1e9 / HBM_PEAK_GBS}
             cfgs[key] = ent
@@ -653,20 +732,30 @@ def main():
             torch.cuda.empty_cache()
         extra["configs"] = cfgs
 
+    # ---- per-rank records: which GPU each rank drove, its own rate and kernel time (gathered over the bookkeeping group) ----
+    box = box_fingerprint(torch, dev)
+    recs = rv.gather({"rank": rank, "device": "cuda:%d" % local, "name": box.get("name"), "uuid": box.get("uuid"),
+                      "world_offset": rank * B, "kernel_us_per_launch": k_us, "launch_floor_us": floor_us,
+                      "env_steps_per_s": stats(rate)})
     if rank == 0:
         copy_gbs = copy_ceiling_gbs(torch, dev)
         fill_gbs = fill_ceiling_gbs(torch, dev)
         for ent in extra.get("configs", {}).values():   # the other configs against this box's measured streaming rates
             ent["roofline"].update({"measured_copy_GBps": copy_gbs, "measured_fill_GBps": fill_gbs,
                                     "frac_of_measured_fill": ent["roofline"]["achieved"] / fill_gbs})
+        if world > 1:   # the per-GPU roofline of an N-GPU job is the SLOWEST rank's kernel (every rank runs the same launch)
+            k_slow = max(r["kernel_us_per_launch"] for r in recs)
+            headline_roof = roofline_entry(leg, k_slow, B, args.mode, floor_us)
+            headline_roof["per_gpu"] = True
+            headline_roof["kernel_us_per_launch_by_rank"] = [r["kernel_us_per_launch"] for r in recs]
         headline_roof.update({
             "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": headline_roof["achieved"] / copy_gbs,
             "measured_fill_GBps": fill_gbs,
             "timed_region_us_per_step": ev_ms * 1e3 / (K * R),
             "note": "achieved = algorithmic bytes per launch / kernel_us_per_launch; kernel_us_per_launch = HIP-event time "
                     "(launch stream) of 400 back-to-back dependent step launches / 400, best of 3 (the rocprofv3 kernel-trace "
-                    "average of the same command is under profiles/); launch_floor_us = the same for a 64-world bookkeeping "
-                    "kernel; timed_region_us_per_step = HIP-event time of the timed region / (steps x graph_replays) and "
+                    "summary of the same command is under profiles/); launch_floor_us = the same for a 64-world bookkeeping "
+                    "kernel; timed_region_us_per_step = HIP-event time of the timed region / timed_steps and "
                     "includes the per-episode reset and move-draw launches"})
         out = {
             "metric": "env steps/sec (whole node), %s N=%d, batch=%d per GPU" % (args.scenario, A, B),
@@ -679,17 +768,23 @@ def main():
                                       if args.protocol == "fresh" else "resident ring of 16 tensors", EP),
                        "protocol": args.protocol, "batch_per_gpu": B, "global_batch": B * world, "mode": args.mode,
                        "graph_replays_in_timed_region": R, "timed_steps": K * R,
-                       "repeats": args.repeats, "streams_per_gpu": args.streams,
-                       "sharding": "worlds by batch index, no collective"},
+                       "timed_region_s": dt, "repeats": args.repeats, "streams_per_gpu": args.streams,
+                       "sharding": "worlds by batch index, no collective on the step path",
+                       "barrier_backend": rv.backend, "barrier_note": rv.note,
+                       "launcher": "torch.distributed.run / env" if world > 1 and not os.environ.get("MPE_SELF_SPAWNED") else
+                                   ("self-spawned (bench.py started the ranks)" if world > 1 else "single process"),
+                       "ranks_seen": len(recs), "ranks": recs},
             "roofline": headline_roof,
+            "repeats": stats(rate),
         }
-        if extra:
-            out["extra"] = extra
-        if not args.no_cpu_baseline and world == 1 and args.scenario not in ("simple", "simple_spread", "simple_tag"):
+        extra["box"] = box
+        out["extra"] = extra
+        # the CPU baseline runs LAST (rank 0 only; the other ranks wait in close()): every GPU leg is behind us
+        if not args.no_cpu_baseline and args.scenario not in ("simple", "simple_spread", "simple_tag"):
             out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
                                    "sample": "none: the per-object CPU restatement (oracle/mpe_loop.py) covers simple / simple_spread / "
                                              "simple_tag; the batched oracle of the other scenarios is test infrastructure only"}
-        elif not args.no_cpu_baseline and world == 1:
+        elif not args.no_cpu_baseline:
             procs = usable_cores()
             agg, single = cpu_baseline(args.scenario, leg.okw, args.cpu_seconds, procs)
             refkey = {"simple": "simple", "simple_tag": "simple_tag"}.get(
@@ -713,8 +808,8 @@ def main():
                     "sample": "oracle/mpe_oracle.c (the same algorithm in plain C, gcc -O2 -fopenmp, one world per "
                               "thread, fp64), %d threads x %.0f s" % (procs, min(args.cpu_seconds, 4.0))}
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    rv.close()
 
 
 if __name__ == "__main__":

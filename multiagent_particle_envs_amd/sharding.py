@@ -1,10 +1,30 @@
 """Multi-GPU: worlds shard by batch index, one process per GPU, no collective on the step path.
 
 World b of a global batch lives on rank b // (B_global / world_size) (contiguous slices).  The only
-communication is bookkeeping around the timed region: a barrier on each side and a MAX-reduce of the
-elapsed time (RCCL when the process group is nccl, gloo in the CPU tests).  RNG streams are indexed
-by global world number (`world.world_offset`), so G shards reproduce one big batch bit-for-bit.
+communication is bookkeeping around the timed region: a barrier on each side, a MAX-reduce of the
+elapsed time and a gather of per-rank records.  RNG streams are indexed by global world number
+(`world.world_offset`), so G shards reproduce one big batch bit-for-bit.
+
+Two things live here besides the shard arithmetic:
+
+`Rendezvous`         the bookkeeping group.  The default process group is ALWAYS gloo (host values are what
+                     is reduced: Python floats and small records); when the caller asks for RCCL ("nccl" /
+                     "auto") an RCCL subgroup is tried on top of it -- created, exercised with one
+                     all-reduce under a deadline, and adopted only if EVERY rank reports success (agreed
+                     over gloo).  A failing or hanging RCCL init therefore costs a warning, not the run:
+                     the step path has no collective, so nothing measured depends on which backend carries
+                     the barrier.
+`spawn_local_ranks`  `python bench.py --gpus N` without a launcher: the parent starts N workers (RANK /
+                     LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rank r -> GPU r), relays rank
+                     0's stdout, and fails if any worker fails.
 """
+import datetime
+import os
+import socket
+import subprocess
+import sys
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -17,32 +37,188 @@ def shard_range(global_batch, rank, world_size):
     return offset, count
 
 
-def barrier(device=None):
+def _sync(device):
     if device is not None and torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
+
+
+def barrier(device=None):
+    _sync(device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
-    if device is not None and torch.device(device).type == "cuda":
-        torch.cuda.synchronize(device)
+    _sync(device)
+
+
+def _reduce(value, op, device="cpu", group=None):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=op, group=group)
+    return float(t.item())
 
 
 def reduce_max(value, device="cpu"):
     """MAX over ranks of a Python float (elapsed seconds)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    return _reduce(value, dist.ReduceOp.MAX, device)
 
 
 def reduce_sum(value, device="cpu"):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t.item())
+    return _reduce(value, dist.ReduceOp.SUM, device)
 
 
 def whole_job_throughput(local_units, local_seconds, device="cpu"):
     """Units all ranks processed / slowest rank's time (the bench contract's `value`)."""
     return reduce_sum(local_units, device) / reduce_max(local_seconds, device)
+
+
+class Rendezvous(object):
+    """The bookkeeping group of one job: barrier, MAX / SUM of host floats, gather of small records.
+
+    backend: "gloo"  gloo only;  "nccl"  RCCL or fail;  "auto"  RCCL when every rank can bring it up, else gloo.
+    `self.backend` says what carries the barrier ("none" for a single process), `self.note` why a fallback
+    happened.  Reductions and gathers of host values always travel over gloo (they are host values)."""
+
+    def __init__(self, rank=None, world=None, device=None, backend="auto", nccl_deadline_s=90.0, timeout_s=1800.0):
+        self.rank = int(os.environ.get("RANK", "0") if rank is None else rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1") if world is None else world)
+        self.device = torch.device(device) if device is not None else None
+        self.backend, self.note, self._nccl, self._abandoned = "none", None, None, False
+        if self.world == 1:
+            return
+        if backend not in ("auto", "nccl", "gloo"):
+            raise ValueError("backend must be auto / nccl / gloo, not %r" % (backend,))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world,
+                                    timeout=datetime.timedelta(seconds=timeout_s))
+        self.backend = "gloo"
+        if backend in ("auto", "nccl"):
+            if self.device is None or self.device.type != "cuda":
+                ok, why = False, "no GPU device for RCCL"
+            else:
+                ok, why = self._try_nccl(nccl_deadline_s)
+            everyone = _reduce(1.0 if ok else 0.0, dist.ReduceOp.MIN) == 1.0
+            if everyone:
+                self.backend = "nccl"
+            else:
+                reasons = self.gather(why)
+                self.note = "RCCL not adopted (%s); barrier over gloo" % "; ".join(
+                    "rank %d: %s" % (r, w) for r, w in enumerate(reasons) if w)
+                self._abandoned = self._nccl is not None
+                self._nccl = None
+                if backend == "nccl":
+                    raise RuntimeError(self.note)
+
+    def _try_nccl(self, deadline_s):
+        """One RCCL subgroup + one all-reduce under a deadline.  -> (ok, reason)."""
+        # a hung RCCL op must not take the process down when the deadline gives up on it
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        try:
+            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=max(deadline_s * 4, 120.0)))
+            self._nccl = g
+            t = torch.ones(1, device=self.device)
+            w = dist.all_reduce(t, group=g, async_op=True)
+            t_end = time.time() + deadline_s
+            while not w.is_completed():
+                if time.time() > t_end:
+                    return False, "RCCL all-reduce did not complete in %.0f s" % deadline_s
+                time.sleep(0.02)
+            torch.cuda.synchronize(self.device)
+            if int(t.item()) != self.world:
+                return False, "RCCL all-reduce returned %r" % (t.item(),)
+            return True, None
+        except Exception as e:   # duplicate GPU, no P2P, missing IPC mode, ...: the reason is reported, not raised
+            return False, "%s: %s" % (type(e).__name__, str(e).strip().splitlines()[0][:200] if str(e).strip() else "")
+
+    def barrier(self):
+        _sync(self.device)
+        if self.world > 1:
+            if self._nccl is not None:
+                dist.barrier(group=self._nccl, device_ids=[self.device.index])
+                _sync(self.device)
+            else:
+                dist.barrier()
+        _sync(self.device)
+
+    def reduce_max(self, value):
+        return _reduce(value, dist.ReduceOp.MAX) if self.world > 1 else float(value)
+
+    def reduce_sum(self, value):
+        return _reduce(value, dist.ReduceOp.SUM) if self.world > 1 else float(value)
+
+    def gather(self, obj):
+        """Every rank's `obj`, in rank order, on every rank."""
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        if self.world > 1 and dist.is_initialized():
+            try:
+                dist.barrier()
+            except Exception:
+                pass
+            if self._abandoned:
+                # an RCCL communicator that never came up may block its own teardown: leave without it
+                sys.stdout.flush()
+                sys.stderr.flush()
+                os._exit(0)
+            dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_local_ranks(argv, n, env=None, one_device=False, timeout_s=3600.0, python=None):
+    """Start `n` copies of `python argv...` as ranks 0..n-1 of one job on this node (what
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` would do), relay rank 0's stdout to ours and
+    every rank's stderr to ours, and return the job's exit code: 0 only if every rank exited 0.
+    Rank r's LOCAL_RANK is r (0 for all when `one_device`): a worker binds to `cuda:LOCAL_RANK`."""
+    base = dict(os.environ if env is None else env)
+    base["MASTER_ADDR"] = "127.0.0.1"
+    base["MASTER_PORT"] = str(free_port())
+    base["WORLD_SIZE"] = str(n)
+    base["LOCAL_WORLD_SIZE"] = str(n)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base["MPE_SELF_SPAWNED"] = "1"
+    procs = []
+    for r in range(n):
+        e = dict(base)
+        e["RANK"] = str(r)
+        e["LOCAL_RANK"] = "0" if one_device else str(r)
+        procs.append(subprocess.Popen([python or sys.executable] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    t_end = time.time() + timeout_s
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:                       # one rank failed: the others would wait for it in a barrier
+                rc = bad[0] if bad[0] > 0 else 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > t_end:
+                rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:            # exact PIDs we started, never a pattern
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+                rc = rc or 1
+    reader.join(5.0)
+    return rc, "".join(c for c in chunks if c)

@@ -1,0 +1,22 @@
+"""Worker of tests/test_sharding_gloo.py: one rank of a job started by sharding.spawn_local_ranks (CPU, gloo)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from multiagent_particle_envs_amd import sharding  # noqa: E402
+
+mode = sys.argv[1]
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if mode == "fail" and rank == 1:
+    sys.exit(3)                       # one rank dies before the rendezvous: the job must fail, not hang
+rv = sharding.Rendezvous(device=None, backend="auto" if mode == "auto" else "gloo")
+rv.barrier()
+secs = 0.5 + 0.25 * rank
+recs = rv.gather({"rank": rank, "local": os.environ["LOCAL_RANK"], "offset": sharding.shard_range(1000, rank, world)[0]})
+tmax, total = rv.reduce_max(secs), rv.reduce_sum(10.0)
+print("rank %d noise on stdout" % rank)
+if rank == 0:
+    print(json.dumps({"n_gpus": world, "tmax": tmax, "total": total, "backend": rv.backend, "note": rv.note, "ranks": recs}))
+rv.close()

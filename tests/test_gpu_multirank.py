@@ -28,26 +28,15 @@ def free_port():
     return p
 
 
-def test_bench_two_ranks_one_gpu(tmp_path):
-    B = 4096
-    env = dict(os.environ)
-    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
-    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--batch", str(B),
-           "--backend", "gloo", "--all-ranks-on-gpu0", "--no-cpu-baseline", "--dump-state", str(tmp_path)]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, "exactly one JSON line (rank 0) expected, got %d" % len(lines)
-    out = json.loads(lines[0])
+def _check_two_rank_job(out, tmp_path, B):
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5
     assert out["config"]["batch_per_gpu"] == B and out["config"]["global_batch"] == 2 * B
     assert out["scaling"] == "weak" and out["unit"] == "env-steps/s"
     # whole-job value = both ranks' worlds over the slowest rank's time
     assert abs(out["value"] - 2 * B / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
-    assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["per_gpu"] and len(out["roofline"]["kernel_us_per_launch_by_rank"]) == 2
+    assert out["config"]["ranks_seen"] == 2 and [r["rank"] for r in out["config"]["ranks"]] == [0, 1]
+    assert [r["world_offset"] for r in out["config"]["ranks"]] == [0, B] and all(r["name"] for r in out["config"]["ranks"])
 
     # one process, one batch of 2B worlds: the same episode-0 reset + step 0
     big = mpe.make_env("simple_spread", batch_size=2 * B, seed=0)
@@ -71,13 +60,66 @@ def test_bench_two_ranks_one_gpu(tmp_path):
     assert not np.array_equal(ref["pos"][:, :, :B], ref["pos"][:, :, B:])   # the two shards are different worlds
 
 
+def _bench_env():
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_two_ranks_one_gpu(tmp_path):
+    B = 4096
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--batch", str(B),
+           "--backend", "gloo", "--all-ranks-on-gpu0", "--no-cpu-baseline", "--region-ms", "50", "--dump-state", str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=_bench_env(), timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0) expected, got %d" % len(lines)
+    out = json.loads(lines[0])
+    assert "cpu_baseline" not in out and out["config"]["barrier_backend"] == "gloo"
+    assert out["config"]["launcher"].startswith("torch.distributed.run")
+    _check_two_rank_job(out, tmp_path, B)
+
+
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the shape of the driver's N=1 command): bench.py starts the two
+    ranks itself.  Both on cuda:0 here, where RCCL cannot come up (one GPU, two ranks): `--backend auto` must notice on
+    every rank, carry the barrier over gloo and still produce the line -- with the CPU baseline and the per-GPU roofline."""
+    B = 4096
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--batch", str(B),
+           "--all-ranks-on-gpu0", "--cpu-seconds", "1", "--region-ms", "50", "--dump-state", str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=_bench_env(), timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["config"]["launcher"].startswith("self-spawned")
+    assert out["config"]["barrier_backend"] in ("gloo", "nccl")
+    if out["config"]["barrier_backend"] == "gloo":
+        assert "RCCL not adopted" in out["config"]["barrier_note"]
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"
+    _check_two_rank_job(out, tmp_path, B)
+
+
+def test_bench_more_gpus_than_the_box_has_is_an_error():
+    n = torch.cuda.device_count() + 7
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "1"],
+                       capture_output=True, text=True, env=_bench_env(), timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "refusing" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_bench_single_gpu_line_carries_the_contract():
     """`python bench.py --steps K --warmup W` (N = 1, as the driver runs it): ONE JSON line with the contract's keys, the
     HBM roofline object and the CPU baseline object; value == worlds x steps / time."""
     env = dict(os.environ)
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-extra",
-                        "--cpu-seconds", "1", "--repeats", "3"], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+                        "--cpu-seconds", "1", "--repeats", "3", "--region-ms", "100"], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1

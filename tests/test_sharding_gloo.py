@@ -1,8 +1,11 @@
 """The N>1 path on CPU: two gloo ranks exercise the shard bookkeeping bench.py uses (contiguous
 batch slices, barrier, MAX-over-ranks time, whole-job throughput) and the shard invariance of the
 counter-based RNG indexing (rank r's draws == slice r of the single-process draws)."""
+import json
 import os
 import socket
+import sys
+import time
 
 import numpy as np
 import torch
@@ -68,3 +71,53 @@ def test_shard_range_partitions():
             for (o, c), (o2, _) in zip(spans, spans[1:]):
                 assert o + c == o2
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _job(mode, n, **kw):
+    rc, out = sharding.spawn_local_ranks([os.path.join(HERE, "_rank_worker.py"), mode], n, timeout_s=120, **kw)
+    return rc, [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+def test_self_spawned_ranks_rendezvous_over_gloo():
+    """What `python bench.py --gpus N` does when no launcher set WORLD_SIZE: N ranks started by the parent, rank r ->
+    LOCAL_RANK r, only rank 0's stdout relayed, bookkeeping over gloo."""
+    rc, lines = _job("gloo", 3)
+    assert rc == 0 and len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 3 and d["tmax"] == 1.0 and d["total"] == 30.0 and d["backend"] == "gloo"
+    assert [r["rank"] for r in d["ranks"]] == [0, 1, 2] and [r["local"] for r in d["ranks"]] == ["0", "1", "2"]
+    assert [r["offset"] for r in d["ranks"]] == [0, 334, 667]
+    rc, lines = _job("gloo", 2, one_device=True)
+    assert rc == 0 and [r["local"] for r in lines[0]["ranks"]] == ["0", "0"]
+
+
+def test_rccl_unavailable_falls_back_to_gloo_on_every_rank():
+    """backend='auto' with no GPU to bring RCCL up on: every rank agrees (over gloo) not to adopt it, the barrier and the
+    reductions still work, and the note says why."""
+    rc, lines = _job("auto", 2)
+    assert rc == 0 and len(lines) == 1
+    d = lines[0]
+    assert d["backend"] == "gloo" and "RCCL not adopted" in d["note"] and "rank 1" in d["note"] and d["tmax"] == 0.75
+
+
+def test_a_failed_rank_fails_the_job_promptly():
+    t0 = time.time()
+    rc, lines = _job("fail", 2)
+    assert rc == 3 and not lines and time.time() - t0 < 60
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked_for():
+    """`python bench.py --gpus 8` on a box with fewer GPUs (here: none) exits non-zero with a message and prints no line."""
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "8"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr and "{" not in r.stdout
+    env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = "2", "0", "0"   # a launcher whose rank count contradicts --gpus
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "8"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 8" in r.stderr and "{" not in r.stdout
