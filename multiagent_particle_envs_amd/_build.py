@@ -20,7 +20,11 @@ LIB = os.path.join(LIBDIR, "libmpe_hip.so")
 SOURCES = ["mpe_abi.hip", "mpe_narrow.hip", "mpe_split.hip", "mpe_wide.hip", "mpe_rng.hip"]
 HEADERS = ["mpe_device.h", "mpe_internal.h", os.path.join("..", "..", "include", "mpe_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function",
+         # kernarg preload (gfx94x/gfx950): the CP writes the first dwords of the kernarg segment into user SGPRs at wave
+         # launch; kernels whose leading arguments are scalars / pointers (k_split, the bookkeeping kernels) start their
+         # global loads without a scalar round trip.  Kernels that begin with a by-value struct are unaffected.
+         "-mllvm", "-amdgpu-kernarg-preload-count=14"]
 
 
 STRESS_SOURCES = ("split", "wide")

@@ -153,6 +153,40 @@ __device__ __forceinline__ size_t wave_off(size_t u) {
   return (size_t)(((uint64_t)hi << 32) | lo);
 }
 
+// Wave-uniform values materialised in SGPRs HERE, all at once: the scalar loads that produce them are issued back to
+// back in front of this point and waited for ONCE, instead of each being sunk into whichever branch first uses it
+// (the contact loop's d.size[j], one scalar round trip per partner on the step's critical path).
+template <int N>
+__device__ __forceinline__ void pin_s(float (&v)[N]) {
+  static_assert(N >= 1 && N <= 26, "pin_s: 1..26 values");
+  if constexpr (N == 1) asm volatile("" : "+s"(v[0]));
+  else if constexpr (N == 2) asm volatile("" : "+s"(v[0]), "+s"(v[1]));
+  else if constexpr (N == 3) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]));
+  else if constexpr (N == 4) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]));
+  else if constexpr (N == 5) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]));
+  else if constexpr (N == 6) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]));
+  else if constexpr (N == 7) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]));
+  else if constexpr (N == 8) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]));
+  else if constexpr (N == 9) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]));
+  else if constexpr (N == 10) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]));
+  else if constexpr (N == 11) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]));
+  else if constexpr (N == 12) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]));
+  else if constexpr (N == 13) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]));
+  else if constexpr (N == 14) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]), "+s"(v[13]));
+  else if constexpr (N == 15) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]), "+s"(v[13]), "+s"(v[14]));
+  else if constexpr (N == 16) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]), "+s"(v[13]), "+s"(v[14]), "+s"(v[15]));
+  else if constexpr (N == 17) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]), "+s"(v[13]), "+s"(v[14]), "+s"(v[15]), "+s"(v[16]));
+  else if constexpr (N == 18) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]), "+s"(v[13]), "+s"(v[14]), "+s"(v[15]), "+s"(v[16]), "+s"(v[17]));
+  else if constexpr (N == 19) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]), "+s"(v[13]), "+s"(v[14]), "+s"(v[15]), "+s"(v[16]), "+s"(v[17]), "+s"(v[18]));
+  else if constexpr (N == 20) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]), "+s"(v[13]), "+s"(v[14]), "+s"(v[15]), "+s"(v[16]), "+s"(v[17]), "+s"(v[18]), "+s"(v[19]));
+  else if constexpr (N == 21) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]), "+s"(v[13]), "+s"(v[14]), "+s"(v[15]), "+s"(v[16]), "+s"(v[17]), "+s"(v[18]), "+s"(v[19]), "+s"(v[20]));
+  else if constexpr (N == 22) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]), "+s"(v[13]), "+s"(v[14]), "+s"(v[15]), "+s"(v[16]), "+s"(v[17]), "+s"(v[18]), "+s"(v[19]), "+s"(v[20]), "+s"(v[21]));
+  else if constexpr (N == 23) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]), "+s"(v[13]), "+s"(v[14]), "+s"(v[15]), "+s"(v[16]), "+s"(v[17]), "+s"(v[18]), "+s"(v[19]), "+s"(v[20]), "+s"(v[21]), "+s"(v[22]));
+  else if constexpr (N == 24) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]), "+s"(v[13]), "+s"(v[14]), "+s"(v[15]), "+s"(v[16]), "+s"(v[17]), "+s"(v[18]), "+s"(v[19]), "+s"(v[20]), "+s"(v[21]), "+s"(v[22]), "+s"(v[23]));
+  else if constexpr (N == 25) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]), "+s"(v[13]), "+s"(v[14]), "+s"(v[15]), "+s"(v[16]), "+s"(v[17]), "+s"(v[18]), "+s"(v[19]), "+s"(v[20]), "+s"(v[21]), "+s"(v[22]), "+s"(v[23]), "+s"(v[24]));
+  else if constexpr (N == 26) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]), "+s"(v[8]), "+s"(v[9]), "+s"(v[10]), "+s"(v[11]), "+s"(v[12]), "+s"(v[13]), "+s"(v[14]), "+s"(v[15]), "+s"(v[16]), "+s"(v[17]), "+s"(v[18]), "+s"(v[19]), "+s"(v[20]), "+s"(v[21]), "+s"(v[22]), "+s"(v[23]), "+s"(v[24]), "+s"(v[25]));
+}
+
 // The same with the address split into a wave-uniform row base (SGPRs: world w0 = first world of the
 // wave) and a 32-bit lane offset, so the loads take the scalar-base addressing form instead of
 // per-lane 64-bit address arithmetic.

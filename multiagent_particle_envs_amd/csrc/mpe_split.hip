@@ -33,6 +33,20 @@
 #define MPE_SPLIT_ABLATE 0
 #endif
 
+// instrumented build (tools/phase_clock.py): lane 0 of every wave of the first workgroups stamps the shader clock at
+// the phase boundaries of each step into the buffer passed as MpeBuffers.force: [workgroup < 4][role < 8][t < 32][8]
+// uint64 -- where a step's cycles go.  Not part of the product build.
+#ifdef MPE_PHASE_CLOCK
+#define MPE_STAMP(k)                                                                                              \
+  do {                                                                                                            \
+    if (blockIdx.x < 4 && lane == 0 && b.force && t < 32)                                                         \
+      reinterpret_cast<unsigned long long *>(b.force)[(((size_t)blockIdx.x * 8 + role) * 32 + t) * 8 + (k)] =     \
+          __builtin_amdgcn_s_memtime();                                                                           \
+  } while (0)
+#else
+#define MPE_STAMP(k) do { } while (0)
+#endif
+
 namespace mpe {
 
 template <int KIND, int A, int L, int NADV>
@@ -105,7 +119,7 @@ template <int KIND, int RP>
 constexpr int aux_policy() { return (KIND == MPE_SCN_TAG && RP == kRowsSc1) ? kRowsSc1 : kRowsPlain; }
 
 template <int KIND, int A, int L, int NADV, bool ROLL, int AUX>
-__device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffers &b, const float *X, int lane,
+__device__ __forceinline__ void reward_wave(const NarrowDesc &d, const float *const sz /* pinned sz[] */, const MpeBuffers &b, const float *X, int lane,
                                             bool live, unsigned ln, size_t B, size_t w0 /* first world of the wave */,
                                             size_t ro /* uniform: row 0 of this step + w0 */, uint64_t seed, uint64_t gw,
                                             uint64_t gt, int goal_roll /* rollout: this world's pick 0 */,
@@ -144,12 +158,12 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
       }
       int cnt[A];
 #pragma unroll
-      for (int a = 0; a < A; ++a) cnt[a] = (d.size[a] + d.size[a] > 0.f) ? 1 : 0;  // the agent against itself (Q1): 0 < 2r
+      for (int a = 0; a < A; ++a) cnt[a] = (sz[a] + sz[a] > 0.f) ? 1 : 0;  // the agent against itself (Q1): 0 < 2r
 #pragma unroll
       for (int a = 0; a < A; ++a) {
 #pragma unroll
         for (int c = a + 1; c < A; ++c) {
-          const bool hit = sqrt_lt(sq2d(px[a] - px[c], py[a] - py[c]), d.size[a] + d.size[c]);
+          const bool hit = sqrt_lt(sq2d(px[a] - px[c], py[a] - py[c]), sz[a] + sz[c]);
           cnt[a] += hit ? 1 : 0;
           cnt[c] += hit ? 1 : 0;
         }
@@ -202,7 +216,7 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
       for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int v = 0; v < NADV; ++v)
-          hit[g][v] = sqrt_lt(sq2d(px[NADV + g] - px[v], py[NADV + g] - py[v]), d.size[NADV + g] + d.size[v]);
+          hit[g][v] = sqrt_lt(sq2d(px[NADV + g] - px[v], py[NADV + g] - py[v]), sz[NADV + g] + sz[v]);
       float adv_rew = 0.f;  // adversary_reward :115-129 -- same value for every adversary
 #pragma unroll
       for (int g = 0; g < NG; ++g)
@@ -327,7 +341,7 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
 #pragma unroll
       for (int v = 0; v < NADV; ++v) {
         const float d2 = sq2d(px[NADV + g] - px[v], py[NADV + g] - py[v]);
-        hit[g][v] = sqrt_lt(d2, d.size[NADV + g] + d.size[v]);
+        hit[g][v] = sqrt_lt(d2, sz[NADV + g] + sz[v]);
         dmin[v] = fminf(dmin[v], d2);
       }
     // food = landmarks 1, 2 (world.landmarks = [obstacle] + food + forests)
@@ -360,7 +374,7 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const MpeBuffer
 #pragma unroll
           for (int f = 0; f < 2; ++f) {
             const float d2 = sq2d(px[a] - fx[f], py[a] - fy[f]);
-            r = r + (sqrt_lt(d2, d.size[a] + d.size[A + 1 + f]) ? 2.f : 0.f);
+            r = r + (sqrt_lt(d2, sz[a] + sz[A + 1 + f]) ? 2.f : 0.f);
             m2 = fminf(m2, d2);
           }
           r = r + 0.05f * fast_sqrt(m2);
@@ -384,8 +398,20 @@ __device__ __forceinline__ void store_state(const MpeBuffers &b, size_t B, int i
 
 template <int KIND, int A, int L, int NADV, bool ROLL, int RP /* row-store policy: kRowsNt / kRowsSc1 (mpe_device.h) */>
 __global__ void __launch_bounds__((A + 1) * kWave)
-k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs ra) {
+k_split(float *const g_pos, float *const g_vel, const float *const g_act, const int32_t *const g_ids, const size_t B,
+        const int g_wpw, const int g_observe_only, const unsigned g_movable, const NarrowDesc d, const MpeBuffers b_in,
+        const RollArgs ra) {
+  // The leading scalar arguments (13 dwords) repeat what the first global loads of a wave need -- the state and
+  // action pointers, the batch size, the worlds per workgroup, the movable mask -- so that the CP can PRELOAD them
+  // into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, _build.py): the wave's loads leave without a
+  // scalar round trip to the kernarg segment in front of them (three dependent ones before: the sizes, the
+  // MpeBuffers block, the per-agent constants).  Everything else still comes from the structs behind them.
   using S = SplitShape<KIND, A, L, NADV>;
+  MpeBuffers b = b_in;
+  b.pos = g_pos;
+  b.vel = g_vel;
+  b.act = g_act;
+  b.ids = g_ids;
   constexpr int E = A + L, XW = S::XW;
   constexpr int AUX = aux_policy<KIND, RP>();
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -395,7 +421,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   const int i = is_agent ? role : 0;
   // worlds of this workgroup: ra.wpw (64, 32 or 16) consecutive ones, lane = world; with fewer than 64 the upper
   // lanes idle, which buys more workgroups -- more waves per SIMD to hide latency -- when the batch is small
-  const int wpw = ra.wpw;
+  const int wpw = g_wpw;
   const size_t w0 = (size_t)blockIdx.x * (size_t)wpw;
   if (w0 >= B) return;  // workgroup-uniform
 #ifdef MPE_STRESS_DELAY_WAVE
@@ -438,6 +464,10 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         food[2 * f + 1] = (b.pos + wave_off((size_t)(2 * (A + 1 + f) + 1) * B + w0))[ln];
       }
     }
+    float sz[E];   // every entity's size, in SGPRs before the barrier (the reward's strict-< tests sit behind it)
+#pragma unroll
+    for (int e = 0; e < E; ++e) sz[e] = d.size[e];
+    pin_s(sz);
     int cd = -1;
     uint64_t ep_r = 0;
     if (TRACK && ra.episode_len > 0) {
@@ -446,6 +476,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       ep_r = ra.step0 / len + (r ? 1 : 0);
     }
     for (int t = 0; t < T; ++t) {
+      MPE_STAMP(0);
       if (TRACK && cd >= 0) {
         if (cd == 0) {
           if (KIND == MPE_SCN_CRYPTO) goal_r = choice_draw(ra.seed, gw_r, ep_r, 0, d.choice_pop[0]);
@@ -471,36 +502,53 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
         }
       }
       const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
+      MPE_STAMP(1);
       __syncthreads();
+      MPE_STAMP(2);
       if (!(MPE_SPLIT_ABLATE & 2))
-      reward_wave<KIND, A, L, NADV, ROLL, AUX>(d, b, X, lane, live, ln, B, w0, (size_t)t * row_stride + w0, ra.seed, gw_r,
+      reward_wave<KIND, A, L, NADV, ROLL, AUX>(d, sz, b, X, lane, live, ln, B, w0, (size_t)t * row_stride + w0, ra.seed, gw_r,
                                           ra.step0 + (uint64_t)t, goal_r, food);
+      MPE_STAMP(3);
     }
     return;
   }
 
   // ---- agent wave i ---------------------------------------------------------------------------------
-  // this agent's constants, selected from the kernarg arrays without dynamic indexing
-  float size_i = 0.f, mass_i = 1.f, accel_i = 0.f, maxspd_i = -1.f;
-  int obs_off_i = 0;
-#pragma unroll
-  for (int a = 0; a < A; ++a)
-    if (a == i) { size_i = d.size[a]; mass_i = d.inv_mass[a]; accel_i = d.accel[a]; maxspd_i = d.max_speed[a]; obs_off_i = d.obs_off[a]; }
-  const bool movable_i = (d.movable >> i) & 1u;
-  const bool collide_i = (d.collide >> i) & 1u;
-
+  // The loads of the world go first: their addresses come from the preloaded arguments alone, so they are in flight
+  // while the scalar loads of this agent's constants (below) and of the remaining buffer pointers are still outstanding.
   float px[E], py[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     px[e] = (b.pos + wave_off((size_t)(2 * e) * B + w0))[ln];
     py[e] = (b.pos + wave_off((size_t)(2 * e + 1) * B + w0))[ln];
   }
+  float mvx = (b.vel + wave_off((size_t)(2 * i) * B + w0))[ln];
+  float mvy = (b.vel + wave_off((size_t)(2 * i + 1) * B + w0))[ln];
+  const bool movable_i = (g_movable >> i) & 1u;
+  const bool step_world = ROLL || !g_observe_only;   // mpe_observe: outputs of the current state only
+  // the move of this step as the caller handed it over: the raw one-hot row differences / the id, scaled further down
+  // (a one-hot row and an id are both decoded to an exact -1 / 0 / +1 pair, so "decode, then scale" is the same product)
+  float ux0 = 0.f, uy0 = 0.f;
+  if (!ROLL && step_world && movable_i && (b.act || b.ids)) fetch_action_wave(b, B, i, w0, ln, 1.0f, ux0, uy0);
+
+  // this agent's constants: one scalar load each at a wave-uniform index, and every entity's size in the same batch
+  // (pinned: left to itself the compiler sinks each d.size[j] load into its iteration of the contact loop, a scalar
+  //  round trip apiece on the step's critical path)
+  float kc[9 + E];
+  kc[0] = d.size[i]; kc[1] = d.inv_mass[i]; kc[2] = d.accel[i]; kc[3] = d.max_speed[i];
+  kc[4] = d.dt; kc[5] = d.damp; kc[6] = d.cforce; kc[7] = d.cmargin; kc[8] = d.cmargin_inv;
+#pragma unroll
+  for (int e = 0; e < E; ++e) kc[9 + e] = d.size[e];
+  pin_s(kc);
+  const float size_i = kc[0], mass_i = kc[1], accel_i = kc[2], maxspd_i = kc[3];
+  const float k_dt = kc[4], k_damp = kc[5], k_cforce = kc[6], k_cmargin = kc[7], k_cmargin_inv = kc[8];
+  const float *const size_e = kc + 9;
+  const int obs_off_i = d.obs_off[i];
+  const bool collide_i = (d.collide >> i) & 1u;
   float mx = 0.f, my = 0.f;
 #pragma unroll
   for (int a = 0; a < A; ++a)
     if (a == i) { mx = px[a]; my = py[a]; }
-  float mvx = (b.vel + wave_off((size_t)(2 * i) * B + w0))[ln];
-  float mvy = (b.vel + wave_off((size_t)(2 * i + 1) * B + w0))[ln];
 
   const uint64_t gw = ra.world_offset + w;  // global world number (RNG streams)
   constexpr bool HAS_GOAL = KIND == MPE_SCN_ADVERSARY || KIND == MPE_SCN_PUSH;
@@ -508,7 +556,6 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
   // this world's picks of reset_world (np.random.choice: goal landmark, key ...)
   int goal = NCH >= 1 ? (b.choice + wave_off(w0))[ln] : 0;
   int pick1 = NCH >= 2 ? (b.choice + wave_off(B + w0))[ln] : 0;
-  const bool step_world = ROLL || !ra.observe_only;   // mpe_observe: outputs of the current state only
 
   // resets fall on global steps that are multiples of episode_len: one 64-bit divide up front, then a
   // countdown (a per-step 64-bit modulo costs ~130 instructions on this ISA)
@@ -522,6 +569,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 
   for (int t = 0; t < T; ++t) {
     float ux, uy;
+    MPE_STAMP(0);
     const uint64_t gt = ra.step0 + (uint64_t)t;   // global step: indexes the move / word streams of the rollout
     if (ROLL) {
       const bool reset_now = countdown == 0;
@@ -543,7 +591,8 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * accel_i;
       uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * accel_i;
     } else if (step_world && movable_i) {
-      fetch_action_wave(b, B, i, w0, ln, accel_i, ux, uy);
+      if (b.act || b.ids) { ux = ux0 * accel_i; uy = uy0 * accel_i; }
+      else fetch_action_wave(b, B, i, w0, ln, accel_i, ux, uy);   // pre-decoded Action.u (mpe_world_step's callers)
     } else {
       ux = 0.f;
       uy = 0.f;
@@ -559,18 +608,22 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
           if (j == i) continue;                        // uniform
           if (!((d.collide >> j) & 1u)) continue;      // uniform
           float gx, gy;
-          contact_force(mx - px[j], my - py[j], size_i + d.size[j], d.cforce, d.cmargin, d.cmargin_inv, gx, gy);
+          contact_force(mx - px[j], my - py[j], size_i + size_e[j], k_cforce, k_cmargin, k_cmargin_inv, gx, gy);
           fx = gx + fx;
           fy = gy + fy;
         }
       }
-      integrate_one(mx, my, mvx, mvy, fx, fy, mass_i, maxspd_i, d.damp, d.dt);
+      integrate_one(mx, my, mvx, mvy, fx, fy, mass_i, maxspd_i, k_damp, k_dt);
 #ifdef MPE_STRESS_STORE_BEFORE_BARRIER   // negative control of tests/test_gpu_race.py: the ordering that races
       if (live && (!ROLL || t == T - 1)) store_state<AUX>(b, B, i, w0, ln, mx, my, mvx, mvy);
 #endif
     }
 
     // ---- publish this agent's new state; read the other agents' ------------------------------------
+#ifdef MPE_PHASE_CLOCK
+    asm volatile("" ::"v"(mx), "v"(my), "v"(mvx), "v"(mvy));   // World.step has finished here
+#endif
+    MPE_STAMP(1);
     float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
     X[(i * XW + 0) * kWave + lane] = mx;
     X[(i * XW + 1) * kWave + lane] = my;
@@ -594,9 +647,11 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 #pragma unroll
       for (int f = 0; f < 2; ++f)
         X[(i * XW + 4 + f) * kWave + lane] =
-            sqrt_lt(sq2d(mx - px[A + 3 + f], my - py[A + 3 + f]), size_i + d.size[A + 3 + f]) ? 1.f : -1.f;
+            sqrt_lt(sq2d(mx - px[A + 3 + f], my - py[A + 3 + f]), size_i + size_e[A + 3 + f]) ? 1.f : -1.f;
     }
+    MPE_STAMP(2);
     __syncthreads();
+    MPE_STAMP(3);
     // The new state goes back to HBM only BEHIND the barrier: every sibling wave loaded this agent's
     // pre-step position at kernel entry and consumed it in its contact loop, which lies before its own
     // arrival at this barrier -- so no wave can observe a post-step position in World.step, whatever
@@ -613,6 +668,11 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       py[a] = X[(a * XW + 1) * kWave + lane];
     }
 
+#ifdef MPE_PHASE_CLOCK
+#pragma unroll
+    for (int a = 0; a < A; ++a) asm volatile("" ::"v"(px[a]), "v"(py[a]));   // the siblings' positions have arrived
+#endif
+    MPE_STAMP(4);
     // ---- observation row of agent i for this step -------------------------------------------------
     float *const obs_t = b.obs + (size_t)t * obs_stride;
     if (KIND == MPE_SCN_SIMPLE) {  // simple.py:45-50
@@ -840,6 +900,7 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
       if (i < NADV) row(std::integral_constant<int, DA>{}, std::true_type{});
       else          row(std::integral_constant<int, DGd>{}, std::false_type{});
     }
+    MPE_STAMP(5);   // this step's rows are on their way
   }
   if (ROLL && NCH >= 1 && ra.episode_len > 0 && live && i == 0) {   // the picks of the last in-kernel reset
     store_aux<AUX>(b.choice + wave_off(w0) + ln, goal);
@@ -872,7 +933,8 @@ k_split(const NarrowDesc d, const MpeBuffers b, const size_t B, const RollArgs r
 // ---- dispatch -----------------------------------------------------------------------------------
 
 constexpr size_t kRowsNtFromBytes = 8u << 20, kRollNtFromBytes = 12u << 20;   // bytes of rows per launch / per rollout step
-using SplitFn = void (*)(const NarrowDesc, const MpeBuffers, const size_t, const RollArgs);
+using SplitFn = void (*)(float *, float *, const float *, const int32_t *, const size_t, const int, const int, const unsigned,
+                         const NarrowDesc, const MpeBuffers, const RollArgs);
 struct SplitEntry {
   int kind, A, L, nadv;
   SplitFn step, step_small, roll, roll_small;   // rows stored nontemporal; *_small: at agent scope (mpe_device.h)
@@ -925,7 +987,7 @@ int launch_split(bool roll, int kind, int A, int L, int nadv, const NarrowDesc &
   const size_t row_bytes = (size_t)d.obs_off[A] * sizeof(float) * B;
   const bool small = row_bytes < (roll ? kRollNtFromBytes : kRowsNtFromBytes);
   hipLaunchKernelGGL(roll ? (small ? e->roll_small : e->roll) : small ? e->step_small : e->step, dim3(grid), dim3((A + 1) * kWave), roll ? e->lds_roll : e->lds_step, stream,
-                     d, b, B, r2);
+                     b.pos, b.vel, b.act, b.ids, B, (int)r2.wpw, (int)r2.observe_only, (unsigned)d.movable, d, b, r2);
   return (int)hipGetLastError();
 }
 

@@ -8,6 +8,12 @@ product package so that a transcription error on either side shows up as a parit
   simple              multiagent/scenarios/simple.py:6-22
   simple_spread       multiagent/scenarios/simple_spread.py:7-29   (3/3 hard-coded there; N here)
   simple_tag          multiagent/scenarios/simple_tag.py:7-36
+  simple_adversary    multiagent/scenarios/simple_adversary.py:8-33
+  simple_push         multiagent/scenarios/simple_push.py:6-32
+  simple_speaker_listener  multiagent/scenarios/simple_speaker_listener.py:6-32
+  simple_reference    multiagent/scenarios/simple_reference.py:6-24
+  simple_crypto       multiagent/scenarios/simple_crypto.py:21-47
+  simple_world_comm   multiagent/scenarios/simple_world_comm.py:7-58
 """
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -32,6 +38,12 @@ class Spec:
     damping: float = 0.25
     contact_force: float = 1e2
     contact_margin: float = 1e-3
+    silent: Optional[List[bool]] = None  # per agent; None -> every agent silent (no communication action)
+    choice_pops: List[int] = field(default_factory=list)   # np.random.choice draws of reset_world, in order: population sizes
+    landmark_ranges: Optional[List[float]] = None          # reset: per-landmark uniform range (None -> landmark_range for all)
+
+    def silent_of(self, i):
+        return True if self.silent is None else self.silent[i]
 
     def mass_of(self, e):
         return 1.0 if self.mass is None else self.mass[e]
@@ -51,6 +63,25 @@ class Spec:
             for i in range(A):
                 n_good_others = sum(1 for j in range(A) if j != i and not self.adversary[j])
                 out.append(4 + 2 * L + 2 * (A - 1) + 2 * n_good_others)
+            return out
+        if self.name == "simple_adversary":     # simple_adversary.py:121-139: good agents see the goal first
+            return [2 * L + 2 * (A - 1) + (0 if self.adversary[i] else 2) for i in range(A)]
+        if self.name == "simple_push":          # simple_push.py:78-96
+            return [2 + 2 * L + 2 * (A - 1) if self.adversary[i] else 2 + 2 + 3 + 2 * L + 3 * L + 2 * (A - 1) for i in range(A)]
+        if self.name == "simple_speaker_listener":   # :69-92
+            return [3, 2 + 2 * L + self.dim_c]
+        if self.name == "simple_reference":     # :63-83
+            return [2 + 2 * L + 3 + self.dim_c] * A
+        if self.name == "simple_crypto":        # :127-169: Eve hears, Bob key + hears, Alice goal + key
+            return [self.dim_c, 2 * self.dim_c, 2 * self.dim_c]
+        if self.name == "simple_world_comm":    # :231-289
+            n_good = sum(1 for a in self.adversary if not a)
+            out = []
+            for i in range(A):
+                if self.adversary[i]:
+                    out.append(4 + 2 * L + 2 * (A - 1) + 2 * n_good + 2 + self.dim_c)
+                else:
+                    out.append(4 + 2 * L + 2 * (A - 1) + 2 + 2 * (n_good - 1))
             return out
         raise KeyError(self.name)
 
@@ -84,5 +115,57 @@ def simple_tag(n_adversaries=3, n_good=1, n_landmarks=2):
                 adversary=adv, landmark_range=0.9)
 
 
+def simple_adversary():
+    # 1 adversary + 2 good agents (size .15, nobody collides), 2 landmarks (size .08); one goal landmark per world
+    return Spec("simple_adversary", 3, 2, 2,
+                size=[0.15] * 3 + [0.08] * 2, movable=[True] * 3 + [False] * 2, collide=[False] * 5,
+                accel=[None] * 3, max_speed=[None] * 3, adversary=[True, False, False], choice_pops=[2])
+
+
+def simple_push():
+    # 1 adversary + 1 good agent, both colliding, default sizes; 2 non-colliding landmarks; one goal landmark per world
+    return Spec("simple_push", 2, 2, 2,
+                size=[0.05] * 4, movable=[True, True, False, False], collide=[True, True, False, False],
+                accel=[None] * 2, max_speed=[None] * 2, adversary=[True, False], choice_pops=[2])
+
+
+def simple_speaker_listener():
+    # agent 0: the immovable speaker; agent 1: the silent listener; 3 landmarks (size .04); shared reward
+    return Spec("simple_speaker_listener", 2, 3, 3,
+                size=[0.075] * 2 + [0.04] * 3, movable=[False, True, False, False, False], collide=[False] * 5,
+                accel=[None] * 2, max_speed=[None] * 2, adversary=[False] * 2, collaborative=True,
+                silent=[False, True], choice_pops=[3])
+
+
+def simple_reference():
+    # 2 agents that move AND speak (10 words), 3 landmarks, nothing collides; shared reward; two goal picks
+    return Spec("simple_reference", 2, 3, 10,
+                size=[0.05] * 5, movable=[True, True, False, False, False], collide=[False] * 5,
+                accel=[None] * 2, max_speed=[None] * 2, adversary=[False] * 2, collaborative=True,
+                silent=[False, False], choice_pops=[3, 3])
+
+
+def simple_crypto():
+    # Eve (adversary), Bob, Alice (speaker): nobody moves, everybody speaks (4 words); goal and key picks among 2 landmarks
+    return Spec("simple_crypto", 3, 2, 4,
+                size=[0.05] * 5, movable=[False] * 5, collide=[False] * 5,
+                accel=[None] * 3, max_speed=[None] * 3, adversary=[True, False, False],
+                silent=[False] * 3, choice_pops=[2, 2])
+
+
+def simple_world_comm():
+    # 4 adversaries (agent 0 the speaking leader) + 2 good agents; landmarks = [obstacle] + 2 food + 2 forests
+    adv = [True] * 4 + [False] * 2
+    return Spec("simple_world_comm", 6, 5, 4,
+                size=[0.075 if a else 0.045 for a in adv] + [0.2, 0.03, 0.03, 0.3, 0.3],
+                movable=[True] * 6 + [False] * 5,
+                collide=[True] * 6 + [True, False, False, False, False],
+                accel=[3.0 if a else 4.0 for a in adv], max_speed=[1.0 if a else 1.3 for a in adv],
+                adversary=adv, silent=[False] + [True] * 5, landmark_range=0.9)
+
+
 def by_name(name, **kw):
-    return {"simple": simple, "simple_spread": simple_spread, "simple_tag": simple_tag}[name](**kw)
+    return {"simple": simple, "simple_spread": simple_spread, "simple_tag": simple_tag,
+            "simple_adversary": simple_adversary, "simple_push": simple_push,
+            "simple_speaker_listener": simple_speaker_listener, "simple_reference": simple_reference,
+            "simple_crypto": simple_crypto, "simple_world_comm": simple_world_comm}[name](**kw)

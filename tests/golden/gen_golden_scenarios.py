@@ -64,15 +64,54 @@ def draw_action(agent, world, rng, soft):
     return np.concatenate(parts)
 
 
-def record(name, seeds, T, squeeze_every=0, squeeze=0.3, customise=None):
+def stage_world(name, w, world, rng):
+    """Worlds staged after their reset so that the scenario's rare discrete branches are well populated (the reference
+    still computes every output from the staged state): returns True when world w was touched.
+    simple_push: every 2nd world has its two agents in contact.  simple_world_comm, by w % 8 (1 = squeezed by 0.3):
+      2 prey in the boundary band (|x| in [0.88, 1.15])   3 prey within reach of an adversary   4 prey on a food item
+      5 everybody fast (speed limits)                      6 agents gathered around the forests   7 = 3 and 5 together"""
+    ag = world.agents
+    if name == "simple_push" and w % 2 == 1:   # (instead of the squeeze: a contact lasts a step or two, so half the worlds start in one)
+        th = rng.uniform(0, 2 * np.pi)
+        ag[1].state.p_pos = ag[0].state.p_pos + rng.uniform(0.05, 0.11) * np.array([np.cos(th), np.sin(th)])
+        return True
+    if name != "simple_world_comm":
+        return False
+    k = w % 8
+    disk = lambda r: (lambda th, rr: rr * np.array([np.cos(th), np.sin(th)]))(rng.uniform(0, 2 * np.pi), r * np.sqrt(rng.uniform(0, 1)))
+    if k == 2:
+        for a in ag[4:]:
+            p = a.state.p_pos.copy()
+            p[rng.randint(0, 2)] = rng.choice([-1, 1]) * rng.uniform(0.88, 1.15)
+            a.state.p_pos = p
+    elif k == 4:
+        for j, a in enumerate(ag[4:]):
+            a.state.p_pos = world.food[j % 2].state.p_pos + disk(0.07)
+    elif k in (3, 5, 7):
+        if k != 5:
+            for a in ag[4:]:
+                a.state.p_pos = ag[rng.randint(0, 4)].state.p_pos + disk(0.13)
+        if k != 3:
+            for a in ag:
+                a.state.p_vel = rng.uniform(-1.5, 1.5, 2)
+    elif k == 6:
+        for a in ag:
+            a.state.p_pos = world.forests[rng.randint(0, 2)].state.p_pos + disk(0.45)
+    else:
+        return False
+    return True
+
+
+def record(name, seeds, T, squeeze_every=0, squeeze=0.3, customise=None, stage=False):
     env = make_env(name)
     world = env.world
     consts = customise(env) if customise else {}     # gen_golden_custom.py: entity / world constants changed after make_world
     A, W, E = env.n, len(seeds), len(world.entities)
     rng = np.random.RandomState(4321)
+    srng = np.random.RandomState(8765)      # staging draws: their own stream
     dims = [env.observation_space[i].shape[0] for i in range(A)]
     adims = action_dims(env)
-    out = {"seeds": np.array(seeds), "pos0": np.zeros((W, E, 2)), "vel0": np.zeros((W, A, 2)),
+    out = {"seeds": np.array(seeds), "pos0": np.zeros((W, E, 2)), "vel0": np.zeros((W, A, 2)), "staged": np.zeros(W, bool),
            "rew": np.zeros((T, W, A)), "pos": np.zeros((T, W, E, 2)), "vel": np.zeros((T, W, A, 2))}
     nch = None
     for i in range(A):
@@ -91,6 +130,10 @@ def record(name, seeds, T, squeeze_every=0, squeeze=0.3, customise=None):
         if squeeze_every and w % squeeze_every == squeeze_every - 1:
             for ent in world.entities:
                 ent.state.p_pos = ent.state.p_pos * squeeze
+            out["staged"][w] = True
+        if stage and stage_world(name, w, world, srng):
+            out["staged"][w] = True
+        if out["staged"][w]:
             obs = [env._get_obs(a) for a in env.agents]
         out["pos0"][w] = np.array([e.state.p_pos for e in world.entities])
         out["vel0"][w] = np.array([a.state.p_vel for a in world.agents])
@@ -113,15 +156,26 @@ def record(name, seeds, T, squeeze_every=0, squeeze=0.3, customise=None):
     return out
 
 
+def coverage(name, d):
+    """Share of the recorded (world, step[, agent / pair]) samples that take each discrete branch of the scenario's
+    callbacks -- printed here and asserted by tests/test_oracle_golden.py (every branch >= 5 %)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import spec as ospec
+    from oracle.mpe_f3 import branch_coverage
+    return branch_coverage(ospec.by_name(name), d)
+
+
 def main():
     t0 = time.time()
-    jobs = [("simple_adversary", 24, 12, 0), ("simple_push", 24, 12, 2), ("simple_speaker_listener", 24, 12, 0),
-            ("simple_reference", 24, 12, 0), ("simple_crypto", 24, 8, 0), ("simple_world_comm", 24, 12, 2)]
+    # W worlds x T steps per scenario; every `sq`-th world squeezed towards the origin after its reset (contacts, forests)
+    jobs = [("simple_adversary", 256, 8, 0), ("simple_push", 384, 4, 0), ("simple_speaker_listener", 256, 8, 0),
+            ("simple_reference", 256, 8, 0), ("simple_crypto", 256, 8, 0), ("simple_world_comm", 384, 4, 8)]
     for name, W, T, sq in jobs:
-        data = record(name, list(range(300, 300 + W)), T, squeeze_every=sq)
+        data = record(name, list(range(300, 300 + W)), T, squeeze_every=sq, stage=True)
         path = os.path.join(HERE, "f3_" + name + ".npz")
         np.savez_compressed(path, **data)
         print("%-26s %8.1f KiB  choices %s" % (name, os.path.getsize(path) / 1024.0, data["choice"][:6].tolist()))
+        print("    coverage: " + ", ".join("%s %.1f%%" % (k, 100 * v) for k, v in coverage(name, data).items()))
     print("done in %.1f s" % (time.time() - t0))
 
 

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 P=multiagent_particle_envs_amd
 TAG=$1; STEM=$2; shift 2
 python -m $P._build > /dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=14 "$@" \
     -c $P/csrc/mpe_$STEM.hip -o $P/build/mpe_${STEM}_ab_$TAG.o
 OBJS=""
 for s in abi narrow split wide rng; do

@@ -2,7 +2,7 @@
 # usage: tools/isa.sh <file-stem>   -> /tmp/isa/<stem>.s, prints per-kernel resource usage
 cd /root/repo
 mkdir -p /tmp/isa
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -S --cuda-device-only -o /tmp/isa/$1.s multiagent_particle_envs_amd/csrc/mpe_$1.hip 2>&1 | grep -v "warning\|^$" | head
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=14 -S --cuda-device-only -o /tmp/isa/$1.s multiagent_particle_envs_amd/csrc/mpe_$1.hip 2>&1 | grep -v "warning\|^$" | head
 python3 - "$1" <<'PY'
 import re,sys
 s=open('/tmp/isa/%s.s'%sys.argv[1]).read()
