@@ -50,22 +50,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, variants=True):
+    """Compile and link libmpe_hip.so; with `variants` also the two test-only stress builds (tests/test_gpu_race.py).
+    The product library is linked FIRST and is what decides staleness on its own: a box that holds only libmpe_hip.so
+    newer than the sources (the GPU box) never invokes hipcc for it, and a compile failure in a variant cannot keep the
+    product from being linked."""
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
-    hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    if not force and not any(_stale(l, srcs + hdrs) for l in [LIB] + [variant_lib(t) for t in STRESS_VARIANTS]):
+    want = [LIB] + ([variant_lib(t) for t in STRESS_VARIANTS] if variants else [])
+    if not force and not any(_stale(l, srcs + hdrs) for l in want):
         return LIB  # the shipped .so files are newer than every source: nothing to do (GPU box)
-    jobs = []
-    objs = []
-    for src in SOURCES:
-        s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+    hipcc = _hipcc()
 
     def run(cmd):
         if verbose:
@@ -75,11 +72,26 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-8000:]))
         if verbose and r.stderr.strip():
             print(r.stderr[-4000:])
-    # test-only variants of the role-split kernels (tests/test_gpu_race.py): one wave of every workgroup is held back
+
+    # ---- the product library -------------------------------------------------------------------------------------------
+    jobs, objs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    if not variants:
+        return LIB
+    # ---- test-only variants of the role-split kernels (tests/test_gpu_race.py): one wave of every workgroup is held back
     # (MPE_STRESS_DELAY_WAVE: ~30 us before its first load in k_split / k_duo, a few us at every step of k_duo_roll);
     # "_racy" additionally restores the store-before-barrier ordering the round-1 k_split had, as the negative control
     # that shows the test can fail
-    variants = []
+    jobs, todo = [], []
     for tag, defs in STRESS_VARIANTS.items():
         vo = {}
         for stem in STRESS_SOURCES:      # the kernel files that carry MPE_STRESS_* hooks
@@ -88,13 +100,11 @@ def build(force=False, verbose=True):
             vo["mpe_%s.o" % stem] = o
             if force or _stale(o, [src] + hdrs):
                 jobs.append([hipcc] + FLAGS + defs + ["-c", src, "-o", o])
-        variants.append((tag, vo))
+        todo.append((tag, vo))
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    for tag, vo in variants:
-        vlib = os.path.join(LIBDIR, "libmpe_hip_%s.so" % tag)
+    for tag, vo in todo:
+        vlib = variant_lib(tag)
         vobjs = [vo.get(os.path.basename(x), x) for x in objs]
         if force or _stale(vlib, vobjs):
             run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", vlib] + vobjs)
@@ -102,4 +112,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, variants="--no-variants" not in sys.argv))

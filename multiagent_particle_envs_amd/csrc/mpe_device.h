@@ -427,11 +427,14 @@ __device__ __forceinline__ void store_aux(T *p, typename aux_value<POLICY, T>::t
   constexpr int F = POLICY;
 #endif
   if constexpr (F == kRowsSc1) {
+    // "memory": these carry the new STATE in simple_tag's small-launch kernels, and the state stores must stay behind
+    // the workgroup barrier (the round-1 race) by a stated dependency, not by the scheduler's habits.
+    // (The row stores above stay clobber-free: nothing reads a row back, and a few lane stores cost no scheduling freedom.)
     if constexpr (sizeof(T) == 4) {
-      asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v));
+      asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
     } else {
       const int vv = (int)v;
-      asm volatile("global_store_byte %0, %1, off sc1" ::"v"(p), "v"(vv));
+      asm volatile("global_store_byte %0, %1, off sc1" ::"v"(p), "v"(vv) : "memory");
     }
   } else if constexpr (F == kRowsNt) {
     __builtin_nontemporal_store(v, p);

@@ -209,9 +209,15 @@ class MultiAgentEnv(object):
         w._desc = None
         w._entity_table = None
         self._constants_seen = w._constants_version
-        if self.fused and any(a.u_noise or (a.c_noise and not a.silent) for a in w.agents):
+        noisy = any(a.u_noise or (a.c_noise and not a.silent) for a in w.agents)
+        if self.fused and noisy:
             self.fused = False          # the fused kernels draw no action / communication noise (core.py:138,176): generic path
             self._comm_kind = False
+            self._unfused_by_noise = True
+        elif not self.fused and not noisy and getattr(self, "_unfused_by_noise", False):
+            self.fused = True           # the noise is gone again: back to the single fused launch
+            self._comm_kind = self._kind in _abi.COMM_KINDS
+            self._unfused_by_noise = False
         if self.fused:
             self._desc = w.scenario_desc(self._kind, getattr(self._scenario, "num_adversaries", 0))
             if self._sets is not None:

@@ -109,7 +109,8 @@ class RandomRollout(object):
             env._comm.copy_(self.pool_c[(self.t - 1) % len(self.pool)])
             for out in env._sets:
                 out.bufs.comm = env._comm.data_ptr()
-        self._mark_stale()
+        if not torch.cuda.is_current_stream_capturing():
+            self._mark_stale()     # host-side bookkeeping + an episode_step fill: not part of a captured graph (capture() / replay do it)
         return env._sets[(self.t - 1) & 1]
 
     def _mark_stale(self):
@@ -139,7 +140,8 @@ class RandomRollout(object):
             with torch.cuda.graph(g, stream=s):
                 self.enqueue(steps)
         torch.cuda.current_stream(self.world.device).wait_stream(s)
-        return g
+        self._mark_stale()
+        return _MarkedGraph(g, self)
 
     def fused(self, steps, trajectory=None):
         """One `mpe_rollout_random` launch covering `steps` env steps.  With `trajectory` (a
@@ -160,6 +162,19 @@ class RandomRollout(object):
         self.t += steps
         self._mark_stale()
         return ret
+
+
+class _MarkedGraph(object):
+    """A captured rollout graph whose replay() also does the host-side bookkeeping of the steps it re-runs (the env's
+    scenario state is stale, its per-world step counters follow the rollout's episode clock) -- outside the graph."""
+
+    def __init__(self, graph, *rollouts):
+        self.graph, self.rollouts = graph, rollouts
+
+    def replay(self):
+        self.graph.replay()
+        for r in self.rollouts:
+            r._mark_stale()
 
 
 class StreamedRollout(object):
@@ -217,7 +232,9 @@ class StreamedRollout(object):
             with torch.cuda.graph(g, stream=main):
                 self.enqueue(steps)
         torch.cuda.current_stream(self.device).wait_stream(main)
-        return g
+        for r in self.rollouts:
+            r._mark_stale()
+        return _MarkedGraph(g, *self.rollouts)
 
     def set_episode_len(self, n):
         for r in self.rollouts:

@@ -43,17 +43,23 @@ for name, data in jobs.items():
 TOL = 1e-12
 
 
+def _base_seed():
+    """The day's seed (yymmdd), or MPE_LIVE_SEED=<yymmdd> to replay the worlds of the day a failure was seen on."""
+    return int(os.environ.get("MPE_LIVE_SEED") or datetime.date.today().strftime("%y%m%d"))
+
+
 def _close(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape
     scale = np.maximum(1.0, np.abs(b))
-    assert np.all(np.abs(a - b) <= TOL * scale), float(np.max(np.abs(a - b) / scale))
+    assert np.all(np.abs(a - b) <= TOL * scale), "max scaled err %.3e (replay these worlds with MPE_LIVE_SEED=%d)" % (
+        float(np.max(np.abs(a - b) / scale)), _base_seed())
 
 
 @pytest.fixture(scope="module")
 def fresh(tmp_path_factory):
     out = tmp_path_factory.mktemp("live_reference")
-    base = int(datetime.date.today().strftime("%y%m%d")) * 100     # new worlds every day, reproducible within one
+    base = _base_seed() * 100     # new worlds every day, reproducible within one (and replayable: MPE_LIVE_SEED)
     env = dict(os.environ, SUPPRESS_MA_PROMPT="1", PYTHONDONTWRITEBYTECODE="1", PYTHONWARNINGS="ignore")
     r = subprocess.run([sys.executable, "-c", RECORDER % {"golden": os.path.join(ROOT, "tests", "golden")}, str(base), str(out)],
                        capture_output=True, text=True, env=env, timeout=600, cwd=str(out))
@@ -139,9 +145,9 @@ import sys, numpy as np
 sys.path.insert(0, %(golden)r)
 import gen_golden_scenarios as gs
 base = int(sys.argv[1])
-for k, (name, sq) in enumerate([("simple_adversary", 0), ("simple_push", 2), ("simple_speaker_listener", 0), ("simple_reference", 0),
-                                ("simple_crypto", 0), ("simple_world_comm", 2)]):
-    data = gs.record(name, [base + 100 * k + j for j in range(8)], 6, squeeze_every=sq)
+for k, (name, sq) in enumerate([("simple_adversary", 0), ("simple_push", 0), ("simple_speaker_listener", 0), ("simple_reference", 0),
+                                ("simple_crypto", 0), ("simple_world_comm", 8)]):
+    data = gs.record(name, [base + 100 * k + j for j in range(64)], 6, squeeze_every=sq, stage=True)
     np.savez(sys.argv[2] + "/f3_" + name + ".npz", **data)
 """
 
@@ -149,7 +155,7 @@ for k, (name, sq) in enumerate([("simple_adversary", 0), ("simple_push", 2), ("s
 @pytest.fixture(scope="module")
 def fresh_f3(tmp_path_factory):
     out = tmp_path_factory.mktemp("live_reference_f3")
-    base = int(datetime.date.today().strftime("%y%m%d")) * 1000 + 7
+    base = _base_seed() * 1000 + 7
     env = dict(os.environ, SUPPRESS_MA_PROMPT="1", PYTHONDONTWRITEBYTECODE="1", PYTHONWARNINGS="ignore")
     r = subprocess.run([sys.executable, "-c", RECORDER_F3 % {"golden": os.path.join(ROOT, "tests", "golden")}, str(base), str(out)],
                        capture_output=True, text=True, env=env, timeout=900, cwd=str(out))
@@ -161,3 +167,19 @@ def test_host_callbacks_of_the_other_six_scenarios_on_fresh_reference_worlds(fre
     import test_f3_scenarios as f3
     for name in f3.NAMES:
         f3.test_reset_and_callbacks_match_reference_on_cpu(name, fresh_f3)
+
+
+def test_f3_oracle_replays_fresh_reference_worlds(fresh_f3):
+    """oracle/mpe_f3.py (the fp64 restatement the GPU tests compare the six other scenarios' fused kernels with) against
+    the reference run live: 64 fresh worlds per scenario, staged like the fixtures, whole trajectories at 1e-12, and
+    the seeded resets (np.random.choice picks, then agents, then landmarks)."""
+    import test_oracle_golden as tg
+    from oracle.mpe_f3 import seeded_initial_state_f3
+    for name in tg.F3:
+        g = fresh_f3("f3_" + name)
+        spec = ospec.by_name(name)
+        tg._replay_f3(spec, g)
+        plain = np.flatnonzero(~g["staged"])
+        pos, vel, choice = seeded_initial_state_f3(spec, g["seeds"])
+        assert np.array_equal(choice, g["choice"]), "MPE_LIVE_SEED=%d" % _base_seed()
+        assert np.array_equal(pos[plain], g["pos0"][plain]), "MPE_LIVE_SEED=%d" % _base_seed()
