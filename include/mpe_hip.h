@@ -18,7 +18,9 @@
  *
  * Device data layout (fp32, structure-of-arrays, batch index innermost => coalesced over b)
  *   pos   [E][2][B]   entity positions, agents first then landmarks   (EntityState.p_pos, core.py:4-9)
- *   vel   [A][2][B]   agent velocities (landmarks are never integrated) (EntityState.p_vel; core.py:160)
+ *   vel   [A][2][B]   agent velocities (EntityState.p_vel); the shipped scenarios' landmarks are immovable and never
+ *                     integrated (core.py:160).  With MOVABLE landmarks (core.py:158-169 integrates every movable
+ *                     entity) vel is [n_dyn][2][B], n_dyn = index of the last movable entity + 1: see mpe_world_step
  *   act   [A][B][5]   per-agent action rows as the reference takes them  (environment.py:174-175)
  *   ids   [A][B]      int32 action ids, the discrete_action_input form    (environment.py:161-167)
  *   obs   agent i's block starts at float offset B*obs_off[i]; inside it [B][D_i] row-major, i.e.
@@ -82,7 +84,7 @@ typedef struct MpeScenarioDesc {
   float mass[MPE_MAX_ENTITIES];      /* Entity.mass (= initial_mass, 1.0)                      */
   float accel[MPE_MAX_ENTITIES];     /* action sensitivity: Agent.accel or 5.0 (environment.py:178-181) */
   float max_speed[MPE_MAX_ENTITIES]; /* Entity.max_speed; < 0 means None (no clamp)            */
-  uint8_t movable[MPE_MAX_ENTITIES]; /* Entity.movable (must be 0 for landmarks)               */
+  uint8_t movable[MPE_MAX_ENTITIES]; /* Entity.movable (landmarks: kind GENERIC / mpe_world_step only) */
   uint8_t collide[MPE_MAX_ENTITIES]; /* Entity.collide                                         */
   int32_t obs_off[MPE_MAX_ENTITIES + 1]; /* prefix sums of per-agent obs widths D_i, [A+1] used */
   int32_t n_choices;                     /* per-world picks drawn at reset (goal = np.random.choice(landmarks), */
@@ -142,7 +144,13 @@ int mpe_step_thread(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t
 int mpe_observe(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, void *stream);
 
 /* mpe_world_step: World.step only (core.py:117-131) incl. action decode; for user-written
- * scenarios whose observation/reward stay host-side tensor code. */
+ * scenarios whose observation/reward stay host-side tensor code.
+ * Movable landmarks (desc->movable[e] != 0 for some e >= n_agents; a Landmark is an Entity, core.py:54-56, and
+ * integrate_state core.py:158-169 integrates every movable entity, get_collision_force :194-195 pushes both
+ * sides of a contact): with n_dyn = (index of the last movable entity) + 1, the entities [n_agents, n_dyn) are
+ * stepped like agents without an action force -- same entity order, so forces are summed in the reference's
+ * order.  The caller passes vel [n_dyn][2][B] and the decoded forces u [n_dyn][2][B] (rows [n_agents, n_dyn)
+ * zero; act / ids cannot carry them).                                                                        */
 int mpe_world_step(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, void *stream);
 
 /* ---- phase-level entry points (one reference function each; tests + generic path) ----------- */
@@ -183,8 +191,10 @@ int mpe_random_comm(float *comm, int32_t n_agents, int64_t B, int32_t dim_c, uin
 
 /* 1 when mpe_step / mpe_observe have a fused kernel for this descriptor (kind, agent / landmark /
  * adversary counts, dim_c), 0 when the caller must keep Scenario.observation / reward itself and
- * use mpe_world_step (e.g. simple_tag with other team sizes than simple_tag.py:10-12), < 0 on an
- * invalid descriptor.  simple_spread is fused at every size up to MPE_MAX_ENTITIES.             */
+ * use mpe_world_step (a user Scenario: kind GENERIC), < 0 on an invalid descriptor or one no fused
+ * kernel can take (MPE_EUNSUPPORTED: the communication scenarios at other than the reference's shapes,
+ * a built-in scenario with a movable landmark).  simple_spread and simple_tag are fused at every size
+ * and every team split up to MPE_MAX_ENTITIES entities.                                          */
 int mpe_step_supported(const MpeScenarioDesc *desc);
 
 /* Episode bookkeeping -- NEW API, no reference counterpart: `done` is always False in the reference

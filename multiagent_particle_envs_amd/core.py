@@ -5,7 +5,9 @@ The reference keeps one Python object per entity, each holding its own 2-vector
 structure-of-arrays tensors with the batch index innermost,
 
     world.pos  [E, 2, B] fp32     agents first, then landmarks   (core.py:103-104 ordering)
-    world.vel  [A, 2, B] fp32     landmarks are never integrated (core.py:160)
+    world.vel  [A, 2, B] fp32     the agents' rows of an [E, 2, B] velocity block: in the shipped scenarios landmarks are
+                                  never integrated (core.py:160, movable = False); a landmark a user makes movable is
+                                  integrated like any entity (core.py:158-169) and its velocity lives in the rows behind
 
 which is the layout the HIP kernels read with coalesced 256-byte wave accesses.  The familiar
 attribute paths still work: `agent.state.p_pos` is a live [B, 2] *view* of that storage and
@@ -53,18 +55,16 @@ class EntityState(object):
     def p_vel(self):
         if self._world is None:
             return self._pending.get("p_vel")
-        if not self._is_agent:
-            return self._world._zero_vel
-        return self._world.vel[self._index].t()
+        return self._world._vel_all[self._index].t()   # (a landmark's row stays zero unless it is movable)
 
     @p_vel.setter
     def p_vel(self, value):
         if self._world is None:
             self._pending["p_vel"] = value
             return
-        if not self._is_agent:
-            return  # landmark velocities are identically zero (never integrated, never observed)
-        self._world.vel[self._index].t().copy_(self._world._as_batch(value, 2))
+        if not self._is_agent and not self._world.entities[self._index].movable:
+            return  # an immovable landmark's velocity is identically zero (never integrated, never observed)
+        self._world._vel_all[self._index].t().copy_(self._world._as_batch(value, 2))
 
 
 class AgentState(EntityState):
@@ -241,7 +241,8 @@ class World(object):
         destroyed at runtime", environment.py:8)."""
         A, E, B = len(self.agents), len(self.entities), self.batch_size
         self.pos = torch.zeros((E, 2, B), dtype=torch.float32, device=self.device)
-        self.vel = torch.zeros((A, 2, B), dtype=torch.float32, device=self.device)
+        self._vel_all = torch.zeros((E, 2, B), dtype=torch.float32, device=self.device)
+        self.vel = self._vel_all[:A]       # what the fused kernels read: [A][2][B], the head of the block
         self._zero_vel = torch.zeros((B, 2), dtype=torch.float32, device=self.device)
         for i, ent in enumerate(self.entities):
             ent.state._bind(self, i, i < A)
@@ -271,19 +272,32 @@ class World(object):
         return t.expand(self.batch_size, width)
 
     def set_state(self, pos, vel=None):
-        """Upload states: pos [B, E, 2], vel [B, A, 2] (host order, as the oracle keeps them)."""
+        """Upload states: pos [B, E, 2], vel [B, A, 2] -- or [B, E, 2] when landmarks move -- (host order, as the
+        oracle keeps them)."""
         p = torch.as_tensor(pos, dtype=torch.float32).reshape(self.batch_size, len(self.entities), 2)
         self.pos.copy_(p.permute(1, 2, 0))
-        if vel is None:
-            self.vel.zero_()
-        else:
-            v = torch.as_tensor(vel, dtype=torch.float32).reshape(self.batch_size, len(self.agents), 2)
-            self.vel.copy_(v.permute(1, 2, 0))
+        self._vel_all.zero_()
+        if vel is not None:
+            v = torch.as_tensor(vel, dtype=torch.float32)
+            v = v.reshape(self.batch_size, v.numel() // (2 * self.batch_size), 2)
+            if v.shape[1] not in (len(self.agents), len(self.entities)):
+                raise _abi.MpeError("set_state: vel holds %d entities (agents: %d, all: %d)" % (v.shape[1], len(self.agents), len(self.entities)))
+            self._vel_all[:v.shape[1]].copy_(v.permute(1, 2, 0))
 
-    def get_state(self):
-        """(pos [B,E,2], vel [B,A,2]) as host NumPy arrays."""
-        return (self.pos.permute(2, 0, 1).contiguous().cpu().numpy(),
-                self.vel.permute(2, 0, 1).contiguous().cpu().numpy())
+    def get_state(self, all_entities=False):
+        """(pos [B,E,2], vel [B,A,2]) as host NumPy arrays; all_entities: vel [B,E,2] (movable landmarks)."""
+        v = self._vel_all if all_entities else self.vel
+        return (self.pos.permute(2, 0, 1).contiguous().cpu().numpy(), v.permute(2, 0, 1).contiguous().cpu().numpy())
+
+    @property
+    def n_dynamic(self):
+        """Entities [0, n_dynamic) are what World.step integrates: the agents, and the landmarks up to the last MOVABLE
+        one (core.py:158-169 integrates every movable entity; `mpe_world_step` takes those as action-less agents)."""
+        n = len(self.agents)
+        for e, ent in enumerate(self.entities):
+            if e >= n and ent.movable:
+                n = e + 1
+        return n
 
     # ---- reset_world bodies shared by the built-in scenarios ---------------------------------------
     def reset_uniform(self, landmark_range=1.0, mask=None, choices=None, seeds=None, redraw=None):
@@ -309,7 +323,7 @@ class World(object):
             m = None if mask is None else torch.as_tensor(mask).cpu().numpy().astype(bool)
             if seeds is not None:
                 assert len(seeds) == B
-            pos, vel = self.get_state() if m is not None else (np.zeros((B, E, 2), np.float64), np.zeros((B, A, 2)))
+            pos, vel = self.get_state(all_entities=True) if m is not None else (np.zeros((B, E, 2), np.float64), np.zeros((B, E, 2)))
             pos = pos.astype(np.float64)
             idx_np = np.zeros((B, len(choices)), np.int64)
             for b in range(B):
@@ -347,6 +361,11 @@ class World(object):
             self._episode += 1
         # comm state of every agent starts at zero (agent.state.c = np.zeros(world.dim_c) in every reset_world)
         keep = None if mask is None else ~torch.as_tensor(mask, device=self.device).bool()
+        if self.n_dynamic > A:     # landmark.state.p_vel = np.zeros(world.dim_p) (every reset_world): the movable ones' rows
+            if keep is None:
+                self._vel_all[A:].zero_()
+            else:
+                self._vel_all[A:].mul_(keep.to(torch.float32)[None, None, :])
         for agent in self.agents:
             z = torch.zeros((B, self.dim_c), dtype=torch.float32, device=self.device)
             if keep is not None and torch.is_tensor(agent.state.c):
@@ -448,8 +467,9 @@ class World(object):
         for agent in self.scripted_agents:
             agent.action = agent.action_callback(agent, self)
         A, B = len(self.agents), self.batch_size
-        if self._u is None:
-            self._u = torch.zeros((A, 2, B), dtype=torch.float32, device=self.device)
+        nd = self.n_dynamic
+        if self._u is None or self._u.shape[0] != nd:
+            self._u = torch.zeros((nd, 2, B), dtype=torch.float32, device=self.device)   # rows [A, nd): movable landmarks, no action
         for i, agent in enumerate(self.agents):
             if agent.movable and agent.action.u is not None:
                 u = self._as_batch(agent.action.u, 2)
@@ -460,7 +480,7 @@ class World(object):
                 self._u[i].zero_()
         desc = self.scenario_desc(_abi.MPE_SCN_GENERIC)
         bufs = _abi.MpeBuffers()
-        bufs.pos, bufs.vel, bufs.u = self.pos.data_ptr(), self.vel.data_ptr(), self._u.data_ptr()
+        bufs.pos, bufs.vel, bufs.u = self.pos.data_ptr(), self._vel_all.data_ptr(), self._u.data_ptr()
         bufs.entity_table = self.entity_table(desc).data_ptr()
         _abi.check(_abi.lib().mpe_world_step(C.byref(desc), C.byref(bufs), B, _abi.raw_stream(self.device)), "mpe_world_step")
         for agent in self.agents:  # update_agent_state (core.py:171-177)

@@ -36,10 +36,15 @@ int check_desc(const MpeScenarioDesc *d, const char *what) {
     return fail(MPE_EINVAL, "%s: need 1 <= A, 0 <= L, A+L <= %d (got A=%d L=%d)", what, MPE_MAX_ENTITIES,
                 d->n_agents, d->n_landmarks);
   if (d->kind < MPE_SCN_GENERIC || d->kind > MPE_SCN_WORLD_COMM) return fail(MPE_EINVAL, "%s: bad kind %d", what, d->kind);
+  // Movable landmarks (core.py:158-169 integrates EVERY movable entity; a Landmark is just an Entity, core.py:54-56) exist
+  // on the physics path only -- kind GENERIC, i.e. mpe_world_step and the phase-free generic path above it; the built-in
+  // scenarios' fused output stages read agent velocities only, so for them a movable landmark is "no kernel for this"
+  // (mpe_step_supported < 1: the env steps such a world through mpe_world_step + the scenario's callbacks).
   for (int e = d->n_agents; e < d->n_agents + d->n_landmarks; ++e)
-    if (d->movable[e]) return fail(MPE_EUNSUPPORTED, "%s: movable landmarks are not supported (entity %d)", what, e);
-  for (int e = 0; e < d->n_agents; ++e)
-    if (!(d->mass[e] > 0.f)) return fail(MPE_EINVAL, "%s: mass[%d] must be > 0", what, e);
+    if (d->movable[e] && d->kind != MPE_SCN_GENERIC)
+      return fail(MPE_EUNSUPPORTED, "%s: a movable landmark (entity %d) is stepped by mpe_world_step (kind GENERIC) only", what, e);
+  for (int e = 0; e < d->n_agents + d->n_landmarks; ++e)
+    if ((e < d->n_agents || d->movable[e]) && !(d->mass[e] > 0.f)) return fail(MPE_EINVAL, "%s: mass[%d] must be > 0", what, e);
   const bool teams = d->kind == MPE_SCN_TAG || d->kind == MPE_SCN_ADVERSARY || d->kind == MPE_SCN_PUSH ||
                      d->kind == MPE_SCN_WORLD_COMM;
   // the communication scenarios exist in the reference's shapes only
@@ -236,6 +241,23 @@ static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, 
     dd.kind = MPE_SCN_GENERIC;
     use = &dd;
   }
+  // ---- movable landmarks: the entities up to the last movable one are stepped as action-less agents ----------------------
+  // World.step treats agents and landmarks alike except for the action force (core.py:134-140 adds it for agents only):
+  // with n_dyn = (index of the last movable entity) + 1, entities [A, n_dyn) enter the physics kernels as agents whose
+  // action force is zero -- same entity order, so every force is summed in the reference's order (Q9) -- and entities
+  // [n_dyn, E) stay landmarks.  The caller's vel and u are [n_dyn][2][B] (rows [A, n_dyn) of u must be zero).
+  int n_dyn = d->n_agents;
+  for (int e = d->n_agents; e < d->n_agents + d->n_landmarks; ++e)
+    if (d->movable[e]) n_dyn = e + 1;
+  if (n_dyn > d->n_agents) {
+    if (out) return fail(MPE_EUNSUPPORTED, "%s: movable landmarks are stepped by mpe_world_step only", what);
+    if (!b->u) return fail(MPE_EINVAL, "%s: movable landmarks need bufs->u ([n_dyn][2][B], n_dyn = %d: zero rows for the landmarks)", what, n_dyn);
+    if (use != &dd) dd = *d;
+    dd.kind = MPE_SCN_GENERIC;
+    dd.n_landmarks = d->n_agents + d->n_landmarks - n_dyn;
+    dd.n_agents = n_dyn;
+    use = &dd;
+  }
   const bool comm_kind = kind >= MPE_SCN_SPEAKER_LISTENER;   // these exist as wave-per-agent kernels only
   if (out && (phys || comm_kind) && d->n_agents + d->n_landmarks <= mpe::kNarrowMaxE &&
       (comm_kind || impl != StepImpl::Thread) &&
@@ -251,8 +273,8 @@ static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, 
   }
   if (use_narrow(use)) {
     const mpe::NarrowDesc n = make_narrow(use, b, (size_t)B);
-    return hip_result(mpe::launch_narrow(phys ? mpe::NarrowOp::Step : mpe::NarrowOp::Observe, kind, d->n_agents,
-                                         d->n_landmarks, d->n_adversaries, n, *b, (size_t)B, s), what);
+    return hip_result(mpe::launch_narrow(phys ? mpe::NarrowOp::Step : mpe::NarrowOp::Observe, kind, use->n_agents,
+                                         use->n_landmarks, d->n_adversaries, n, *b, (size_t)B, s), what);
   }
   if (kind == MPE_SCN_GENERIC || kind == MPE_SCN_SPREAD || kind == MPE_SCN_TAG) {
     if (int rc = need(b->entity_table, what, "entity_table (required by the wave-per-world kernel)")) return rc;

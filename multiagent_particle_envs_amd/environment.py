@@ -134,7 +134,7 @@ class MultiAgentEnv(object):
         # ANY Python callback (evaluated on the post-step world after the launch: "partial fusion")
         own = builtin is not None and kind is not None and \
             getattr(reset_callback, "__self__", None) is sc and is_builtin(observation_callback, "observation") and \
-            len(world.scripted_agents) == 0 and \
+            len(world.scripted_agents) == 0 and not any(l.movable for l in world.landmarks) and \
             all((a.silent or (kind in _abi.COMM_KINDS and not a.c_noise)) and not a.u_noise for a in world.agents)
         if own:   # ... and a kernel for this shape (the f3 scenarios are fused at the reference's team sizes)
             own = _abi.lib().mpe_step_supported(C.byref(world.scenario_desc(kind, getattr(sc, "num_adversaries", 0)))) == 1
@@ -209,7 +209,9 @@ class MultiAgentEnv(object):
         w._desc = None
         w._entity_table = None
         self._constants_seen = w._constants_version
-        noisy = any(a.u_noise or (a.c_noise and not a.silent) for a in w.agents)
+        # (a landmark made movable is integrated like any entity, core.py:158-169: physics through mpe_world_step, the
+        #  scenario's callbacks in Python -- the fused output stages know agent velocities only)
+        noisy = any(a.u_noise or (a.c_noise and not a.silent) for a in w.agents) or any(l.movable for l in w.landmarks)
         if self.fused and noisy:
             self.fused = False          # the fused kernels draw no action / communication noise (core.py:138,176): generic path
             self._comm_kind = False

@@ -31,7 +31,10 @@ class BatchedOracle(object):
     def __init__(self, spec, batch, dtype=np.float64, benchmark=False):
         self.spec, self.B, self.dt_, self.benchmark = spec, batch, np.dtype(dtype), benchmark
         self.pos = np.zeros((batch, spec.n_entities, 2), self.dt_)
-        self.vel = np.zeros((batch, spec.n_agents, 2), self.dt_)
+        # core.py:158-169 integrates EVERY movable entity: agents, and any landmark a scenario makes movable.  vel holds
+        # the agents' rows [B,A,2] as everywhere else, or all entities' [B,E,2] when a landmark moves.
+        self.n_dyn = spec.n_entities if any(spec.movable[spec.n_agents:]) else spec.n_agents
+        self.vel = np.zeros((batch, self.n_dyn, 2), self.dt_)
         self.size = np.asarray(spec.size, self.dt_)
 
     def set_state(self, pos, vel):
@@ -92,14 +95,15 @@ class BatchedOracle(object):
         s = self.spec
         one_minus = self.dt_.type(1 - s.damping)
         dt = self.dt_.type(s.dt)
-        for i in range(s.n_agents):
+        for i in range(self.n_dyn):
             if not s.movable[i]:
                 continue
             v = self.vel[:, i] * one_minus
             if f[i] is not None:
                 v = v + (f[i] / self.dt_.type(s.mass_of(i))) * dt            # core.py:162
-            if s.max_speed[i] is not None:
-                ms = self.dt_.type(s.max_speed[i])
+            ms_i = s.max_speed[i] if i < len(s.max_speed) else None          # (per agent; a landmark's Entity.max_speed is None)
+            if ms_i is not None:
+                ms = self.dt_.type(ms_i)
                 speed = np.sqrt(np.square(v[:, 0]) + np.square(v[:, 1]))
                 with np.errstate(all="ignore"):
                     clamped = v / speed[:, None] * ms

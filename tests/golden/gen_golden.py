@@ -65,22 +65,24 @@ def spread_n(n):
     return MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, sc.benchmark_data)
 
 
-def state_of(env):
+def state_of(env, all_vel=False):
     ents = env.world.entities
     pos = np.array([e.state.p_pos for e in ents])
-    vel = np.array([a.state.p_vel for a in env.world.agents])
+    vel = np.array([a.state.p_vel for a in (ents if all_vel else env.world.agents)])
     return pos, vel
 
 
-def record(name, env, seeds, T, squeeze_every=0, squeeze=0.3, soft_every=4, ids=False, arng=None):
+def record(name, env, seeds, T, squeeze_every=0, squeeze=0.3, soft_every=4, ids=False, arng=None, all_vel=False):
+    """all_vel: record the velocity of EVERY entity (worlds with a movable landmark, core.py:158-169)."""
     A = env.n
     W = len(seeds)
     E = len(env.world.entities)
+    NV = E if all_vel else A
     arng = arng or np.random.RandomState(1234)
     dims = [env.observation_space[i].shape[0] for i in range(A)]
-    out = {"seeds": np.array(seeds), "pos0": np.zeros((W, E, 2)), "vel0": np.zeros((W, A, 2)),
+    out = {"seeds": np.array(seeds), "pos0": np.zeros((W, E, 2)), "vel0": np.zeros((W, NV, 2)),
            "act": np.zeros((T, W, A, 5)), "rew": np.zeros((T, W, A)), "done": np.zeros((T, W, A), bool),
-           "pos": np.zeros((T, W, E, 2)), "vel": np.zeros((T, W, A, 2))}
+           "pos": np.zeros((T, W, E, 2)), "vel": np.zeros((T, W, NV, 2))}
     if ids:
         out["ids"] = np.zeros((T, W, A), np.int64)
     for i in range(A):
@@ -94,7 +96,7 @@ def record(name, env, seeds, T, squeeze_every=0, squeeze=0.3, soft_every=4, ids=
             for ent in env.world.entities:
                 ent.state.p_pos = ent.state.p_pos * squeeze
             obs = [env._get_obs(a) for a in env.agents]
-        out["pos0"][w], out["vel0"][w] = state_of(env)
+        out["pos0"][w], out["vel0"][w] = state_of(env, all_vel)
         for i in range(A):
             out["obs_reset%d" % i][w] = obs[i]
         for t in range(T):
@@ -117,7 +119,7 @@ def record(name, env, seeds, T, squeeze_every=0, squeeze=0.3, soft_every=4, ids=
                 out["obs%d" % i][t, w] = obs[i]
             out["rew"][t, w] = np.array(rew, dtype=np.float64)
             out["done"][t, w] = done
-            out["pos"][t, w], out["vel"][t, w] = state_of(env)
+            out["pos"][t, w], out["vel"][t, w] = state_of(env, all_vel)
             inf = info["n"]
             if name.startswith("simple_spread") and inf and inf[0] != {}:
                 if info_keys is None:

@@ -148,7 +148,30 @@ def main_noise():
         print("%-28s %8.1f KiB" % (os.path.basename(path), os.path.getsize(path) / 1024.0))
 
 
+def main_movable():
+    """A landmark made MOVABLE after make_world (core.py:54-56: a Landmark is an Entity; World.integrate_state
+    core.py:158-169 integrates every movable entity, and get_collision_force :194-195 pushes both sides of a contact):
+      movable_simple_tag     obstacle 0 becomes a pushable ball of mass 3 (it collides already, size 0.2)
+      movable_simple_spread  landmark 1 (of 0, 1, 2) becomes a colliding ball of mass 0.5 and size 0.1 -- an immovable
+                             landmark in front of it and one behind it in the entity order
+    Velocities are recorded for every entity (vel0 [W,E,2], vel [T,W,E,2])."""
+    for name, setup in (("simple_tag", lambda w: (setattr(w.landmarks[0], "movable", True), setattr(w.landmarks[0], "initial_mass", 3.0))),
+                        ("simple_spread", lambda w: (setattr(w.landmarks[1], "movable", True), setattr(w.landmarks[1], "collide", True),
+                                                     setattr(w.landmarks[1], "initial_mass", 0.5), setattr(w.landmarks[1], "size", 0.1)))):
+        env = G.make_env(name, benchmark=True)
+        setup(env.world)
+        data = G.record(name, env, list(range(1100, 1132)), 12, squeeze_every=2, squeeze=0.3, all_vel=True)
+        w = env.world
+        data.update({"c_size": np.array([e.size for e in w.entities]), "c_mass": np.array([e.mass for e in w.entities]),
+                     "c_collide": np.array([bool(e.collide) for e in w.entities]),
+                     "c_movable": np.array([bool(e.movable) for e in w.entities])})
+        moved = np.abs(data["vel"][:, :, env.n:]).max()
+        path = os.path.join(HERE, "movable_%s.npz" % name)
+        np.savez_compressed(path, **data)
+        print("%-28s %8.1f KiB   fastest landmark %.3f" % (os.path.basename(path), os.path.getsize(path) / 1024.0, moved))
+
+
 if __name__ == "__main__":
     import sys
     (main_noise() if "--noise" in sys.argv else main_modes() if "--modes" in sys.argv else
-     main_f3() if "--f3" in sys.argv else main())
+     main_f3() if "--f3" in sys.argv else main_movable() if "--movable" in sys.argv else main())

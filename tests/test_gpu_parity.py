@@ -579,6 +579,55 @@ def test_customised_constants_against_reference_golden(name, fused, golden):
         assert np.array_equal(got[ok], g["info_collisions"][t][ok])
 
 
+@pytest.mark.parametrize("name", ["simple_tag", "simple_spread"])
+@pytest.mark.parametrize("when", ["before", "live"])
+def test_movable_landmark_against_reference_golden(name, when, golden, record_parity):
+    """tests/golden/movable_*.npz: the reference with a landmark made movable (simple_tag's obstacle 0 a ball of mass 3;
+    simple_spread's landmark 1 a colliding ball of mass 0.5 between two immovable ones).  core.py:158-169 integrates every
+    movable entity and core.py:194-195 pushes both sides of a contact: the landmark's position AND velocity are compared
+    at 1e-5, teacher-forced, next to the agents'.  `mpe_world_step` steps the entities up to the last movable one as
+    action-less agents (same entity order); the scenario's callbacks run on the post-step world.  'live': the landmark
+    is made movable on a fused env that is already stepping -- the env must leave the fused path by itself."""
+    from test_oracle_golden import movable_spec
+    g = golden("movable_" + name)
+    spec = movable_spec(name, g)
+    T, W, A = g["rew"].shape
+    E = spec.n_entities
+
+    def customise(w):
+        for k, e in enumerate(w.entities):
+            e.size, e.initial_mass, e.collide, e.movable = float(g["c_size"][k]), float(g["c_mass"][k]), bool(g["c_collide"][k]), bool(g["c_movable"][k])
+    if when == "before":
+        sc = mpe.scenarios.load(name + ".py").Scenario()
+        w = sc.make_world(batch_size=W)
+        customise(w)
+        env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, sc.benchmark_data)
+    else:
+        env = mpe.make_env(name, batch_size=W, benchmark=True)
+        w = env.world
+        assert env.fused
+        env.reset()
+        env.step(torch.zeros((A, W, 5), device="cuda"))
+        customise(w)
+    worst = 0.0
+    for t in range(T):
+        w.set_state(g["pos0"] if t == 0 else g["pos"][t - 1], g["vel0"] if t == 0 else g["vel"][t - 1])
+        act = torch.as_tensor(np.transpose(g["act"][t], (1, 0, 2)), dtype=torch.float32).cuda().contiguous()
+        obs_n, rew_n, _, info = env.step([act[i] for i in range(A)])
+        assert not env.fused
+        pos, vel = w.get_state(all_entities=True)
+        assert vel.shape == (W, E, 2)
+        worst = max(worst, close(pos, g["pos"][t], what="pos t=%d" % t), close(vel, g["vel"][t], what="vel t=%d" % t))
+        ok = guard_ok(spec, g["pos"][t])
+        for i in range(A):
+            worst = max(worst, close(np_(obs_n[i]), g["obs%d" % i][t], what="obs%d t=%d" % (i, t)))
+            worst = max(worst, close((np_(rew_n[i]) * np.ones(W))[ok], g["rew"][t][:, i][ok], what="rew%d t=%d" % (i, t)))
+    lm = [k for k in range(A, E) if g["c_movable"][k]]
+    assert np.abs(vel[:, lm]).max() > 0.05          # it moved here too
+    record_parity("movable_landmark_%s_%s" % (name, when), {"worlds": W, "steps": T, "max_scaled_err": worst,
+                                                             "against": "tests/golden/movable_%s.npz (the reference itself), teacher-forced" % name})
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "generic"])
 def test_force_discrete_and_continuous_action_modes_against_reference_golden(fused, golden):
     """environment.py:169-172 (force_discrete_action: the soft row becomes the one-hot of its argmax) and :176-177

@@ -276,3 +276,31 @@ def test_f3_goldens_populate_every_branch(name, golden):
     print("%s coverage: %s" % (name, ", ".join("%s %.1f%%" % (k, 100 * v) for k, v in cov.items())))
     low = {k: v for k, v in cov.items() if v < 0.05}
     assert not low, low
+
+
+# ---- movable landmarks (core.py:158-169 integrates every movable entity) -------------------------------------------------
+def movable_spec(name, g):
+    import dataclasses
+    base = ospec.by_name(name)
+    return dataclasses.replace(base, size=[float(x) for x in g["c_size"]], mass=[float(x) for x in g["c_mass"]],
+                               collide=[bool(x) for x in g["c_collide"]], movable=[bool(x) for x in g["c_movable"]])
+
+
+@pytest.mark.parametrize("name", ["simple_tag", "simple_spread"])
+def test_oracle_integrates_movable_landmarks_like_the_reference(name, golden):
+    """A landmark a user makes movable is pushed by contacts and integrated (its own velocity, damping, mass): the
+    batched oracle over the reference's trajectories, all entities' velocities compared."""
+    g = golden("movable_" + name)
+    spec = movable_spec(name, g)
+    T, W, A = g["rew"].shape
+    assert g["vel"].shape[2] == spec.n_entities and np.abs(g["vel"][:, :, A:]).max() > 0.1   # the landmark really moves
+    orc = BatchedOracle(spec, W, np.float64, benchmark=True)
+    orc.set_state(g["pos0"], g["vel0"])
+    for t in range(T):
+        obs, rew, done, info = orc.step(np.transpose(g["act"][t], (1, 0, 2)))
+        _close(orc.pos, g["pos"][t])
+        _close(orc.vel, g["vel"][t])
+        for i in range(A):
+            _close(obs[i], g["obs%d" % i][t])
+        _close(rew.T, g["rew"][t])
+        assert np.array_equal(info["collisions"].T, g["info_collisions"][t])
