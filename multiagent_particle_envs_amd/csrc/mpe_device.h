@@ -506,6 +506,51 @@ __device__ __forceinline__ void flush_rows(const float *tile, float *__restrict_
   __builtin_amdgcn_wave_barrier();
 }
 
+// flush_rows in phases (k_split's pipelined rollout puts other work between them):
+//   kRowsBuild  nothing here (the caller has written the tile)
+//   kRowsLoad   the tile read back as the 16-byte pieces of the output segment, into registers fr[]
+//   kRowsStore  those registers stored
+//   kRowsAll    the three back to back = flush_rows
+// Full waves with aligned rows (every workgroup but a ragged last one) take the split path; anything else is flushed
+// whole in the store phase by flush_rows itself -- same bytes either way.
+enum { kRowsNone = 0, kRowsBuild = 1, kRowsLoad = 2, kRowsStore = 3, kRowsAll = 4 };
+template <int PH, int D, bool PAIRS, int RP, int N>
+__device__ __forceinline__ void flush_phase(const float *tile, float4 (&fr)[N], float *__restrict__ g, int nvalid, int lane,
+                                            bool vec4) {
+  constexpr int S = PAIRS ? pair_stride<D>() : tile_stride<D>();
+  constexpr int NQ = 16 * D, NIT = (NQ + kWave - 1) / kWave;
+  constexpr int NSW = (PAIRS && row_vec4<D>() && ((D / 4) & 1) == 0) ? D / 4 : 0;
+  if constexpr (PH == kRowsAll) {
+    flush_rows<D, PAIRS, RP>(tile, g, nvalid, lane, vec4);
+  } else if constexpr ((PH == kRowsLoad || PH == kRowsStore) && NIT <= N) {   // (NIT > N: another scenario's dead branch)
+    const bool fast = S == D && vec4 && nvalid == kWave;   // wave-uniform
+    if (PH == kRowsLoad) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (fast) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int q = lane + kWave * it;
+          const int qs = NSW ? (q ^ swz4<NSW>(q / (NSW ? NSW : 1))) : q;
+          if ((it + 1) * kWave <= NQ || q < NQ) fr[it] = *reinterpret_cast<const float4 *>(tile + 4 * qs);
+        }
+      }
+    } else {
+      if (fast) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int q = lane + kWave * it;
+          if ((it + 1) * kWave <= NQ || q < NQ) store_row4<RP>(g + 4 * q, fr[it]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        flush_rows<D, PAIRS, RP>(tile, g, nvalid, lane, vec4);
+      }
+    }
+  }
+}
+
 template <int D>
 __device__ __forceinline__ void store_rows(float *tile, const float (&row)[D], float *__restrict__ g,
                                            int nvalid, int lane, bool vec4) {

@@ -49,6 +49,17 @@
 
 namespace mpe {
 
+// The fused rollout of these kinds overlaps step t's observation rows with step t+1's World.step (k_split's PIPE loop).
+// Rows wider than 24 floats would hold more than 6 x 16 bytes per lane in flight: left unpipelined.
+#ifndef MPE_SPLIT_PIPE
+#define MPE_SPLIT_PIPE 1
+#endif
+template <int KIND, bool ROLL, int DMAX>
+constexpr bool pipelined() {
+  return (MPE_SPLIT_PIPE) && ROLL && DMAX <= 24 &&
+         (KIND == MPE_SCN_SIMPLE || KIND == MPE_SCN_SPREAD || KIND == MPE_SCN_TAG || KIND == MPE_SCN_ADVERSARY);
+}
+
 template <int KIND, int A, int L, int NADV>
 struct SplitShape {
   static constexpr int E = A + L;
@@ -567,9 +578,12 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
     ep = ra.step0 / len + (r ? 1 : 0);
   }
 
-  for (int t = 0; t < T; ++t) {
+  // ---- one step of agent i, in the pieces the two loop shapes below are made of ---------------------------------
+  float gx = 0.f, gy = 0.f;   // this world's goal landmark (publish -> rows)
+  // step_forces: [in-kernel reset,] this step's move, the action force and the contacts with every other entity in
+  // ascending order (Q9) -- everything of World.step (core.py:117-155) up to the force on agent i
+  auto step_forces = [&](const int t, float &fx, float &fy) {
     float ux, uy;
-    MPE_STAMP(0);
     const uint64_t gt = ra.step0 + (uint64_t)t;   // global step: indexes the move / word streams of the rollout
     if (ROLL) {
       const bool reset_now = countdown == 0;
@@ -597,33 +611,34 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       ux = 0.f;
       uy = 0.f;
     }
-
-    // ---- World.step for agent i (core.py:117-169): action force, contacts with every other entity
-    //      in ascending order (Q9), integrate ------------------------------------------------------
-    if (movable_i && step_world) {
-      float fx = ux + 0.f, fy = uy + 0.f;
-      if (collide_i && !(MPE_SPLIT_ABLATE & 1)) {
+    fx = ux + 0.f;
+    fy = uy + 0.f;
+    if (movable_i && step_world && collide_i && !(MPE_SPLIT_ABLATE & 1)) {
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-          if (j == i) continue;                        // uniform
-          if (!((d.collide >> j) & 1u)) continue;      // uniform
-          float gx, gy;
-          contact_force(mx - px[j], my - py[j], size_i + size_e[j], k_cforce, k_cmargin, k_cmargin_inv, gx, gy);
-          fx = gx + fx;
-          fy = gy + fy;
-        }
+      for (int j = 0; j < E; ++j) {
+        if (j == i) continue;                        // uniform
+        if (!((d.collide >> j) & 1u)) continue;      // uniform
+        float cx, cy;
+        contact_force(mx - px[j], my - py[j], size_i + size_e[j], k_cforce, k_cmargin, k_cmargin_inv, cx, cy);
+        fx = cx + fx;
+        fy = cy + fy;
       }
+    }
+  };
+  // step_integrate: integrate_state for agent i (core.py:158-169)
+  auto step_integrate = [&](const int t, const float fx, const float fy) {
+    if (movable_i && step_world) {
       integrate_one(mx, my, mvx, mvy, fx, fy, mass_i, maxspd_i, k_damp, k_dt);
 #ifdef MPE_STRESS_STORE_BEFORE_BARRIER   // negative control of tests/test_gpu_race.py: the ordering that races
       if (live && (!ROLL || t == T - 1)) store_state<AUX>(b, B, i, w0, ln, mx, my, mvx, mvy);
 #endif
     }
-
-    // ---- publish this agent's new state; read the other agents' ------------------------------------
 #ifdef MPE_PHASE_CLOCK
     asm volatile("" ::"v"(mx), "v"(my), "v"(mvx), "v"(mvy));   // World.step has finished here
 #endif
-    MPE_STAMP(1);
+  };
+  // publish: this agent's new state (and what the reward wave needs of it) into the exchange block of step t's parity
+  auto publish = [&](const int t) {
     float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
     X[(i * XW + 0) * kWave + lane] = mx;
     X[(i * XW + 1) * kWave + lane] = my;
@@ -634,7 +649,6 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       for (int l = 0; l < L; ++l) X[(i * XW + 4 + l) * kWave + lane] = sq2d(mx - px[A + l], my - py[A + l]);
     }
     if (KIND == MPE_SCN_SIMPLE) X[(i * XW + 4) * kWave + lane] = sq2d(mx - px[A], my - py[A]);
-    float gx = 0.f, gy = 0.f;
     if (HAS_GOAL || KIND == MPE_SCN_SPEAKER_LISTENER) {
       goal_pos<A, L>(px, py, goal, gx, gy);
       X[(i * XW + 4) * kWave + lane] = sq2d(mx - gx, my - gy);
@@ -649,9 +663,9 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         X[(i * XW + 4 + f) * kWave + lane] =
             sqrt_lt(sq2d(mx - px[A + 3 + f], my - py[A + 3 + f]), size_i + size_e[A + 3 + f]) ? 1.f : -1.f;
     }
-    MPE_STAMP(2);
-    __syncthreads();
-    MPE_STAMP(3);
+  };
+  // behind_barrier: the state store and the siblings' new positions
+  auto behind_barrier = [&](const int t) {
     // The new state goes back to HBM only BEHIND the barrier: every sibling wave loaded this agent's
     // pre-step position at kernel entry and consumed it in its contact loop, which lies before its own
     // arrival at this barrier -- so no wave can observe a post-step position in World.step, whatever
@@ -660,59 +674,50 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
     if (movable_i && step_world && live && (!ROLL || t == T - 1) && !(MPE_SPLIT_ABLATE & 8))
       store_state<AUX>(b, B, i, w0, ln, mx, my, mvx, mvy);
 #endif
-    if (MPE_SPLIT_ABLATE & 4) continue;   // (no observation rows)
+    const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       if (a == i) { px[a] = mx; py[a] = my; continue; }  // uniform
       px[a] = X[(a * XW + 0) * kWave + lane];
       py[a] = X[(a * XW + 1) * kWave + lane];
     }
-
 #ifdef MPE_PHASE_CLOCK
 #pragma unroll
     for (int a = 0; a < A; ++a) asm volatile("" ::"v"(px[a]), "v"(py[a]));   // the siblings' positions have arrived
 #endif
-    MPE_STAMP(4);
-    // ---- observation row of agent i for this step -------------------------------------------------
+  };
+  // rows: agent i's observation row of step t in three phases -- kRowsBuild: assemble the 64 rows in the wave's LDS tile;
+  // kRowsLoad: read the tile back as the 16-byte pieces of the output segment (registers `fr`); kRowsStore: store them.
+  // Back to back they are the old single stage; the pipelined rollout puts the next step's World.step between them.
+  constexpr bool PIPE = pipelined<KIND, ROLL, S::DMAX>();
+  float4 fr[PIPE ? (S::DMAX + 3) / 4 : 1];
+  auto rows = [&](const int t, auto ph) {
+    constexpr int PH = PIPE ? decltype(ph)::value : (decltype(ph)::value == kRowsBuild ? kRowsAll : kRowsNone);
+    if constexpr (PH == kRowsNone) return;
+    constexpr bool BUILD = PH == kRowsBuild || PH == kRowsAll;
+    if (MPE_SPLIT_ABLATE & 4) return;   // (no observation rows)
+    const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
+    const uint64_t gt = ra.step0 + (uint64_t)t;   // global step (the word stream of the rollout)
     float *const obs_t = b.obs + (size_t)t * obs_stride;
     if (KIND == MPE_SCN_SIMPLE) {  // simple.py:45-50
       constexpr int D = 2 + 2 * L;
-      RowPairs<D> r(tile, lane);
-      r.put(0, mvx, mvy);
+      if constexpr (BUILD) {
+        RowPairs<D> r(tile, lane);
+        r.put(0, mvx, mvy);
 #pragma unroll
-      for (int l = 0; l < L; ++l) r.put(2 + 2 * l, px[A + l] - mx, py[A + l] - my);
-      flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        for (int l = 0; l < L; ++l) r.put(2 + 2 * l, px[A + l] - mx, py[A + l] - my);
+      }
+      flush_phase<PH, D, true, RP>(tile, fr, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
     }
     if (KIND == MPE_SCN_SPREAD) {  // simple_spread.py:84-100
       constexpr int D = 4 + 2 * L + 4 * (A - 1);
-      RowPairs<D> r(tile, lane);
-      r.put(0, mvx, mvy);
-      r.put(2, mx, my);
-#pragma unroll
-      for (int l = 0; l < L; ++l) r.put(4 + 2 * l, px[A + l] - mx, py[A + l] - my);
-      int k = 4 + 2 * L;  // uniform running column
-#pragma unroll
-      for (int j = 0; j < A; ++j) {
-        if (j == i) continue;
-        r.put(k, px[j] - mx, py[j] - my);
-        k += 2;
-      }
-#pragma unroll
-      for (int z = 0; z < 2 * (A - 1); z += 2) r.put(k + z, 0.f, 0.f);  // silent agents' comm
-      flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
-    }
-    if (KIND == MPE_SCN_TAG) {  // simple_tag.py:131-147
-      constexpr int NG = A - NADV;
-      constexpr int DA = 4 + 2 * L + 2 * (A - 1) + 2 * NG, DG = DA - 2;
-      const bool adv = i < NADV;
-      auto row = [&](auto dsel) {  // one observation row of width D (adversaries DA, good agents DG)
-        constexpr int D = decltype(dsel)::value;
+      if constexpr (BUILD) {
         RowPairs<D> r(tile, lane);
         r.put(0, mvx, mvy);
         r.put(2, mx, my);
 #pragma unroll
         for (int l = 0; l < L; ++l) r.put(4 + 2 * l, px[A + l] - mx, py[A + l] - my);
-        int k = 4 + 2 * L;
+        int k = 4 + 2 * L;  // uniform running column
 #pragma unroll
         for (int j = 0; j < A; ++j) {
           if (j == i) continue;
@@ -720,12 +725,37 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
           k += 2;
         }
 #pragma unroll
-        for (int j = NADV; j < A; ++j) {
-          if (j == i) continue;
-          r.put(k, X[(j * XW + 2) * kWave + lane], X[(j * XW + 3) * kWave + lane]);
-          k += 2;
+        for (int z = 0; z < 2 * (A - 1); z += 2) r.put(k + z, 0.f, 0.f);  // silent agents' comm
+      }
+      flush_phase<PH, D, true, RP>(tile, fr, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+    }
+    if (KIND == MPE_SCN_TAG) {  // simple_tag.py:131-147
+      constexpr int NG = A - NADV;
+      constexpr int DA = 4 + 2 * L + 2 * (A - 1) + 2 * NG, DG = DA - 2;
+      const bool adv = i < NADV;
+      auto row = [&](auto dsel) {  // one observation row of width D (adversaries DA, good agents DG)
+        constexpr int D = decltype(dsel)::value;
+        if constexpr (BUILD) {
+          RowPairs<D> r(tile, lane);
+          r.put(0, mvx, mvy);
+          r.put(2, mx, my);
+#pragma unroll
+          for (int l = 0; l < L; ++l) r.put(4 + 2 * l, px[A + l] - mx, py[A + l] - my);
+          int k = 4 + 2 * L;
+#pragma unroll
+          for (int j = 0; j < A; ++j) {
+            if (j == i) continue;
+            r.put(k, px[j] - mx, py[j] - my);
+            k += 2;
+          }
+#pragma unroll
+          for (int j = NADV; j < A; ++j) {
+            if (j == i) continue;
+            r.put(k, X[(j * XW + 2) * kWave + lane], X[(j * XW + 3) * kWave + lane]);
+            k += 2;
+          }
         }
-        flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_phase<PH, D, true, RP>(tile, fr, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       };
       if (adv) row(std::integral_constant<int, DA>{});
       else     row(std::integral_constant<int, DG>{});
@@ -735,23 +765,25 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       const bool adv = i < NADV;
       auto row = [&](auto dsel, auto good) {
         constexpr int D = decltype(dsel)::value;
-        RowPairs<D> r(tile, lane);
-        int k = 0;
-        if (decltype(good)::value) { r.put(k, gx - mx, gy - my); k += 2; }
+        if constexpr (BUILD) {
+          RowPairs<D> r(tile, lane);
+          int k = 0;
+          if (decltype(good)::value) { r.put(k, gx - mx, gy - my); k += 2; }
 #pragma unroll
-        for (int l = 0; l < L; ++l) { r.put(k, px[A + l] - mx, py[A + l] - my); k += 2; }
+          for (int l = 0; l < L; ++l) { r.put(k, px[A + l] - mx, py[A + l] - my); k += 2; }
 #pragma unroll
-        for (int j = 0; j < A; ++j) {
-          if (j == i) continue;
-          r.put(k, px[j] - mx, py[j] - my);
-          k += 2;
+          for (int j = 0; j < A; ++j) {
+            if (j == i) continue;
+            r.put(k, px[j] - mx, py[j] - my);
+            k += 2;
+          }
         }
-        flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_phase<PH, D, true, RP>(tile, fr, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       };
       if (adv) row(std::integral_constant<int, DA>{}, std::false_type{});
       else     row(std::integral_constant<int, DG>{}, std::true_type{});
     }
-    if (KIND == MPE_SCN_PUSH) {  // simple_push.py:78-96
+    if constexpr (KIND == MPE_SCN_PUSH && BUILD) {  // simple_push.py:78-96 (whole rows in the build phase)
       constexpr int DG = 7 + 5 * L + 2 * (A - 1), DA = 2 + 2 * L + 2 * (A - 1);
       const bool adv = i < NADV;
       auto row = [&](auto dsel, auto good) {
@@ -793,7 +825,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       if (adv) row(std::integral_constant<int, DA>{}, std::false_type{});
       else     row(std::integral_constant<int, DG>{}, std::true_type{});
     }
-    if constexpr (KIND == MPE_SCN_SPEAKER_LISTENER) {  // simple_speaker_listener.py:69-92
+    if constexpr (KIND == MPE_SCN_SPEAKER_LISTENER && BUILD) {  // simple_speaker_listener.py:69-92
       if (i == 0) {   // speaker: the goal landmark's colour (0.65 on channel goal, 0.15 elsewhere)
         constexpr int D = 3, RS = tile_stride<D>();
 #pragma unroll
@@ -810,7 +842,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         flush_rows<D, false, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       }
     }
-    if constexpr (KIND == MPE_SCN_REFERENCE) {  // simple_reference.py:63-83
+    if constexpr (KIND == MPE_SCN_REFERENCE && BUILD) {  // simple_reference.py:63-83
       constexpr int D = 2 + 2 * L + 3 + DC, RS = tile_stride<D>();
       const int mine = i == 0 ? goal : pick1;   // agent.goal_b
       put1<RS>(tile, lane, 0, mvx); put1<RS>(tile, lane, 1, mvy);
@@ -823,7 +855,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, 5 + 2 * L + c, co[c]);
       flush_rows<D, false, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
     }
-    if constexpr (KIND == MPE_SCN_CRYPTO) {  // simple_crypto.py:127-169 (goal = pick 0, key = pick 1; colours are one-hots of width dim_c)
+    if constexpr (KIND == MPE_SCN_CRYPTO && BUILD) {  // simple_crypto.py:127-169 (goal = pick 0, key = pick 1; colours are one-hots of width dim_c)
       const Word<ROLL> cs = word_of<DC, ROLL>(b, B, w0, ln, 2, ra.seed, gw, gt);   // the speaker's utterance
       static_assert((DC & 1) == 0, "crypto rows are written as pairs");
       if (i == 0) {          // Eve: what the speaker says
@@ -846,7 +878,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       }
     }
-    if constexpr (KIND == MPE_SCN_WORLD_COMM) {  // simple_world_comm.py:231-289
+    if constexpr (KIND == MPE_SCN_WORLD_COMM && BUILD) {  // simple_world_comm.py:231-289
       constexpr int NG = A - NADV;
       constexpr int DA = 4 + 2 * L + 2 * (A - 1) + 2 * NG + 2 + DC, DGd = 4 + 2 * L + 2 * (A - 1) + 2 + 2 * (NG - 1);
       const bool f1 = X[(i * XW + 4) * kWave + lane] > 0.f, f2 = X[(i * XW + 5) * kWave + lane] > 0.f;
@@ -900,7 +932,62 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       if (i < NADV) row(std::integral_constant<int, DA>{}, std::true_type{});
       else          row(std::integral_constant<int, DGd>{}, std::false_type{});
     }
-    MPE_STAMP(5);   // this step's rows are on their way
+  };
+  using PhBuild = std::integral_constant<int, kRowsBuild>;
+  using PhLoad = std::integral_constant<int, kRowsLoad>;
+  using PhStore = std::integral_constant<int, kRowsStore>;
+
+  if constexpr (PIPE) {
+    // ---- the pipelined rollout: step t's rows leave while step t+1's World.step is computed ------------------------
+    // Per step an agent wave used to run World.step -> publish -> barrier -> sibling reads -> rows (LDS tile write ->
+    // tile read -> global stores) as ONE dependent chain with nothing to fill its waits (one workgroup per CU at 16 384
+    // worlds: a wave per SIMD).  The rows of step t and the forces of step t+1 depend on the same inputs -- the state
+    // behind barrier t -- and not on each other, so step t+1's move + contact loop sits between the tile writes and the
+    // tile read-back, its integration between the read-back and the stores: the LDS round trip and the store issue of
+    // the rows hide under the longest arithmetic chain of the step.  Same functions, same order per value: results are
+    // bit-identical to the unpipelined loop (tests/test_gpu_rollout.py: rollout == T x {reset; random_actions; step}).
+    float fx, fy;
+    { const int t = 0; MPE_STAMP(0); }
+    step_forces(0, fx, fy);
+    step_integrate(0, fx, fy);
+    { const int t = 0; MPE_STAMP(1); }
+    publish(0);
+    for (int t = 0; t < T; ++t) {
+      MPE_STAMP(2);
+      __syncthreads();
+      MPE_STAMP(3);
+      behind_barrier(t);
+      MPE_STAMP(4);
+      rows(t, PhBuild{});
+      const bool more = t + 1 < T;
+      if (more) step_forces(t + 1, fx, fy);
+      rows(t, PhLoad{});
+      if (more) step_integrate(t + 1, fx, fy);
+      rows(t, PhStore{});
+      MPE_STAMP(5);
+      if (more) {
+        { const int t0_ = t; const int t = t0_ + 1; MPE_STAMP(1); }
+        publish(t + 1);
+      }
+    }
+  } else {
+    for (int t = 0; t < T; ++t) {
+      float fx, fy;
+      MPE_STAMP(0);
+      step_forces(t, fx, fy);
+      step_integrate(t, fx, fy);
+      MPE_STAMP(1);
+      publish(t);
+      MPE_STAMP(2);
+      __syncthreads();
+      MPE_STAMP(3);
+      behind_barrier(t);
+      MPE_STAMP(4);
+      rows(t, PhBuild{});
+      rows(t, PhLoad{});
+      rows(t, PhStore{});
+      MPE_STAMP(5);   // this step's rows are on their way
+    }
   }
   if (ROLL && NCH >= 1 && ra.episode_len > 0 && live && i == 0) {   // the picks of the last in-kernel reset
     store_aux<AUX>(b.choice + wave_off(w0) + ln, goal);

@@ -226,8 +226,8 @@ def staged_batch(spec, B, rs):
     def disk(n, r):
         th, rr = rs.uniform(0, 2 * np.pi, n), r * np.sqrt(rs.uniform(0, 1, n))
         return np.stack([rr * np.cos(th), rr * np.sin(th)], axis=1)
-    if spec.name == "simple_push":
-        w = np.flatnonzero(k == 2)
+    if spec.name == "simple_push":      # a contact lasts a step or two: most worlds start in (or at the edge of) one
+        w = np.flatnonzero(k >= 2)
         pos[w, 1] = pos[w, 0] + disk(len(w), 0.11)
     if spec.name == "simple_world_comm":
         for g in (4, 5):
