@@ -101,9 +101,11 @@ typedef struct MpeBuffers {
   float *obs;
   float *rew;
   uint8_t *done;
-  float *info_rew;          /* spread: per-agent reward before the shared sum                  */
-  int32_t *info_collisions; /* spread: #agents in contact incl. self (Q1); tag: adversary's #prey contacts */
-  float *info_min_dists;    /* spread */
+  float *info_rew;          /* spread: per-agent reward before the shared sum; simple_adversary: [A][B] squared distance
+                               to the goal landmark (benchmark_data, simple_adversary.py:57-67)                          */
+  int32_t *info_collisions; /* spread: #agents in contact incl. self (Q1); tag and simple_world_comm: an adversary's
+                               #contacts with good agents (0 for the good agents; simple_world_comm.py:115-124)          */
+  float *info_min_dists;    /* spread: [A][B]; simple_adversary: [L][A][B] squared distance to landmark l (with info_rew) */
   int32_t *info_occupied;   /* spread */
   float *force;             /* [A][2][B] scratch, only for the phase-level entry points        */
   const float *entity_table; /* device copy of mpe_fill_entity_table(); needed when A+L > 16   */

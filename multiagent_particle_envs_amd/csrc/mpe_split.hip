@@ -34,13 +34,13 @@
 #endif
 
 // instrumented build (tools/phase_clock.py): lane 0 of every wave of the first workgroups stamps the shader clock at
-// the phase boundaries of each step into the buffer passed as MpeBuffers.force: [workgroup < 4][role < 8][t < 32][8]
+// the phase boundaries of each step into the buffer passed as MpeBuffers.force: [workgroup < 4][role < 16][t < 32][8]
 // uint64 -- where a step's cycles go.  Not part of the product build.
 #ifdef MPE_PHASE_CLOCK
 #define MPE_STAMP(k)                                                                                              \
   do {                                                                                                            \
     if (blockIdx.x < 4 && lane == 0 && b.force && t < 32)                                                         \
-      reinterpret_cast<unsigned long long *>(b.force)[(((size_t)blockIdx.x * 8 + role) * 32 + t) * 8 + (k)] =     \
+      reinterpret_cast<unsigned long long *>(b.force)[(((size_t)blockIdx.x * 16 + role) * 32 + t) * 8 + (k)] =     \
           __builtin_amdgcn_s_memtime();                                                                           \
   } while (0)
 #else
@@ -49,15 +49,23 @@
 
 namespace mpe {
 
-// The fused rollout of these kinds overlaps step t's observation rows with step t+1's World.step (k_split's PIPE loop).
-// Rows wider than 24 floats would hold more than 6 x 16 bytes per lane in flight: left unpipelined.
-#ifndef MPE_SPLIT_PIPE
-#define MPE_SPLIT_PIPE 1
+// DUAL roles in the fused rollout: every agent gets TWO waves -- a PHYSICS wave (World.step of step t+1: move, contacts,
+// integration, publish) and a ROWS wave (observation rows of step t from what the physics waves published) -- next to the
+// reward wave.  In the rollout a step of an agent is one ~600-instruction dependent chain (World.step -> publish ->
+// barrier -> sibling reads -> row tile -> flush); at 16 384 worlds a CU holds one workgroup, i.e. ONE wave per SIMD issuing
+// an instruction every 4-5 cycles with six LDS round trips in between: the SIMDs idle ~70 % of the time (round-2 PMC: a
+// wave issues 36 % of its lifetime).  Interleaving the two halves inside one wave does not help (measured: the same
+// instructions still issue serially, tag 1.38-1.42 vs 1.31 us per step); giving them to two waves does: step t's rows
+// and step t+1's World.step depend on the same published state and not on each other, so they run side by side, and
+// every workgroup barrier has twice the waves to hide its round trips under.  Same device functions, same values in
+// the same order: bit-identical to the single-role loop (tests/test_gpu_rollout.py).
+#ifndef MPE_SPLIT_DUAL
+#define MPE_SPLIT_DUAL 1
 #endif
-template <int KIND, bool ROLL, int DMAX>
-constexpr bool pipelined() {
-  return (MPE_SPLIT_PIPE) && ROLL && DMAX <= 24 &&
-         (KIND == MPE_SCN_SIMPLE || KIND == MPE_SCN_SPREAD || KIND == MPE_SCN_TAG || KIND == MPE_SCN_ADVERSARY);
+template <int KIND, bool ROLL>
+constexpr bool dual_roles() {
+  return (MPE_SPLIT_DUAL) && ROLL &&
+         (KIND == MPE_SCN_SIMPLE || KIND == MPE_SCN_SPREAD || KIND == MPE_SCN_TAG || KIND == MPE_SCN_ADVERSARY || KIND == MPE_SCN_PUSH);
 }
 
 template <int KIND, int A, int L, int NADV>
@@ -90,7 +98,8 @@ struct SplitShape {
   // (19.4-19.7 vs 18.3-18.8 us) and keeps 64 rows.
   static constexpr int trows(bool roll) { return (KIND == MPE_SCN_WORLD_COMM && roll) ? 32 : kWave; }
   static constexpr int tile_floats(bool roll) { return trows(roll) * (DMAX | 1); }  // >= trows * tile_stride<D>() of every row width
-  static constexpr int WAVES = A + 1;              // A agent waves + the reward wave
+  // A agent waves (+ A rows waves in the dual-role rollout) + the reward wave
+  static constexpr int waves(bool roll) { return (roll && dual_roles<KIND, true>() ? 2 * A : A) + 1; }
   // rollout: + the moves of the next step, drawn by the reward wave for all agents (two buffers by step parity)
   static constexpr size_t lds_bytes(bool roll) {
     return sizeof(float) * ((roll ? 2 : 1) * A * XW * kWave + A * tile_floats(roll) + (roll ? 2 * A * kWave : 0));
@@ -393,6 +402,14 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const float *co
         const size_t o = ro + (size_t)a * B;
         if (b.rew) store_aux<AUX>(b.rew + wave_off(o) + ln, r);
         if (b.done) store_aux<AUX>(b.done + wave_off(o) + ln, 0);
+        if (b.info_collisions) {   // benchmark_data, simple_world_comm.py:115-124: an adversary's contacts with good agents, 0 for the others
+          int c = 0;
+          if (a < NADV) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) c += hit[g][a < NADV ? a : 0] ? 1 : 0;
+          }
+          store_aux<AUX>(b.info_collisions + wave_off(o) + ln, c);
+        }
       }
     }
   }
@@ -408,7 +425,7 @@ __device__ __forceinline__ void store_state(const MpeBuffers &b, size_t B, int i
 }
 
 template <int KIND, int A, int L, int NADV, bool ROLL, int RP /* row-store policy: kRowsNt / kRowsSc1 (mpe_device.h) */>
-__global__ void __launch_bounds__((A + 1) * kWave)
+__global__ void __launch_bounds__((SplitShape<KIND, A, L, NADV>::waves(ROLL) * kWave))
 k_split(float *const g_pos, float *const g_vel, const float *const g_act, const int32_t *const g_ids, const size_t B,
         const int g_wpw, const int g_observe_only, const unsigned g_movable, const NarrowDesc d, const MpeBuffers b_in,
         const RollArgs ra) {
@@ -427,9 +444,14 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
   constexpr int AUX = aux_policy<KIND, RP>();
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & (kWave - 1);
-  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // uniform: agent index, or A = reward
-  const bool is_agent = role < A;
-  const int i = is_agent ? role : 0;
+  // uniform role of this wave: [0, A) the agent waves (in the dual-role rollout: the PHYSICS waves), then -- dual-role
+  // rollout only -- [A, 2A) the ROWS waves, and last the reward wave
+  constexpr bool DUAL = dual_roles<KIND, ROLL>();
+  constexpr int NAW = DUAL ? 2 * A : A;   // agent-side waves
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool is_agent = role < NAW;
+  const bool is_rows = DUAL && role >= A && role < NAW;
+  const int i = is_agent ? (role >= A ? role - A : role) : 0;
   // worlds of this workgroup: ra.wpw (64, 32 or 16) consecutive ones, lane = world; with fewer than 64 the upper
   // lanes idle, which buys more workgroups -- more waves per SIMD to hide latency -- when the batch is small
   const int wpw = g_wpw;
@@ -674,6 +696,18 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
     if (movable_i && step_world && live && (!ROLL || t == T - 1) && !(MPE_SPLIT_ABLATE & 8))
       store_state<AUX>(b, B, i, w0, ln, mx, my, mvx, mvy);
 #endif
+    if constexpr (KIND == MPE_SCN_ADVERSARY && !ROLL) {
+      // benchmark_data (simple_adversary.py:57-67): the squared distance to the goal landmark (an adversary's datum, the
+      // last of a good agent's) and to every landmark (a good agent's first L) -- each agent wave writes its own
+      if (live && b.info_rew) {
+        store_aux<AUX>(b.info_rew + wave_off((size_t)i * B + w0) + ln, sq2d(mx - gx, my - gy));
+        if (b.info_min_dists) {
+#pragma unroll
+          for (int l = 0; l < L; ++l)
+            store_aux<AUX>(b.info_min_dists + wave_off(((size_t)l * A + i) * B + w0) + ln, sq2d(mx - px[A + l], my - py[A + l]));
+        }
+      }
+    }
     const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
 #pragma unroll
     for (int a = 0; a < A; ++a) {
@@ -686,32 +720,25 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
     for (int a = 0; a < A; ++a) asm volatile("" ::"v"(px[a]), "v"(py[a]));   // the siblings' positions have arrived
 #endif
   };
-  // rows: agent i's observation row of step t in three phases -- kRowsBuild: assemble the 64 rows in the wave's LDS tile;
-  // kRowsLoad: read the tile back as the 16-byte pieces of the output segment (registers `fr`); kRowsStore: store them.
-  // Back to back they are the old single stage; the pipelined rollout puts the next step's World.step between them.
-  constexpr bool PIPE = pipelined<KIND, ROLL, S::DMAX>();
-  float4 fr[PIPE ? (S::DMAX + 3) / 4 : 1];
-  auto rows = [&](const int t, auto ph) {
-    constexpr int PH = PIPE ? decltype(ph)::value : (decltype(ph)::value == kRowsBuild ? kRowsAll : kRowsNone);
-    if constexpr (PH == kRowsNone) return;
-    constexpr bool BUILD = PH == kRowsBuild || PH == kRowsAll;
+  // rows: agent i's observation row of step t -- the 64 rows of the wave assembled in its LDS tile, streamed out
+  auto rows = [&](const int t) {
     if (MPE_SPLIT_ABLATE & 4) return;   // (no observation rows)
     const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
     const uint64_t gt = ra.step0 + (uint64_t)t;   // global step (the word stream of the rollout)
     float *const obs_t = b.obs + (size_t)t * obs_stride;
     if (KIND == MPE_SCN_SIMPLE) {  // simple.py:45-50
       constexpr int D = 2 + 2 * L;
-      if constexpr (BUILD) {
+      {
         RowPairs<D> r(tile, lane);
         r.put(0, mvx, mvy);
 #pragma unroll
         for (int l = 0; l < L; ++l) r.put(2 + 2 * l, px[A + l] - mx, py[A + l] - my);
       }
-      flush_phase<PH, D, true, RP>(tile, fr, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
     }
     if (KIND == MPE_SCN_SPREAD) {  // simple_spread.py:84-100
       constexpr int D = 4 + 2 * L + 4 * (A - 1);
-      if constexpr (BUILD) {
+      {
         RowPairs<D> r(tile, lane);
         r.put(0, mvx, mvy);
         r.put(2, mx, my);
@@ -727,7 +754,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
 #pragma unroll
         for (int z = 0; z < 2 * (A - 1); z += 2) r.put(k + z, 0.f, 0.f);  // silent agents' comm
       }
-      flush_phase<PH, D, true, RP>(tile, fr, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+      flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
     }
     if (KIND == MPE_SCN_TAG) {  // simple_tag.py:131-147
       constexpr int NG = A - NADV;
@@ -735,7 +762,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       const bool adv = i < NADV;
       auto row = [&](auto dsel) {  // one observation row of width D (adversaries DA, good agents DG)
         constexpr int D = decltype(dsel)::value;
-        if constexpr (BUILD) {
+        {
           RowPairs<D> r(tile, lane);
           r.put(0, mvx, mvy);
           r.put(2, mx, my);
@@ -755,7 +782,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
             k += 2;
           }
         }
-        flush_phase<PH, D, true, RP>(tile, fr, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       };
       if (adv) row(std::integral_constant<int, DA>{});
       else     row(std::integral_constant<int, DG>{});
@@ -765,7 +792,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       const bool adv = i < NADV;
       auto row = [&](auto dsel, auto good) {
         constexpr int D = decltype(dsel)::value;
-        if constexpr (BUILD) {
+        {
           RowPairs<D> r(tile, lane);
           int k = 0;
           if (decltype(good)::value) { r.put(k, gx - mx, gy - my); k += 2; }
@@ -778,12 +805,12 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
             k += 2;
           }
         }
-        flush_phase<PH, D, true, RP>(tile, fr, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
+        flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       };
       if (adv) row(std::integral_constant<int, DA>{}, std::false_type{});
       else     row(std::integral_constant<int, DG>{}, std::true_type{});
     }
-    if constexpr (KIND == MPE_SCN_PUSH && BUILD) {  // simple_push.py:78-96 (whole rows in the build phase)
+    if constexpr (KIND == MPE_SCN_PUSH) {  // simple_push.py:78-96
       constexpr int DG = 7 + 5 * L + 2 * (A - 1), DA = 2 + 2 * L + 2 * (A - 1);
       const bool adv = i < NADV;
       auto row = [&](auto dsel, auto good) {
@@ -825,7 +852,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       if (adv) row(std::integral_constant<int, DA>{}, std::false_type{});
       else     row(std::integral_constant<int, DG>{}, std::true_type{});
     }
-    if constexpr (KIND == MPE_SCN_SPEAKER_LISTENER && BUILD) {  // simple_speaker_listener.py:69-92
+    if constexpr (KIND == MPE_SCN_SPEAKER_LISTENER) {  // simple_speaker_listener.py:69-92
       if (i == 0) {   // speaker: the goal landmark's colour (0.65 on channel goal, 0.15 elsewhere)
         constexpr int D = 3, RS = tile_stride<D>();
 #pragma unroll
@@ -842,7 +869,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         flush_rows<D, false, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       }
     }
-    if constexpr (KIND == MPE_SCN_REFERENCE && BUILD) {  // simple_reference.py:63-83
+    if constexpr (KIND == MPE_SCN_REFERENCE) {  // simple_reference.py:63-83
       constexpr int D = 2 + 2 * L + 3 + DC, RS = tile_stride<D>();
       const int mine = i == 0 ? goal : pick1;   // agent.goal_b
       put1<RS>(tile, lane, 0, mvx); put1<RS>(tile, lane, 1, mvy);
@@ -855,7 +882,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, 5 + 2 * L + c, co[c]);
       flush_rows<D, false, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
     }
-    if constexpr (KIND == MPE_SCN_CRYPTO && BUILD) {  // simple_crypto.py:127-169 (goal = pick 0, key = pick 1; colours are one-hots of width dim_c)
+    if constexpr (KIND == MPE_SCN_CRYPTO) {  // simple_crypto.py:127-169 (goal = pick 0, key = pick 1; colours are one-hots of width dim_c)
       const Word<ROLL> cs = word_of<DC, ROLL>(b, B, w0, ln, 2, ra.seed, gw, gt);   // the speaker's utterance
       static_assert((DC & 1) == 0, "crypto rows are written as pairs");
       if (i == 0) {          // Eve: what the speaker says
@@ -878,7 +905,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         flush_rows<D, true, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
       }
     }
-    if constexpr (KIND == MPE_SCN_WORLD_COMM && BUILD) {  // simple_world_comm.py:231-289
+    if constexpr (KIND == MPE_SCN_WORLD_COMM) {  // simple_world_comm.py:231-289
       constexpr int NG = A - NADV;
       constexpr int DA = 4 + 2 * L + 2 * (A - 1) + 2 * NG + 2 + DC, DGd = 4 + 2 * L + 2 * (A - 1) + 2 + 2 * (NG - 1);
       const bool f1 = X[(i * XW + 4) * kWave + lane] > 0.f, f2 = X[(i * XW + 5) * kWave + lane] > 0.f;
@@ -933,19 +960,47 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       else          row(std::integral_constant<int, DGd>{}, std::false_type{});
     }
   };
-  using PhBuild = std::integral_constant<int, kRowsBuild>;
-  using PhLoad = std::integral_constant<int, kRowsLoad>;
-  using PhStore = std::integral_constant<int, kRowsStore>;
-
-  if constexpr (PIPE) {
-    // ---- the pipelined rollout: step t's rows leave while step t+1's World.step is computed ------------------------
-    // Per step an agent wave used to run World.step -> publish -> barrier -> sibling reads -> rows (LDS tile write ->
-    // tile read -> global stores) as ONE dependent chain with nothing to fill its waits (one workgroup per CU at 16 384
-    // worlds: a wave per SIMD).  The rows of step t and the forces of step t+1 depend on the same inputs -- the state
-    // behind barrier t -- and not on each other, so step t+1's move + contact loop sits between the tile writes and the
-    // tile read-back, its integration between the read-back and the stores: the LDS round trip and the store issue of
-    // the rows hide under the longest arithmetic chain of the step.  Same functions, same order per value: results are
-    // bit-identical to the unpipelined loop (tests/test_gpu_rollout.py: rollout == T x {reset; random_actions; step}).
+  if constexpr (DUAL) {
+    if (is_rows) {
+      // ---- ROWS wave of agent i: behind barrier t, step t's state of every agent out of the exchange block -> rows ------
+      // (the landmarks and the per-world picks follow the in-kernel resets with the physics waves' countdown)
+      for (int t = 0; t < T; ++t) {
+        MPE_STAMP(0);
+        const bool reset_now = countdown == 0;
+        if (countdown >= 0) countdown = reset_now ? ra.episode_len - 1 : countdown - 1;
+        if (reset_now) {
+#pragma unroll
+          for (int l = 0; l < L; ++l) reset_draw(ra.seed, gw, ep, A + l, ra.landmark_range, px[A + l], py[A + l]);
+          if (NCH >= 1) goal = choice_draw(ra.seed, gw, ep, 0, d.choice_pop[0]);
+          if (NCH >= 2) pick1 = choice_draw(ra.seed, gw, ep, 1, d.choice_pop[1]);
+          ++ep;
+        }
+        if (HAS_GOAL || KIND == MPE_SCN_SPEAKER_LISTENER) goal_pos<A, L>(px, py, goal, gx, gy);
+        MPE_STAMP(2);
+        __syncthreads();
+        MPE_STAMP(3);
+        const float *const X = xch + (t & 1) * A * XW * kWave;
+        mx = X[(i * XW + 0) * kWave + lane];
+        my = X[(i * XW + 1) * kWave + lane];
+        mvx = X[(i * XW + 2) * kWave + lane];
+        mvy = X[(i * XW + 3) * kWave + lane];
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          if (a == i) { px[a] = mx; py[a] = my; continue; }  // uniform
+          px[a] = X[(a * XW + 0) * kWave + lane];
+          py[a] = X[(a * XW + 1) * kWave + lane];
+        }
+#ifdef MPE_PHASE_CLOCK
+#pragma unroll
+        for (int a = 0; a < A; ++a) asm volatile("" ::"v"(px[a]), "v"(py[a]));
+#endif
+        MPE_STAMP(4);
+        rows(t);
+        MPE_STAMP(5);
+      }
+      return;
+    }
+    // ---- PHYSICS wave of agent i: World.step of step t+1 behind barrier t, from the siblings' state of step t -----------
     float fx, fy;
     { const int t = 0; MPE_STAMP(0); }
     step_forces(0, fx, fy);
@@ -958,15 +1013,10 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       MPE_STAMP(3);
       behind_barrier(t);
       MPE_STAMP(4);
-      rows(t, PhBuild{});
-      const bool more = t + 1 < T;
-      if (more) step_forces(t + 1, fx, fy);
-      rows(t, PhLoad{});
-      if (more) step_integrate(t + 1, fx, fy);
-      rows(t, PhStore{});
-      MPE_STAMP(5);
-      if (more) {
-        { const int t0_ = t; const int t = t0_ + 1; MPE_STAMP(1); }
+      if (t + 1 < T) {
+        step_forces(t + 1, fx, fy);
+        step_integrate(t + 1, fx, fy);
+        MPE_STAMP(5);
         publish(t + 1);
       }
     }
@@ -983,9 +1033,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       MPE_STAMP(3);
       behind_barrier(t);
       MPE_STAMP(4);
-      rows(t, PhBuild{});
-      rows(t, PhLoad{});
-      rows(t, PhStore{});
+      rows(t);
       MPE_STAMP(5);   // this step's rows are on their way
     }
   }
@@ -1026,11 +1074,13 @@ struct SplitEntry {
   int kind, A, L, nadv;
   SplitFn step, step_small, roll, roll_small;   // rows stored nontemporal; *_small: at agent scope (mpe_device.h)
   size_t lds_step, lds_roll;
+  int waves_step, waves_roll;
 };
 #define MPE_SPLIT_ENTRY(KIND, A, L, NADV)                                                                         \
   { KIND, A, L, NADV, k_split<KIND, A, L, NADV, false, kRowsNt>, k_split<KIND, A, L, NADV, false, kRowsSc1>,       \
     k_split<KIND, A, L, NADV, true, kRowsNt>, k_split<KIND, A, L, NADV, true, kRowsSc1>,                           \
-    SplitShape<KIND, A, L, NADV>::lds_bytes(false), SplitShape<KIND, A, L, NADV>::lds_bytes(true) }
+    SplitShape<KIND, A, L, NADV>::lds_bytes(false), SplitShape<KIND, A, L, NADV>::lds_bytes(true),                 \
+    SplitShape<KIND, A, L, NADV>::waves(false), SplitShape<KIND, A, L, NADV>::waves(true) }
 
 static const SplitEntry kSplitTable[] = {
     MPE_SPLIT_ENTRY(MPE_SCN_SIMPLE, 1, 1, 0),
@@ -1073,7 +1123,7 @@ int launch_split(bool roll, int kind, int A, int L, int nadv, const NarrowDesc &
   // 10.8 plain / 10.7 nt / 16.5 sc1).
   const size_t row_bytes = (size_t)d.obs_off[A] * sizeof(float) * B;
   const bool small = row_bytes < (roll ? kRollNtFromBytes : kRowsNtFromBytes);
-  hipLaunchKernelGGL(roll ? (small ? e->roll_small : e->roll) : small ? e->step_small : e->step, dim3(grid), dim3((A + 1) * kWave), roll ? e->lds_roll : e->lds_step, stream,
+  hipLaunchKernelGGL(roll ? (small ? e->roll_small : e->roll) : small ? e->step_small : e->step, dim3(grid), dim3((roll ? e->waves_roll : e->waves_step) * kWave), roll ? e->lds_roll : e->lds_step, stream,
                      b.pos, b.vel, b.act, b.ids, B, (int)r2.wpw, (int)r2.observe_only, (unsigned)d.movable, d, b, r2);
   return (int)hipGetLastError();
 }

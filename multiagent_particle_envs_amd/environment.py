@@ -50,8 +50,11 @@ class _OutputSet(object):
                              "collisions": torch.zeros((A, B), dtype=torch.int32, device=dev),
                              "min_dists": torch.zeros((A, B), dtype=torch.float32, device=dev),
                              "occupied_landmarks": torch.zeros((A, B), dtype=torch.int32, device=dev)}
-            elif env._kind == _abi.MPE_SCN_TAG:
+            elif env._kind in (_abi.MPE_SCN_TAG, _abi.MPE_SCN_WORLD_COMM):
                 self.info = {"collisions": torch.zeros((A, B), dtype=torch.int32, device=dev)}
+            elif env._kind == _abi.MPE_SCN_ADVERSARY:   # squared distances: to the goal [A,B], to every landmark [L,A,B]
+                self.info = {"goal_d2": torch.zeros((A, B), dtype=torch.float32, device=dev),
+                             "landmark_d2": torch.zeros((len(w.landmarks), A, B), dtype=torch.float32, device=dev)}
         b = _abi.MpeBuffers()
         b.pos, b.vel = w.pos.data_ptr(), w.vel.data_ptr()
         b.obs, b.rew, b.done = self.obs.data_ptr(), self.rew.data_ptr(), self.done.data_ptr()
@@ -61,6 +64,9 @@ class _OutputSet(object):
             b.info_occupied = self.info["occupied_landmarks"].data_ptr()
         if "collisions" in self.info:
             b.info_collisions = self.info["collisions"].data_ptr()
+        if "goal_d2" in self.info:
+            b.info_rew = self.info["goal_d2"].data_ptr()
+            b.info_min_dists = self.info["landmark_d2"].data_ptr()
         if env._entity_table is not None:
             b.entity_table = env._entity_table.data_ptr()
         if w.choice_i32 is not None:      # per-world picks (goal landmark ...): updated in place by resets
@@ -80,8 +86,12 @@ class _OutputSet(object):
             i_ = self.info
             return {"n": [(i_["rew"][i], i_["collisions"][i], i_["min_dists"][i], i_["occupied_landmarks"][i])
                           for i in range(A)]}
-        if env._kind == _abi.MPE_SCN_TAG:
+        if env._kind in (_abi.MPE_SCN_TAG, _abi.MPE_SCN_WORLD_COMM):
             return {"n": [self.info["collisions"][i] for i in range(A)]}
+        if env._kind == _abi.MPE_SCN_ADVERSARY:     # simple_adversary.py:57-67: a scalar for an adversary, a tuple for a good agent
+            g, l = self.info["goal_d2"], self.info["landmark_d2"]
+            return {"n": [g[i] if a.adversary else tuple(l[k][i] for k in range(l.shape[0])) + (g[i],)
+                          for i, a in enumerate(env.agents)]}
         return {"n": [{} for _ in range(A)]}
 
 
@@ -140,7 +150,8 @@ class MultiAgentEnv(object):
             own = _abi.lib().mpe_step_supported(C.byref(world.scenario_desc(kind, getattr(sc, "num_adversaries", 0)))) == 1
         self._py_reward = own and not is_builtin(reward_callback, "reward")
         self._py_info = own and info_callback is not None and not (
-            is_builtin(info_callback, "benchmark_data") and kind in (_abi.MPE_SCN_SPREAD, _abi.MPE_SCN_TAG))
+            is_builtin(info_callback, "benchmark_data") and kind in (_abi.MPE_SCN_SPREAD, _abi.MPE_SCN_TAG, _abi.MPE_SCN_ADVERSARY,
+                                                                      _abi.MPE_SCN_WORLD_COMM))
         self._py_done = own and done_callback is not None
         if fused is None:
             fused = own

@@ -103,7 +103,8 @@ def stage_world(name, w, world, rng):
 
 
 def record(name, seeds, T, squeeze_every=0, squeeze=0.3, customise=None, stage=False):
-    env = make_env(name)
+    bench = name in ("simple_adversary", "simple_world_comm")   # benchmark_data as the info callback (make_env.py:36-43)
+    env = make_env(name, benchmark=bench)
     world = env.world
     consts = customise(env) if customise else {}     # gen_golden_custom.py: entity / world constants changed after make_world
     A, W, E = env.n, len(seeds), len(world.entities)
@@ -146,6 +147,18 @@ def record(name, seeds, T, squeeze_every=0, squeeze=0.3, customise=None, stage=F
                 out["act%d" % i][t, w] = a
                 act.append(a.copy())
             obs, rew, done, info = env.step(act)
+            if bench:    # simple_adversary.py:57-67 (adversary: a squared distance; good agents: L + 1 of them), simple_world_comm.py:115-124
+                inf = info["n"]
+                if name == "simple_adversary":
+                    if "info_adv" not in out:
+                        out["info_adv"] = np.zeros((T, W, 1))
+                        out["info_good"] = np.zeros((T, W, A - 1, len(world.landmarks) + 1))
+                    out["info_adv"][t, w, 0] = inf[0]
+                    out["info_good"][t, w] = np.array([list(x) for x in inf[1:]])
+                else:
+                    if "info_collisions" not in out:
+                        out["info_collisions"] = np.zeros((T, W, A), np.int32)
+                    out["info_collisions"][t, w] = np.array(inf, dtype=np.int32)
             for i in range(A):
                 out["obs%d" % i][t, w] = obs[i]
                 out["c%d" % i][t, w] = world.agents[i].state.c

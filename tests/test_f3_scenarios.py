@@ -854,15 +854,17 @@ def test_constants_assigned_on_a_live_env_are_honoured_without_a_refresh_call():
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["simple_adversary", "simple_crypto", "simple_world_comm"])
 def test_benchmark_data_of_the_f3_scenarios_rides_on_the_fused_step(name):
-    """make_env(name, benchmark=True): the kernels have no benchmark_data stage for these scenarios; the env keeps the fused
-    launch for physics + observations + rewards and evaluates the scenario's own benchmark_data in Python on the
-    post-step world (partial fusion) -- same info as the all-Python generic path."""
+    """make_env(name, benchmark=True): simple_adversary's squared distances and simple_world_comm's contact counts come out
+    of the SAME launch as the step (round 3: agent waves / reward wave write them; no Python evaluation); simple_crypto's
+    benchmark_data is (agent.state.c, goal colour) -- views of what the env holds, evaluated in Python without a launch.
+    Same info as the all-Python generic path."""
     B = 500
     ef = mpe.make_env(name, benchmark=True, batch_size=B, seed=2)
     eg = mpe.make_env(name, benchmark=True, batch_size=B, seed=2, fused=False)
     if not hasattr(ef.scenario, "benchmark_data"):
         pytest.skip("no benchmark_data in this scenario")
-    assert ef.fused and ef._py_info and not ef._py_reward and not eg.fused
+    assert ef.fused and not ef._py_reward and not eg.fused
+    assert ef._py_info == (name == "simple_crypto")      # the others: written by the step's own launch
     eg.world.pos.copy_(ef.world.pos)
     eg.world.vel.copy_(ef.world.vel)
     if ef.world.choice_i32 is not None:
@@ -883,3 +885,37 @@ def test_benchmark_data_of_the_f3_scenarios_rides_on_the_fused_step(name):
             for x, y in zip(a, b):
                 x, y = np_(x).astype(np.float64), np_(y).astype(np.float64)
                 close(np.broadcast_to(x, np.broadcast(x, y).shape), np.broadcast_to(y, np.broadcast(x, y).shape), what="info%d" % i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["simple_adversary", "simple_world_comm"])
+def test_fused_benchmark_data_against_reference_golden(name, golden):
+    """benchmark_data of simple_adversary (squared distances: simple_adversary.py:57-67) and simple_world_comm (an
+    adversary's contacts with good agents: simple_world_comm.py:115-124) as the reference returned them
+    (tests/golden/f3_*.npz, info_* arrays), from the fused step's own launch, teacher-forced: floats at 1e-5, the counts
+    exact outside a 1e-6 band around the contact threshold."""
+    from oracle import spec as ospec
+    from oracle.mpe_f3 import knife_edge
+    g = golden("f3_" + name)
+    W, T = len(g["seeds"]), g["rew"].shape[0]
+    env = mpe.make_env(name, batch_size=W, benchmark=True)
+    assert env.fused and not env._py_info
+    A = env.n
+    set_choices(env, g["choice"])
+    for t in range(T):
+        env.world.set_state(g["pos0"] if t == 0 else g["pos"][t - 1], g["vel0"] if t == 0 else g["vel"][t - 1])
+        set_comm(env, g, t - 1)
+        act = [torch.as_tensor(g["act%d" % i][t], dtype=torch.float32).cuda() for i in range(A)]
+        _, _, _, info = env.step(act)
+        inf = info["n"]
+        if name == "simple_adversary":
+            close(np_(inf[0]), g["info_adv"][t][:, 0], what="t=%d adversary" % t)
+            for k in range(1, A):
+                assert isinstance(inf[k], tuple) and len(inf[k]) == g["info_good"].shape[-1]
+                for j, x in enumerate(inf[k]):
+                    close(np_(x), g["info_good"][t][:, k - 1, j], what="t=%d good %d datum %d" % (t, k, j))
+        else:
+            ok = ~knife_edge(ospec.by_name(name), g["pos"][t], 1e-6)
+            got = np.stack([np_(x) for x in inf], axis=1)
+            assert got.dtype == np.int32 and np.array_equal(got[ok], g["info_collisions"][t][ok]) and ok.mean() > 0.99
+            assert g["info_collisions"][t].sum() > 0 or t > 0

@@ -232,8 +232,11 @@ def _replay_f3(spec, g, check_reset=True):
             _close(orc.c[i], g["c%d" % i][t])
         _close(rew.T, g["rew"][t])
         assert not done.any()
-        if "info_collisions" in g:
+        if "info_collisions" in g:      # simple_world_comm.py:115-124
             assert np.array_equal(info["collisions"].T, g["info_collisions"][t])
+        if "info_adv" in g:             # simple_adversary.py:57-67
+            _close(info["adv_goal_d2"].T, g["info_adv"][t])
+            _close(np.transpose(info["good_d2"], (2, 0, 1)), g["info_good"][t])
     return worst
 
 

@@ -25,7 +25,7 @@ def main():
     kw = {"num_agents": int(sys.argv[4])} if len(sys.argv) > 4 else {}
     env = mpe.make_env(scn, batch_size=B, seed=0, **kw)
     rr = RandomRollout(env, episode_len=25, pool=25, regenerate=False)
-    dbg = torch.zeros(4 * 8 * 32 * 8, dtype=torch.int64, device="cuda")
+    dbg = torch.zeros(4 * 16 * 32 * 8, dtype=torch.int64, device="cuda")
     A = len(env.world.agents)
     T = 25
     traj = Trajectory(env, T)
@@ -43,17 +43,17 @@ def main():
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    d = dbg.cpu().numpy().reshape(4, 8, 32, 8).astype(np.int64)
+    d = dbg.cpu().numpy().reshape(4, 16, 32, 8).astype(np.int64)
     nt = T if mode == "roll" else 1
     print("%s B=%d %s: launch %.2f us by events (%d steps)" % (scn, B, mode, ms * 1e3, nt))
     t_first = d[:, :, 0, 0][d[:, :, 0, 0] > 0].min()
     t_last = d[:, :, :nt, :].max()
     print("  first stamp -> last stamp: %d ticks; if the launch is ~that long, a tick is %.2f ns" % (t_last - t_first, ms * 1e6 / max(t_last - t_first, 1)))
-    for role in range(8):
+    for role in range(16):
         st = d[:, role, :nt, :]
         if not st[:, :, 0].any():
             continue
-        nst = 6 if st[:, :, 5].any() else 4
+        nst = 6 if st[:, :, 5].any() or st[:, :, 4].any() else 4
         steps = st[:, 1:, 0] - st[:, :-1, 0] if nt > 1 else None
         line = "  role %d (%s): " % (role, "agent" if nst == 6 else "reward")
         for k in range(1, nst):
