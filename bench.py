@@ -638,6 +638,7 @@ def main():
 
     dt, R, ev_ms, rate = leg.timed(torch, rv, dev, args.mode, args.protocol, K, W, args.repeats, args.region_ms)
     k_us = leg.kernel_time_us(torch, args.mode)
+    head_probe = leg.env.placement_probe
     floor_us = launch_floor_us(torch, dev)
     extra = {}
     solo = world == 1 and not args.no_extra and args.streams == 1
@@ -724,7 +725,7 @@ def main():
             d1, R1, _, r1_ = lg.timed(torch, rv, dev, "graph", "fresh", kk, 10, 5, 2 * SR)
             k1 = lg.kernel_time_us(torch, "graph", n=200 if bb * ag < 100000 else 100)
             ent = {"value": bb * kk * R1 / d1, "unit": "env-steps/s", "ms_per_step": d1 * 1e3 / (kk * R1), "repeats": stats(r1_),
-                   "timed_steps": kk * R1,
+                   "timed_steps": kk * R1, "placement_probe": lg.env.placement_probe,
                    "workload": "%s A=%d L=%d, %d worlds" % (scn, lg.A, lg.Lm, bb), "roofline": roofline_entry(lg, k1, bb, "graph", floor_us)}
             d2, R2, _, r2_ = lg.timed(torch, rv, dev, "fused", "resident", kk, 10, 5, SR)
             k2 = lg.kernel_time_us(torch, "fused", n=200 if bb * ag < 100000 else 100)
@@ -779,7 +780,8 @@ def main():
                        "barrier_backend": rv.backend, "barrier_note": rv.note,
                        "launcher": "torch.distributed.run / env" if world > 1 and not os.environ.get("MPE_SELF_SPAWNED") else
                                    ("self-spawned (bench.py started the ranks)" if world > 1 else "single process"),
-                       "ranks_seen": len(recs), "ranks": recs},
+                       "ranks_seen": len(recs), "ranks": recs,
+                       "placement_probe": head_probe},
             "roofline": headline_roof,
             "repeats": stats(rate),
         }

@@ -68,7 +68,11 @@ __device__ __forceinline__ bool sqrt_lt(float s2, float m) {
   const bool below = s2 < m2 * 0.9999996f;                    // surely less
   const bool above = s2 > m2 * 1.0000004f && m2 > 1e-30f;     // surely not (a vanishing threshold has no band)
   bool r = below;
-  if (!below && !above) r = sqrtf(s2) < m;                    // the guard band (and NaN): one rare branch
+  // the guard band (and NaN): a WAVE-uniform branch -- left as a per-lane `if` the compiler if-converts it and every call
+  // pays the ~20-instruction correctly rounded sqrt (seen in the reward waves' ISA: three to six of them per step)
+  if (__builtin_amdgcn_ballot_w64(!below && !above) != 0) {
+    if (!below && !above) r = sqrtf(s2) < m;
+  }
   return r;
 }
 __device__ __forceinline__ float sq2d(float dx, float dy) {

@@ -62,9 +62,9 @@ namespace mpe {
 #ifndef MPE_SPLIT_DUAL
 #define MPE_SPLIT_DUAL 1
 #endif
-template <int KIND, bool ROLL>
-constexpr bool dual_roles() {
-  return (MPE_SPLIT_DUAL) && ROLL &&
+template <int KIND>
+constexpr bool dual_kind() {   // the kinds that have a dual-role rollout kernel
+  return (MPE_SPLIT_DUAL) &&
          (KIND == MPE_SCN_SIMPLE || KIND == MPE_SCN_SPREAD || KIND == MPE_SCN_TAG || KIND == MPE_SCN_ADVERSARY || KIND == MPE_SCN_PUSH);
 }
 
@@ -99,7 +99,7 @@ struct SplitShape {
   static constexpr int trows(bool roll) { return (KIND == MPE_SCN_WORLD_COMM && roll) ? 32 : kWave; }
   static constexpr int tile_floats(bool roll) { return trows(roll) * (DMAX | 1); }  // >= trows * tile_stride<D>() of every row width
   // A agent waves (+ A rows waves in the dual-role rollout) + the reward wave
-  static constexpr int waves(bool roll) { return (roll && dual_roles<KIND, true>() ? 2 * A : A) + 1; }
+  static constexpr int waves(bool dual) { return (dual ? 2 * A : A) + 1; }
   // rollout: + the moves of the next step, drawn by the reward wave for all agents (two buffers by step parity)
   static constexpr size_t lds_bytes(bool roll) {
     return sizeof(float) * ((roll ? 2 : 1) * A * XW * kWave + A * tile_floats(roll) + (roll ? 2 * A * kWave : 0));
@@ -174,7 +174,7 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const float *co
         const float m = fast_sqrt(m2);
         lm_term = lm_term - m;
         md = md + m;
-        occupied += sqrt_lt(m2, 0.1f) ? 1 : 0;  // the integer output takes the exact test
+        if (b.info_rew) occupied += sqrt_lt(m2, 0.1f) ? 1 : 0;  // benchmark_data only (uniform); the integer output takes the exact test
       }
       int cnt[A];
 #pragma unroll
@@ -424,8 +424,9 @@ __device__ __forceinline__ void store_state(const MpeBuffers &b, size_t B, int i
   store_aux<AUX>(b.vel + wave_off((size_t)(2 * i + 1) * B + w0) + ln, mvy);
 }
 
-template <int KIND, int A, int L, int NADV, bool ROLL, int RP /* row-store policy: kRowsNt / kRowsSc1 (mpe_device.h) */>
-__global__ void __launch_bounds__((SplitShape<KIND, A, L, NADV>::waves(ROLL) * kWave))
+template <int KIND, int A, int L, int NADV, bool ROLL, int RP /* row-store policy: kRowsNt / kRowsSc1 (mpe_device.h) */,
+          bool DUALP = false /* the dual-role rollout: physics + rows waves per agent */>
+__global__ void __launch_bounds__((SplitShape<KIND, A, L, NADV>::waves(DUALP) * kWave))
 k_split(float *const g_pos, float *const g_vel, const float *const g_act, const int32_t *const g_ids, const size_t B,
         const int g_wpw, const int g_observe_only, const unsigned g_movable, const NarrowDesc d, const MpeBuffers b_in,
         const RollArgs ra) {
@@ -446,7 +447,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
   const int lane = threadIdx.x & (kWave - 1);
   // uniform role of this wave: [0, A) the agent waves (in the dual-role rollout: the PHYSICS waves), then -- dual-role
   // rollout only -- [A, 2A) the ROWS waves, and last the reward wave
-  constexpr bool DUAL = dual_roles<KIND, ROLL>();
+  constexpr bool DUAL = DUALP && ROLL;
   constexpr int NAW = DUAL ? 2 * A : A;   // agent-side waves
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const bool is_agent = role < NAW;
@@ -523,7 +524,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
           --cd;
         }
       }
-      if (ROLL && t + 1 < T) {   // the moves of step t + 1: read by the agent waves behind this step's barrier
+      if (ROLL && !DUAL && t + 1 < T) {   // the moves of step t + 1: read by the agent waves behind this step's barrier
         const uint64_t gt1 = ra.step0 + (uint64_t)t + 1;
 #pragma unroll
         for (int q = 0; q < (A + 3) / 4; ++q) {
@@ -623,7 +624,9 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         ++ep;
       }
       // the one-hot row mpe_random_actions would write: drawn here at the first step, by the reward wave afterwards
-      const int m = t == 0 ? action_draw(ra.seed, gw, gt, i) : mv[((t & 1) * A + i) * kWave + lane];
+      // (dual-role rollout: always drawn here -- the physics wave reaches the barrier ahead of the reward wave anyway, and
+      //  the reward wave's per-step chain, Philox -> barrier -> reward, is what the step then waits for)
+      const int m = (t == 0 || DUAL) ? action_draw(ra.seed, gw, gt, i) : mv[((t & 1) * A + i) * kWave + lane];
       ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * accel_i;
       uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * accel_i;
     } else if (step_world && movable_i) {
@@ -1073,14 +1076,19 @@ using SplitFn = void (*)(float *, float *, const float *, const int32_t *, const
 struct SplitEntry {
   int kind, A, L, nadv;
   SplitFn step, step_small, roll, roll_small;   // rows stored nontemporal; *_small: at agent scope (mpe_device.h)
+  SplitFn roll_dual, roll_dual_small;           // the dual-role rollout (small batches), or nullptr
   size_t lds_step, lds_roll;
-  int waves_step, waves_roll;
 };
+template <int KIND, int A, int L, int NADV, int RP>
+constexpr SplitFn dual_fn() {
+  if constexpr (dual_kind<KIND>() && SplitShape<KIND, A, L, NADV>::waves(true) * kWave <= 1024) return k_split<KIND, A, L, NADV, true, RP, true>;
+  else return nullptr;
+}
 #define MPE_SPLIT_ENTRY(KIND, A, L, NADV)                                                                         \
   { KIND, A, L, NADV, k_split<KIND, A, L, NADV, false, kRowsNt>, k_split<KIND, A, L, NADV, false, kRowsSc1>,       \
     k_split<KIND, A, L, NADV, true, kRowsNt>, k_split<KIND, A, L, NADV, true, kRowsSc1>,                           \
-    SplitShape<KIND, A, L, NADV>::lds_bytes(false), SplitShape<KIND, A, L, NADV>::lds_bytes(true),                 \
-    SplitShape<KIND, A, L, NADV>::waves(false), SplitShape<KIND, A, L, NADV>::waves(true) }
+    dual_fn<KIND, A, L, NADV, kRowsNt>(), dual_fn<KIND, A, L, NADV, kRowsSc1>(),                                   \
+    SplitShape<KIND, A, L, NADV>::lds_bytes(false), SplitShape<KIND, A, L, NADV>::lds_bytes(true) }
 
 static const SplitEntry kSplitTable[] = {
     MPE_SPLIT_ENTRY(MPE_SCN_SIMPLE, 1, 1, 0),
@@ -1123,7 +1131,28 @@ int launch_split(bool roll, int kind, int A, int L, int nadv, const NarrowDesc &
   // 10.8 plain / 10.7 nt / 16.5 sc1).
   const size_t row_bytes = (size_t)d.obs_off[A] * sizeof(float) * B;
   const bool small = row_bytes < (roll ? kRollNtFromBytes : kRowsNtFromBytes);
-  hipLaunchKernelGGL(roll ? (small ? e->roll_small : e->roll) : small ? e->step_small : e->step, dim3(grid), dim3((roll ? e->waves_roll : e->waves_step) * kWave), roll ? e->lds_roll : e->lds_step, stream,
+  SplitFn fn = roll ? (small ? e->roll_small : e->roll) : small ? e->step_small : e->step;
+  int waves = A + 1;
+  // The dual-role rollout (a physics and a rows wave per agent) where the chip is under-filled: up to 1.5 workgroups per
+  // CU the extra waves find idle SIMD time (simple_tag at 16 384 worlds 1.31 -> 1.01 us per step); from ~4 per CU on the
+  // CUs are full either way and the second barrier partner only costs (simple_tag at 65 536 worlds 3.54 -> 3.80).
+  static const int n_cu = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
+    (void)hipGetLastError();
+    return 256;
+  }();
+#ifdef MPE_SPLIT_DUAL_MAX_WG_PER_CU_X2
+  const unsigned dual_max = (unsigned)n_cu * (MPE_SPLIT_DUAL_MAX_WG_PER_CU_X2) / 2;
+#else
+  const unsigned dual_max = (unsigned)n_cu * 3 / 2;
+#endif
+  SplitFn dual = small ? e->roll_dual_small : e->roll_dual;
+  if (roll && dual && grid <= dual_max) {
+    fn = dual;
+    waves = 2 * A + 1;
+  }
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * kWave), roll ? e->lds_roll : e->lds_step, stream,
                      b.pos, b.vel, b.act, b.ids, B, (int)r2.wpw, (int)r2.observe_only, (unsigned)d.movable, d, b, r2);
   return (int)hipGetLastError();
 }

@@ -13,7 +13,7 @@ Everything on the step path runs in libmpe_hip.so on a HIP device; there is no C
 
 
 def make_env(scenario_name, benchmark=False, batch_size=None, device=None, seed=0, fresh_outputs=False,
-             fused=None, max_episode_steps=None, auto_reset=False, **scenario_kwargs):
+             fused=None, max_episode_steps=None, auto_reset=False, probe_placement=True, **scenario_kwargs):
     from .environment import MultiAgentEnv
     from . import scenarios
 
@@ -29,6 +29,6 @@ def make_env(scenario_name, benchmark=False, batch_size=None, device=None, seed=
     info_cb = getattr(scenario, "benchmark_data", None) if benchmark else None
     env = MultiAgentEnv(world, scenario.reset_world, scenario.reward, scenario.observation, info_cb,
                         numpy_io=compat, fresh_outputs=fresh_outputs or compat, fused=fused,
-                        max_episode_steps=max_episode_steps, auto_reset=auto_reset)
+                        max_episode_steps=max_episode_steps, auto_reset=auto_reset, probe_placement=probe_placement)
     env.scenario = scenario
     return env
