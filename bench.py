@@ -492,8 +492,7 @@ def roofline_entry(leg, k_us, B, mode, floor_us):
             "l3_resident": resident,
             "algorithmic_bytes_per_env_step": bytes_step, "algorithmic_bytes_per_launch": per_launch,
             "kernel": kname, "kernel_us_per_launch": k_us, "env_steps_per_launch": B,
-            "launch_floor_us": floor_us,
-            "frac_excluding_launch_floor": (per_launch / max((k_us - floor_us), 1e-3) / 1e3 / HBM_PEAK_GBS) if floor_us else None}
+            "launch_floor_us": floor_us}
 
 
 def box_fingerprint(torch, dev):

@@ -62,6 +62,21 @@ namespace mpe {
 #ifndef MPE_SPLIT_DUAL
 #define MPE_SPLIT_DUAL 1
 #endif
+// Who draws the next step's moves in the dual-role rollout (bit KIND set: every physics wave its own, at the head of its
+// step; clear: the reward wave for everybody, as in the single-role rollout).  The reward wave's chain per step is
+// [Philox ->] barrier -> reward; where the reward is heavy (simple_spread: A (A-1) / 2 strict-< tests, L minima and square
+// roots) that chain is what the step waits for and the draw is better off in the physics waves; where it is light the
+// physics waves are the longer chain and the draw stays with the reward wave.  Same-box A/B, us per rollout step
+// (single-role | dual, reward wave draws | dual, physics waves draw; profiles/r3_ab_logs.txt session 8):
+//   simple_spread N=3  4096 worlds 1.08 | 1.09 | 0.99      16 384 worlds 1.13 | 1.14 | 1.06      N=4, 16 384: 1.83 | 1.83 | 1.69
+//   simple_adversary  16 384 worlds 0.79 | 0.58 | 0.64     simple_push 16 384: 0.93 | 0.65 | 0.76     simple 16 384: 0.43 | 0.37 | 0.46
+//   simple_tag        16 384 worlds 1.31 | 1.01-1.15 | 1.09-1.10 (by box)
+#ifndef MPE_SPLIT_DUAL_OWN_DRAW
+#define MPE_SPLIT_DUAL_OWN_DRAW (1 << MPE_SCN_SPREAD)
+#endif
+template <int KIND>
+constexpr bool dual_own_draw() { return ((MPE_SPLIT_DUAL_OWN_DRAW) >> KIND) & 1; }
+
 template <int KIND>
 constexpr bool dual_kind() {   // the kinds that have a dual-role rollout kernel
   return (MPE_SPLIT_DUAL) &&
@@ -448,6 +463,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
   // uniform role of this wave: [0, A) the agent waves (in the dual-role rollout: the PHYSICS waves), then -- dual-role
   // rollout only -- [A, 2A) the ROWS waves, and last the reward wave
   constexpr bool DUAL = DUALP && ROLL;
+  constexpr bool OWN_DRAW = DUAL && dual_own_draw<KIND>();   // the physics waves draw their own moves
   constexpr int NAW = DUAL ? 2 * A : A;   // agent-side waves
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const bool is_agent = role < NAW;
@@ -524,7 +540,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
           --cd;
         }
       }
-      if (ROLL && !DUAL && t + 1 < T) {   // the moves of step t + 1: read by the agent waves behind this step's barrier
+      if (ROLL && !OWN_DRAW && t + 1 < T) {   // the moves of step t + 1: read by the agent waves behind this step's barrier
         const uint64_t gt1 = ra.step0 + (uint64_t)t + 1;
 #pragma unroll
         for (int q = 0; q < (A + 3) / 4; ++q) {
@@ -624,9 +640,8 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         ++ep;
       }
       // the one-hot row mpe_random_actions would write: drawn here at the first step, by the reward wave afterwards
-      // (dual-role rollout: always drawn here -- the physics wave reaches the barrier ahead of the reward wave anyway, and
-      //  the reward wave's per-step chain, Philox -> barrier -> reward, is what the step then waits for)
-      const int m = (t == 0 || DUAL) ? action_draw(ra.seed, gw, gt, i) : mv[((t & 1) * A + i) * kWave + lane];
+      // (dual-role rollout of the kinds in MPE_SPLIT_DUAL_OWN_DRAW: always drawn here)
+      const int m = (t == 0 || OWN_DRAW) ? action_draw(ra.seed, gw, gt, i) : mv[((t & 1) * A + i) * kWave + lane];
       ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * accel_i;
       uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * accel_i;
     } else if (step_world && movable_i) {
