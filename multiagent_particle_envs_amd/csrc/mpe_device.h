@@ -71,6 +71,7 @@ __device__ __forceinline__ bool sqrt_lt(float s2, float m) {
   // the guard band (and NaN): a WAVE-uniform branch -- left as a per-lane `if` the compiler if-converts it and every call
   // pays the ~20-instruction correctly rounded sqrt (seen in the reward waves' ISA: three to six of them per step)
   if (__builtin_amdgcn_ballot_w64(!below && !above) != 0) {
+    asm volatile("" ::: "memory");   // (keeps the block a block: without it the compiler speculates the sqrt out of the branch again)
     if (!below && !above) r = sqrtf(s2) < m;
   }
   return r;
