@@ -385,24 +385,32 @@ class Leg(object):
         return rv.reduce_max(walls[med]), R, evs[med], rate
 
     def kernel_time_us(self, torch, mode, n=400, protocol="resident"):
-        """The dominant kernel's time per env step, from HIP events on the launch stream around n back-to-back
-        dependent launches with nothing else in between (no resets, no redraws): graph replay / fused launches."""
+        """The dominant kernel's time per env step, from HIP events on the launch stream around back-to-back dependent
+        launches with nothing else in between (no resets, no redraws): graph replay / fused launches.  Two bodies of n
+        and 2n launches are timed (best of 3 each) and the SLOPE (t_2n - t_n) / n is returned: what one more launch costs.
+        A single body's average also carries the replay's fixed cost (graph launch, first dispatch) -- 0.1-0.15 ms per
+        replay, i.e. +0.3-0.6 us on a 3 us kernel at n = 200, which is what made C2 / C3 read 15 % slower inside the
+        default run (n = 200) than in a process of their own (n = 400) in round 2 and early round 3."""
         roll = self.roll(protocol)
         roll.set_episode_len(0)
         try:
-            body = self.body("fused" if mode == "fused" else "graph", protocol, n)
-            body()
-            torch.cuda.synchronize()
-            best = None
-            for _ in range(3):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+            def best(m):
+                body = self.body("fused" if mode == "fused" else "graph", protocol, m)
                 body()
-                e1.record()
                 torch.cuda.synchronize()
-                us = e0.elapsed_time(e1) * 1e3 / n
-                best = us if best is None else min(best, us)
-            return best
+                t = None
+                for _ in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    body()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1)
+                    t = ms if t is None else min(t, ms)
+                return t
+            t1, t2 = best(n), best(2 * n)
+            self.last_kernel_timing = {"launches": [n, 2 * n], "ms": [t1, t2], "avg_us_single_body": t2 * 1e3 / (2 * n)}
+            return (t2 - t1) * 1e3 / n
         finally:
             roll.set_episode_len(self.EP)
 
@@ -419,29 +427,36 @@ def _abi_action_dim():
 
 
 def launch_floor_us(torch, dev, n=400):
-    """Empty-ish dependent launch: `mpe_episode_tick` on 64 worlds, n launches captured in a HIP graph."""
+    """Empty-ish dependent launch: `mpe_episode_tick` on 64 worlds; graphs of n and 2n launches, slope per launch."""
     from multiagent_particle_envs_amd import _abi
     L = _abi.lib()
     cnt = torch.zeros(64, dtype=torch.int32, device=dev)
     done = torch.zeros((1, 64), dtype=torch.bool, device=dev)
-    s = torch.cuda.Stream(device=dev)
-    s.wait_stream(torch.cuda.current_stream(dev))
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.stream(s):
-        L.mpe_episode_tick(cnt.data_ptr(), done.data_ptr(), 1, 64, 0, 0, _abi.raw_stream(dev))
+
+    def timed(m):
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            L.mpe_episode_tick(cnt.data_ptr(), done.data_ptr(), 1, 64, 0, 0, _abi.raw_stream(dev))
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                for _ in range(m):
+                    L.mpe_episode_tick(cnt.data_ptr(), done.data_ptr(), 1, 64, 0, 0, _abi.raw_stream(dev))
+        torch.cuda.current_stream(dev).wait_stream(s)
+        g.replay()
         torch.cuda.synchronize()
-        with torch.cuda.graph(g, stream=s):
-            for _ in range(n):
-                L.mpe_episode_tick(cnt.data_ptr(), done.data_ptr(), 1, 64, 0, 0, _abi.raw_stream(dev))
-    torch.cuda.current_stream(dev).wait_stream(s)
-    g.replay()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    g.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / n
+        best = None
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+        return best
+    return (timed(2 * n) - timed(n)) * 1e3 / n
 
 
 def copy_ceiling_gbs(torch, dev):
@@ -475,7 +490,7 @@ def fill_ceiling_gbs(torch, dev):
     return 5 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def roofline_entry(leg, k_us, B, mode, floor_us):
+def roofline_entry(leg, k_us, B, mode, floor_us, timing=None):
     obs_total, bytes_step, compulsory_roll, kname = leg.geometry()
     per_launch = bytes_step * B
     achieved = per_launch / (k_us * 1e-6) / 1e9
@@ -492,6 +507,7 @@ def roofline_entry(leg, k_us, B, mode, floor_us):
             "l3_resident": resident,
             "algorithmic_bytes_per_env_step": bytes_step, "algorithmic_bytes_per_launch": per_launch,
             "kernel": kname, "kernel_us_per_launch": k_us, "env_steps_per_launch": B,
+            "kernel_timing": timing,
             "launch_floor_us": floor_us}
 
 
@@ -637,6 +653,7 @@ def main():
 
     dt, R, ev_ms, rate = leg.timed(torch, rv, dev, args.mode, args.protocol, K, W, args.repeats, args.region_ms)
     k_us = leg.kernel_time_us(torch, args.mode)
+    head_timing = leg.last_kernel_timing
     head_probe = leg.env.placement_probe
     floor_us = launch_floor_us(torch, dev)
     extra = {}
@@ -698,7 +715,7 @@ def main():
             "value": B * nh / dth, "unit": "env-steps/s", "ms_per_step": dth * 1e3 / nh,
             "pcie_bytes_per_env_step": io_bytes, "pcie_GBps": B * nh * io_bytes / dth / 1e9}
 
-    headline_roof = roofline_entry(leg, k_us, B, args.mode, floor_us)
+    headline_roof = roofline_entry(leg, k_us, B, args.mode, floor_us, head_timing)
     default_line = solo and args.scenario == "simple_spread" and args.agents == 3 and B == 65536
     if default_line:
         leg.release()
@@ -707,7 +724,7 @@ def main():
         big = Leg(mpe, "simple_spread", 3, 1 << 20, EP, rank, 1, args.seed)
         dtb, Rb, _, rb_ = big.timed(torch, rv, dev, "graph", "fresh", 25, 5, 5, 2 * SR)
         kb = big.kernel_time_us(torch, "graph", n=100)
-        rb = roofline_entry(big, kb, 1 << 20, "graph", floor_us)
+        rb = roofline_entry(big, kb, 1 << 20, "graph", floor_us, big.last_kernel_timing)
         extra["hbm_resident"] = {"what": "simple_spread N=3 at 1048576 worlds (431 MB per launch, 2 GB of moves per episode): "
                                          "same kernel, same protocol, HBM-resident",
                                  "value": (1 << 20) * 25 * Rb / dtb, "unit": "env-steps/s", "repeats": stats(rb_),
@@ -723,9 +740,10 @@ def main():
             lg = Leg(mpe, scn, ag, bb, EP, rank, 1, args.seed)
             d1, R1, _, r1_ = lg.timed(torch, rv, dev, "graph", "fresh", kk, 10, 5, 2 * SR)
             k1 = lg.kernel_time_us(torch, "graph", n=200 if bb * ag < 100000 else 100)
+            t1_ = lg.last_kernel_timing
             ent = {"value": bb * kk * R1 / d1, "unit": "env-steps/s", "ms_per_step": d1 * 1e3 / (kk * R1), "repeats": stats(r1_),
                    "timed_steps": kk * R1, "placement_probe": lg.env.placement_probe,
-                   "workload": "%s A=%d L=%d, %d worlds" % (scn, lg.A, lg.Lm, bb), "roofline": roofline_entry(lg, k1, bb, "graph", floor_us)}
+                   "workload": "%s A=%d L=%d, %d worlds" % (scn, lg.A, lg.Lm, bb), "roofline": roofline_entry(lg, k1, bb, "graph", floor_us, t1_)}
             d2, R2, _, r2_ = lg.timed(torch, rv, dev, "fused", "resident", kk, 10, 5, SR)
             k2 = lg.kernel_time_us(torch, "fused", n=200 if bb * ag < 100000 else 100)
             comp = lg.geometry()[2]
@@ -751,16 +769,16 @@ def main():
                                     "frac_of_measured_fill": ent["roofline"]["achieved"] / fill_gbs})
         if world > 1:   # the per-GPU roofline of an N-GPU job is the SLOWEST rank's kernel (every rank runs the same launch)
             k_slow = max(r["kernel_us_per_launch"] for r in recs)
-            headline_roof = roofline_entry(leg, k_slow, B, args.mode, floor_us)
+            headline_roof = roofline_entry(leg, k_slow, B, args.mode, floor_us, head_timing)
             headline_roof["per_gpu"] = True
             headline_roof["kernel_us_per_launch_by_rank"] = [r["kernel_us_per_launch"] for r in recs]
         headline_roof.update({
             "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": headline_roof["achieved"] / copy_gbs,
             "measured_fill_GBps": fill_gbs,
             "timed_region_us_per_step": ev_ms * 1e3 / (K * R),
-            "note": "achieved = algorithmic bytes per launch / kernel_us_per_launch; kernel_us_per_launch = HIP-event time "
-                    "(launch stream) of 400 back-to-back dependent step launches / 400, best of 3 (the rocprofv3 kernel-trace "
-                    "summary of the same command is under profiles/); launch_floor_us = the same for a 64-world bookkeeping "
+            "note": "achieved = algorithmic bytes per launch / kernel_us_per_launch; kernel_us_per_launch = (HIP-event time of 2n "
+                    "back-to-back dependent step launches - that of n) / n on the launch stream, best of 3 each, n = 400 (the "
+                    "rocprofv3 kernel-trace summary of the same command is under profiles/); launch_floor_us = the same for a 64-world bookkeeping "
                     "kernel; timed_region_us_per_step = HIP-event time of the timed region / timed_steps and "
                     "includes the per-episode reset and move-draw launches"})
         out = {

@@ -180,6 +180,34 @@ class EntityChoice(object):
         return self._world.constant(sizes)[self.index.long()]
 
 
+def _i64(x):
+    """A 64-bit pattern as the signed value torch.int64 holds."""
+    x &= (1 << 64) - 1
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def _mix64(z):
+    """SplitMix64's finaliser on int64 tensors (wrapping multiplies, logical shifts spelled out)."""
+    z = (z ^ ((z >> 30) & ((1 << 34) - 1))) * _i64(0xBF58476D1CE4E5B9)
+    z = (z ^ ((z >> 27) & ((1 << 37) - 1))) * _i64(0x94D049BB133111EB)
+    return z ^ ((z >> 31) & ((1 << 33) - 1))
+
+
+def counter_randn(seed, world_offset, draw, shape, device):
+    """[B, k] standard normals as a pure function of (seed, global world index, draw number, column): Box-Muller over
+    two 24-bit uniforms hashed from those four numbers.  Shard-invariant by construction."""
+    B, k = int(shape[0]), int(shape[1]) if len(shape) > 1 else 1
+    w = torch.arange(B, dtype=torch.int64, device=device).unsqueeze(1) + int(world_offset)
+    j = torch.arange(k, dtype=torch.int64, device=device).unsqueeze(0)
+    x = w * _i64(0x9E3779B97F4A7C15) + j * _i64(0xD1B54A32D192ED03) + _i64(seed * 0xA0761D6478BD642F + draw * 0xE7037ED1A0B428DB)
+    h1 = _mix64(x + _i64(0x9E3779B97F4A7C15))
+    h2 = _mix64(h1 + _i64(0x9E3779B97F4A7C15))
+    u1 = (((h1 >> 40) & 0xFFFFFF).to(torch.float32) + 1.0) * (1.0 / 16777216.0)     # (0, 1]
+    u2 = ((h2 >> 40) & 0xFFFFFF).to(torch.float32) * (1.0 / 16777216.0)             # [0, 1)
+    n = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(6.283185307179586 * u2)
+    return n.reshape(shape)
+
+
 class World(object):
     """B particle worlds stepped in lock-step (reference: core.py:82-196 for one world)."""
 
@@ -446,18 +474,16 @@ class World(object):
         """Standard-normal noise for u_noise / c_noise (core.py:138,176).  rng_mode 'numpy' (reference-compatibility):
         drawn from the process-global np.random in the reference's order (agents in order: the u draws before the
         physics, the c draws after), so `np.random.seed(s)` reproduces the reference's noisy trajectories and leaves
-        the stream where the reference leaves it for the next reset.  rng_mode 'device': a torch generator keyed by
-        (world.seed, world.world_offset) -- reproducible per shard, independent of torch's global generator."""
+        the stream where the reference leaves it for the next reset.  rng_mode 'device': counter-based like the resets
+        and the synthetic moves -- the value for (seed, GLOBAL world, draw number, element) is a hash of exactly those,
+        so a batch sharded over several GPUs (world_offset) draws what one big batch would, whatever the shard sizes;
+        independent of torch's global generator."""
         if self.rng_mode == "numpy":
             import numpy as np
             return torch.as_tensor(np.random.randn(*shape), dtype=torch.float32).to(self.device)
-        g = self.__dict__.get("_noise_gen")
-        key = (int(self.seed), int(self.world_offset), str(self.device))
-        if g is None or self.__dict__.get("_noise_key") != key:
-            g = torch.Generator(device=self.device)
-            g.manual_seed((int(self.seed) * 0x9E3779B97F4A7C15 + int(self.world_offset) + 0x5EED) & (2 ** 63 - 1))
-            self.__dict__["_noise_gen"], self.__dict__["_noise_key"] = g, key
-        return torch.randn(tuple(shape), generator=g, dtype=torch.float32, device=self.device)
+        draw = self.__dict__.get("_noise_draw", 0)
+        self.__dict__["_noise_draw"] = draw + 1
+        return counter_randn(int(self.seed), int(self.world_offset), draw, tuple(shape), self.device)
 
     # ---- World.step (core.py:117-131) -----------------------------------------------------------
     def step(self):

@@ -210,3 +210,20 @@ def test_header_is_plain_c_and_a_c_program_can_call_the_library(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout, r.stderr)
+
+
+def test_device_mode_noise_is_a_function_of_the_global_world_index():
+    """u_noise / c_noise in batched mode (core.py:138,176 draw Gaussian noise inside World.step): counter-based, keyed by
+    (seed, global world, draw number, column) -- shards of any sizes draw exactly the rows of one big batch, successive
+    draws differ, and the numbers are standard normal."""
+    import torch
+    from multiagent_particle_envs_amd.core import counter_randn
+    full = counter_randn(9, 0, 2, (1000, 2), "cpu")
+    for off, cnt in ((0, 300), (300, 500), (800, 200)):
+        assert torch.equal(counter_randn(9, off, 2, (cnt, 2), "cpu"), full[off:off + cnt])
+    other = counter_randn(9, 0, 3, (1000, 2), "cpu")
+    assert not torch.equal(other, full) and not torch.equal(counter_randn(10, 0, 2, (1000, 2), "cpu"), full)
+    x = counter_randn(1, 0, 0, (200000, 4), "cpu")
+    assert abs(float(x.mean())) < 0.01 and abs(float(x.std()) - 1.0) < 0.01
+    assert abs(float((x[:, 0] * x[:, 1]).mean())) < 0.01 and abs(float((x[:-1, 0] * x[1:, 0]).mean())) < 0.01
+    assert abs(float((x.abs() > 1.959964).float().mean()) - 0.05) < 0.003
