@@ -29,7 +29,8 @@ Besides the headline the line carries (N=1 only):
                        Cache: the limit there is launch + latency, and the line says so.
   extra.hbm_resident   the same kernel and protocol at B=1048576 (431 MB per launch: beyond the Infinity Cache)
   extra.configs        BASELINE.json's other single-GPU configs: C2 spread N=3 B=4096, C3 simple_tag B=16384,
-                       C4 spread N=64 B=4096 -- each with its own roofline entry and min / median / max over 5 repeats
+                       C4 spread N=64 B=4096 -- each measured in a process of its own (as a user of that config would),
+                       with its own roofline entry and min / median / max over 5 repeats
   extra.fused_rollout  `mpe_rollout_random`: one launch per episode, state on chip, moves drawn in-kernel
   extra.moves_resident the round-1 headline: moves read from a resident ring that is never redrawn
   extra.box            which GPU / clocks / power cap / partition modes / driver this line was measured on
@@ -511,6 +512,54 @@ def roofline_entry(leg, k_us, B, mode, floor_us, timing=None):
             "launch_floor_us": floor_us}
 
 
+CONFIG_LEGS = (("C2_spread_n3_B4096", "simple_spread", 3, 4096, 200),
+               ("C3_tag_B16384", "simple_tag", 3, 16384, 200),
+               ("C4_spread_n64_B4096", "simple_spread", 64, 4096, 50))
+
+
+def run_config_leg(key, floor_us, seed, EP, dev_index):
+    """One of BASELINE.json's other single-GPU configs, measured in this (fresh) process -> the entry of extra.configs."""
+    import torch
+    import multiagent_particle_envs_amd as mpe
+    from multiagent_particle_envs_amd import sharding
+    _, scn, ag, bb, kk = [c for c in CONFIG_LEGS if c[0] == key][0]
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    rv = sharding.Rendezvous(0, 1, dev)
+    SR = SIDE_REGION_MS
+
+    def stats(rate):
+        return {"min": rate[0], "median": rate[1], "max": rate[2], "unit": "env-steps/s per GPU"}
+    lg = Leg(mpe, scn, ag, bb, EP, 0, 1, seed)
+    d1, R1, _, r1_ = lg.timed(torch, rv, dev, "graph", "fresh", kk, 10, 5, 2 * SR)
+    k1 = lg.kernel_time_us(torch, "graph", n=400 if bb * ag < 100000 else 100)
+    t1_ = lg.last_kernel_timing
+    ent = {"value": bb * kk * R1 / d1, "unit": "env-steps/s", "ms_per_step": d1 * 1e3 / (kk * R1), "repeats": stats(r1_),
+           "timed_steps": kk * R1, "placement_probe": lg.env.placement_probe, "measured_in": "a process of its own",
+           "workload": "%s A=%d L=%d, %d worlds" % (scn, lg.A, lg.Lm, bb), "roofline": roofline_entry(lg, k1, bb, "graph", floor_us, t1_)}
+    d2, R2, _, r2_ = lg.timed(torch, rv, dev, "fused", "resident", kk, 10, 5, SR)
+    k2 = lg.kernel_time_us(torch, "fused", n=400 if bb * ag < 100000 else 100)
+    comp = lg.geometry()[2]
+    ent["fused_rollout"] = {"value": bb * kk * R2 / d2, "unit": "env-steps/s", "kernel_us_per_step": k2, "repeats": stats(r2_),
+                            "compulsory_bytes_per_env_step": comp,
+                            "frac_compulsory": comp * bb / (k2 * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    return ent
+
+
+def config_leg_subprocess(key, args, floor_us, dev_index):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg-json", key, "--leg-floor-us", repr(float(floor_us)),
+                        "--seed", str(args.seed), "--episode-len", str(args.episode_len), "--leg-device", str(dev_index)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("config leg %s failed (exit %d): %s" % (key, r.returncode, r.stderr[-1500:]))
+    return json.loads(lines[-1])
+
+
 def box_fingerprint(torch, dev):
     """What this rank's GPU is and how the box is set up: device properties from the runtime, clocks / power cap /
     partition modes / driver from rocm-smi when it answers (C4's 20 % box-to-box spread, DESIGN 2.7, needs a label)."""
@@ -569,6 +618,9 @@ def parse_args(argv=None):
                          "rew to DIR/rank<r>.npz (the multi-rank rehearsal test compares them with one big batch)")
     ap.add_argument("--generic", action="store_true",
                     help="step through the generic path (torch callbacks + mpe_world_step) although a fused kernel exists")
+    ap.add_argument("--leg-json", default=None, help=argparse.SUPPRESS)      # internal: measure one config leg, print its entry
+    ap.add_argument("--leg-floor-us", type=float, default=0.0, help=argparse.SUPPRESS)
+    ap.add_argument("--leg-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--streams", type=int, default=1,
                     help="cut the per-GPU batch into this many independent sub-batches, one HIP stream each")
     return ap.parse_args(argv)
@@ -604,6 +656,9 @@ def launch_ranks(args):
 
 def main():
     args = parse_args()
+    if args.leg_json:
+        print(json.dumps(run_config_leg(args.leg_json, args.leg_floor_us, args.seed, args.episode_len, args.leg_device)))
+        return
     env_world = int(os.environ.get("WORLD_SIZE", "1") or "1")
     if args.gpus > 1 and env_world == 1:
         sys.exit(launch_ranks(args))
@@ -732,28 +787,13 @@ def main():
         big.release()
         del big
         torch.cuda.empty_cache()
-        # ---- BASELINE.json's other single-GPU configs ------------------------------------------------------------
+        # ---- BASELINE.json's other single-GPU configs, each in a process of its own ------------------------------------
+        # (a leg measured after the 1M leg in THIS process reads 15-25 % slower on the launch-bound configs than the same
+        #  leg in a fresh process -- 4.07-4.32 vs 3.45 us for C3, not thermal: a fresh process started right after this
+        #  run gives 3.45 again, profiles/r3_ab_logs.txt session 9 -- so each config gets what a user of that config gets)
         cfgs = {}
-        for key, scn, ag, bb, kk in (("C2_spread_n3_B4096", "simple_spread", 3, 4096, 200),
-                                     ("C3_tag_B16384", "simple_tag", 3, 16384, 200),
-                                     ("C4_spread_n64_B4096", "simple_spread", 64, 4096, 50)):
-            lg = Leg(mpe, scn, ag, bb, EP, rank, 1, args.seed)
-            d1, R1, _, r1_ = lg.timed(torch, rv, dev, "graph", "fresh", kk, 10, 5, 2 * SR)
-            k1 = lg.kernel_time_us(torch, "graph", n=200 if bb * ag < 100000 else 100)
-            t1_ = lg.last_kernel_timing
-            ent = {"value": bb * kk * R1 / d1, "unit": "env-steps/s", "ms_per_step": d1 * 1e3 / (kk * R1), "repeats": stats(r1_),
-                   "timed_steps": kk * R1, "placement_probe": lg.env.placement_probe,
-                   "workload": "%s A=%d L=%d, %d worlds" % (scn, lg.A, lg.Lm, bb), "roofline": roofline_entry(lg, k1, bb, "graph", floor_us, t1_)}
-            d2, R2, _, r2_ = lg.timed(torch, rv, dev, "fused", "resident", kk, 10, 5, SR)
-            k2 = lg.kernel_time_us(torch, "fused", n=200 if bb * ag < 100000 else 100)
-            comp = lg.geometry()[2]
-            ent["fused_rollout"] = {"value": bb * kk * R2 / d2, "unit": "env-steps/s", "kernel_us_per_step": k2, "repeats": stats(r2_),
-                                    "compulsory_bytes_per_env_step": comp,
-                                    "frac_compulsory": comp * bb / (k2 * 1e-6) / 1e9 / HBM_PEAK_GBS}
-            cfgs[key] = ent
-            lg.release()
-            del lg
-            torch.cuda.empty_cache()
+        for key, scn, ag, bb, kk in CONFIG_LEGS:
+            cfgs[key] = config_leg_subprocess(key, args, floor_us, local)
         extra["configs"] = cfgs
 
     # ---- per-rank records: which GPU each rank drove, its own rate and kernel time (gathered over the bookkeeping group) ----

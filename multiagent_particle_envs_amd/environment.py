@@ -290,7 +290,7 @@ class MultiAgentEnv(object):
 
     # observation blocks from this size on are placed by a timed probe (below)
     PROBE_MIN_BYTES = 128 << 20
-    PROBE_CANDIDATES = 8
+    PROBE_CANDIDATES = 16
 
     def _place_observation_buffers(self, n):
         """Observation buffers for the env's `n` output sets.  Small ones are plain allocations.  For LARGE row blocks
@@ -299,8 +299,9 @@ class MultiAgentEnv(object):
         same process, whatever the offset inside the buffer or the bits of its virtual address (profiles/
         r3_c4_placement_*.txt; the address-translation counters are flat, the L2's memory-side write stalls are DRAM-credit
         stalls: where the driver put the pages in HBM).  So a handful of candidates is allocated, the real step kernel is
-        timed on each (state and outputs in scratch copies: the world does not move), and the fastest `n` are kept.  Costs
-        a few milliseconds and PROBE_CANDIDATES x the block transiently, once per env; results do not depend on it."""
+        timed on each (state and outputs in scratch copies: the world does not move) until `n` of them take the rows at
+        < 1.2 x the time of a plain fill of the block (at most PROBE_CANDIDATES), and the fastest `n` are kept.  Costs a few
+        milliseconds and, transiently, that many blocks, once per env; results do not depend on it."""
         w = self.world
         nfl = int(self._obs_off[-1]) * w.batch_size
         if not self.probe_placement or not self.fused or nfl * 4 < self.PROBE_MIN_BYTES or \
@@ -326,15 +327,24 @@ class MultiAgentEnv(object):
             e1.record()
             e1.synchronize()
             return e0.elapsed_time(e1) / launches
+        # a plain fill of the block is placement-insensitive: buffers the step streams into at < 1.2 x that are "fast" ones
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        first.fill_(0.0)
+        e0.record()
+        for _ in range(4):
+            first.fill_(0.0)
+        e1.record()
+        e1.synchronize()
+        fill_ms = e0.elapsed_time(e1) / 4
         cands = [(timed(first), 0, first)]
         try:
-            for _ in range(self.PROBE_CANDIDATES - 1):
+            while len(cands) < self.PROBE_CANDIDATES and sum(1 for c in cands if c[0] < 1.2 * fill_ms) < n:
                 t = torch.zeros(nfl, dtype=torch.float32, device=dev)
                 cands.append((timed(t), len(cands), t))
         except torch.cuda.OutOfMemoryError:      # keep what fits
             pass
         cands.sort(key=lambda c: c[0])
-        self.placement_probe = {"candidates_ms": [round(c[0], 5) for c in cands], "kept": n}
+        self.placement_probe = {"candidates_ms": [round(c[0], 5) for c in cands], "kept": n, "fill_ms": round(fill_ms, 5)}
         keep = [c[2] for c in cands[:n]]
         while len(keep) < n:
             keep.append(None)
