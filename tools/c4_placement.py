@@ -21,8 +21,9 @@ from multiagent_particle_envs_amd.rollout import RandomRollout  # noqa: E402
 
 def main():
     K = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    brief = len(sys.argv) > 2 and sys.argv[2] == "brief"      # only the K separate allocations, one summary line
     N, B = 64, 4096
-    env = mpe.make_env("simple_spread", batch_size=B, num_agents=N, seed=0)
+    env = mpe.make_env("simple_spread", batch_size=B, num_agents=N, seed=0, probe_placement=False)
     rr = RandomRollout(env, episode_len=0, pool=4, regenerate=False)
     L = _abi.lib()
     st = _abi.raw_stream(env.world.device)
@@ -51,10 +52,17 @@ def main():
     for k in range(2):
         show("env output set %d" % k, env._sets[k].obs.data_ptr(), time_on(env._sets[k].obs.data_ptr()))
     keep = []
+    times = []
     for k in range(K):
         t = torch.empty(nfl, dtype=torch.float32, device=env.world.device)
         keep.append(t)
-        show("separate alloc %d" % k, t.data_ptr(), time_on(t.data_ptr()))
+        times.append(time_on(t.data_ptr()))
+        if not brief:
+            show("separate alloc %d" % k, t.data_ptr(), times[-1])
+    if brief:
+        tag = os.path.basename(os.environ.get("MPE_HIP_LIB", "base")).replace("libmpe_hip_ab_", "").replace(".so", "")
+        print("%-8s %d buffers, us per launch sorted: %s" % (tag, K, " ".join("%.1f" % x for x in sorted(times))), flush=True)
+        return
     for k in range(2):   # the same buffers again: is the time a property of the buffer?
         show("again: alloc %d" % k, keep[k].data_ptr(), time_on(keep[k].data_ptr()))
     del keep

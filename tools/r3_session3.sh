@@ -38,8 +38,12 @@ trace spread64_B4096 --agents 64 --batch 4096 --steps 50 --warmup 10
 trace spread3_B1M --batch 1048576 --steps 25 --warmup 5
 trace rollout_tag_B16384 --scenario simple_tag --batch 16384 --steps 200 --mode fused
 trace rollout_spread3_B4096 --batch 4096 --steps 200 --mode fused
-tools/pmc.sh ${TAG}_spread3_B4096 --batch 4096 > /dev/null 2>&1
-tools/pmc.sh ${TAG}_tag_B16384 --scenario simple_tag --batch 16384 > /dev/null 2>&1
+for cfg in "spread3_B4096 --batch 4096" "tag_B16384 --scenario simple_tag --batch 16384"; do
+  set -- $cfg; name=$1; shift
+  tools/pmc.sh ${TAG}_$name "$@" > /dev/null 2>&1
+  python profiles/pmc_summary.py $R/gpurun_out/pmc_${TAG}_$name k_split > $O/pmc_$name.txt 2>>$O/err.log
+  rm -rf $R/gpurun_out/pmc_${TAG}_$name        # (raw counter CSVs: tens of MB; the summary is what travels back)
+done
 for k in 1 2 3 4 5; do
   timeout 200 python bench.py --agents 64 --batch 4096 --steps 50 --warmup 10 --no-extra --no-cpu-baseline --region-ms 300 >> $O/c4_processes.jsonl 2>> $O/c4.err
 done
