@@ -191,8 +191,7 @@ __device__ __forceinline__ void emit_rows(const float2 *Q, const float2 *V, int 
 // arithmetic in the row loop beyond the broadcast read of (pos_i, vel_i) for the next row.
 template <int RP /* row-store policy (mpe_device.h): kRowsNt when a row is a whole number of lines, else kRowsPlain */>
 __device__ __forceinline__ void emit_rows_fast(const float2 *Q, const float2 *V, int A, int L, int D,
-                                               float *obs_w, size_t rowlen, int lane, int i_begin = 0, int i_end = -1,
-                                               int i_step = 1) {
+                                               float *obs_w, size_t rowlen, int lane, int i_begin = 0, int i_end = -1) {
   if (i_end < 0) i_end = A;
   const int E = A + L;
   const int P = D >> 2;             // 16-byte pieces per row, <= 128
@@ -214,10 +213,10 @@ __device__ __forceinline__ void emit_rows_fast(const float2 *Q, const float2 *V,
   const bool st0 = lane < P, st1 = lane + kWave < P;
   const bool tail0 = 2 * kWave > kpz;  // uniform: the first wave store already reaches the zero tail
   float2 me = Q[L + min(i_begin, A - 1)], vel = V[min(i_begin, A - 1)];
-  for (int i = i_begin; i < i_end; i += i_step) {
+  for (int i = i_begin; i < i_end; ++i) {
     const int thr = L + i;
     float *const row = obs_w + (size_t)i * rowlen;  // wave-uniform
-    const int inext = min(i + i_step, A - 1);
+    const int inext = min(i + 1, A - 1);
     const float2 me_n = Q[L + inext], vel_n = V[inext];  // next row's operands: in flight under this row
     {
       float4 o;
@@ -878,10 +877,6 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   const bool rows16 = (D & 3) == 0 && ((B * (size_t)D) & 3) == 0;
   if (role == 0) {
     if (wok && !(MPE_DUO_ABLATE & 4)) {
-#ifdef MPE_DUO_INTERLEAVE   // experiment: the two waves of a world write ADJACENT agent blocks (even / odd rows)
-      if (rows16 && d.rows_nt) emit_rows_fast<kRowsNt>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, A, 2);
-      else
-#endif
       if (rows16 && d.rows_nt) emit_rows_fast<kRowsNt>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
       else if (rows16) emit_rows_fast<kRowsPlain>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
       else        emit_rows<2>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
@@ -905,10 +900,6 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   if (!wok) return;
   if (!(MPE_DUO_ABLATE & 1)) duo_reward(d, b, Q, A, L, B, w, (size_t)lane * B + w, lane, collide);
   if (!(MPE_DUO_ABLATE & 4)) {
-#ifdef MPE_DUO_INTERLEAVE
-    if (rows16 && d.rows_nt) emit_rows_fast<kRowsNt>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 1, A, 2);
-    else
-#endif
     if (rows16 && d.rows_nt) emit_rows_fast<kRowsNt>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
     else if (rows16) emit_rows_fast<kRowsPlain>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
     else        emit_rows<2>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, split, A);
