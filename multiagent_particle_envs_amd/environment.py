@@ -304,8 +304,10 @@ class MultiAgentEnv(object):
         milliseconds and, transiently, that many blocks, once per env; results do not depend on it."""
         w = self.world
         nfl = int(self._obs_off[-1]) * w.batch_size
-        if not self.probe_placement or not self.fused or nfl * 4 < self.PROBE_MIN_BYTES or \
-                self._kind not in (_abi.MPE_SCN_SPREAD, _abi.MPE_SCN_TAG, _abi.MPE_SCN_SIMPLE):
+        # (only the wave-per-world kernels -- more than 16 entities, dozens of agent blocks written side by side -- are
+        #  placement-sensitive; the 1M-world N=3 step writes three contiguous 75 MB blocks and is not: 68-70 us anywhere)
+        if not self.probe_placement or not self.fused or nfl * 4 < self.PROBE_MIN_BYTES or len(w.entities) <= 16 or \
+                self._kind not in (_abi.MPE_SCN_SPREAD, _abi.MPE_SCN_TAG):
             return [None] * n
         dev = w.device
         first = torch.zeros(nfl, dtype=torch.float32, device=dev)
