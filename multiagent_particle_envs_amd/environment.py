@@ -495,7 +495,11 @@ class MultiAgentEnv(object):
                                                self._stream()), "mpe_episode_tick")
         if self.done_callback is not None and self.auto_reset:
             # a done_callback can end a world at ANY step: restart every world some agent (or the horizon) flagged,
-            # at every step, and restart its step counter too (the tick only clears it at the horizon)
+            # at every step, and restart its step counter too (the tick only clears it at the horizon).
+            # Cost, knowingly paid: a masked reset_callback, a comm fill and (the caller's) mpe_observe relaunch on EVERY
+            # step, whether or not a world finished -- skipping them when nothing finished would need the host to read a
+            # device flag (a synchronisation per step, which costs more than the three small launches it saves); the
+            # horizon-only path below knows on the host when a world CAN finish and skips them everywhere else.
             finished = done.any(dim=0)
             self.episode_step.masked_fill_(finished, 0)
             self.reset_callback(w, mask=finished)

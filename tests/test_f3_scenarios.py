@@ -405,9 +405,10 @@ def test_discrete_action_input_on_a_comm_scenario_matches_one_hot_rows():
 def test_action_noise_and_scripted_agents_on_the_generic_path():
     """core.py:119-120,138,176 (u_noise / c_noise: Gaussian noise on the applied force and the emitted word) and
     core.py:112-114,119-120 (agents with an action_callback are scripted: not policy agents, stepped by the world).
-    No shipped scenario sets them; they force the generic path.  In device mode the noise comes from a
-    generator keyed by (world.seed, world.world_offset) -- not torch's global one -- so a second world with the same
-    key re-draws the same normals, and torch.manual_seed does not move them."""
+    No shipped scenario sets them; they force the generic path.  In device mode the noise is counter-based
+    -- a hash of (world.seed, global world index, draw number, column), not torch's global generator -- so a second
+    world with the same seed re-draws the same normals draw by draw, torch.manual_seed does not move them, and another
+    shard (world_offset) draws different ones (shard invariance itself: tests/test_host_cpu.py)."""
     B = 257
     Base = mpe.scenarios.load("simple_speaker_listener.py").Scenario
     sc = Base()
