@@ -24,7 +24,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          # kernarg preload (gfx94x/gfx950): the CP writes the first dwords of the kernarg segment into user SGPRs at wave
          # launch; kernels whose leading arguments are scalars / pointers (k_split, the bookkeeping kernels) start their
          # global loads without a scalar round trip.  Kernels that begin with a by-value struct are unaffected.
-         "-mllvm", "-amdgpu-kernarg-preload-count=14"]
+         "-mllvm", "-amdgpu-kernarg-preload-count=14",
+         # keep the device assembly next to the objects (build/*-gfx950.s): tests/test_host_cpu.py reads the kernels' resource
+         # metadata from it -- a kernel that starts using scratch memory (private_segment_fixed_size > 0) fails the CPU suite
+         "-save-temps=obj"]
 
 
 STRESS_SOURCES = ("split", "wide")
@@ -96,7 +99,8 @@ def build(force=False, verbose=True, variants=True):
         vo = {}
         for stem in STRESS_SOURCES:      # the kernel files that carry MPE_STRESS_* hooks
             src = os.path.join(CSRC, "mpe_%s.hip" % stem)
-            o = os.path.join(OBJ, "mpe_%s_%s.o" % (stem, tag))
+            os.makedirs(os.path.join(OBJ, tag), exist_ok=True)     # own directory: -save-temps names its files after the source
+            o = os.path.join(OBJ, tag, "mpe_%s.o" % stem)
             vo["mpe_%s.o" % stem] = o
             if force or _stale(o, [src] + hdrs):
                 jobs.append([hipcc] + FLAGS + defs + ["-c", src, "-o", o])

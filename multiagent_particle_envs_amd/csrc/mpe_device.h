@@ -205,11 +205,23 @@ __device__ __forceinline__ void fetch_action_wave(const MpeBuffers &b, size_t B,
 // position of the landmark world-local index g picks (agent.goal_a = np.random.choice(world.landmarks))
 template <int A, int L>
 __device__ __forceinline__ void goal_pos(const float (&px)[A + L], const float (&py)[A + L], int g, float &gx, float &gy) {
-  gx = px[A];
-  gy = py[A];
+  // the candidates as VALUES first (an empty asm each): a chain of `if (g == l) gx = px[A + l]` over three or more
+  // landmarks is otherwise turned into a phi of POINTERS into px / py, which keeps both arrays (and what is declared next
+  // to them) in scratch memory -- seen on the two 3-landmark communication kernels, 48 bytes and a dozen scratch loads
+  float cx[L], cy[L];
 #pragma unroll
-  for (int l = 1; l < L; ++l)
-    if (g == l) { gx = px[A + l]; gy = py[A + l]; }
+  for (int l = 0; l < L; ++l) {
+    cx[l] = px[A + l];
+    cy[l] = py[A + l];
+    asm volatile("" : "+v"(cx[l]), "+v"(cy[l]));
+  }
+  gx = cx[0];
+  gy = cy[0];
+#pragma unroll
+  for (int l = 1; l < L; ++l) {
+    gx = g == l ? cx[l] : gx;
+    gy = g == l ? cy[l] : gy;
+  }
 }
 
 // simple_tag.py:103-108
