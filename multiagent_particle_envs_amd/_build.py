@@ -53,6 +53,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _drop_temps(d):
+    """-save-temps leaves ~25 MB of intermediates per source; only the device assembly (*-gfx950.s) is wanted."""
+    import glob
+    for pat in ("*.bc", "*.hipi", "*.out", "*.resolution.txt", "*.hipfb", "*-host-*.s", "*-gfx950.o"):
+        for f in glob.glob(os.path.join(d, pat)):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+
+
 def build(force=False, verbose=True, variants=True):
     """Compile and link libmpe_hip.so; with `variants` also the two test-only stress builds (tests/test_gpu_race.py).
     The product library is linked FIRST and is what decides staleness on its own: a box that holds only libmpe_hip.so
@@ -88,6 +99,7 @@ def build(force=False, verbose=True, variants=True):
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    _drop_temps(OBJ)
     if not variants:
         return LIB
     # ---- test-only variants of the role-split kernels (tests/test_gpu_race.py): one wave of every workgroup is held back
@@ -107,6 +119,8 @@ def build(force=False, verbose=True, variants=True):
         todo.append((tag, vo))
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
+    for tag in STRESS_VARIANTS:
+        _drop_temps(os.path.join(OBJ, tag))
     for tag, vo in todo:
         vlib = variant_lib(tag)
         vobjs = [vo.get(os.path.basename(x), x) for x in objs]
