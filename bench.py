@@ -224,12 +224,13 @@ def bench_generic(args, env, dev, rank, world, rv):
 class Leg(object):
     """One workload (scenario, sizes, batch) on this rank's GPU: env(s), rollout driver, measurements."""
 
-    def __init__(self, mpe, scenario, agents, B, EP, rank, streams=1, seed=0, generic=False):
+    def __init__(self, mpe, scenario, agents, B, EP, rank, streams=1, seed=0, generic=False, scenario_kw=None):
         from multiagent_particle_envs_amd.rollout import RandomRollout, StreamedRollout
         self.kw, self.okw = {}, {}
         if scenario == "simple_spread" and agents != 3:
             self.kw["num_agents"] = agents
             self.okw["n"] = agents
+        self.kw.update(scenario_kw or {})               # (tools/ab_kernels.py: team sizes of the other scenarios)
         self.scenario, self.B, self.EP, self.S = scenario, B, EP, max(1, streams)
         assert B % self.S == 0, "--batch must be a multiple of --streams"
         self.envs = []

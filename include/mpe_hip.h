@@ -194,9 +194,12 @@ int mpe_random_comm(float *comm, int32_t n_agents, int64_t B, int32_t dim_c, uin
 /* 1 when mpe_step / mpe_observe have a fused kernel for this descriptor (kind, agent / landmark /
  * adversary counts, dim_c), 0 when the caller must keep Scenario.observation / reward itself and
  * use mpe_world_step (a user Scenario: kind GENERIC), < 0 on an invalid descriptor or one no fused
- * kernel can take (MPE_EUNSUPPORTED: the communication scenarios at other than the reference's shapes,
- * a built-in scenario with a movable landmark).  simple_spread and simple_tag are fused at every size
- * and every team split up to MPE_MAX_ENTITIES entities.                                          */
+ * kernel can take (MPE_EUNSUPPORTED: simple_speaker_listener / simple_reference / simple_crypto at other
+ * than the reference's shapes, simple_world_comm with other than its one obstacle, two food items and
+ * two forests, a built-in scenario with a movable landmark).  simple_spread and simple_tag are fused at
+ * every size and every team split up to MPE_MAX_ENTITIES entities; simple_adversary and simple_world_comm
+ * at the reference's team sizes and a table of others (csrc/mpe_split.hip, kSplitTable: 2-6 agents with
+ * 1-2 adversaries; 1-3 good agents with 2-5 adversaries), 0 beyond it.                                */
 int mpe_step_supported(const MpeScenarioDesc *desc);
 
 /* Episode bookkeeping -- NEW API, no reference counterpart: `done` is always False in the reference

@@ -47,12 +47,15 @@ int check_desc(const MpeScenarioDesc *d, const char *what) {
     if ((e < d->n_agents || d->movable[e]) && !(d->mass[e] > 0.f)) return fail(MPE_EINVAL, "%s: mass[%d] must be > 0", what, e);
   const bool teams = d->kind == MPE_SCN_TAG || d->kind == MPE_SCN_ADVERSARY || d->kind == MPE_SCN_PUSH ||
                      d->kind == MPE_SCN_WORLD_COMM;
-  // the communication scenarios exist in the reference's shapes only
+  // the communication scenarios exist in the reference's shapes only -- except simple_world_comm's team sizes, which its
+  // callbacks leave open (simple_world_comm.py:126-289 loop over good_agents / adversaries): one obstacle, two food items
+  // and two forests as in its make_world (the observation reads forests[0] and [1] by index, :241-248), any A and
+  // n_adversaries that mpe_split.hip has an entry for (A = 0 below: not checked here)
   struct Shape { int kind, A, L, dim_c, n_choices, nadv; };
   static const Shape kComm[] = {{MPE_SCN_SPEAKER_LISTENER, 2, 3, 3, 1, 0}, {MPE_SCN_REFERENCE, 2, 3, 10, 2, 0},
-                                {MPE_SCN_CRYPTO, 3, 2, 4, 2, 1}, {MPE_SCN_WORLD_COMM, 6, 5, 4, 0, 4}};
+                                {MPE_SCN_CRYPTO, 3, 2, 4, 2, 1}, {MPE_SCN_WORLD_COMM, 0, 5, 4, 0, 0}};
   for (const Shape &sh : kComm)
-    if (d->kind == sh.kind && (d->n_agents != sh.A || d->n_landmarks != sh.L || d->dim_c != sh.dim_c ||
+    if (d->kind == sh.kind && ((sh.A && d->n_agents != sh.A) || d->n_landmarks != sh.L || d->dim_c != sh.dim_c ||
                                d->n_choices != sh.n_choices || (sh.nadv && d->n_adversaries != sh.nadv)))
       return fail(MPE_EUNSUPPORTED, "%s: kind %d is built for A=%d L=%d dim_c=%d n_choices=%d (got A=%d L=%d dim_c=%d n_choices=%d)",
                   what, sh.kind, sh.A, sh.L, sh.dim_c, sh.n_choices, d->n_agents, d->n_landmarks, d->dim_c, d->n_choices);

@@ -1115,6 +1115,15 @@ static const SplitEntry kSplitTable[] = {
     MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 3, 2, 1), MPE_SPLIT_ENTRY(MPE_SCN_PUSH, 2, 2, 1),
     MPE_SPLIT_ENTRY(MPE_SCN_SPEAKER_LISTENER, 2, 3, 0), MPE_SPLIT_ENTRY(MPE_SCN_REFERENCE, 2, 3, 0),
     MPE_SPLIT_ENTRY(MPE_SCN_CRYPTO, 3, 2, 1), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 6, 5, 4),
+    // Team sizes other than the reference's make_world, where its callbacks are written for any (simple_adversary.py:69-139
+    // over good_agents / adversaries lists with num_landmarks = num_agents - 1; simple_world_comm.py:126-289 likewise, with
+    // its one obstacle, two food items and two forests): A, L, n_adversaries
+    MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 2, 1, 1), MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 4, 3, 1),
+    MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 4, 3, 2), MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 5, 4, 1),
+    MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 6, 5, 2),
+    MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 3, 5, 2), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 4, 5, 2),
+    MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 4, 5, 3), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 5, 5, 3),
+    MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 8, 5, 5),
 };
 
 static const SplitEntry *find_split(int kind, int A, int L, int nadv) {

@@ -149,7 +149,7 @@ class MultiAgentEnv(object):
             getattr(reset_callback, "__self__", None) is sc and is_builtin(observation_callback, "observation") and \
             len(world.scripted_agents) == 0 and not any(l.movable for l in world.landmarks) and \
             all((a.silent or (kind in _abi.COMM_KINDS and not a.c_noise)) and not a.u_noise for a in world.agents)
-        if own:   # ... and a kernel for this shape (the f3 scenarios are fused at the reference's team sizes)
+        if own:   # ... and a kernel for this shape (mpe_split.hip's table: the reference's team sizes and some others)
             own = _abi.lib().mpe_step_supported(C.byref(world.scenario_desc(kind, getattr(sc, "num_adversaries", 0)))) == 1
         self._py_reward = own and not is_builtin(reward_callback, "reward")
         self._py_info = own and info_callback is not None and not (

@@ -13,10 +13,13 @@ class Scenario(BaseScenario):
     num_adversaries = 4
     landmark_range = 0.9                           # simple_world_comm.py:104-113
 
-    def make_world(self, batch_size=1, device=None):
+    def make_world(self, batch_size=1, device=None, num_good_agents=2, num_adversaries=4):
+        """The reference's world (2 prey, 4 predators) by default.  Its callbacks are written for any team sizes
+        (good_agents / adversaries lists, simple_world_comm.py:126-289), so those are arguments here; the obstacle, the
+        two food items and the two forests stay (the observation reads forests[0] and forests[1] by index, :241-248)."""
         world = World(batch_size, device)          # simple_world_comm.py:7-61
         world.dim_c = 4
-        num_good_agents, num_adversaries = 2, 4
+        self.num_adversaries = num_adversaries
         num_agents = num_adversaries + num_good_agents
         num_landmarks, num_food, num_forests = 1, 2, 2
         world.agents = [Agent() for _ in range(num_agents)]

@@ -115,11 +115,13 @@ def simple_tag(n_adversaries=3, n_good=1, n_landmarks=2):
                 adversary=adv, landmark_range=0.9)
 
 
-def simple_adversary():
-    # 1 adversary + 2 good agents (size .15, nobody collides), 2 landmarks (size .08); one goal landmark per world
-    return Spec("simple_adversary", 3, 2, 2,
-                size=[0.15] * 3 + [0.08] * 2, movable=[True] * 3 + [False] * 2, collide=[False] * 5,
-                accel=[None] * 3, max_speed=[None] * 3, adversary=[True, False, False], choice_pops=[2])
+def simple_adversary(n_agents=3, n_adversaries=1):
+    # n_adversaries adversaries first, then the good agents (size .15, nobody collides), n_agents - 1 landmarks (size .08);
+    # one goal landmark per world (reference make_world: 3 agents, 1 adversary)
+    A, L = n_agents, n_agents - 1
+    return Spec("simple_adversary", A, L, 2,
+                size=[0.15] * A + [0.08] * L, movable=[True] * A + [False] * L, collide=[False] * (A + L),
+                accel=[None] * A, max_speed=[None] * A, adversary=[i < n_adversaries for i in range(A)], choice_pops=[L])
 
 
 def simple_push():
@@ -153,15 +155,17 @@ def simple_crypto():
                 silent=[False] * 3, choice_pops=[2, 2])
 
 
-def simple_world_comm():
-    # 4 adversaries (agent 0 the speaking leader) + 2 good agents; landmarks = [obstacle] + 2 food + 2 forests
-    adv = [True] * 4 + [False] * 2
-    return Spec("simple_world_comm", 6, 5, 4,
+def simple_world_comm(n_good=2, n_adversaries=4):
+    # n_adversaries adversaries (agent 0 the speaking leader) + n_good good agents; landmarks = [obstacle] + 2 food + 2 forests
+    # (reference make_world: 4 + 2)
+    A = n_good + n_adversaries
+    adv = [True] * n_adversaries + [False] * n_good
+    return Spec("simple_world_comm", A, 5, 4,
                 size=[0.075 if a else 0.045 for a in adv] + [0.2, 0.03, 0.03, 0.3, 0.3],
-                movable=[True] * 6 + [False] * 5,
-                collide=[True] * 6 + [True, False, False, False, False],
+                movable=[True] * A + [False] * 5,
+                collide=[True] * A + [True, False, False, False, False],
                 accel=[3.0 if a else 4.0 for a in adv], max_speed=[1.0 if a else 1.3 for a in adv],
-                adversary=adv, silent=[False] + [True] * 5, landmark_range=0.9)
+                adversary=adv, silent=[False] + [True] * (A - 1), landmark_range=0.9)
 
 
 def by_name(name, **kw):

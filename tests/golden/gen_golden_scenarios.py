@@ -79,18 +79,20 @@ def stage_world(name, w, world, rng):
         return False
     k = w % 8
     disk = lambda r: (lambda th, rr: rr * np.array([np.cos(th), np.sin(th)]))(rng.uniform(0, 2 * np.pi), r * np.sqrt(rng.uniform(0, 1)))
+    good = [a for a in ag if not a.adversary]
+    advs = [a for a in ag if a.adversary]
     if k == 2:
-        for a in ag[4:]:
+        for a in good:
             p = a.state.p_pos.copy()
             p[rng.randint(0, 2)] = rng.choice([-1, 1]) * rng.uniform(0.88, 1.15)
             a.state.p_pos = p
     elif k == 4:
-        for j, a in enumerate(ag[4:]):
+        for j, a in enumerate(good):
             a.state.p_pos = world.food[j % 2].state.p_pos + disk(0.07)
     elif k in (3, 5, 7):
         if k != 5:
-            for a in ag[4:]:
-                a.state.p_pos = ag[rng.randint(0, 4)].state.p_pos + disk(0.13)
+            for a in good:
+                a.state.p_pos = advs[rng.randint(0, len(advs))].state.p_pos + disk(0.13)
         if k != 3:
             for a in ag:
                 a.state.p_vel = rng.uniform(-1.5, 1.5, 2)
@@ -102,9 +104,9 @@ def stage_world(name, w, world, rng):
     return True
 
 
-def record(name, seeds, T, squeeze_every=0, squeeze=0.3, customise=None, stage=False):
+def record(name, seeds, T, squeeze_every=0, squeeze=0.3, customise=None, stage=False, env_factory=None):
     bench = name in ("simple_adversary", "simple_world_comm")   # benchmark_data as the info callback (make_env.py:36-43)
-    env = make_env(name, benchmark=bench)
+    env = env_factory(bench) if env_factory else make_env(name, benchmark=bench)   # (gen_golden_shapes.py: other team sizes)
     world = env.world
     consts = customise(env) if customise else {}     # gen_golden_custom.py: entity / world constants changed after make_world
     A, W, E = env.n, len(seeds), len(world.entities)
@@ -151,10 +153,12 @@ def record(name, seeds, T, squeeze_every=0, squeeze=0.3, customise=None, stage=F
                 inf = info["n"]
                 if name == "simple_adversary":
                     if "info_adv" not in out:
-                        out["info_adv"] = np.zeros((T, W, 1))
-                        out["info_good"] = np.zeros((T, W, A - 1, len(world.landmarks) + 1))
-                    out["info_adv"][t, w, 0] = inf[0]
-                    out["info_good"][t, w] = np.array([list(x) for x in inf[1:]])
+                        nadv = sum(1 for a in env.agents if a.adversary)
+                        out["info_adv"] = np.zeros((T, W, nadv))
+                        out["info_good"] = np.zeros((T, W, A - nadv, len(world.landmarks) + 1))
+                    nadv = sum(1 for a in env.agents if a.adversary)
+                    out["info_adv"][t, w, :] = inf[:nadv]
+                    out["info_good"][t, w] = np.array([list(x) for x in inf[nadv:]])
                 else:
                     if "info_collisions" not in out:
                         out["info_collisions"] = np.zeros((T, W, A), np.int32)

@@ -135,9 +135,14 @@ FUSED_ROLLOUT = ["simple_adversary", "simple_push"]
                          ids=[n + "-generic" for n in NAMES] + [n + "-fused" for n in FUSED])
 def test_step_teacher_forced_against_reference_golden(name, fused, golden):
     g = golden("f3_" + name)
-    W, T = len(g["seeds"]), g["rew"].shape[0]
-    env = mpe.make_env(name, batch_size=W, fused=fused)
+    env = mpe.make_env(name, batch_size=len(g["seeds"]), fused=fused)
     assert env.fused == fused
+    print("max scaled err %s: %.3e" % (name, teacher_forced_against_golden(env, g)))
+
+
+def teacher_forced_against_golden(env, g):
+    """Every recorded step from the reference's own pre-step state: pos / vel / obs / reward / comm state at 1e-5."""
+    W, T = len(g["seeds"]), g["rew"].shape[0]
     A = env.n
     set_choices(env, g["choice"])
     worst = 0.0
@@ -157,7 +162,7 @@ def test_step_teacher_forced_against_reference_golden(name, fused, golden):
             worst = max(worst, close(np_(rew_n[i]) * np.ones(W), g["rew"][t][:, i], what="t=%d rew%d" % (t, i)))
             worst = max(worst, close(np_(env.world.agents[i].state.c), g["c%d" % i][t], what="t=%d c%d" % (t, i)))
             assert not np_(done_n[i]).any()
-    print("max scaled err %s: %.3e" % (name, worst))
+    return worst
 
 
 def random_actions(env, rs, B):
@@ -230,13 +235,14 @@ def staged_batch(spec, B, rs):
         w = np.flatnonzero(k >= 2)
         pos[w, 1] = pos[w, 0] + disk(len(w), 0.11)
     if spec.name == "simple_world_comm":
-        for g in (4, 5):
+        nadv = sum(spec.adversary)
+        for g in range(nadv, A):        # the good agents
             w = np.flatnonzero(k == 2)
             pos[w, g, rs.randint(0, 2, len(w))] = rs.choice([-1, 1], len(w)) * rs.uniform(0.88, 1.15, len(w))
             w = np.flatnonzero((k == 3) | (k == 7))
-            pos[w, g] = pos[w, rs.randint(0, 4, len(w))] + disk(len(w), 0.13)
+            pos[w, g] = pos[w, rs.randint(0, nadv, len(w))] + disk(len(w), 0.13)
             w = np.flatnonzero(k == 4)
-            pos[w, g] = pos[w, A + 1 + (g - 4)] + disk(len(w), 0.07)
+            pos[w, g] = pos[w, A + 1 + (g - nadv) % 2] + disk(len(w), 0.07)
         w = np.flatnonzero((k == 5) | (k == 7))
         vel[w] = rs.uniform(-1.5, 1.5, (len(w), A, 2))
         w = np.flatnonzero(k == 6)
@@ -248,6 +254,10 @@ def staged_batch(spec, B, rs):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", NAMES)
 def test_fused_step_teacher_forced_against_the_fp64_oracle_at_size(name, record_parity):
+    against_the_fp64_oracle(name, {}, {}, 65536, record_parity, "f3_" + name)
+
+
+def against_the_fp64_oracle(name, spec_kw, env_kw, B, record_parity, key, min_cov=0.05):
     """65 536 worlds, three teacher-forced steps: the fused kernels (KIND specialisations of k_split) against
     oracle/mpe_f3.py -- the fp64 restatement that tests/test_oracle_golden.py pins to the reference at 1e-12 -- instead
     of against the package's own torch callbacks.  Per-element 1e-5 for obs / reward / pos / vel / comm state; worlds in
@@ -255,10 +265,10 @@ def test_fused_step_teacher_forced_against_the_fp64_oracle_at_size(name, record_
     masked, counted, and must stay below 1 %; branch coverage of the batch is printed and must be >= 5 % everywhere."""
     from oracle import spec as ospec
     from oracle.mpe_f3 import F3Oracle, branch_coverage, knife_edge
-    B, T = 65536, 3
-    spec = ospec.by_name(name)
+    T = 3
+    spec = ospec.by_name(name, **spec_kw)
     rs = np.random.RandomState(77)
-    env = mpe.make_env(name, batch_size=B)
+    env = mpe.make_env(name, batch_size=B, **env_kw)
     assert env.fused
     A, E = spec.n_agents, spec.n_entities
     pos, vel = staged_batch(spec, B, rs)
@@ -313,11 +323,85 @@ def test_fused_step_teacher_forced_against_the_fp64_oracle_at_size(name, record_
         g["c%d" % i] = np.stack(rec["c"][i])
     cov = branch_coverage(spec, g)
     print("%s: max scaled err %s; %d of %d worlds masked (knife edge); coverage %s"
-          % (name, {k: "%.2e" % x for k, x in worst.items()}, masked, B, {k: "%.1f%%" % (100 * x) for k, x in cov.items()}))
+          % (key, {k: "%.2e" % x for k, x in worst.items()}, masked, B, {k: "%.1f%%" % (100 * x) for k, x in cov.items()}))
     assert masked <= 0.01 * B
-    assert all(x >= 0.05 for x in cov.values()), cov
-    record_parity("f3_" + name, {"worlds": B, "steps": T, "max_scaled_err": worst, "worlds_masked_knife_edge": masked,
+    assert all(x >= min_cov for x in cov.values()), cov
+    record_parity(key, {"worlds": B, "steps": T, "max_scaled_err": worst, "worlds_masked_knife_edge": masked,
                                  "branch_coverage": cov, "against": "oracle/mpe_f3.py fp64, teacher-forced"})
+
+
+# ---- team sizes other than the reference's make_world (its callbacks are written for any: simple_adversary.py:69-139,
+# simple_world_comm.py:126-289); goldens: tests/golden/gen_golden_shapes.py --------------------------------------------------
+SHAPES = [("simple_adversary", 2, 1), ("simple_adversary", 4, 1), ("simple_adversary", 4, 2), ("simple_adversary", 5, 1),
+          ("simple_adversary", 6, 2),
+          ("simple_world_comm", 3, 2), ("simple_world_comm", 4, 2), ("simple_world_comm", 4, 3), ("simple_world_comm", 5, 3),
+          ("simple_world_comm", 8, 5)]
+SHAPE_IDS = ["%s-%d-%d" % s for s in SHAPES]
+
+
+def shape_kw(name, A, nadv):
+    """(oracle spec kwargs, make_env kwargs) of a team-size variant."""
+    if name == "simple_world_comm":
+        return {"n_good": A - nadv, "n_adversaries": nadv}, {"num_good_agents": A - nadv, "num_adversaries": nadv}
+    return {"n_agents": A, "n_adversaries": nadv}, {"num_agents": A, "num_adversaries": nadv}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "generic"])
+@pytest.mark.parametrize("name,A,nadv", SHAPES, ids=SHAPE_IDS)
+def test_other_team_sizes_against_reference_golden(name, A, nadv, fused, golden):
+    """The reference's callbacks on worlds of other team sizes (recorded by gen_golden_shapes.py), teacher-forced: the
+    fused kernels built for these shapes (mpe_split.hip's table) and the generic path, both at 1e-5; with
+    benchmark=True the fused launch also delivers the reference's benchmark_data."""
+    from oracle import spec as ospec
+    from oracle.mpe_f3 import knife_edge
+    g = golden("shape_%s_%d_%d" % (name, A, nadv))
+    spec_kw, env_kw = shape_kw(name, A, nadv)
+    env = mpe.make_env(name, batch_size=len(g["seeds"]), fused=fused, **env_kw)
+    assert env.fused == fused and env.n == A
+    print("max scaled err %s %d/%d: %.3e" % (name, A, nadv, teacher_forced_against_golden(env, g)))
+    if not fused:
+        return
+    env = mpe.make_env(name, batch_size=len(g["seeds"]), benchmark=True, **env_kw)
+    assert env.fused and not env._py_info
+    set_choices(env, g["choice"])
+    for t in range(g["rew"].shape[0]):
+        env.world.set_state(g["pos0"] if t == 0 else g["pos"][t - 1], g["vel0"] if t == 0 else g["vel"][t - 1])
+        set_comm(env, g, t - 1)
+        _, _, _, info = env.step([torch.as_tensor(g["act%d" % i][t], dtype=torch.float32).cuda() for i in range(A)])
+        inf = info["n"]
+        if name == "simple_adversary":      # simple_adversary.py:57-67
+            for k in range(A):
+                if k < nadv:
+                    close(np_(inf[k]), g["info_adv"][t][:, k], what="t=%d adversary %d" % (t, k))
+                else:
+                    assert isinstance(inf[k], tuple) and len(inf[k]) == g["info_good"].shape[-1]
+                    for j, x in enumerate(inf[k]):
+                        close(np_(x), g["info_good"][t][:, k - nadv, j], what="t=%d good %d datum %d" % (t, k, j))
+        else:                               # simple_world_comm.py:115-124: exact outside the knife edge
+            ok = ~knife_edge(ospec.by_name(name, **spec_kw), g["pos"][t], 1e-6)
+            got = np.stack([np_(x) for x in inf], axis=1)
+            assert got.dtype == np.int32 and np.array_equal(got[ok], g["info_collisions"][t][ok]) and ok.mean() > 0.98
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,A,nadv", SHAPES, ids=SHAPE_IDS)
+def test_other_team_sizes_against_the_fp64_oracle_at_size(name, A, nadv, record_parity):
+    """16 384 staged worlds per team-size variant against oracle/mpe_f3.py (pinned to the reference at these very shapes
+    by tests/test_oracle_golden.py), same protocol and bars as the reference shapes above."""
+    spec_kw, env_kw = shape_kw(name, A, nadv)
+    against_the_fp64_oracle(name, spec_kw, env_kw, 16384, record_parity, "shape_%s_%d_%d" % (name, A, nadv))
+
+
+@pytest.mark.gpu
+def test_a_team_size_without_a_kernel_takes_the_generic_path():
+    env = mpe.make_env("simple_world_comm", batch_size=64, num_good_agents=5, num_adversaries=6)
+    assert not env.fused
+    with pytest.raises(RuntimeError):      # _abi.MpeError
+        mpe.make_env("simple_world_comm", batch_size=64, num_good_agents=5, num_adversaries=6, fused=True)
+    rs = np.random.RandomState(0)
+    obs, rew, done, _ = env.step(random_actions(env, rs, 64))
+    assert len(obs) == 11 and all(torch.isfinite(o).all() for o in obs)
 
 
 @pytest.mark.gpu

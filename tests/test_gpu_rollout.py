@@ -74,6 +74,12 @@ def test_split_and_thread_kernels_bit_identical(name, kw, B):
                                             # the communication scenarios: words drawn in-kernel, picks re-drawn by in-kernel resets
                                             ("simple_speaker_listener", {}, 700, 13, 4), ("simple_reference", {}, 333, 11, 3),
                                             ("simple_crypto", {}, 200, 9, 4), ("simple_world_comm", {}, 129, 10, 5),
+                                            # team sizes beyond the reference's make_world (mpe_split.hip's table)
+                                            ("simple_adversary", {"num_agents": 4, "num_adversaries": 2}, 500, 12, 5),
+                                            ("simple_adversary", {"num_agents": 6, "num_adversaries": 2}, 300, 8, 3),
+                                            ("simple_adversary", {"num_agents": 2}, 70000, 4, 3),
+                                            ("simple_world_comm", {"num_good_agents": 1, "num_adversaries": 2}, 200, 9, 4),
+                                            ("simple_world_comm", {"num_good_agents": 3, "num_adversaries": 5}, 129, 6, 3),
                                             # >= 12 MB of rows per step: the rollout kernels built with nontemporal row stores
                                             ("simple_spread", {}, 65536, 3, 2), ("simple_world_comm", {}, 20000, 3, 2)])
 def test_fused_rollout_equals_stepwise(name, kw, B, T, ep):

@@ -281,6 +281,34 @@ def test_f3_goldens_populate_every_branch(name, golden):
     assert not low, low
 
 
+# ---- team sizes other than the reference's make_world (tests/golden/gen_golden_shapes.py) ----------------------------------
+SHAPES = [("simple_adversary", 2, 1), ("simple_adversary", 4, 1), ("simple_adversary", 4, 2), ("simple_adversary", 5, 1),
+          ("simple_adversary", 6, 2),
+          ("simple_world_comm", 3, 2), ("simple_world_comm", 4, 2), ("simple_world_comm", 4, 3), ("simple_world_comm", 5, 3),
+          ("simple_world_comm", 8, 5)]
+
+
+def shape_spec(name, A, nadv):
+    if name == "simple_world_comm":
+        return ospec.by_name(name, n_good=A - nadv, n_adversaries=nadv)
+    return ospec.by_name(name, n_agents=A, n_adversaries=nadv)
+
+
+@pytest.mark.parametrize("name,A,nadv", SHAPES, ids=["%s-%d-%d" % s for s in SHAPES])
+def test_f3_oracle_at_other_team_sizes_matches_reference(name, A, nadv, golden):
+    """The reference's callbacks on worlds with other team sizes than its make_world builds (its agent / landmark lists
+    resized, gen_golden_shapes.py): the oracle replays them at 1e-12, seeded resets included."""
+    from oracle.mpe_f3 import seeded_initial_state_f3
+    g = golden("shape_%s_%d_%d" % (name, A, nadv))
+    spec = shape_spec(name, A, nadv)
+    assert (spec.n_agents, sum(spec.adversary)) == (int(g["n_agents"]), int(g["n_adversaries"])) == (A, nadv)
+    _replay_f3(spec, g)
+    plain = np.flatnonzero(~g["staged"])
+    pos, vel, choice = seeded_initial_state_f3(spec, g["seeds"])
+    assert np.array_equal(choice, g["choice"])
+    assert np.array_equal(pos[plain], g["pos0"][plain]) and np.array_equal(vel[plain], g["vel0"][plain])
+
+
 # ---- movable landmarks (core.py:158-169 integrates every movable entity) -------------------------------------------------
 def movable_spec(name, g):
     import dataclasses

@@ -21,9 +21,10 @@ def main():
     tag = os.path.basename(os.environ.get("MPE_HIP_LIB", "base")).replace("libmpe_hip_ab_", "").replace(".so", "")
     out = []
     for spec in sys.argv[1:]:
-        scn, ag, B = spec.split(":")
+        scn, ag, B = spec.split(":")[:3]      # optional 4th field: make_world arguments, "num_agents=6,num_adversaries=2"
+        kw = {k: int(v) for k, v in (x.split("=") for x in spec.split(":")[3].split(","))} if spec.count(":") > 2 else None
         scn = {"tag": "simple_tag", "spread": "simple_spread"}.get(scn, scn)
-        leg = bench.Leg(mpe, scn, int(ag), int(B), 25, 0, 1, 0)
+        leg = bench.Leg(mpe, scn, int(ag), int(B), 25, 0, 1, 0, scenario_kw=kw)
         n = 400 if int(B) * leg.A < 400000 else 100
         k = leg.kernel_time_us(torch, "graph", n=n)
         f = leg.kernel_time_us(torch, "fused", n=n)
