@@ -390,7 +390,8 @@ struct RowPairs {
 // emitter obeys -- a wave store is a whole-line, contiguous, in-order run.  Their cache policy is worth 5-15 % of a launch
 // (same-box A/B, profiles/r2_ab_logs.txt session 40):
 //   kRowsNt   nontemporal ("nt": the line is not kept): best when a launch writes tens of MB -- spread N=3 at 65 536
-//             worlds 6.38 -> 5.52 us, at 1 M worlds 72 -> 69 us, N=64 78-85 -> 74.8 us (and no more bimodality)
+//             worlds 6.38 -> 5.52 us, at 1 M worlds 72 -> 69 us, N=64 78-85 -> 74.8 us (and no more bimodality; round 3 re-measured
+//             sc1 for k_duo: better into one buffer, worse under the env's ping-pong of two)
 //   kRowsSc1  agent scope ("sc1": written through the XCD's L2): best for the small launches, whose end-of-kernel
 //             write-back of dirty lines is otherwise exposed -- tag at 16 384 worlds 4.14 -> 3.75 us (nt 3.98) -- and for
 //             the k_split rollouts, where nt can lose (simple_adversary 1.47 -> 1.73 us per step, sc1 1.39)

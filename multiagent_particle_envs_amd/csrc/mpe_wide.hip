@@ -55,6 +55,9 @@
 #ifndef MPE_DUO_G
 #define MPE_DUO_G 4   // worlds per workgroup of k_duo (1, 2, 4 or 8)
 #endif
+#ifndef MPE_DUO_LDS_PAD
+#define MPE_DUO_LDS_PAD 0   // A/B builds: unused dynamic LDS bytes per k_duo workgroup (caps the workgroups resident per CU)
+#endif
 // ablation builds (tools/ab_build.sh): bit 0 skip the reward, bit 1 skip the contact loop, bit 2 skip the row stores
 #ifndef MPE_DUO_ABLATE
 #define MPE_DUO_ABLATE 0
@@ -877,6 +880,9 @@ k_duo(const WideDesc d, const MpeBuffers b, const size_t B) {
   const bool rows16 = (D & 3) == 0 && ((B * (size_t)D) & 3) == 0;
   if (role == 0) {
     if (wok && !(MPE_DUO_ABLATE & 4)) {
+      // (nontemporal rows.  Agent scope (sc1) wins by 0.5-2.5 us when ONE buffer is written launch after launch (profiles/
+      //  r3_ab_logs.txt sessions 24-25: 66.6-67.0 vs 67.0-69.2 us fast buffers, 79-82 vs 82-84 slow ones) and loses 0.7 us under
+      //  the env's ping-pong of two output sets (session 30: 68.0-69.1 vs 67.3-67.8) -- the protocol that counts)
       if (rows16 && d.rows_nt) emit_rows_fast<kRowsNt>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
       else if (rows16) emit_rows_fast<kRowsPlain>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
       else        emit_rows<2>(Q, V, A, L, D, b.obs + w * (size_t)D, (size_t)B * D, lane, 0, split);
@@ -1493,7 +1499,7 @@ int launch_wide(bool phys, bool out, const WideDesc &d_in, const MpeBuffers &b, 
     constexpr int G = MPE_DUO_G;
     const size_t padded_w = (B + 255) / 256 * 256;   // whole 256-world blocks of the XCD map
     if (padded_w <= 0x7fffffffull) {
-      const size_t dlds = (size_t)G * duo_carve(d.A, d.L).slot_bytes;
+      const size_t dlds = (size_t)G * duo_carve(d.A, d.L).slot_bytes + (MPE_DUO_LDS_PAD);
       hipLaunchKernelGGL(k_duo<G>, dim3((unsigned)(padded_w / G)), dim3(2 * G * kWave), dlds, stream, d, b, B);
       return (int)hipGetLastError();
     }
