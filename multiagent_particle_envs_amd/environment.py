@@ -141,16 +141,21 @@ class MultiAgentEnv(object):
         builtin = next((c for c in type(sc).__mro__ if c.__module__.startswith(pkg)), None) if sc is not None else None
         def is_builtin(cb, name):
             return getattr(cb, "__self__", None) is sc and getattr(cb, "__func__", None) is builtin.__dict__.get(name)
-        # the kernel side of a step (action decode, World.step, observation rows) needs the built-in observation, a
-        # reset_world of the same scenario object, no scripted agents, no action / communication noise, and a kernel
-        # for this shape; reward / benchmark_data / done may each be the built-in (computed in the same launch) or
-        # ANY Python callback (evaluated on the post-step world after the launch: "partial fusion")
+        # the kernel side of a step (action decode, World.step, observation rows, reward) needs a built-in scenario's world,
+        # a reset_world of the same scenario object, no scripted agents, no action / communication noise, and a kernel
+        # for this shape; observation / reward / benchmark_data / done may each be the built-in (computed in the same
+        # launch) or ANY Python callback (evaluated on the post-step world after the launch: "partial fusion").  A scenario
+        # that overrides BOTH observation and reward has nothing left for the kernel but World.step: generic path.
         own = builtin is not None and kind is not None and \
-            getattr(reset_callback, "__self__", None) is sc and is_builtin(observation_callback, "observation") and \
+            getattr(reset_callback, "__self__", None) is sc and getattr(observation_callback, "__self__", None) is sc and \
+            (is_builtin(observation_callback, "observation") or is_builtin(reward_callback, "reward")) and \
             len(world.scripted_agents) == 0 and not any(l.movable for l in world.landmarks) and \
             all((a.silent or (kind in _abi.COMM_KINDS and not a.c_noise)) and not a.u_noise for a in world.agents)
         if own:   # ... and a kernel for this shape (mpe_split.hip's table: the reference's team sizes and some others)
             own = _abi.lib().mpe_step_supported(C.byref(world.scenario_desc(kind, getattr(sc, "num_adversaries", 0)))) == 1
+        # the observation is a Python callback: the launch still writes the built-in rows (into the env's buffers, unused:
+        # they are 4 of the kernel's 5-6 us at simple_spread's 65 536 worlds, against the ~150 launches of the generic path)
+        self._py_obs = own and not is_builtin(observation_callback, "observation")
         self._py_reward = own and not is_builtin(reward_callback, "reward")
         self._py_info = own and info_callback is not None and not (
             is_builtin(info_callback, "benchmark_data") and kind in (_abi.MPE_SCN_SPREAD, _abi.MPE_SCN_TAG, _abi.MPE_SCN_ADVERSARY,
@@ -159,15 +164,15 @@ class MultiAgentEnv(object):
         if fused is None:
             fused = own
         if fused and not own:
-            raise _abi.MpeError("fused=True needs the unmodified observation callback of a built-in scenario at a shape "
-                                "libmpe_hip.so has a kernel for (mpe_step_supported), without scripted agents or noise")
+            raise _abi.MpeError("fused=True needs a built-in scenario with its own observation or its own reward callback at a "
+                                "shape libmpe_hip.so has a kernel for (mpe_step_supported), without scripted agents or noise")
         self.fused = bool(fused)
         self._comm_kind = self.fused and kind in _abi.COMM_KINDS
         self._scenario = sc
         self._kind = kind if self.fused else _abi.MPE_SCN_GENERIC
         self._benchmark = self.fused and info_callback is not None and not self._py_info
         if not self.fused:
-            self._py_reward = self._py_info = self._py_done = False
+            self._py_obs = self._py_reward = self._py_info = self._py_done = False
 
         # ---- spaces (environment.py:38-70) -------------------------------------------------------------
         self.action_space = []
@@ -176,6 +181,8 @@ class MultiAgentEnv(object):
             self._desc = world.scenario_desc(kind, getattr(sc, "num_adversaries", 0))
             self._obs_off = [int(self._desc.obs_off[i]) for i in range(len(world.agents) + 1)]
             obs_dims = [self._obs_off[i + 1] - self._obs_off[i] for i in range(len(world.agents))]
+            if self._py_obs:    # the user's rows, whatever their width
+                obs_dims = [int(observation_callback(agent, self.world).shape[-1]) for agent in self.agents]
         else:
             self._desc = None
             obs_dims = [int(observation_callback(agent, self.world).shape[-1]) for agent in self.agents]
@@ -474,9 +481,10 @@ class MultiAgentEnv(object):
                 info_n = {'n': [self._get_info(a) for a in self.agents]}
         if info_n is None:
             info_n = out.info_n(self)
-        if self.max_episode_steps and self._episode_tick(done):
+        if self.max_episode_steps and self._episode_tick(done) and not self._py_obs:
             self._observe_into(out)         # worlds that finished were reset: their rows are the new episode's first
-        return self._deliver(out.obs_n, reward_n, done_n, info_n)
+        obs_n = [self._get_obs(a) for a in self.agents] if self._py_obs else out.obs_n
+        return self._deliver(obs_n, reward_n, done_n, info_n)
 
     def _episode_tick(self, done):
         """After a step: count it for every world, mark the worlds that reached max_episode_steps done (all agents),
@@ -564,6 +572,8 @@ class MultiAgentEnv(object):
                 self._comm.zero_()
             else:
                 self._comm[:, torch.as_tensor(mask, device=self._comm.device).bool()] = 0.0
+        if self._py_obs:
+            return self._deliver([self._get_obs(agent) for agent in self.agents], None, None, None)[0]
         out = self._next_set()
         self._observe_into(out)
         return self._deliver(out.obs_n, None, None, None)[0]

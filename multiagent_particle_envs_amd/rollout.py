@@ -33,6 +33,9 @@ class RandomRollout(object):
         concurrent kernels do not overlap usefully on this stack.  The block draw is one 98 MB-write launch per 25 steps.)"""
         if not env.fused:
             raise _abi.MpeError("RandomRollout drives the fused built-in scenarios")
+        if env._py_obs or env._py_reward or env._py_done or env._py_info:
+            raise _abi.MpeError("RandomRollout runs on the device and evaluates the built-in callbacks only: this env has "
+                                "Python observation / reward / done / info callbacks (use env.step, or GraphedStep)")
         self.env = env
         self.world = env.world
         self.episode_len = int(episode_len)

@@ -760,6 +760,87 @@ def test_two_waves_per_world_kernel_is_bit_identical_to_the_wave_per_world_kerne
 
 
 @pytest.mark.parametrize("name,kw", [("simple_spread", {}), ("simple_tag", {}), ("simple_spread", {"num_agents": 20}),
+                                     ("simple_reference", {}), ("simple_world_comm", {})])
+def test_partial_fusion_python_observation_over_the_fused_step(name, kw):
+    """A user who overrides only `observation` (extra features, another layout) keeps ONE launch for action decode,
+    World.step and the built-in reward; the Python rows are evaluated on the post-step world (environment.py:92-97).
+    Rewards / state bit-identical to the fully fused env, rows identical to what the generic path returns for the same
+    subclass; reset() and the device-side auto-reset hand out the Python rows too."""
+    B = 600
+    Base = mpe.scenarios.load(name + ".py").Scenario
+
+    class Mine(Base):
+        def observation(self, agent, world):
+            return torch.cat([Base.observation(self, agent, world) * 2.0, agent.state.p_pos.norm(dim=1, keepdim=True)], dim=1)
+    sc = Mine()
+    w = sc.make_world(batch_size=B, **kw)
+    sc.reset_world(w)
+    part = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation)
+    part.scenario = sc
+    assert part.fused and part._py_obs and not part._py_reward
+    ref = mpe.make_env(name, batch_size=B, **kw)
+    sc2 = Mine()
+    w2 = sc2.make_world(batch_size=B, **kw)
+    gen = mpe.MultiAgentEnv(w2, sc2.reset_world, sc2.reward, sc2.observation, fused=False)
+    assert not gen.fused
+    for i in range(part.n):
+        assert part.observation_space[i].shape == (ref.observation_space[i].shape[0] + 1,) == gen.observation_space[i].shape
+    for e, s_ in ((ref, ref.scenario), (gen, sc2)):
+        e.world.pos.copy_(w.pos)
+        e.world.vel.copy_(w.vel)
+        if w.choice_i32 is not None:
+            e.world.choice_i32.copy_(w.choice_i32)
+            if hasattr(s_, "_apply"):
+                s_._apply(e.world)
+    if w.choice_i32 is not None and hasattr(sc, "_apply"):
+        sc._apply(w)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(3):
+        acts = []
+        for agent in part.agents:
+            parts = []
+            if agent.movable:
+                parts.append(torch.nn.functional.one_hot(torch.randint(0, 5, (B,), device="cuda", generator=g), 5).float())
+            if not agent.silent:
+                parts.append(torch.nn.functional.one_hot(torch.randint(0, w.dim_c, (B,), device="cuda", generator=g), w.dim_c).float())
+            acts.append(torch.cat(parts, dim=1))
+        o_p, r_p, d_p, _ = part.step(acts)
+        o_r, r_r, _, _ = ref.step(acts)
+        o_g, r_g, _, _ = gen.step(acts)
+        assert torch.equal(part.world.pos, ref.world.pos) and torch.equal(part.world.vel, ref.world.vel)
+        for i in range(part.n):
+            assert torch.equal(r_p[i], r_r[i]) and not d_p[i].any()
+            close(np_(r_p[i]), np_(r_g[i]), what="rew%d vs generic" % i)
+            assert o_p[i].shape == (B, o_r[i].shape[1] + 1)
+            close(np_(o_p[i][:, :-1]), np_(o_r[i]) * 2.0, what="obs%d vs fused rows" % i)
+            close(np_(o_p[i]), np_(o_g[i]), what="obs%d vs generic" % i)
+    # reset(): Python rows of the fresh state
+    seeds = list(range(40, 40 + B))
+    o_p, o_r = part.reset(seeds=seeds), ref.reset(seeds=seeds)
+    for i in range(part.n):
+        close(np_(o_p[i][:, :-1]), np_(o_r[i]) * 2.0, what="reset obs%d" % i)
+        close(np_(o_p[i][:, -1]), np.linalg.norm(np_(part.world.agents[i].state.p_pos), axis=1), what="reset extra column %d" % i)
+    # the device-side auto-reset at the horizon: the rows returned at that step are the new episode's first
+    sc3 = Mine()
+    w3 = sc3.make_world(batch_size=B, **kw)
+    sc3.reset_world(w3)
+    auto = mpe.MultiAgentEnv(w3, sc3.reset_world, sc3.reward, sc3.observation, max_episode_steps=2, auto_reset=True)
+    assert auto.fused and auto._py_obs
+    auto.reset()
+    zero = [torch.zeros_like(a) for a in acts]
+    auto.step(zero)
+    before = auto.world.pos.clone()
+    o, _, d, _ = auto.step(zero)
+    assert all(x.all() for x in d) and not torch.equal(auto.world.pos, before)
+    for i in range(auto.n):
+        close(np_(o[i][:, -1]), np.linalg.norm(np_(auto.world.agents[i].state.p_pos), axis=1), what="auto-reset rows %d" % i)
+    from multiagent_particle_envs_amd import _abi
+    from multiagent_particle_envs_amd.rollout import RandomRollout
+    with pytest.raises(_abi.MpeError):
+        RandomRollout(part)
+
+
+@pytest.mark.parametrize("name,kw", [("simple_spread", {}), ("simple_tag", {}), ("simple_spread", {"num_agents": 20}),
                                      ("simple_reference", {})])
 def test_partial_fusion_python_reward_done_info_over_the_fused_step(name, kw):
     """A user who overrides only reward (or adds done / benchmark callbacks) keeps ONE launch for action decode,

@@ -147,7 +147,8 @@ def test_scenario_loader_and_generic_detection(tmp_path):
         mpe.scenarios.load("simple_no_such_scenario.py")
     assert mpe.scenarios.load("simple_crypto.py").Scenario.kind == _abi.MPE_SCN_CRYPTO
     # a subclass that overrides REWARD keeps the kernel for action decode + World.step + observation rows and gets its
-    # own reward evaluated in Python on the post-step world (partial fusion); overriding OBSERVATION leaves the kernel
+    # own reward evaluated in Python on the post-step world (partial fusion); one that overrides OBSERVATION keeps it for
+    # action decode + World.step + reward and gets its own rows evaluated in Python; overriding both leaves the kernel
     Base = mpe.scenarios.load("simple_spread.py").Scenario
 
     class MyReward(Base):
@@ -156,20 +157,29 @@ def test_scenario_loader_and_generic_detection(tmp_path):
 
     class MyObs(Base):
         def observation(self, agent, world):
-            return Base.observation(self, agent, world)
+            return Base.observation(self, agent, world)[:, :7]
+
+    class Both(MyReward, MyObs):
+        pass
     sc = MyReward()
     w = sc.make_world(batch_size=3, device="cpu")
     env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation)
-    assert env.fused and env._py_reward and not env._py_done and not env._py_info
+    assert env.fused and env._py_reward and not env._py_obs and not env._py_done and not env._py_info
     assert env.observation_space[0].shape == (18,)
     env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, done_callback=lambda agent, world: False)
     assert env.fused and env._py_done
     sc = MyObs()
     w = sc.make_world(batch_size=3, device="cpu")
     env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation)
-    assert not env.fused and not env._py_reward and env.observation_space[0].shape == (18,)
+    assert env.fused and env._py_obs and not env._py_reward and env.observation_space[0].shape == (7,)
+    sc = Both()
+    w = sc.make_world(batch_size=3, device="cpu")
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation)
+    assert not env.fused and not env._py_reward and not env._py_obs and env.observation_space[0].shape == (7,)
     with pytest.raises(_abi.MpeError):
         mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, fused=True)
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, lambda agent, world: agent.state.p_pos)   # not the scenario's method
+    assert not env.fused and env.observation_space[0].shape == (2,)
 
 
 def test_fused_kernels_cover_the_reference_shapes_and_other_shapes_fall_back():
