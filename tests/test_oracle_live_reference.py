@@ -149,6 +149,11 @@ for k, (name, sq) in enumerate([("simple_adversary", 0), ("simple_push", 0), ("s
                                 ("simple_crypto", 0), ("simple_world_comm", 8)]):
     data = gs.record(name, [base + 100 * k + j for j in range(64)], 6, squeeze_every=sq, stage=True)
     np.savez(sys.argv[2] + "/f3_" + name + ".npz", **data)
+import gen_golden_shapes as gsh      # other team sizes: the reference's callbacks on resized agent lists
+for k, (name, A, nadv) in enumerate(gsh.SHAPES):
+    data = gs.record(name, [base + 1000 + 100 * k + j for j in range(32)], 4, squeeze_every=8 if name == "simple_world_comm" else 0,
+                     stage=True, env_factory=gsh.factory(name, A, nadv))
+    np.savez(sys.argv[2] + "/shape_" + name + "_" + str(A) + "_" + str(nadv) + ".npz", **data)
 """
 
 
@@ -178,6 +183,20 @@ def test_f3_oracle_replays_fresh_reference_worlds(fresh_f3):
     for name in tg.F3:
         g = fresh_f3("f3_" + name)
         spec = ospec.by_name(name)
+        tg._replay_f3(spec, g)
+        plain = np.flatnonzero(~g["staged"])
+        pos, vel, choice = seeded_initial_state_f3(spec, g["seeds"])
+        assert np.array_equal(choice, g["choice"]), "MPE_LIVE_SEED=%d" % _base_seed()
+        assert np.array_equal(pos[plain], g["pos0"][plain]), "MPE_LIVE_SEED=%d" % _base_seed()
+
+
+def test_f3_oracle_at_other_team_sizes_replays_fresh_reference_worlds(fresh_f3):
+    """The team-size variants of simple_adversary / simple_world_comm (tests/golden/gen_golden_shapes.py) on fresh seeds."""
+    import test_oracle_golden as tg
+    from oracle.mpe_f3 import seeded_initial_state_f3
+    for name, A, nadv in tg.SHAPES:
+        g = fresh_f3("shape_%s_%d_%d" % (name, A, nadv))
+        spec = tg.shape_spec(name, A, nadv)
         tg._replay_f3(spec, g)
         plain = np.flatnonzero(~g["staged"])
         pos, vel, choice = seeded_initial_state_f3(spec, g["seeds"])
