@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, GPU visit 3: parity suite (+ parity_r3.json), driver-style bench, kernel traces of every BASELINE config, PMC for C2, C4 x 5 processes
+# round 3, GPU visit 3: parity suite (+ parity_r3.json), driver-style bench, kernel traces of every BASELINE config, PMC for C2, C4 x 3 processes
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}; TAG=${1:-r3s3}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 export TMPDIR=/tmp
@@ -44,7 +44,7 @@ for cfg in "spread3_B4096 --batch 4096" "tag_B16384 --scenario simple_tag --batc
   python profiles/pmc_summary.py $R/gpurun_out/pmc_${TAG}_$name k_split > $O/pmc_$name.txt 2>>$O/err.log
   rm -rf $R/gpurun_out/pmc_${TAG}_$name        # (raw counter CSVs: tens of MB; the summary is what travels back)
 done
-for k in 1 2 3 4 5; do
+for k in 1 2 3; do
   timeout 200 python bench.py --agents 64 --batch 4096 --steps 50 --warmup 10 --no-extra --no-cpu-baseline --region-ms 300 >> $O/c4_processes.jsonl 2>> $O/c4.err
 done
 python - <<PY
