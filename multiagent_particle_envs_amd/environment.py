@@ -25,6 +25,7 @@ call k stay intact until call k+2 returns (so `obs_n`/`new_obs_n` of the usual t
 alias).  Pass fresh_outputs=True for reference-style freshly allocated outputs on every call.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -77,6 +78,7 @@ class _OutputSet(object):
         self.bufs_ref = C.byref(b)
         self.reward_n = [self.rew[i] for i in range(A)]
         self.done_n = [self.done[i] for i in range(A)]
+        self.act_ptr = None       # MultiAgentEnv.step's fast path: the action pointer b.act currently holds
 
     def info_n(self, env):
         A = len(env.agents)
@@ -215,6 +217,7 @@ class MultiAgentEnv(object):
         # ---- device buffers for the fused path ----------------------------------------------------------
         self._sets = None
         self._flip = 0
+        self._fast_acts = {}      # step()'s fast path: id -> weak reference of the caller's action tensors a full step validated
         self._act = None
         self._ids = None
         self._comm = None
@@ -440,6 +443,26 @@ class MultiAgentEnv(object):
 
     def step(self, action_n):
         """environment.py:80-104 for B worlds."""
+        # ---- the common case in as few Python operations as it takes: one of the caller's preallocated [A,B,5] device
+        # tensors again (one that an earlier step validated; contents rewritten in place), a fully fused non-communication
+        # env, nothing flipped since.  One step() then costs the host ~3 us instead of ~7 (the headline kernel takes 5.5: the
+        # Python API stops being host-bound).  The tensors are remembered by weak reference: nothing is kept alive.
+        known = self._fast_acts.get(id(action_n))
+        if known is not None and known() is action_n and self._constants_seen == self.world._constants_version and \
+                not self._scenario_state_stale and not self.discrete_action_input and self.discrete_action_space and \
+                not self.force_discrete_action and len(self.agents) == len(self.world.agents) and self.fused and \
+                not self.fresh_outputs:
+            self._flip ^= 1
+            out = self._sets[self._flip]
+            p = action_n.data_ptr()
+            if out.act_ptr != p:
+                b = out.bufs
+                b.act, b.ids, b.u = p, None, None
+                out.act_ptr = p
+            rc = self._mpe_step(self._desc_ref, out.bufs_ref, self.batch_size, self._stream())
+            if rc:
+                _abi.check(rc, "mpe_step")
+            return list(out.obs_n), list(out.reward_n), list(out.done_n), out.info_n(self)
         if self._scenario_state_stale:
             self.sync_from_device()
         if len(self.agents) != len(self.world.agents):   # environment.py:85 re-reads world.policy_agents every step
@@ -455,6 +478,13 @@ class MultiAgentEnv(object):
         b.act = act.data_ptr() if act is not None else None
         b.ids = ids.data_ptr() if ids is not None else None
         b.u = None
+        out.act_ptr = None      # (the fast path's note of what b.act holds: re-established there)
+        # arm the fast path for the next call with this very tensor: zero-copy moves, nothing evaluated in Python afterwards
+        if act is action_n and not self._comm_kind and not self.fresh_outputs and not self.numpy_io and \
+                not self.max_episode_steps and not (self._py_obs or self._py_reward or self._py_done or self._py_info):
+            if len(self._fast_acts) >= 64:
+                self._fast_acts.clear()
+            self._fast_acts[id(action_n)] = weakref.ref(action_n)
         if self._py_reward:          # the reward is a Python callback: the launch skips its reward stage
             b.rew = None
         rc = self._mpe_step(self._desc_ref, out.bufs_ref, self.batch_size, self._stream())

@@ -759,6 +759,64 @@ def test_two_waves_per_world_kernel_is_bit_identical_to_the_wave_per_world_kerne
             assert torch.equal(e1._sets[e1._flip].info[k], out.info[k]), k
 
 
+@pytest.mark.parametrize("name,kw,bench", [("simple_spread", {}, False), ("simple_tag", {}, True), ("simple_spread", {"num_agents": 20}, False)])
+def test_step_fast_path_is_the_same_step(name, kw, bench):
+    """MultiAgentEnv.step has a short path for the caller who passes the SAME preallocated [A,B,5] device tensor step after
+    step (contents rewritten in place).  It must be the very same step: bit-identical to an env that is handed a fresh
+    tensor every time, and it must stand down whenever something was flipped on the env or the world in between."""
+    B = 513
+    fast = mpe.make_env(name, batch_size=B, seed=11, benchmark=bench, **kw)
+    slow = mpe.make_env(name, batch_size=B, seed=11, benchmark=bench, **kw)
+    A = fast.n
+    act = torch.zeros((A, B, 5), device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(1)
+
+    def both(t):
+        act.copy_(torch.rand((A, B, 5), device="cuda", generator=g))
+        of, rf, df, nf = fast.step(act)
+        os_, rs, ds, ns = slow.step(act.clone())
+        assert torch.equal(fast.world.pos, slow.world.pos) and torch.equal(fast.world.vel, slow.world.vel), t
+        for i in range(A):
+            assert torch.equal(of[i], os_[i]) and torch.equal(rf[i], rs[i]) and torch.equal(df[i], ds[i]), (t, i)
+            a, b = nf["n"][i], ns["n"][i]
+            for x, y in zip(a if isinstance(a, tuple) else (a,), b if isinstance(b, tuple) else (b,)):
+                assert (not torch.is_tensor(x)) or torch.equal(x, y)
+    for t in range(4):
+        both(t)
+        assert id(act) in fast._fast_acts and id(act) not in slow._fast_acts
+    for e in (fast, slow):                         # a constant assigned on a live env: honoured at the next step
+        e.world.agents[0].size = 0.4
+    both("after a constant changed")
+    both("and again")
+    for e in (fast, slow):
+        e.force_discrete_action = True             # environment.py:169-172: needs the argmax pass -> not the short path
+    both("force_discrete_action")
+    for e in (fast, slow):
+        e.force_discrete_action = False
+    o1, o2 = fast.reset(seeds=list(range(B))), slow.reset(seeds=list(range(B)))
+    for i in range(A):
+        assert torch.equal(o1[i], o2[i])
+    both("after a reset")
+    both("armed after the reset")
+    ring = [torch.rand((A, B, 5), device="cuda", generator=g) for _ in range(3)]     # a caller cycling through a few buffers
+    for t in range(7):
+        of = fast.step(ring[t % 3])[0]
+        os_ = slow.step(ring[t % 3].clone())[0]
+        assert all(torch.equal(a, b) for a, b in zip(of, os_)), t
+    assert all(id(r) in fast._fast_acts for r in ring)
+    k = id(ring[0])
+    del ring, of
+    import gc
+    gc.collect()
+    assert fast._fast_acts[k]() is None            # remembered by weak reference only
+    # outputs are still the ping-pong views: the rows of step t stay valid through step t + 1
+    act.copy_(torch.rand((A, B, 5), device="cuda", generator=g))
+    o_t = fast.step(act)[0]
+    keep = [x.clone() for x in o_t]
+    fast.step(act)
+    assert all(torch.equal(a, b) for a, b in zip(o_t, keep))
+
+
 @pytest.mark.parametrize("name,kw", [("simple_spread", {}), ("simple_tag", {}), ("simple_spread", {"num_agents": 20}),
                                      ("simple_reference", {}), ("simple_world_comm", {})])
 def test_partial_fusion_python_observation_over_the_fused_step(name, kw):
