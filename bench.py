@@ -410,9 +410,27 @@ class Leg(object):
                     ms = e0.elapsed_time(e1)
                     t = ms if t is None else min(t, ms)
                 return t
-            t1, t2 = best(n), best(2 * n)
-            self.last_kernel_timing = {"launches": [n, 2 * n], "ms": [t1, t2], "avg_us_single_body": t2 * 1e3 / (2 * n)}
-            return (t2 - t1) * 1e3 / n
+            # The slope is only as good as both points: a body that comes out slow three times in a row (seen once: the
+            # n-launch graph of the int-ids leg at 6.9 us per launch next to 5.2 for the 2n one, which read as a 3.5 us kernel)
+            # shows as an implausible fixed cost t_n - n * slope.  A replay's fixed cost is 0.03-0.15 ms: outside
+            # [-0.05, 0.35] ms (or 2 % of the body, for long kernels) the pair is measured again (3 attempts), and failing that the 2n body's plain average -- an
+            # upper bound on the slope -- is reported, flagged.
+            tries = []
+            for _ in range(3):
+                t1, t2 = best(n), best(2 * n)
+                slope_ms = (t2 - t1) / n
+                fixed_ms = t1 - slope_ms * n
+                tries.append({"ms": [t1, t2], "fixed_ms": fixed_ms})
+                lo, hi = -max(0.05, 0.02 * t1), max(0.35, 0.02 * t1)     # (long bodies: 2 % of the body is measurement noise)
+                if lo <= fixed_ms <= hi:
+                    break
+            ok = lo <= fixed_ms <= hi
+            self.last_kernel_timing = {"launches": [n, 2 * n], "ms": [t1, t2], "avg_us_single_body": t2 * 1e3 / (2 * n),
+                                       "replay_fixed_cost_ms": fixed_ms, "attempts": len(tries)}
+            if not ok:
+                self.last_kernel_timing["fallback"] = "two-point slope implausible in 3 attempts: the 2n body's average is reported"
+                return t2 * 1e3 / (2 * n)
+            return slope_ms * 1e3
         finally:
             roll.set_episode_len(self.EP)
 
