@@ -415,22 +415,18 @@ class Leg(object):
             # shows as an implausible fixed cost t_n - n * slope.  A replay's fixed cost is 0.03-0.15 ms: outside
             # [-0.05, 0.35] ms (or 2 % of the body, for long kernels) the pair is measured again (3 attempts), and failing that the 2n body's plain average -- an
             # upper bound on the slope -- is reported, flagged.
-            tries = []
-            for _ in range(3):
+            tries = 0
+            while True:
                 t1, t2 = best(n), best(2 * n)
-                slope_ms = (t2 - t1) / n
-                fixed_ms = t1 - slope_ms * n
-                tries.append({"ms": [t1, t2], "fixed_ms": fixed_ms})
-                lo, hi = -max(0.05, 0.02 * t1), max(0.35, 0.02 * t1)     # (long bodies: 2 % of the body is measurement noise)
-                if lo <= fixed_ms <= hi:
+                tries += 1
+                us, fixed_ms, ok = two_point_slope_us(t1, t2, n)
+                if ok or tries == 3:
                     break
-            ok = lo <= fixed_ms <= hi
             self.last_kernel_timing = {"launches": [n, 2 * n], "ms": [t1, t2], "avg_us_single_body": t2 * 1e3 / (2 * n),
-                                       "replay_fixed_cost_ms": fixed_ms, "attempts": len(tries)}
+                                       "replay_fixed_cost_ms": fixed_ms, "attempts": tries}
             if not ok:
                 self.last_kernel_timing["fallback"] = "two-point slope implausible in 3 attempts: the 2n body's average is reported"
-                return t2 * 1e3 / (2 * n)
-            return slope_ms * 1e3
+            return us
         finally:
             roll.set_episode_len(self.EP)
 
@@ -439,6 +435,17 @@ class Leg(object):
         self.trajs = None
         self.envs = []
         self.env = None
+
+
+def two_point_slope_us(t1_ms, t2_ms, n):
+    """(us per launch, implied fixed cost of a replay in ms, plausible?) from the times of an n-launch and a 2n-launch body.
+    Plausible: the fixed cost t_n - n * slope lies in [-0.05, 0.35] ms, or within 2 % of the body for long kernels (measurement
+    noise).  When it does not, the 2n body's plain average -- an upper bound on the slope -- is returned instead of the slope."""
+    slope_ms = (t2_ms - t1_ms) / n
+    fixed_ms = t1_ms - slope_ms * n
+    lo, hi = -max(0.05, 0.02 * t1_ms), max(0.35, 0.02 * t1_ms)
+    ok = lo <= fixed_ms <= hi
+    return (slope_ms * 1e3 if ok else t2_ms * 1e3 / (2 * n)), fixed_ms, ok
 
 
 def _abi_action_dim():

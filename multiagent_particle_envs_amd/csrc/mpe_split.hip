@@ -1020,10 +1020,10 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
     }
     // ---- PHYSICS wave of agent i: World.step of step t+1 behind barrier t, from the siblings' state of step t -----------
     float fx, fy;
-    { const int t = 0; MPE_STAMP(0); }
+    { [[maybe_unused]] const int t = 0; MPE_STAMP(0); }
     step_forces(0, fx, fy);
     step_integrate(0, fx, fy);
-    { const int t = 0; MPE_STAMP(1); }
+    { [[maybe_unused]] const int t = 0; MPE_STAMP(1); }
     publish(0);
     for (int t = 0; t < T; ++t) {
       MPE_STAMP(2);

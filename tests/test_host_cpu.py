@@ -4,6 +4,7 @@ mirror of the reference API (spaces, observation widths, scenario constants, sta
 NumPy-order reset) behaves like the reference."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -271,3 +272,19 @@ def test_no_kernel_uses_scratch_memory():
                 bad.append((os.path.basename(f), m.group(1)[:90], int(m.group(2))))
     assert n > 100, n          # the library has a few hundred kernels
     assert not bad, bad
+
+
+def test_bench_two_point_slope_rejects_a_bad_point():
+    """bench.py times a kernel as the slope between a body of n and one of 2n launches.  One slow body must not pass as a
+    fast kernel (seen once: 2.76 ms / 4.17 ms for n = 400 / 800 read as 3.5 us for a 5.2 us kernel): the implied fixed
+    cost of a replay is checked, and the 2n body's average -- an upper bound -- is reported when it is implausible."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    us, fixed, ok = bench.two_point_slope_us(2.2034, 4.3679, 400)            # the headline's own raw times: sound
+    assert ok and abs(us - 5.411) < 0.01 and 0.0 < fixed < 0.06
+    us, fixed, ok = bench.two_point_slope_us(2.7603, 4.1715, 400)            # the int-ids leg's bad pair
+    assert not ok and fixed > 1.0 and abs(us - 4.1715e3 / 800) < 1e-9
+    us, fixed, ok = bench.two_point_slope_us(6.8078, 13.5060, 100)           # C4: a long kernel, fixed cost inside 2 % of the body
+    assert ok and abs(us - 66.98) < 0.01
+    us, fixed, ok = bench.two_point_slope_us(2.0683, 4.1764, 400)            # slightly negative fixed cost: measurement noise
+    assert ok and -0.05 < fixed < 0.0
