@@ -4,7 +4,7 @@
 Times the step kernel on each of K separately allocated observation buffers (same state, same moves) and prints each
 buffer's device address next to its time; then the same for sub-allocations at different offsets inside one big block.
 
-    python tools/c4_placement.py [K]
+    python tools/c4_placement.py [K] [brief [N B]]
 """
 import ctypes as C
 import os
@@ -22,7 +22,7 @@ from multiagent_particle_envs_amd.rollout import RandomRollout  # noqa: E402
 def main():
     K = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     brief = len(sys.argv) > 2 and sys.argv[2] == "brief"      # only the K separate allocations, one summary line
-    N, B = 64, 4096
+    N, B = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (64, 4096)     # (any simple_spread shape)
     env = mpe.make_env("simple_spread", batch_size=B, num_agents=N, seed=0, probe_placement=False)
     rr = RandomRollout(env, episode_len=0, pool=4, regenerate=False)
     L = _abi.lib()
