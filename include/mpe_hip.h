@@ -198,7 +198,7 @@ int mpe_random_comm(float *comm, int32_t n_agents, int64_t B, int32_t dim_c, uin
  * than the reference's shapes, simple_world_comm with other than its one obstacle, two food items and
  * two forests, a built-in scenario with a movable landmark).  simple_spread and simple_tag are fused at
  * every size and every team split up to MPE_MAX_ENTITIES entities; simple_adversary and simple_world_comm
- * at the reference's team sizes and a table of others (csrc/mpe_split.hip, kSplitTable: 2-6 agents with
+ * at the reference's team sizes and every other of a grid (csrc/mpe_split.hip, kSplitTable: 2-6 agents with
  * 1-2 adversaries; 1-3 good agents with 2-5 adversaries), 0 beyond it.                                */
 int mpe_step_supported(const MpeScenarioDesc *desc);
 

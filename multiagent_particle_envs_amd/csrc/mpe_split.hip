@@ -1118,12 +1118,18 @@ static const SplitEntry kSplitTable[] = {
     // Team sizes other than the reference's make_world, where its callbacks are written for any (simple_adversary.py:69-139
     // over good_agents / adversaries lists with num_landmarks = num_agents - 1; simple_world_comm.py:126-289 likewise, with
     // its one obstacle, two food items and two forests): A, L, n_adversaries
-    MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 2, 1, 1), MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 4, 3, 1),
-    MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 4, 3, 2), MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 5, 4, 1),
-    MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 6, 5, 2),
-    MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 3, 5, 2), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 4, 5, 2),
-    MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 4, 5, 3), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 5, 5, 3),
-    MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 8, 5, 5),
+    // simple_adversary: 2..6 agents with 1 or 2 adversaries (L = A - 1)
+    MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 2, 1, 1), MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 3, 2, 2),
+    MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 4, 3, 1), MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 4, 3, 2),
+    MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 5, 4, 1), MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 5, 4, 2),
+    MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 6, 5, 1), MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 6, 5, 2),
+    // simple_world_comm: 1..3 good agents with 2..5 adversaries (A = good + adversaries, n_adversaries)
+    MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 3, 5, 2), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 4, 5, 3),
+    MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 5, 5, 4), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 6, 5, 5),
+    MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 4, 5, 2), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 5, 5, 3),
+    MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 7, 5, 5),
+    MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 5, 5, 2), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 6, 5, 3),
+    MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 7, 5, 4), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 8, 5, 5),
 };
 
 static const SplitEntry *find_split(int kind, int A, int L, int nadv) {

@@ -168,6 +168,19 @@ def simple_world_comm(n_good=2, n_adversaries=4):
                 adversary=adv, silent=[False] + [True] * (A - 1), landmark_range=0.9)
 
 
+# Team sizes other than the reference's make_world that the tests cover (name, n_agents, n_adversaries): simple_adversary with 2..6
+# agents and 1 or 2 adversaries, simple_world_comm with 1..3 good agents and 2..5 adversaries (the reference's own 3/1 and 6/4 are
+# the f3_* goldens).  tests/golden/gen_golden_shapes.py records a golden per entry from the reference's callbacks.
+TEAM_SIZE_VARIANTS = [("simple_adversary", a, v) for a in range(2, 7) for v in (1, 2) if v < a and (a, v) != (3, 1)] + \
+                     [("simple_world_comm", g + v, v) for g in (1, 2, 3) for v in (2, 3, 4, 5) if (g, v) != (2, 4)]
+
+
+def team_size_spec(name, n_agents, n_adversaries):
+    if name == "simple_world_comm":
+        return simple_world_comm(n_good=n_agents - n_adversaries, n_adversaries=n_adversaries)
+    return simple_adversary(n_agents=n_agents, n_adversaries=n_adversaries)
+
+
 def by_name(name, **kw):
     return {"simple": simple, "simple_spread": simple_spread, "simple_tag": simple_tag,
             "simple_adversary": simple_adversary, "simple_push": simple_push,

@@ -52,26 +52,21 @@ def factory(name, n_agents, n_adv):
     return make
 
 
-SHAPES = [("simple_adversary", 2, 1), ("simple_adversary", 4, 1), ("simple_adversary", 4, 2), ("simple_adversary", 5, 1),
-          ("simple_adversary", 6, 2),
-          ("simple_world_comm", 3, 2), ("simple_world_comm", 4, 2), ("simple_world_comm", 4, 3), ("simple_world_comm", 5, 3),
-          ("simple_world_comm", 8, 5)]
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle.spec import TEAM_SIZE_VARIANTS as SHAPES, team_size_spec  # noqa: E402  (the list the tests iterate over)
 
 
 def main():
-    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-    from oracle import spec as ospec
     from oracle.mpe_f3 import branch_coverage
     for name, A, nadv in SHAPES:
         wc = name == "simple_world_comm"
-        W, T = (96, 3) if wc else (48, 4)
+        W, T = (64, 3) if wc else (40, 3)
         data = G.record(name, list(range(700, 700 + W)), T, squeeze_every=8 if wc else 0, stage=True,
                         env_factory=factory(name, A, nadv))
         data["n_agents"], data["n_adversaries"] = np.int64(A), np.int64(nadv)
         path = os.path.join(HERE, "shape_%s_%d_%d.npz" % (name, A, nadv))
         np.savez_compressed(path, **data)
-        kw = {"n_agents": A, "n_adversaries": nadv} if not wc else {"n_good": A - nadv, "n_adversaries": nadv}
-        cov = branch_coverage(ospec.by_name(name, **kw), data)
+        cov = branch_coverage(team_size_spec(name, A, nadv), data)
         print("%-40s %7.1f KiB  coverage: %s" % (os.path.basename(path), os.path.getsize(path) / 1024.0,
                                                 ", ".join("%s %.1f%%" % (k, 100 * v) for k, v in cov.items())))
 

@@ -332,10 +332,7 @@ def against_the_fp64_oracle(name, spec_kw, env_kw, B, record_parity, key, min_co
 
 # ---- team sizes other than the reference's make_world (its callbacks are written for any: simple_adversary.py:69-139,
 # simple_world_comm.py:126-289); goldens: tests/golden/gen_golden_shapes.py --------------------------------------------------
-SHAPES = [("simple_adversary", 2, 1), ("simple_adversary", 4, 1), ("simple_adversary", 4, 2), ("simple_adversary", 5, 1),
-          ("simple_adversary", 6, 2),
-          ("simple_world_comm", 3, 2), ("simple_world_comm", 4, 2), ("simple_world_comm", 4, 3), ("simple_world_comm", 5, 3),
-          ("simple_world_comm", 8, 5)]
+from oracle.spec import TEAM_SIZE_VARIANTS as SHAPES  # noqa: E402  (2..6 agents x 1..2 adversaries; 1..3 prey x 2..5 predators)
 SHAPE_IDS = ["%s-%d-%d" % s for s in SHAPES]
 
 

@@ -173,15 +173,15 @@ def test_error_reporting():
     assert L.mpe_step(C.byref(desc), C.byref(b), 64, None) == -1 and b"pos" in L.mpe_last_error()
     b.pos, b.vel = env.world.pos.data_ptr(), env.world.vel.data_ptr()
     assert L.mpe_step(C.byref(desc), C.byref(b), 64, None) == -1 and b"act" in L.mpe_last_error()
-    # a shape no kernel was built for (simple_adversary away from the reference's team sizes): the C ABI says so
+    # a shape no kernel was built for (simple_adversary beyond the table of team sizes): the C ABI says so
     # (mpe_step_supported 0, mpe_step MPE_EUNSUPPORTED) and the env keeps the scenario's torch callbacks around
     # mpe_world_step instead
-    enva = make_env("simple_adversary", batch_size=8, num_agents=5, num_adversaries=2)
-    assert not enva.fused and len(enva.reset()) == 5
-    da = enva.world.scenario_desc(_abi.MPE_SCN_ADVERSARY, 2)
+    enva = make_env("simple_adversary", batch_size=8, num_agents=7, num_adversaries=3)
+    assert not enva.fused and len(enva.reset()) == 7
+    da = enva.world.scenario_desc(_abi.MPE_SCN_ADVERSARY, 3)
     assert L.mpe_step_supported(C.byref(da)) == 0
-    obs = torch.zeros(8 * int(da.obs_off[5]), device="cuda")
-    act = torch.zeros((5, 8, 5), device="cuda")
+    obs = torch.zeros(8 * int(da.obs_off[7]), device="cuda")
+    act = torch.zeros((7, 8, 5), device="cuda")
     b2 = _abi.MpeBuffers()
     b2.pos, b2.vel, b2.obs, b2.act = enva.world.pos.data_ptr(), enva.world.vel.data_ptr(), obs.data_ptr(), act.data_ptr()
     b2.choice = enva.world.choice_i32.data_ptr()

@@ -200,16 +200,20 @@ def test_fused_kernels_cover_the_reference_shapes_and_other_shapes_fall_back():
     assert big.fused and big.observation_space[0].shape == (4 + 40 + 138 + 60,)
     assert big.observation_space[69].shape == (4 + 40 + 138 + 58,)
     assert env_of("simple_tag", num_adversaries=2).fused
-    # simple_adversary / simple_world_comm: the reference's team sizes and a table of others (mpe_split.hip); beyond it, torch callbacks
-    for kw in ({"num_agents": 2}, {"num_agents": 4}, {"num_agents": 4, "num_adversaries": 2}, {"num_agents": 5},
-               {"num_agents": 6, "num_adversaries": 2}):
-        assert env_of("simple_adversary", **kw).fused, kw
-    for good, adv in ((1, 2), (2, 2), (1, 3), (2, 3), (3, 5)):
-        e = env_of("simple_world_comm", num_good_agents=good, num_adversaries=adv)
-        assert e.fused and e.n == good + adv, (good, adv)
-        assert e.observation_space[0].shape == (4 + 10 + 2 * (good + adv - 1) + 2 * good + 2 + 4,)
-        assert e.observation_space[adv].shape == (4 + 10 + 2 * (good + adv - 1) + 2 + 2 * (good - 1),)
-    assert not env_of("simple_adversary", num_agents=5, num_adversaries=2).fused
+    # simple_adversary / simple_world_comm: the reference's team sizes and a grid of others (mpe_split.hip: 2..6 agents with 1..2
+    # adversaries; 1..3 good agents with 2..5 adversaries); beyond it, torch callbacks around mpe_world_step
+    from oracle.spec import TEAM_SIZE_VARIANTS
+    for name, A, nadv in TEAM_SIZE_VARIANTS:
+        if name == "simple_adversary":
+            e = env_of(name, num_agents=A, num_adversaries=nadv)
+            assert e.fused and e.n == A, (name, A, nadv)
+        else:
+            good, adv = A - nadv, nadv
+            e = env_of(name, num_good_agents=good, num_adversaries=adv)
+            assert e.fused and e.n == A, (good, adv)
+            assert e.observation_space[0].shape == (4 + 10 + 2 * (A - 1) + 2 * good + 2 + 4,)
+            assert e.observation_space[adv].shape == (4 + 10 + 2 * (A - 1) + 2 + 2 * (good - 1),)
+    assert not env_of("simple_adversary", num_agents=7, num_adversaries=3).fused
     assert not env_of("simple_world_comm", num_good_agents=5, num_adversaries=6).fused
     d = big.world.scenario_desc(_abi.MPE_SCN_GENERIC)
     assert _abi.lib().mpe_step_supported(C.byref(d)) == 0

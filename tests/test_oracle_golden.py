@@ -282,16 +282,8 @@ def test_f3_goldens_populate_every_branch(name, golden):
 
 
 # ---- team sizes other than the reference's make_world (tests/golden/gen_golden_shapes.py) ----------------------------------
-SHAPES = [("simple_adversary", 2, 1), ("simple_adversary", 4, 1), ("simple_adversary", 4, 2), ("simple_adversary", 5, 1),
-          ("simple_adversary", 6, 2),
-          ("simple_world_comm", 3, 2), ("simple_world_comm", 4, 2), ("simple_world_comm", 4, 3), ("simple_world_comm", 5, 3),
-          ("simple_world_comm", 8, 5)]
-
-
-def shape_spec(name, A, nadv):
-    if name == "simple_world_comm":
-        return ospec.by_name(name, n_good=A - nadv, n_adversaries=nadv)
-    return ospec.by_name(name, n_agents=A, n_adversaries=nadv)
+SHAPES = ospec.TEAM_SIZE_VARIANTS
+shape_spec = ospec.team_size_spec
 
 
 @pytest.mark.parametrize("name,A,nadv", SHAPES, ids=["%s-%d-%d" % s for s in SHAPES])
