@@ -53,10 +53,10 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _drop_temps(d):
-    """-save-temps leaves ~25 MB of intermediates per source; only the device assembly (*-gfx950.s) is wanted."""
+def _drop_temps(d, keep_asm=True):
+    """-save-temps leaves ~25 MB of intermediates per source; only the product build's device assembly (*-gfx950.s) is wanted."""
     import glob
-    for pat in ("*.bc", "*.hipi", "*.out", "*.resolution.txt", "*.hipfb", "*-host-*.s", "*-gfx950.o"):
+    for pat in ("*.bc", "*.hipi", "*.out", "*.resolution.txt", "*.hipfb", "*-host-*.s", "*-gfx950.o") + (() if keep_asm else ("*-gfx950.s",)):
         for f in glob.glob(os.path.join(d, pat)):
             try:
                 os.remove(f)
@@ -120,7 +120,7 @@ def build(force=False, verbose=True, variants=True):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     for tag in STRESS_VARIANTS:
-        _drop_temps(os.path.join(OBJ, tag))
+        _drop_temps(os.path.join(OBJ, tag), keep_asm=False)
     for tag, vo in todo:
         vlib = variant_lib(tag)
         vobjs = [vo.get(os.path.basename(x), x) for x in objs]
