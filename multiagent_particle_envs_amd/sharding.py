@@ -82,7 +82,7 @@ class Rendezvous(object):
         self.rank = int(os.environ.get("RANK", "0") if rank is None else rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1") if world is None else world)
         self.device = torch.device(device) if device is not None else None
-        self.backend, self.note, self._nccl, self._abandoned = "none", None, None, False
+        self.backend, self.note, self._nccl, self._abandoned, self._stuck = "none", None, None, False, False
         if self.world == 1:
             return
         if backend not in ("auto", "nccl", "gloo"):
@@ -104,31 +104,50 @@ class Rendezvous(object):
                 reasons = self.gather(why)
                 self.note = "RCCL not adopted (%s); barrier over gloo" % "; ".join(
                     "rank %d: %s" % (r, w) for r, w in enumerate(reasons) if w)
-                self._abandoned = self._nccl is not None
+                self._abandoned = self._nccl is not None or self._stuck
                 self._nccl = None
                 if backend == "nccl":
                     raise RuntimeError(self.note)
 
     def _try_nccl(self, deadline_s):
-        """One RCCL subgroup + one all-reduce under a deadline.  -> (ok, reason)."""
+        """One RCCL subgroup + one all-reduce under a deadline.  -> (ok, reason).
+        The bring-up runs in a helper thread: communicator creation happens inside the first collective CALL (not behind
+        its async handle), so a bring-up that hangs would otherwise hang this process before any deadline could be looked
+        at.  A thread that does not come back is left behind (daemon), the vote is "no", and close() leaves the process
+        without tearing the half-made communicator down."""
+        import threading
         # a hung RCCL op must not take the process down when the deadline gives up on it
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
-        try:
-            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=max(deadline_s * 4, 120.0)))
-            self._nccl = g
-            t = torch.ones(1, device=self.device)
-            w = dist.all_reduce(t, group=g, async_op=True)
-            t_end = time.time() + deadline_s
-            while not w.is_completed():
-                if time.time() > t_end:
-                    return False, "RCCL all-reduce did not complete in %.0f s" % deadline_s
-                time.sleep(0.02)
-            torch.cuda.synchronize(self.device)
-            if int(t.item()) != self.world:
-                return False, "RCCL all-reduce returned %r" % (t.item(),)
-            return True, None
-        except Exception as e:   # duplicate GPU, no P2P, missing IPC mode, ...: the reason is reported, not raised
-            return False, "%s: %s" % (type(e).__name__, str(e).strip().splitlines()[0][:200] if str(e).strip() else "")
+        result = {}
+
+        def bring_up():
+            try:
+                torch.cuda.set_device(self.device)
+                g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=max(deadline_s * 4, 120.0)))
+                self._nccl = g
+                t = torch.ones(1, device=self.device)
+                w = dist.all_reduce(t, group=g, async_op=True)
+                t_end = time.time() + deadline_s
+                while not w.is_completed():
+                    if time.time() > t_end:
+                        result["v"] = (False, "RCCL all-reduce did not complete in %.0f s" % deadline_s)
+                        return
+                    time.sleep(0.02)
+                torch.cuda.synchronize(self.device)
+                if int(t.item()) != self.world:
+                    result["v"] = (False, "RCCL all-reduce returned %r" % (t.item(),))
+                    return
+                result["v"] = (True, None)
+            except Exception as e:   # duplicate GPU, no P2P, missing IPC mode, ...: the reason is reported, not raised
+                result["v"] = (False, "%s: %s" % (type(e).__name__,
+                                                  str(e).strip().splitlines()[0][:200] if str(e).strip() else ""))
+        th = threading.Thread(target=bring_up, name="rccl-bring-up", daemon=True)
+        th.start()
+        th.join(deadline_s + 10.0)
+        if th.is_alive() or "v" not in result:
+            self._stuck = True
+            return False, "RCCL bring-up did not return in %.0f s" % (deadline_s + 10.0)
+        return result["v"]
 
     def barrier(self):
         _sync(self.device)
