@@ -489,6 +489,11 @@ static const NarrowEntry kNarrowTable[] = {
     MPE_SCN_ENTRY(MPE_SCN_TAG, 4, 2, 3), MPE_SCN_ENTRY(MPE_SCN_TAG, 2, 1, 1),
     MPE_SCN_ENTRY(MPE_SCN_TAG, 6, 3, 4),
     MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 3, 2, 1), MPE_SCN_ENTRY(MPE_SCN_PUSH, 2, 2, 1),
+    // simple_adversary at the other team sizes mpe_split.hip has (the second implementation the bit-identity test holds them to)
+    MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 2, 1, 1), MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 3, 2, 2),
+    MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 4, 3, 1), MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 4, 3, 2),
+    MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 5, 4, 1), MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 5, 4, 2),
+    MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 6, 5, 1), MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 6, 5, 2),
     MPE_GEN_ENTRY(1, 0), MPE_GEN_ENTRY(1, 1), MPE_GEN_ENTRY(1, 2), MPE_GEN_ENTRY(1, 3),
     MPE_GEN_ENTRY(2, 0), MPE_GEN_ENTRY(2, 1), MPE_GEN_ENTRY(2, 2), MPE_GEN_ENTRY(2, 3), MPE_GEN_ENTRY(2, 4),
     MPE_GEN_ENTRY(3, 0), MPE_GEN_ENTRY(3, 1), MPE_GEN_ENTRY(3, 2), MPE_GEN_ENTRY(3, 3), MPE_GEN_ENTRY(3, 4),

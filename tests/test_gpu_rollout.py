@@ -22,7 +22,13 @@ def stream():
 
 @pytest.mark.parametrize("name,kw,B", [("simple", {}, 3000), ("simple_spread", {}, 5000), ("simple_tag", {}, 4097),
                                        ("simple_spread", {"num_agents": 5}, 777),
-                                       ("simple_adversary", {}, 2000), ("simple_push", {}, 1111)])
+                                       ("simple_adversary", {}, 2000), ("simple_push", {}, 1111),
+                                       # simple_adversary at other team sizes: both families have them
+                                       ("simple_adversary", {"num_agents": 2}, 1000),
+                                       ("simple_adversary", {"num_agents": 3, "num_adversaries": 2}, 650),
+                                       ("simple_adversary", {"num_agents": 4, "num_adversaries": 2}, 900),
+                                       ("simple_adversary", {"num_agents": 5}, 700),
+                                       ("simple_adversary", {"num_agents": 6, "num_adversaries": 2}, 500)])
 def test_split_and_thread_kernels_bit_identical(name, kw, B):
     rs = np.random.RandomState(1)
     outs = {}
