@@ -262,7 +262,9 @@ static int run(const char *what, bool phys, bool out, const MpeScenarioDesc *d, 
     use = &dd;
   }
   const bool comm_kind = kind >= MPE_SCN_SPEAKER_LISTENER;   // these exist as wave-per-agent kernels only
-  if (out && (phys || comm_kind) && d->n_agents + d->n_landmarks <= mpe::kNarrowMaxE &&
+  // (an observe-only call goes to the thread-per-world kernel where one exists -- no barrier, no exchange block needed --
+  //  and to the wave-per-agent kernel's observe half for the shapes that exist there only)
+  if (out && (phys || comm_kind || !use_narrow(use)) && d->n_agents + d->n_landmarks <= mpe::kNarrowMaxE &&
       (comm_kind || impl != StepImpl::Thread) &&
       mpe::split_supports(kind, d->n_agents, d->n_landmarks, d->n_adversaries)) {
     // the fused step: wave-per-agent / lane-per-world (mpe_split.hip)

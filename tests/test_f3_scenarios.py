@@ -391,6 +391,32 @@ def test_other_team_sizes_against_the_fp64_oracle_at_size(name, A, nadv, record_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,A,nadv", SHAPES, ids=SHAPE_IDS)
+def test_other_team_sizes_reset_and_auto_reset(name, A, nadv):
+    """env.reset() (mpe_observe: the kernels' observe half) and the device-side auto-reset at the horizon, fused against the
+    generic path's torch observation() on the same seeded worlds."""
+    _, env_kw = shape_kw(name, A, nadv)
+    B = 300
+    ef = mpe.make_env(name, batch_size=B, max_episode_steps=2, auto_reset=True, seed=9, **env_kw)
+    eg = mpe.make_env(name, batch_size=B, fused=False, **env_kw)
+    assert ef.fused and not eg.fused
+    seeds = list(range(500, 500 + B))
+    of, og = ef.reset(seeds=seeds), eg.reset(seeds=seeds)
+    for i in range(A):
+        close(np_(of[i]), np_(og[i]), what="reset obs%d" % i)
+    rs = np.random.RandomState(3)
+    ef.step(random_actions(ef, rs, B))
+    o, _, d, _ = ef.step(random_actions(ef, rs, B))          # the horizon: every world restarts, rows of the new episode
+    assert all(np_(x).all() for x in d)
+    eg.world.set_state(*ef.world.get_state())
+    set_choices(eg, get_choices(ef))
+    for i, agent in enumerate(eg.world.agents):
+        agent.state.c = torch.zeros_like(agent.state.c)
+    for i in range(A):
+        close(np_(o[i]), np_(eg._get_obs(eg.agents[i])), what="auto-reset obs%d" % i)
+
+
+@pytest.mark.gpu
 def test_a_team_size_without_a_kernel_takes_the_generic_path():
     env = mpe.make_env("simple_world_comm", batch_size=64, num_good_agents=5, num_adversaries=6)
     assert not env.fused

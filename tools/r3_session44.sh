@@ -1,0 +1,7 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}; TAG=${1:-r3s44}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+rm -f $R/gpurun_out/parity_r3.json
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
+cp $R/gpurun_out/parity_r3.json $O/ 2>/dev/null
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
