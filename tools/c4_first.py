@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """C4 placement: is the FIRST large allocation of a process the fast one, and does that survive a larger block?
-    python tools/c4_first.py single|double|triple     (one process each; tools/r3_session12.sh interleaves them)"""
+    python tools/c4_first.py single|double|triple     (one process each; tools/sessions/r3_session12.sh interleaves them)"""
 import ctypes as C
 import os
 import sys
