@@ -586,7 +586,33 @@ def config_leg_subprocess(key, args, floor_us, dev_index):
     return json.loads(lines[-1])
 
 
-def box_fingerprint(torch, dev):
+def gpu_identity(rec):
+    """What tells two GPUs apart in a rank record: the device UUID, else the PCI address (None when neither is known)."""
+    return rec.get("uuid") or rec.get("pci")
+
+
+def duplicate_gpus(recs):
+    """Ranks that drive the same physical GPU, as a readable string ('' when every rank has its own).  A rank whose GPU has
+    no identity at all (no UUID, no PCI address) cannot be told apart and is reported too."""
+    seen, bad = {}, []
+    for r in recs:
+        k = gpu_identity(r)
+        if k is None:
+            bad.append("rank %d: no UUID / PCI address" % r["rank"])
+        elif k in seen:
+            bad.append("ranks %d and %d on %s" % (seen[k], r["rank"], k))
+        else:
+            seen[k] = r["rank"]
+    return "; ".join(bad)
+
+
+def per_gpu_stats(recs):
+    """min / median / max over ranks of each rank's own median rate (env-steps/s per GPU)."""
+    v = sorted(r["env_steps_per_s"]["median"] for r in recs)
+    return {"min": v[0], "median": v[len(v) // 2], "max": v[-1], "unit": "env-steps/s per GPU", "ranks": len(v)}
+
+
+def box_fingerprint(torch, dev, smi=True):
     """What this rank's GPU is and how the box is set up: device properties from the runtime, clocks / power cap /
     partition modes / driver from rocm-smi when it answers (C4's 20 % box-to-box spread, DESIGN 2.7, needs a label)."""
     fp = {}
@@ -596,12 +622,17 @@ def box_fingerprint(torch, dev):
                    "hbm_bytes": pr.total_memory, "uuid": str(getattr(pr, "uuid", "")) or None,
                    "clock_rate_khz": getattr(pr, "clock_rate", None), "memory_clock_rate_khz": getattr(pr, "memory_clock_rate", None),
                    "l2_bytes": getattr(pr, "L2_cache_size", None)})
+        if getattr(pr, "pci_bus_id", None) is not None:
+            fp["pci"] = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
         fp["hip"] = torch.version.hip
     except Exception as e:
         fp["error"] = repr(e)
+    if not smi:
+        return fp
     try:
         import subprocess
-        r = subprocess.run(["rocm-smi", "-d", str(dev.index), "--showclocks", "--showpower", "--showmaxpower", "--showmemorypartition",
+        # (rocm-smi numbers the node's cards, whatever HIP_VISIBLE_DEVICES says: a self-spawned rank knows its card as MPE_GPU_ID)
+        r = subprocess.run(["rocm-smi", "-d", os.environ.get("MPE_GPU_ID", str(dev.index)), "--showclocks", "--showpower", "--showmaxpower", "--showmemorypartition",
                             "--showcomputepartition", "--showdriverversion", "--showperflevel", "--json"],
                            capture_output=True, text=True, timeout=30)
         d = json.loads(r.stdout[r.stdout.index("{"):])
@@ -639,6 +670,9 @@ def parse_args(argv=None):
                     help="what carries the N>1 barrier: auto = RCCL when every rank can bring it up, else gloo (the step "
                          "path has no collective either way)")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--device-map", default=None, metavar="I,J,...",
+                    help="rank r drives visible GPU number <r-th entry> instead of GPU r (ranks that share a GPU are refused "
+                         "unless --all-ranks-on-gpu0)")
     ap.add_argument("--dump-state", default=None, metavar="DIR",
                     help="before timing: run the rollout's episode-0 reset + step 0 and save this rank's pos / vel / obs / "
                          "rew to DIR/rank<r>.npz (the multi-rank rehearsal test compares them with one big batch)")
@@ -652,6 +686,16 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def device_map(args, n):
+    """--device-map as a list of n visible-GPU numbers, or None."""
+    if not args.device_map:
+        return None
+    m = [int(x) for x in args.device_map.split(",") if x.strip() != ""]
+    if len(m) != n or min(m) < 0:
+        raise SystemExit("bench.py: --device-map needs %d non-negative entries (one per rank), got %r" % (n, args.device_map))
+    return m
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one per GPU), relay rank 0's
     line.  Never measures fewer GPUs than were asked for: too few visible GPUs, a failed rank or a line whose n_gpus is
@@ -660,13 +704,15 @@ def launch_ranks(args):
     from multiagent_particle_envs_amd import sharding
     n = args.gpus
     seen = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if seen < (1 if args.all_ranks_on_gpu0 else n):
+    dmap = device_map(args, n)
+    if seen < (1 if args.all_ranks_on_gpu0 else (max(dmap) + 1 if dmap is not None else n)):
         sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this node -- refusing to measure fewer GPUs "
                          "than requested (run with --gpus <= %d, or --all-ranks-on-gpu0 for the one-GPU rehearsal)\n"
                          % (n, seen, max(seen, 1)))
         return 2
     sys.stderr.write("bench.py: --gpus %d without a launcher (WORLD_SIZE unset): starting %d ranks, one per GPU\n" % (n, n))
-    rc, out = sharding.spawn_local_ranks([os.path.abspath(__file__)] + sys.argv[1:], n, one_device=args.all_ranks_on_gpu0)
+    rc, out = sharding.spawn_local_ranks([os.path.abspath(__file__)] + sys.argv[1:], n, one_device=args.all_ranks_on_gpu0,
+                                         gpu_slots=dmap)
     lines = [l for l in out.splitlines() if l.startswith("{")]
     if rc != 0 or len(lines) != 1:
         sys.stderr.write("bench.py: the %d-rank job failed (exit %s, %d JSON lines)\n%s\n" % (n, rc, len(lines), out[-2000:]))
@@ -689,6 +735,7 @@ def main():
     if args.gpus > 1 and env_world == 1:
         sys.exit(launch_ranks(args))
 
+    t_start = time.time()
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = env_world
@@ -696,6 +743,8 @@ def main():
         raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d: launch with --nproc-per-node == --gpus (or drop the launcher: "
                          "`python bench.py --gpus N` starts its own ranks)" % (world, args.gpus))
     local = 0 if args.all_ranks_on_gpu0 else int(os.environ.get("LOCAL_RANK", "0"))
+    if device_map(args, world) is not None and not os.environ.get("MPE_SELF_SPAWNED") and not args.all_ranks_on_gpu0:
+        local = device_map(args, world)[rank]      # (self-spawned ranks were handed that GPU as their only one: cuda:0)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the step path has no CPU fallback)")
     if local >= torch.cuda.device_count():
@@ -705,15 +754,29 @@ def main():
 
     import multiagent_particle_envs_amd as mpe
     from multiagent_particle_envs_amd import sharding
+    # this rank's place among the node's ranks (self-spawned ranks see ONE GPU each and carry their slot in MPE_LOCAL_RANK;
+    # under a launcher the slot is LOCAL_RANK) -> an even slice of the allowed CPUs for its Python host
+    slot = int(os.environ.get("MPE_LOCAL_RANK", os.environ.get("LOCAL_RANK", "0")) or 0)
+    cpus = sharding.pin_rank(slot, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)) or world)) if world > 1 else None
     rv = sharding.Rendezvous(rank, world, dev, backend=args.backend)
     if rv.note and rank == 0:
         sys.stderr.write("bench.py: %s\n" % rv.note)
+
+    def leave(status=0):
+        """End of this rank: flush, close the rendezvous; a job that abandoned an RCCL communicator leaves through
+        os._exit WITH ITS STATUS (tearing the communicator down may block) -- decided here, not inside the library."""
+        sys.stdout.flush()
+        sys.stderr.flush()
+        if not rv.close():
+            os._exit(status)
+        if status:
+            sys.exit(status)
 
     B, K, W, EP = args.batch, args.steps, args.warmup, args.episode_len
     leg = Leg(mpe, args.scenario, args.agents, B, EP, rank, args.streams, args.seed, args.generic)
     if not leg.env.fused:
         bench_generic(args, leg.env, dev, rank, world, rv)
-        return rv.close()
+        return leave(0)
     A, Lm = leg.A, leg.Lm
     obs_total, bytes_step, compulsory_roll, kname = leg.geometry()
     can_fuse = A + Lm <= 16 or args.scenario in ("simple_spread", "simple_tag")
@@ -732,6 +795,24 @@ def main():
     def stats(rate):
         return {"min": rate[0], "median": rate[1], "max": rate[2], "unit": "env-steps/s per GPU"}
 
+    # ---- N > 1: every rank must be driving a GPU of its own -- checked BEFORE anything is measured --------------------
+    me = box_fingerprint(torch, dev, smi=False)
+    ids = rv.gather({"rank": rank, "uuid": me.get("uuid"), "pci": me.get("pci"), "gpu_env": os.environ.get("HIP_VISIBLE_DEVICES")})
+    dup = duplicate_gpus(ids) if world > 1 else ""
+    if dup and not args.all_ranks_on_gpu0:
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but ranks share a GPU (%s) -- a mis-mapped job would print n_gpus=%d for fewer "
+                             "GPUs; refusing (use --all-ranks-on-gpu0 for the one-GPU rehearsal)\n" % (world, dup, world))
+        return leave(3)
+    solo_rate = None
+    if world > 1:
+        # rank 0 runs one repeat of the SAME timed region alone (the others wait at a barrier): what one GPU of this node
+        # does when its neighbours are idle -- the reference point of the N-GPU line (config.scaling_diagnostic)
+        lone = sharding.Rendezvous(0, 1, dev)
+        if rank == 0:
+            d1, R1, _, _ = leg.timed(torch, lone, dev, args.mode, args.protocol, K, W, 1, min(args.region_ms, 1000.0))
+            solo_rate = B * K * R1 / d1
+        rv.barrier()
     dt, R, ev_ms, rate = leg.timed(torch, rv, dev, args.mode, args.protocol, K, W, args.repeats, args.region_ms)
     k_us = leg.kernel_time_us(torch, args.mode)
     head_timing = leg.last_kernel_timing
@@ -823,8 +904,9 @@ def main():
         extra["configs"] = cfgs
 
     # ---- per-rank records: which GPU each rank drove, its own rate and kernel time (gathered over the bookkeeping group) ----
-    box = box_fingerprint(torch, dev)
-    recs = rv.gather({"rank": rank, "device": "cuda:%d" % local, "name": box.get("name"), "uuid": box.get("uuid"),
+    box = box_fingerprint(torch, dev, smi=(rank == 0))
+    recs = rv.gather({"rank": rank, "device": "cuda:%d" % local, "gpu_env": os.environ.get("HIP_VISIBLE_DEVICES"),
+                      "name": box.get("name"), "uuid": box.get("uuid"), "pci": box.get("pci"), "cpus": cpus,
                       "world_offset": rank * B, "kernel_us_per_launch": k_us, "launch_floor_us": floor_us,
                       "env_steps_per_s": stats(rate)})
     if rank == 0:
@@ -842,6 +924,12 @@ def main():
             "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": headline_roof["achieved"] / copy_gbs,
             "measured_fill_GBps": fill_gbs,
             "timed_region_us_per_step": ev_ms * 1e3 / (K * R),
+            # the same algorithmic bytes over the TIMED REGION's time per step (fresh move draws and resets included): the
+            # end-to-end fraction next to the kernel-only `frac` -- both are printed, the smaller one is the job's
+            "frac_timed_region": bytes_step * B / (dt / (K * R)) / 1e9 / HBM_PEAK_GBS,
+            "achieved_timed_region": bytes_step * B / (dt / (K * R)) / 1e9,
+            "frac_definition": "frac = algorithmic bytes per launch / kernel_us_per_launch (two-point slope of resident-move, "
+                               "no-reset launches) / peak; frac_timed_region = algorithmic bytes per step / ms_per_step / peak",
             "note": "achieved = algorithmic bytes per launch / kernel_us_per_launch; kernel_us_per_launch = (HIP-event time of 2n "
                     "back-to-back dependent step launches - that of n) / n on the launch stream, best of 3 each, n = 400 (the "
                     "rocprofv3 kernel-trace summary of the same command is under profiles/); launch_floor_us = the same for a 64-world bookkeeping "
@@ -851,7 +939,8 @@ def main():
             "metric": "env steps/sec (whole node), %s N=%d, batch=%d per GPU" % (args.scenario, A, B),
             "value": B * K * R * world / dt, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt * 1e3 / (K * R), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "timed_region_s": dt, "timed_steps": K * R,
+            "per_gpu_value": per_gpu_stats(recs),
             "config": {"workload": "%s A=%d L=%d, %d worlds/GPU, one-hot random moves (%s), device reset every %d steps"
                                    % (args.scenario, A, Lm, B,
                                       "fresh for every step: one block draw per episode inside the timed region"
@@ -864,6 +953,14 @@ def main():
                        "launcher": "torch.distributed.run / env" if world > 1 and not os.environ.get("MPE_SELF_SPAWNED") else
                                    ("self-spawned (bench.py started the ranks)" if world > 1 else "single process"),
                        "ranks_seen": len(recs), "ranks": recs,
+                       "distinct_gpus": len(set(gpu_identity(r) for r in recs)),
+                       "barrier_fallbacks": rv.barrier_fallbacks,
+                       "scaling_diagnostic": None if solo_rate is None else {
+                           "what": "rank 0 alone (its neighbours idle at a barrier), one repeat of the same timed region, inside this "
+                                   "job; value_over_n_times_rank0_solo = value / (n_gpus x that rate)",
+                           "rank0_solo_env_steps_per_s": solo_rate,
+                           "value_over_n_times_rank0_solo": (B * K * R * world / dt) / (world * solo_rate)},
+                       "wall_s_since_start": time.time() - t_start,
                        "placement_probe": head_probe},
             "roofline": headline_roof,
             "repeats": stats(rate),
@@ -877,6 +974,8 @@ def main():
                                              "simple_tag; the batched oracle of the other scenarios is test infrastructure only"}
         elif not args.no_cpu_baseline:
             procs = usable_cores()
+            if world > 1:      # the N-GPU line keeps the baseline but not its length: the job's wall time is bounded
+                args.cpu_seconds = min(args.cpu_seconds, 3.0)
             agg, single = cpu_baseline(args.scenario, leg.okw, args.cpu_seconds, procs)
             refkey = {"simple": "simple", "simple_tag": "simple_tag"}.get(
                 args.scenario, "simple_spread_n%d" % A if args.scenario == "simple_spread" else None)
@@ -900,7 +999,7 @@ def main():
                               "thread, fp64), %d threads x %.0f s" % (procs, min(args.cpu_seconds, 4.0))}
         print(json.dumps(out))
         sys.stdout.flush()
-    rv.close()
+    leave(0)
 
 
 if __name__ == "__main__":

@@ -312,8 +312,12 @@ class World(object):
                 raise _abi.MpeError("set_state: vel holds %d entities (agents: %d, all: %d)" % (v.shape[1], len(self.agents), len(self.entities)))
             self._vel_all[:v.shape[1]].copy_(v.permute(1, 2, 0))
 
-    def get_state(self, all_entities=False):
-        """(pos [B,E,2], vel [B,A,2]) as host NumPy arrays; all_entities: vel [B,E,2] (movable landmarks)."""
+    def get_state(self, all_entities=None):
+        """(pos [B,E,2], vel [B,A,2]) as host NumPy arrays; all_entities: vel [B,E,2].  Default: the agents' rows -- and
+        every entity's as soon as a landmark is movable (its velocity is state, core.py:158-169), so that
+        `set_state(*get_state())` restores the world either way."""
+        if all_entities is None:
+            all_entities = self.n_dynamic > len(self.agents)
         v = self._vel_all if all_entities else self.vel
         return (self.pos.permute(2, 0, 1).contiguous().cpu().numpy(), v.permute(2, 0, 1).contiguous().cpu().numpy())
 

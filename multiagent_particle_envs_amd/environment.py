@@ -311,13 +311,17 @@ class MultiAgentEnv(object):
         stalls: where the driver put the pages in HBM).  So a handful of candidates is allocated, the real step kernel is
         timed on each (state and outputs in scratch copies: the world does not move) until `n` of them take the rows at
         < 1.2 x the time of a plain fill of the block (at most PROBE_CANDIDATES), and the fastest `n` are kept.  Costs a few
-        milliseconds and, transiently, that many blocks, once per env; results do not depend on it."""
+        milliseconds and, transiently, that many blocks (peak: PROBE_CANDIDATES x the block, 6.4 GB for N = 64 at 4096 worlds;
+        the rejected ones are returned to the device with empty_cache()), once per env; results do not depend on it."""
         w = self.world
         nfl = int(self._obs_off[-1]) * w.batch_size
         # (only the wave-per-world kernels -- more than 16 entities, dozens of agent blocks written side by side -- are
         #  placement-sensitive; the 1M-world N=3 step writes three contiguous 75 MB blocks and is not: 68-70 us anywhere)
+        # (not for an env that allocates fresh outputs on every call -- it never uses the placed buffers -- and not under
+        #  stream capture: the probe synchronises on events)
         if not self.probe_placement or not self.fused or nfl * 4 < self.PROBE_MIN_BYTES or len(w.entities) <= 16 or \
-                self._kind not in (_abi.MPE_SCN_SPREAD, _abi.MPE_SCN_TAG):
+                self._kind not in (_abi.MPE_SCN_SPREAD, _abi.MPE_SCN_TAG) or self.fresh_outputs or \
+                torch.cuda.is_current_stream_capturing():
             return [None] * n
         dev = w.device
         first = torch.zeros(nfl, dtype=torch.float32, device=dev)
@@ -363,6 +367,11 @@ class MultiAgentEnv(object):
         for k in keep:
             if k is not None:
                 k.zero_()
+        # the losers go back to the DEVICE, not just to torch's caching allocator (up to 16 blocks of 403 MB at N = 64,
+        # 4096 worlds: 6.4 GB peak, transient) -- the kept blocks are live tensors and stay where they are
+        del cands, first, scratch, pos, vel, b, timed
+        torch.cuda.synchronize(dev)
+        torch.cuda.empty_cache()
         return keep
 
     def _stream(self):
@@ -478,7 +487,8 @@ class MultiAgentEnv(object):
         b.act = act.data_ptr() if act is not None else None
         b.ids = ids.data_ptr() if ids is not None else None
         b.u = None
-        out.act_ptr = None      # (the fast path's note of what b.act holds: re-established there)
+        for o in self._sets:    # (the fast path's note of what each set's b.act holds: re-established there.  EVERY set: whatever
+            o.act_ptr = None    #  sent this call down the slow path -- a rollout that edited the bufs, a flag flipped -- may have touched both)
         # arm the fast path for the next call with this very tensor: zero-copy moves, nothing evaluated in Python afterwards
         if act is action_n and not self._comm_kind and not self.fresh_outputs and not self.numpy_io and \
                 not self.max_episode_steps and not (self._py_obs or self._py_reward or self._py_done or self._py_info):
@@ -751,7 +761,7 @@ class GraphedStep(object):
         as_list = not torch.is_tensor(action_n)
         self.action_n = [torch.as_tensor(a, device=dev).clone() for a in action_n] if as_list else action_n.clone()
         fresh, env.fresh_outputs = env.fresh_outputs, True     # the graph owns its outputs
-        pos, vel = env.world.pos.clone(), env.world.vel.clone()
+        pos, vel = env.world.pos.clone(), env.world._vel_all.clone()     # every entity's row: movable landmarks are integrated too
         comm = [a.state.c.clone() if torch.is_tensor(a.state.c) else a.state.c for a in env.world.agents]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -768,7 +778,7 @@ class GraphedStep(object):
         torch.cuda.current_stream(dev).wait_stream(side)
         self._comm_state = [a.state.c for a in env.world.agents]   # the tensors the graph writes (resets re-point state.c)
         env.world.pos.copy_(pos)                   # the warm-up steps did not happen
-        env.world.vel.copy_(vel)
+        env.world._vel_all.copy_(vel)
         for a, c in zip(env.world.agents, comm):
             if torch.is_tensor(c) and torch.is_tensor(a.state.c):
                 a.state.c.copy_(c)

@@ -104,6 +104,7 @@ class RandomRollout(object):
             move = self.pool[self.t % len(self.pool)].data_ptr()
             b.act, b.ids = (None, move) if self.action_ids else (move, None)
             b.u = None
+            out.act_ptr = None      # MultiAgentEnv.step's fast path must not trust its note of what b.act holds
             if self.pool_c is not None:
                 b.comm = self.pool_c[self.t % len(self.pool)].data_ptr()
             _abi.check(L.mpe_step(C.byref(desc), C.byref(b), B, st), "mpe_step")
@@ -122,6 +123,9 @@ class RandomRollout(object):
         per-world step counters follow the rollout's episode clock."""
         env = self.env
         env._scenario_state_stale = True
+        env._fast_acts.clear()      # step()'s fast path re-validates the caller's action tensor after a device-side rollout
+        for out in env._sets or ():
+            out.act_ptr = None
         if env.episode_step is not None and self.episode_len:
             env.episode_step.fill_(self.t % self.episode_len)
 
@@ -158,6 +162,8 @@ class RandomRollout(object):
             b = trajectory.bufs
             ret = trajectory
         b.act = b.ids = b.u = None
+        if trajectory is None:
+            ret.act_ptr = None      # (as in enqueue: the env's set 0 no longer points at the caller's action tensor)
         _abi.check(self._L.mpe_rollout_random(C.byref(self._desc), C.byref(b), self.B, int(steps), self.episode_len,
                                               self._lr, self.seed, self.t, int(self.world.world_offset),
                                               1 if trajectory is not None else 0, self._stream()),

@@ -78,11 +78,13 @@ class Rendezvous(object):
     `self.backend` says what carries the barrier ("none" for a single process), `self.note` why a fallback
     happened.  Reductions and gathers of host values always travel over gloo (they are host values)."""
 
-    def __init__(self, rank=None, world=None, device=None, backend="auto", nccl_deadline_s=90.0, timeout_s=1800.0):
+    def __init__(self, rank=None, world=None, device=None, backend="auto", nccl_deadline_s=40.0, timeout_s=1800.0):
         self.rank = int(os.environ.get("RANK", "0") if rank is None else rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1") if world is None else world)
         self.device = torch.device(device) if device is not None else None
         self.backend, self.note, self._nccl, self._abandoned, self._stuck = "none", None, None, False, False
+        self._nccl_candidate = None
+        self.barrier_fallbacks = 0     # RCCL barriers that failed at run time and were redone over gloo
         if self.world == 1:
             return
         if backend not in ("auto", "nccl", "gloo"):
@@ -98,13 +100,15 @@ class Rendezvous(object):
             else:
                 ok, why = self._try_nccl(nccl_deadline_s)
             everyone = _reduce(1.0 if ok else 0.0, dist.ReduceOp.MIN) == 1.0
+            cand = getattr(self, "_nccl_candidate", None)
             if everyone:
+                self._nccl = cand        # adopted by the main thread, and only on a unanimous yes
                 self.backend = "nccl"
             else:
                 reasons = self.gather(why)
                 self.note = "RCCL not adopted (%s); barrier over gloo" % "; ".join(
                     "rank %d: %s" % (r, w) for r, w in enumerate(reasons) if w)
-                self._abandoned = self._nccl is not None or self._stuck
+                self._abandoned = cand is not None or self._stuck
                 self._nccl = None
                 if backend == "nccl":
                     raise RuntimeError(self.note)
@@ -124,7 +128,7 @@ class Rendezvous(object):
             try:
                 torch.cuda.set_device(self.device)
                 g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=max(deadline_s * 4, 120.0)))
-                self._nccl = g
+                result["group"] = g      # handed to the main thread; adopted there only if the bring-up came back in time
                 t = torch.ones(1, device=self.device)
                 w = dist.all_reduce(t, group=g, async_op=True)
                 t_end = time.time() + deadline_s
@@ -145,16 +149,37 @@ class Rendezvous(object):
         th.start()
         th.join(deadline_s + 10.0)
         if th.is_alive() or "v" not in result:
-            self._stuck = True
+            self._stuck = True       # (a thread that returns later finds nobody reading `result`: self._nccl is the main thread's)
             return False, "RCCL bring-up did not return in %.0f s" % (deadline_s + 10.0)
+        self._nccl_candidate = result.get("group")
         return result["v"]
 
     def barrier(self):
+        """All ranks meet here, with this rank's GPU idle on both sides.  Over RCCL when the bring-up adopted it; an RCCL
+        barrier that raises at run time (the adopted group's first real use on an N-GPU box) is not fatal: every rank then
+        agrees over gloo -- one MIN-reduce of "mine worked" -- to drop RCCL for the rest of the job (`backend` becomes
+        "gloo", `note` says why, one warning on stderr), and the barrier is completed over gloo.  Nothing measured
+        depends on which backend carries it: the step path has no collective."""
         _sync(self.device)
         if self.world > 1:
             if self._nccl is not None:
-                dist.barrier(group=self._nccl, device_ids=[self.device.index])
-                _sync(self.device)
+                ok, why = True, None
+                try:
+                    dist.barrier(group=self._nccl, device_ids=[self.device.index])
+                    _sync(self.device)
+                except Exception as e:
+                    ok, why = False, "%s: %s" % (type(e).__name__, (str(e).strip().splitlines() or [""])[0][:200])
+                # the vote is what completes the barrier when RCCL failed somewhere; it costs one small gloo all-reduce
+                # (outside the timed region: barrier() brackets it, and the clock starts after the barrier returns)
+                if _reduce(1.0 if ok else 0.0, dist.ReduceOp.MIN) != 1.0:
+                    reasons = self.gather(why)
+                    self.note = "RCCL barrier failed at run time (%s); barrier over gloo from here on" % "; ".join(
+                        "rank %d: %s" % (r, w) for r, w in enumerate(reasons) if w)
+                    if self.rank == 0:
+                        sys.stderr.write("sharding.Rendezvous: %s\n" % self.note)
+                    self._nccl, self.backend, self._abandoned = None, "gloo", True
+                    self.barrier_fallbacks += 1
+                    dist.barrier()
             else:
                 dist.barrier()
         _sync(self.device)
@@ -174,17 +199,19 @@ class Rendezvous(object):
         return out
 
     def close(self):
+        """Leave the job.  Returns True when the process group was torn down normally, False when an RCCL communicator
+        was abandoned (its bring-up failed, hung, or a barrier failed at run time): tearing such a communicator down may
+        block, so the group is left as it is and THE CALLER decides how to end the process (bench.py: flush its output,
+        then `os._exit(status)` with the status it would have returned).  A library call never exits the process."""
         if self.world > 1 and dist.is_initialized():
             try:
                 dist.barrier()
             except Exception:
                 pass
             if self._abandoned:
-                # an RCCL communicator that never came up may block its own teardown: leave without it
-                sys.stdout.flush()
-                sys.stderr.flush()
-                os._exit(0)
+                return False
             dist.destroy_process_group()
+        return True
 
 
 def free_port():
@@ -195,11 +222,49 @@ def free_port():
     return p
 
 
-def spawn_local_ranks(argv, n, env=None, one_device=False, timeout_s=3600.0, python=None):
+def _visible_gpu_ids(env=None):
+    """The GPU ids a process with environment `env` may use, as the strings HIP_VISIBLE_DEVICES takes (None: no restriction)."""
+    env = os.environ if env is None else env
+    vis = env.get("HIP_VISIBLE_DEVICES") or env.get("CUDA_VISIBLE_DEVICES")
+    if not vis:
+        return None
+    return [v.strip() for v in vis.split(",") if v.strip()]
+
+
+def rank_cpu_slice(local_rank, local_world, allowed=None):
+    """The CPUs rank `local_rank` of `local_world` ranks on this node is pinned to: an even, contiguous slice of the CPUs
+    the process may run on (all of them when there are fewer CPUs than ranks).  The step path leaves the host idle inside
+    the timed region (graph replay); the slice keeps N Python hosts from migrating over each other around it."""
+    cpus = sorted(allowed if allowed is not None else
+                  (os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else range(os.cpu_count() or 1)))
+    n, g = len(cpus), max(1, int(local_world))
+    if n < g:
+        return cpus
+    per = n // g
+    return cpus[local_rank * per:(local_rank + 1) * per]
+
+
+def pin_rank(local_rank, local_world):
+    """sched_setaffinity to rank_cpu_slice; -> the CPU list in force afterwards (a description for the bench record)."""
+    if not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        sl = rank_cpu_slice(local_rank, local_world)
+        if sl:
+            os.sched_setaffinity(0, sl)
+        return sorted(os.sched_getaffinity(0))
+    except OSError:
+        return None
+
+
+def spawn_local_ranks(argv, n, env=None, one_device=False, timeout_s=3600.0, python=None, gpu_slots=None):
     """Start `n` copies of `python argv...` as ranks 0..n-1 of one job on this node (what
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` would do), relay rank 0's stdout to ours and
     every rank's stderr to ours, and return the job's exit code: 0 only if every rank exited 0.
-    Rank r's LOCAL_RANK is r (0 for all when `one_device`): a worker binds to `cuda:LOCAL_RANK`."""
+    Rank r is handed exactly ONE GPU -- HIP_VISIBLE_DEVICES = the r-th GPU this process may use, so the worker's
+    `cuda:0` is that GPU and a mis-mapped rank cannot land on a neighbour's device -- and LOCAL_RANK 0 with
+    MPE_LOCAL_RANK = r for the CPU slice (`one_device`: every rank gets the first GPU, the one-GPU rehearsal;
+    `gpu_slots`: rank r gets visible GPU number gpu_slots[r] instead of number r)."""
     base = dict(os.environ if env is None else env)
     base["MASTER_ADDR"] = "127.0.0.1"
     base["MASTER_PORT"] = str(free_port())
@@ -207,11 +272,18 @@ def spawn_local_ranks(argv, n, env=None, one_device=False, timeout_s=3600.0, pyt
     base["LOCAL_WORLD_SIZE"] = str(n)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     base["MPE_SELF_SPAWNED"] = "1"
+    ids = _visible_gpu_ids(base)
     procs = []
     for r in range(n):
         e = dict(base)
         e["RANK"] = str(r)
-        e["LOCAL_RANK"] = "0" if one_device else str(r)
+        e["LOCAL_RANK"] = "0"              # the one GPU the rank sees
+        e["MPE_LOCAL_RANK"] = str(r)       # its place among the node's ranks (CPU slice, records)
+        k = 0 if one_device else (int(gpu_slots[r]) if gpu_slots is not None else r)
+        gpu = ids[k] if ids is not None and k < len(ids) else str(k)
+        e["HIP_VISIBLE_DEVICES"] = gpu
+        e.pop("CUDA_VISIBLE_DEVICES", None)
+        e["MPE_GPU_ID"] = gpu
         procs.append(subprocess.Popen([python or sys.executable] + list(argv), env=e,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
     import threading

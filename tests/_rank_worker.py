@@ -14,7 +14,9 @@ if mode == "fail" and rank == 1:
 rv = sharding.Rendezvous(device=None, backend="auto" if mode == "auto" else "gloo")
 rv.barrier()
 secs = 0.5 + 0.25 * rank
-recs = rv.gather({"rank": rank, "local": os.environ["LOCAL_RANK"], "offset": sharding.shard_range(1000, rank, world)[0]})
+recs = rv.gather({"rank": rank, "local": os.environ["LOCAL_RANK"], "slot": os.environ.get("MPE_LOCAL_RANK"),
+                  "gpu": os.environ.get("HIP_VISIBLE_DEVICES"), "cpus": sharding.pin_rank(int(os.environ.get("MPE_LOCAL_RANK", "0")), world),
+                  "offset": sharding.shard_range(1000, rank, world)[0]})
 tmax, total = rv.reduce_max(secs), rv.reduce_sum(10.0)
 print("rank %d noise on stdout" % rank)
 if rank == 0:

@@ -728,6 +728,43 @@ def test_graphed_step_replays_the_eager_step(name, fused):
             env_e.reset()
 
 
+@pytest.mark.gpu
+def test_graphed_step_and_state_round_trip_with_a_movable_landmark():
+    """A movable landmark's velocity is state (core.py:158-169): GraphedStep's warm-up steps must not leave a trace in it,
+    and set_state(*get_state()) must restore it (round-3 ADVICE)."""
+    B = 256
+    rs = np.random.RandomState(9)
+    envs = []
+    for _ in range(2):
+        sc = mpe.scenarios.load("simple_tag.py").Scenario()
+        w = sc.make_world(batch_size=B)
+        w.seed = 4
+        w.landmarks[0].movable, w.landmarks[0].initial_mass = True, 2.0
+        env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation)
+        env.reset()
+        w.pos.mul_(0.3)                       # crowded: the landmark gets pushed
+        envs.append(env)
+    env_g, env_e = envs
+    assert not env_g.fused
+    for e in envs:
+        for _ in range(3):
+            e.step(random_actions(e, np.random.RandomState(1), B))
+    p0, v0 = env_g.world.get_state()
+    assert v0.shape[1] == len(env_g.world.entities) and np.abs(v0[:, len(env_g.world.agents)]).max() > 0    # the landmark moves
+    gs = mpe.GraphedStep(env_g, random_actions(env_g, rs, B))
+    p1, v1 = env_g.world.get_state()
+    assert np.array_equal(p0, p1) and np.array_equal(v0, v1)            # the warm-up steps did not happen, landmark rows included
+    for t in range(4):
+        act = random_actions(env_e, rs, B)
+        gs.step(act)
+        env_e.step(act)
+        assert torch.equal(env_g.world.pos, env_e.world.pos) and torch.equal(env_g.world._vel_all, env_e.world._vel_all), t
+    p, v = env_e.world.get_state()
+    env_e.world.set_state(np.zeros_like(p), None)
+    env_e.world.set_state(p, v)
+    assert torch.equal(env_g.world.pos, env_e.world.pos) and torch.equal(env_g.world._vel_all, env_e.world._vel_all)
+
+
 CUSTOM = [("simple_spread", {}), ("simple_spread", {"num_agents": 8}), ("simple_spread", {"num_agents": 40, "num_landmarks": 7}),
           ("simple_tag", {}), ("simple_adversary", {}), ("simple_push", {}), ("simple_world_comm", {}), ("simple", {})]
 

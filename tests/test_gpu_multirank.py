@@ -28,24 +28,31 @@ def free_port():
     return p
 
 
-def _check_two_rank_job(out, tmp_path, B):
-    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5
-    assert out["config"]["batch_per_gpu"] == B and out["config"]["global_batch"] == 2 * B
+def _check_two_rank_job(out, tmp_path, B, n=2):
+    assert out["n_gpus"] == n and out["steps"] == 20 and out["warmup"] == 5
+    assert out["config"]["batch_per_gpu"] == B and out["config"]["global_batch"] == n * B
     assert out["scaling"] == "weak" and out["unit"] == "env-steps/s"
-    # whole-job value = both ranks' worlds over the slowest rank's time
-    assert abs(out["value"] - 2 * B / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
-    assert out["roofline"]["frac"] > 0 and out["roofline"]["per_gpu"] and len(out["roofline"]["kernel_us_per_launch_by_rank"]) == 2
-    assert out["config"]["ranks_seen"] == 2 and [r["rank"] for r in out["config"]["ranks"]] == [0, 1]
-    assert [r["world_offset"] for r in out["config"]["ranks"]] == [0, B] and all(r["name"] for r in out["config"]["ranks"])
+    # whole-job value = all ranks' worlds over the slowest rank's time
+    assert abs(out["value"] - n * B / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["per_gpu"] and len(out["roofline"]["kernel_us_per_launch_by_rank"]) == n
+    assert out["roofline"]["frac_timed_region"] > 0 and out["roofline"]["frac_timed_region"] <= out["roofline"]["frac"] * 1.05
+    assert out["config"]["ranks_seen"] == n and [r["rank"] for r in out["config"]["ranks"]] == list(range(n))
+    assert [r["world_offset"] for r in out["config"]["ranks"]] == [r * B for r in range(n)] and all(r["name"] for r in out["config"]["ranks"])
+    assert out["config"]["distinct_gpus"] == 1 and all(r["uuid"] or r["pci"] for r in out["config"]["ranks"])   # the rehearsal: one GPU under all ranks
+    pg = out["per_gpu_value"]
+    assert pg["ranks"] == n and pg["min"] <= pg["median"] <= pg["max"] and pg["min"] > 0
+    sd = out["config"]["scaling_diagnostic"]
+    assert sd["rank0_solo_env_steps_per_s"] > 0 and 0 < sd["value_over_n_times_rank0_solo"] < 1.5
+    assert out["timed_region_s"] > 0 and out["timed_steps"] == out["config"]["timed_steps"]
 
-    # one process, one batch of 2B worlds: the same episode-0 reset + step 0
-    big = mpe.make_env("simple_spread", batch_size=2 * B, seed=0)
+    # one process, one batch of n*B worlds: the same episode-0 reset + step 0
+    big = mpe.make_env("simple_spread", batch_size=n * B, seed=0)
     rr = RandomRollout(big, episode_len=25, pool=25, regenerate=True)
     o = rr.enqueue(1)
     torch.cuda.synchronize()
     ref = {"pos": big.world.pos.cpu().numpy(), "vel": big.world.vel.cpu().numpy(), "rew": o.rew.cpu().numpy()}
     obs = [x.cpu().numpy() for x in o.obs_n]
-    for rank in (0, 1):
+    for rank in range(n):
         d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
         assert int(d["world_offset"]) == rank * B
         sl = slice(rank * B, (rank + 1) * B)
@@ -102,7 +109,36 @@ def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks(tmp_path):
     if out["config"]["barrier_backend"] == "gloo":
         assert "RCCL not adopted" in out["config"]["barrier_note"]
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"
+    assert [r["gpu_env"] for r in out["config"]["ranks"]] == [out["config"]["ranks"][0]["gpu_env"]] * 2      # both were handed the first GPU
     _check_two_rank_job(out, tmp_path, B)
+
+
+def test_bench_eight_ranks_rehearsal_on_one_gpu(tmp_path):
+    """The driver's largest job, rehearsed: `python bench.py --gpus 8 --all-ranks-on-gpu0` -- an 8-way rendezvous, 8 shards of
+    4096 worlds each bit-identical to one batch of 32 768, one line with n_gpus = 8, inside a bounded wall time."""
+    import time
+    B = 4096
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--batch", str(B),
+           "--all-ranks-on-gpu0", "--backend", "gloo", "--no-cpu-baseline", "--region-ms", "50", "--dump-state", str(tmp_path)]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=_bench_env(), timeout=900, cwd=ROOT)
+    wall = time.time() - t0
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    _check_two_rank_job(out, tmp_path, B, n=8)
+    assert wall < 240, wall        # (8 Python hosts importing torch on one box included; the timed work is ~1 s)
+
+
+def test_bench_refuses_two_ranks_mapped_to_one_gpu():
+    """Two ranks on the same GPU WITHOUT the rehearsal flag (a mis-mapped job: here --device-map 0,0): refused before anything
+    is measured, non-zero exit, no line."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--batch", "1024",
+           "--device-map", "0,0", "--backend", "gloo", "--no-cpu-baseline", "--region-ms", "20"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=_bench_env(), timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and "share a GPU" in r.stderr, (r.returncode, r.stderr[-2000:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_bench_more_gpus_than_the_box_has_is_an_error():

@@ -817,6 +817,48 @@ def test_step_fast_path_is_the_same_step(name, kw, bench):
     assert all(torch.equal(a, b) for a, b in zip(o_t, keep))
 
 
+@pytest.mark.parametrize("ids", [False, True])
+def test_step_fast_path_survives_a_rollout_in_between(ids):
+    """A RandomRollout writes the env's MpeBuffers (act / ids of BOTH output sets) behind step()'s back: the short path's
+    note of what each set's `act` holds must not survive that (round-3 ADVICE: step x3, enqueue, step, step stepped with the
+    rollout's pool moves).  Sequence from the finding, against an env that never takes the short path."""
+    from multiagent_particle_envs_amd.rollout import RandomRollout
+    B = 640
+    fast = mpe.make_env("simple_spread", batch_size=B, seed=5)
+    slow = mpe.make_env("simple_spread", batch_size=B, seed=5)
+    A = fast.n
+    act = torch.zeros((A, B, 5), device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rolls = [RandomRollout(e, episode_len=0, pool=4, action_ids=ids) for e in (fast, slow)]
+
+    def both(tag):
+        act.copy_(torch.rand((A, B, 5), device="cuda", generator=g))
+        of, rf = fast.step(act)[:2]
+        os_, rs = slow.step(act.clone())[:2]
+        assert torch.equal(fast.world.pos, slow.world.pos) and torch.equal(fast.world.vel, slow.world.vel), tag
+        for i in range(A):
+            assert torch.equal(of[i], os_[i]) and torch.equal(rf[i], rs[i]), (tag, i)
+    for t in range(3):
+        both(("armed", t))
+    assert id(act) in fast._fast_acts
+    for n in (1, 2, 3):
+        for r in rolls:
+            r.enqueue(n)
+        both(("after enqueue", n, 0))
+        both(("after enqueue", n, 1))
+        both(("after enqueue", n, 2))
+    for r in rolls:
+        r.fused(3)
+    for t in range(3):
+        both(("after fused", t))
+    gr = [r.capture(4) for r in rolls]
+    for k in range(2):
+        for x in gr:
+            x.replay()
+        for t in range(3):
+            both(("after replay", k, t))
+
+
 @pytest.mark.parametrize("name,kw", [("simple_spread", {}), ("simple_tag", {}), ("simple_spread", {"num_agents": 20}),
                                      ("simple_reference", {}), ("simple_world_comm", {})])
 def test_partial_fusion_python_observation_over_the_fused_step(name, kw):

@@ -292,3 +292,20 @@ def test_bench_two_point_slope_rejects_a_bad_point():
     assert ok and abs(us - 66.98) < 0.01
     us, fixed, ok = bench.two_point_slope_us(2.0683, 4.1764, 400)            # slightly negative fixed cost: measurement noise
     assert ok and -0.05 < fixed < 0.0
+
+
+def test_bench_refuses_ranks_that_share_a_gpu():
+    """bench.py --gpus N checks, before measuring, that the N ranks drive N different GPUs (UUID, else PCI address): a
+    mis-mapped job must not print n_gpus = N for fewer GPUs."""
+    import bench
+    ok = [{"rank": r, "uuid": "GPU-%04d" % r, "pci": None} for r in range(8)]
+    assert bench.duplicate_gpus(ok) == ""
+    two = [dict(x) for x in ok]
+    two[5]["uuid"] = two[2]["uuid"]
+    assert "ranks 2 and 5" in bench.duplicate_gpus(two)
+    pci = [{"rank": r, "uuid": None, "pci": "0000:%02x:00" % (r // 2)} for r in range(4)]      # no UUIDs: the PCI address decides
+    msg = bench.duplicate_gpus(pci)
+    assert "ranks 0 and 1" in msg and "ranks 2 and 3" in msg
+    assert "no UUID" in bench.duplicate_gpus([{"rank": 0, "uuid": None, "pci": None}, {"rank": 1, "uuid": "a", "pci": None}])
+    st = bench.per_gpu_stats([{"env_steps_per_s": {"median": v}} for v in (9.0, 10.0, 7.0, 8.0)])
+    assert (st["min"], st["median"], st["max"], st["ranks"]) == (7.0, 9.0, 10.0, 4)

@@ -82,16 +82,48 @@ def _job(mode, n, **kw):
 
 
 def test_self_spawned_ranks_rendezvous_over_gloo():
-    """What `python bench.py --gpus N` does when no launcher set WORLD_SIZE: N ranks started by the parent, rank r ->
-    LOCAL_RANK r, only rank 0's stdout relayed, bookkeeping over gloo."""
+    """What `python bench.py --gpus N` does when no launcher set WORLD_SIZE: N ranks started by the parent, rank r sees
+    exactly one GPU (HIP_VISIBLE_DEVICES = the r-th visible one, so its cuda:0 is that GPU: LOCAL_RANK 0) and keeps its slot r
+    for the CPU slice; only rank 0's stdout relayed, bookkeeping over gloo."""
     rc, lines = _job("gloo", 3)
     assert rc == 0 and len(lines) == 1
     d = lines[0]
     assert d["n_gpus"] == 3 and d["tmax"] == 1.0 and d["total"] == 30.0 and d["backend"] == "gloo"
-    assert [r["rank"] for r in d["ranks"]] == [0, 1, 2] and [r["local"] for r in d["ranks"]] == ["0", "1", "2"]
+    assert [r["rank"] for r in d["ranks"]] == [0, 1, 2] and [r["local"] for r in d["ranks"]] == ["0", "0", "0"]
+    assert [r["slot"] for r in d["ranks"]] == ["0", "1", "2"] and [r["gpu"] for r in d["ranks"]] == ["0", "1", "2"]
     assert [r["offset"] for r in d["ranks"]] == [0, 334, 667]
+    cpus = [r["cpus"] for r in d["ranks"]]
+    if all(cpus) and len(os.sched_getaffinity(0)) >= 3:     # disjoint CPU slices
+        assert all(not (set(a) & set(b)) for i, a in enumerate(cpus) for b in cpus[i + 1:])
     rc, lines = _job("gloo", 2, one_device=True)
-    assert rc == 0 and [r["local"] for r in lines[0]["ranks"]] == ["0", "0"]
+    assert rc == 0 and [r["gpu"] for r in lines[0]["ranks"]] == ["0", "0"]
+    # a parent that is itself restricted hands out ITS GPUs: the r-th entry of its list
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = "5,2,7"
+    rc, lines = _job("gloo", 3, env=env)
+    assert rc == 0 and [r["gpu"] for r in lines[0]["ranks"]] == ["5", "2", "7"]
+
+
+def test_eight_rank_rendezvous_over_gloo():
+    """The size of the driver's largest job: 8 ranks meet, reduce and gather over gloo (CPU)."""
+    rc, lines = _job("gloo", 8)
+    assert rc == 0 and len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 8 and d["total"] == 80.0 and d["tmax"] == 0.5 + 0.25 * 7
+    assert [r["rank"] for r in d["ranks"]] == list(range(8)) and [r["gpu"] for r in d["ranks"]] == [str(i) for i in range(8)]
+
+
+def test_rank_cpu_slices_partition_the_allowed_cpus():
+    for n_cpu in (1, 3, 8, 96, 255):
+        for g in (1, 2, 4, 8):
+            allowed = list(range(10, 10 + n_cpu))
+            sl = [sharding.rank_cpu_slice(r, g, allowed) for r in range(g)]
+            assert all(s for s in sl)
+            if n_cpu >= g:
+                assert all(len(s) == n_cpu // g for s in sl)
+                assert all(not (set(a) & set(b)) for i, a in enumerate(sl) for b in sl[i + 1:])
+            else:
+                assert all(s == allowed for s in sl)
 
 
 def test_rccl_unavailable_falls_back_to_gloo_on_every_rank():
