@@ -32,7 +32,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 
 STRESS_SOURCES = ("split", "wide")
 STRESS_VARIANTS = {"stress": ["-DMPE_STRESS_DELAY_WAVE=1"],
-                   "stress_racy": ["-DMPE_STRESS_DELAY_WAVE=1", "-DMPE_STRESS_STORE_BEFORE_BARRIER"]}
+                   "stress_racy": ["-DMPE_STRESS_DELAY_WAVE=1", "-DMPE_STRESS_STORE_BEFORE_BARRIER"],
+                   # measurement build (tools/device_span.py): every wave of k_split stamps the device wall clock at its
+                   # start and end -> per-launch spans and periods from the device's own clock
+                   "span": ["-DMPE_DEVICE_SPAN"]}
+VARIANT_SOURCES = {"span": ("split",)}     # which kernel files a variant recompiles (default: STRESS_SOURCES)
 
 
 def variant_lib(tag):
@@ -109,7 +113,7 @@ def build(force=False, verbose=True, variants=True):
     jobs, todo = [], []
     for tag, defs in STRESS_VARIANTS.items():
         vo = {}
-        for stem in STRESS_SOURCES:      # the kernel files that carry MPE_STRESS_* hooks
+        for stem in VARIANT_SOURCES.get(tag, STRESS_SOURCES):      # the kernel files that carry the variant's hooks
             src = os.path.join(CSRC, "mpe_%s.hip" % stem)
             os.makedirs(os.path.join(OBJ, tag), exist_ok=True)     # own directory: -save-temps names its files after the source
             o = os.path.join(OBJ, tag, "mpe_%s.o" % stem)

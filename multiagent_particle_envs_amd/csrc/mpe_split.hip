@@ -47,6 +47,29 @@
 #define MPE_STAMP(k) do { } while (0)
 #endif
 
+// instrumented build (libmpe_hip_span.so, tools/device_span.py): lane 0 of every wave stamps the device's constant-rate
+// wall clock (s_memrealtime, 100 MHz, one counter for the whole chip) at its first instruction and at its last, into the
+// buffer passed as MpeBuffers.force: [workgroup][role < 8][2] uint64.  min(start) over a launch's waves is when the launch
+// began ON THE DEVICE; start-to-start of consecutive launches is the per-launch period of a dependent chain -- a time that
+// needs neither the profiler's per-dispatch packets nor the host's events, and that the end stamps do not enter.
+// The end stamp comes in two flavours, chosen per launch by bit 0 of the pointer: clear -- taken when the wave has ISSUED
+// its last store (the stamp's own store overlaps the row stores: the launch is not lengthened; span is a lower bound);
+// set -- taken after `s_waitcnt vmcnt(0)`, i.e. when the wave's stores are ACKNOWLEDGED (the true end of its memory work,
+// but the stamp's store then adds one more round trip behind it: ~0.6 us on the launch).  Not part of the product build.
+#ifdef MPE_DEVICE_SPAN
+#define MPE_SPAN_STAMP(k)                                                                                          \
+  do {                                                                                                             \
+    if (b_in.force && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) {                                           \
+      const uintptr_t sp_ = reinterpret_cast<uintptr_t>(b_in.force);                                                \
+      if ((k) && (sp_ & 1)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                             \
+      reinterpret_cast<unsigned long long *>(sp_ & ~(uintptr_t)7)[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 2 + (k)] = \
+          wall_clock64();                                                                                          \
+    }                                                                                                              \
+  } while (0)
+#else
+#define MPE_SPAN_STAMP(k) do { } while (0)
+#endif
+
 namespace mpe {
 
 // DUAL roles in the fused rollout: every agent gets TWO waves -- a PHYSICS wave (World.step of step t+1: move, contacts,
@@ -451,6 +474,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
   // scalar round trip to the kernarg segment in front of them (three dependent ones before: the sizes, the
   // MpeBuffers block, the per-agent constants).  Everything else still comes from the structs behind them.
   using S = SplitShape<KIND, A, L, NADV>;
+  MPE_SPAN_STAMP(0);
   MpeBuffers b = b_in;
   b.pos = g_pos;
   b.vel = g_vel;
@@ -560,6 +584,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
                                           ra.step0 + (uint64_t)t, goal_r, food);
       MPE_STAMP(3);
     }
+    MPE_SPAN_STAMP(1);
     return;
   }
 
@@ -1016,6 +1041,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         rows(t);
         MPE_STAMP(5);
       }
+      MPE_SPAN_STAMP(1);
       return;
     }
     // ---- PHYSICS wave of agent i: World.step of step t+1 behind barrier t, from the siblings' state of step t -----------
@@ -1081,6 +1107,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       store_aux<AUX>(b.vel + wave_off((size_t)(2 * i + 1) * B + w0) + ln, mvy);
     }
   }
+  MPE_SPAN_STAMP(1);
 }
 
 // ---- dispatch -----------------------------------------------------------------------------------

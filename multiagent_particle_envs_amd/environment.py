@@ -631,6 +631,8 @@ class MultiAgentEnv(object):
             def conv(x):
                 if isinstance(x, tuple):
                     return tuple(conv(y) for y in x)
+                if isinstance(x, list):      # per-world Python objects (a reference-style benchmark_data): world 0's
+                    return x[0] if x else x
                 if torch.is_tensor(x):
                     v = x[0].item()
                     return v

@@ -8,6 +8,11 @@
     env = make_env('simple_tag', batch_size=16384, max_episode_steps=25, auto_reset=True)
                                                              # new: done at the horizon + device-side auto-reset
 
+    env = make_env('/path/to/my_scenario.py')                # a REFERENCE-STYLE scenario file, unmodified (`from multiagent.core
+    env = make_env('/path/to/my_scenario.py', batch_size=256)  # import World ...`, make_world(self), NumPy callbacks): the file's
+                                                             # callbacks run per world on the host over the device physics
+                                                             # (refstyle.py: the compatibility / migration path, slow by construction)
+
 Everything on the step path runs in libmpe_hip.so on a HIP device; there is no CPU fallback.
 """
 
@@ -17,7 +22,15 @@ def make_env(scenario_name, benchmark=False, batch_size=None, device=None, seed=
     from .environment import MultiAgentEnv
     from . import scenarios
 
-    scenario = scenarios.load(scenario_name + ".py").Scenario()
+    scenario = scenarios.load(scenario_name if scenario_name.endswith(".py") else scenario_name + ".py").Scenario()
+    from . import refstyle
+    if refstyle.is_reference_style(scenario):
+        # written against the reference's own contract (scenario.py:4-10: make_world(self), NumPy per-world callbacks)
+        if scenario_kwargs or fused:
+            raise TypeError("a reference-style scenario takes no scenario kwargs and has no fused kernel (got %r, fused=%r)"
+                            % (sorted(scenario_kwargs), fused))
+        return refstyle.make_ref_env(scenario, benchmark=benchmark, batch_size=batch_size, device=device, seed=seed,
+                                     max_episode_steps=max_episode_steps, auto_reset=auto_reset)
     compat = batch_size is None
     world = scenario.make_world(batch_size=1 if compat else int(batch_size), device=device, **scenario_kwargs)
     world.seed = seed

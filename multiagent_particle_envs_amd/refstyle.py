@@ -1,0 +1,283 @@
+"""Reference-style Scenario files, unmodified, over the device physics.
+
+The reference's plug-in contract (multiagent/scenario.py:4-10, scenarios/__init__.py:5-7, make_env.py:36-43, README
+"Creating new environments") is a file whose `Scenario` builds ONE world of Python objects holding NumPy 2-vectors and
+answers `reward(agent, world)` / `observation(agent, world)` with NumPy scalars / 1-D arrays.  This package's own
+protocol (scenario.py) is the batched one -- `make_world(batch_size, device)`, `[B]` torch tensors -- because that is
+what a GPU can evaluate.  `RefScenarioAdapter` lets the first kind run on the second kind's engine:
+
+    B shadow worlds   `scenario.make_world()` called B times: the file's own objects (`multiagent.core` classes, see
+                      compat/), one per world, holding whatever per-world Python state the scenario keeps on them
+                      (`agent.goal_a`, colours, keys ...)
+    one device World  the SoA tensors of all B worlds; `World.step` = `mpe_world_step` (libmpe_hip.so), action decode
+                      = the env's `_set_action` in torch -- exactly the generic path of the torch protocol
+    after every step  ONE device-to-host copy of the state; every shadow entity's `state.p_pos / p_vel / c` and
+                      `action.u / c` become NumPy views of its row; the file's callbacks are then evaluated per world
+                      ON THE HOST, in the reference's order (environment.py:92-97), and stacked into [B, .] outputs
+    reset             `scenario.reset_world(shadow_b)` per (masked) world -- the file draws from `np.random` exactly as
+                      it does in the reference -- then one upload
+
+Correct and slow by construction: B x A Python calls per step (about 4 us per NumPy op; a 4096-world simple_spread step
+is ~0.3 s).  It is the COMPATIBILITY path -- one world with NumPy in / NumPy out is the reference's own use, seed for
+seed -- and the migration path: a scenario that matters gets rewritten against the torch protocol (or ObsSpec /
+RewardSpec, rowspec.py) and runs 3-5 orders of magnitude faster.  The physics never runs on the CPU either way.
+"""
+import inspect
+
+import numpy as np
+import torch
+
+from . import _abi
+from .core import World, Agent, Landmark, Action
+
+# constants World.step reads (core.py:27-51, 59-79): identical in every shadow world, or the batch cannot be one launch
+_ENTITY_KEYS = ("size", "movable", "collide", "max_speed", "accel", "mass")
+_AGENT_KEYS = ("silent", "u_noise", "c_noise", "u_range", "blind")
+_WORLD_KEYS = ("dim_c", "dim_p", "dt", "damping", "contact_force", "contact_margin")
+
+
+def is_reference_style(scenario):
+    """A Scenario written against the reference's contract: `make_world(self)` takes no batch size."""
+    try:
+        params = inspect.signature(scenario.make_world).parameters
+    except (TypeError, ValueError):
+        return False
+    return "batch_size" not in params and not any(p.kind == p.VAR_KEYWORD for p in params.values())
+
+
+class _MirroredWorld(World):
+    """The device World of a reference-style env: after every step the shadows are brought up to date."""
+
+    def __init__(self, adapter, batch_size, device):
+        super(_MirroredWorld, self).__init__(batch_size, device)
+        self.__dict__["_adapter"] = adapter
+
+    def step(self):
+        super(_MirroredWorld, self).step()
+        self._adapter.pull()
+
+    def set_state(self, pos, vel=None):
+        super(_MirroredWorld, self).set_state(pos, vel)
+        if self.__dict__.get("_adapter_ready"):
+            self._adapter.pull()
+
+
+class RefScenarioAdapter(object):
+    """Presents a reference-style Scenario to MultiAgentEnv as a (generic-path) batched one."""
+    kind = None            # no fused kernel: the callbacks are the file's own Python
+    reference_style = True
+
+    def __init__(self, scenario, batch_size=1, device=None, host_outputs=False):
+        self.scenario = scenario
+        self.B = int(batch_size)
+        self.host_outputs = bool(host_outputs)     # compat mode (one world, NumPy I/O): fp64 host tensors, no round trip
+        self.shadows = [scenario.make_world() for _ in range(self.B)]
+        w0 = self.shadows[0]
+        self._agents = [list(w.agents) for w in self.shadows]          # "no agents created / destroyed at runtime" (environment.py:8)
+        self._entities = [list(w.agents) + list(w.landmarks) for w in self.shadows]
+        self._check_uniform()
+        world = _MirroredWorld(self, self.B, device)
+        for k in _WORLD_KEYS:
+            setattr(world, k, getattr(w0, k))
+        for k in ("collaborative", "discrete_action"):                  # optional attributes the env looks for (environment.py:34-36)
+            if hasattr(w0, k):
+                setattr(world, k, getattr(w0, k))
+        world.agents = [self._mirror(a, Agent(), i) for i, a in enumerate(w0.agents)]
+        world.landmarks = [self._mirror(l, Landmark(), None) for l in w0.landmarks]
+        world.allocate()
+        self.world = world
+        for w in self.shadows:                       # environment.py:70: agent.action.c = np.zeros(world.dim_c)
+            for a in w.agents:
+                a.action.c = np.zeros(w.dim_c)
+                if a.action.u is None:
+                    a.action.u = np.zeros(w.dim_p)
+        self.push()
+        world.__dict__["_adapter_ready"] = True
+
+    # ---- construction ------------------------------------------------------------------------------------------------
+    def _check_uniform(self):
+        w0 = self.shadows[0]
+        ref = [tuple(getattr(e, k) for k in _ENTITY_KEYS) for e in self._entities[0]]
+        refa = [tuple(getattr(a, k, None) for k in _AGENT_KEYS) + (a.action_callback is not None,) for a in self._agents[0]]
+        refw = tuple(getattr(w0, k) for k in _WORLD_KEYS)
+        for b, w in enumerate(self.shadows[1:], 1):
+            if len(w.agents) != len(w0.agents) or len(w.landmarks) != len(w0.landmarks) or \
+                    tuple(getattr(w, k) for k in _WORLD_KEYS) != refw or \
+                    [tuple(getattr(e, k) for k in _ENTITY_KEYS) for e in self._entities[b]] != ref or \
+                    [tuple(getattr(a, k, None) for k in _AGENT_KEYS) + (a.action_callback is not None,) for a in self._agents[b]] != refa:
+                raise _abi.MpeError("reference-style scenario: make_world() built world %d with other entity counts or physics "
+                                    "constants (size / movable / collide / max_speed / accel / mass / noise) than world 0 -- B worlds "
+                                    "step in one launch and share them; per-world randomness belongs in reset_world" % b)
+
+    def _mirror(self, src, dst, agent_index):
+        dst.name = src.name
+        dst.size, dst.movable, dst.collide = float(src.size), bool(src.movable), bool(src.collide)
+        dst.max_speed, dst.accel, dst.initial_mass = src.max_speed, src.accel, float(src.mass)
+        dst.density, dst.color = getattr(src, "density", 25.0), None
+        if agent_index is not None:
+            dst.silent, dst.blind = bool(src.silent), bool(getattr(src, "blind", False))
+            dst.u_noise, dst.c_noise, dst.u_range = src.u_noise, src.c_noise, getattr(src, "u_range", 1.0)
+            if src.action_callback is not None:     # a scripted agent: its action comes from the file's callback, world by world
+                dst.action_callback = lambda agent, world, i=agent_index: self._scripted_action(i)
+        return dst
+
+    def refresh_constants(self):
+        """Re-read the physics constants from shadow world 0 (a caller changed them on the reference-style objects)."""
+        self._check_uniform()
+        w0 = self.shadows[0]
+        for k in _WORLD_KEYS[2:]:
+            setattr(self.world, k, getattr(w0, k))
+        for src, dst in zip(self._entities[0], self.world.entities):
+            dst.size, dst.movable, dst.collide = float(src.size), bool(src.movable), bool(src.collide)
+            dst.max_speed, dst.accel, dst.initial_mass = src.max_speed, src.accel, float(src.mass)
+        for src, dst in zip(self._agents[0], self.world.agents):
+            dst.silent, dst.u_noise, dst.c_noise = bool(src.silent), src.u_noise, src.c_noise
+
+    # ---- state traffic ---------------------------------------------------------------------------------------------
+    def push(self):
+        """Shadow worlds -> device: positions, velocities, utterances (after make_world / reset_world), then pull, so
+        the shadows hold exactly what the device holds (fp32-rounded)."""
+        w = self.world
+        E, A, dc = len(w.entities), len(w.agents), int(w.dim_c)
+        pos = np.zeros((self.B, E, 2), np.float64)
+        vel = np.zeros((self.B, E, 2), np.float64)
+        c = np.zeros((A, self.B, dc), np.float32)
+        for b, ents in enumerate(self._entities):
+            for e, ent in enumerate(ents):
+                if ent.state.p_pos is not None:
+                    pos[b, e] = ent.state.p_pos
+                if ent.state.p_vel is not None:
+                    vel[b, e] = ent.state.p_vel
+            if dc:
+                for i, a in enumerate(self._agents[b]):
+                    if a.state.c is not None:
+                        c[i, b] = a.state.c
+        World.set_state(w, pos, vel)
+        for i, agent in enumerate(w.agents):
+            agent.state.c = torch.as_tensor(c[i]).to(w.device)
+        self.pull()
+
+    def pull(self):
+        """Device -> shadow worlds: every entity's state row and every agent's utterance / action become NumPy views of
+        ONE host copy (fp64, as reference-style callbacks expect)."""
+        w = self.world
+        if w.pos.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise _abi.MpeError("a reference-style scenario's callbacks run on the host: its step cannot be captured into a HIP graph")
+        A = len(w.agents)
+        pos = w.pos.permute(2, 0, 1).contiguous().cpu().numpy().astype(np.float64)          # [B, E, 2]
+        vel = w._vel_all.permute(2, 0, 1).contiguous().cpu().numpy().astype(np.float64)
+
+        def host(t, width):
+            if t is None or not torch.is_tensor(t) or width == 0:
+                return np.zeros((self.B, width), np.float64)
+            return t.detach().to("cpu", torch.float64).reshape(-1, width).expand(self.B, width).contiguous().numpy()
+        dc, dp = int(w.dim_c), int(w.dim_p)
+        sc = [host(a.state.c, dc) for a in w.agents]
+        au = [host(a.action.u, dp) for a in w.agents]
+        ac = [host(a.action.c, dc) for a in w.agents]
+        for b, ents in enumerate(self._entities):
+            pb, vb = pos[b], vel[b]
+            for e, ent in enumerate(ents):
+                st = ent.state
+                st.p_pos, st.p_vel = pb[e], vb[e]
+            for i in range(A):
+                a = ents[i]
+                a.state.c = sc[i][b]
+                a.action.u, a.action.c = au[i][b], ac[i][b]
+
+    def _scripted_action(self, i):
+        """World.step for a scripted agent (core.py:119-121): the file's action_callback per world -> one batched Action."""
+        u = np.zeros((self.B, int(self.world.dim_p)), np.float32)
+        c = np.zeros((self.B, int(self.world.dim_c)), np.float32)
+        for b, w in enumerate(self.shadows):
+            a = self._agents[b][i]
+            act = a.action_callback(a, w)
+            a.action = act
+            if act.u is not None:
+                u[b] = act.u
+            if act.c is not None and c.shape[1]:
+                c[b] = act.c
+        out = Action()
+        out.u, out.c = torch.as_tensor(u).to(self.world.device), torch.as_tensor(c).to(self.world.device)
+        return out
+
+    # ---- the callbacks MultiAgentEnv calls -----------------------------------------------------------------------------
+    def _index(self, agent):
+        return self.world.agents.index(agent)
+
+    def _tensor(self, arr, dtype=torch.float32):
+        if self.host_outputs:
+            return torch.from_numpy(np.ascontiguousarray(arr))
+        return torch.as_tensor(np.ascontiguousarray(arr)).to(self.world.device, dtype)
+
+    def reset_world(self, world, mask=None, seeds=None):
+        """Scenario.reset_world for every (masked) world; `seeds`: `np.random.seed(seeds[b])` right before world b's --
+        the reference's `np.random.seed(s); env.reset()` per world."""
+        m = None if mask is None else torch.as_tensor(mask).cpu().numpy().astype(bool).reshape(-1)
+        for b, w in enumerate(self.shadows):
+            if m is not None and not m[b]:
+                continue
+            if seeds is not None:
+                np.random.seed(int(seeds[b]))
+            self.scenario.reset_world(w)
+        self.push()
+
+    def observation(self, agent, world):
+        i = self._index(agent)
+        f = self.scenario.observation
+        return self._tensor(np.stack([np.asarray(f(self._agents[b][i], w), np.float64).reshape(-1) for b, w in enumerate(self.shadows)]))
+
+    def reward(self, agent, world):
+        i = self._index(agent)
+        f = self.scenario.reward
+        return self._tensor(np.array([float(f(self._agents[b][i], w)) for b, w in enumerate(self.shadows)], np.float64))
+
+    def done(self, agent, world):
+        i = self._index(agent)
+        f = self.scenario.done
+        v = np.array([bool(f(self._agents[b][i], w)) for b, w in enumerate(self.shadows)])
+        return torch.from_numpy(v) if self.host_outputs else torch.from_numpy(v).to(self.world.device)
+
+    def benchmark_data(self, agent, world):
+        """The file's benchmark_data per world: numbers (or tuples of numbers) are stacked into [B] tensors (tuples of
+        them), anything else comes back as the list of the B per-world objects."""
+        i = self._index(agent)
+        f = self.scenario.benchmark_data
+        vals = [f(self._agents[b][i], w) for b, w in enumerate(self.shadows)]
+        return _stack_info(vals, self)
+
+
+def _is_num(x):
+    return isinstance(x, (int, float, bool, np.integer, np.floating, np.bool_)) or (isinstance(x, np.ndarray) and x.ndim == 0)
+
+
+def _stack_info(vals, ad):
+    if all(_is_num(v) for v in vals):
+        arr = np.asarray(vals)
+        return ad._tensor(arr, torch.int32 if arr.dtype.kind in "iub" else torch.float32)
+    if all(isinstance(v, tuple) for v in vals) and len(set(len(v) for v in vals)) == 1 and \
+            all(_is_num(x) for v in vals for x in v):
+        return tuple(_stack_info([v[k] for v in vals], ad) for k in range(len(vals[0])))
+    return list(vals)
+
+
+def make_ref_env(scenario, benchmark=False, batch_size=None, device=None, seed=0, max_episode_steps=None, auto_reset=False,
+                 done_callback=False):
+    """make_env for a reference-style Scenario object (make_env.py:36-43): one world with NumPy in / NumPy out when
+    `batch_size` is None -- the reference's own use, np.random stream included --, B worlds with [B, .] tensors otherwise."""
+    from .environment import MultiAgentEnv
+    compat = batch_size is None
+    ad = RefScenarioAdapter(scenario, 1 if compat else int(batch_size), device, host_outputs=compat)
+    world = ad.world
+    world.seed = seed
+    world.rng_mode = "numpy" if compat else "device"      # where action / communication noise is drawn from (core.py:138,176)
+    info_cb = ad.benchmark_data if benchmark and hasattr(scenario, "benchmark_data") else None
+    # (the reference's make_env passes no done_callback, make_env.py:41-43: done stays False unless asked for)
+    done_cb = ad.done if done_callback and hasattr(scenario, "done") else None
+    env = MultiAgentEnv(world, ad.reset_world, ad.reward, ad.observation, info_cb, done_cb,
+                        numpy_io=compat, fresh_outputs=True, fused=False,
+                        max_episode_steps=max_episode_steps, auto_reset=auto_reset)
+    env.scenario = ad
+    env.ref_scenario = scenario
+    env.ref_worlds = ad.shadows          # the file's own world objects, one per world, kept current after every step / reset
+    return env

@@ -309,3 +309,15 @@ def test_bench_refuses_ranks_that_share_a_gpu():
     assert "no UUID" in bench.duplicate_gpus([{"rank": 0, "uuid": None, "pci": None}, {"rank": 1, "uuid": "a", "pci": None}])
     st = bench.per_gpu_stats([{"env_steps_per_s": {"median": v}} for v in (9.0, 10.0, 7.0, 8.0)])
     assert (st["min"], st["median"], st["max"], st["ranks"]) == (7.0, 9.0, 10.0, 4)
+
+
+def test_pmc_traffic_json_is_what_the_cited_files_say():
+    """bench.py's `roofline.traffic` comes from profiles/pmc_traffic.json; every entry there must equal the last line of the
+    PMC summary it cites (profiles/make_pmc_traffic.py regenerates it; round-3 verdict: two entries were 0.5-2 % off)."""
+    import importlib.util
+    p = os.path.join(ROOT, "profiles", "make_pmc_traffic.py")
+    spec = importlib.util.spec_from_file_location("make_pmc_traffic", p)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    import json
+    assert json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))) == m.build()
