@@ -120,6 +120,7 @@ int mpe_abi_version(void);
 const char *mpe_last_error(void);
 size_t mpe_sizeof_desc(void);
 size_t mpe_sizeof_buffers(void);
+size_t mpe_sizeof_row_program(void);
 /* Observation widths of the built-in scenarios: fills desc->obs_off[0..A]; returns D_total or <0. */
 int mpe_fill_obs_layout(MpeScenarioDesc *desc);
 /* Per-entity constants as one float table for the wave-per-world (large N) kernel:
@@ -226,6 +227,68 @@ int mpe_episode_tick(int32_t *episode_step, uint8_t *done, int32_t n_agents, int
 int mpe_rollout_random(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, int32_t T,
                        int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0,
                        int64_t world_offset, int32_t trajectory, void *stream);
+
+/* ---- composable output stage: a USER scenario's observation / reward as a row program ---------------------------------
+ * The reference's plug-in promise (README "Creating new environments", scenario.py:4-10) is that new scenarios are the
+ * normal use; every shipped observation is a concatenation of a few segment kinds and every shipped reward an ordered
+ * sum of a few term kinds (simple_spread.py:72-100, simple_tag.py:84-147, simple_adversary.py:76-139, simple_push.py:60-96,
+ * simple_speaker_listener.py:63-92, simple_reference.py:57-83, simple_crypto.py:97-169, simple_world_comm.py:143-289).
+ * mpe_rows interprets such a list -- 16 bytes per op -- on the post-step state: a scenario nobody wrote a kernel for steps
+ * in two launches, mpe_world_step + mpe_rows.  Entities are indexed agents [0, A) then landmarks; A + L <= 16.
+ *
+ * An op is four int32 words: w0 = code | a0 << 8 | a1 << 16 | a2 << 24, w1 = an integer argument, w2 / w3 = float bits.
+ * Observation ops append columns to the agent's row, in program order (a0 = MPE_ROW_SELF: the observing agent):          */
+#define MPE_ROWS_MAX_ENTITIES 16
+#define MPE_ROW_SELF 255
+enum MpeRowOp {
+  MPE_ROW_OBS_VEL = 1,       /* p_vel of entity a0 (2)                                                  */
+  MPE_ROW_OBS_POS = 2,       /* p_pos of entity a0 (2)                                                  */
+  MPE_ROW_OBS_REL = 3,       /* p_pos[a0] - p_pos[self] (2)                                             */
+  MPE_ROW_OBS_REL_PICK = 4,  /* p_pos[w1 + choice[a1]] - p_pos[self] (2): the per-world goal            */
+  MPE_ROW_OBS_COMM = 5,      /* AgentState.c of agent a0: a1 floats of its MpeBuffers.comm row          */
+  MPE_ROW_OBS_CONST = 6,     /* the float w2 (1)                                                        */
+  MPE_ROW_OBS_ONEHOT = 7,    /* a1 floats: w3 where choice[a0] + w1 == column, w2 elsewhere (colours)   */
+  MPE_ROW_OBS_REL_VIS = 8,   /* OBS_REL, zeroed when self cannot see a0 (regions, simple_world_comm.py:231-261) */
+  MPE_ROW_OBS_VEL_VIS = 9,   /* OBS_VEL, likewise                                                       */
+  MPE_ROW_OBS_IN_REGION = 10,/* +1 / -1: is entity a0 inside region a1 (1)                              */
+  /* reward machine: a value register v, accumulators acc0 / acc1 (a2 & 1 selects), 8 slots.  Arithmetic in program
+   * order is what fixes the rounding: the same order as the reference gives the reference's float (in fp32).         */
+  MPE_ROW_R_D2 = 32,         /* v = |p[a0] - p[a1]|^2                                                   */
+  MPE_ROW_R_MIN_D2 = 33,     /* v = min(v, |p[a0] - p[a1]|^2)                                           */
+  MPE_ROW_R_D2_PICK = 34,    /* v = |p[a0] - p[w1 + choice[a1]]|^2                                      */
+  MPE_ROW_R_MIN_D2_PICK = 35,
+  MPE_ROW_R_SQRT = 36,       /* v = sqrt(v)                                                             */
+  MPE_ROW_R_BOUND = 37,      /* v = bound(|coordinate a1 of p[a0]|), simple_tag.py:103-108              */
+  MPE_ROW_R_COMM_ERR = 38,   /* v = sum_c (c[a0][c] - onehot(choice[a1])[c])^2, 0 for an all-zero utterance (simple_crypto.py:97-124) */
+  MPE_ROW_R_COMM_SUM = 39,   /* v = sum_c c[a0][c]                                                      */
+  MPE_ROW_R_CONST = 40,      /* v = w2                                                                  */
+  MPE_ROW_R_SAVE = 41,       /* slot[a0] = v                                                            */
+  MPE_ROW_R_LOAD = 42,       /* v = slot[a0]                                                            */
+  MPE_ROW_R_ZERO = 43,       /* acc = 0                                                                 */
+  MPE_ROW_R_ADD = 44,        /* acc = acc + w2 * v                                                      */
+  MPE_ROW_R_ADD_IF_HIT = 45, /* if |p[a0] - p[a1]| < size[a0] + size[a1] (strict, exact): acc = acc + w2 */
+  MPE_ROW_R_ADD_ACC = 46,    /* acc0 = acc0 + acc1                                                      */
+  MPE_ROW_R_STORE = 47       /* reward of agent a0 = acc0                                               */
+};
+/* Host POD describing one env's programs; the ops live in DEVICE memory the caller owns (uploaded once).               */
+typedef struct MpeRowProgram {
+  const int32_t *ops_device;  /* n_ops x 4 int32 words                                                  */
+  int32_t n_ops;
+  int32_t obs_begin[MPE_ROWS_MAX_ENTITIES + 1]; /* agent i's observation ops: [obs_begin[i], obs_begin[i+1]); its row width is
+                                                   desc->obs_off[i+1] - desc->obs_off[i] (filled by the caller)            */
+  int32_t rew_begin, rew_end; /* the reward program (one, for all agents: STORE hands each agent's reward over) */
+  int32_t n_vel;              /* rows of MpeBuffers.vel: entities [0, n_vel) have a velocity, the rest read 0      */
+  int32_t n_regions;          /* 0..2 landmarks that hide what is inside them                            */
+  int32_t region_entity[2];
+  uint32_t all_seeing;        /* bit i: agent i sees everybody (simple_world_comm.py:253: the leader)   */
+} MpeRowProgram;
+/* Checks a program against the descriptor (entity / pick / slot indices, row widths == obs_off): ops_host are the same
+ * n_ops x 4 words in HOST memory.  0 or MPE_EINVAL with mpe_last_error() naming the op.                               */
+int mpe_rows_validate(const MpeScenarioDesc *desc, const MpeRowProgram *prog, const int32_t *ops_host);
+/* Scenario.observation / reward / done of every agent from the CURRENT state (environment.py:92-102 after World.step, or
+ * :113-115 after a reset): obs rows, rew (shared sum when desc->collaborative), done = 0.  desc->kind is ignored (GENERIC
+ * is what a user scenario has); reads pos, vel, comm, choice; bufs->rew / done may be NULL.                            */
+int mpe_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, const MpeRowProgram *prog, int64_t B, void *stream);
 
 #ifdef __cplusplus
 }

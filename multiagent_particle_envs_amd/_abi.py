@@ -13,6 +13,14 @@ MPE_SCN_GENERIC, MPE_SCN_SIMPLE, MPE_SCN_SPREAD, MPE_SCN_TAG, MPE_SCN_ADVERSARY,
 MPE_SCN_SPEAKER_LISTENER, MPE_SCN_REFERENCE, MPE_SCN_CRYPTO, MPE_SCN_WORLD_COMM = 6, 7, 8, 9
 COMM_KINDS = (MPE_SCN_SPEAKER_LISTENER, MPE_SCN_REFERENCE, MPE_SCN_CRYPTO, MPE_SCN_WORLD_COMM)   # agents speak: MpeBuffers.comm
 MPE_MAX_CHOICES = 4
+# the composable output stage (include/mpe_hip.h, enum MpeRowOp)
+MPE_ROWS_MAX_ENTITIES = 16
+MPE_ROW_SELF = 255
+(MPE_ROW_OBS_VEL, MPE_ROW_OBS_POS, MPE_ROW_OBS_REL, MPE_ROW_OBS_REL_PICK, MPE_ROW_OBS_COMM, MPE_ROW_OBS_CONST, MPE_ROW_OBS_ONEHOT,
+ MPE_ROW_OBS_REL_VIS, MPE_ROW_OBS_VEL_VIS, MPE_ROW_OBS_IN_REGION) = range(1, 11)
+(MPE_ROW_R_D2, MPE_ROW_R_MIN_D2, MPE_ROW_R_D2_PICK, MPE_ROW_R_MIN_D2_PICK, MPE_ROW_R_SQRT, MPE_ROW_R_BOUND, MPE_ROW_R_COMM_ERR,
+ MPE_ROW_R_COMM_SUM, MPE_ROW_R_CONST, MPE_ROW_R_SAVE, MPE_ROW_R_LOAD, MPE_ROW_R_ZERO, MPE_ROW_R_ADD, MPE_ROW_R_ADD_IF_HIT,
+ MPE_ROW_R_ADD_ACC, MPE_ROW_R_STORE) = range(32, 48)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPE_HIP_LIB") or os.path.join(_HERE, "lib", "libmpe_hip.so")  # override: A/B builds
@@ -42,6 +50,14 @@ class MpeBuffers(C.Structure):
     ]
 
 
+class MpeRowProgram(C.Structure):
+    _fields_ = [
+        ("ops_device", C.c_void_p), ("n_ops", C.c_int32), ("obs_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)),
+        ("rew_begin", C.c_int32), ("rew_end", C.c_int32), ("n_vel", C.c_int32), ("n_regions", C.c_int32),
+        ("region_entity", C.c_int32 * 2), ("all_seeing", C.c_uint32),
+    ]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "mpe_abi_version": (C.c_int, []),
@@ -66,6 +82,9 @@ EXPORTS = {
                                            C.c_int32, C.c_int64, C.c_void_p]),
     "mpe_random_comm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_uint32, C.c_uint64, C.c_uint64,
                                   C.c_int32, C.c_int64, C.c_void_p]),
+    "mpe_rows_validate": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeRowProgram), C.POINTER(C.c_int32)]),
+    "mpe_rows": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.POINTER(MpeRowProgram), C.c_int64, C.c_void_p]),
+    "mpe_sizeof_row_program": (C.c_size_t, []),
     "mpe_episode_tick": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "mpe_rollout_random": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_int32,
                                      C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32,
@@ -97,7 +116,8 @@ def lib():
         fn.argtypes = args
     if handle.mpe_abi_version() != MPE_ABI_VERSION:
         raise MpeError("ABI version mismatch: library %d, binding %d" % (handle.mpe_abi_version(), MPE_ABI_VERSION))
-    if handle.mpe_sizeof_desc() != C.sizeof(MpeScenarioDesc) or handle.mpe_sizeof_buffers() != C.sizeof(MpeBuffers):
+    if handle.mpe_sizeof_desc() != C.sizeof(MpeScenarioDesc) or handle.mpe_sizeof_buffers() != C.sizeof(MpeBuffers) or \
+            handle.mpe_sizeof_row_program() != C.sizeof(MpeRowProgram):
         raise MpeError("struct layout mismatch between include/mpe_hip.h and _abi.py")
     _lib = handle
     return _lib

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmpe_hip.so")
-SOURCES = ["mpe_abi.hip", "mpe_narrow.hip", "mpe_split.hip", "mpe_wide.hip", "mpe_rng.hip"]
+SOURCES = ["mpe_abi.hip", "mpe_narrow.hip", "mpe_split.hip", "mpe_wide.hip", "mpe_rng.hip", "mpe_rows.hip"]
 HEADERS = ["mpe_device.h", "mpe_internal.h", os.path.join("..", "..", "include", "mpe_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function",

@@ -169,6 +169,7 @@ int mpe_abi_version(void) { return MPE_ABI_VERSION; }
 const char *mpe_last_error(void) { return g_err; }
 size_t mpe_sizeof_desc(void) { return sizeof(MpeScenarioDesc); }
 size_t mpe_sizeof_buffers(void) { return sizeof(MpeBuffers); }
+size_t mpe_sizeof_row_program(void) { return sizeof(MpeRowProgram); }
 
 int mpe_fill_obs_layout(MpeScenarioDesc *d) {
   if (int rc = check_desc(d, "mpe_fill_obs_layout")) return rc;
@@ -426,6 +427,138 @@ int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
   const mpe::NarrowDesc n = make_narrow(d, b, (size_t)B);
   return hip_result(mpe::launch_split(true, d->kind, d->n_agents, d->n_landmarks, d->n_adversaries, n, *b, (size_t)B,
                                       ra, s), what);
+}
+
+// ---- the composable output stage (mpe_rows.hip) -------------------------------------------------------------------------
+static int rows_header(const char *what, const MpeScenarioDesc *d, const MpeRowProgram *p, mpe::RowHeader *h) {
+  if (int rc = check_desc(d, what)) return rc;
+  if (!p) return fail(MPE_EINVAL, "%s: prog is NULL", what);
+  const int A = d->n_agents, E = d->n_agents + d->n_landmarks;
+  if (E > MPE_ROWS_MAX_ENTITIES) return fail(MPE_EUNSUPPORTED, "%s: row programs cover A + L <= %d (got %d)", what, MPE_ROWS_MAX_ENTITIES, E);
+  if (p->n_ops < 0 || (p->n_ops > 0 && !p->ops_device)) return fail(MPE_EINVAL, "%s: prog->ops_device is NULL", what);
+  if (p->n_vel < 0 || p->n_vel > E) return fail(MPE_EINVAL, "%s: prog->n_vel = %d, need 0 .. A + L", what, p->n_vel);
+  if (p->n_regions < 0 || p->n_regions > 2) return fail(MPE_EINVAL, "%s: prog->n_regions = %d, need 0 .. 2", what, p->n_regions);
+  for (int r = 0; r < p->n_regions; ++r)
+    if (p->region_entity[r] < 0 || p->region_entity[r] >= E) return fail(MPE_EINVAL, "%s: region %d names entity %d", what, r, p->region_entity[r]);
+  int prev = 0;
+  for (int i = 0; i <= A; ++i) {
+    if (p->obs_begin[i] < prev || p->obs_begin[i] > p->n_ops) return fail(MPE_EINVAL, "%s: obs_begin[%d] = %d out of order / range", what, i, p->obs_begin[i]);
+    prev = p->obs_begin[i];
+  }
+  if (p->rew_begin < 0 || p->rew_end < p->rew_begin || p->rew_end > p->n_ops) return fail(MPE_EINVAL, "%s: bad reward program range", what);
+  h->n_agents = A;
+  h->n_entities = E;
+  h->n_vel = p->n_vel;
+  h->dim_c = d->dim_c;
+  h->collaborative = d->collaborative;
+  h->d_max = 1;
+  for (int i = 0; i < A; ++i) {
+    const int D = d->obs_off[i + 1] - d->obs_off[i];
+    if (D < 0) return fail(MPE_EINVAL, "%s: desc->obs_off is not a prefix sum", what);
+    if (D > h->d_max) h->d_max = D;
+  }
+  for (int i = 0; i <= MPE_ROWS_MAX_ENTITIES; ++i) h->obs_begin[i] = i <= A ? p->obs_begin[i] : p->obs_begin[A];
+  h->rew_begin = p->rew_begin;
+  h->rew_end = p->rew_end;
+  h->n_regions = p->n_regions;
+  h->region_entity[0] = p->n_regions > 0 ? p->region_entity[0] : 0;
+  h->region_entity[1] = p->n_regions > 1 ? p->region_entity[1] : 0;
+  h->all_seeing = p->all_seeing;
+  return 0;
+}
+
+int mpe_rows_validate(const MpeScenarioDesc *d, const MpeRowProgram *p, const int32_t *ops) {
+  const char *what = "mpe_rows_validate";
+  mpe::RowHeader h;
+  if (int rc = rows_header(what, d, p, &h)) return rc;
+  if (p->n_ops > 0 && !ops) return fail(MPE_EINVAL, "%s: ops_host is NULL", what);
+  const int A = d->n_agents, E = A + d->n_landmarks;
+  auto ent = [&](int a, bool self_ok) { return (self_ok && a == MPE_ROW_SELF) || (a >= 0 && a < E); };
+  for (int i = 0; i < A; ++i) {
+    int width = 0;
+    for (int pc = p->obs_begin[i]; pc < p->obs_begin[i + 1]; ++pc) {
+      const int32_t w0 = ops[4 * pc], w1 = ops[4 * pc + 1];
+      const int code = w0 & 0xff, a0 = (w0 >> 8) & 0xff, a1 = (w0 >> 16) & 0xff;
+      switch (code) {
+        case MPE_ROW_OBS_VEL: case MPE_ROW_OBS_POS: case MPE_ROW_OBS_REL: case MPE_ROW_OBS_REL_VIS: case MPE_ROW_OBS_VEL_VIS:
+          if (!ent(a0, true)) return fail(MPE_EINVAL, "%s: op %d (agent %d): entity %d out of range", what, pc, i, a0);
+          if ((code == MPE_ROW_OBS_REL_VIS || code == MPE_ROW_OBS_VEL_VIS) && (a0 == MPE_ROW_SELF ? i : a0) >= A)
+            return fail(MPE_EINVAL, "%s: op %d: visibility is defined between agents", what, pc);
+          width += 2;
+          break;
+        case MPE_ROW_OBS_REL_PICK:
+          if (a1 >= d->n_choices || w1 < 0 || w1 + d->choice_pop[a1 < MPE_MAX_CHOICES ? a1 : 0] > E)
+            return fail(MPE_EINVAL, "%s: op %d (agent %d): pick %d with base %d leaves the entity list", what, pc, i, a1, w1);
+          width += 2;
+          break;
+        case MPE_ROW_OBS_COMM:
+          if (!ent(a0, true) || (a0 == MPE_ROW_SELF ? i : a0) >= A || a1 > d->dim_c)
+            return fail(MPE_EINVAL, "%s: op %d (agent %d): utterance of agent %d, %d floats (dim_c = %d)", what, pc, i, a0, a1, d->dim_c);
+          width += a1;
+          break;
+        case MPE_ROW_OBS_CONST: width += 1; break;
+        case MPE_ROW_OBS_ONEHOT:
+          if (a0 >= d->n_choices) return fail(MPE_EINVAL, "%s: op %d (agent %d): pick %d of %d", what, pc, i, a0, d->n_choices);
+          width += a1;
+          break;
+        case MPE_ROW_OBS_IN_REGION:
+          if (!ent(a0, true) || a1 >= p->n_regions) return fail(MPE_EINVAL, "%s: op %d (agent %d): region %d of %d", what, pc, i, a1, p->n_regions);
+          width += 1;
+          break;
+        default: return fail(MPE_EINVAL, "%s: op %d (agent %d): code %d is not an observation op", what, pc, i, code);
+      }
+    }
+    if (width != d->obs_off[i + 1] - d->obs_off[i])
+      return fail(MPE_EINVAL, "%s: agent %d's program emits %d columns, desc->obs_off says %d", what, i, width, d->obs_off[i + 1] - d->obs_off[i]);
+  }
+  int stored = 0;
+  for (int pc = p->rew_begin; pc < p->rew_end; ++pc) {
+    const int32_t w0 = ops[4 * pc], w1 = ops[4 * pc + 1];
+    const int code = w0 & 0xff, a0 = (w0 >> 8) & 0xff, a1 = (w0 >> 16) & 0xff;
+    switch (code) {
+      case MPE_ROW_R_D2: case MPE_ROW_R_MIN_D2: case MPE_ROW_R_ADD_IF_HIT:
+        if (!ent(a0, false) || !ent(a1, false)) return fail(MPE_EINVAL, "%s: reward op %d: entities %d, %d out of range", what, pc, a0, a1);
+        break;
+      case MPE_ROW_R_D2_PICK: case MPE_ROW_R_MIN_D2_PICK:
+        if (!ent(a0, false) || a1 >= d->n_choices || w1 < 0 || w1 + d->choice_pop[a1 < MPE_MAX_CHOICES ? a1 : 0] > E)
+          return fail(MPE_EINVAL, "%s: reward op %d: pick %d with base %d leaves the entity list", what, pc, a1, w1);
+        break;
+      case MPE_ROW_R_BOUND:
+        if (!ent(a0, false) || a1 > 1) return fail(MPE_EINVAL, "%s: reward op %d: coordinate %d of entity %d", what, pc, a1, a0);
+        break;
+      case MPE_ROW_R_COMM_ERR:
+        if (a0 >= A || a1 >= d->n_choices) return fail(MPE_EINVAL, "%s: reward op %d: utterance of agent %d against pick %d", what, pc, a0, a1);
+        break;
+      case MPE_ROW_R_COMM_SUM:
+        if (a0 >= A) return fail(MPE_EINVAL, "%s: reward op %d: utterance of agent %d", what, pc, a0);
+        break;
+      case MPE_ROW_R_SAVE: case MPE_ROW_R_LOAD:
+        if (a0 >= mpe::kRowSlots) return fail(MPE_EINVAL, "%s: reward op %d: slot %d of %d", what, pc, a0, mpe::kRowSlots);
+        break;
+      case MPE_ROW_R_STORE:
+        if (a0 >= A || ((stored >> a0) & 1)) return fail(MPE_EINVAL, "%s: reward op %d: STORE of agent %d (out of range or twice)", what, pc, a0);
+        stored |= 1 << a0;
+        break;
+      case MPE_ROW_R_SQRT: case MPE_ROW_R_CONST: case MPE_ROW_R_ZERO: case MPE_ROW_R_ADD: case MPE_ROW_R_ADD_ACC: break;
+      default: return fail(MPE_EINVAL, "%s: op %d: code %d is not a reward op", what, pc, code);
+    }
+  }
+  if (p->rew_end > p->rew_begin && stored != (1 << A) - 1)
+    return fail(MPE_EINVAL, "%s: the reward program stores agents %#x, not all %d", what, stored, A);
+  return 0;
+}
+
+int mpe_rows(const MpeScenarioDesc *d, const MpeBuffers *b, const MpeRowProgram *p, int64_t B, void *stream) {
+  const char *what = "mpe_rows";
+  mpe::RowHeader h;
+  if (int rc = rows_header(what, d, p, &h)) return rc;
+  if (int rc = check_state(b, B, what)) return rc;
+  if (int rc = need(b->obs, what, "obs")) return rc;
+  if (d->n_choices > 0) if (int rc = need(b->choice, what, "choice (the per-world picks of reset_world)")) return rc;
+  if (d->dim_c > 0) if (int rc = need(b->comm, what, "comm (the agents' utterances)")) return rc;
+  if (B == 0) return 0;
+  const mpe::NarrowDesc n = make_narrow(d, b, (size_t)B);
+  return hip_result(mpe::launch_rows(n, *b, h, p->ops_device, (size_t)B, static_cast<hipStream_t>(stream)), what);
 }
 
 }  // extern "C"

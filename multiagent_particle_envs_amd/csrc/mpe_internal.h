@@ -57,4 +57,28 @@ bool split_supports(int kind, int A, int L, int nadv);
 int launch_split(bool roll, int kind, int A, int L, int nadv, const NarrowDesc &d, const MpeBuffers &b, size_t B,
                  const RollArgs &ra, hipStream_t stream);
 
+// the composable output stage (mpe_rows.hip): kernel-side header of an MpeRowProgram
+constexpr int kRowSlots = 8;
+constexpr int kRowMaxObsWaves = 15;   // + the reward wave = 1024 threads
+constexpr int kRowSelf = MPE_ROW_SELF;
+enum {
+  ROW_OBS_VEL = MPE_ROW_OBS_VEL, ROW_OBS_POS = MPE_ROW_OBS_POS, ROW_OBS_REL = MPE_ROW_OBS_REL, ROW_OBS_REL_PICK = MPE_ROW_OBS_REL_PICK,
+  ROW_OBS_COMM = MPE_ROW_OBS_COMM, ROW_OBS_CONST = MPE_ROW_OBS_CONST, ROW_OBS_ONEHOT = MPE_ROW_OBS_ONEHOT,
+  ROW_OBS_REL_VIS = MPE_ROW_OBS_REL_VIS, ROW_OBS_VEL_VIS = MPE_ROW_OBS_VEL_VIS, ROW_OBS_IN_REGION = MPE_ROW_OBS_IN_REGION,
+  ROW_R_D2 = MPE_ROW_R_D2, ROW_R_MIN_D2 = MPE_ROW_R_MIN_D2, ROW_R_D2_PICK = MPE_ROW_R_D2_PICK, ROW_R_MIN_D2_PICK = MPE_ROW_R_MIN_D2_PICK,
+  ROW_R_SQRT = MPE_ROW_R_SQRT, ROW_R_BOUND = MPE_ROW_R_BOUND, ROW_R_COMM_ERR = MPE_ROW_R_COMM_ERR, ROW_R_COMM_SUM = MPE_ROW_R_COMM_SUM,
+  ROW_R_CONST = MPE_ROW_R_CONST, ROW_R_SAVE = MPE_ROW_R_SAVE, ROW_R_LOAD = MPE_ROW_R_LOAD, ROW_R_ZERO = MPE_ROW_R_ZERO,
+  ROW_R_ADD = MPE_ROW_R_ADD, ROW_R_ADD_IF_HIT = MPE_ROW_R_ADD_IF_HIT, ROW_R_ADD_ACC = MPE_ROW_R_ADD_ACC, ROW_R_STORE = MPE_ROW_R_STORE
+};
+struct RowHeader {
+  int32_t n_agents, n_entities, n_vel, dim_c, collaborative;
+  int32_t d_max;                 // widest observation row (floats): the waves' tile size
+  int32_t obs_begin[MPE_ROWS_MAX_ENTITIES + 1];
+  int32_t rew_begin, rew_end;
+  int32_t n_regions, region_entity[2];
+  uint32_t all_seeing;
+};
+int launch_rows(const NarrowDesc &d, const MpeBuffers &b, const RowHeader &h, const int32_t *ops_device, size_t B,
+                hipStream_t stream);
+
 }  // namespace mpe

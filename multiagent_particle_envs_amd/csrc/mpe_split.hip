@@ -57,17 +57,24 @@
 // set -- taken after `s_waitcnt vmcnt(0)`, i.e. when the wave's stores are ACKNOWLEDGED (the true end of its memory work,
 // but the stamp's store then adds one more round trip behind it: ~0.6 us on the launch).  Not part of the product build.
 #ifdef MPE_DEVICE_SPAN
-#define MPE_SPAN_STAMP(k)                                                                                          \
+// (the start time is only READ at the top -- s_memrealtime into SGPRs, in flight next to the kernel's own scalar loads -- and
+//  stored together with the end time by ONE 16-byte store at the wave's end: a store, or a wait for the clock, in front of
+//  the wave's first loads would put a scalar round trip on the launch's critical path: measured +0.5-0.9 us on a 3 us launch)
+#define MPE_SPAN_BEGIN() const unsigned long long span_t0_ = (unsigned long long)wall_clock64()
+#define MPE_SPAN_END()                                                                                             \
   do {                                                                                                             \
     if (b_in.force && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) {                                           \
       const uintptr_t sp_ = reinterpret_cast<uintptr_t>(b_in.force);                                                \
-      if ((k) && (sp_ & 1)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                             \
-      reinterpret_cast<unsigned long long *>(sp_ & ~(uintptr_t)7)[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 2 + (k)] = \
-          wall_clock64();                                                                                          \
+      if (sp_ & 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
+      ulonglong2 st_;                                                                                              \
+      st_.x = span_t0_;                                                                                            \
+      st_.y = (unsigned long long)wall_clock64();                                                                  \
+      reinterpret_cast<ulonglong2 *>(sp_ & ~(uintptr_t)7)[(size_t)blockIdx.x * 8 + (threadIdx.x >> 6)] = st_;       \
     }                                                                                                              \
   } while (0)
 #else
-#define MPE_SPAN_STAMP(k) do { } while (0)
+#define MPE_SPAN_BEGIN() do { } while (0)
+#define MPE_SPAN_END() do { } while (0)
 #endif
 
 namespace mpe {
@@ -474,7 +481,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
   // scalar round trip to the kernarg segment in front of them (three dependent ones before: the sizes, the
   // MpeBuffers block, the per-agent constants).  Everything else still comes from the structs behind them.
   using S = SplitShape<KIND, A, L, NADV>;
-  MPE_SPAN_STAMP(0);
+  MPE_SPAN_BEGIN();
   MpeBuffers b = b_in;
   b.pos = g_pos;
   b.vel = g_vel;
@@ -584,7 +591,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
                                           ra.step0 + (uint64_t)t, goal_r, food);
       MPE_STAMP(3);
     }
-    MPE_SPAN_STAMP(1);
+    MPE_SPAN_END();
     return;
   }
 
@@ -1041,7 +1048,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         rows(t);
         MPE_STAMP(5);
       }
-      MPE_SPAN_STAMP(1);
+      MPE_SPAN_END();
       return;
     }
     // ---- PHYSICS wave of agent i: World.step of step t+1 behind barrier t, from the siblings' state of step t -----------
@@ -1107,7 +1114,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       store_aux<AUX>(b.vel + wave_off((size_t)(2 * i + 1) * B + w0) + ln, mvy);
     }
   }
-  MPE_SPAN_STAMP(1);
+  MPE_SPAN_END();
 }
 
 // ---- dispatch -----------------------------------------------------------------------------------

@@ -163,23 +163,48 @@ class MultiAgentEnv(object):
             is_builtin(info_callback, "benchmark_data") and kind in (_abi.MPE_SCN_SPREAD, _abi.MPE_SCN_TAG, _abi.MPE_SCN_ADVERSARY,
                                                                       _abi.MPE_SCN_WORLD_COMM))
         self._py_done = own and done_callback is not None
+        # ---- ... or as World.step + an interpreted row program (rowspec.py: the scenario DESCRIBES its rows and rewards) ----
+        # A scenario without a kernel of its own that supplies obs_spec / reward_spec for every agent steps in two launches
+        # (mpe_world_step + mpe_rows) instead of the generic path's ~100; the specs win over Python observation / reward
+        # callbacks of the same scenario (pass fused=False to keep the Python ones).
+        self._prog = None
+        if sc is None:
+            sc = next((getattr(cb, "__self__", None) for cb in (reward_callback, reset_callback) if cb is not None), None)
+        if not own and fused is not False and sc is not None and hasattr(sc, "obs_spec") and hasattr(sc, "reward_spec") and \
+                len(world.scripted_agents) == 0 and not any(l.movable for l in world.landmarks) and \
+                len(world.entities) <= _abi.MPE_ROWS_MAX_ENTITIES and \
+                not any(a.u_noise or (a.c_noise and not a.silent) for a in world.agents) and world.pos is not None:
+            from . import rowspec
+            self._prog = rowspec.compile_scenario(sc, world)
         if fused is None:
-            fused = own
-        if fused and not own:
+            fused = own or self._prog is not None
+        if fused and not own and self._prog is None:
             raise _abi.MpeError("fused=True needs a built-in scenario with its own observation or its own reward callback at a "
-                                "shape libmpe_hip.so has a kernel for (mpe_step_supported), without scripted agents or noise")
+                                "shape libmpe_hip.so has a kernel for (mpe_step_supported), or a scenario with obs_spec / "
+                                "reward_spec, without scripted agents or noise")
         self.fused = bool(fused)
-        self._comm_kind = self.fused and kind in _abi.COMM_KINDS
+        if not self.fused or own:
+            self._prog = None
+        self._has_speakers = any(not a.silent for a in world.agents)
+        self._comm_kind = self.fused and (kind in _abi.COMM_KINDS if self._prog is None else self._has_speakers)
         self._scenario = sc
-        self._kind = kind if self.fused else _abi.MPE_SCN_GENERIC
-        self._benchmark = self.fused and info_callback is not None and not self._py_info
+        self._kind = kind if self.fused and self._prog is None else _abi.MPE_SCN_GENERIC
+        self._benchmark = self.fused and self._prog is None and info_callback is not None and not self._py_info
         if not self.fused:
             self._py_obs = self._py_reward = self._py_info = self._py_done = False
+        if self._prog is not None:      # rows and rewards are the program's; benchmark_data / done stay Python callbacks
+            self._py_obs = self._py_reward = False
+            self._py_info = info_callback is not None
+            self._py_done = done_callback is not None
 
         # ---- spaces (environment.py:38-70) -------------------------------------------------------------
         self.action_space = []
         self.observation_space = []
-        if self.fused:
+        if self._prog is not None:
+            self._desc = self._program_desc()
+            self._obs_off = [int(self._desc.obs_off[i]) for i in range(len(world.agents) + 1)]
+            obs_dims = list(self._prog.widths)
+        elif self.fused:
             self._desc = world.scenario_desc(kind, getattr(sc, "num_adversaries", 0))
             self._obs_off = [int(self._desc.obs_off[i]) for i in range(len(world.agents) + 1)]
             obs_dims = [self._obs_off[i + 1] - self._obs_off[i] for i in range(len(world.agents))]
@@ -245,12 +270,31 @@ class MultiAgentEnv(object):
             self._comm_kind = self._kind in _abi.COMM_KINDS
             self._unfused_by_noise = False
         if self.fused:
-            self._desc = w.scenario_desc(self._kind, getattr(self._scenario, "num_adversaries", 0))
+            self._desc = self._program_desc() if self._prog is not None else \
+                w.scenario_desc(self._kind, getattr(self._scenario, "num_adversaries", 0))
             if self._sets is not None:
                 self._entity_table = w.entity_table(self._desc)
                 self._desc_ref = C.byref(self._desc)
                 for out in self._sets:
                     out.bufs.entity_table = self._entity_table.data_ptr()
+
+    def _program_desc(self):
+        """The descriptor of a row-program env: the world's physics constants (kind GENERIC) + the programs' row widths."""
+        src = self.world.scenario_desc(_abi.MPE_SCN_GENERIC)
+        d = _abi.MpeScenarioDesc()
+        C.memmove(C.byref(d), C.byref(src), C.sizeof(d))
+        off = 0
+        for i, wd in enumerate(self._prog.widths):
+            d.obs_off[i] = off
+            off += int(wd)
+        d.obs_off[len(self._prog.widths)] = off
+        self._prog.validate(d)
+        return d
+
+    def _program_step(self, desc_ref, bufs_ref, B, st):
+        """World.step, then every agent's row / reward / done from the post-step state: two launches."""
+        L = _abi.lib()
+        return L.mpe_world_step(desc_ref, bufs_ref, B, st) or L.mpe_rows(desc_ref, bufs_ref, self._prog.ref, B, st)
 
     @property
     def step_impl(self):
@@ -264,7 +308,7 @@ class MultiAgentEnv(object):
         if value not in ("split", "thread"):
             raise _abi.MpeError("step_impl is 'split' or 'thread'")
         self._step_impl = value
-        if self._sets is not None:
+        if self._sets is not None and self._prog is None:
             self._mpe_step = _abi.lib().mpe_step_thread if value == "thread" else _abi.lib().mpe_step
 
     @property
@@ -292,7 +336,9 @@ class MultiAgentEnv(object):
         self._entity_table = w.entity_table(self._desc)   # read by the wave-per-world (large N) kernel only
         self._desc_ref = C.byref(self._desc)
         self._mpe_step = _abi.lib().mpe_step_thread if self.step_impl == "thread" else _abi.lib().mpe_step
-        if self._kind in _abi.COMM_KINDS:
+        if self._prog is not None:
+            self._mpe_step = self._program_step
+        if self._kind in _abi.COMM_KINDS or (self._prog is not None and w.dim_c > 0):
             self._comm = torch.zeros((A, B, w.dim_c), dtype=torch.float32, device=w.device)
         self._act = torch.zeros((A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=w.device)
         self._ids = torch.zeros((A, B), dtype=torch.int32, device=w.device)
@@ -387,7 +433,7 @@ class MultiAgentEnv(object):
         """Bring the caller's actions into the [A,B,5] fp32 (or [A,B] int32) device layout; a tensor
         that already has it is used in place (zero copy)."""
         A, B = len(self.agents), self.batch_size
-        if self._comm is not None:
+        if self._comm is not None and self._has_speakers:
             return self._stage_comm_actions(action_n), None
         if self.discrete_action_input:
             if torch.is_tensor(action_n) and action_n.shape == (A, B) and action_n.dtype == torch.int32 \
@@ -584,8 +630,12 @@ class MultiAgentEnv(object):
         b.rew = b.done = b.info_rew = b.info_collisions = b.info_min_dists = b.info_occupied = None
         b.act = b.ids = b.u = None
         try:
-            _abi.check(_abi.lib().mpe_observe(C.byref(self._desc), C.byref(b), self.batch_size, self._stream()),
-                       "mpe_observe")
+            if self._prog is not None:
+                _abi.check(_abi.lib().mpe_rows(C.byref(self._desc), C.byref(b), self._prog.ref, self.batch_size, self._stream()),
+                           "mpe_rows")
+            else:
+                _abi.check(_abi.lib().mpe_observe(C.byref(self._desc), C.byref(b), self.batch_size, self._stream()),
+                           "mpe_observe")
         finally:
             (b.rew, b.done, b.info_rew, b.info_collisions, b.info_min_dists, b.info_occupied, b.act, b.ids, b.u) = saved
 
@@ -716,6 +766,26 @@ class MultiAgentEnv(object):
         for i, agent in enumerate(self.agents):
             self._set_action(action_n[i], agent, self.action_space[i])
         self.world.step()
+        if self._prog is not None and self.fused:
+            # an action mode the physics launch does not decode (integer ids with communication, continuous forces): the
+            # actions were decoded in torch and World.step ran on its own; rows and rewards are still the program's
+            self._ensure_buffers()
+            for i, agent in enumerate(self.world.agents):
+                if self._comm is not None and not agent.silent and torch.is_tensor(agent.state.c):
+                    self._comm[i].copy_(agent.state.c)
+            out = self._next_set()
+            b = out.bufs
+            b.act = b.ids = b.u = None
+            _abi.check(_abi.lib().mpe_rows(C.byref(self._desc), out.bufs_ref, self._prog.ref, self.batch_size, self._stream()), "mpe_rows")
+            done_n, done = out.done_n, out.done
+            if self._py_done:
+                done = torch.stack([torch.as_tensor(self._get_done(a), device=self.world.device).bool().expand(self.batch_size)
+                                    for a in self.agents]).contiguous()
+                done_n = [done[i] for i in range(self.n)]
+            info_n = {'n': [self._get_info(a) for a in self.agents]}
+            if self.max_episode_steps and self._episode_tick(done):
+                self._observe_into(out)
+            return self._deliver(out.obs_n, out.reward_n, done_n, info_n)
         obs_n, reward_n, done_n, info_n = [], [], [], {'n': []}
         for agent in self.agents:
             obs_n.append(self._get_obs(agent))

@@ -40,7 +40,8 @@ def make_env(scenario_name, benchmark=False, batch_size=None, device=None, seed=
     if world.pos.is_cuda or compat:
         scenario.reset_world(world)
     info_cb = getattr(scenario, "benchmark_data", None) if benchmark else None
-    env = MultiAgentEnv(world, scenario.reset_world, scenario.reward, scenario.observation, info_cb,
+    # (a scenario that DESCRIBES its rows -- obs_spec / reward_spec, rowspec.py -- need not have Python callbacks at all)
+    env = MultiAgentEnv(world, scenario.reset_world, getattr(scenario, "reward", None), getattr(scenario, "observation", None), info_cb,
                         numpy_io=compat, fresh_outputs=fresh_outputs or compat, fused=fused,
                         max_episode_steps=max_episode_steps, auto_reset=auto_reset, probe_placement=probe_placement)
     env.scenario = scenario

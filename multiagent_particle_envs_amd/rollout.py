@@ -31,8 +31,8 @@ class RandomRollout(object):
         measured slower still: 13.0 vs 9.4 us per step; drawing the next BLOCK on a side stream, one fork/join per
         episode (commit d24e237), is slower too: 8.2-8.3 vs 7.3 us per step at B = 65536, 92.9 vs 85.2 at B = 1M --
         concurrent kernels do not overlap usefully on this stack.  The block draw is one 98 MB-write launch per 25 steps.)"""
-        if not env.fused:
-            raise _abi.MpeError("RandomRollout drives the fused built-in scenarios")
+        if not env.fused or getattr(env, "_prog", None) is not None:
+            raise _abi.MpeError("RandomRollout drives the fused built-in scenarios (a row-program env steps through env.step / GraphedStep)")
         if env._py_obs or env._py_reward or env._py_done or env._py_info:
             raise _abi.MpeError("RandomRollout runs on the device and evaluates the built-in callbacks only: this env has "
                                 "Python observation / reward / done / info callbacks (use env.step, or GraphedStep)")

@@ -1,0 +1,459 @@
+"""ObsSpec / RewardSpec: a scenario's observation and reward as DATA the `mpe_rows` kernel interprets.
+
+The reference's plug-in promise is that writing a new scenario is the normal use (README "Creating new environments",
+scenario.py:4-10).  With the torch protocol a new scenario's callbacks are Python: a hundred-odd small launches per
+step.  But every observation the reference ships is a concatenation of a few SEGMENT kinds, and every reward an
+ordered sum of a few TERM kinds (simple_spread.py:72-100, simple_tag.py:84-147, simple_world_comm.py:143-289 ...), so a
+scenario can say WHAT its rows are instead of computing them:
+
+    class Scenario(BaseScenario):
+        def make_world(self, batch_size=1, device=None): ...
+        def reset_world(self, world, mask=None, seeds=None): ...
+        def obs_spec(self, agent, world):                 # instead of (or next to) observation(agent, world)
+            o = ObsSpec(world, agent)
+            o.vel().pos()
+            for lm in world.landmarks: o.rel(lm)
+            for other in world.agents:
+                if other is not agent: o.rel(other)
+            return o
+        def reward_spec(self, agent, world):              # instead of (or next to) reward(agent, world)
+            r = RewardSpec(world, agent)
+            for lm in world.landmarks:
+                r.min_dist([a for a in world.agents], lm).add(-1.0)
+            for a in world.agents:
+                r.add_if_touching(a, agent, -1.0)
+            return r
+
+`MultiAgentEnv` then steps the scenario in TWO launches -- `mpe_world_step` (World.step) + `mpe_rows` (every agent's
+row, reward, done) -- whatever the scenario is; no JIT, no generated code: the specs compile to a list of 16-byte ops
+(include/mpe_hip.h, enum MpeRowOp) uploaded once.  Arithmetic happens in program order with the kernels' own device
+functions, so a spec that follows a reference callback's order reproduces it to the fp32 bit; `builtin_specs` below
+holds the nine shipped scenarios written this way (tests/test_gpu_rowspec.py: bit-identical to their fused kernels).
+
+Entities are named by the objects themselves (`world.agents[k]`, `world.landmarks[k]`) or by index into
+`world.entities`; per-world picks (`agent.goal_a = np.random.choice(world.landmarks)`) by their row of
+`world.choice_i32`.
+"""
+import ctypes as C
+import struct
+
+import torch
+
+from . import _abi
+
+SELF = _abi.MPE_ROW_SELF
+
+
+def _f2i(x):
+    return struct.unpack("<i", struct.pack("<f", float(x)))[0]
+
+
+def _op(code, a0=0, a1=0, a2=0, w1=0, f0=0.0, f1=0.0):
+    for v in (code, a0, a1, a2):
+        if not 0 <= int(v) <= 255:
+            raise _abi.MpeError("row program: argument %r does not fit a byte" % (v,))
+    w0 = int(code) | (int(a0) << 8) | (int(a1) << 16) | (int(a2) << 24)
+    if w0 >= 1 << 31:
+        w0 -= 1 << 32
+    return (w0, int(w1), _f2i(f0), _f2i(f1))
+
+
+class _Spec(object):
+    def __init__(self, world, agent=None):
+        self.world = world
+        self.agent = agent
+        self.ops = []
+        self._ents = world.entities
+
+    def _e(self, ent, self_ok=False):
+        """An entity object / index -> its index in world.entities."""
+        if ent is None or (self_ok and ent is self.agent):
+            if self.agent is None:
+                raise _abi.MpeError("spec: no observing agent to default to")
+            return SELF if self_ok else self._ents.index(self.agent)
+        if isinstance(ent, int):
+            if not 0 <= ent < len(self._ents):
+                raise _abi.MpeError("spec: entity index %d out of range" % ent)
+            return ent
+        for k, e in enumerate(self._ents):
+            if e is ent:
+                return k
+        raise _abi.MpeError("spec: %r is not an entity of this world" % (ent,))
+
+    def _a(self, agent):
+        k = self._e(agent)
+        if k >= len(self.world.agents):
+            raise _abi.MpeError("spec: entity %d is not an agent" % k)
+        return k
+
+
+class ObsSpec(_Spec):
+    """One agent's observation row as a list of segments, in the order they are concatenated."""
+
+    def __init__(self, world, agent):
+        super(ObsSpec, self).__init__(world, agent)
+        self.width = 0
+
+    def _emit(self, op, w):
+        self.ops.append(op)
+        self.width += w
+        return self
+
+    def vel(self, ent=None):
+        """entity.state.p_vel (default: the observing agent's) -- 2 columns."""
+        return self._emit(_op(_abi.MPE_ROW_OBS_VEL, self._e(ent, True)), 2)
+
+    def pos(self, ent=None):
+        """entity.state.p_pos -- 2 columns."""
+        return self._emit(_op(_abi.MPE_ROW_OBS_POS, self._e(ent, True)), 2)
+
+    def rel(self, ent):
+        """ent.state.p_pos - agent.state.p_pos -- 2 columns."""
+        return self._emit(_op(_abi.MPE_ROW_OBS_REL, self._e(ent)), 2)
+
+    def rel_pick(self, pick, among):
+        """among[choice[pick]].state.p_pos - agent.state.p_pos: the per-world goal (`agent.goal_a.state.p_pos - ...`).
+        `among` = the entity list the pick indexes (consecutive in world.entities, e.g. world.landmarks)."""
+        base = self._e(among[0])
+        for k, e in enumerate(among):
+            if self._e(e) != base + k:
+                raise _abi.MpeError("spec: the entities a pick chooses among must be consecutive in world.entities")
+        return self._emit(_op(_abi.MPE_ROW_OBS_REL_PICK, 0, int(pick), 0, w1=base), 2)
+
+    def comm(self, agent, width=None):
+        """agent.state.c (what it said at this step) -- dim_c columns."""
+        n = int(self.world.dim_c if width is None else width)
+        return self._emit(_op(_abi.MPE_ROW_OBS_COMM, self._a(agent), n), n)
+
+    def const(self, *values):
+        """Constants (a colour, zeros for silent agents' utterances ...) -- one column each."""
+        for v in values:
+            self._emit(_op(_abi.MPE_ROW_OBS_CONST, f0=float(v)), 1)
+        return self
+
+    def onehot(self, pick, width, lo=0.0, hi=1.0, offset=0):
+        """`width` columns: hi where choice[pick] + offset == column, lo elsewhere -- a goal colour, a key."""
+        return self._emit(_op(_abi.MPE_ROW_OBS_ONEHOT, int(pick), int(width), 0, w1=int(offset), f0=lo, f1=hi), int(width))
+
+    def rel_visible(self, agent):
+        """rel(agent), zeros when the observer cannot see it (regions of the world: simple_world_comm.py:231-261)."""
+        return self._emit(_op(_abi.MPE_ROW_OBS_REL_VIS, self._a(agent)), 2)
+
+    def vel_visible(self, agent):
+        return self._emit(_op(_abi.MPE_ROW_OBS_VEL_VIS, self._a(agent)), 2)
+
+    def in_region(self, region, ent=None):
+        """+1 / -1: is the entity (default: the observer) inside region number `region` -- 1 column."""
+        return self._emit(_op(_abi.MPE_ROW_OBS_IN_REGION, self._e(ent, True), int(region)), 1)
+
+
+class RewardSpec(_Spec):
+    """One agent's reward as an ordered list of terms: a value register, two accumulators (acc 0 is the reward), 8 slots.
+    Every method returns self; `min_dist(...).add(-1.0)` reads "minus the distance of the nearest ..."."""
+
+    def dist2(self, a, b):
+        """v = |a - b|^2"""
+        self.ops.append(_op(_abi.MPE_ROW_R_D2, self._e(a), self._e(b)))
+        return self
+
+    def min_dist2(self, agents, b):
+        """v = min over `agents` of |agent - b|^2 (in list order)"""
+        for k, a in enumerate(agents):
+            self.ops.append(_op(_abi.MPE_ROW_R_D2 if k == 0 else _abi.MPE_ROW_R_MIN_D2, self._e(a), self._e(b)))
+        return self
+
+    def min_dist2_from(self, a, targets):
+        """v = min over `targets` of |a - target|^2"""
+        for k, t in enumerate(targets):
+            self.ops.append(_op(_abi.MPE_ROW_R_D2 if k == 0 else _abi.MPE_ROW_R_MIN_D2, self._e(a), self._e(t)))
+        return self
+
+    def dist2_pick(self, a, pick, among, minimum=False):
+        """v = |a - among[choice[pick]]|^2 (or min(v, that))"""
+        base = self._e(among[0])
+        self.ops.append(_op(_abi.MPE_ROW_R_MIN_D2_PICK if minimum else _abi.MPE_ROW_R_D2_PICK, self._e(a), int(pick), 0, w1=base))
+        return self
+
+    def sqrt(self):
+        self.ops.append(_op(_abi.MPE_ROW_R_SQRT))
+        return self
+
+    def min_dist(self, agents, b):
+        """v = min over `agents` of |agent - b| (the minimum is taken on the squares: sqrt is monotone)"""
+        return self.min_dist2(agents, b).sqrt()
+
+    def dist(self, a, b):
+        return self.dist2(a, b).sqrt()
+
+    def bound(self, ent, axis):
+        """v = bound(|coordinate|): 0 below 0.9, 10 (x - 0.9) to 1.0, min(exp(2x - 2), 10) beyond (simple_tag.py:103-108)"""
+        self.ops.append(_op(_abi.MPE_ROW_R_BOUND, self._e(ent), int(axis)))
+        return self
+
+    def comm_error(self, agent, pick):
+        """v = sum_c (agent.state.c[c] - onehot(choice[pick])[c])^2, 0 when the utterance is all zeros (simple_crypto.py:97-124)"""
+        self.ops.append(_op(_abi.MPE_ROW_R_COMM_ERR, self._a(agent), int(pick)))
+        return self
+
+    def comm_sum(self, agent):
+        self.ops.append(_op(_abi.MPE_ROW_R_COMM_SUM, self._a(agent)))
+        return self
+
+    def value(self, x):
+        self.ops.append(_op(_abi.MPE_ROW_R_CONST, f0=float(x)))
+        return self
+
+    def save(self, slot):
+        self.ops.append(_op(_abi.MPE_ROW_R_SAVE, int(slot)))
+        return self
+
+    def load(self, slot):
+        self.ops.append(_op(_abi.MPE_ROW_R_LOAD, int(slot)))
+        return self
+
+    def zero(self, acc=0):
+        self.ops.append(_op(_abi.MPE_ROW_R_ZERO, 0, 0, int(acc)))
+        return self
+
+    def add(self, coef=1.0, acc=0):
+        """acc = acc + coef * v"""
+        self.ops.append(_op(_abi.MPE_ROW_R_ADD, 0, 0, int(acc), f0=float(coef)))
+        return self
+
+    def add_if_touching(self, a, b, coef, acc=0):
+        """if |a - b| < a.size + b.size (strict, decided exactly): acc = acc + coef -- `if self.is_collision(a, b): rew += coef`"""
+        self.ops.append(_op(_abi.MPE_ROW_R_ADD_IF_HIT, self._e(a), self._e(b), int(acc), f0=float(coef)))
+        return self
+
+    def add_acc1(self):
+        """acc0 = acc0 + acc1 (a sub-sum the reference forms separately)"""
+        self.ops.append(_op(_abi.MPE_ROW_R_ADD_ACC))
+        return self
+
+
+class Regions(object):
+    """Landmarks that hide what is inside them (at most two) and the agents that see everybody anyway: the visibility rule
+    of ObsSpec.rel_visible / vel_visible / in_region (simple_world_comm.py:231-261: the forests, the leader)."""
+
+    def __init__(self, landmarks=(), all_seeing=()):
+        self.landmarks = list(landmarks)
+        self.all_seeing = list(all_seeing)
+
+
+class RowProgram(object):
+    """The compiled programs of one env: ops on the device + the MpeRowProgram header the C ABI takes."""
+
+    def __init__(self, world, obs_specs, reward_specs, regions=None):
+        A = len(world.agents)
+        if len(world.entities) > _abi.MPE_ROWS_MAX_ENTITIES:
+            raise _abi.MpeError("row programs cover at most %d entities" % _abi.MPE_ROWS_MAX_ENTITIES)
+        if len(obs_specs) != A or len(reward_specs) != A:
+            raise _abi.MpeError("one ObsSpec and one RewardSpec per agent")
+        ops, begin = [], [0]
+        for o in obs_specs:
+            ops += o.ops
+            begin.append(len(ops))
+        self.widths = [o.width for o in obs_specs]
+        rew_begin = len(ops)
+        for i, r in enumerate(reward_specs):
+            ops.append(_op(_abi.MPE_ROW_R_ZERO, 0, 0, 0))
+            ops.append(_op(_abi.MPE_ROW_R_ZERO, 0, 0, 1))
+            ops += r.ops
+            ops.append(_op(_abi.MPE_ROW_R_STORE, i))
+        self.n_ops = len(ops)
+        flat = [w for op in ops for w in op]
+        self.ops_host = (C.c_int32 * max(1, len(flat)))(*flat)
+        self.ops_device = torch.tensor(flat if flat else [0], dtype=torch.int32, device=world.device)
+        p = _abi.MpeRowProgram()
+        p.ops_device = self.ops_device.data_ptr()
+        p.n_ops = self.n_ops
+        for i in range(_abi.MPE_ROWS_MAX_ENTITIES + 1):
+            p.obs_begin[i] = begin[min(i, A)]
+        p.rew_begin, p.rew_end = rew_begin, len(ops)
+        p.n_vel = world.n_dynamic
+        regions = regions or Regions()
+        if len(regions.landmarks) > 2:
+            raise _abi.MpeError("at most two regions")
+        p.n_regions = len(regions.landmarks)
+        ents = world.entities
+        for r, lm in enumerate(regions.landmarks):
+            p.region_entity[r] = lm if isinstance(lm, int) else next(k for k, e in enumerate(ents) if e is lm)
+        mask = 0
+        for a in regions.all_seeing:
+            mask |= 1 << (a if isinstance(a, int) else next(k for k, e in enumerate(world.agents) if e is a))
+        p.all_seeing = mask
+        self.struct = p
+        self.ref = C.byref(p)
+
+    def validate(self, desc):
+        _abi.check(_abi.lib().mpe_rows_validate(C.byref(desc), self.ref, self.ops_host), "mpe_rows_validate")
+
+
+def compile_scenario(scenario, world):
+    """-> RowProgram when the scenario describes every agent's observation AND reward as specs (`obs_spec(agent, world)`,
+    `reward_spec(agent, world)`, optional `regions(world)`), else None."""
+    osf, rsf = getattr(scenario, "obs_spec", None), getattr(scenario, "reward_spec", None)
+    if osf is None or rsf is None:
+        return None
+    obs = [osf(a, world) for a in world.agents]
+    rew = [rsf(a, world) for a in world.agents]
+    if any(o is None for o in obs) or any(r is None for r in rew):
+        return None
+    rg = scenario.regions(world) if hasattr(scenario, "regions") else None
+    return RowProgram(world, obs, rew, rg)
+
+
+# ---- the nine shipped scenarios as specs: each follows its fused kernel's (= the reference callback's) order ---------------------
+def _others(world, agent):
+    return [a for a in world.agents if a is not agent]
+
+
+def builtin_specs(name, world):
+    """(obs_specs, reward_specs, regions) of a built-in scenario's world (as its make_world builds it)."""
+    ag, lm = world.agents, world.landmarks
+    A = len(ag)
+    nadv = sum(1 for a in ag if getattr(a, "adversary", False))
+    obs, rew, regions = [], [], None
+    collide = lambda a: bool(a.collide)
+    for i, me in enumerate(ag):
+        o, r = ObsSpec(world, me), RewardSpec(world, me)
+        adv = bool(getattr(me, "adversary", False))
+        good = [a for a in ag if not getattr(a, "adversary", False)]
+        advs = [a for a in ag if getattr(a, "adversary", False)]
+        if name == "simple":                       # simple.py:41-50
+            o.vel()
+            for l in lm:
+                o.rel(l)
+            r.dist2(me, lm[0]).add(-1.0)
+        elif name == "simple_spread":              # simple_spread.py:72-100
+            o.vel().pos()
+            for l in lm:
+                o.rel(l)
+            for a in _others(world, me):
+                o.rel(a)
+            o.const(*([0.0] * (world.dim_c * (A - 1))))
+            for l in lm:
+                r.min_dist(ag, l).add(-1.0)
+            if collide(me):
+                r.add_if_touching(me, me, -1.0)             # the agent against itself (Q1)
+                for a in _others(world, me):
+                    r.add_if_touching(a, me, -1.0)
+        elif name == "simple_tag":                 # simple_tag.py:84-147
+            o.vel().pos()
+            for l in lm:
+                o.rel(l)
+            for a in _others(world, me):
+                o.rel(a)
+            for a in _others(world, me):
+                if not a.adversary:
+                    o.vel(a)
+            if adv:
+                if collide(me):
+                    for g in good:
+                        for v in advs:
+                            r.add_if_touching(g, v, 10.0)
+            else:
+                if collide(me):
+                    for v in advs:
+                        r.add_if_touching(me, v, -10.0)
+                r.bound(me, 0).add(-1.0).bound(me, 1).add(-1.0)
+        elif name == "simple_adversary":           # simple_adversary.py:76-139
+            if not adv:
+                o.rel_pick(0, lm)
+            for l in lm:
+                o.rel(l)
+            for a in _others(world, me):
+                o.rel(a)
+            if adv:
+                r.dist2_pick(me, 0, lm).add(-1.0)
+            else:
+                for k, g in enumerate(good):
+                    r.dist2_pick(g, 0, lm, minimum=k > 0)
+                r.sqrt().add(-1.0)
+                for v in advs:
+                    r.dist2_pick(v, 0, lm).sqrt().add(1.0, acc=1)
+                r.add_acc1()
+        elif name == "simple_push":                # simple_push.py:60-96
+            o.vel()
+            if not adv:
+                o.rel_pick(0, lm)
+                o.onehot(0, 3, 0.25, 0.75, offset=1)
+            for l in lm:
+                o.rel(l)
+            if not adv:
+                for k in range(len(lm)):
+                    o.const(*[(0.1 + 0.8) if k + 1 == c else 0.1 for c in range(3)])
+            for a in _others(world, me):
+                o.rel(a)
+            if adv:
+                for k, g in enumerate(good):
+                    r.dist2_pick(g, 0, lm, minimum=k > 0)
+                r.sqrt().add(1.0)
+                r.dist2_pick(me, 0, lm).sqrt().add(-1.0)
+            else:
+                r.dist2_pick(me, 0, lm).sqrt().add(-1.0)
+        elif name == "simple_speaker_listener":    # simple_speaker_listener.py:63-92
+            if i == 0:
+                o.onehot(0, 3, 0.15, 0.65)
+            else:
+                o.vel()
+                for l in lm:
+                    o.rel(l)
+                o.comm(ag[0])
+            r.dist2_pick(ag[1], 0, lm).add(-1.0)
+        elif name == "simple_reference":           # simple_reference.py:57-83
+            o.vel()
+            for l in lm:
+                o.rel(l)
+            o.onehot(i, 3, 0.25, 0.75)
+            o.comm(ag[1 - i])
+            r.dist2_pick(ag[1 - i], i, lm).add(-1.0)
+        elif name == "simple_crypto":              # simple_crypto.py:97-169 (goal = pick 0, key = pick 1)
+            dc = world.dim_c
+            if i == 0:
+                o.comm(ag[2])
+                r.comm_error(ag[0], 0).add(-1.0)
+            else:
+                if i == 1:
+                    o.onehot(1, dc).comm(ag[2])
+                else:
+                    o.onehot(0, dc).onehot(1, dc)
+                r.comm_error(ag[0], 0).add(1.0)
+                r.comm_error(ag[1], 0).add(-1.0, acc=1)
+                r.add_acc1()
+        elif name == "simple_world_comm":          # simple_world_comm.py:143-289: landmarks = [obstacle] + food (2) + forests (2)
+            regions = Regions(lm[3:5], [ag[0]])
+            food = lm[1:3]
+            o.vel().pos()
+            for l in lm:
+                o.rel(l)
+            for a in _others(world, me):
+                o.rel_visible(a)
+            if not adv:
+                o.in_region(0).in_region(1)
+            for a in good:
+                if a is not me:
+                    o.vel_visible(a)
+            if adv:
+                o.in_region(0).in_region(1)
+                o.comm(ag[0])
+                for k, g in enumerate(good):
+                    r.ops.append(_op(_abi.MPE_ROW_R_D2 if k == 0 else _abi.MPE_ROW_R_MIN_D2, r._e(g), r._e(me)))
+                r.sqrt().add(-0.1)
+                if collide(me):
+                    for g in good:
+                        for v in advs:
+                            r.add_if_touching(g, v, 5.0)
+            else:
+                if collide(me):
+                    for v in advs:
+                        r.add_if_touching(me, v, -5.0)
+                r.bound(me, 0).add(-2.0).bound(me, 1).add(-2.0)
+                for f in food:
+                    r.add_if_touching(me, f, 2.0)
+                r.min_dist2_from(me, food).sqrt().add(0.05)
+        else:
+            raise KeyError(name)
+        obs.append(o)
+        rew.append(r)
+    return obs, rew, regions

@@ -11,7 +11,15 @@ scenario builds a World and supplies the reset / reward / observation callbacks 
     benchmark_data(agent, world)  (optional)             what `make_env(..., benchmark=True)` returns as info
 
 A scenario whose class attribute `kind` names one of the `MPE_SCN_*` kernels, with its callbacks left
-unmodified, is stepped by one fused launch; anything else runs these callbacks over the HIP physics.
+unmodified, is stepped by one fused launch.  A scenario of your own has two ways to run:
+
+    obs_spec(agent, world) -> rowspec.ObsSpec            DESCRIBE the row (segments) and the reward (ordered terms):
+    reward_spec(agent, world) -> rowspec.RewardSpec      two launches per step (mpe_world_step + mpe_rows), any scenario
+    observation(agent, world) / reward(agent, world)     COMPUTE them with torch ops on [B, .] views: the generic path,
+                                                         ~100 small launches per step (GraphedStep replays them as one)
+
+Specs win when a scenario has both (fused=False keeps the Python callbacks).  A file written against the REFERENCE's
+contract (`make_world(self)`, NumPy callbacks) loads unmodified through refstyle.py.
 """
 
 

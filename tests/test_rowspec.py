@@ -1,0 +1,309 @@
+"""ObsSpec / RewardSpec row programs (rowspec.py, csrc/mpe_rows.hip): a scenario DESCRIBES its observation rows and reward
+terms, `mpe_rows` interprets them -- two launches per step for any scenario.
+
+  not gpu   the nine built-ins compile to programs whose row widths equal the kernels' layout (mpe_fill_obs_layout) and pass
+            mpe_rows_validate; malformed programs are refused with the op named
+  -m gpu    the nine built-ins expressed as specs are BIT-IDENTICAL to their fused kernels (rows, rewards, state) over
+            seeded episodes with resets; a custom scenario written only as specs matches its own torch callbacks (generic
+            path) and steps through env.step, reset, auto-reset, GraphedStep
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import multiagent_particle_envs_amd as mpe
+from multiagent_particle_envs_amd import _abi, rowspec
+from multiagent_particle_envs_amd.core import World, Agent, Landmark
+from multiagent_particle_envs_amd.scenario import BaseScenario
+
+NINE = ["simple", "simple_spread", "simple_tag", "simple_adversary", "simple_push", "simple_speaker_listener", "simple_reference",
+        "simple_crypto", "simple_world_comm"]
+
+
+def spec_scenario(name):
+    """The built-in scenario `name` with its callbacks REPLACED by specs (no kernel of its own: kind = None)."""
+    Base = mpe.scenarios.load(name + ".py").Scenario
+
+    class AsSpecs(Base):
+        kind = None
+
+        def _specs(self, world):
+            if getattr(self, "_cache", None) is None or self._cache[0] is not world:
+                self._cache = (world, rowspec.builtin_specs(name, world))
+            return self._cache[1]
+
+        def obs_spec(self, agent, world):
+            return self._specs(world)[0][world.agents.index(agent)]
+
+        def reward_spec(self, agent, world):
+            return self._specs(world)[1][world.agents.index(agent)]
+
+        def regions(self, world):
+            return self._specs(world)[2]
+    return AsSpecs()
+
+
+def make_spec_env(name, B, device=None, seed=0, **kw):
+    sc = spec_scenario(name)
+    w = sc.make_world(batch_size=B, device=device)
+    w.seed = seed
+    if w.pos.is_cuda:
+        sc.reset_world(w)          # as make_env does (the reference's make_world ends with reset_world): same episode numbering
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, **kw)
+    env.scenario = sc
+    return env
+
+
+@pytest.mark.parametrize("name", NINE)
+def test_builtin_specs_compile_to_the_kernels_row_layout(name):
+    env = make_spec_env(name, 4, device="cpu")
+    assert env.fused and env._prog is not None and env._kind == _abi.MPE_SCN_GENERIC
+    ref = mpe.scenarios.load(name + ".py").Scenario()
+    w = ref.make_world(batch_size=4, device="cpu")
+    d = w.scenario_desc(ref.kind, getattr(ref, "num_adversaries", 0))
+    A = len(w.agents)
+    assert [int(env._desc.obs_off[i]) for i in range(A + 1)] == [int(d.obs_off[i]) for i in range(A + 1)]
+    assert [s.shape[0] for s in env.observation_space] == [int(d.obs_off[i + 1] - d.obs_off[i]) for i in range(A)]
+    assert env._prog.n_ops < 400
+
+
+def test_malformed_programs_are_refused_with_the_op_named():
+    sc = mpe.scenarios.load("simple_adversary.py").Scenario()
+    w = sc.make_world(batch_size=2, device="cpu")
+    obs, rew, _ = rowspec.builtin_specs("simple_adversary", w)
+    good = rowspec.RowProgram(w, obs, rew)
+    d = w.scenario_desc(_abi.MPE_SCN_GENERIC)
+    dd = _abi.MpeScenarioDesc()
+    C.memmove(C.byref(dd), C.byref(d), C.sizeof(d))
+    off = 0
+    for i, wd in enumerate(good.widths):
+        dd.obs_off[i] = off
+        off += wd
+    dd.obs_off[len(good.widths)] = off
+    good.validate(dd)
+    dd.obs_off[1] += 1                                   # a row width that is not what the program emits
+    with pytest.raises(_abi.MpeError, match="emits"):
+        good.validate(dd)
+    dd.obs_off[1] -= 1
+    bad = rowspec.ObsSpec(w, w.agents[0])
+    bad.ops.append(rowspec._op(_abi.MPE_ROW_OBS_REL, 77))          # entity 77 of 5
+    bad.width = 2
+    with pytest.raises(_abi.MpeError, match="entity 77"):
+        p = rowspec.RowProgram(w, [bad] + obs[1:], rew)
+        dd.obs_off[1], dd.obs_off[2], dd.obs_off[3] = 2, 2 + good.widths[1], 2 + good.widths[1] + good.widths[2]
+        p.validate(dd)
+    r = rowspec.RewardSpec(w, w.agents[0])
+    r.ops.append(rowspec._op(_abi.MPE_ROW_R_LOAD, 9))              # slot 9 of 8
+    with pytest.raises(_abi.MpeError, match="slot 9"):
+        p = rowspec.RowProgram(w, obs, [r] + rew[1:])
+        for i in range(4):
+            dd.obs_off[i] = sum(good.widths[:i])
+        p.validate(dd)
+    with pytest.raises(_abi.MpeError, match="not an entity"):
+        rowspec.ObsSpec(w, w.agents[0]).rel(Landmark())
+
+
+# ---- a scenario nobody wrote a kernel for, described by specs only -------------------------------------------------------------
+class Corral(BaseScenario):
+    """Two herders and a stray; three posts, one of them (picked per world) is the gate.  Rows and rewards as specs AND as
+    torch callbacks (the generic path), so that the two can be held against each other."""
+
+    def make_world(self, batch_size=1, device=None):
+        world = World(batch_size, device)
+        world.dim_c = 0
+        world.choice_pops = [3]
+        world.agents = [Agent() for _ in range(3)]
+        for i, a in enumerate(world.agents):
+            a.name, a.silent, a.collide = "agent %d" % i, True, True
+            a.size = 0.1 if i < 2 else 0.05
+            a.accel = 3.0 if i < 2 else 4.5
+            a.max_speed = 1.0 if i < 2 else 1.4
+        world.landmarks = [Landmark() for _ in range(3)]
+        for l in world.landmarks:
+            l.collide, l.movable, l.size = False, False, 0.08
+        world.allocate()
+        return world
+
+    def reset_world(self, world, mask=None, seeds=None):
+        idx = world.reset_uniform(0.9, mask, choices=[3], seeds=seeds)
+        if world.choice_i32 is not None:
+            world.choice_i32[0].copy_(World.merge_choice(world.choice_i32[0].long(), idx[:, 0].to(world.device), mask).to(torch.int32))
+
+    def obs_spec(self, agent, world):
+        o = rowspec.ObsSpec(world, agent)
+        o.vel().pos().rel_pick(0, world.landmarks).onehot(0, 3, 0.1, 0.9)
+        for l in world.landmarks:
+            o.rel(l)
+        for a in world.agents:
+            if a is not agent:
+                o.rel(a).vel(a)
+        return o.const(0.5)
+
+    def reward_spec(self, agent, world):
+        r = rowspec.RewardSpec(world, agent)
+        stray = world.agents[2]
+        r.dist2_pick(stray, 0, world.landmarks).sqrt().add(-1.0)             # the stray's distance to the gate
+        r.min_dist2_from(agent, world.landmarks).add(-0.25)                  # squared distance to the nearest post
+        for a in world.agents:
+            if a is not agent:
+                r.add_if_touching(a, agent, -3.0)
+        r.bound(agent, 0).add(-1.0).bound(agent, 1).add(-1.0)
+        return r
+
+    # the same in torch (generic path)
+    def _gate(self, world):
+        pos = torch.stack([l.state.p_pos for l in world.landmarks])           # [3, B, 2]
+        g = world.choice_i32[0].long()
+        return pos[g, torch.arange(world.batch_size, device=pos.device)]
+
+    def observation(self, agent, world):
+        from multiagent_particle_envs_amd.scenarios._util import one_hot_rows
+        me = agent.state.p_pos
+        cols = [agent.state.p_vel, me, self._gate(world) - me, one_hot_rows(world, world.choice_i32[0], 3, 0.8) + 0.1]
+        cols += [l.state.p_pos - me for l in world.landmarks]
+        for a in world.agents:
+            if a is not agent:
+                cols += [a.state.p_pos - me, a.state.p_vel]
+        cols.append(torch.full((world.batch_size, 1), 0.5, device=world.device))
+        return torch.cat(cols, dim=1)
+
+    def reward(self, agent, world):
+        from multiagent_particle_envs_amd.scenarios._util import bound, dist2, is_collision
+        stray = world.agents[2]
+        d = stray.state.p_pos - self._gate(world)
+        rew = -torch.sqrt((d * d).sum(dim=1))
+        rew = rew - 0.25 * torch.stack([dist2(agent, l) for l in world.landmarks]).min(dim=0).values
+        for a in world.agents:
+            if a is not agent:
+                rew = rew - 3.0 * is_collision(a, agent).float()
+        return rew - bound(agent.state.p_pos[:, 0].abs()) - bound(agent.state.p_pos[:, 1].abs())
+
+
+def corral_env(B, fused=None, **kw):
+    sc = Corral()
+    w = sc.make_world(batch_size=B)
+    w.seed = 3
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, fused=fused, **kw)
+    env.scenario = sc
+    return env
+
+
+def rand_actions(env, rs, B):
+    acts = []
+    for agent in env.agents:
+        parts = []
+        if agent.movable:
+            parts.append(np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=B)])
+        if not agent.silent:
+            parts.append(np.eye(env.world.dim_c, dtype=np.float32)[rs.randint(0, env.world.dim_c, size=B)])
+        acts.append(torch.as_tensor(np.concatenate(parts, axis=1)).cuda())
+    return acts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NINE)
+@pytest.mark.parametrize("B", [1000, 8192])
+def test_builtins_as_specs_are_bit_identical_to_their_fused_kernels(name, B):
+    """Same seed, same moves / words, resets in between: rows, rewards, dones and state of the two-launch program path ==
+    the one-launch fused kernel's, to the bit (B = 1000: a ragged last workgroup and unaligned rows)."""
+    fused = mpe.make_env(name, batch_size=B, seed=5)
+    prog = make_spec_env(name, B, seed=5)
+    assert fused.fused and fused._prog is None and prog.fused and prog._prog is not None
+    rs = np.random.RandomState(B)
+    of, op = fused.reset(), prog.reset()
+    for i in range(fused.n):
+        assert torch.equal(of[i], op[i]), ("reset", i)
+    for t in range(9):
+        if t == 2:                                   # crowd the worlds: contacts, boundary penalties
+            for e in (fused, prog):
+                e.world.pos.mul_(0.35)
+        if t == 6:
+            of, op = fused.reset(), prog.reset()
+            for i in range(fused.n):
+                assert torch.equal(of[i], op[i]), ("second reset", i)
+        act = rand_actions(fused, rs, B)
+        of, rf, df, _ = fused.step(act)
+        op, rp, dp, _ = prog.step(act)
+        assert torch.equal(fused.world.pos, prog.world.pos) and torch.equal(fused.world.vel, prog.world.vel), t
+        for i in range(fused.n):
+            assert torch.equal(of[i], op[i]), (name, "obs", t, i, float((of[i] - op[i]).abs().max()))
+            assert torch.equal(rf[i], rp[i]), (name, "rew", t, i, float((rf[i] - rp[i]).abs().max()))
+            assert torch.equal(df[i], dp[i])
+
+
+@pytest.mark.gpu
+def test_moves_as_one_tensor_and_integer_ids_on_the_program_path():
+    B = 2048
+    fused, prog = mpe.make_env("simple_spread", batch_size=B, seed=1), make_spec_env("simple_spread", B, seed=1)
+    fused.reset(), prog.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    act = torch.rand((3, B, 5), device="cuda", generator=g)
+    for t in range(4):                                # the same preallocated tensor again: the step's short path
+        act.copy_(torch.rand((3, B, 5), device="cuda", generator=g))
+        of, rf = fused.step(act)[:2]
+        op, rp = prog.step(act)[:2]
+        assert all(torch.equal(a, b) for a, b in zip(of + rf, op + rp)), t
+    assert id(act) in prog._fast_acts
+    for e in (fused, prog):
+        e.discrete_action_input = True
+    ids = torch.randint(0, 5, (3, B), device="cuda", dtype=torch.int32, generator=g)
+    of, rf = fused.step(ids)[:2]
+    op, rp = prog.step(ids)[:2]
+    assert all(torch.equal(a, b) for a, b in zip(of + rf, op + rp))
+
+
+@pytest.mark.gpu
+def test_custom_scenario_specs_against_its_own_torch_callbacks():
+    """Corral has no kernel: as specs it runs World.step + mpe_rows, as torch callbacks the generic path; same worlds, same
+    moves -- rows to 1e-6 (differences and copies), rewards to 1e-5 (torch's sqrt / exp vs the kernels'), state bit-identical."""
+    B = 4096
+    ps, pt = corral_env(B), corral_env(B, fused=False)
+    assert ps._prog is not None and ps.fused and not pt.fused
+    rs = np.random.RandomState(0)
+    o1, o2 = ps.reset(), pt.reset()
+    assert torch.equal(ps.world.choice_i32, pt.world.choice_i32) and len(set(ps.world.choice_i32[0].tolist())) == 3
+    for i in range(3):
+        assert o1[i].shape == (B, 27) and torch.allclose(o1[i], o2[i], atol=1e-6, rtol=0)
+    for t in range(12):
+        if t == 3:
+            for e in (ps, pt):
+                e.world.pos.mul_(0.3)
+        if t == 8:
+            m = torch.arange(B, device="cuda") % 3 == 0
+            ps.reset(mask=m), pt.reset(mask=m)
+        act = rand_actions(ps, rs, B)
+        o1, r1, d1, _ = ps.step(act)
+        o2, r2, d2, _ = pt.step(act)
+        assert torch.equal(ps.world.pos, pt.world.pos) and torch.equal(ps.world.vel, pt.world.vel)
+        for i in range(3):
+            assert torch.allclose(o1[i], o2[i], atol=1e-6, rtol=0), (t, i)
+            err = ((r1[i] - r2[i]).abs() / r2[i].abs().clamp(min=1.0)).max()
+            assert float(err) <= 1e-5, (t, i, float(err))
+            assert not d1[i].any()
+    assert float(torch.stack(r1).min()) < -3.0           # contacts happened
+
+
+@pytest.mark.gpu
+def test_program_env_auto_reset_and_graphed_step():
+    B = 512
+    env = corral_env(B, max_episode_steps=4, auto_reset=True)
+    ref = corral_env(B, fused=False, max_episode_steps=4, auto_reset=True)
+    rs = np.random.RandomState(2)
+    env.reset(), ref.reset()
+    for t in range(1, 10):
+        act = rand_actions(env, rs, B)
+        o1, r1, d1, _ = env.step(act)
+        o2, r2, d2, _ = ref.step(act)
+        assert bool(d1[0].all()) == (t % 4 == 0) and torch.equal(d1[0], d2[0])
+        for i in range(3):
+            assert torch.allclose(o1[i], o2[i], atol=1e-6, rtol=0), (t, i)      # the finished worlds' rows are the new episode's first
+    e2, e3 = corral_env(B), corral_env(B)
+    e2.reset(), e3.reset()
+    gs = mpe.GraphedStep(e2, rand_actions(e2, rs, B))
+    for t in range(5):
+        act = rand_actions(e2, rs, B)
+        og, rg, _, _ = gs.step(act)
+        oe, re_, _, _ = e3.step(act)
+        assert all(torch.equal(a, b) for a, b in zip(og + rg, oe + re_)), t

@@ -146,6 +146,8 @@ def run(key, n, product_slope):
         spans, gaps, periods, skews = [], [], [], []
         for rep in range(3):
             span.zero_()
+            g.replay()          # two replays in front, back to back: the measured one runs at the clocks of a busy GPU, as the
+            g.replay()          # bench's best-of-3 bodies do (each replay overwrites the stamps: the last one's are read)
             g.replay()
             torch.cuda.synchronize()
             st = span[:, :, :A + 1, 0]
