@@ -612,6 +612,41 @@ def per_gpu_stats(recs):
     return {"min": v[0], "median": v[len(v) // 2], "max": v[-1], "unit": "env-steps/s per GPU", "ranks": len(v)}
 
 
+def user_scenario_leg(torch, mpe, B, EP):
+    """A scenario WITHOUT a kernel of its own (examples/corral.py: 3 agents, 3 posts, a per-world gate), stepped from Python
+    through the drop-in API: described by ObsSpec / RewardSpec (World.step + the interpreted rows in one launch,
+    mpe_step_rows) and, beside it, through its torch callbacks (the generic path: ~100 launches per step)."""
+    path = os.path.join(ROOT, "examples", "corral.py")
+    out = {"what": "examples/corral.py (a user scenario, no kernel of its own) from Python, env.step / env.reset every %d steps, %d worlds: "
+                   "`program` = obs_spec / reward_spec interpreted by mpe_step_rows (one launch per step); `generic` = the same "
+                   "scenario's torch observation / reward callbacks over mpe_world_step" % (EP or 25, B)}
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for key, kw, n in (("program", {}, 2000), ("generic", {"fused": False}, 60)):
+        env = mpe.make_env(path, batch_size=B, **kw)
+        acts = [torch.nn.functional.one_hot(torch.randint(0, 5, (env.n, B), generator=g), 5).float().cuda() for _ in range(4)]
+        if not env.fused:
+            acts = [[a[i] for i in range(env.n)] for a in acts]
+        env.reset()
+        for k in range(20):
+            env.step(acts[k % 4])
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for k in range(n):
+                if k % (EP or 25) == 0:
+                    env.reset()
+                env.step(acts[k % 4])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out[key] = {"value": B * n / best, "unit": "env-steps/s", "us_per_step": best / n * 1e6, "steps": n,
+                    "path": "mpe_step_rows" if env.fused else "torch callbacks + mpe_world_step"}
+        del env
+    out["program_over_generic"] = out["program"]["value"] / out["generic"]["value"]
+    return out
+
+
 def box_fingerprint(torch, dev, smi=True):
     """What this rank's GPU is and how the box is set up: device properties from the runtime, clocks / power cap /
     partition modes / driver from rocm-smi when it answers (C4's 20 % box-to-box spread, DESIGN 2.7, needs a label)."""
@@ -877,8 +912,10 @@ def main():
             "value": B * nh / dth, "unit": "env-steps/s", "ms_per_step": dth * 1e3 / nh,
             "pcie_bytes_per_env_step": io_bytes, "pcie_GBps": B * nh * io_bytes / dth / 1e9}
 
-    headline_roof = roofline_entry(leg, k_us, B, args.mode, floor_us, head_timing)
     default_line = solo and args.scenario == "simple_spread" and args.agents == 3 and B == 65536
+    if default_line:
+        extra["user_scenario"] = user_scenario_leg(torch, mpe, B, EP)
+    headline_roof = roofline_entry(leg, k_us, B, args.mode, floor_us, head_timing)
     if default_line:
         leg.release()
         torch.cuda.empty_cache()

@@ -234,11 +234,12 @@ int mpe_rollout_random(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int6
  * sum of a few term kinds (simple_spread.py:72-100, simple_tag.py:84-147, simple_adversary.py:76-139, simple_push.py:60-96,
  * simple_speaker_listener.py:63-92, simple_reference.py:57-83, simple_crypto.py:97-169, simple_world_comm.py:143-289).
  * mpe_rows interprets such a list -- 16 bytes per op -- on the post-step state: a scenario nobody wrote a kernel for steps
- * in two launches, mpe_world_step + mpe_rows.  Entities are indexed agents [0, A) then landmarks; A + L <= 16.
+ * in two launches, mpe_world_step + mpe_rows.  Entities are indexed agents [0, A) then landmarks; A + L <= 64 (and at
+ * most 32 agents when regions hide agents from each other).
  *
  * An op is four int32 words: w0 = code | a0 << 8 | a1 << 16 | a2 << 24, w1 = an integer argument, w2 / w3 = float bits.
  * Observation ops append columns to the agent's row, in program order (a0 = MPE_ROW_SELF: the observing agent):          */
-#define MPE_ROWS_MAX_ENTITIES 16
+#define MPE_ROWS_MAX_ENTITIES 64
 #define MPE_ROW_SELF 255
 enum MpeRowOp {
   MPE_ROW_OBS_VEL = 1,       /* p_vel of entity a0 (2)                                                  */
@@ -268,7 +269,7 @@ enum MpeRowOp {
   MPE_ROW_R_ADD = 44,        /* acc = acc + w2 * v                                                      */
   MPE_ROW_R_ADD_IF_HIT = 45, /* if |p[a0] - p[a1]| < size[a0] + size[a1] (strict, exact): acc = acc + w2 */
   MPE_ROW_R_ADD_ACC = 46,    /* acc0 = acc0 + acc1                                                      */
-  MPE_ROW_R_STORE = 47       /* reward of agent a0 = acc0                                               */
+  MPE_ROW_R_STORE = 47       /* reward of agent a0 = acc0 (a0 = the agent whose program this is)        */
 };
 /* Host POD describing one env's programs; the ops live in DEVICE memory the caller owns (uploaded once).               */
 typedef struct MpeRowProgram {
@@ -276,7 +277,7 @@ typedef struct MpeRowProgram {
   int32_t n_ops;
   int32_t obs_begin[MPE_ROWS_MAX_ENTITIES + 1]; /* agent i's observation ops: [obs_begin[i], obs_begin[i+1]); its row width is
                                                    desc->obs_off[i+1] - desc->obs_off[i] (filled by the caller)            */
-  int32_t rew_begin, rew_end; /* the reward program (one, for all agents: STORE hands each agent's reward over) */
+  int32_t rew_begin[MPE_ROWS_MAX_ENTITIES + 1]; /* agent i's reward ops: [rew_begin[i], rew_begin[i+1]), ending in its STORE */
   int32_t n_vel;              /* rows of MpeBuffers.vel: entities [0, n_vel) have a velocity, the rest read 0      */
   int32_t n_regions;          /* 0..2 landmarks that hide what is inside them                            */
   int32_t region_entity[2];
@@ -289,6 +290,20 @@ int mpe_rows_validate(const MpeScenarioDesc *desc, const MpeRowProgram *prog, co
  * :113-115 after a reset): obs rows, rew (shared sum when desc->collaborative), done = 0.  desc->kind is ignored (GENERIC
  * is what a user scenario has); reads pos, vel, comm, choice; bufs->rew / done may be NULL.                            */
 int mpe_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, const MpeRowProgram *prog, int64_t B, void *stream);
+/* mpe_step_rows: one MultiAgentEnv.step of a user scenario in ONE launch -- _set_action + World.step (environment.py:144-181,
+ * core.py:117-177; exactly one of bufs->act / ids / u, no movable landmarks: those go through mpe_world_step) by the
+ * agents' waves, then the row programs on the post-step state as in mpe_rows.  State bit-identical to mpe_world_step's.  */
+int mpe_step_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, const MpeRowProgram *prog, int64_t B, void *stream);
+/* mpe_episode_finish: what follows a step when episodes end on the device -- NEW API like mpe_episode_tick (the reference's
+ * done is always False, environment.py:132-135) -- in ONE launch: count the step (episode_step[w] += 1; worlds at
+ * max_episode_steps > 0 get done = 1 in every agent's row), find the finished worlds (any done row set, by the horizon or by
+ * the caller's done callback), and for those: counter = 0, Scenario.reset_world (the draws of
+ * mpe_reset(mask, landmark_range, seed, episode, world_offset): positions, zero velocities, per-world picks, utterances
+ * zeroed) and the observation rows of the new episode's first state.  A workgroup (64 worlds) without a finished world
+ * returns after reading its counters and flags: when nothing finished the call costs a launch and little else.         */
+int mpe_episode_finish(const MpeScenarioDesc *desc, const MpeBuffers *bufs, const MpeRowProgram *prog, int64_t B,
+                       int32_t *episode_step, int32_t max_episode_steps, float landmark_range, uint64_t seed,
+                       uint64_t episode, int64_t world_offset, void *stream);
 
 #ifdef __cplusplus
 }

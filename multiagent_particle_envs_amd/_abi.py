@@ -14,7 +14,7 @@ MPE_SCN_SPEAKER_LISTENER, MPE_SCN_REFERENCE, MPE_SCN_CRYPTO, MPE_SCN_WORLD_COMM 
 COMM_KINDS = (MPE_SCN_SPEAKER_LISTENER, MPE_SCN_REFERENCE, MPE_SCN_CRYPTO, MPE_SCN_WORLD_COMM)   # agents speak: MpeBuffers.comm
 MPE_MAX_CHOICES = 4
 # the composable output stage (include/mpe_hip.h, enum MpeRowOp)
-MPE_ROWS_MAX_ENTITIES = 16
+MPE_ROWS_MAX_ENTITIES = 64
 MPE_ROW_SELF = 255
 (MPE_ROW_OBS_VEL, MPE_ROW_OBS_POS, MPE_ROW_OBS_REL, MPE_ROW_OBS_REL_PICK, MPE_ROW_OBS_COMM, MPE_ROW_OBS_CONST, MPE_ROW_OBS_ONEHOT,
  MPE_ROW_OBS_REL_VIS, MPE_ROW_OBS_VEL_VIS, MPE_ROW_OBS_IN_REGION) = range(1, 11)
@@ -53,7 +53,7 @@ class MpeBuffers(C.Structure):
 class MpeRowProgram(C.Structure):
     _fields_ = [
         ("ops_device", C.c_void_p), ("n_ops", C.c_int32), ("obs_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)),
-        ("rew_begin", C.c_int32), ("rew_end", C.c_int32), ("n_vel", C.c_int32), ("n_regions", C.c_int32),
+        ("rew_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)), ("n_vel", C.c_int32), ("n_regions", C.c_int32),
         ("region_entity", C.c_int32 * 2), ("all_seeing", C.c_uint32),
     ]
 
@@ -84,6 +84,9 @@ EXPORTS = {
                                   C.c_int32, C.c_int64, C.c_void_p]),
     "mpe_rows_validate": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeRowProgram), C.POINTER(C.c_int32)]),
     "mpe_rows": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.POINTER(MpeRowProgram), C.c_int64, C.c_void_p]),
+    "mpe_step_rows": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.POINTER(MpeRowProgram), C.c_int64, C.c_void_p]),
+    "mpe_episode_finish": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.POINTER(MpeRowProgram), C.c_int64, C.c_void_p,
+                                     C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]),
     "mpe_sizeof_row_program": (C.c_size_t, []),
     "mpe_episode_tick": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "mpe_rollout_random": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_int32,

@@ -36,7 +36,11 @@ STRESS_VARIANTS = {"stress": ["-DMPE_STRESS_DELAY_WAVE=1"],
                    # measurement build (tools/device_span.py): every wave of k_split stamps the device wall clock at its
                    # start and end -> per-launch spans and periods from the device's own clock
                    "span": ["-DMPE_DEVICE_SPAN"]}
-VARIANT_SOURCES = {"span": ("split",)}     # which kernel files a variant recompiles (default: STRESS_SOURCES)
+VARIANT_SOURCES = {"span": ("split",), "teamgrid": ("split", "narrow")}     # which kernel files a variant recompiles (default: STRESS_SOURCES)
+# A/B builds made on request only (`python -m multiagent_particle_envs_amd._build --ab teamgrid`), never by build():
+#   teamgrid   round 3's 19 extra k_split entries (simple_adversary / simple_world_comm team sizes) put back, to hold the
+#              row-program path that replaced them against (profiles/r4_team_sizes_ab.txt)
+AB_VARIANTS = {"teamgrid": ["-DMPE_SPLIT_TEAM_GRID"]}
 
 
 def variant_lib(tag):
@@ -68,7 +72,7 @@ def _drop_temps(d, keep_asm=True):
                 pass
 
 
-def build(force=False, verbose=True, variants=True):
+def build(force=False, verbose=True, variants=True, ab=()):
     """Compile and link libmpe_hip.so; with `variants` also the two test-only stress builds (tests/test_gpu_race.py).
     The product library is linked FIRST and is what decides staleness on its own: a box that holds only libmpe_hip.so
     newer than the sources (the GPU box) never invokes hipcc for it, and a compile failure in a variant cannot keep the
@@ -77,7 +81,7 @@ def build(force=False, verbose=True, variants=True):
     os.makedirs(LIBDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    want = [LIB] + ([variant_lib(t) for t in STRESS_VARIANTS] if variants else [])
+    want = [LIB] + ([variant_lib(t) for t in list(STRESS_VARIANTS) + list(ab)] if variants else [])
     if not force and not any(_stale(l, srcs + hdrs) for l in want):
         return LIB  # the shipped .so files are newer than every source: nothing to do (GPU box)
     hipcc = _hipcc()
@@ -111,7 +115,9 @@ def build(force=False, verbose=True, variants=True):
     # "_racy" additionally restores the store-before-barrier ordering the round-1 k_split had, as the negative control
     # that shows the test can fail
     jobs, todo = [], []
-    for tag, defs in STRESS_VARIANTS.items():
+    wanted = dict(STRESS_VARIANTS)
+    wanted.update({t: AB_VARIANTS[t] for t in ab})
+    for tag, defs in wanted.items():
         vo = {}
         for stem in VARIANT_SOURCES.get(tag, STRESS_SOURCES):      # the kernel files that carry the variant's hooks
             src = os.path.join(CSRC, "mpe_%s.hip" % stem)
@@ -123,7 +129,7 @@ def build(force=False, verbose=True, variants=True):
         todo.append((tag, vo))
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    for tag in STRESS_VARIANTS:
+    for tag in wanted:
         _drop_temps(os.path.join(OBJ, tag), keep_asm=False)
     for tag, vo in todo:
         vlib = variant_lib(tag)
@@ -134,4 +140,5 @@ def build(force=False, verbose=True, variants=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, variants="--no-variants" not in sys.argv))
+    ab = [sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--ab"]
+    print(build(force="--force" in sys.argv, variants="--no-variants" not in sys.argv, ab=ab))

@@ -445,7 +445,11 @@ static int rows_header(const char *what, const MpeScenarioDesc *d, const MpeRowP
     if (p->obs_begin[i] < prev || p->obs_begin[i] > p->n_ops) return fail(MPE_EINVAL, "%s: obs_begin[%d] = %d out of order / range", what, i, p->obs_begin[i]);
     prev = p->obs_begin[i];
   }
-  if (p->rew_begin < 0 || p->rew_end < p->rew_begin || p->rew_end > p->n_ops) return fail(MPE_EINVAL, "%s: bad reward program range", what);
+  prev = 0;
+  for (int i = 0; i <= A; ++i) {
+    if (p->rew_begin[i] < prev || p->rew_begin[i] > p->n_ops) return fail(MPE_EINVAL, "%s: rew_begin[%d] = %d out of order / range", what, i, p->rew_begin[i]);
+    prev = p->rew_begin[i];
+  }
   h->n_agents = A;
   h->n_entities = E;
   h->n_vel = p->n_vel;
@@ -458,8 +462,12 @@ static int rows_header(const char *what, const MpeScenarioDesc *d, const MpeRowP
     if (D > h->d_max) h->d_max = D;
   }
   for (int i = 0; i <= MPE_ROWS_MAX_ENTITIES; ++i) h->obs_begin[i] = i <= A ? p->obs_begin[i] : p->obs_begin[A];
-  h->rew_begin = p->rew_begin;
-  h->rew_end = p->rew_end;
+  for (int i = 0; i <= MPE_ROWS_MAX_ENTITIES; ++i) h->obs_off[i] = i <= A ? d->obs_off[i] : d->obs_off[A];
+  for (int e = 0; e < MPE_ROWS_MAX_ENTITIES; ++e) h->size[e] = e < E ? d->size[e] : 0.f;
+  h->vec4 = 0;
+  h->n_picks = d->n_choices;
+  if (p->n_regions > 0 && A > 32) return fail(MPE_EUNSUPPORTED, "%s: regions hide agents from each other for A <= 32 (got %d)", what, A);
+  for (int i = 0; i <= MPE_ROWS_MAX_ENTITIES; ++i) h->rew_begin[i] = i <= A ? p->rew_begin[i] : p->rew_begin[A];
   h->n_regions = p->n_regions;
   h->region_entity[0] = p->n_regions > 0 ? p->region_entity[0] : 0;
   h->region_entity[1] = p->n_regions > 1 ? p->region_entity[1] : 0;
@@ -511,54 +519,115 @@ int mpe_rows_validate(const MpeScenarioDesc *d, const MpeRowProgram *p, const in
     if (width != d->obs_off[i + 1] - d->obs_off[i])
       return fail(MPE_EINVAL, "%s: agent %d's program emits %d columns, desc->obs_off says %d", what, i, width, d->obs_off[i + 1] - d->obs_off[i]);
   }
-  int stored = 0;
-  for (int pc = p->rew_begin; pc < p->rew_end; ++pc) {
-    const int32_t w0 = ops[4 * pc], w1 = ops[4 * pc + 1];
-    const int code = w0 & 0xff, a0 = (w0 >> 8) & 0xff, a1 = (w0 >> 16) & 0xff;
-    switch (code) {
-      case MPE_ROW_R_D2: case MPE_ROW_R_MIN_D2: case MPE_ROW_R_ADD_IF_HIT:
-        if (!ent(a0, false) || !ent(a1, false)) return fail(MPE_EINVAL, "%s: reward op %d: entities %d, %d out of range", what, pc, a0, a1);
-        break;
-      case MPE_ROW_R_D2_PICK: case MPE_ROW_R_MIN_D2_PICK:
-        if (!ent(a0, false) || a1 >= d->n_choices || w1 < 0 || w1 + d->choice_pop[a1 < MPE_MAX_CHOICES ? a1 : 0] > E)
-          return fail(MPE_EINVAL, "%s: reward op %d: pick %d with base %d leaves the entity list", what, pc, a1, w1);
-        break;
-      case MPE_ROW_R_BOUND:
-        if (!ent(a0, false) || a1 > 1) return fail(MPE_EINVAL, "%s: reward op %d: coordinate %d of entity %d", what, pc, a1, a0);
-        break;
-      case MPE_ROW_R_COMM_ERR:
-        if (a0 >= A || a1 >= d->n_choices) return fail(MPE_EINVAL, "%s: reward op %d: utterance of agent %d against pick %d", what, pc, a0, a1);
-        break;
-      case MPE_ROW_R_COMM_SUM:
-        if (a0 >= A) return fail(MPE_EINVAL, "%s: reward op %d: utterance of agent %d", what, pc, a0);
-        break;
-      case MPE_ROW_R_SAVE: case MPE_ROW_R_LOAD:
-        if (a0 >= mpe::kRowSlots) return fail(MPE_EINVAL, "%s: reward op %d: slot %d of %d", what, pc, a0, mpe::kRowSlots);
-        break;
-      case MPE_ROW_R_STORE:
-        if (a0 >= A || ((stored >> a0) & 1)) return fail(MPE_EINVAL, "%s: reward op %d: STORE of agent %d (out of range or twice)", what, pc, a0);
-        stored |= 1 << a0;
-        break;
-      case MPE_ROW_R_SQRT: case MPE_ROW_R_CONST: case MPE_ROW_R_ZERO: case MPE_ROW_R_ADD: case MPE_ROW_R_ADD_ACC: break;
-      default: return fail(MPE_EINVAL, "%s: op %d: code %d is not a reward op", what, pc, code);
+  for (int i = 0; i < A; ++i) {
+    bool stored = false;
+    for (int pc = p->rew_begin[i]; pc < p->rew_begin[i + 1]; ++pc) {
+      const int32_t w0 = ops[4 * pc], w1 = ops[4 * pc + 1];
+      const int code = w0 & 0xff, a0 = (w0 >> 8) & 0xff, a1 = (w0 >> 16) & 0xff;
+      switch (code) {
+        case MPE_ROW_R_D2: case MPE_ROW_R_MIN_D2: case MPE_ROW_R_ADD_IF_HIT:
+          if (!ent(a0, false) || !ent(a1, false)) return fail(MPE_EINVAL, "%s: reward op %d: entities %d, %d out of range", what, pc, a0, a1);
+          break;
+        case MPE_ROW_R_D2_PICK: case MPE_ROW_R_MIN_D2_PICK:
+          if (!ent(a0, false) || a1 >= d->n_choices || w1 < 0 || w1 + d->choice_pop[a1 < MPE_MAX_CHOICES ? a1 : 0] > E)
+            return fail(MPE_EINVAL, "%s: reward op %d: pick %d with base %d leaves the entity list", what, pc, a1, w1);
+          break;
+        case MPE_ROW_R_BOUND:
+          if (!ent(a0, false) || a1 > 1) return fail(MPE_EINVAL, "%s: reward op %d: coordinate %d of entity %d", what, pc, a1, a0);
+          break;
+        case MPE_ROW_R_COMM_ERR:
+          if (a0 >= A || a1 >= d->n_choices) return fail(MPE_EINVAL, "%s: reward op %d: utterance of agent %d against pick %d", what, pc, a0, a1);
+          break;
+        case MPE_ROW_R_COMM_SUM:
+          if (a0 >= A) return fail(MPE_EINVAL, "%s: reward op %d: utterance of agent %d", what, pc, a0);
+          break;
+        case MPE_ROW_R_SAVE: case MPE_ROW_R_LOAD:
+          if (a0 >= mpe::kRowSlots) return fail(MPE_EINVAL, "%s: reward op %d: slot %d of %d", what, pc, a0, mpe::kRowSlots);
+          break;
+        case MPE_ROW_R_STORE:
+          if (a0 != i || stored) return fail(MPE_EINVAL, "%s: reward op %d: agent %d's program stores agent %d (or twice)", what, pc, i, a0);
+          stored = true;
+          break;
+        case MPE_ROW_R_SQRT: case MPE_ROW_R_CONST: case MPE_ROW_R_ZERO: case MPE_ROW_R_ADD: case MPE_ROW_R_ADD_ACC: break;
+        default: return fail(MPE_EINVAL, "%s: op %d: code %d is not a reward op", what, pc, code);
+      }
     }
+    if (p->rew_begin[i + 1] > p->rew_begin[i] && !stored)
+      return fail(MPE_EINVAL, "%s: agent %d's reward program has no STORE", what, i);
   }
-  if (p->rew_end > p->rew_begin && stored != (1 << A) - 1)
-    return fail(MPE_EINVAL, "%s: the reward program stores agents %#x, not all %d", what, stored, A);
   return 0;
 }
 
-int mpe_rows(const MpeScenarioDesc *d, const MpeBuffers *b, const MpeRowProgram *p, int64_t B, void *stream) {
-  const char *what = "mpe_rows";
+static int rows_call(const char *what, bool phys, const MpeScenarioDesc *d, const MpeBuffers *b, const MpeRowProgram *p, int64_t B,
+                     const mpe::RowEpisode *episode, void *stream) {
   mpe::RowHeader h;
   if (int rc = rows_header(what, d, p, &h)) return rc;
   if (int rc = check_state(b, B, what)) return rc;
   if (int rc = need(b->obs, what, "obs")) return rc;
   if (d->n_choices > 0) if (int rc = need(b->choice, what, "choice (the per-world picks of reset_world)")) return rc;
-  if (d->dim_c > 0) if (int rc = need(b->comm, what, "comm (the agents' utterances)")) return rc;
+  // (bufs->comm may be NULL: every utterance then reads as zero -- the state of agents that never speak)
+  mpe::RowPhys ph;
+  std::memset(&ph, 0, sizeof(ph));
+  if (phys) {
+    if (int rc = check_actions(b, what)) return rc;
+    const int A = d->n_agents, E = A + d->n_landmarks;
+    for (int e = A; e < E; ++e)
+      if (d->movable[e]) return fail(MPE_EUNSUPPORTED, "%s: a movable landmark (entity %d) is stepped by mpe_world_step only", what, e);
+    ph.enabled = 1;
+    for (int e = 0; e < E; ++e) {
+      ph.inv_mass[e] = d->mass[e] > 0.f ? 1.0f / d->mass[e] : 1.0f;
+      ph.accel[e] = d->accel[e];
+      ph.max_speed[e] = d->max_speed[e];
+      if (d->movable[e]) ph.movable |= 1ull << e;
+      if (d->collide[e]) ph.collide |= 1ull << e;
+    }
+    ph.dt = d->dt;
+    ph.damp = 1.0f - d->damping;
+    ph.cforce = d->contact_force;
+    ph.cmargin = d->contact_margin;
+    ph.cmargin_inv = 1.0f / d->contact_margin;
+  }
+  mpe::RowEpisode ep;
+  std::memset(&ep, 0, sizeof(ep));
+  if (episode) ep = *episode;
   if (B == 0) return 0;
-  const mpe::NarrowDesc n = make_narrow(d, b, (size_t)B);
-  return hip_result(mpe::launch_rows(n, *b, h, p->ops_device, (size_t)B, static_cast<hipStream_t>(stream)), what);
+  bool vec4 = reinterpret_cast<uintptr_t>(b->obs) % 16 == 0;
+  for (int i = 0; i <= d->n_agents; ++i)
+    if (((size_t)d->obs_off[i] * (size_t)B) % 4 != 0) vec4 = false;
+  h.vec4 = vec4 ? 1 : 0;
+  return hip_result(mpe::launch_rows(*b, h, ph, ep, p->ops_device, (size_t)B, static_cast<hipStream_t>(stream)), what);
+}
+
+int mpe_rows(const MpeScenarioDesc *d, const MpeBuffers *b, const MpeRowProgram *p, int64_t B, void *stream) {
+  return rows_call("mpe_rows", false, d, b, p, B, nullptr, stream);
+}
+
+int mpe_step_rows(const MpeScenarioDesc *d, const MpeBuffers *b, const MpeRowProgram *p, int64_t B, void *stream) {
+  return rows_call("mpe_step_rows", true, d, b, p, B, nullptr, stream);
+}
+
+int mpe_episode_finish(const MpeScenarioDesc *d, const MpeBuffers *b, const MpeRowProgram *p, int64_t B, int32_t *episode_step,
+                       int32_t max_episode_steps, float landmark_range, uint64_t seed, uint64_t episode, int64_t world_offset,
+                       void *stream) {
+  const char *what = "mpe_episode_finish";
+  if (!episode_step) return fail(MPE_EINVAL, "%s: episode_step is NULL", what);
+  if (!b || !b->done) return fail(MPE_EINVAL, "%s: bufs->done (the rows the step / the done callback wrote) is NULL", what);
+  if (max_episode_steps < 0) return fail(MPE_EINVAL, "%s: max_episode_steps < 0", what);
+  if (!d) return fail(MPE_EINVAL, "%s: desc is NULL", what);
+  mpe::RowEpisode ep;
+  std::memset(&ep, 0, sizeof(ep));
+  ep.enabled = 1;
+  ep.max_steps = max_episode_steps;
+  ep.episode_step = episode_step;
+  ep.landmark_range = landmark_range;
+  ep.n_choices = d->n_choices;
+  for (int k = 0; k < MPE_MAX_CHOICES; ++k) ep.choice_pop[k] = k < d->n_choices ? d->choice_pop[k] : 1;
+  ep.seed = seed;
+  ep.episode = episode;
+  ep.world_offset = (uint64_t)world_offset;
+  MpeBuffers bb = *b;
+  bb.rew = nullptr;          // rewards belong to the step that just ran; only rows (and the finished worlds' state) change here
+  return rows_call(what, false, d, &bb, p, B, &ep, stream);
 }
 
 }  // extern "C"

@@ -59,7 +59,8 @@ int launch_split(bool roll, int kind, int A, int L, int nadv, const NarrowDesc &
 
 // the composable output stage (mpe_rows.hip): kernel-side header of an MpeRowProgram
 constexpr int kRowSlots = 8;
-constexpr int kRowMaxObsWaves = 15;   // + the reward wave = 1024 threads
+constexpr int kRowPicks = MPE_MAX_CHOICES;
+constexpr int kRowMaxObsWaves = 16;   // 1024 threads
 constexpr int kRowSelf = MPE_ROW_SELF;
 enum {
   ROW_OBS_VEL = MPE_ROW_OBS_VEL, ROW_OBS_POS = MPE_ROW_OBS_POS, ROW_OBS_REL = MPE_ROW_OBS_REL, ROW_OBS_REL_PICK = MPE_ROW_OBS_REL_PICK,
@@ -73,12 +74,32 @@ enum {
 struct RowHeader {
   int32_t n_agents, n_entities, n_vel, dim_c, collaborative;
   int32_t d_max;                 // widest observation row (floats): the waves' tile size
+  int32_t vec4;                  // rows may leave as 16-byte stores (alignment checked on the host)
+  int32_t n_picks;               // rows of MpeBuffers.choice (desc->n_choices)
   int32_t obs_begin[MPE_ROWS_MAX_ENTITIES + 1];
-  int32_t rew_begin, rew_end;
+  int32_t obs_off[MPE_ROWS_MAX_ENTITIES + 1];
+  float size[MPE_ROWS_MAX_ENTITIES];
+  int32_t rew_begin[MPE_ROWS_MAX_ENTITIES + 1];   // agent i's reward ops: [rew_begin[i], rew_begin[i + 1])
   int32_t n_regions, region_entity[2];
   uint32_t all_seeing;
 };
-int launch_rows(const NarrowDesc &d, const MpeBuffers &b, const RowHeader &h, const int32_t *ops_device, size_t B,
+// World.step inside the same launch (mpe_step_rows): per-entity physics constants and the world's
+struct RowPhys {
+  int32_t enabled;
+  float inv_mass[MPE_ROWS_MAX_ENTITIES], accel[MPE_ROWS_MAX_ENTITIES], max_speed[MPE_ROWS_MAX_ENTITIES];
+  uint64_t movable, collide;     // bit e
+  float dt, damp, cforce, cmargin, cmargin_inv;
+};
+// episode bookkeeping + masked reset in front of the rows (mpe_episode_finish)
+struct RowEpisode {
+  int32_t enabled;
+  int32_t max_steps;
+  int32_t *episode_step;
+  float landmark_range;
+  int32_t n_choices, choice_pop[MPE_MAX_CHOICES];
+  uint64_t seed, episode, world_offset;
+};
+int launch_rows(const MpeBuffers &b, const RowHeader &h, const RowPhys &ph, const RowEpisode &ep, const int32_t *ops_device, size_t B,
                 hipStream_t stream);
 
 }  // namespace mpe

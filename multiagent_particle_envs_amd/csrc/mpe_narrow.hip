@@ -489,11 +489,14 @@ static const NarrowEntry kNarrowTable[] = {
     MPE_SCN_ENTRY(MPE_SCN_TAG, 4, 2, 3), MPE_SCN_ENTRY(MPE_SCN_TAG, 2, 1, 1),
     MPE_SCN_ENTRY(MPE_SCN_TAG, 6, 3, 4),
     MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 3, 2, 1), MPE_SCN_ENTRY(MPE_SCN_PUSH, 2, 2, 1),
-    // simple_adversary at the other team sizes mpe_split.hip has (the second implementation the bit-identity test holds them to)
+    // (simple_adversary at the other team sizes of round 3's grid: with the k_split entries, in the -DMPE_SPLIT_TEAM_GRID A/B build
+    //  only -- those shapes step through their row programs, mpe_split.hip's table says why)
+#ifdef MPE_SPLIT_TEAM_GRID
     MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 2, 1, 1), MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 3, 2, 2),
     MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 4, 3, 1), MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 4, 3, 2),
     MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 5, 4, 1), MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 5, 4, 2),
     MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 6, 5, 1), MPE_SCN_ENTRY(MPE_SCN_ADVERSARY, 6, 5, 2),
+#endif
     MPE_GEN_ENTRY(1, 0), MPE_GEN_ENTRY(1, 1), MPE_GEN_ENTRY(1, 2), MPE_GEN_ENTRY(1, 3),
     MPE_GEN_ENTRY(2, 0), MPE_GEN_ENTRY(2, 1), MPE_GEN_ENTRY(2, 2), MPE_GEN_ENTRY(2, 3), MPE_GEN_ENTRY(2, 4),
     MPE_GEN_ENTRY(3, 0), MPE_GEN_ENTRY(3, 1), MPE_GEN_ENTRY(3, 2), MPE_GEN_ENTRY(3, 3), MPE_GEN_ENTRY(3, 4),

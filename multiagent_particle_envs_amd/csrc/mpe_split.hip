@@ -1149,21 +1149,23 @@ static const SplitEntry kSplitTable[] = {
     MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 3, 2, 1), MPE_SPLIT_ENTRY(MPE_SCN_PUSH, 2, 2, 1),
     MPE_SPLIT_ENTRY(MPE_SCN_SPEAKER_LISTENER, 2, 3, 0), MPE_SPLIT_ENTRY(MPE_SCN_REFERENCE, 2, 3, 0),
     MPE_SPLIT_ENTRY(MPE_SCN_CRYPTO, 3, 2, 1), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 6, 5, 4),
-    // Team sizes other than the reference's make_world, where its callbacks are written for any (simple_adversary.py:69-139
-    // over good_agents / adversaries lists with num_landmarks = num_agents - 1; simple_world_comm.py:126-289 likewise, with
-    // its one obstacle, two food items and two forests): A, L, n_adversaries
-    // simple_adversary: 2..6 agents with 1 or 2 adversaries (L = A - 1)
+    // (Round 3 listed 19 more entries here -- simple_adversary at 2-6 agents x 1-2 adversaries, simple_world_comm at 1-3 prey x
+    //  2-5 predators: 360 instantiations, a 2.5 min build.  Their callbacks are written for any team size, and so are their
+    //  row programs: shapes without an entry step as World.step + mpe_rows (rowspec.builtin_program), every team size up to
+    //  64 entities, no instantiation per shape.  A/B of the two on the removed shapes: profiles/r4_team_sizes_ab.txt,
+    //  measured with the -DMPE_SPLIT_TEAM_GRID build, which puts the entries back.)
+#ifdef MPE_SPLIT_TEAM_GRID
     MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 2, 1, 1), MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 3, 2, 2),
     MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 4, 3, 1), MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 4, 3, 2),
     MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 5, 4, 1), MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 5, 4, 2),
     MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 6, 5, 1), MPE_SPLIT_ENTRY(MPE_SCN_ADVERSARY, 6, 5, 2),
-    // simple_world_comm: 1..3 good agents with 2..5 adversaries (A = good + adversaries, n_adversaries)
     MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 3, 5, 2), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 4, 5, 3),
     MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 5, 5, 4), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 6, 5, 5),
     MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 4, 5, 2), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 5, 5, 3),
     MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 7, 5, 5),
     MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 5, 5, 2), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 6, 5, 3),
     MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 7, 5, 4), MPE_SPLIT_ENTRY(MPE_SCN_WORLD_COMM, 8, 5, 5),
+#endif
 };
 
 static const SplitEntry *find_split(int kind, int A, int L, int nadv) {

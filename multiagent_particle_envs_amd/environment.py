@@ -168,14 +168,22 @@ class MultiAgentEnv(object):
         # (mpe_world_step + mpe_rows) instead of the generic path's ~100; the specs win over Python observation / reward
         # callbacks of the same scenario (pass fused=False to keep the Python ones).
         self._prog = None
+        self.two_launch_program = False
+        self.finish_launch = True       # done_callback + auto_reset: restart finished worlds in one launch (mpe_episode_finish)
         if sc is None:
             sc = next((getattr(cb, "__self__", None) for cb in (reward_callback, reset_callback) if cb is not None), None)
-        if not own and fused is not False and sc is not None and hasattr(sc, "obs_spec") and hasattr(sc, "reward_spec") and \
+        if not own and fused is not False and sc is not None and \
                 len(world.scripted_agents) == 0 and not any(l.movable for l in world.landmarks) and \
                 len(world.entities) <= _abi.MPE_ROWS_MAX_ENTITIES and \
                 not any(a.u_noise or (a.c_noise and not a.silent) for a in world.agents) and world.pos is not None:
             from . import rowspec
-            self._prog = rowspec.compile_scenario(sc, world)
+            if hasattr(sc, "obs_spec") and hasattr(sc, "reward_spec"):
+                self._prog = rowspec.compile_scenario(sc, world)
+            elif builtin is not None and kind in rowspec.BUILTIN_PROGRAM_KINDS and is_builtin(observation_callback, "observation") and \
+                    is_builtin(reward_callback, "reward") and getattr(reset_callback, "__self__", None) is sc:
+                # a built-in scenario at a team size libmpe_hip.so has no kernel for: its callbacks are N-generic
+                # (simple_adversary.py:69-139, simple_world_comm.py:126-289 loop over team lists) and so are their specs
+                self._prog = rowspec.builtin_program(rowspec.BUILTIN_PROGRAM_KINDS[kind], world)
         if fused is None:
             fused = own or self._prog is not None
         if fused and not own and self._prog is None:
@@ -292,9 +300,12 @@ class MultiAgentEnv(object):
         return d
 
     def _program_step(self, desc_ref, bufs_ref, B, st):
-        """World.step, then every agent's row / reward / done from the post-step state: two launches."""
+        """World.step by the agents' waves, then every agent's row / reward / done from the post-step state by the row
+        programs: ONE launch (`mpe_step_rows`; `two_launch_program = True` keeps mpe_world_step + mpe_rows, the A/B)."""
         L = _abi.lib()
-        return L.mpe_world_step(desc_ref, bufs_ref, B, st) or L.mpe_rows(desc_ref, bufs_ref, self._prog.ref, B, st)
+        if self.two_launch_program:
+            return L.mpe_world_step(desc_ref, bufs_ref, B, st) or L.mpe_rows(desc_ref, bufs_ref, self._prog.ref, B, st)
+        return L.mpe_step_rows(desc_ref, bufs_ref, self._prog.ref, B, st)
 
     @property
     def step_impl(self):
@@ -567,12 +578,38 @@ class MultiAgentEnv(object):
                 info_n = {'n': [self._get_info(a) for a in self.agents]}
         if info_n is None:
             info_n = out.info_n(self)
-        if self.max_episode_steps and self._episode_tick(done) and not self._py_obs:
+        if self.max_episode_steps and self._episode_tick(done, out) and not self._py_obs:
             self._observe_into(out)         # worlds that finished were reset: their rows are the new episode's first
         obs_n = [self._get_obs(a) for a in self.agents] if self._py_obs else out.obs_n
         return self._deliver(obs_n, reward_n, done_n, info_n)
 
-    def _episode_tick(self, done):
+    _BUILTIN_NAMES = {_abi.MPE_SCN_SIMPLE: "simple", _abi.MPE_SCN_SPREAD: "simple_spread", _abi.MPE_SCN_TAG: "simple_tag",
+                      _abi.MPE_SCN_ADVERSARY: "simple_adversary", _abi.MPE_SCN_PUSH: "simple_push",
+                      _abi.MPE_SCN_SPEAKER_LISTENER: "simple_speaker_listener", _abi.MPE_SCN_REFERENCE: "simple_reference",
+                      _abi.MPE_SCN_CRYPTO: "simple_crypto", _abi.MPE_SCN_WORLD_COMM: "simple_world_comm"}
+
+    def _finish_program(self):
+        """The row program mpe_episode_finish rewrites the restarted worlds' rows with: the env's own, or -- a built-in
+        scenario stepping through a kernel of its own -- that scenario's rows as a program (bit-identical to the kernel's,
+        tests/test_rowspec.py); None where there is none (more than 64 entities, Python observation rows, `finish_launch`
+        switched off)."""
+        if not self.finish_launch or not self.fused or self._py_obs:
+            return None
+        if self._prog is not None:
+            return self._prog
+        if self.__dict__.get("_finish_prog") is None:
+            self._finish_prog = False
+            name = self._BUILTIN_NAMES.get(self._kind)
+            if name is not None and len(self.world.entities) <= _abi.MPE_ROWS_MAX_ENTITIES and \
+                    not any(l.movable for l in self.world.landmarks):
+                from . import rowspec
+                prog = rowspec.builtin_program(name, self.world)
+                if list(prog.widths) == [self._obs_off[i + 1] - self._obs_off[i] for i in range(len(prog.widths))]:
+                    prog.validate(self._desc)
+                    self._finish_prog = prog
+        return self._finish_prog or None
+
+    def _episode_tick(self, done, out=None):
         """After a step: count it for every world, mark the worlds that reached max_episode_steps done (all agents),
         and -- auto_reset -- start their next episode (reset_callback with mask = the done row).  `done` is the
         [A,B] bool tensor the step wrote.  Returns True when a reset was issued (observations must be refreshed).
@@ -584,10 +621,31 @@ class MultiAgentEnv(object):
             self.episode_step = torch.zeros(self.batch_size, dtype=torch.int32, device=w.device)
             self._may_finish.add(self._steps_taken + self.max_episode_steps)
         self._steps_taken += 1
+        if self.done_callback is not None and self.auto_reset and out is not None and self._finish_program() is not None:
+            # a done_callback can end a world at ANY step.  ONE launch (mpe_episode_finish) counts the step, finds the worlds
+            # some agent's done row (or the horizon) flagged, restarts exactly those -- reset_world's draws, counters, comm
+            # state -- and rewrites their observation rows; a workgroup of 64 worlds none of which finished returns after
+            # reading its flags, so a step at which nothing ends costs one small launch more (round 3: a tick, a mask
+            # reduction, a masked reset, a comm fill and a full mpe_observe relaunch on every step).
+            prog = self._finish_program()
+            b = _abi.MpeBuffers()
+            C.memmove(C.byref(b), C.byref(out.bufs), C.sizeof(b))
+            b.done = done.data_ptr()
+            b.act = b.ids = b.u = None
+            _abi.check(_abi.lib().mpe_episode_finish(C.byref(self._desc), C.byref(b), prog.ref, self.batch_size,
+                                                     self.episode_step.data_ptr(), self.max_episode_steps,
+                                                     float(getattr(self._scenario, "landmark_range", 1.0)),
+                                                     int(w.seed) & (2 ** 64 - 1), int(w._episode), int(w.world_offset),
+                                                     self._stream()), "mpe_episode_finish")
+            w._episode += 1
+            if hasattr(self._scenario, "_apply"):     # per-world Python state of the scenario (goal colours ...) follows lazily
+                self._scenario_state_stale = True
+            return False          # (the rows of the restarted worlds are already the new episode's first)
         _abi.check(_abi.lib().mpe_episode_tick(self.episode_step.data_ptr(), done.data_ptr(), done.shape[0],
                                                self.batch_size, self.max_episode_steps, 1 if self.auto_reset else 0,
                                                self._stream()), "mpe_episode_tick")
         if self.done_callback is not None and self.auto_reset:
+            # (shapes without a row program -- more than 64 entities -- and the generic path: the same in separate launches)
             # a done_callback can end a world at ANY step: restart every world some agent (or the horizon) flagged,
             # at every step, and restart its step counter too (the tick only clears it at the horizon).
             # Cost, knowingly paid: a masked reset_callback, a comm fill and (the caller's) mpe_observe relaunch on EVERY
@@ -783,7 +841,7 @@ class MultiAgentEnv(object):
                                     for a in self.agents]).contiguous()
                 done_n = [done[i] for i in range(self.n)]
             info_n = {'n': [self._get_info(a) for a in self.agents]}
-            if self.max_episode_steps and self._episode_tick(done):
+            if self.max_episode_steps and self._episode_tick(done, out):
                 self._observe_into(out)
             return self._deliver(out.obs_n, out.reward_n, done_n, info_n)
         obs_n, reward_n, done_n, info_n = [], [], [], {'n': []}

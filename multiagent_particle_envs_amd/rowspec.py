@@ -254,12 +254,13 @@ class RowProgram(object):
             ops += o.ops
             begin.append(len(ops))
         self.widths = [o.width for o in obs_specs]
-        rew_begin = len(ops)
-        for i, r in enumerate(reward_specs):
+        rbegin = [len(ops)]
+        for i, r in enumerate(reward_specs):         # agent i's reward program: both accumulators start at 0, STORE at the end
             ops.append(_op(_abi.MPE_ROW_R_ZERO, 0, 0, 0))
             ops.append(_op(_abi.MPE_ROW_R_ZERO, 0, 0, 1))
             ops += r.ops
             ops.append(_op(_abi.MPE_ROW_R_STORE, i))
+            rbegin.append(len(ops))
         self.n_ops = len(ops)
         flat = [w for op in ops for w in op]
         self.ops_host = (C.c_int32 * max(1, len(flat)))(*flat)
@@ -269,7 +270,8 @@ class RowProgram(object):
         p.n_ops = self.n_ops
         for i in range(_abi.MPE_ROWS_MAX_ENTITIES + 1):
             p.obs_begin[i] = begin[min(i, A)]
-        p.rew_begin, p.rew_end = rew_begin, len(ops)
+        for i in range(_abi.MPE_ROWS_MAX_ENTITIES + 1):
+            p.rew_begin[i] = rbegin[min(i, A)]
         p.n_vel = world.n_dynamic
         regions = regions or Regions()
         if len(regions.landmarks) > 2:
@@ -301,6 +303,17 @@ def compile_scenario(scenario, world):
         return None
     rg = scenario.regions(world) if hasattr(scenario, "regions") else None
     return RowProgram(world, obs, rew, rg)
+
+
+# built-in scenarios whose callbacks are written for any team size: where no fused kernel exists for a shape, the env runs
+# their specs (World.step + mpe_rows) instead of falling back to the torch callbacks
+BUILTIN_PROGRAM_KINDS = {_abi.MPE_SCN_SIMPLE: "simple", _abi.MPE_SCN_ADVERSARY: "simple_adversary", _abi.MPE_SCN_PUSH: "simple_push",
+                         _abi.MPE_SCN_WORLD_COMM: "simple_world_comm"}
+
+
+def builtin_program(name, world):
+    obs, rew, regions = builtin_specs(name, world)
+    return RowProgram(world, obs, rew, regions)
 
 
 # ---- the nine shipped scenarios as specs: each follows its fused kernel's (= the reference callback's) order ---------------------

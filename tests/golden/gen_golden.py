@@ -148,6 +148,8 @@ def main():
     if only == ["simple_spread_n64"]:
         jobs = [("simple_spread_n64", record_n64())]
         return write(jobs, t0)
+    if only == ["simple_spread_n64_w64"]:
+        return write([("simple_spread_n64_w64", record_n64_wide())], t0, compressed=True)
     jobs = []
     # C1: simple, 100 random-action steps (BASELINE.json configs[0]) -- plumbing check
     jobs.append(("simple", record("simple", make_env("simple"), list(range(16)), 100)))
@@ -175,9 +177,28 @@ def record_n64():
     return record("simple_spread_n64", spread_n(64), [7, 8, 9, 10, 11, 12, 13, 14], 3, squeeze_every=2, squeeze=0.5)
 
 
-def write(jobs, t0):
+N64_WIDE_AGENTS = (0, 17, 63)
+
+
+def record_n64_wide():
+    """simple_spread N=64, 64 worlds x 3 steps (round 4: reference data for the REAL grid of the two-waves-per-world kernel --
+    the GPU test places these worlds among 4096).  Full state, rewards and benchmark counts of every agent; observation rows
+    (384 floats each) of agents 0, 17 and 63 only: every row of all 64 agents would be 38 MB."""
+    data = record("simple_spread_n64", spread_n(64), list(range(300, 364)), 3, squeeze_every=2, squeeze=0.5)
+    for k in list(data):
+        if k.startswith("obs") and int(k.replace("obs_reset", "").replace("obs", "")) not in N64_WIDE_AGENTS:
+            del data[k]
+    data["obs_agents"] = np.array(N64_WIDE_AGENTS)
+    return data
+
+
+def write(jobs, t0, compressed=False):
     for name, data in jobs:
         path = os.path.join(HERE, name + ".npz")
+        if compressed:
+            np.savez_compressed(path, **data)
+            print("%-24s %6.2f MB (compressed)" % (name, os.path.getsize(path) / 1e6))
+            continue
         np.savez_compressed(path, **data)
         print("%-22s %8.1f KiB" % (name, os.path.getsize(path) / 1024.0))
     print("done in %.1f s" % (time.time() - t0))

@@ -360,7 +360,9 @@ def test_other_team_sizes_against_reference_golden(name, A, nadv, fused, golden)
     if not fused:
         return
     env = mpe.make_env(name, batch_size=len(g["seeds"]), benchmark=True, **env_kw)
-    assert env.fused and not env._py_info
+    # (a shape with a kernel of its own gets its benchmark_data from the same launch; a row-program shape evaluates the
+    #  scenario's benchmark_data callback on the post-step world)
+    assert env.fused and env._py_info == (env._prog is not None)
     set_choices(env, g["choice"])
     for t in range(g["rew"].shape[0]):
         env.world.set_state(g["pos0"] if t == 0 else g["pos"][t - 1], g["vel0"] if t == 0 else g["vel"][t - 1])
@@ -417,14 +419,31 @@ def test_other_team_sizes_reset_and_auto_reset(name, A, nadv):
 
 
 @pytest.mark.gpu
-def test_a_team_size_without_a_kernel_takes_the_generic_path():
-    env = mpe.make_env("simple_world_comm", batch_size=64, num_good_agents=5, num_adversaries=6)
-    assert not env.fused
-    with pytest.raises(RuntimeError):      # _abi.MpeError
-        mpe.make_env("simple_world_comm", batch_size=64, num_good_agents=5, num_adversaries=6, fused=True)
+def test_a_team_size_without_a_kernel_steps_through_its_row_program():
+    """11 agents (5 prey, 6 predators): no k_split entry -- World.step + the scenario's row program in one launch, held to the
+    torch callbacks of the generic path on the same worlds (and past 64 entities: the generic path itself)."""
+    B = 512
+    env = mpe.make_env("simple_world_comm", batch_size=B, num_good_agents=5, num_adversaries=6, seed=2)
+    gen = mpe.make_env("simple_world_comm", batch_size=B, num_good_agents=5, num_adversaries=6, seed=2, fused=False)
+    assert env.fused and env._prog is not None and not gen.fused
     rs = np.random.RandomState(0)
-    obs, rew, done, _ = env.step(random_actions(env, rs, 64))
-    assert len(obs) == 11 and all(torch.isfinite(o).all() for o in obs)
+    o1, o2 = env.reset(), gen.reset()
+    for t in range(4):
+        if t == 1:
+            for e in (env, gen):
+                e.world.pos.mul_(0.4)
+        act = random_actions(env, rs, B)
+        o1, r1, _, _ = env.step(act)
+        o2, r2, _, _ = gen.step(act)
+        assert torch.equal(env.world.pos, gen.world.pos) and torch.equal(env.world.vel, gen.world.vel)
+        for i in range(11):
+            assert o1[i].shape == o2[i].shape and torch.allclose(o1[i], o2[i], atol=1e-6, rtol=0), (t, i)
+            err = ((r1[i] - r2[i]).abs() / r2[i].abs().clamp(min=1.0))
+            assert float(err.quantile(0.999)) <= 1e-5, (t, i, float(err.max()))      # (a knife-edge contact may flip in one path)
+    big = mpe.make_env("simple_adversary", batch_size=16, num_agents=40, num_adversaries=3)     # 79 entities
+    assert not big.fused
+    with pytest.raises(RuntimeError):      # _abi.MpeError
+        mpe.make_env("simple_adversary", batch_size=16, num_agents=40, num_adversaries=3, fused=True)
 
 
 @pytest.mark.gpu

@@ -173,11 +173,11 @@ def test_error_reporting():
     assert L.mpe_step(C.byref(desc), C.byref(b), 64, None) == -1 and b"pos" in L.mpe_last_error()
     b.pos, b.vel = env.world.pos.data_ptr(), env.world.vel.data_ptr()
     assert L.mpe_step(C.byref(desc), C.byref(b), 64, None) == -1 and b"act" in L.mpe_last_error()
-    # a shape no kernel was built for (simple_adversary beyond the table of team sizes): the C ABI says so
-    # (mpe_step_supported 0, mpe_step MPE_EUNSUPPORTED) and the env keeps the scenario's torch callbacks around
-    # mpe_world_step instead
+    # a shape no kernel was built for (simple_adversary beyond the reference's team size): the C ABI says so
+    # (mpe_step_supported 0, mpe_step MPE_EUNSUPPORTED) and the env steps it through the scenario's row program instead
+    # (mpe_step_rows: World.step + the interpreted rows in one launch)
     enva = make_env("simple_adversary", batch_size=8, num_agents=7, num_adversaries=3)
-    assert not enva.fused and len(enva.reset()) == 7
+    assert enva.fused and enva._prog is not None and len(enva.reset()) == 7
     da = enva.world.scenario_desc(_abi.MPE_SCN_ADVERSARY, 3)
     assert L.mpe_step_supported(C.byref(da)) == 0
     obs = torch.zeros(8 * int(da.obs_off[7]), device="cuda")

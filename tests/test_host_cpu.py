@@ -200,21 +200,25 @@ def test_fused_kernels_cover_the_reference_shapes_and_other_shapes_fall_back():
     assert big.fused and big.observation_space[0].shape == (4 + 40 + 138 + 60,)
     assert big.observation_space[69].shape == (4 + 40 + 138 + 58,)
     assert env_of("simple_tag", num_adversaries=2).fused
-    # simple_adversary / simple_world_comm: the reference's team sizes and a grid of others (mpe_split.hip: 2..6 agents with 1..2
-    # adversaries; 1..3 good agents with 2..5 adversaries); beyond it, torch callbacks around mpe_world_step
+    # simple_adversary / simple_world_comm (callbacks written for any team size): the reference's team sizes have a kernel of
+    # their own, every other -- round 3's grid of 19 and beyond, up to 64 entities -- steps as World.step + the scenario's row
+    # program (rowspec.builtin_program): two launches, no instantiation per shape
     from oracle.spec import TEAM_SIZE_VARIANTS
     for name, A, nadv in TEAM_SIZE_VARIANTS:
         if name == "simple_adversary":
             e = env_of(name, num_agents=A, num_adversaries=nadv)
-            assert e.fused and e.n == A, (name, A, nadv)
+            assert e.fused and e.n == A and e._prog is not None, (name, A, nadv)
         else:
             good, adv = A - nadv, nadv
             e = env_of(name, num_good_agents=good, num_adversaries=adv)
-            assert e.fused and e.n == A, (good, adv)
+            assert e.fused and e.n == A and e._prog is not None, (good, adv)
             assert e.observation_space[0].shape == (4 + 10 + 2 * (A - 1) + 2 * good + 2 + 4,)
             assert e.observation_space[adv].shape == (4 + 10 + 2 * (A - 1) + 2 + 2 * (good - 1),)
-    assert not env_of("simple_adversary", num_agents=7, num_adversaries=3).fused
-    assert not env_of("simple_world_comm", num_good_agents=5, num_adversaries=6).fused
+    assert env_of("simple_adversary").fused and env_of("simple_adversary")._prog is None          # the reference's shape: its own kernel
+    for e in (env_of("simple_adversary", num_agents=7, num_adversaries=3), env_of("simple_world_comm", num_good_agents=5, num_adversaries=6),
+              env_of("simple_adversary", num_agents=30, num_adversaries=9), env_of("simple_world_comm", num_good_agents=20, num_adversaries=12)):
+        assert e.fused and e._prog is not None and e._kind == _abi.MPE_SCN_GENERIC
+    assert not env_of("simple_adversary", num_agents=40, num_adversaries=3).fused            # 79 entities: past the row programs' 64
     d = big.world.scenario_desc(_abi.MPE_SCN_GENERIC)
     assert _abi.lib().mpe_step_supported(C.byref(d)) == 0
     d = _abi.MpeScenarioDesc()

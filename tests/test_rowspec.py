@@ -45,9 +45,9 @@ def spec_scenario(name):
     return AsSpecs()
 
 
-def make_spec_env(name, B, device=None, seed=0, **kw):
+def make_spec_env(name, B, device=None, seed=0, scenario_kw=None, **kw):
     sc = spec_scenario(name)
-    w = sc.make_world(batch_size=B, device=device)
+    w = sc.make_world(batch_size=B, device=device, **(scenario_kw or {}))
     w.seed = seed
     if w.pos.is_cuda:
         sc.reset_world(w)          # as make_env does (the reference's make_world ends with reset_world): same episode numbering
@@ -95,6 +95,13 @@ def test_malformed_programs_are_refused_with_the_op_named():
         dd.obs_off[1], dd.obs_off[2], dd.obs_off[3] = 2, 2 + good.widths[1], 2 + good.widths[1] + good.widths[2]
         p.validate(dd)
     r = rowspec.RewardSpec(w, w.agents[0])
+    r.ops.append(rowspec._op(_abi.MPE_ROW_R_STORE, 2))             # agent 0's program storing agent 2's reward
+    with pytest.raises(_abi.MpeError, match="stores agent 2"):
+        p = rowspec.RowProgram(w, obs, [r] + rew[1:])
+        for i in range(4):
+            dd.obs_off[i] = sum(good.widths[:i])
+        p.validate(dd)
+    r = rowspec.RewardSpec(w, w.agents[0])
     r.ops.append(rowspec._op(_abi.MPE_ROW_R_LOAD, 9))              # slot 9 of 8
     with pytest.raises(_abi.MpeError, match="slot 9"):
         p = rowspec.RowProgram(w, obs, [r] + rew[1:])
@@ -105,80 +112,11 @@ def test_malformed_programs_are_refused_with_the_op_named():
         rowspec.ObsSpec(w, w.agents[0]).rel(Landmark())
 
 
-# ---- a scenario nobody wrote a kernel for, described by specs only -------------------------------------------------------------
-class Corral(BaseScenario):
-    """Two herders and a stray; three posts, one of them (picked per world) is the gate.  Rows and rewards as specs AND as
-    torch callbacks (the generic path), so that the two can be held against each other."""
-
-    def make_world(self, batch_size=1, device=None):
-        world = World(batch_size, device)
-        world.dim_c = 0
-        world.choice_pops = [3]
-        world.agents = [Agent() for _ in range(3)]
-        for i, a in enumerate(world.agents):
-            a.name, a.silent, a.collide = "agent %d" % i, True, True
-            a.size = 0.1 if i < 2 else 0.05
-            a.accel = 3.0 if i < 2 else 4.5
-            a.max_speed = 1.0 if i < 2 else 1.4
-        world.landmarks = [Landmark() for _ in range(3)]
-        for l in world.landmarks:
-            l.collide, l.movable, l.size = False, False, 0.08
-        world.allocate()
-        return world
-
-    def reset_world(self, world, mask=None, seeds=None):
-        idx = world.reset_uniform(0.9, mask, choices=[3], seeds=seeds)
-        if world.choice_i32 is not None:
-            world.choice_i32[0].copy_(World.merge_choice(world.choice_i32[0].long(), idx[:, 0].to(world.device), mask).to(torch.int32))
-
-    def obs_spec(self, agent, world):
-        o = rowspec.ObsSpec(world, agent)
-        o.vel().pos().rel_pick(0, world.landmarks).onehot(0, 3, 0.1, 0.9)
-        for l in world.landmarks:
-            o.rel(l)
-        for a in world.agents:
-            if a is not agent:
-                o.rel(a).vel(a)
-        return o.const(0.5)
-
-    def reward_spec(self, agent, world):
-        r = rowspec.RewardSpec(world, agent)
-        stray = world.agents[2]
-        r.dist2_pick(stray, 0, world.landmarks).sqrt().add(-1.0)             # the stray's distance to the gate
-        r.min_dist2_from(agent, world.landmarks).add(-0.25)                  # squared distance to the nearest post
-        for a in world.agents:
-            if a is not agent:
-                r.add_if_touching(a, agent, -3.0)
-        r.bound(agent, 0).add(-1.0).bound(agent, 1).add(-1.0)
-        return r
-
-    # the same in torch (generic path)
-    def _gate(self, world):
-        pos = torch.stack([l.state.p_pos for l in world.landmarks])           # [3, B, 2]
-        g = world.choice_i32[0].long()
-        return pos[g, torch.arange(world.batch_size, device=pos.device)]
-
-    def observation(self, agent, world):
-        from multiagent_particle_envs_amd.scenarios._util import one_hot_rows
-        me = agent.state.p_pos
-        cols = [agent.state.p_vel, me, self._gate(world) - me, one_hot_rows(world, world.choice_i32[0], 3, 0.8) + 0.1]
-        cols += [l.state.p_pos - me for l in world.landmarks]
-        for a in world.agents:
-            if a is not agent:
-                cols += [a.state.p_pos - me, a.state.p_vel]
-        cols.append(torch.full((world.batch_size, 1), 0.5, device=world.device))
-        return torch.cat(cols, dim=1)
-
-    def reward(self, agent, world):
-        from multiagent_particle_envs_amd.scenarios._util import bound, dist2, is_collision
-        stray = world.agents[2]
-        d = stray.state.p_pos - self._gate(world)
-        rew = -torch.sqrt((d * d).sum(dim=1))
-        rew = rew - 0.25 * torch.stack([dist2(agent, l) for l in world.landmarks]).min(dim=0).values
-        for a in world.agents:
-            if a is not agent:
-                rew = rew - 3.0 * is_collision(a, agent).float()
-        return rew - bound(agent.state.p_pos[:, 0].abs()) - bound(agent.state.p_pos[:, 1].abs())
+# ---- a scenario nobody wrote a kernel for, described by specs only: examples/corral.py ------------------------------------------
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+from corral import Scenario as Corral  # noqa: E402
 
 
 def corral_env(B, fused=None, **kw):
@@ -209,28 +147,33 @@ def test_builtins_as_specs_are_bit_identical_to_their_fused_kernels(name, B):
     """Same seed, same moves / words, resets in between: rows, rewards, dones and state of the two-launch program path ==
     the one-launch fused kernel's, to the bit (B = 1000: a ragged last workgroup and unaligned rows)."""
     fused = mpe.make_env(name, batch_size=B, seed=5)
-    prog = make_spec_env(name, B, seed=5)
+    prog = make_spec_env(name, B, seed=5)                 # mpe_step_rows: World.step + the programs in ONE launch
+    prog2 = make_spec_env(name, B, seed=5)                # mpe_world_step + mpe_rows: two launches
+    prog2.two_launch_program = True
     assert fused.fused and fused._prog is None and prog.fused and prog._prog is not None
     rs = np.random.RandomState(B)
-    of, op = fused.reset(), prog.reset()
+    of, op, op2 = fused.reset(), prog.reset(), prog2.reset()
     for i in range(fused.n):
-        assert torch.equal(of[i], op[i]), ("reset", i)
+        assert torch.equal(of[i], op[i]) and torch.equal(of[i], op2[i]), ("reset", i)
     for t in range(9):
         if t == 2:                                   # crowd the worlds: contacts, boundary penalties
-            for e in (fused, prog):
+            for e in (fused, prog, prog2):
                 e.world.pos.mul_(0.35)
         if t == 6:
-            of, op = fused.reset(), prog.reset()
+            of, op, op2 = fused.reset(), prog.reset(), prog2.reset()
             for i in range(fused.n):
-                assert torch.equal(of[i], op[i]), ("second reset", i)
+                assert torch.equal(of[i], op[i]) and torch.equal(of[i], op2[i]), ("second reset", i)
         act = rand_actions(fused, rs, B)
         of, rf, df, _ = fused.step(act)
         op, rp, dp, _ = prog.step(act)
-        assert torch.equal(fused.world.pos, prog.world.pos) and torch.equal(fused.world.vel, prog.world.vel), t
+        op2, rp2, _, _ = prog2.step(act)
+        for e in (prog, prog2):
+            assert torch.equal(fused.world.pos, e.world.pos) and torch.equal(fused.world.vel, e.world.vel), t
         for i in range(fused.n):
             assert torch.equal(of[i], op[i]), (name, "obs", t, i, float((of[i] - op[i]).abs().max()))
             assert torch.equal(rf[i], rp[i]), (name, "rew", t, i, float((rf[i] - rp[i]).abs().max()))
             assert torch.equal(df[i], dp[i])
+            assert torch.equal(of[i], op2[i]) and torch.equal(rf[i], rp2[i]), (name, "two launches", t, i)
 
 
 @pytest.mark.gpu
@@ -265,7 +208,7 @@ def test_custom_scenario_specs_against_its_own_torch_callbacks():
     o1, o2 = ps.reset(), pt.reset()
     assert torch.equal(ps.world.choice_i32, pt.world.choice_i32) and len(set(ps.world.choice_i32[0].tolist())) == 3
     for i in range(3):
-        assert o1[i].shape == (B, 27) and torch.allclose(o1[i], o2[i], atol=1e-6, rtol=0)
+        assert o1[i].shape == (B, 24) and torch.allclose(o1[i], o2[i], atol=1e-6, rtol=0)
     for t in range(12):
         if t == 3:
             for e in (ps, pt):
@@ -307,3 +250,49 @@ def test_program_env_auto_reset_and_graphed_step():
         og, rg, _, _ = gs.step(act)
         oe, re_, _, _ = e3.step(act)
         assert all(torch.equal(a, b) for a, b in zip(og + rg, oe + re_)), t
+
+
+def _strayed(agent, world):
+    """A done callback: the agent left the arena (any world, any step)."""
+    return (agent.state.p_pos.abs() > 0.95).any(dim=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["simple_spread", "simple_tag", "simple_adversary", "simple_reference", "simple_world_comm", "corral"])
+def test_done_callback_auto_reset_in_one_launch_equals_the_separate_launches(name):
+    """done_callback + auto_reset: mpe_episode_finish (tick, finished worlds, masked reset_world, comm state, their rows -- one
+    launch with a per-workgroup early-out) against round 3's sequence of separate launches (tick, mask reduction, masked
+    mpe_reset, comm fill, full mpe_observe): same worlds, same moves -- rows, rewards, dones, counters, state, picks to the bit."""
+    B = 3000
+
+    def build(finish):
+        if name == "corral":
+            env = corral_env(B, max_episode_steps=7, auto_reset=True, done_callback=_strayed)
+        else:
+            env = mpe.make_env(name, batch_size=B, seed=4, max_episode_steps=7, auto_reset=True)
+            env.done_callback = _strayed
+            env._py_done = True
+        env.finish_launch = finish
+        return env
+    new, old = build(True), build(False)
+    assert new.fused and new._finish_program() is not None and old._finish_program() is None
+    rs = np.random.RandomState(1)
+    o1, o2 = new.reset(), old.reset()
+    restarted = 0
+    for t in range(1, 17):
+        act = rand_actions(new, rs, B)
+        o1, r1, d1, _ = new.step(act)
+        o2, r2, d2, _ = old.step(act)
+        assert torch.equal(new.world.pos, old.world.pos) and torch.equal(new.world._vel_all, old.world._vel_all), t
+        assert torch.equal(new.episode_step, old.episode_step), t
+        if new.world.choice_i32 is not None:
+            assert torch.equal(new.world.choice_i32, old.world.choice_i32), t
+        if new._comm is not None:
+            assert torch.equal(new._comm, old._comm), t
+        for i in range(new.n):
+            assert torch.equal(o1[i], o2[i]), (name, t, i)
+            assert torch.equal(r1[i], r2[i]) and torch.equal(d1[i], d2[i]), (name, t, i)
+        fin = torch.stack(d1).any(dim=0)
+        restarted += int(fin.sum())
+        assert torch.equal(new.episode_step == 0, fin), t          # exactly the finished worlds restarted their count
+    assert 0 < restarted < 16 * B          # some worlds strayed early, most steps most worlds did not finish

@@ -50,6 +50,8 @@ def measure(label, env, B, n, out):
         acts = [torch.stack(a).contiguous() for a in acts]
     r, us = rate(env.step, acts, B, n, env.reset)
     out.append({"what": label + " eager env.step", "env_steps_per_s": r, "us_per_step": us})
+    if EAGER_ONLY:
+        return
     gs = mpe.GraphedStep(env, acts[0])
     r, us = rate(gs.step, acts, B, n)
     out.append({"what": label + " GraphedStep", "env_steps_per_s": r, "us_per_step": us})
@@ -57,21 +59,34 @@ def measure(label, env, B, n, out):
     out.append({"what": label + " graph replay only (actions resident)", "env_steps_per_s": r, "us_per_step": us})
 
 
+EAGER_ONLY = False
+
+
 def main():
+    global EAGER_ONLY
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--scenarios", default="corral,simple_spread,simple_tag,simple_world_comm")
+    ap.add_argument("--no-generic", action="store_true")
+    ap.add_argument("--eager-only", action="store_true")
     args = ap.parse_args()
+    EAGER_ONLY = args.eager_only
     B, out = args.batch, []
     for name in args.scenarios.split(","):
         if name == "corral":
-            measure("corral  program (2 launches)", tr.corral_env(B), B, args.steps, out)
+            measure("corral  program (1 launch) ", tr.corral_env(B), B, args.steps, out)
             measure("corral  generic (torch callbacks)", tr.corral_env(B, fused=False), B, max(50, args.steps // 8), out)
-        else:
-            measure("%-18s fused (1 launch)" % name, mpe.make_env(name, batch_size=B), B, args.steps, out)
-            measure("%-18s program (2 launches)" % name, tr.make_spec_env(name, B), B, args.steps, out)
-            measure("%-18s generic (torch callbacks)" % name, mpe.make_env(name, batch_size=B, fused=False), B, max(50, args.steps // 8), out)
+        else:       # name[:key=value ...]: scenario kwargs (team sizes)
+            parts = name.split(":")
+            name, kw = parts[0], {k: int(v) for k, v in (p.split("=") for p in parts[1:])}
+            tag = name.replace("simple_", "") + ("(" + ",".join(str(v) for v in kw.values()) + ")" if kw else "")
+            e = mpe.make_env(name, batch_size=B, **kw)
+            if e._prog is None and e.fused:
+                measure("%-18s fused (1 launch)" % tag, e, B, args.steps, out)
+            measure("%-18s program (1 launch) " % tag, tr.make_spec_env(name, B, scenario_kw=kw), B, args.steps, out)
+            if not args.no_generic:
+                measure("%-18s generic (torch callbacks)" % tag, mpe.make_env(name, batch_size=B, fused=False, **kw), B, max(50, args.steps // 8), out)
     print("# env-steps/s at %d worlds per path (tools/rowspec_rate.py); best of 3 x %d steps, reset every 25 in the eager rows" % (B, args.steps))
     for o in out:
         print("%-62s %10.1f M env-steps/s   %8.2f us / step" % (o["what"], o["env_steps_per_s"] / 1e6, o["us_per_step"]))
