@@ -118,6 +118,21 @@ void *vmm_compose(const int *order, int n) {
   return base;
 }
 
+// release every range and every physical chunk (a new vmm_create may follow, e.g. with another chunk size)
+int vmm_destroy() {
+  for (auto &r : g.ranges)
+    if (r.first) {
+      hipMemUnmap(r.first, r.second);
+      hipMemAddressFree(r.first, r.second);
+    }
+  g.ranges.clear();
+  for (auto h : g.h) hipMemRelease(h);
+  g.h.clear();
+  if (g.scratch) hipMemAddressFree(g.scratch, g.chunk);
+  g.scratch = nullptr;
+  return 0;
+}
+
 int vmm_release_range(void *base) {
   for (auto &r : g.ranges)
     if (r.first == base) {
