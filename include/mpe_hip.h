@@ -252,6 +252,10 @@ enum MpeRowOp {
   MPE_ROW_OBS_REL_VIS = 8,   /* OBS_REL, zeroed when self cannot see a0 (regions, simple_world_comm.py:231-261) */
   MPE_ROW_OBS_VEL_VIS = 9,   /* OBS_VEL, likewise                                                       */
   MPE_ROW_OBS_IN_REGION = 10,/* +1 / -1: is entity a0 inside region a1 (1)                              */
+  /* range forms (what the host's peephole pass turns runs of the ops above into: one decode, an inner loop):
+   * entities a0 .. a0 + a1 - 1, a2 & 1: skip the observing agent itself                                  */
+  MPE_ROW_OBS_REL_RANGE = 11, MPE_ROW_OBS_VEL_RANGE = 12, MPE_ROW_OBS_REL_VIS_RANGE = 13, MPE_ROW_OBS_VEL_VIS_RANGE = 14,
+  MPE_ROW_OBS_CONST_N = 15,  /* the float w2, a1 times                                                  */
   /* reward machine: a value register v, accumulators acc0 / acc1 (a2 & 1 selects), 8 slots.  Arithmetic in program
    * order is what fixes the rounding: the same order as the reference gives the reference's float (in fp32).         */
   MPE_ROW_R_D2 = 32,         /* v = |p[a0] - p[a1]|^2                                                   */
@@ -269,11 +273,21 @@ enum MpeRowOp {
   MPE_ROW_R_ADD = 44,        /* acc = acc + w2 * v                                                      */
   MPE_ROW_R_ADD_IF_HIT = 45, /* if |p[a0] - p[a1]| < size[a0] + size[a1] (strict, exact): acc = acc + w2 */
   MPE_ROW_R_ADD_ACC = 46,    /* acc0 = acc0 + acc1                                                      */
-  MPE_ROW_R_STORE = 47       /* reward of agent a0 = acc0 (a0 = the agent whose program this is)        */
+  MPE_ROW_R_STORE = 47,      /* reward of agent a0 = acc0 (a0 = the agent whose program this is)        */
+  MPE_ROW_R_MIN_D2_RANGE = 48,    /* v = min over a in a0 .. a0 + w1 - 1 of |p[a] - p[a1]|^2, in that order     */
+  MPE_ROW_R_MIN_D2_TO_RANGE = 49, /* v = min over b in a1 .. a1 + w1 - 1 of |p[a0] - p[b]|^2                     */
+  MPE_ROW_R_ADD_IF_HIT_GRID = 50, /* for a in a0 .. a0 + (w1 & 255) - 1, b in a1 .. a1 + (w1 >> 8) - 1: ADD_IF_HIT(a, b, w2) */
+  MPE_ROW_R_ADD_MIN_DIST_GRID = 51 /* for b in a1 .. a1 + (w1 >> 8) - 1: v = sqrt(min over a in a0 .. a0 + (w1 & 255) - 1 of |p[a] - p[b]|^2);
+                                      acc = acc + w2 * v   (simple_spread.py:72-77: minus the distance of the nearest agent, per landmark) */
 };
 /* Host POD describing one env's programs; the ops live in DEVICE memory the caller owns (uploaded once).               */
+#define MPE_ROWS_HEADER_BYTES 4096 /* >= the kernel-side header (row layout, program ranges, per-entity constants) */
 typedef struct MpeRowProgram {
   const int32_t *ops_device;  /* n_ops x 4 int32 words                                                  */
+  void *header_device;        /* MPE_ROWS_HEADER_BYTES of caller-owned DEVICE memory: the library keeps the kernel-side header
+                                 there (as kernel arguments its ~30 cache lines would be fetched from host memory one by one) and
+                                 re-uploads it -- one 64-thread launch on the call's stream -- whenever its content changes       */
+  uint64_t header_hash;       /* in / out: what header_device holds (0 = nothing yet).  A program is used by one thread at a time. */
   int32_t n_ops;
   int32_t obs_begin[MPE_ROWS_MAX_ENTITIES + 1]; /* agent i's observation ops: [obs_begin[i], obs_begin[i+1]); its row width is
                                                    desc->obs_off[i+1] - desc->obs_off[i] (filled by the caller)            */
@@ -289,11 +303,11 @@ int mpe_rows_validate(const MpeScenarioDesc *desc, const MpeRowProgram *prog, co
 /* Scenario.observation / reward / done of every agent from the CURRENT state (environment.py:92-102 after World.step, or
  * :113-115 after a reset): obs rows, rew (shared sum when desc->collaborative), done = 0.  desc->kind is ignored (GENERIC
  * is what a user scenario has); reads pos, vel, comm, choice; bufs->rew / done may be NULL.                            */
-int mpe_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, const MpeRowProgram *prog, int64_t B, void *stream);
+int mpe_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowProgram *prog, int64_t B, void *stream);
 /* mpe_step_rows: one MultiAgentEnv.step of a user scenario in ONE launch -- _set_action + World.step (environment.py:144-181,
  * core.py:117-177; exactly one of bufs->act / ids / u, no movable landmarks: those go through mpe_world_step) by the
  * agents' waves, then the row programs on the post-step state as in mpe_rows.  State bit-identical to mpe_world_step's.  */
-int mpe_step_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, const MpeRowProgram *prog, int64_t B, void *stream);
+int mpe_step_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowProgram *prog, int64_t B, void *stream);
 /* mpe_episode_finish: what follows a step when episodes end on the device -- NEW API like mpe_episode_tick (the reference's
  * done is always False, environment.py:132-135) -- in ONE launch: count the step (episode_step[w] += 1; worlds at
  * max_episode_steps > 0 get done = 1 in every agent's row), find the finished worlds (any done row set, by the horizon or by
@@ -301,7 +315,7 @@ int mpe_step_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, const Mpe
  * mpe_reset(mask, landmark_range, seed, episode, world_offset): positions, zero velocities, per-world picks, utterances
  * zeroed) and the observation rows of the new episode's first state.  A workgroup (64 worlds) without a finished world
  * returns after reading its counters and flags: when nothing finished the call costs a launch and little else.         */
-int mpe_episode_finish(const MpeScenarioDesc *desc, const MpeBuffers *bufs, const MpeRowProgram *prog, int64_t B,
+int mpe_episode_finish(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowProgram *prog, int64_t B,
                        int32_t *episode_step, int32_t max_episode_steps, float landmark_range, uint64_t seed,
                        uint64_t episode, int64_t world_offset, void *stream);
 

@@ -16,8 +16,11 @@ MPE_MAX_CHOICES = 4
 # the composable output stage (include/mpe_hip.h, enum MpeRowOp)
 MPE_ROWS_MAX_ENTITIES = 64
 MPE_ROW_SELF = 255
+MPE_ROWS_HEADER_BYTES = 4096
 (MPE_ROW_OBS_VEL, MPE_ROW_OBS_POS, MPE_ROW_OBS_REL, MPE_ROW_OBS_REL_PICK, MPE_ROW_OBS_COMM, MPE_ROW_OBS_CONST, MPE_ROW_OBS_ONEHOT,
  MPE_ROW_OBS_REL_VIS, MPE_ROW_OBS_VEL_VIS, MPE_ROW_OBS_IN_REGION) = range(1, 11)
+(MPE_ROW_OBS_REL_RANGE, MPE_ROW_OBS_VEL_RANGE, MPE_ROW_OBS_REL_VIS_RANGE, MPE_ROW_OBS_VEL_VIS_RANGE, MPE_ROW_OBS_CONST_N) = range(11, 16)
+MPE_ROW_R_MIN_D2_RANGE, MPE_ROW_R_MIN_D2_TO_RANGE, MPE_ROW_R_ADD_IF_HIT_GRID, MPE_ROW_R_ADD_MIN_DIST_GRID = 48, 49, 50, 51
 (MPE_ROW_R_D2, MPE_ROW_R_MIN_D2, MPE_ROW_R_D2_PICK, MPE_ROW_R_MIN_D2_PICK, MPE_ROW_R_SQRT, MPE_ROW_R_BOUND, MPE_ROW_R_COMM_ERR,
  MPE_ROW_R_COMM_SUM, MPE_ROW_R_CONST, MPE_ROW_R_SAVE, MPE_ROW_R_LOAD, MPE_ROW_R_ZERO, MPE_ROW_R_ADD, MPE_ROW_R_ADD_IF_HIT,
  MPE_ROW_R_ADD_ACC, MPE_ROW_R_STORE) = range(32, 48)
@@ -52,7 +55,7 @@ class MpeBuffers(C.Structure):
 
 class MpeRowProgram(C.Structure):
     _fields_ = [
-        ("ops_device", C.c_void_p), ("n_ops", C.c_int32), ("obs_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)),
+        ("ops_device", C.c_void_p), ("header_device", C.c_void_p), ("header_hash", C.c_uint64), ("n_ops", C.c_int32), ("obs_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)),
         ("rew_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)), ("n_vel", C.c_int32), ("n_regions", C.c_int32),
         ("region_entity", C.c_int32 * 2), ("all_seeing", C.c_uint32),
     ]

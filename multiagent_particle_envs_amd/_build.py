@@ -36,11 +36,12 @@ STRESS_VARIANTS = {"stress": ["-DMPE_STRESS_DELAY_WAVE=1"],
                    # measurement build (tools/device_span.py): every wave of k_split stamps the device wall clock at its
                    # start and end -> per-launch spans and periods from the device's own clock
                    "span": ["-DMPE_DEVICE_SPAN"]}
-VARIANT_SOURCES = {"span": ("split",), "teamgrid": ("split", "narrow")}     # which kernel files a variant recompiles (default: STRESS_SOURCES)
+VARIANT_SOURCES = {"span": ("split",), "teamgrid": ("split", "narrow"), "rowsclock": ("rows",)}     # which kernel files a variant recompiles (default: STRESS_SOURCES)
 # A/B builds made on request only (`python -m multiagent_particle_envs_amd._build --ab teamgrid`), never by build():
 #   teamgrid   round 3's 19 extra k_split entries (simple_adversary / simple_world_comm team sizes) put back, to hold the
 #              row-program path that replaced them against (profiles/r4_team_sizes_ab.txt)
-AB_VARIANTS = {"teamgrid": ["-DMPE_SPLIT_TEAM_GRID"]}
+#   rowsclock  mpe_rows.hip with phase stamps (tools/rows_clock.py: where a row-program step's cycles go)
+AB_VARIANTS = {"teamgrid": ["-DMPE_SPLIT_TEAM_GRID"], "rowsclock": ["-DMPE_ROWS_CLOCK"]}
 
 
 def variant_lib(tag):

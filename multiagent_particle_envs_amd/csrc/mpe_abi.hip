@@ -430,7 +430,7 @@ int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
 }
 
 // ---- the composable output stage (mpe_rows.hip) -------------------------------------------------------------------------
-static int rows_header(const char *what, const MpeScenarioDesc *d, const MpeRowProgram *p, mpe::RowHeader *h) {
+static int rows_header(const char *what, const MpeScenarioDesc *d, const MpeRowProgram *p, mpe::RowDims *h, mpe::RowTables *t) {
   if (int rc = check_desc(d, what)) return rc;
   if (!p) return fail(MPE_EINVAL, "%s: prog is NULL", what);
   const int A = d->n_agents, E = d->n_agents + d->n_landmarks;
@@ -450,35 +450,54 @@ static int rows_header(const char *what, const MpeScenarioDesc *d, const MpeRowP
     if (p->rew_begin[i] < prev || p->rew_begin[i] > p->n_ops) return fail(MPE_EINVAL, "%s: rew_begin[%d] = %d out of order / range", what, i, p->rew_begin[i]);
     prev = p->rew_begin[i];
   }
+  if (p->n_regions > 0 && A > 32) return fail(MPE_EUNSUPPORTED, "%s: regions hide agents from each other for A <= 32 (got %d)", what, A);
+  std::memset(h, 0, sizeof(*h));
+  std::memset(t, 0, sizeof(*t));
   h->n_agents = A;
   h->n_entities = E;
   h->n_vel = p->n_vel;
   h->dim_c = d->dim_c;
   h->collaborative = d->collaborative;
+  h->n_picks = d->n_choices;
+  h->n_ops = p->n_ops;
   h->d_max = 1;
   for (int i = 0; i < A; ++i) {
     const int D = d->obs_off[i + 1] - d->obs_off[i];
     if (D < 0) return fail(MPE_EINVAL, "%s: desc->obs_off is not a prefix sum", what);
     if (D > h->d_max) h->d_max = D;
   }
-  for (int i = 0; i <= MPE_ROWS_MAX_ENTITIES; ++i) h->obs_begin[i] = i <= A ? p->obs_begin[i] : p->obs_begin[A];
-  for (int i = 0; i <= MPE_ROWS_MAX_ENTITIES; ++i) h->obs_off[i] = i <= A ? d->obs_off[i] : d->obs_off[A];
-  for (int e = 0; e < MPE_ROWS_MAX_ENTITIES; ++e) h->size[e] = e < E ? d->size[e] : 0.f;
-  h->vec4 = 0;
-  h->n_picks = d->n_choices;
-  if (p->n_regions > 0 && A > 32) return fail(MPE_EUNSUPPORTED, "%s: regions hide agents from each other for A <= 32 (got %d)", what, A);
-  for (int i = 0; i <= MPE_ROWS_MAX_ENTITIES; ++i) h->rew_begin[i] = i <= A ? p->rew_begin[i] : p->rew_begin[A];
   h->n_regions = p->n_regions;
   h->region_entity[0] = p->n_regions > 0 ? p->region_entity[0] : 0;
   h->region_entity[1] = p->n_regions > 1 ? p->region_entity[1] : 0;
   h->all_seeing = p->all_seeing;
+  // (the physics constants are part of the tables whether or not a call steps the world: mpe_step_rows, mpe_rows and
+  //  mpe_episode_finish of one program share ONE table content, and alternating between them uploads nothing)
+  for (int e = 0; e < E; ++e) {
+    t->size[e] = d->size[e];
+    t->inv_mass[e] = d->mass[e] > 0.f ? 1.0f / d->mass[e] : 1.0f;
+    t->accel[e] = d->accel[e];
+    t->max_speed[e] = d->max_speed[e];
+    if (d->movable[e]) h->movable |= 1ull << e;
+    if (d->collide[e]) h->collide |= 1ull << e;
+  }
+  for (int i = 0; i <= MPE_ROWS_MAX_ENTITIES; ++i) {
+    t->obs_off[i] = i <= A ? d->obs_off[i] : d->obs_off[A];
+    t->obs_begin[i] = i <= A ? p->obs_begin[i] : p->obs_begin[A];
+    t->rew_begin[i] = i <= A ? p->rew_begin[i] : p->rew_begin[A];
+  }
+  h->dt = d->dt;
+  h->damp = 1.0f - d->damping;
+  h->cforce = d->contact_force;
+  h->cmargin = d->contact_margin;
+  h->cmargin_inv = 1.0f / d->contact_margin;
   return 0;
 }
 
 int mpe_rows_validate(const MpeScenarioDesc *d, const MpeRowProgram *p, const int32_t *ops) {
   const char *what = "mpe_rows_validate";
-  mpe::RowHeader h;
-  if (int rc = rows_header(what, d, p, &h)) return rc;
+  mpe::RowDims h;
+  mpe::RowTables tabs;
+  if (int rc = rows_header(what, d, p, &h, &tabs)) return rc;
   if (p->n_ops > 0 && !ops) return fail(MPE_EINVAL, "%s: ops_host is NULL", what);
   const int A = d->n_agents, E = A + d->n_landmarks;
   auto ent = [&](int a, bool self_ok) { return (self_ok && a == MPE_ROW_SELF) || (a >= 0 && a < E); };
@@ -505,6 +524,15 @@ int mpe_rows_validate(const MpeScenarioDesc *d, const MpeRowProgram *p, const in
           width += a1;
           break;
         case MPE_ROW_OBS_CONST: width += 1; break;
+        case MPE_ROW_OBS_CONST_N: width += a1; break;
+        case MPE_ROW_OBS_REL_RANGE: case MPE_ROW_OBS_VEL_RANGE: case MPE_ROW_OBS_REL_VIS_RANGE: case MPE_ROW_OBS_VEL_VIS_RANGE: {
+          const bool vis = code == MPE_ROW_OBS_REL_VIS_RANGE || code == MPE_ROW_OBS_VEL_VIS_RANGE;
+          if (a1 < 1 || a0 + a1 > (vis ? A : E))
+            return fail(MPE_EINVAL, "%s: op %d (agent %d): entities %d .. %d leave the %s list", what, pc, i, a0, a0 + a1 - 1, vis ? "agent" : "entity");
+          const bool skip = ((w0 >> 24) & 1) && i >= a0 && i < a0 + a1;
+          width += 2 * (a1 - (skip ? 1 : 0));
+          break;
+        }
         case MPE_ROW_OBS_ONEHOT:
           if (a0 >= d->n_choices) return fail(MPE_EINVAL, "%s: op %d (agent %d): pick %d of %d", what, pc, i, a0, d->n_choices);
           width += a1;
@@ -548,6 +576,17 @@ int mpe_rows_validate(const MpeScenarioDesc *d, const MpeRowProgram *p, const in
           if (a0 != i || stored) return fail(MPE_EINVAL, "%s: reward op %d: agent %d's program stores agent %d (or twice)", what, pc, i, a0);
           stored = true;
           break;
+        case MPE_ROW_R_MIN_D2_RANGE:
+          if (w1 < 1 || a0 + w1 > E || !ent(a1, false)) return fail(MPE_EINVAL, "%s: reward op %d: entities %d .. %d against %d", what, pc, a0, a0 + w1 - 1, a1);
+          break;
+        case MPE_ROW_R_MIN_D2_TO_RANGE:
+          if (w1 < 1 || a1 + w1 > E || !ent(a0, false)) return fail(MPE_EINVAL, "%s: reward op %d: entity %d against %d .. %d", what, pc, a0, a1, a1 + w1 - 1);
+          break;
+        case MPE_ROW_R_ADD_IF_HIT_GRID: case MPE_ROW_R_ADD_MIN_DIST_GRID: {
+          const int na = w1 & 255, nb = (w1 >> 8) & 255;
+          if (na < 1 || nb < 1 || a0 + na > E || a1 + nb > E) return fail(MPE_EINVAL, "%s: reward op %d: contact grid %d+%d x %d+%d leaves the entity list", what, pc, a0, na, a1, nb);
+          break;
+        }
         case MPE_ROW_R_SQRT: case MPE_ROW_R_CONST: case MPE_ROW_R_ZERO: case MPE_ROW_R_ADD: case MPE_ROW_R_ADD_ACC: break;
         default: return fail(MPE_EINVAL, "%s: op %d: code %d is not a reward op", what, pc, code);
       }
@@ -558,34 +597,21 @@ int mpe_rows_validate(const MpeScenarioDesc *d, const MpeRowProgram *p, const in
   return 0;
 }
 
-static int rows_call(const char *what, bool phys, const MpeScenarioDesc *d, const MpeBuffers *b, const MpeRowProgram *p, int64_t B,
+static int rows_call(const char *what, bool phys, const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B,
                      const mpe::RowEpisode *episode, void *stream) {
-  mpe::RowHeader h;
-  if (int rc = rows_header(what, d, p, &h)) return rc;
+  static_assert(sizeof(mpe::RowTables) <= MPE_ROWS_HEADER_BYTES, "MPE_ROWS_HEADER_BYTES too small");
+  mpe::RowDims h;
+  mpe::RowTables tabs;
+  if (int rc = rows_header(what, d, p, &h, &tabs)) return rc;
+  if (!p->header_device) return fail(MPE_EINVAL, "%s: prog->header_device is NULL (MPE_ROWS_HEADER_BYTES of device memory)", what);
   if (int rc = check_state(b, B, what)) return rc;
   if (int rc = need(b->obs, what, "obs")) return rc;
   if (d->n_choices > 0) if (int rc = need(b->choice, what, "choice (the per-world picks of reset_world)")) return rc;
   // (bufs->comm may be NULL: every utterance then reads as zero -- the state of agents that never speak)
-  mpe::RowPhys ph;
-  std::memset(&ph, 0, sizeof(ph));
   if (phys) {
     if (int rc = check_actions(b, what)) return rc;
-    const int A = d->n_agents, E = A + d->n_landmarks;
-    for (int e = A; e < E; ++e)
+    for (int e = d->n_agents; e < d->n_agents + d->n_landmarks; ++e)
       if (d->movable[e]) return fail(MPE_EUNSUPPORTED, "%s: a movable landmark (entity %d) is stepped by mpe_world_step only", what, e);
-    ph.enabled = 1;
-    for (int e = 0; e < E; ++e) {
-      ph.inv_mass[e] = d->mass[e] > 0.f ? 1.0f / d->mass[e] : 1.0f;
-      ph.accel[e] = d->accel[e];
-      ph.max_speed[e] = d->max_speed[e];
-      if (d->movable[e]) ph.movable |= 1ull << e;
-      if (d->collide[e]) ph.collide |= 1ull << e;
-    }
-    ph.dt = d->dt;
-    ph.damp = 1.0f - d->damping;
-    ph.cforce = d->contact_force;
-    ph.cmargin = d->contact_margin;
-    ph.cmargin_inv = 1.0f / d->contact_margin;
   }
   mpe::RowEpisode ep;
   std::memset(&ep, 0, sizeof(ep));
@@ -594,19 +620,28 @@ static int rows_call(const char *what, bool phys, const MpeScenarioDesc *d, cons
   bool vec4 = reinterpret_cast<uintptr_t>(b->obs) % 16 == 0;
   for (int i = 0; i <= d->n_agents; ++i)
     if (((size_t)d->obs_off[i] * (size_t)B) % 4 != 0) vec4 = false;
-  h.vec4 = vec4 ? 1 : 0;
-  return hip_result(mpe::launch_rows(*b, h, ph, ep, p->ops_device, (size_t)B, static_cast<hipStream_t>(stream)), what);
+  // the tables in device memory: uploaded when their content differs from what the program holds (FNV-1a over the bytes)
+  uint64_t hash = 1469598103934665603ull;
+  const unsigned char *bytes = reinterpret_cast<const unsigned char *>(&tabs);
+  for (size_t k = 0; k < sizeof(tabs); ++k) hash = (hash ^ bytes[k]) * 1099511628211ull;
+  hash |= 1ull;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hash != p->header_hash) {
+    if (int rc = mpe::launch_rows_header(tabs, p->header_device, s)) return hip_result(rc, what);
+    p->header_hash = hash;
+  }
+  return hip_result(mpe::launch_rows(*b, h, tabs, p->header_device, phys, vec4 ? 1 : 0, ep, p->ops_device, (size_t)B, s), what);
 }
 
-int mpe_rows(const MpeScenarioDesc *d, const MpeBuffers *b, const MpeRowProgram *p, int64_t B, void *stream) {
+int mpe_rows(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B, void *stream) {
   return rows_call("mpe_rows", false, d, b, p, B, nullptr, stream);
 }
 
-int mpe_step_rows(const MpeScenarioDesc *d, const MpeBuffers *b, const MpeRowProgram *p, int64_t B, void *stream) {
+int mpe_step_rows(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B, void *stream) {
   return rows_call("mpe_step_rows", true, d, b, p, B, nullptr, stream);
 }
 
-int mpe_episode_finish(const MpeScenarioDesc *d, const MpeBuffers *b, const MpeRowProgram *p, int64_t B, int32_t *episode_step,
+int mpe_episode_finish(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B, int32_t *episode_step,
                        int32_t max_episode_steps, float landmark_range, uint64_t seed, uint64_t episode, int64_t world_offset,
                        void *stream) {
   const char *what = "mpe_episode_finish";

@@ -66,29 +66,34 @@ enum {
   ROW_OBS_VEL = MPE_ROW_OBS_VEL, ROW_OBS_POS = MPE_ROW_OBS_POS, ROW_OBS_REL = MPE_ROW_OBS_REL, ROW_OBS_REL_PICK = MPE_ROW_OBS_REL_PICK,
   ROW_OBS_COMM = MPE_ROW_OBS_COMM, ROW_OBS_CONST = MPE_ROW_OBS_CONST, ROW_OBS_ONEHOT = MPE_ROW_OBS_ONEHOT,
   ROW_OBS_REL_VIS = MPE_ROW_OBS_REL_VIS, ROW_OBS_VEL_VIS = MPE_ROW_OBS_VEL_VIS, ROW_OBS_IN_REGION = MPE_ROW_OBS_IN_REGION,
+  ROW_OBS_REL_RANGE = MPE_ROW_OBS_REL_RANGE, ROW_OBS_VEL_RANGE = MPE_ROW_OBS_VEL_RANGE, ROW_OBS_REL_VIS_RANGE = MPE_ROW_OBS_REL_VIS_RANGE,
+  ROW_OBS_VEL_VIS_RANGE = MPE_ROW_OBS_VEL_VIS_RANGE, ROW_OBS_CONST_N = MPE_ROW_OBS_CONST_N,
+  ROW_R_MIN_D2_RANGE = MPE_ROW_R_MIN_D2_RANGE, ROW_R_MIN_D2_TO_RANGE = MPE_ROW_R_MIN_D2_TO_RANGE, ROW_R_ADD_IF_HIT_GRID = MPE_ROW_R_ADD_IF_HIT_GRID, ROW_R_ADD_MIN_DIST_GRID = MPE_ROW_R_ADD_MIN_DIST_GRID,
   ROW_R_D2 = MPE_ROW_R_D2, ROW_R_MIN_D2 = MPE_ROW_R_MIN_D2, ROW_R_D2_PICK = MPE_ROW_R_D2_PICK, ROW_R_MIN_D2_PICK = MPE_ROW_R_MIN_D2_PICK,
   ROW_R_SQRT = MPE_ROW_R_SQRT, ROW_R_BOUND = MPE_ROW_R_BOUND, ROW_R_COMM_ERR = MPE_ROW_R_COMM_ERR, ROW_R_COMM_SUM = MPE_ROW_R_COMM_SUM,
   ROW_R_CONST = MPE_ROW_R_CONST, ROW_R_SAVE = MPE_ROW_R_SAVE, ROW_R_LOAD = MPE_ROW_R_LOAD, ROW_R_ZERO = MPE_ROW_R_ZERO,
   ROW_R_ADD = MPE_ROW_R_ADD, ROW_R_ADD_IF_HIT = MPE_ROW_R_ADD_IF_HIT, ROW_R_ADD_ACC = MPE_ROW_R_ADD_ACC, ROW_R_STORE = MPE_ROW_R_STORE
 };
-struct RowHeader {
+// Scalars of a program: kernel arguments (one batch of scalar loads at wave start).
+struct RowDims {
   int32_t n_agents, n_entities, n_vel, dim_c, collaborative;
   int32_t d_max;                 // widest observation row (floats): the waves' tile size
-  int32_t vec4;                  // rows may leave as 16-byte stores (alignment checked on the host)
   int32_t n_picks;               // rows of MpeBuffers.choice (desc->n_choices)
-  int32_t obs_begin[MPE_ROWS_MAX_ENTITIES + 1];
-  int32_t obs_off[MPE_ROWS_MAX_ENTITIES + 1];
-  float size[MPE_ROWS_MAX_ENTITIES];
-  int32_t rew_begin[MPE_ROWS_MAX_ENTITIES + 1];   // agent i's reward ops: [rew_begin[i], rew_begin[i + 1])
+  int32_t n_ops;                 // 16-byte ops (staged in LDS)
   int32_t n_regions, region_entity[2];
   uint32_t all_seeing;
-};
-// World.step inside the same launch (mpe_step_rows): per-entity physics constants and the world's
-struct RowPhys {
-  int32_t enabled;
-  float inv_mass[MPE_ROWS_MAX_ENTITIES], accel[MPE_ROWS_MAX_ENTITIES], max_speed[MPE_ROWS_MAX_ENTITIES];
   uint64_t movable, collide;     // bit e
   float dt, damp, cforce, cmargin, cmargin_inv;
+};
+// Tables of a program: DEVICE memory (uploaded by launch_rows_header whenever their content changes), copied to LDS by
+// every workgroup next to the ops: a table entry or an op is then one LDS broadcast read away, not a scalar memory load
+// (PMC of the first version: 33 scalar loads per wave, 70 % of a wave's life spent waiting, mostly on them).
+struct RowTables {
+  float size[MPE_ROWS_MAX_ENTITIES], inv_mass[MPE_ROWS_MAX_ENTITIES], accel[MPE_ROWS_MAX_ENTITIES], max_speed[MPE_ROWS_MAX_ENTITIES];
+  int32_t obs_off[MPE_ROWS_MAX_ENTITIES + 1];     // prefix sums of the row widths
+  int32_t obs_begin[MPE_ROWS_MAX_ENTITIES + 1];   // agent i's observation ops: [obs_begin[i], obs_begin[i + 1])
+  int32_t rew_begin[MPE_ROWS_MAX_ENTITIES + 1];   // agent i's reward ops
+  int32_t pad_;
 };
 // episode bookkeeping + masked reset in front of the rows (mpe_episode_finish)
 struct RowEpisode {
@@ -99,7 +104,8 @@ struct RowEpisode {
   int32_t n_choices, choice_pop[MPE_MAX_CHOICES];
   uint64_t seed, episode, world_offset;
 };
-int launch_rows(const MpeBuffers &b, const RowHeader &h, const RowPhys &ph, const RowEpisode &ep, const int32_t *ops_device, size_t B,
-                hipStream_t stream);
+int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream);
+int launch_rows(const MpeBuffers &b, const RowDims &dims, const RowTables &host, const void *tables_device, bool phys, int vec4,
+                const RowEpisode &ep, const int32_t *ops_device, size_t B, hipStream_t stream);
 
 }  // namespace mpe

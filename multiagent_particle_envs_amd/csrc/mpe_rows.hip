@@ -18,11 +18,26 @@
 //   wave w       agents w, w + W, ...: [World.step of the agent (mpe_step_rows)], its observation program -- each op appends
 //                its columns to the wave's LDS tile ([64][D] row-major = the output segment), the tile leaves as contiguous
 //                16-byte stores -- and its reward program (two accumulators, one value register, eight slots); behind one
-//                barrier the shared-reward sum (environment.py:100-102) in the reference's order.  The next op is fetched
-//                (one scalar 16-byte load) while the current one executes: an op costs its own LDS round trip, not two.
+//                barrier the shared-reward sum (environment.py:100-102) in the reference's order.
+// The program (ops) and its tables (sizes, masses, row offsets, program ranges) are copied from device memory into LDS by
+// every workgroup, in the same round trip as the state: an op or a table entry is then a broadcast LDS read, not a scalar
+// memory load (first version: 33 scalar loads per wave, each a dependent ~200-cycle round trip: 70 % of a wave's life).
 // Arithmetic is the device functions of mpe_device.h (sq2d, sqrt_lt, fast_sqrt, tag_bound) in program order: a built-in
 // scenario written as a program reproduces its fused kernel bit for bit (tests/test_gpu_rowspec.py).
 #include "mpe_internal.h"
+
+// instrumented build (-DMPE_ROWS_CLOCK, tools/rows_clock.py): lane 0 of every wave of the first 8 workgroups stamps the
+// shader clock at the phase boundaries into MpeBuffers.force: [workgroup < 8][wave < 16][8] uint64.  Not in the product build.
+#ifdef MPE_ROWS_CLOCK
+#define MPE_RSTAMP(k)                                                                                           \
+  do {                                                                                                          \
+    if (b.force && blockIdx.x < 8 && (threadIdx.x & 63) == 0)                                                   \
+      reinterpret_cast<unsigned long long *>(b.force)[(((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8) + (k)] = \
+          __builtin_amdgcn_s_memtime();                                                                         \
+  } while (0)
+#else
+#define MPE_RSTAMP(k) do { } while (0)
+#endif
 
 namespace mpe {
 
@@ -47,21 +62,48 @@ __device__ __forceinline__ void flush_tile(const float *tile, float *__restrict_
   __builtin_amdgcn_wave_barrier();
 }
 
+// The tables live in DEVICE memory (uploaded by this 64-thread kernel whenever their content changes: they arrive as its
+// kernel argument, captured at launch time) -- as kernel arguments of k_rows their ~30 cache lines would each be a scalar
+// load from the host-coherent kernarg segment.
+__global__ void __launch_bounds__(64) k_rows_header(const RowTables t, RowTables *__restrict__ dst) {
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(&t);
+  uint32_t *out = reinterpret_cast<uint32_t *>(dst);
+  for (unsigned k = threadIdx.x; k < sizeof(RowTables) / 4; k += 64) out[k] = src[k];
+}
+
+#define MPE_TAB(field) ((int)(offsetof(RowTables, field) / 4))
+
 template <bool NT, bool PHYS>
-__global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowHeader h, const RowPhys ph, const RowEpisode ep,
-                                                 const int4 *__restrict__ const ops, const size_t B) {
+__global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpisode ep, const RowDims h,
+                                                 const uint32_t *__restrict__ const tables, const int32_t vec4, const int32_t split,
+                                                 const uint32_t *__restrict__ const ops_g, const size_t B) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = uni((int)(threadIdx.x >> 6));
-  const int NW = uni((int)(blockDim.x >> 6));          // waves of the workgroup: wave w takes agents w, w + NW, ...
+  const int NW = uni((int)(blockDim.x >> 6));          // waves of the workgroup
+  // roles: with `split` (two waves per agent: the launch has 2 RW waves) waves [0, RW) run World.step and the observation
+  // programs of agents w, w + RW, ..., waves [RW, 2 RW) the reward programs of the same agents at the same time; without it
+  // every wave does both.  (Measured slower at every shape tried -- spread N=3 15.3 vs 13.1 us: the launch is not bound by
+  // one wave's chain -- and switched off in launch_rows; kept as the A/B.)
+  const int RW = split ? NW / 2 : NW;
+  const bool is_rows = !split || wave < RW, is_rew = !split || wave >= RW;
   const int A = h.n_agents, E = h.n_entities, NV = h.n_vel, DC = h.dim_c;
+  const int rwave = is_rew ? (split ? wave - RW : wave) : A;      // (a rows-only wave owns no reward program: its loops are empty)
   const size_t w0 = (size_t)blockIdx.x * kWave;
   if (w0 >= B) return;
   const int nvalid = (B - w0) < (size_t)kWave ? (int)(B - w0) : kWave;
   const bool live = lane < nvalid;
   const unsigned ln = (unsigned)(live ? lane : nvalid - 1) & 63u;
 
-  float *const S_pos = smem;                              // [E][2][64]
+  MPE_RSTAMP(0);
+  // LDS: [tables | ops] (read-only after the first barrier), then the state and the per-wave scratch
+  // the per-entity tables and the ops stay in device memory and are read with scalar loads (uniform addresses): staging them
+  // in LDS per workgroup measured 7 % slower at 65 536 worlds (one more dependent load + barrier in front of every wave) and
+  // halves the waves of the largest programs
+  const int4 *const ops = reinterpret_cast<const int4 *>(ops_g);
+  auto TI = [&](int base, int k) { return (int)tables[base + k]; };
+  auto TF = [&](int base, int k) { return __builtin_bit_cast(float, tables[base + k]); };
+  float *const S_pos = reinterpret_cast<float *>(smem);   // [E][2][64]
   float *const S_vel = S_pos + 2 * E * kWave;             // [NV][2][64]
   float *const S_rew = S_vel + 2 * NV * kWave;            // [A][64]    rewards before the shared sum
   float *const S_slot = S_rew + A * kWave;                // [NW][8][64] the reward programs' value slots, per wave
@@ -90,25 +132,48 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowHead
   }
   const uint64_t gw = ep.world_offset + w0 + ln;
 
+  // ---- (World.step) this wave's first agent's move leaves for HBM together with the state loads: one memory round trip, not two
+  float act_x = 0.f, act_y = 0.f;
+  if constexpr (PHYS) {
+    if (is_rows && wave < A && ((h.movable >> wave) & 1ull)) fetch_action_wave(b, B, wave, w0, ln, 1.0f, act_x, act_y);   // raw: scaled by accel below
+  }
   // ---- stage the state (finished worlds: reset_world first -- the draws of mpe_reset for (seed, world, episode)) -----------
-  for (int e = wave; e < E; e += NW) {
-    float x = (b.pos + wave_off((size_t)(2 * e) * B + w0))[ln], y = (b.pos + wave_off((size_t)(2 * e + 1) * B + w0))[ln];
-    if (fin) {
-      reset_draw(ep.seed, gw, ep.episode, e, e < A ? 1.0f : ep.landmark_range, x, y);
-      (b.pos + wave_off((size_t)(2 * e) * B + w0))[ln] = x;
-      (b.pos + wave_off((size_t)(2 * e + 1) * B + w0))[ln] = y;
-    }
-    S_pos[(2 * e) * kWave + lane] = x;
-    S_pos[(2 * e + 1) * kWave + lane] = y;
-    if (e < NV) {
-      float vx = (b.vel + wave_off((size_t)(2 * e) * B + w0))[ln], vy = (b.vel + wave_off((size_t)(2 * e + 1) * B + w0))[ln];
-      if (fin && e < A) {
-        vx = vy = 0.f;
-        (b.vel + wave_off((size_t)(2 * e) * B + w0))[ln] = 0.f;
-        (b.vel + wave_off((size_t)(2 * e + 1) * B + w0))[ln] = 0.f;
+  // two entities per turn: their eight loads are in flight together before the first LDS write waits for any of them
+  for (int e0 = wave; e0 < E; e0 += 2 * NW) {
+    const int e1 = e0 + NW;
+    const bool two = e1 < E;
+    float x[2], y[2], vx[2] = {0.f, 0.f}, vy[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = k ? e1 : e0;
+      if (k && !two) break;      // uniform
+      x[k] = (b.pos + wave_off((size_t)(2 * e) * B + w0))[ln];
+      y[k] = (b.pos + wave_off((size_t)(2 * e + 1) * B + w0))[ln];
+      if (e < NV) {
+        vx[k] = (b.vel + wave_off((size_t)(2 * e) * B + w0))[ln];
+        vy[k] = (b.vel + wave_off((size_t)(2 * e + 1) * B + w0))[ln];
       }
-      S_vel[(2 * e) * kWave + lane] = vx;
-      S_vel[(2 * e + 1) * kWave + lane] = vy;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = k ? e1 : e0;
+      if (k && !two) break;
+      if (fin) {
+        reset_draw(ep.seed, gw, ep.episode, e, e < A ? 1.0f : ep.landmark_range, x[k], y[k]);
+        (b.pos + wave_off((size_t)(2 * e) * B + w0))[ln] = x[k];
+        (b.pos + wave_off((size_t)(2 * e + 1) * B + w0))[ln] = y[k];
+        if (e < NV && e < A) {
+          vx[k] = vy[k] = 0.f;
+          (b.vel + wave_off((size_t)(2 * e) * B + w0))[ln] = 0.f;
+          (b.vel + wave_off((size_t)(2 * e + 1) * B + w0))[ln] = 0.f;
+        }
+      }
+      S_pos[(2 * e) * kWave + lane] = x[k];
+      S_pos[(2 * e + 1) * kWave + lane] = y[k];
+      if (e < NV) {
+        S_vel[(2 * e) * kWave + lane] = vx[k];
+        S_vel[(2 * e + 1) * kWave + lane] = vy[k];
+      }
     }
   }
   for (int k = wave; k < h.n_picks; k += NW) {
@@ -124,7 +189,9 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowHead
       if (fin)
         for (int c = 0; c < DC; ++c) (const_cast<float *>(b.comm) + wave_off(((size_t)a * B + w0) * DC))[ln * DC + c] = 0.f;
   }
+  MPE_RSTAMP(1);      // state loads issued and parked in LDS
   __syncthreads();
+  MPE_RSTAMP(2);
 
   auto P = [&](int e, int c) { return S_pos[(2 * e + c) * kWave + lane]; };
   auto V = [&](int e, int c) { return e < NV ? S_vel[(2 * e + c) * kWave + lane] : 0.f; };
@@ -133,7 +200,7 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowHead
   // inside region r (a landmark, e.g. a forest of simple_world_comm.py:231-261): strict |e - region| < size_e + size_region
   auto in_region = [&](int e, int r) {
     const int f = h.region_entity[r];
-    return sqrt_lt(sq2d(P(e, 0) - P(f, 0), P(e, 1) - P(f, 1)), h.size[e] + h.size[f]);
+    return sqrt_lt(sq2d(P(e, 0) - P(f, 0), P(e, 1) - P(f, 1)), TF(MPE_TAB(size), e) + TF(MPE_TAB(size), f));
   };
 
   if constexpr (PHYS) {
@@ -142,22 +209,28 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowHead
     // that leaves here is theirs to the bit.  New state -> S_new; behind the barrier it replaces the staged one and goes
     // back to HBM (no wave still reads pre-step positions then).
     {
-      for (int i = wave; i < A; i += NW) {
+      for (int i = is_rows ? wave : A; i < A; i += RW) {
         float mx = P(i, 0), my = P(i, 1), mvx = V(i, 0), mvy = V(i, 1);
-        if ((ph.movable >> i) & 1ull) {
+        if ((h.movable >> i) & 1ull) {
           float ux, uy;
-          fetch_action_wave(b, B, i, w0, ln, ph.accel[i], ux, uy);
+          if (i == wave) {         // prefetched at kernel entry; a one-hot row / an id decodes to exact -1 / 0 / +1: scale now
+            const bool raw = b.act || b.ids;
+            ux = raw ? act_x * TF(MPE_TAB(accel), i) : act_x;
+            uy = raw ? act_y * TF(MPE_TAB(accel), i) : act_y;
+          } else {
+            fetch_action_wave(b, B, i, w0, ln, TF(MPE_TAB(accel), i), ux, uy);
+          }
           float fx = ux + 0.f, fy = uy + 0.f;
-          if ((ph.collide >> i) & 1ull) {
+          if ((h.collide >> i) & 1ull) {
             for (int j = 0; j < E; ++j) {
-              if (j == i || !((ph.collide >> j) & 1ull)) continue;      // uniform
+              if (j == i || !((h.collide >> j) & 1ull)) continue;      // uniform
               float cx, cy;
-              contact_force(mx - P(j, 0), my - P(j, 1), h.size[i] + h.size[j], ph.cforce, ph.cmargin, ph.cmargin_inv, cx, cy);
+              contact_force(mx - P(j, 0), my - P(j, 1), TF(MPE_TAB(size), i) + TF(MPE_TAB(size), j), h.cforce, h.cmargin, h.cmargin_inv, cx, cy);
               fx = cx + fx;
               fy = cy + fy;
             }
           }
-          integrate_one(mx, my, mvx, mvy, fx, fy, ph.inv_mass[i], ph.max_speed[i], ph.damp, ph.dt);
+          integrate_one(mx, my, mvx, mvy, fx, fy, TF(MPE_TAB(inv_mass), i), TF(MPE_TAB(max_speed), i), h.damp, h.dt);
         }
         S_new[(4 * i + 0) * kWave + lane] = mx;
         S_new[(4 * i + 1) * kWave + lane] = my;
@@ -165,6 +238,7 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowHead
         S_new[(4 * i + 3) * kWave + lane] = mvy;
       }
     }
+    MPE_RSTAMP(3);    // World.step of this wave's agents computed
     __syncthreads();
     for (int i = wave; i < A; i += NW) {
       const float mx = S_new[(4 * i + 0) * kWave + lane], my = S_new[(4 * i + 1) * kWave + lane];
@@ -173,7 +247,7 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowHead
       S_pos[(2 * i + 1) * kWave + lane] = my;
       S_vel[(2 * i) * kWave + lane] = mvx;
       S_vel[(2 * i + 1) * kWave + lane] = mvy;
-      if (live && ((ph.movable >> i) & 1ull)) {
+      if (live && ((h.movable >> i) & 1ull)) {
         (b.pos + wave_off((size_t)(2 * i) * B + w0))[ln] = mx;
         (b.pos + wave_off((size_t)(2 * i + 1) * B + w0))[ln] = my;
         (b.vel + wave_off((size_t)(2 * i) * B + w0))[ln] = mvx;
@@ -182,12 +256,13 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowHead
     }
     __syncthreads();
   }
+  MPE_RSTAMP(4);      // the post-step state is in LDS
 
   // ---- observation programs of this wave's agents ------------------------------------------------------------------------
   {
     float *const tile = tiles + (size_t)wave * kWave * h.d_max;
-    for (int i = wave; i < A; i += NW) {
-      const int D = h.obs_off[i + 1] - h.obs_off[i];
+    for (int i = is_rows ? wave : A; i < A; i += RW) {
+      const int D = TI(MPE_TAB(obs_off), i + 1) - TI(MPE_TAB(obs_off), i);
       if (D == 0) continue;
       const float mx = P(i, 0), my = P(i, 1);
       // who is inside which region: bit (e * 2 + r), for the visibility rule (same region, or both in the open; agents in
@@ -203,7 +278,7 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowHead
       };
       float *const row = tile + lane * D;
       int col = 0;
-      const int pc0 = h.obs_begin[i], pc1 = h.obs_begin[i + 1];
+      const int pc0 = TI(MPE_TAB(obs_begin), i), pc1 = TI(MPE_TAB(obs_begin), i + 1);
       int4 nxt = pc0 < pc1 ? ops[pc0] : make_int4(0, 0, 0, 0);
       for (int pc = pc0; pc < pc1; ++pc) {
         const int4 op = nxt;
@@ -242,20 +317,40 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowHead
             break;
           }
           case ROW_OBS_IN_REGION: row[col] = ((inmask >> (2 * e + a1)) & 1ull) ? 1.f : -1.f; col += 1; break;
+          // ---- range forms: one decode, the entities of a run in an inner loop (two of them in flight per LDS round trip) ----
+          case ROW_OBS_REL_RANGE: case ROW_OBS_VEL_RANGE: case ROW_OBS_REL_VIS_RANGE: case ROW_OBS_VEL_VIS_RANGE: {
+            const int skip = (uni(op.x >> 24) & 1) ? i : -1;
+            const bool rel = code == ROW_OBS_REL_RANGE || code == ROW_OBS_REL_VIS_RANGE;
+            const bool vis = code == ROW_OBS_REL_VIS_RANGE || code == ROW_OBS_VEL_VIS_RANGE;
+            for (int q = a0; q < a0 + a1; ++q) {
+              if (q == skip) continue;      // uniform
+              float x = rel ? P(q, 0) - mx : V(q, 0), y = rel ? P(q, 1) - my : V(q, 1);
+              if (vis) { const bool s_ = visible(q); x = s_ ? x : 0.f; y = s_ ? y : 0.f; }
+              row[col] = x; row[col + 1] = y; col += 2;
+            }
+            break;
+          }
+          case ROW_OBS_CONST_N: {
+            const float cv = unif(__builtin_bit_cast(float, op.z));
+            for (int c = 0; c < a1; ++c) row[col + c] = cv;
+            col += a1;
+            break;
+          }
           default: break;
         }
       }
-      flush_tile<NT>(tile, b.obs + B * (size_t)h.obs_off[i] + w0 * (size_t)D, D, nvalid, lane, h.vec4 != 0);
+      flush_tile<NT>(tile, b.obs + B * (size_t)TI(MPE_TAB(obs_off), i) + w0 * (size_t)D, D, nvalid, lane, vec4 != 0);
     }
   }
+  MPE_RSTAMP(5);      // observation rows stored
   if (ep.enabled) return;      // (mpe_episode_finish: rewards and dones belong to the step that just ran)
 
   // ---- reward programs of this wave's agents -----------------------------------------------------------------------------
   if (b.rew) {
     float *const slot = S_slot + (size_t)wave * kRowSlots * kWave;      // this wave's eight value slots
-    for (int i = wave; i < A; i += NW) {
+    for (int i = rwave; i < A; i += RW) {
       float acc[2] = {0.f, 0.f}, v = 0.f;
-      const int pc0 = h.rew_begin[i], pc1 = h.rew_begin[i + 1];
+      const int pc0 = TI(MPE_TAB(rew_begin), i), pc1 = TI(MPE_TAB(rew_begin), i + 1);
       int4 nxt = pc0 < pc1 ? ops[pc0] : make_int4(0, 0, 0, 0);
       for (int pc = pc0; pc < pc1; ++pc) {
         const int4 op = nxt;
@@ -301,17 +396,59 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowHead
             break;
           }
           case ROW_R_ADD_IF_HIT: {      // strict contact test, the reference's `if self.is_collision(a, b): rew += coef`
-            const bool hit = sqrt_lt(sq2d(P(a0, 0) - P(a1, 0), P(a0, 1) - P(a1, 1)), h.size[a0] + h.size[a1]);
+            const bool hit = sqrt_lt(sq2d(P(a0, 0) - P(a1, 0), P(a0, 1) - P(a1, 1)), TF(MPE_TAB(size), a0) + TF(MPE_TAB(size), a1));
             const float t = hit ? f : 0.f;
             if (a2 & 1) acc[1] = acc[1] + t; else acc[0] = acc[0] + t;
             break;
           }
           case ROW_R_ADD_ACC: acc[0] = acc[0] + acc[1]; break;
           case ROW_R_STORE: S_rew[a0 * kWave + lane] = acc[0]; break;
+          // ---- range forms ---------------------------------------------------------------------------------------------------
+          case ROW_R_MIN_D2_RANGE: {      // min over agents a0 .. a0 + n - 1 of |a - p[a1]|^2, first to last
+            const int n = uni(op.y);
+            const float bx = P(a1, 0), by = P(a1, 1);
+            v = sq2d(P(a0, 0) - bx, P(a0, 1) - by);
+            for (int q = a0 + 1; q < a0 + n; ++q) v = fminf(v, sq2d(P(q, 0) - bx, P(q, 1) - by));
+            break;
+          }
+          case ROW_R_MIN_D2_TO_RANGE: {   // min over targets a1 .. a1 + n - 1 of |p[a0] - target|^2
+            const int n = uni(op.y);
+            const float ax = P(a0, 0), ay = P(a0, 1);
+            v = sq2d(ax - P(a1, 0), ay - P(a1, 1));
+            for (int q = a1 + 1; q < a1 + n; ++q) v = fminf(v, sq2d(ax - P(q, 0), ay - P(q, 1)));
+            break;
+          }
+          case ROW_R_ADD_IF_HIT_GRID: {   // every pair of two entity runs: the same constant per contact, any order gives the same float
+            const int na = uni(op.y) & 255, nb = (uni(op.y) >> 8) & 255;
+            float t = acc[a2 & 1];
+            for (int qa = a0; qa < a0 + na; ++qa) {
+              const float ax = P(qa, 0), ay = P(qa, 1), sa = TF(MPE_TAB(size), qa);
+              for (int qb = a1; qb < a1 + nb; ++qb) {
+                const bool hit = sqrt_lt(sq2d(ax - P(qb, 0), ay - P(qb, 1)), sa + TF(MPE_TAB(size), qb));
+                t = t + (hit ? f : 0.f);
+              }
+            }
+            if (a2 & 1) acc[1] = t; else acc[0] = t;
+            break;
+          }
+          case ROW_R_ADD_MIN_DIST_GRID: {  // per target b: the distance of the nearest of a run of entities, accumulated in target order
+            const int na = uni(op.y) & 255, nb = (uni(op.y) >> 8) & 255;
+            float t = acc[a2 & 1];
+            for (int qb = a1; qb < a1 + nb; ++qb) {
+              const float bx = P(qb, 0), by = P(qb, 1);
+              float m2 = sq2d(P(a0, 0) - bx, P(a0, 1) - by);
+              for (int qa = a0 + 1; qa < a0 + na; ++qa) m2 = fminf(m2, sq2d(P(qa, 0) - bx, P(qa, 1) - by));
+              v = fast_sqrt(m2);
+              t = t + f * v;
+            }
+            if (a2 & 1) acc[1] = t; else acc[0] = t;
+            break;
+          }
           default: break;
         }
       }
     }
+    MPE_RSTAMP(6);    // reward programs done
     if (h.collaborative) __syncthreads();      // (uniform: a kernel argument)
     // environment.py:100-102: every agent gets np.sum(reward_n) = r0 + (((0 + r1) + r2) + ...) for n < 9
     float total = 0.f;
@@ -321,36 +458,44 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowHead
       total = A > 1 ? S_rew[lane] + rest : S_rew[lane];
     }
     if (live)
-      for (int i = wave; i < A; i += NW) (b.rew + wave_off((size_t)i * B + w0))[ln] = h.collaborative ? total : S_rew[i * kWave + lane];
+      for (int i = rwave; i < A; i += RW) (b.rew + wave_off((size_t)i * B + w0))[ln] = h.collaborative ? total : S_rew[i * kWave + lane];
   }
   if (b.done && live)
-    for (int i = wave; i < A; i += NW) (b.done + wave_off((size_t)i * B + w0))[ln] = 0;
+    for (int i = rwave; i < A; i += RW) (b.done + wave_off((size_t)i * B + w0))[ln] = 0;
 }
 
 }  // namespace
 
-int launch_rows(const MpeBuffers &b, const RowHeader &h, const RowPhys &ph, const RowEpisode &ep, const int32_t *ops_device, size_t B,
-                hipStream_t stream) {
-  // LDS: the staged state + reward scratch, and one [64][d_max] tile per observation wave -- as many waves as fit (each
-  // wave takes its share of the agents in turn), at most one per agent and 15 (+ the reward wave = 1024 threads)
+int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream) {
+  hipLaunchKernelGGL(k_rows_header, dim3(1), dim3(64), 0, stream, t, reinterpret_cast<RowTables *>(dst));
+  return (int)hipGetLastError();
+}
+
+int launch_rows(const MpeBuffers &b, const RowDims &h, const RowTables &host, const void *tables_device, bool phys, int vec4,
+                const RowEpisode &ep, const int32_t *ops_device, size_t B, hipStream_t stream) {
+  // LDS: the staged state + reward scratch, and one [64][d_max] tile + eight slots per wave -- as many waves as
+  // fit (each wave takes its share of the agents in turn), at most one per agent and 16
   constexpr size_t kLdsCap = 160 * 1024;
-  const size_t fixed = sizeof(float) * (size_t)(2 * h.n_entities + 2 * h.n_vel + h.n_agents + kRowPicks +
-                                                (ph.enabled ? 4 * h.n_agents : 0)) * kWave;
-  const size_t tile = sizeof(float) * (size_t)kWave * ((size_t)h.d_max + kRowSlots);      // a wave's row tile + its eight slots
-  if (fixed + tile > kLdsCap) return MPE_EUNSUPPORTED;
+  const size_t fixed = sizeof(float) * (size_t)(2 * h.n_entities + 2 * h.n_vel + h.n_agents + kRowPicks + (phys ? 4 * h.n_agents : 0)) * kWave;
+  const size_t slots = sizeof(float) * (size_t)kWave * kRowSlots;
+  const size_t tile_only = sizeof(float) * (size_t)kWave * (size_t)h.d_max;
+  if (fixed + tile_only + slots > kLdsCap) return MPE_EUNSUPPORTED;
   int W = h.n_agents < kRowMaxObsWaves ? h.n_agents : kRowMaxObsWaves;
-  while (W > 1 && fixed + (size_t)W * tile > (W > 4 ? 64u * 1024u : kLdsCap)) --W;   // (past 4 waves, stay within 64 KB: two workgroups per CU)
-  const size_t lds = fixed + (size_t)W * tile;
+  const bool split = false;      // two waves per agent (rows || reward): measured slower (see k_rows), kept for the A/B only
+  auto need = [&](int w, bool sp) { return fixed + (size_t)w * tile_only + (size_t)(sp ? 2 * w : w) * slots; };
+  while (W > 1 && need(W, split) > (W > 4 ? 64u * 1024u : kLdsCap)) --W;   // (past 4 waves, stay within 64 KB: two workgroups per CU)
+  const size_t lds = need(W, split);
+  const int NWL = split ? 2 * W : W;
   const unsigned grid = (unsigned)((B + kWave - 1) / kWave);
-  const size_t row_bytes = (size_t)h.obs_off[h.n_agents] * sizeof(float) * B;
-  const int4 *ops = reinterpret_cast<const int4 *>(ops_device);
-  const bool nt = row_bytes >= (8u << 20) && h.vec4 && !ep.enabled;
-  auto fn = ph.enabled ? (nt ? k_rows<true, true> : k_rows<false, true>) : (nt ? k_rows<true, false> : k_rows<false, false>);
+  const size_t row_bytes = (size_t)host.obs_off[h.n_agents] * sizeof(float) * B;
+  const bool nt = row_bytes >= (8u << 20) && vec4 && !ep.enabled;
+  auto fn = phys ? (nt ? k_rows<true, true> : k_rows<false, true>) : (nt ? k_rows<true, false> : k_rows<false, false>);
   if (lds > 64 * 1024) {
     const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return (int)rc;
   }
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(W * kWave), lds, stream, b, h, ph, ep, ops, B);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(NWL * kWave), lds, stream, b, ep, h, reinterpret_cast<const uint32_t *>(tables_device),
+                     (int32_t)vec4, (int32_t)(split ? 1 : 0), reinterpret_cast<const uint32_t *>(ops_device), B);
   return (int)hipGetLastError();
 }
 

@@ -42,6 +42,7 @@ import torch
 from . import _abi
 
 SELF = _abi.MPE_ROW_SELF
+FUSE = True      # RowProgram's default: fuse runs of per-entity ops into range forms (tests switch it off for the A/B)
 
 
 def _f2i(x):
@@ -240,33 +241,166 @@ class Regions(object):
         self.all_seeing = list(all_seeing)
 
 
+# ---- peephole pass: runs of per-entity ops -> range forms (one decode, an inner loop in the kernel) ------------------------------
+def _fields(op):
+    w0 = op[0] & 0xFFFFFFFF
+    return w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255, (w0 >> 24) & 255
+
+
+_RANGE_OF = {_abi.MPE_ROW_OBS_REL: _abi.MPE_ROW_OBS_REL_RANGE, _abi.MPE_ROW_OBS_VEL: _abi.MPE_ROW_OBS_VEL_RANGE,
+             _abi.MPE_ROW_OBS_REL_VIS: _abi.MPE_ROW_OBS_REL_VIS_RANGE, _abi.MPE_ROW_OBS_VEL_VIS: _abi.MPE_ROW_OBS_VEL_VIS_RANGE}
+
+
+def fuse_obs(ops, me):
+    """Consecutive rel / vel (/ visible) ops over consecutive entities -> one range op (a gap exactly at the observing agent is
+    the range's skip-self flag); equal constants in a row -> CONST_N.  Same columns, same values, fewer decodes."""
+    out, k = [], 0
+    while k < len(ops):
+        code, a0, a1, a2 = _fields(ops[k])
+        if code in _RANGE_OF and a0 != SELF:
+            ents, j = [a0], k + 1
+            while j < len(ops):
+                c2, b0, _, _ = _fields(ops[j])
+                nxt = ents[-1] + 1
+                if c2 == code and b0 != SELF and (b0 == nxt or (nxt == me and b0 == nxt + 1)):
+                    ents.append(b0)
+                    j += 1
+                else:
+                    break
+            if len(ents) >= 2:
+                first, count = ents[0], ents[-1] - ents[0] + 1
+                skip = 1 if count != len(ents) else 0          # the only possible gap is the observer
+                out.append(_op(_RANGE_OF[code], first, count, skip))
+                k = j
+                continue
+        if code == _abi.MPE_ROW_OBS_CONST:
+            j = k + 1
+            while j < len(ops) and _fields(ops[j])[0] == code and ops[j][2] == ops[k][2] and j - k < 255:
+                j += 1
+            if j - k >= 2:
+                out.append((_op(_abi.MPE_ROW_OBS_CONST_N, 0, j - k)[0], 0, ops[k][2], 0))
+                k = j
+                continue
+        out.append(ops[k])
+        k += 1
+    return out
+
+
+def fuse_reward(ops):
+    """D2 + MIN_D2 chains over consecutive entities -> MIN_D2_RANGE / MIN_D2_TO_RANGE (same order); runs of ADD_IF_HIT with one
+    coefficient into one accumulator -> contact grids (every contact adds the same constant, a miss adds nothing: the sum does
+    not depend on the order of the tests)."""
+    out, k = [], 0
+    while k < len(ops):
+        code, a0, a1, a2 = _fields(ops[k])
+        if code == _abi.MPE_ROW_R_D2:
+            j, same_b, same_a = k + 1, True, True
+            chain = [(a0, a1)]
+            while j < len(ops) and _fields(ops[j])[0] == _abi.MPE_ROW_R_MIN_D2:
+                chain.append(_fields(ops[j])[1:3])
+                j += 1
+            if len(chain) >= 2:
+                if all(b == a1 for _, b in chain) and [a for a, _ in chain] == list(range(a0, a0 + len(chain))):
+                    out.append(_op(_abi.MPE_ROW_R_MIN_D2_RANGE, a0, a1, 0, w1=len(chain)))
+                    k = j
+                    continue
+                if all(a == a0 for a, _ in chain) and [b for _, b in chain] == list(range(a1, a1 + len(chain))):
+                    out.append(_op(_abi.MPE_ROW_R_MIN_D2_TO_RANGE, a0, a1, 0, w1=len(chain)))
+                    k = j
+                    continue
+        if code == _abi.MPE_ROW_R_ADD_IF_HIT:
+            j = k + 1
+            while j < len(ops) and _fields(ops[j])[0] == code and _fields(ops[j])[3] == a2 and ops[j][2] == ops[k][2]:
+                j += 1
+            pairs = sorted(set(_fields(o)[1:3] for o in ops[k:j]))
+            if len(pairs) == j - k and len(pairs) >= 2:        # no pair twice (a repeated test would add twice: keep those as they are)
+                by_b = {}
+                for a, b in pairs:
+                    by_b.setdefault(b, []).append(a)
+                As = sorted(set(a for a, _ in pairs))
+                Bs = sorted(by_b)
+                full = all(by_b[b] == As for b in Bs) and As == list(range(As[0], As[0] + len(As))) and Bs == list(range(Bs[0], Bs[0] + len(Bs)))
+                grids = []
+                if full:
+                    grids.append((As[0], len(As), Bs[0], len(Bs)))
+                else:                                            # per partner b: maximal runs of consecutive a
+                    for b in Bs:
+                        run = [by_b[b][0]]
+                        for a in by_b[b][1:] + [None]:
+                            if a is not None and a == run[-1] + 1:
+                                run.append(a)
+                            else:
+                                grids.append((run[0], len(run), b, 1))
+                                run = [a]
+                for fa, na, fb, nb in grids:
+                    if na * nb == 1:
+                        out.append((_op(_abi.MPE_ROW_R_ADD_IF_HIT, fa, fb, a2)[0], 0, ops[k][2], 0))
+                    else:
+                        out.append((_op(_abi.MPE_ROW_R_ADD_IF_HIT_GRID, fa, fb, a2)[0], na | (nb << 8), ops[k][2], 0))
+                k = j
+                continue
+        out.append(ops[k])
+        k += 1
+    # second pass: [MIN_D2_RANGE(a.., b), SQRT, ADD coef] for consecutive targets b -> one grid op (the nearest-agent term of
+    # simple_spread.py:72-77 over all landmarks)
+    ops, out, k = out, [], 0
+    while k < len(ops):
+        def triple(q):      # (q + 2 < len(ops) is the caller's)
+            c0, x0, x1, _ = _fields(ops[q])
+            if c0 != _abi.MPE_ROW_R_MIN_D2_RANGE or _fields(ops[q + 1])[0] != _abi.MPE_ROW_R_SQRT or _fields(ops[q + 2])[0] != _abi.MPE_ROW_R_ADD:
+                return None
+            return (x0, ops[q][1], x1, _fields(ops[q + 2])[3], ops[q + 2][2])      # first a, count, b, acc, coef bits
+        t0 = triple(k) if k + 2 < len(ops) else None
+        if t0 is not None:
+            nb, q = 1, k + 3
+            while q + 2 < len(ops):
+                t = triple(q)
+                if t is None or t[0] != t0[0] or t[1] != t0[1] or t[3] != t0[3] or t[4] != t0[4] or t[2] != t0[2] + nb:
+                    break
+                nb += 1
+                q += 3
+            if nb >= 2 or t0[1] >= 2:
+                out.append((_op(_abi.MPE_ROW_R_ADD_MIN_DIST_GRID, t0[0], t0[2], t0[3])[0], t0[1] | (nb << 8), t0[4], 0))
+                k = q
+                continue
+        out.append(ops[k])
+        k += 1
+    return out
+
+
 class RowProgram(object):
     """The compiled programs of one env: ops on the device + the MpeRowProgram header the C ABI takes."""
 
-    def __init__(self, world, obs_specs, reward_specs, regions=None):
+    def __init__(self, world, obs_specs, reward_specs, regions=None, fuse=None):
+        """fuse: run the peephole pass (runs of per-entity ops -> range forms); False keeps one op per spec call (the A/B);
+        None: the module's FUSE switch."""
+        fuse = FUSE if fuse is None else fuse
         A = len(world.agents)
         if len(world.entities) > _abi.MPE_ROWS_MAX_ENTITIES:
             raise _abi.MpeError("row programs cover at most %d entities" % _abi.MPE_ROWS_MAX_ENTITIES)
         if len(obs_specs) != A or len(reward_specs) != A:
             raise _abi.MpeError("one ObsSpec and one RewardSpec per agent")
         ops, begin = [], [0]
-        for o in obs_specs:
-            ops += o.ops
+        for i, o in enumerate(obs_specs):
+            ops += fuse_obs(o.ops, i) if fuse else o.ops
             begin.append(len(ops))
         self.widths = [o.width for o in obs_specs]
         rbegin = [len(ops)]
         for i, r in enumerate(reward_specs):         # agent i's reward program: both accumulators start at 0, STORE at the end
             ops.append(_op(_abi.MPE_ROW_R_ZERO, 0, 0, 0))
             ops.append(_op(_abi.MPE_ROW_R_ZERO, 0, 0, 1))
-            ops += r.ops
+            ops += fuse_reward(r.ops) if fuse else r.ops
             ops.append(_op(_abi.MPE_ROW_R_STORE, i))
             rbegin.append(len(ops))
         self.n_ops = len(ops)
         flat = [w for op in ops for w in op]
         self.ops_host = (C.c_int32 * max(1, len(flat)))(*flat)
         self.ops_device = torch.tensor(flat if flat else [0], dtype=torch.int32, device=world.device)
+        self.header_device = torch.zeros(_abi.MPE_ROWS_HEADER_BYTES // 4, dtype=torch.int32, device=world.device)   # the library's
         p = _abi.MpeRowProgram()
         p.ops_device = self.ops_device.data_ptr()
+        p.header_device = self.header_device.data_ptr()
+        p.header_hash = 0
         p.n_ops = self.n_ops
         for i in range(_abi.MPE_ROWS_MAX_ENTITIES + 1):
             p.obs_begin[i] = begin[min(i, A)]

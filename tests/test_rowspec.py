@@ -148,8 +148,13 @@ def test_builtins_as_specs_are_bit_identical_to_their_fused_kernels(name, B):
     the one-launch fused kernel's, to the bit (B = 1000: a ragged last workgroup and unaligned rows)."""
     fused = mpe.make_env(name, batch_size=B, seed=5)
     prog = make_spec_env(name, B, seed=5)                 # mpe_step_rows: World.step + the programs in ONE launch
-    prog2 = make_spec_env(name, B, seed=5)                # mpe_world_step + mpe_rows: two launches
+    rowspec.FUSE = False
+    try:
+        prog2 = make_spec_env(name, B, seed=5)            # mpe_world_step + mpe_rows: two launches, and one op per spec call (no range forms)
+    finally:
+        rowspec.FUSE = True
     prog2.two_launch_program = True
+    assert prog2._prog.n_ops >= prog._prog.n_ops
     assert fused.fused and fused._prog is None and prog.fused and prog._prog is not None
     rs = np.random.RandomState(B)
     of, op, op2 = fused.reset(), prog.reset(), prog2.reset()
