@@ -322,11 +322,30 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
             const int skip = (uni(op.x >> 24) & 1) ? i : -1;
             const bool rel = code == ROW_OBS_REL_RANGE || code == ROW_OBS_REL_VIS_RANGE;
             const bool vis = code == ROW_OBS_REL_VIS_RANGE || code == ROW_OBS_VEL_VIS_RANGE;
-            for (int q = a0; q < a0 + a1; ++q) {
-              if (q == skip) continue;      // uniform
-              float x = rel ? P(q, 0) - mx : V(q, 0), y = rel ? P(q, 1) - my : V(q, 1);
-              if (vis) { const bool s_ = visible(q); x = s_ ? x : 0.f; y = s_ ? y : 0.f; }
-              row[col] = x; row[col + 1] = y; col += 2;
+            const float *const src = rel ? S_pos : S_vel;
+            const int end = a0 + a1;
+            for (int q = a0; q < end; q += 4) {
+              // four entities' coordinates leave for LDS together (one round trip for the group, not one per entity); slots
+              // past the run re-read its first entity and are dropped
+              float xs[4], ys[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int qq = q + k < end ? q + k : q;
+                const bool have = rel || qq < NV;
+                const int qs = have ? qq : 0;
+                const float x = src[(2 * qs) * kWave + lane], y = src[(2 * qs + 1) * kWave + lane];
+                xs[k] = have ? x : 0.f;
+                ys[k] = have ? y : 0.f;
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int qq = q + k;
+                if (qq < end && qq != skip) {      // uniform
+                  float x = rel ? xs[k] - mx : xs[k], y = rel ? ys[k] - my : ys[k];
+                  if (vis) { const bool s_ = visible(qq); x = s_ ? x : 0.f; y = s_ ? y : 0.f; }
+                  row[col] = x; row[col + 1] = y; col += 2;
+                }
+              }
             }
             break;
           }
@@ -348,6 +367,26 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
   // ---- reward programs of this wave's agents -----------------------------------------------------------------------------
   if (b.rew) {
     float *const slot = S_slot + (size_t)wave * kRowSlots * kWave;      // this wave's eight value slots
+    // min over the run first .. first + n - 1 of |p[q] - o|^2 (flip: |o - p[q]|^2), first to last; four positions per LDS round trip
+    auto min_d2_run = [&](int first, int n, float ox, float oy, bool flip) {
+      const int end = first + n;
+      float m = 0.f;
+      for (int q = first; q < end; q += 4) {
+        float xs[4], ys[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int qq = q + k < end ? q + k : q;
+          xs[k] = P(qq, 0); ys[k] = P(qq, 1);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (q + k < end) {      // uniform
+            const float d2 = flip ? sq2d(ox - xs[k], oy - ys[k]) : sq2d(xs[k] - ox, ys[k] - oy);
+            m = (q + k == first) ? d2 : fminf(m, d2);
+          }
+      }
+      return m;
+    };
     for (int i = rwave; i < A; i += RW) {
       float acc[2] = {0.f, 0.f}, v = 0.f;
       const int pc0 = TI(MPE_TAB(rew_begin), i), pc1 = TI(MPE_TAB(rew_begin), i + 1);
@@ -404,28 +443,31 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
           case ROW_R_ADD_ACC: acc[0] = acc[0] + acc[1]; break;
           case ROW_R_STORE: S_rew[a0 * kWave + lane] = acc[0]; break;
           // ---- range forms ---------------------------------------------------------------------------------------------------
-          case ROW_R_MIN_D2_RANGE: {      // min over agents a0 .. a0 + n - 1 of |a - p[a1]|^2, first to last
-            const int n = uni(op.y);
-            const float bx = P(a1, 0), by = P(a1, 1);
-            v = sq2d(P(a0, 0) - bx, P(a0, 1) - by);
-            for (int q = a0 + 1; q < a0 + n; ++q) v = fminf(v, sq2d(P(q, 0) - bx, P(q, 1) - by));
+          case ROW_R_MIN_D2_RANGE:        // min over agents a0 .. a0 + n - 1 of |a - p[a1]|^2, first to last
+            v = min_d2_run(a0, uni(op.y), P(a1, 0), P(a1, 1), false);
             break;
-          }
-          case ROW_R_MIN_D2_TO_RANGE: {   // min over targets a1 .. a1 + n - 1 of |p[a0] - target|^2
-            const int n = uni(op.y);
-            const float ax = P(a0, 0), ay = P(a0, 1);
-            v = sq2d(ax - P(a1, 0), ay - P(a1, 1));
-            for (int q = a1 + 1; q < a1 + n; ++q) v = fminf(v, sq2d(ax - P(q, 0), ay - P(q, 1)));
+          case ROW_R_MIN_D2_TO_RANGE:     // min over targets a1 .. a1 + n - 1 of |p[a0] - target|^2
+            v = min_d2_run(a1, uni(op.y), P(a0, 0), P(a0, 1), true);
             break;
-          }
           case ROW_R_ADD_IF_HIT_GRID: {   // every pair of two entity runs: the same constant per contact, any order gives the same float
             const int na = uni(op.y) & 255, nb = (uni(op.y) >> 8) & 255;
             float t = acc[a2 & 1];
             for (int qa = a0; qa < a0 + na; ++qa) {
               const float ax = P(qa, 0), ay = P(qa, 1), sa = TF(MPE_TAB(size), qa);
-              for (int qb = a1; qb < a1 + nb; ++qb) {
-                const bool hit = sqrt_lt(sq2d(ax - P(qb, 0), ay - P(qb, 1)), sa + TF(MPE_TAB(size), qb));
-                t = t + (hit ? f : 0.f);
+              const int end = a1 + nb;
+              for (int qb = a1; qb < end; qb += 4) {
+                float xs[4], ys[4], ss[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const int qq = qb + k < end ? qb + k : qb;
+                  xs[k] = P(qq, 0); ys[k] = P(qq, 1); ss[k] = TF(MPE_TAB(size), qq);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  if (qb + k < end) {
+                    const bool hit = sqrt_lt(sq2d(ax - xs[k], ay - ys[k]), sa + ss[k]);
+                    t = t + (hit ? f : 0.f);
+                  }
               }
             }
             if (a2 & 1) acc[1] = t; else acc[0] = t;
@@ -435,10 +477,7 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
             const int na = uni(op.y) & 255, nb = (uni(op.y) >> 8) & 255;
             float t = acc[a2 & 1];
             for (int qb = a1; qb < a1 + nb; ++qb) {
-              const float bx = P(qb, 0), by = P(qb, 1);
-              float m2 = sq2d(P(a0, 0) - bx, P(a0, 1) - by);
-              for (int qa = a0 + 1; qa < a0 + na; ++qa) m2 = fminf(m2, sq2d(P(qa, 0) - bx, P(qa, 1) - by));
-              v = fast_sqrt(m2);
+              v = fast_sqrt(min_d2_run(a0, na, P(qb, 0), P(qb, 1), false));
               t = t + f * v;
             }
             if (a2 & 1) acc[1] = t; else acc[0] = t;
