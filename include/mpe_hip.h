@@ -296,6 +296,7 @@ typedef struct MpeRowProgram {
   int32_t n_regions;          /* 0..2 landmarks that hide what is inside them                            */
   int32_t region_entity[2];
   uint32_t all_seeing;        /* bit i: agent i sees everybody (simple_world_comm.py:253: the leader)   */
+  void *image;                /* NULL, or what mpe_rows_load_image attached: the program compiled in (owned by the library)       */
 } MpeRowProgram;
 /* Checks a program against the descriptor (entity / pick / slot indices, row widths == obs_off): ops_host are the same
  * n_ops x 4 words in HOST memory.  0 or MPE_EINVAL with mpe_last_error() naming the op.                               */
@@ -318,6 +319,27 @@ int mpe_step_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowPro
 int mpe_episode_finish(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowProgram *prog, int64_t B,
                        int32_t *episode_step, int32_t max_episode_steps, float landmark_range, uint64_t seed,
                        uint64_t episode, int64_t world_offset, void *stream);
+
+/* ---- a row program COMPILED IN: the interpreter specialised away ---------------------------------------------------------
+ * mpe_rows / mpe_step_rows / mpe_episode_finish interpret a program op by op.  For a program that stays the same for the
+ * life of an env the same kernel source can be compiled WITH the program as constants (every op code, entity index, column
+ * and per-entity constant a literal): the interpreter folds into straight-line code in the same arithmetic order -- results
+ * bit-identical to the interpreted launch, at about the cost of a hand-fused kernel.  Three steps, each plain C:
+ *   1. mpe_rows_static_source writes a generated header (a few #defines: name, dims, tables, ops) into `buf`;
+ *   2. the caller compiles csrc/mpe_rows.hip with it:  hipcc --genco --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off
+ *      -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=14 -include <header> -I include -I csrc mpe_rows.hip -o prog.hsaco
+ *      (multiagent_particle_envs_amd/_build.py: compile_rows_image does exactly this and caches by content);
+ *   3. mpe_rows_load_image attaches the code object to the program; the three entry points above then launch it whenever
+ *      the call's descriptor still equals the one it was compiled for (constants are part of the image: after a change
+ *      -- an entity resized, dt edited -- calls fall back to the interpreter, still correct, until a new image is loaded).
+ * Programs whose workgroup needs more than 64 KB of LDS stay interpreted (MPE_EUNSUPPORTED from steps 1 and 3).           */
+int mpe_rows_static_source(const MpeScenarioDesc *desc, const MpeRowProgram *prog, const int32_t *ops_host, char *buf,
+                           size_t cap, size_t *needed);
+int mpe_rows_load_image(const MpeScenarioDesc *desc, MpeRowProgram *prog, const int32_t *ops_host, const void *image,
+                        size_t bytes);
+void mpe_rows_unload_image(MpeRowProgram *prog);
+/* 1 if the next mpe_rows / mpe_step_rows call with this descriptor would launch the compiled image, else 0.              */
+int mpe_rows_image_active(const MpeScenarioDesc *desc, const MpeRowProgram *prog);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "mpe_internal.h"
 
@@ -597,6 +598,47 @@ int mpe_rows_validate(const MpeScenarioDesc *d, const MpeRowProgram *p, const in
   return 0;
 }
 
+static uint64_t fnv1a(uint64_t hash, const void *data, size_t n) {
+  const unsigned char *bytes = static_cast<const unsigned char *>(data);
+  for (size_t k = 0; k < n; ++k) hash = (hash ^ bytes[k]) * 1099511628211ull;
+  return hash;
+}
+static constexpr uint64_t kFnvSeed = 1469598103934665603ull;
+static uint64_t tables_hash(const mpe::RowTables &tabs) { return fnv1a(kFnvSeed, &tabs, sizeof(tabs)) | 1ull; }
+
+// a program compiled in (mpe_rows_load_image): the module, its four entry points, and what it was compiled for
+struct RowImage {
+  hipModule_t module;
+  void *fns[4];            // _ns, _ps, _nr, _pr
+  mpe::RowDims dims;
+  uint64_t tables;
+  const int32_t *ops_device;
+  int32_t n_ops;
+};
+static bool image_matches(const MpeRowProgram *p, const mpe::RowDims &h, uint64_t tabs_hash) {
+  const RowImage *im = static_cast<const RowImage *>(p->image);
+  return im && im->tables == tabs_hash && std::memcmp(&im->dims, &h, sizeof(h)) == 0 && im->ops_device == p->ops_device &&
+         im->n_ops == p->n_ops;
+}
+// geometry + name of the compiled form; MPE_EUNSUPPORTED when a workgroup would need more than 64 KB of LDS
+static int static_identity(const char *what, const mpe::RowDims &h, const mpe::RowTables &tabs, const int32_t *ops, int waves[2],
+                           char name[40]) {
+  size_t lds[2] = {0, 0};
+  for (int phys = 0; phys < 2; ++phys) {
+    if (int rc = mpe::rows_geometry(h, phys != 0, &waves[phys], &lds[phys]))
+      return fail(rc, "%s: the program does not fit a workgroup's LDS", what);
+    if (lds[phys] > 64 * 1024)
+      return fail(MPE_EUNSUPPORTED, "%s: a workgroup of this program needs %zu bytes of LDS; compiled programs stay within 64 KB (it runs interpreted)",
+                  what, lds[phys]);
+  }
+  uint64_t hash = fnv1a(kFnvSeed, &h, sizeof(h));
+  hash = fnv1a(hash, &tabs, sizeof(tabs));
+  hash = fnv1a(hash, ops, (size_t)h.n_ops * 16);
+  hash = fnv1a(hash, waves, 2 * sizeof(int));
+  std::snprintf(name, 40, "mpe_rows_%016llx", (unsigned long long)hash);
+  return 0;
+}
+
 static int rows_call(const char *what, bool phys, const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B,
                      const mpe::RowEpisode *episode, void *stream) {
   static_assert(sizeof(mpe::RowTables) <= MPE_ROWS_HEADER_BYTES, "MPE_ROWS_HEADER_BYTES too small");
@@ -621,11 +663,10 @@ static int rows_call(const char *what, bool phys, const MpeScenarioDesc *d, cons
   for (int i = 0; i <= d->n_agents; ++i)
     if (((size_t)d->obs_off[i] * (size_t)B) % 4 != 0) vec4 = false;
   // the tables in device memory: uploaded when their content differs from what the program holds (FNV-1a over the bytes)
-  uint64_t hash = 1469598103934665603ull;
-  const unsigned char *bytes = reinterpret_cast<const unsigned char *>(&tabs);
-  for (size_t k = 0; k < sizeof(tabs); ++k) hash = (hash ^ bytes[k]) * 1099511628211ull;
-  hash |= 1ull;
+  const uint64_t hash = tables_hash(tabs);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (image_matches(p, h, hash))      // the program compiled in, and still the descriptor it was compiled for
+    return hip_result(mpe::launch_rows_image(static_cast<RowImage *>(p->image)->fns, *b, h, tabs, phys, vec4 ? 1 : 0, ep, (size_t)B, s), what);
   if (hash != p->header_hash) {
     if (int rc = mpe::launch_rows_header(tabs, p->header_device, s)) return hip_result(rc, what);
     p->header_hash = hash;
@@ -663,6 +704,104 @@ int mpe_episode_finish(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProg
   MpeBuffers bb = *b;
   bb.rew = nullptr;          // rewards belong to the step that just ran; only rows (and the finished worlds' state) change here
   return rows_call(what, false, d, &bb, p, B, &ep, stream);
+}
+
+int mpe_rows_static_source(const MpeScenarioDesc *d, const MpeRowProgram *p, const int32_t *ops, char *buf, size_t cap, size_t *needed) {
+  const char *what = "mpe_rows_static_source";
+  if (int rc = mpe_rows_validate(d, p, ops)) return rc;
+  mpe::RowDims h;
+  mpe::RowTables tabs;
+  if (int rc = rows_header(what, d, p, &h, &tabs)) return rc;
+  int waves[2];
+  char name[40];
+  if (int rc = static_identity(what, h, tabs, ops, waves, name)) return rc;
+  std::string out;
+  char line[256];
+  auto put = [&](const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(line, sizeof(line), fmt, ap);
+    va_end(ap);
+    out += line;
+  };
+  auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+  put("// generated by mpe_rows_static_source for csrc/mpe_rows.hip (-include this file): a row program as constants\n");
+  put("#define MPE_ROWS_STATIC 1\n#define MPE_ROWS_STATIC_NAME %s\n", name);
+  put("#define MPE_ROWS_STATIC_WAVES_ROWS %d\n#define MPE_ROWS_STATIC_WAVES_STEP %d\n", waves[0], waves[1]);
+  put("#define MPE_ROWS_STATIC_DIMS { %d, %d, %d, %d, %d, %d, %d, %d, %d, {%d, %d}, 0x%xu, 0x%llxull, 0x%llxull, ", h.n_agents, h.n_entities,
+      h.n_vel, h.dim_c, h.collaborative, h.d_max, h.n_picks, h.n_ops, h.n_regions, h.region_entity[0], h.region_entity[1], h.all_seeing,
+      (unsigned long long)h.movable, (unsigned long long)h.collide);
+  put("__builtin_bit_cast(float, 0x%08xu), __builtin_bit_cast(float, 0x%08xu), __builtin_bit_cast(float, 0x%08xu), "
+      "__builtin_bit_cast(float, 0x%08xu), __builtin_bit_cast(float, 0x%08xu) }\n", fbits(h.dt), fbits(h.damp), fbits(h.cforce),
+      fbits(h.cmargin), fbits(h.cmargin_inv));
+  out += "#define MPE_ROWS_STATIC_TABLES { ";
+  const uint32_t *tw = reinterpret_cast<const uint32_t *>(&tabs);
+  for (size_t k = 0; k < sizeof(tabs) / 4; ++k) put("0x%xu,%s", tw[k], k % 16 == 15 ? " \\\n  " : " ");
+  out += "}\n#define MPE_ROWS_STATIC_OPS { ";
+  for (int pc = 0; pc < h.n_ops; ++pc) put("{%d, %d, %d, %d},%s", ops[4 * pc], ops[4 * pc + 1], ops[4 * pc + 2], ops[4 * pc + 3], pc % 4 == 3 ? " \\\n  " : " ");
+  if (h.n_ops == 0) out += "{0, 0, 0, 0} ";
+  out += "}\n";
+  if (needed) *needed = out.size() + 1;
+  if (!buf || cap < out.size() + 1) {
+    if (buf) return fail(MPE_EINVAL, "%s: the header needs %zu bytes, cap = %zu", what, out.size() + 1, cap);
+    return 0;      // (size query)
+  }
+  std::memcpy(buf, out.c_str(), out.size() + 1);
+  return 0;
+}
+
+void mpe_rows_unload_image(MpeRowProgram *p) {
+  if (!p || !p->image) return;
+  RowImage *im = static_cast<RowImage *>(p->image);
+  if (im->module) (void)hipModuleUnload(im->module);
+  delete im;
+  p->image = nullptr;
+}
+
+int mpe_rows_load_image(const MpeScenarioDesc *d, MpeRowProgram *p, const int32_t *ops, const void *image, size_t bytes) {
+  const char *what = "mpe_rows_load_image";
+  if (!image || bytes == 0) return fail(MPE_EINVAL, "%s: image is empty", what);
+  if (int rc = mpe_rows_validate(d, p, ops)) return rc;
+  mpe::RowDims h;
+  mpe::RowTables tabs;
+  if (int rc = rows_header(what, d, p, &h, &tabs)) return rc;
+  int waves[2];
+  char name[40];
+  if (int rc = static_identity(what, h, tabs, ops, waves, name)) return rc;
+  mpe_rows_unload_image(p);
+  RowImage *im = new RowImage();
+  std::memset(static_cast<void *>(im), 0, sizeof(*im));
+  hipError_t rc = hipModuleLoadData(&im->module, image);
+  if (rc != hipSuccess) {
+    delete im;
+    return fail((int)rc, "%s: hipModuleLoadData: %s", what, hipGetErrorString(rc));
+  }
+  static const char *const suffix[4] = {"_ns", "_ps", "_nr", "_pr"};
+  for (int k = 0; k < 4; ++k) {
+    const std::string fn = std::string(name) + suffix[k];
+    hipFunction_t f = nullptr;
+    rc = hipModuleGetFunction(&f, im->module, fn.c_str());
+    if (rc != hipSuccess || !f) {
+      (void)hipModuleUnload(im->module);
+      delete im;
+      return fail(MPE_EINVAL, "%s: the image has no kernel %s: it was compiled for another program, descriptor or library version", what, fn.c_str());
+    }
+    im->fns[k] = f;
+  }
+  im->dims = h;
+  im->tables = tables_hash(tabs);
+  im->ops_device = p->ops_device;
+  im->n_ops = p->n_ops;
+  p->image = im;
+  return 0;
+}
+
+int mpe_rows_image_active(const MpeScenarioDesc *d, const MpeRowProgram *p) {
+  if (!d || !p || !p->image) return 0;
+  mpe::RowDims h;
+  mpe::RowTables tabs;
+  if (rows_header("mpe_rows_image_active", d, p, &h, &tabs)) return 0;
+  return image_matches(p, h, tables_hash(tabs)) ? 1 : 0;
 }
 
 }  // extern "C"

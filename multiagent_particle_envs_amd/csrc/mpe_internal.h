@@ -79,15 +79,14 @@ struct RowDims {
   int32_t n_agents, n_entities, n_vel, dim_c, collaborative;
   int32_t d_max;                 // widest observation row (floats): the waves' tile size
   int32_t n_picks;               // rows of MpeBuffers.choice (desc->n_choices)
-  int32_t n_ops;                 // 16-byte ops (staged in LDS)
+  int32_t n_ops;                 // 16-byte ops
   int32_t n_regions, region_entity[2];
   uint32_t all_seeing;
   uint64_t movable, collide;     // bit e
   float dt, damp, cforce, cmargin, cmargin_inv;
 };
-// Tables of a program: DEVICE memory (uploaded by launch_rows_header whenever their content changes), copied to LDS by
-// every workgroup next to the ops: a table entry or an op is then one LDS broadcast read away, not a scalar memory load
-// (PMC of the first version: 33 scalar loads per wave, 70 % of a wave's life spent waiting, mostly on them).
+// Tables of a program: DEVICE memory (uploaded by launch_rows_header whenever their content changes), read by scalar loads;
+// a compiled program (MPE_ROWS_STATIC) carries them as constants.
 struct RowTables {
   float size[MPE_ROWS_MAX_ENTITIES], inv_mass[MPE_ROWS_MAX_ENTITIES], accel[MPE_ROWS_MAX_ENTITIES], max_speed[MPE_ROWS_MAX_ENTITIES];
   int32_t obs_off[MPE_ROWS_MAX_ENTITIES + 1];     // prefix sums of the row widths
@@ -107,5 +106,8 @@ struct RowEpisode {
 int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream);
 int launch_rows(const MpeBuffers &b, const RowDims &dims, const RowTables &host, const void *tables_device, bool phys, int vec4,
                 const RowEpisode &ep, const int32_t *ops_device, size_t B, hipStream_t stream);
+int rows_geometry(const RowDims &dims, bool phys, int *waves, size_t *lds_bytes);
+int launch_rows_image(void *const fns[4], const MpeBuffers &b, const RowDims &dims, const RowTables &host, bool phys, int vec4,
+                      const RowEpisode &ep, size_t B, hipStream_t stream);
 
 }  // namespace mpe

@@ -73,14 +73,58 @@ __global__ void __launch_bounds__(64) k_rows_header(const RowTables t, RowTables
 
 #define MPE_TAB(field) ((int)(offsetof(RowTables, field) / 4))
 
-template <bool NT, bool PHYS>
-__global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpisode ep, const RowDims h,
-                                                 const uint32_t *__restrict__ const tables, const int32_t vec4, const int32_t split,
-                                                 const uint32_t *__restrict__ const ops_g, const size_t B) {
+// ---- a program COMPILED IN (mpe_rows_static_source -> hipcc --genco -> mpe_rows_load_image) ---------------------------------
+// The same body, instantiated with STATIC = true, reads its dims, tables and ops from constexpr arrays a generated header
+// defines, and walks its agents through literal indices: after inlining, every op code, entity index, column and LDS
+// address is a compile-time constant -- the interpreter folds away into straight-line code (the switch, the scalar loads,
+// the loop control), the LDS reads of a program batch up, and what is left is the arithmetic in the same order: the
+// interpreted and the compiled step agree bit for bit (tests/test_gpu_rowspec.py).
+#ifdef MPE_ROWS_STATIC
+template <bool PHYS> constexpr int static_waves() { return PHYS ? MPE_ROWS_STATIC_WAVES_STEP : MPE_ROWS_STATIC_WAVES_ROWS; }
+__device__ __forceinline__ constexpr RowDims static_dims() { constexpr RowDims d = MPE_ROWS_STATIC_DIMS; return d; }
+__device__ __forceinline__ uint32_t static_tab(int k) { constexpr uint32_t T[] = MPE_ROWS_STATIC_TABLES; return T[k]; }
+__device__ __forceinline__ int4 static_op(int pc) {
+  constexpr int32_t O[][4] = MPE_ROWS_STATIC_OPS;
+  return make_int4(O[pc][0], O[pc][1], O[pc][2], O[pc][3]);
+}
+#else
+template <bool PHYS> constexpr int static_waves() { return 1; }
+__device__ __forceinline__ constexpr RowDims static_dims() { return RowDims{}; }
+__device__ __forceinline__ uint32_t static_tab(int) { return 0u; }
+__device__ __forceinline__ int4 static_op(int) { return make_int4(0, 0, 0, 0); }
+#endif
+
+// agents W, W + NW, ... < A of wave `wave`, each through a literal index (the compiled form); f is always_inline
+template <int I, int NW, int A, class F>
+__device__ __forceinline__ void static_agents_from(F &f) {
+  if constexpr (I < A) {
+    f(I);
+    static_agents_from<I + NW, NW, A>(f);
+  }
+}
+template <int W, int NW, int A, class F>
+__device__ __forceinline__ void static_agents_of_wave(int wave, F &f) {
+  if constexpr (W < NW) {
+    if (wave == W) static_agents_from<W, NW, A>(f);
+    else static_agents_of_wave<W + 1, NW, A>(wave, f);
+  }
+}
+template <bool STATIC, bool PHYS, class F>
+__device__ __forceinline__ void agents_of_wave(int first, int stride, int A, F &f) {
+  if constexpr (STATIC) static_agents_of_wave<0, static_waves<PHYS>(), static_dims().n_agents>(first, f);
+  else for (int i = first; i < A; i += stride) f(i);
+}
+
+template <bool NT, bool PHYS, bool STATIC>
+__device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode &ep, const RowDims &h_arg,
+                                          const uint32_t *__restrict__ const tables, const int32_t vec4, const int32_t split_arg,
+                                          const uint32_t *__restrict__ const ops_g, const size_t B) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const RowDims h = STATIC ? static_dims() : h_arg;
+  const int32_t split = STATIC ? 0 : split_arg;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = uni((int)(threadIdx.x >> 6));
-  const int NW = uni((int)(blockDim.x >> 6));          // waves of the workgroup
+  const int NW = STATIC ? static_waves<PHYS>() : uni((int)(blockDim.x >> 6));          // waves of the workgroup
   // roles: with `split` (two waves per agent: the launch has 2 RW waves) waves [0, RW) run World.step and the observation
   // programs of agents w, w + RW, ..., waves [RW, 2 RW) the reward programs of the same agents at the same time; without it
   // every wave does both.  (Measured slower at every shape tried -- spread N=3 15.3 vs 13.1 us: the launch is not bound by
@@ -100,9 +144,11 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
   // the per-entity tables and the ops stay in device memory and are read with scalar loads (uniform addresses): staging them
   // in LDS per workgroup measured 7 % slower at 65 536 worlds (one more dependent load + barrier in front of every wave) and
   // halves the waves of the largest programs
-  const int4 *const ops = reinterpret_cast<const int4 *>(ops_g);
-  auto TI = [&](int base, int k) { return (int)tables[base + k]; };
-  auto TF = [&](int base, int k) { return __builtin_bit_cast(float, tables[base + k]); };
+  const int4 *const ops_d = reinterpret_cast<const int4 *>(ops_g);
+  auto OP = [&](int pc) { if constexpr (STATIC) return static_op(pc); else return ops_d[pc]; };
+  auto TU = [&](int k) { if constexpr (STATIC) return static_tab(k); else return tables[k]; };
+  auto TI = [&](int base, int k) { return (int)TU(base + k); };
+  auto TF = [&](int base, int k) { return __builtin_bit_cast(float, TU(base + k)); };
   float *const S_pos = reinterpret_cast<float *>(smem);   // [E][2][64]
   float *const S_vel = S_pos + 2 * E * kWave;             // [NV][2][64]
   float *const S_rew = S_vel + 2 * NV * kWave;            // [A][64]    rewards before the shared sum
@@ -209,7 +255,7 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
     // that leaves here is theirs to the bit.  New state -> S_new; behind the barrier it replaces the staged one and goes
     // back to HBM (no wave still reads pre-step positions then).
     {
-      for (int i = is_rows ? wave : A; i < A; i += RW) {
+      auto phys_agent = [&](const int i) __attribute__((always_inline)) {
         float mx = P(i, 0), my = P(i, 1), mvx = V(i, 0), mvy = V(i, 1);
         if ((h.movable >> i) & 1ull) {
           float ux, uy;
@@ -236,7 +282,8 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
         S_new[(4 * i + 1) * kWave + lane] = my;
         S_new[(4 * i + 2) * kWave + lane] = mvx;
         S_new[(4 * i + 3) * kWave + lane] = mvy;
-      }
+      };
+      agents_of_wave<STATIC, PHYS>(is_rows ? wave : A, RW, A, phys_agent);
     }
     MPE_RSTAMP(3);    // World.step of this wave's agents computed
     __syncthreads();
@@ -261,9 +308,9 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
   // ---- observation programs of this wave's agents ------------------------------------------------------------------------
   {
     float *const tile = tiles + (size_t)wave * kWave * h.d_max;
-    for (int i = is_rows ? wave : A; i < A; i += RW) {
+    auto obs_agent = [&](const int i) __attribute__((always_inline)) {
       const int D = TI(MPE_TAB(obs_off), i + 1) - TI(MPE_TAB(obs_off), i);
-      if (D == 0) continue;
+      if (D == 0) return;
       const float mx = P(i, 0), my = P(i, 1);
       // who is inside which region: bit (e * 2 + r), for the visibility rule (same region, or both in the open; agents in
       // h.all_seeing see everybody -- the leader of simple_world_comm.py:253)
@@ -279,10 +326,10 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
       float *const row = tile + lane * D;
       int col = 0;
       const int pc0 = TI(MPE_TAB(obs_begin), i), pc1 = TI(MPE_TAB(obs_begin), i + 1);
-      int4 nxt = pc0 < pc1 ? ops[pc0] : make_int4(0, 0, 0, 0);
+      int4 nxt = pc0 < pc1 ? OP(pc0) : make_int4(0, 0, 0, 0);
       for (int pc = pc0; pc < pc1; ++pc) {
         const int4 op = nxt;
-        if (pc + 1 < pc1) nxt = ops[pc + 1];        // in flight while this op executes
+        if (pc + 1 < pc1) nxt = OP(pc + 1);        // in flight while this op executes
         const int code = uni(op.x & 0xff), a0 = uni((op.x >> 8) & 0xff), a1 = uni((op.x >> 16) & 0xff);
         const int e = a0 == kRowSelf ? i : a0;
         switch (code) {
@@ -359,7 +406,8 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
         }
       }
       flush_tile<NT>(tile, b.obs + B * (size_t)TI(MPE_TAB(obs_off), i) + w0 * (size_t)D, D, nvalid, lane, vec4 != 0);
-    }
+    };
+    agents_of_wave<STATIC, PHYS>(is_rows ? wave : A, RW, A, obs_agent);
   }
   MPE_RSTAMP(5);      // observation rows stored
   if (ep.enabled) return;      // (mpe_episode_finish: rewards and dones belong to the step that just ran)
@@ -387,13 +435,13 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
       }
       return m;
     };
-    for (int i = rwave; i < A; i += RW) {
+    auto rew_agent = [&](const int i) __attribute__((always_inline)) {
       float acc[2] = {0.f, 0.f}, v = 0.f;
       const int pc0 = TI(MPE_TAB(rew_begin), i), pc1 = TI(MPE_TAB(rew_begin), i + 1);
-      int4 nxt = pc0 < pc1 ? ops[pc0] : make_int4(0, 0, 0, 0);
+      int4 nxt = pc0 < pc1 ? OP(pc0) : make_int4(0, 0, 0, 0);
       for (int pc = pc0; pc < pc1; ++pc) {
         const int4 op = nxt;
-        if (pc + 1 < pc1) nxt = ops[pc + 1];
+        if (pc + 1 < pc1) nxt = OP(pc + 1);
         const int code = uni(op.x & 0xff), a0 = uni((op.x >> 8) & 0xff), a1 = uni((op.x >> 16) & 0xff), a2 = uni((op.x >> 24) & 0xff);
         const float f = unif(__builtin_bit_cast(float, op.z));
         switch (code) {
@@ -486,7 +534,8 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
           default: break;
         }
       }
-    }
+    };
+    agents_of_wave<STATIC, PHYS>(rwave, RW, A, rew_agent);
     MPE_RSTAMP(6);    // reward programs done
     if (h.collaborative) __syncthreads();      // (uniform: a kernel argument)
     // environment.py:100-102: every agent gets np.sum(reward_n) = r0 + (((0 + r1) + r2) + ...) for n < 9
@@ -503,39 +552,92 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
     for (int i = rwave; i < A; i += RW) (b.done + wave_off((size_t)i * B + w0))[ln] = 0;
 }
 
+#ifndef MPE_ROWS_STATIC
+template <bool NT, bool PHYS>
+__global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpisode ep, const RowDims h,
+                                                 const uint32_t *__restrict__ const tables, const int32_t vec4, const int32_t split,
+                                                 const uint32_t *__restrict__ const ops_g, const size_t B) {
+  rows_body<NT, PHYS, false>(b, ep, h, tables, vec4, split, ops_g, B);
+}
+#endif
+
 }  // namespace
+
+#ifdef MPE_ROWS_STATIC
+// the four entry points of a compiled program: <name>_{n,p}{s,r} = {nontemporal, plain} row stores x {step, rows only}
+#define MPE_ROWS_CAT2(a, b) a##b
+#define MPE_ROWS_CAT(a, b) MPE_ROWS_CAT2(a, b)
+#define MPE_ROWS_STATIC_KERNEL(suffix, NT, PHYS)                                                                              \
+  extern "C" __global__ void __launch_bounds__(static_waves<PHYS>() * kWave)                                                   \
+      MPE_ROWS_CAT(MPE_ROWS_STATIC_NAME, suffix)(const MpeBuffers b, const RowEpisode ep, const int32_t vec4, const size_t B) { \
+    rows_body<NT, PHYS, true>(b, ep, RowDims{}, nullptr, vec4, 0, nullptr, B);                                                 \
+  }
+MPE_ROWS_STATIC_KERNEL(_ns, true, true)
+MPE_ROWS_STATIC_KERNEL(_ps, false, true)
+MPE_ROWS_STATIC_KERNEL(_nr, true, false)
+MPE_ROWS_STATIC_KERNEL(_pr, false, false)
+#else
 
 int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream) {
   hipLaunchKernelGGL(k_rows_header, dim3(1), dim3(64), 0, stream, t, reinterpret_cast<RowTables *>(dst));
   return (int)hipGetLastError();
 }
 
-int launch_rows(const MpeBuffers &b, const RowDims &h, const RowTables &host, const void *tables_device, bool phys, int vec4,
-                const RowEpisode &ep, const int32_t *ops_device, size_t B, hipStream_t stream) {
-  // LDS: the staged state + reward scratch, and one [64][d_max] tile + eight slots per wave -- as many waves as
-  // fit (each wave takes its share of the agents in turn), at most one per agent and 16
+// LDS: the staged state + reward scratch, and one [64][d_max] tile + eight slots per wave -- as many waves as fit (each
+// wave takes its share of the agents in turn), at most one per agent and 16; past 4 waves stay within 64 KB (two workgroups
+// per CU).  One function for the launch and for the generator of compiled programs (the wave count is a constant there).
+int rows_geometry(const RowDims &h, bool phys, int *waves, size_t *lds_bytes) {
   constexpr size_t kLdsCap = 160 * 1024;
   const size_t fixed = sizeof(float) * (size_t)(2 * h.n_entities + 2 * h.n_vel + h.n_agents + kRowPicks + (phys ? 4 * h.n_agents : 0)) * kWave;
-  const size_t slots = sizeof(float) * (size_t)kWave * kRowSlots;
-  const size_t tile_only = sizeof(float) * (size_t)kWave * (size_t)h.d_max;
-  if (fixed + tile_only + slots > kLdsCap) return MPE_EUNSUPPORTED;
+  const size_t per_wave = sizeof(float) * (size_t)kWave * ((size_t)h.d_max + kRowSlots);
+  if (fixed + per_wave > kLdsCap) return MPE_EUNSUPPORTED;
   int W = h.n_agents < kRowMaxObsWaves ? h.n_agents : kRowMaxObsWaves;
-  const bool split = false;      // two waves per agent (rows || reward): measured slower (see k_rows), kept for the A/B only
-  auto need = [&](int w, bool sp) { return fixed + (size_t)w * tile_only + (size_t)(sp ? 2 * w : w) * slots; };
-  while (W > 1 && need(W, split) > (W > 4 ? 64u * 1024u : kLdsCap)) --W;   // (past 4 waves, stay within 64 KB: two workgroups per CU)
-  const size_t lds = need(W, split);
-  const int NWL = split ? 2 * W : W;
-  const unsigned grid = (unsigned)((B + kWave - 1) / kWave);
+  while (W > 1 && fixed + (size_t)W * per_wave > (W > 4 ? 64u * 1024u : kLdsCap)) --W;
+  *waves = W;
+  *lds_bytes = fixed + (size_t)W * per_wave;
+  return 0;
+}
+
+static bool rows_nontemporal(const RowDims &h, const RowTables &host, int vec4, const RowEpisode &ep, size_t B) {
   const size_t row_bytes = (size_t)host.obs_off[h.n_agents] * sizeof(float) * B;
-  const bool nt = row_bytes >= (8u << 20) && vec4 && !ep.enabled;
+  return row_bytes >= (8u << 20) && vec4 && !ep.enabled;
+}
+
+int launch_rows(const MpeBuffers &b, const RowDims &h, const RowTables &host, const void *tables_device, bool phys, int vec4,
+                const RowEpisode &ep, const int32_t *ops_device, size_t B, hipStream_t stream) {
+  int W = 0;
+  size_t lds = 0;
+  if (int rc = rows_geometry(h, phys, &W, &lds)) return rc;
+  // (two waves per agent, rows || reward -- `split` -- measured slower, see rows_body; the kernel keeps the switch for the A/B)
+  const unsigned grid = (unsigned)((B + kWave - 1) / kWave);
+  const bool nt = rows_nontemporal(h, host, vec4, ep, B);
   auto fn = phys ? (nt ? k_rows<true, true> : k_rows<false, true>) : (nt ? k_rows<true, false> : k_rows<false, false>);
   if (lds > 64 * 1024) {
     const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return (int)rc;
   }
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(NWL * kWave), lds, stream, b, ep, h, reinterpret_cast<const uint32_t *>(tables_device),
-                     (int32_t)vec4, (int32_t)(split ? 1 : 0), reinterpret_cast<const uint32_t *>(ops_device), B);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(W * kWave), lds, stream, b, ep, h, reinterpret_cast<const uint32_t *>(tables_device),
+                     (int32_t)vec4, (int32_t)0, reinterpret_cast<const uint32_t *>(ops_device), B);
   return (int)hipGetLastError();
 }
+
+// a compiled program (hipModule functions in the order ns, ps, nr, pr): same geometry, no tables, no ops
+int launch_rows_image(void *const fns[4], const MpeBuffers &b, const RowDims &h, const RowTables &host, bool phys, int vec4,
+                      const RowEpisode &ep, size_t B, hipStream_t stream) {
+  int W = 0;
+  size_t lds = 0;
+  if (int rc = rows_geometry(h, phys, &W, &lds)) return rc;
+  if (lds > 64 * 1024) return MPE_EUNSUPPORTED;      // (mpe_rows_load_image refuses such programs: never reached)
+  const bool nt = rows_nontemporal(h, host, vec4, ep, B);
+  hipFunction_t fn = static_cast<hipFunction_t>(fns[(phys ? 0 : 2) + (nt ? 0 : 1)]);
+  MpeBuffers b_ = b;
+  RowEpisode ep_ = ep;
+  int32_t vec4_ = vec4;
+  size_t B_ = B;
+  void *args[] = {&b_, &ep_, &vec4_, &B_};
+  const unsigned grid = (unsigned)((B + kWave - 1) / kWave);
+  return (int)hipModuleLaunchKernel(fn, grid, 1, 1, (unsigned)(W * kWave), 1, 1, (unsigned)lds, stream, args, nullptr);
+}
+#endif
 
 }  // namespace mpe
