@@ -332,12 +332,13 @@ int mpe_episode_finish(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeR
  *   3. mpe_rows_load_image attaches the code object to the program; the three entry points above then launch it whenever
  *      the call's descriptor still equals the one it was compiled for (constants are part of the image: after a change
  *      -- an entity resized, dt edited -- calls fall back to the interpreter, still correct, until a new image is loaded).
- * Programs whose workgroup needs more than 64 KB of LDS stay interpreted (MPE_EUNSUPPORTED from steps 1 and 3).           */
+ * Programs of more than MPE_ROWS_STATIC_MAX_OPS ops stay interpreted (MPE_EUNSUPPORTED from steps 1 and 3).              */
+#define MPE_ROWS_STATIC_MAX_OPS 512
 int mpe_rows_static_source(const MpeScenarioDesc *desc, const MpeRowProgram *prog, const int32_t *ops_host, char *buf,
                            size_t cap, size_t *needed);
 int mpe_rows_load_image(const MpeScenarioDesc *desc, MpeRowProgram *prog, const int32_t *ops_host, const void *image,
                         size_t bytes);
-void mpe_rows_unload_image(MpeRowProgram *prog);
+int mpe_rows_unload_image(MpeRowProgram *prog); /* 0; a program without an image is left alone */
 /* 1 if the next mpe_rows / mpe_step_rows call with this descriptor would launch the compiled image, else 0.              */
 int mpe_rows_image_active(const MpeScenarioDesc *desc, const MpeRowProgram *prog);
 

@@ -57,7 +57,7 @@ class MpeRowProgram(C.Structure):
     _fields_ = [
         ("ops_device", C.c_void_p), ("header_device", C.c_void_p), ("header_hash", C.c_uint64), ("n_ops", C.c_int32), ("obs_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)),
         ("rew_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)), ("n_vel", C.c_int32), ("n_regions", C.c_int32),
-        ("region_entity", C.c_int32 * 2), ("all_seeing", C.c_uint32),
+        ("region_entity", C.c_int32 * 2), ("all_seeing", C.c_uint32), ("image", C.c_void_p),
     ]
 
 
@@ -91,6 +91,12 @@ EXPORTS = {
     "mpe_episode_finish": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.POINTER(MpeRowProgram), C.c_int64, C.c_void_p,
                                      C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]),
     "mpe_sizeof_row_program": (C.c_size_t, []),
+    "mpe_rows_static_source": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeRowProgram), C.POINTER(C.c_int32), C.c_char_p,
+                                         C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mpe_rows_load_image": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeRowProgram), C.POINTER(C.c_int32), C.c_void_p,
+                                      C.c_size_t]),
+    "mpe_rows_unload_image": (C.c_int, [C.POINTER(MpeRowProgram)]),
+    "mpe_rows_image_active": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeRowProgram)]),
     "mpe_episode_tick": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "mpe_rollout_random": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_int32,
                                      C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32,

@@ -44,6 +44,40 @@ VARIANT_SOURCES = {"span": ("split",), "teamgrid": ("split", "narrow"), "rowsclo
 AB_VARIANTS = {"teamgrid": ["-DMPE_SPLIT_TEAM_GRID"], "rowsclock": ["-DMPE_ROWS_CLOCK"]}
 
 
+ROWS_CACHE = os.path.join(LIBDIR, "rows_cache")      # compiled row programs: <sha256 of header + sources + flags>.hsaco
+
+
+def compile_rows_image(header_text, verbose=False):
+    """A row program compiled in: csrc/mpe_rows.hip built with the generated header (mpe_rows_static_source) as a gfx950 code
+    object (`hipcc --genco`, the library's own flags: same arithmetic, same kernarg preload) -> its bytes, for
+    mpe_rows_load_image.  Cached by content under lib/rows_cache/ (travels with the tree; delete at will)."""
+    import hashlib
+    src = os.path.join(CSRC, "mpe_rows.hip")
+    flags = [f for f in FLAGS if f not in ("-fPIC", "-save-temps=obj", "-Wall")]
+    h = hashlib.sha256()
+    h.update(header_text.encode())
+    for f in [src] + [os.path.join(CSRC, x) for x in HEADERS]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(flags).encode())
+    os.makedirs(ROWS_CACHE, exist_ok=True)
+    out = os.path.join(ROWS_CACHE, h.hexdigest()[:32] + ".hsaco")
+    if not os.path.exists(out):
+        hdr = out[:-6] + ".h"
+        with open(hdr, "w") as fh:
+            fh.write(header_text)
+        tmp = out + ".tmp%d" % os.getpid()
+        cmd = [_hipcc(), "--genco"] + flags + ["-include", hdr, "-I", CSRC, "-I", os.path.join(HERE, "..", "include"), src, "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on a compiled row program:\n%s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
+        os.replace(tmp, out)
+    with open(out, "rb") as fh:
+        return fh.read()
+
+
 def variant_lib(tag):
     return os.path.join(LIBDIR, "libmpe_hip_%s.so" % tag)
 

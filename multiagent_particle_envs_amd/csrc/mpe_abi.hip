@@ -620,17 +620,15 @@ static bool image_matches(const MpeRowProgram *p, const mpe::RowDims &h, uint64_
   return im && im->tables == tabs_hash && std::memcmp(&im->dims, &h, sizeof(h)) == 0 && im->ops_device == p->ops_device &&
          im->n_ops == p->n_ops;
 }
-// geometry + name of the compiled form; MPE_EUNSUPPORTED when a workgroup would need more than 64 KB of LDS
+// geometry + name of the compiled form
 static int static_identity(const char *what, const mpe::RowDims &h, const mpe::RowTables &tabs, const int32_t *ops, int waves[2],
-                           char name[40]) {
-  size_t lds[2] = {0, 0};
-  for (int phys = 0; phys < 2; ++phys) {
+                           size_t lds[2], char name[40]) {
+  for (int phys = 0; phys < 2; ++phys)
     if (int rc = mpe::rows_geometry(h, phys != 0, &waves[phys], &lds[phys]))
       return fail(rc, "%s: the program does not fit a workgroup's LDS", what);
-    if (lds[phys] > 64 * 1024)
-      return fail(MPE_EUNSUPPORTED, "%s: a workgroup of this program needs %zu bytes of LDS; compiled programs stay within 64 KB (it runs interpreted)",
-                  what, lds[phys]);
-  }
+  if (h.n_ops > MPE_ROWS_STATIC_MAX_OPS)
+    return fail(MPE_EUNSUPPORTED, "%s: %d ops; programs of more than %d ops stay interpreted (every op becomes code: compile time and "
+                "instruction-cache footprint grow with it)", what, h.n_ops, MPE_ROWS_STATIC_MAX_OPS);
   uint64_t hash = fnv1a(kFnvSeed, &h, sizeof(h));
   hash = fnv1a(hash, &tabs, sizeof(tabs));
   hash = fnv1a(hash, ops, (size_t)h.n_ops * 16);
@@ -713,8 +711,9 @@ int mpe_rows_static_source(const MpeScenarioDesc *d, const MpeRowProgram *p, con
   mpe::RowTables tabs;
   if (int rc = rows_header(what, d, p, &h, &tabs)) return rc;
   int waves[2];
+  size_t lds[2];
   char name[40];
-  if (int rc = static_identity(what, h, tabs, ops, waves, name)) return rc;
+  if (int rc = static_identity(what, h, tabs, ops, waves, lds, name)) return rc;
   std::string out;
   char line[256];
   auto put = [&](const char *fmt, ...) {
@@ -728,6 +727,7 @@ int mpe_rows_static_source(const MpeScenarioDesc *d, const MpeRowProgram *p, con
   put("// generated by mpe_rows_static_source for csrc/mpe_rows.hip (-include this file): a row program as constants\n");
   put("#define MPE_ROWS_STATIC 1\n#define MPE_ROWS_STATIC_NAME %s\n", name);
   put("#define MPE_ROWS_STATIC_WAVES_ROWS %d\n#define MPE_ROWS_STATIC_WAVES_STEP %d\n", waves[0], waves[1]);
+  put("#define MPE_ROWS_STATIC_LDS_ROWS %zu\n#define MPE_ROWS_STATIC_LDS_STEP %zu\n", lds[0], lds[1]);
   put("#define MPE_ROWS_STATIC_DIMS { %d, %d, %d, %d, %d, %d, %d, %d, %d, {%d, %d}, 0x%xu, 0x%llxull, 0x%llxull, ", h.n_agents, h.n_entities,
       h.n_vel, h.dim_c, h.collaborative, h.d_max, h.n_picks, h.n_ops, h.n_regions, h.region_entity[0], h.region_entity[1], h.all_seeing,
       (unsigned long long)h.movable, (unsigned long long)h.collide);
@@ -750,12 +750,13 @@ int mpe_rows_static_source(const MpeScenarioDesc *d, const MpeRowProgram *p, con
   return 0;
 }
 
-void mpe_rows_unload_image(MpeRowProgram *p) {
-  if (!p || !p->image) return;
+int mpe_rows_unload_image(MpeRowProgram *p) {
+  if (!p || !p->image) return 0;
   RowImage *im = static_cast<RowImage *>(p->image);
   if (im->module) (void)hipModuleUnload(im->module);
   delete im;
   p->image = nullptr;
+  return 0;
 }
 
 int mpe_rows_load_image(const MpeScenarioDesc *d, MpeRowProgram *p, const int32_t *ops, const void *image, size_t bytes) {
@@ -766,8 +767,9 @@ int mpe_rows_load_image(const MpeScenarioDesc *d, MpeRowProgram *p, const int32_
   mpe::RowTables tabs;
   if (int rc = rows_header(what, d, p, &h, &tabs)) return rc;
   int waves[2];
+  size_t lds[2];
   char name[40];
-  if (int rc = static_identity(what, h, tabs, ops, waves, name)) return rc;
+  if (int rc = static_identity(what, h, tabs, ops, waves, lds, name)) return rc;
   mpe_rows_unload_image(p);
   RowImage *im = new RowImage();
   std::memset(static_cast<void *>(im), 0, sizeof(*im));

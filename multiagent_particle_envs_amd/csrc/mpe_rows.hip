@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(64) k_rows_header(const RowTables t, RowTables
 // interpreted and the compiled step agree bit for bit (tests/test_gpu_rowspec.py).
 #ifdef MPE_ROWS_STATIC
 template <bool PHYS> constexpr int static_waves() { return PHYS ? MPE_ROWS_STATIC_WAVES_STEP : MPE_ROWS_STATIC_WAVES_ROWS; }
+template <bool PHYS> constexpr int static_lds_floats() { return (PHYS ? MPE_ROWS_STATIC_LDS_STEP : MPE_ROWS_STATIC_LDS_ROWS) / 4; }
 __device__ __forceinline__ constexpr RowDims static_dims() { constexpr RowDims d = MPE_ROWS_STATIC_DIMS; return d; }
 __device__ __forceinline__ uint32_t static_tab(int k) { constexpr uint32_t T[] = MPE_ROWS_STATIC_TABLES; return T[k]; }
 __device__ __forceinline__ int4 static_op(int pc) {
@@ -89,6 +90,7 @@ __device__ __forceinline__ int4 static_op(int pc) {
 }
 #else
 template <bool PHYS> constexpr int static_waves() { return 1; }
+template <bool PHYS> constexpr int static_lds_floats() { return 4; }
 __device__ __forceinline__ constexpr RowDims static_dims() { return RowDims{}; }
 __device__ __forceinline__ uint32_t static_tab(int) { return 0u; }
 __device__ __forceinline__ int4 static_op(int) { return make_int4(0, 0, 0, 0); }
@@ -119,7 +121,15 @@ template <bool NT, bool PHYS, bool STATIC>
 __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode &ep, const RowDims &h_arg,
                                           const uint32_t *__restrict__ const tables, const int32_t vec4, const int32_t split_arg,
                                           const uint32_t *__restrict__ const ops_g, const size_t B) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // LDS: a launch parameter for the interpreter; a compiled program knows its size (no 64 KB opt-in for module kernels needed)
+  float *smem;
+  if constexpr (STATIC) {
+    __shared__ __attribute__((aligned(16))) float smem_static[static_lds_floats<PHYS>()];
+    smem = smem_static;
+  } else {
+    extern __shared__ __attribute__((aligned(16))) float smem_dynamic[];
+    smem = smem_dynamic;
+  }
   const RowDims h = STATIC ? static_dims() : h_arg;
   const int32_t split = STATIC ? 0 : split_arg;
   const int lane = threadIdx.x & (kWave - 1);
@@ -326,10 +336,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
       float *const row = tile + lane * D;
       int col = 0;
       const int pc0 = TI(MPE_TAB(obs_begin), i), pc1 = TI(MPE_TAB(obs_begin), i + 1);
-      int4 nxt = pc0 < pc1 ? OP(pc0) : make_int4(0, 0, 0, 0);
-      for (int pc = pc0; pc < pc1; ++pc) {
-        const int4 op = nxt;
-        if (pc + 1 < pc1) nxt = OP(pc + 1);        // in flight while this op executes
+      auto obs_op = [&](const int4 op) __attribute__((always_inline)) {
         const int code = uni(op.x & 0xff), a0 = uni((op.x >> 8) & 0xff), a1 = uni((op.x >> 16) & 0xff);
         const int e = a0 == kRowSelf ? i : a0;
         switch (code) {
@@ -404,6 +411,17 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
           }
           default: break;
         }
+      };
+      if constexpr (STATIC) {      // every op a constant: the loop unrolls, the switch folds
+#pragma unroll
+        for (int pc = pc0; pc < pc1; ++pc) obs_op(OP(pc));
+      } else {
+        int4 nxt = pc0 < pc1 ? OP(pc0) : make_int4(0, 0, 0, 0);
+        for (int pc = pc0; pc < pc1; ++pc) {
+          const int4 op = nxt;
+          if (pc + 1 < pc1) nxt = OP(pc + 1);        // in flight while this op executes
+          obs_op(op);
+        }
       }
       flush_tile<NT>(tile, b.obs + B * (size_t)TI(MPE_TAB(obs_off), i) + w0 * (size_t)D, D, nvalid, lane, vec4 != 0);
     };
@@ -438,10 +456,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
     auto rew_agent = [&](const int i) __attribute__((always_inline)) {
       float acc[2] = {0.f, 0.f}, v = 0.f;
       const int pc0 = TI(MPE_TAB(rew_begin), i), pc1 = TI(MPE_TAB(rew_begin), i + 1);
-      int4 nxt = pc0 < pc1 ? OP(pc0) : make_int4(0, 0, 0, 0);
-      for (int pc = pc0; pc < pc1; ++pc) {
-        const int4 op = nxt;
-        if (pc + 1 < pc1) nxt = OP(pc + 1);
+      auto rew_op = [&](const int4 op) __attribute__((always_inline)) {
         const int code = uni(op.x & 0xff), a0 = uni((op.x >> 8) & 0xff), a1 = uni((op.x >> 16) & 0xff), a2 = uni((op.x >> 24) & 0xff);
         const float f = unif(__builtin_bit_cast(float, op.z));
         switch (code) {
@@ -532,6 +547,17 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
             break;
           }
           default: break;
+        }
+      };
+      if constexpr (STATIC) {
+#pragma unroll
+        for (int pc = pc0; pc < pc1; ++pc) rew_op(OP(pc));
+      } else {
+        int4 nxt = pc0 < pc1 ? OP(pc0) : make_int4(0, 0, 0, 0);
+        for (int pc = pc0; pc < pc1; ++pc) {
+          const int4 op = nxt;
+          if (pc + 1 < pc1) nxt = OP(pc + 1);
+          rew_op(op);
         }
       }
     };
@@ -627,7 +653,6 @@ int launch_rows_image(void *const fns[4], const MpeBuffers &b, const RowDims &h,
   int W = 0;
   size_t lds = 0;
   if (int rc = rows_geometry(h, phys, &W, &lds)) return rc;
-  if (lds > 64 * 1024) return MPE_EUNSUPPORTED;      // (mpe_rows_load_image refuses such programs: never reached)
   const bool nt = rows_nontemporal(h, host, vec4, ep, B);
   hipFunction_t fn = static_cast<hipFunction_t>(fns[(phys ? 0 : 2) + (nt ? 0 : 1)]);
   MpeBuffers b_ = b;
@@ -636,7 +661,7 @@ int launch_rows_image(void *const fns[4], const MpeBuffers &b, const RowDims &h,
   size_t B_ = B;
   void *args[] = {&b_, &ep_, &vec4_, &B_};
   const unsigned grid = (unsigned)((B + kWave - 1) / kWave);
-  return (int)hipModuleLaunchKernel(fn, grid, 1, 1, (unsigned)(W * kWave), 1, 1, (unsigned)lds, stream, args, nullptr);
+  return (int)hipModuleLaunchKernel(fn, grid, 1, 1, (unsigned)(W * kWave), 1, 1, 0u, stream, args, nullptr);      // (its LDS is static)
 }
 #endif
 

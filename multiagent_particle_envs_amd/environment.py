@@ -307,6 +307,25 @@ class MultiAgentEnv(object):
             return L.mpe_world_step(desc_ref, bufs_ref, B, st) or L.mpe_rows(desc_ref, bufs_ref, self._prog.ref, B, st)
         return L.mpe_step_rows(desc_ref, bufs_ref, self._prog.ref, B, st)
 
+    def compile_program(self, verbose=False):
+        """Compile this env's row program IN (`mpe_rows_static_source` -> hipcc --genco -> `mpe_rows_load_image`; a few
+        seconds the first time, cached by content under lib/rows_cache/): `step()` then launches the program as straight-line
+        code specialised to this world's shape and constants -- bit-identical results, about the cost of a hand-fused kernel.
+        The image is bound to the current constants: after an edit (an entity resized, dt changed) steps run interpreted again
+        until the next compile_program().  Returns True when the image is the one the next step launches; raises MpeError for
+        an env without a row program or one of more than 512 ops."""
+        if self._prog is None:
+            raise _abi.MpeError("compile_program: this env steps through %s, not through a row program"
+                                % ("a fused kernel" if self.fused else "its scenario's torch callbacks"))
+        self.refresh_constants()
+        self._prog.compile(self._desc, verbose=verbose)
+        return self._prog.image_active(self._desc)
+
+    @property
+    def program_compiled(self):
+        """True when the next step launches a compiled image of the row program (False: interpreted, or no program)."""
+        return self._prog is not None and self.fused and self._prog.image_active(self._desc)
+
     @property
     def step_impl(self):
         """Which kernel family the fused step launches: 'split' (wave-per-agent, `mpe_step`, the default) or

@@ -424,6 +424,39 @@ class RowProgram(object):
     def validate(self, desc):
         _abi.check(_abi.lib().mpe_rows_validate(C.byref(desc), self.ref, self.ops_host), "mpe_rows_validate")
 
+    # ---- the program compiled in (include/mpe_hip.h: mpe_rows_static_source / mpe_rows_load_image) ----------------------------
+    def static_source(self, desc):
+        """The generated header (name, dims, tables, ops as #defines) csrc/mpe_rows.hip is compiled with."""
+        need = C.c_size_t(0)
+        L = _abi.lib()
+        _abi.check(L.mpe_rows_static_source(C.byref(desc), self.ref, self.ops_host, None, 0, C.byref(need)), "mpe_rows_static_source")
+        buf = C.create_string_buffer(need.value)
+        _abi.check(L.mpe_rows_static_source(C.byref(desc), self.ref, self.ops_host, buf, need.value, None), "mpe_rows_static_source")
+        return buf.value.decode()
+
+    def compile(self, desc, verbose=False):
+        """Compile the program in for THIS descriptor (hipcc --genco, cached by content under lib/rows_cache/) and attach it:
+        mpe_rows / mpe_step_rows / mpe_episode_finish launch the image while the descriptor stays what it was compiled for."""
+        from . import _build
+        image = _build.compile_rows_image(self.static_source(desc), verbose=verbose)
+        self._image = C.create_string_buffer(image, len(image))
+        _abi.check(_abi.lib().mpe_rows_load_image(C.byref(desc), self.ref, self.ops_host, self._image, len(image)), "mpe_rows_load_image")
+        return len(image)
+
+    def unload(self):
+        _abi.lib().mpe_rows_unload_image(self.ref)
+        self._image = None
+
+    def image_active(self, desc):
+        return bool(_abi.lib().mpe_rows_image_active(C.byref(desc), self.ref))
+
+    def __del__(self):
+        try:
+            if self.struct.image:
+                _abi.lib().mpe_rows_unload_image(self.ref)
+        except Exception:
+            pass
+
 
 def compile_scenario(scenario, world):
     """-> RowProgram when the scenario describes every agent's observation AND reward as specs (`obs_spec(agent, world)`,

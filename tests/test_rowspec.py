@@ -119,9 +119,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from corral import Scenario as Corral  # noqa: E402
 
 
-def corral_env(B, fused=None, **kw):
+def corral_env(B, fused=None, device=None, **kw):
     sc = Corral()
-    w = sc.make_world(batch_size=B)
+    w = sc.make_world(batch_size=B, device=device) if device else sc.make_world(batch_size=B)
     w.seed = 3
     env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, fused=fused, **kw)
     env.scenario = sc
@@ -154,31 +154,37 @@ def test_builtins_as_specs_are_bit_identical_to_their_fused_kernels(name, B):
     finally:
         rowspec.FUSE = True
     prog2.two_launch_program = True
+    progc = make_spec_env(name, B, seed=5)                # the program COMPILED IN (mpe_rows_load_image): straight-line code
+    assert progc.compile_program() and progc.program_compiled and not prog.program_compiled
     assert prog2._prog.n_ops >= prog._prog.n_ops
     assert fused.fused and fused._prog is None and prog.fused and prog._prog is not None
     rs = np.random.RandomState(B)
-    of, op, op2 = fused.reset(), prog.reset(), prog2.reset()
+    of, op, op2, oc = fused.reset(), prog.reset(), prog2.reset(), progc.reset()
     for i in range(fused.n):
-        assert torch.equal(of[i], op[i]) and torch.equal(of[i], op2[i]), ("reset", i)
+        assert torch.equal(of[i], op[i]) and torch.equal(of[i], op2[i]) and torch.equal(of[i], oc[i]), ("reset", i)
     for t in range(9):
         if t == 2:                                   # crowd the worlds: contacts, boundary penalties
-            for e in (fused, prog, prog2):
+            for e in (fused, prog, prog2, progc):
                 e.world.pos.mul_(0.35)
         if t == 6:
-            of, op, op2 = fused.reset(), prog.reset(), prog2.reset()
+            of, op, op2, oc = fused.reset(), prog.reset(), prog2.reset(), progc.reset()
             for i in range(fused.n):
-                assert torch.equal(of[i], op[i]) and torch.equal(of[i], op2[i]), ("second reset", i)
+                assert torch.equal(of[i], op[i]) and torch.equal(of[i], op2[i]) and torch.equal(of[i], oc[i]), ("second reset", i)
         act = rand_actions(fused, rs, B)
         of, rf, df, _ = fused.step(act)
         op, rp, dp, _ = prog.step(act)
         op2, rp2, _, _ = prog2.step(act)
-        for e in (prog, prog2):
+        oc, rc, dc, _ = progc.step(act)
+        for e in (prog, prog2, progc):
             assert torch.equal(fused.world.pos, e.world.pos) and torch.equal(fused.world.vel, e.world.vel), t
         for i in range(fused.n):
             assert torch.equal(of[i], op[i]), (name, "obs", t, i, float((of[i] - op[i]).abs().max()))
             assert torch.equal(rf[i], rp[i]), (name, "rew", t, i, float((rf[i] - rp[i]).abs().max()))
             assert torch.equal(df[i], dp[i])
             assert torch.equal(of[i], op2[i]) and torch.equal(rf[i], rp2[i]), (name, "two launches", t, i)
+            assert torch.equal(of[i], oc[i]), (name, "compiled obs", t, i, float((of[i] - oc[i]).abs().max()))
+            assert torch.equal(rf[i], rc[i]) and torch.equal(df[i], dc[i]), (name, "compiled rew", t, i, float((rf[i] - rc[i]).abs().max()))
+    assert progc.program_compiled
 
 
 @pytest.mark.gpu
@@ -255,6 +261,92 @@ def test_program_env_auto_reset_and_graphed_step():
         og, rg, _, _ = gs.step(act)
         oe, re_, _, _ = e3.step(act)
         assert all(torch.equal(a, b) for a, b in zip(og + rg, oe + re_)), t
+
+
+@pytest.mark.gpu
+def test_compiled_custom_scenario_equals_the_interpreted_one_and_falls_back_when_constants_change():
+    """examples/corral.py compiled in: rows / rewards / state == the interpreted program's to the bit, also through the
+    done_callback + auto_reset launch (mpe_episode_finish runs the image too) and a GraphedStep.  An edited constant (an
+    agent resized) no longer equals what the image was compiled for: steps fall back to the interpreter -- still equal to a
+    fresh interpreted env with the same edit -- until compile_program() is called again."""
+    B = 3000
+    kw = dict(max_episode_steps=6, auto_reset=True, done_callback=_strayed)
+    a, b = corral_env(B, **kw), corral_env(B, **kw)
+    assert a.compile_program() and a.program_compiled and not b.program_compiled
+    rs = np.random.RandomState(3)
+    a.reset(), b.reset()
+
+    def same(t):
+        act = rand_actions(a, rs, B)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(a.world.pos, b.world.pos) and torch.equal(a.world.vel, b.world.vel), t
+        assert torch.equal(a.episode_step, b.episode_step) and torch.equal(a.world.choice_i32, b.world.choice_i32), t
+        assert all(torch.equal(x, y) for x, y in zip(oa + ra + da, ob + rb + db)), t
+    for t in range(14):
+        if t == 4:
+            for e in (a, b):
+                e.world.pos.mul_(0.3)
+        same(t)
+    for e in (a, b):
+        e.world.agents[1].size = 0.11
+    same("edited")
+    assert not a.program_compiled                      # the image is for the old size: interpreted now
+    assert a.compile_program() and a.program_compiled  # a new image for the new constants
+    for t in range(4):
+        same(("recompiled", t))
+    c, d = corral_env(B), corral_env(B)
+    assert c.compile_program()
+    c.reset(), d.reset()
+    gs = mpe.GraphedStep(c, rand_actions(c, rs, B))
+    for t in range(4):
+        act = rand_actions(c, rs, B)
+        og, rg, _, _ = gs.step(act)
+        oe, re_, _, _ = d.step(act)
+        assert all(torch.equal(x, y) for x, y in zip(og + rg, oe + re_)), t
+
+
+@pytest.mark.gpu
+def test_an_image_of_another_program_is_refused():
+    a, b = corral_env(64), make_spec_env("simple_spread", 64)
+    from multiagent_particle_envs_amd import _build
+    image = _build.compile_rows_image(a._prog.static_source(a._desc))
+    buf = C.create_string_buffer(image, len(image))
+    rc = _abi.lib().mpe_rows_load_image(C.byref(b._desc), b._prog.ref, b._prog.ops_host, buf, len(image))
+    assert rc == -1 and b"compiled for another program" in _abi.lib().mpe_last_error()      # MPE_EINVAL
+    assert not b.program_compiled
+    with pytest.raises(_abi.MpeError, match="not through a row program"):
+        mpe.make_env("simple_spread", batch_size=64).compile_program()
+
+
+def test_static_source_and_image_of_a_program_on_the_cpu():
+    """The generator and the compile need no GPU: the header names the kernels by a hash of (dims, tables, ops, waves), the
+    code object holds the four entry points under that name; an edited constant gives another name."""
+    env = make_spec_env("simple_tag", 4, device="cpu")
+    src = env._prog.static_source(env._desc)
+    name = [l.split()[2] for l in src.splitlines() if l.startswith("#define MPE_ROWS_STATIC_NAME")][0]
+    assert name.startswith("mpe_rows_") and len(name) == 9 + 16
+    for key in ("MPE_ROWS_STATIC_DIMS", "MPE_ROWS_STATIC_TABLES", "MPE_ROWS_STATIC_OPS", "MPE_ROWS_STATIC_WAVES_STEP", "MPE_ROWS_STATIC_WAVES_ROWS",
+                "MPE_ROWS_STATIC_LDS_STEP", "MPE_ROWS_STATIC_LDS_ROWS"):
+        assert "#define %s " % key in src
+    assert src.count("{") - 3 == env._prog.n_ops + 1          # one {a, b, c, d} per op (+ the dims' region pair)
+    from multiagent_particle_envs_amd import _build
+    image = _build.compile_rows_image(src)
+    for suffix in ("_ns", "_ps", "_nr", "_pr"):
+        assert (name + suffix).encode() in image
+    assert _build.compile_rows_image(src) == image            # cached by content
+    env.world.agents[0].size = 0.2
+    env.refresh_constants()
+    other = env._prog.static_source(env._desc)
+    assert [l for l in other.splitlines() if "STATIC_NAME" in l] != [l for l in src.splitlines() if "STATIC_NAME" in l]
+    assert not env._prog.image_active(env._desc)
+
+
+def test_a_program_of_too_many_ops_stays_interpreted():
+    env = make_spec_env("simple_adversary", 4, device="cpu", scenario_kw={"num_agents": 30, "num_adversaries": 9})
+    assert env._prog.n_ops > 512
+    with pytest.raises(_abi.MpeError, match="stay interpreted"):
+        env._prog.static_source(env._desc)
 
 
 def _strayed(agent, world):

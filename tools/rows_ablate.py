@@ -85,6 +85,12 @@ def main():
                               ("+ the reward programs (= the full step)", True, True), ("reward programs without the observation programs", False, True)):
             env = variant(name, B, ko, kr, kw)
             rows.append((label, time_env(env, B), env._prog.n_ops))
+            if ko and kr:      # the full step once more, the program compiled in (env.compile_program())
+                try:
+                    if env.compile_program():
+                        rows.append(("   the same, the program COMPILED IN", time_env(env, B), env._prog.n_ops))
+                except _abi.MpeError as err:
+                    rows.append(("   (not compiled: %s)" % str(err)[:60], float("nan"), env._prog.n_ops))
         fused = None
         try:
             e = mpe.make_env(name, batch_size=B, **(kw or {}))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """What a USER scenario costs per step on each path (round-4): env-steps/s at 65 536 worlds of
 
-    program   obs_spec / reward_spec -> World.step + mpe_rows: 2 launches per step (eager env.step, and GraphedStep)
+    program   obs_spec / reward_spec -> mpe_step_rows: 1 launch per step, the program interpreted (eager env.step, and GraphedStep)
+    compiled  the same program compiled in (env.compile_program(): mpe_rows_static_source -> hipcc --genco -> mpe_rows_load_image)
     generic   torch observation / reward callbacks over mpe_world_step: ~100 launches (eager, and GraphedStep)
     fused     the built-in's own kernel: 1 launch (built-ins only)
 
@@ -22,6 +23,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import multiagent_particle_envs_amd as mpe  # noqa: E402
+from multiagent_particle_envs_amd import _abi  # noqa: E402
 import test_rowspec as tr  # noqa: E402
 
 
@@ -70,12 +72,19 @@ def main():
     ap.add_argument("--scenarios", default="corral,simple_spread,simple_tag,simple_world_comm")
     ap.add_argument("--no-generic", action="store_true")
     ap.add_argument("--eager-only", action="store_true")
+    ap.add_argument("--compiled", action="store_true", help="add a row per program with the program compiled in")
     args = ap.parse_args()
     EAGER_ONLY = args.eager_only
     B, out = args.batch, []
     for name in args.scenarios.split(","):
         if name == "corral":
             measure("corral  program (1 launch) ", tr.corral_env(B), B, args.steps, out)
+            if args.compiled:
+                e = tr.corral_env(B)
+                t0 = time.perf_counter()
+                assert e.compile_program()
+                sys.stderr.write("corral: compile_program %.1f s\n" % (time.perf_counter() - t0))
+                measure("corral  program COMPILED IN", e, B, args.steps, out)
             measure("corral  generic (torch callbacks)", tr.corral_env(B, fused=False), B, max(50, args.steps // 8), out)
         else:       # name[:key=value ...]: scenario kwargs (team sizes)
             parts = name.split(":")
@@ -85,6 +94,16 @@ def main():
             if e._prog is None and e.fused:
                 measure("%-18s fused (1 launch)" % tag, e, B, args.steps, out)
             measure("%-18s program (1 launch) " % tag, tr.make_spec_env(name, B, scenario_kw=kw), B, args.steps, out)
+            if args.compiled:
+                e = tr.make_spec_env(name, B, scenario_kw=kw)
+                t0 = time.perf_counter()
+                try:
+                    ok = e.compile_program()
+                    sys.stderr.write("%s: compile_program %.1f s, %d ops\n" % (tag, time.perf_counter() - t0, e._prog.n_ops))
+                    assert ok
+                    measure("%-18s program COMPILED IN" % tag, e, B, args.steps, out)
+                except _abi.MpeError as err:
+                    sys.stderr.write("%s: not compiled: %s\n" % (tag, err))
             if not args.no_generic:
                 measure("%-18s generic (torch callbacks)" % tag, mpe.make_env(name, batch_size=B, fused=False, **kw), B, max(50, args.steps // 8), out)
     print("# env-steps/s at %d worlds per path (tools/rowspec_rate.py); best of 3 x %d steps, reset every 25 in the eager rows" % (B, args.steps))
