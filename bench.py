@@ -614,15 +614,23 @@ def per_gpu_stats(recs):
 
 def user_scenario_leg(torch, mpe, B, EP):
     """A scenario WITHOUT a kernel of its own (examples/corral.py: 3 agents, 3 posts, a per-world gate), stepped from Python
-    through the drop-in API: described by ObsSpec / RewardSpec (World.step + the interpreted rows in one launch,
-    mpe_step_rows) and, beside it, through its torch callbacks (the generic path: ~100 launches per step)."""
+    through the drop-in API: described by ObsSpec / RewardSpec (World.step + the rows in one launch, mpe_step_rows -- the program
+    interpreted, and compiled in) and, beside it, through its torch callbacks (the generic path: ~100 launches per step)."""
     path = os.path.join(ROOT, "examples", "corral.py")
     out = {"what": "examples/corral.py (a user scenario, no kernel of its own) from Python, env.step / env.reset every %d steps, %d worlds: "
-                   "`program` = obs_spec / reward_spec interpreted by mpe_step_rows (one launch per step); `generic` = the same "
-                   "scenario's torch observation / reward callbacks over mpe_world_step" % (EP or 25, B)}
+                   "`program` = obs_spec / reward_spec interpreted by mpe_step_rows (one launch per step); `compiled` = the same program "
+                   "compiled in (env.compile_program(): mpe_rows_static_source -> hipcc --genco -> mpe_rows_load_image; bit-identical "
+                   "results); `generic` = the same scenario's torch observation / reward callbacks over mpe_world_step" % (EP or 25, B)}
     g = torch.Generator(device="cpu").manual_seed(0)
-    for key, kw, n in (("program", {}, 2000), ("generic", {"fused": False}, 60)):
+    for key, kw, n in (("program", {"compile_program": False}, 2000), ("compiled", {"compile_program": False}, 2000),
+                       ("generic", {"fused": False}, 60)):
         env = mpe.make_env(path, batch_size=B, **kw)
+        if key == "compiled":
+            t0 = time.perf_counter()
+            ok = env.compile_program()
+            out["compile_program_s"] = time.perf_counter() - t0      # (0.0x s when lib/rows_cache/ already holds the image)
+            if not ok:
+                raise RuntimeError("compile_program() did not activate the image")
         acts = [torch.nn.functional.one_hot(torch.randint(0, 5, (env.n, B), generator=g), 5).float().cuda() for _ in range(4)]
         if not env.fused:
             acts = [[a[i] for i in range(env.n)] for a in acts]
@@ -641,9 +649,11 @@ def user_scenario_leg(torch, mpe, B, EP):
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         out[key] = {"value": B * n / best, "unit": "env-steps/s", "us_per_step": best / n * 1e6, "steps": n,
-                    "path": "mpe_step_rows" if env.fused else "torch callbacks + mpe_world_step"}
+                    "path": ("mpe_step_rows, compiled image" if env.program_compiled else "mpe_step_rows, interpreted") if env.fused
+                            else "torch callbacks + mpe_world_step"}
         del env
     out["program_over_generic"] = out["program"]["value"] / out["generic"]["value"]
+    out["compiled_over_generic"] = out["compiled"]["value"] / out["generic"]["value"]
     return out
 
 

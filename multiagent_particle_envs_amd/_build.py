@@ -47,27 +47,48 @@ AB_VARIANTS = {"teamgrid": ["-DMPE_SPLIT_TEAM_GRID"], "rowsclock": ["-DMPE_ROWS_
 ROWS_CACHE = os.path.join(LIBDIR, "rows_cache")      # compiled row programs: <sha256 of header + sources + flags>.hsaco
 
 
+_rows_sources_digest = None
+
+
+def _rows_image_path(header_text):
+    """lib/rows_cache/<sha256(header, mpe_rows.hip + its headers, flags)>.hsaco, and the flags"""
+    global _rows_sources_digest
+    import hashlib
+    flags = [f for f in FLAGS if f not in ("-fPIC", "-save-temps=obj", "-Wall")]
+    if _rows_sources_digest is None:
+        h = hashlib.sha256()
+        for f in [os.path.join(CSRC, "mpe_rows.hip")] + [os.path.join(CSRC, x) for x in HEADERS]:
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+        h.update(" ".join(flags).encode())
+        _rows_sources_digest = h.digest()
+    h = hashlib.sha256(_rows_sources_digest)
+    h.update(header_text.encode())
+    return os.path.join(ROWS_CACHE, h.hexdigest()[:32] + ".hsaco"), flags
+
+
+def cached_rows_image(header_text):
+    """The code object of a compiled row program if lib/rows_cache/ holds it (never runs hipcc), else None."""
+    out, _ = _rows_image_path(header_text)
+    if not os.path.exists(out):
+        return None
+    with open(out, "rb") as fh:
+        return fh.read()
+
+
 def compile_rows_image(header_text, verbose=False):
     """A row program compiled in: csrc/mpe_rows.hip built with the generated header (mpe_rows_static_source) as a gfx950 code
     object (`hipcc --genco`, the library's own flags: same arithmetic, same kernarg preload) -> its bytes, for
     mpe_rows_load_image.  Cached by content under lib/rows_cache/ (travels with the tree; delete at will)."""
-    import hashlib
-    src = os.path.join(CSRC, "mpe_rows.hip")
-    flags = [f for f in FLAGS if f not in ("-fPIC", "-save-temps=obj", "-Wall")]
-    h = hashlib.sha256()
-    h.update(header_text.encode())
-    for f in [src] + [os.path.join(CSRC, x) for x in HEADERS]:
-        with open(f, "rb") as fh:
-            h.update(fh.read())
-    h.update(" ".join(flags).encode())
-    os.makedirs(ROWS_CACHE, exist_ok=True)
-    out = os.path.join(ROWS_CACHE, h.hexdigest()[:32] + ".hsaco")
+    out, flags = _rows_image_path(header_text)
     if not os.path.exists(out):
+        os.makedirs(ROWS_CACHE, exist_ok=True)
         hdr = out[:-6] + ".h"
         with open(hdr, "w") as fh:
             fh.write(header_text)
         tmp = out + ".tmp%d" % os.getpid()
-        cmd = [_hipcc(), "--genco"] + flags + ["-include", hdr, "-I", CSRC, "-I", os.path.join(HERE, "..", "include"), src, "-o", tmp]
+        cmd = [_hipcc(), "--genco"] + flags + ["-include", hdr, "-I", CSRC, "-I", os.path.join(HERE, "..", "include"),
+                                               os.path.join(CSRC, "mpe_rows.hip"), "-o", tmp]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -130,47 +151,53 @@ def build(force=False, verbose=True, variants=True, ab=()):
         if verbose and r.stderr.strip():
             print(r.stderr[-4000:])
 
-    # ---- the product library -------------------------------------------------------------------------------------------
+    # ---- every compile job (product + variants) in ONE pool, the long ones (mpe_split: ~29 s) first; the product library is
+    # linked as soon as its own objects exist, the variants after theirs
+    long_first = {"mpe_split.hip": 0, "mpe_narrow.hip": 1}
     jobs, objs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    _drop_temps(OBJ)
-    if not variants:
-        return LIB
-    # ---- test-only variants of the role-split kernels (tests/test_gpu_race.py): one wave of every workgroup is held back
+            jobs.append((long_first.get(src, 2), "product", [hipcc] + FLAGS + ["-c", s, "-o", o]))
+    # test-only variants of the role-split kernels (tests/test_gpu_race.py): one wave of every workgroup is held back
     # (MPE_STRESS_DELAY_WAVE: ~30 us before its first load in k_split / k_duo, a few us at every step of k_duo_roll);
     # "_racy" additionally restores the store-before-barrier ordering the round-1 k_split had, as the negative control
     # that shows the test can fail
-    jobs, todo = [], []
-    wanted = dict(STRESS_VARIANTS)
+    todo = []
+    wanted = dict(STRESS_VARIANTS) if variants else {}
     wanted.update({t: AB_VARIANTS[t] for t in ab})
+    vflags = [f for f in FLAGS if f != "-save-temps=obj"]      # (no assembly kept for the variants)
     for tag, defs in wanted.items():
         vo = {}
         for stem in VARIANT_SOURCES.get(tag, STRESS_SOURCES):      # the kernel files that carry the variant's hooks
             src = os.path.join(CSRC, "mpe_%s.hip" % stem)
-            os.makedirs(os.path.join(OBJ, tag), exist_ok=True)     # own directory: -save-temps names its files after the source
+            os.makedirs(os.path.join(OBJ, tag), exist_ok=True)
             o = os.path.join(OBJ, tag, "mpe_%s.o" % stem)
             vo["mpe_%s.o" % stem] = o
             if force or _stale(o, [src] + hdrs):
-                jobs.append([hipcc] + FLAGS + defs + ["-c", src, "-o", o])
+                jobs.append((long_first.get("mpe_%s.hip" % stem, 2), tag, [hipcc] + vflags + defs + ["-c", src, "-o", o]))
         todo.append((tag, vo))
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        list(ex.map(run, jobs))
-    for tag in wanted:
-        _drop_temps(os.path.join(OBJ, tag), keep_asm=False)
-    for tag, vo in todo:
-        vlib = variant_lib(tag)
-        vobjs = [vo.get(os.path.basename(x), x) for x in objs]
-        if force or _stale(vlib, vobjs):
-            run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", vlib] + vobjs)
+    jobs.sort(key=lambda j: j[0])
+    with ThreadPoolExecutor(max_workers=max(4, os.cpu_count() or 4)) as ex:
+        futs = [(tag, ex.submit(run, cmd)) for _, tag, cmd in jobs]
+        for tag, f in futs:
+            if tag == "product":
+                f.result()       # a product compile error surfaces here, before anything is linked
+        if force or any(t == "product" for t, _ in futs) or _stale(LIB, objs):
+            run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        _drop_temps(OBJ)
+        for tag, f in futs:      # (a compile failure in a variant cannot keep the product from being linked: it is, by now)
+            f.result()
+        links = []
+        for tag, vo in todo:
+            vlib = variant_lib(tag)
+            vobjs = [vo.get(os.path.basename(x), x) for x in objs]
+            if force or _stale(vlib, vobjs):
+                links.append(ex.submit(run, [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", vlib] + vobjs))
+        for f in links:
+            f.result()
     return LIB
 
 

@@ -1,6 +1,7 @@
-// mpe_rows.hip -- the composable output stage: Scenario.observation / reward of a USER scenario as a small program the
-// kernel interprets (mpe_rows), so that a scenario nobody wrote a kernel for still steps in two launches
-// (mpe_world_step + mpe_rows) instead of the generic path's hundred-odd torch launches.
+// mpe_rows.hip -- the composable output stage: Scenario.observation / reward of a USER scenario as a small program, so that
+// a scenario nobody wrote a kernel for still steps in ONE launch (mpe_step_rows) instead of the generic path's hundred-odd
+// torch launches -- interpreted op by op, or, for a program that stays the same, compiled in (the same body with the
+// program as constants: MPE_ROWS_STATIC below).
 //
 // What a reference observation is made of (simple_spread.py:84-100, simple_tag.py:131-147, simple_adversary.py:121-139,
 // simple_push.py:78-96, simple_speaker_listener.py:69-92, simple_reference.py:63-83, simple_crypto.py:127-169,
@@ -9,7 +10,7 @@
 // one-hot / colour of a per-world pick, constants, and simple_world_comm's forest visibility.  And a reference reward is
 // an ordered sum of a few TERM kinds -- (minimum) distances, strict-< contact tests, the boundary penalty, squared
 // utterance errors -- in an order that fixes the rounding.  A program is that list, 16 bytes per op, built on the host
-// from ObsSpec / RewardSpec objects (multiagent_particle_envs_amd/rowspec.py); no JIT, no code generation.
+// from ObsSpec / RewardSpec objects (multiagent_particle_envs_amd/rowspec.py).
 //
 // Shape of the kernel (E = A + L <= 64): a workgroup is 64 worlds x W waves (W <= min(A, 16)), lane = world.
 //   all waves    stage the worlds' state in LDS once -- pos [E][2][64], vel [n_vel][2][64]: coalesced 256-byte loads; every
@@ -19,11 +20,13 @@
 //                its columns to the wave's LDS tile ([64][D] row-major = the output segment), the tile leaves as contiguous
 //                16-byte stores -- and its reward program (two accumulators, one value register, eight slots); behind one
 //                barrier the shared-reward sum (environment.py:100-102) in the reference's order.
-// The program (ops) and its tables (sizes, masses, row offsets, program ranges) are copied from device memory into LDS by
-// every workgroup, in the same round trip as the state: an op or a table entry is then a broadcast LDS read, not a scalar
-// memory load (first version: 33 scalar loads per wave, each a dependent ~200-cycle round trip: 70 % of a wave's life).
+// Interpreted: the ops and the per-entity tables (sizes, masses, row offsets, program ranges) sit in device memory and are
+// read by scalar loads, one op ahead.  (Staging them in LDS per workgroup, and two waves per agent, were both measured
+// slower: profiles/r4_ab_logs.txt.)  The interpreter costs 3-4x the instructions of a fused kernel (1350 scalar + 560 vector
+// per wave against 165 + 158 for simple_spread): 13.4 us per launch at 65 536 worlds where the fused kernel takes 5.5.
+// Compiled in: 5.8 us.
 // Arithmetic is the device functions of mpe_device.h (sq2d, sqrt_lt, fast_sqrt, tag_bound) in program order: a built-in
-// scenario written as a program reproduces its fused kernel bit for bit (tests/test_gpu_rowspec.py).
+// scenario written as a program reproduces its fused kernel bit for bit, interpreted and compiled (tests/test_rowspec.py).
 #include "mpe_internal.h"
 
 // instrumented build (-DMPE_ROWS_CLOCK, tools/rows_clock.py): lane 0 of every wave of the first 8 workgroups stamps the
@@ -150,10 +153,9 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   const unsigned ln = (unsigned)(live ? lane : nvalid - 1) & 63u;
 
   MPE_RSTAMP(0);
-  // LDS: [tables | ops] (read-only after the first barrier), then the state and the per-wave scratch
-  // the per-entity tables and the ops stay in device memory and are read with scalar loads (uniform addresses): staging them
-  // in LDS per workgroup measured 7 % slower at 65 536 worlds (one more dependent load + barrier in front of every wave) and
-  // halves the waves of the largest programs
+  // the per-entity tables and the ops: device memory read with scalar loads (uniform addresses) -- staging them in LDS per
+  // workgroup measured 7 % slower at 65 536 worlds (one more dependent load + barrier in front of every wave) and halves the
+  // waves of the largest programs --, or constants of the image (STATIC)
   const int4 *const ops_d = reinterpret_cast<const int4 *>(ops_g);
   auto OP = [&](int pc) { if constexpr (STATIC) return static_op(pc); else return ops_d[pc]; };
   auto TU = [&](int k) { if constexpr (STATIC) return static_tab(k); else return tables[k]; };

@@ -103,8 +103,11 @@ class MultiAgentEnv(object):
     def __init__(self, world, reset_callback=None, reward_callback=None, observation_callback=None,
                  info_callback=None, done_callback=None, shared_viewer=True,
                  numpy_io=False, fresh_outputs=False, fused=None, max_episode_steps=None, auto_reset=False,
-                 probe_placement=True):
+                 probe_placement=True, compile_program=None):
         self.world = world
+        # a row program compiled in (compile_program()): None = attach an image lib/rows_cache/ already holds, never run
+        # hipcc; True = compile whenever the program or its constants are new; False = always interpret
+        self.compile_program_policy = compile_program
         self.probe_placement = bool(probe_placement)
         self.placement_probe = None
         self.agents = self.world.policy_agents
@@ -210,6 +213,7 @@ class MultiAgentEnv(object):
         self.observation_space = []
         if self._prog is not None:
             self._desc = self._program_desc()
+            self._attach_program_image()
             self._obs_off = [int(self._desc.obs_off[i]) for i in range(len(world.agents) + 1)]
             obs_dims = list(self._prog.widths)
         elif self.fused:
@@ -280,6 +284,7 @@ class MultiAgentEnv(object):
         if self.fused:
             self._desc = self._program_desc() if self._prog is not None else \
                 w.scenario_desc(self._kind, getattr(self._scenario, "num_adversaries", 0))
+            self._attach_program_image()
             if self._sets is not None:
                 self._entity_table = w.entity_table(self._desc)
                 self._desc_ref = C.byref(self._desc)
@@ -307,6 +312,22 @@ class MultiAgentEnv(object):
             return L.mpe_world_step(desc_ref, bufs_ref, B, st) or L.mpe_rows(desc_ref, bufs_ref, self._prog.ref, B, st)
         return L.mpe_step_rows(desc_ref, bufs_ref, self._prog.ref, B, st)
 
+    def _attach_program_image(self):
+        """After the descriptor of a row-program env was (re)built: bring the compiled image in line with the policy."""
+        prog = self._prog
+        if prog is None or self.world.device.type != "cuda":
+            return
+        pol = self.compile_program_policy
+        try:
+            if pol is False:
+                prog.unload()
+            elif not prog.image_active(self._desc):
+                prog.compile(self._desc, cached_only=pol is None)
+        except _abi.MpeError:
+            if pol:          # asked for explicitly: say why not
+                raise
+            # (None: a program that cannot be compiled in -- more than MPE_ROWS_STATIC_MAX_OPS ops -- runs interpreted)
+
     def compile_program(self, verbose=False):
         """Compile this env's row program IN (`mpe_rows_static_source` -> hipcc --genco -> `mpe_rows_load_image`; a few
         seconds the first time, cached by content under lib/rows_cache/): `step()` then launches the program as straight-line
@@ -317,6 +338,8 @@ class MultiAgentEnv(object):
         if self._prog is None:
             raise _abi.MpeError("compile_program: this env steps through %s, not through a row program"
                                 % ("a fused kernel" if self.fused else "its scenario's torch callbacks"))
+        if self.compile_program_policy is False:
+            self.compile_program_policy = None
         self.refresh_constants()
         self._prog.compile(self._desc, verbose=verbose)
         return self._prog.image_active(self._desc)
@@ -625,6 +648,11 @@ class MultiAgentEnv(object):
                 prog = rowspec.builtin_program(name, self.world)
                 if list(prog.widths) == [self._obs_off[i + 1] - self._obs_off[i] for i in range(len(prog.widths))]:
                     prog.validate(self._desc)
+                    if self.compile_program_policy is not False and self.world.device.type == "cuda":
+                        try:
+                            prog.compile(self._desc, cached_only=self.compile_program_policy is None)
+                        except _abi.MpeError:
+                            pass
                     self._finish_prog = prog
         return self._finish_prog or None
 

@@ -18,7 +18,7 @@ Everything on the step path runs in libmpe_hip.so on a HIP device; there is no C
 
 
 def make_env(scenario_name, benchmark=False, batch_size=None, device=None, seed=0, fresh_outputs=False,
-             fused=None, max_episode_steps=None, auto_reset=False, probe_placement=True, **scenario_kwargs):
+             fused=None, max_episode_steps=None, auto_reset=False, probe_placement=True, compile_program=None, **scenario_kwargs):
     from .environment import MultiAgentEnv
     from . import scenarios
 
@@ -43,6 +43,7 @@ def make_env(scenario_name, benchmark=False, batch_size=None, device=None, seed=
     # (a scenario that DESCRIBES its rows -- obs_spec / reward_spec, rowspec.py -- need not have Python callbacks at all)
     env = MultiAgentEnv(world, scenario.reset_world, getattr(scenario, "reward", None), getattr(scenario, "observation", None), info_cb,
                         numpy_io=compat, fresh_outputs=fresh_outputs or compat, fused=fused,
-                        max_episode_steps=max_episode_steps, auto_reset=auto_reset, probe_placement=probe_placement)
+                        max_episode_steps=max_episode_steps, auto_reset=auto_reset, probe_placement=probe_placement,
+                        compile_program=compile_program)
     env.scenario = scenario
     return env

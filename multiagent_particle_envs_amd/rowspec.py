@@ -434,11 +434,15 @@ class RowProgram(object):
         _abi.check(L.mpe_rows_static_source(C.byref(desc), self.ref, self.ops_host, buf, need.value, None), "mpe_rows_static_source")
         return buf.value.decode()
 
-    def compile(self, desc, verbose=False):
+    def compile(self, desc, verbose=False, cached_only=False):
         """Compile the program in for THIS descriptor (hipcc --genco, cached by content under lib/rows_cache/) and attach it:
-        mpe_rows / mpe_step_rows / mpe_episode_finish launch the image while the descriptor stays what it was compiled for."""
+        mpe_rows / mpe_step_rows / mpe_episode_finish launch the image while the descriptor stays what it was compiled for.
+        cached_only: attach an image the cache already holds, never run hipcc; returns 0 when there is none."""
         from . import _build
-        image = _build.compile_rows_image(self.static_source(desc), verbose=verbose)
+        src = self.static_source(desc)
+        image = _build.cached_rows_image(src) if cached_only else _build.compile_rows_image(src, verbose=verbose)
+        if image is None:
+            return 0
         self._image = C.create_string_buffer(image, len(image))
         _abi.check(_abi.lib().mpe_rows_load_image(C.byref(desc), self.ref, self.ops_host, self._image, len(image)), "mpe_rows_load_image")
         return len(image)

@@ -51,6 +51,7 @@ def make_spec_env(name, B, device=None, seed=0, scenario_kw=None, **kw):
     w.seed = seed
     if w.pos.is_cuda:
         sc.reset_world(w)          # as make_env does (the reference's make_world ends with reset_world): same episode numbering
+    kw.setdefault("compile_program", False)      # interpreted unless a test compiles it in (a cached image would attach itself)
     env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, **kw)
     env.scenario = sc
     return env
@@ -123,6 +124,7 @@ def corral_env(B, fused=None, device=None, **kw):
     sc = Corral()
     w = sc.make_world(batch_size=B, device=device) if device else sc.make_world(batch_size=B)
     w.seed = 3
+    kw.setdefault("compile_program", False)
     env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, fused=fused, **kw)
     env.scenario = sc
     return env
@@ -304,6 +306,25 @@ def test_compiled_custom_scenario_equals_the_interpreted_one_and_falls_back_when
         og, rg, _, _ = gs.step(act)
         oe, re_, _, _ = d.step(act)
         assert all(torch.equal(x, y) for x, y in zip(og + rg, oe + re_)), t
+
+
+@pytest.mark.gpu
+def test_a_cached_image_attaches_itself_and_a_missing_one_does_not_start_hipcc(tmp_path, monkeypatch):
+    from multiagent_particle_envs_amd import _build
+    warm = corral_env(64)
+    assert warm.compile_program()                               # the cache holds Corral's image now
+    assert corral_env(64, compile_program=None).program_compiled            # default policy: found, attached
+    assert not corral_env(64, compile_program=False).program_compiled
+    monkeypatch.setattr(_build, "ROWS_CACHE", str(tmp_path))    # an empty cache
+    monkeypatch.setattr(_build, "_hipcc", lambda: (_ for _ in ()).throw(AssertionError("hipcc must not run")))
+    assert not corral_env(64, compile_program=None).program_compiled        # nothing cached: interpreted, no compiler
+    monkeypatch.undo()
+    e = corral_env(64, compile_program=True)
+    assert e.program_compiled
+    e.world.agents[0].size = 0.07                               # policy True: a new image with the new constants at the next step
+    e.reset()
+    e.step(rand_actions(e, np.random.RandomState(0), 64))
+    assert e.program_compiled
 
 
 @pytest.mark.gpu
