@@ -624,7 +624,7 @@ static bool image_matches(const MpeRowProgram *p, const mpe::RowDims &h, uint64_
 static int static_identity(const char *what, const mpe::RowDims &h, const mpe::RowTables &tabs, const int32_t *ops, int waves[2],
                            size_t lds[2], char name[40]) {
   for (int phys = 0; phys < 2; ++phys)
-    if (int rc = mpe::rows_geometry(h, phys != 0, &waves[phys], &lds[phys]))
+    if (int rc = mpe::rows_geometry(h, phys != 0, &waves[phys], &lds[phys], 0))
       return fail(rc, "%s: the program does not fit a workgroup's LDS", what);
   if (h.n_ops > MPE_ROWS_STATIC_MAX_OPS)
     return fail(MPE_EUNSUPPORTED, "%s: %d ops; programs of more than %d ops stay interpreted (every op becomes code: compile time and "
@@ -775,6 +775,7 @@ int mpe_rows_load_image(const MpeScenarioDesc *d, MpeRowProgram *p, const int32_
   std::memset(static_cast<void *>(im), 0, sizeof(*im));
   hipError_t rc = hipModuleLoadData(&im->module, image);
   if (rc != hipSuccess) {
+    (void)hipGetLastError();
     delete im;
     return fail((int)rc, "%s: hipModuleLoadData: %s", what, hipGetErrorString(rc));
   }
@@ -785,6 +786,7 @@ int mpe_rows_load_image(const MpeScenarioDesc *d, MpeRowProgram *p, const int32_
     rc = hipModuleGetFunction(&f, im->module, fn.c_str());
     if (rc != hipSuccess || !f) {
       (void)hipModuleUnload(im->module);
+      (void)hipGetLastError();      // (the failed lookup is reported through our return code, not left behind for the next HIP call)
       delete im;
       return fail(MPE_EINVAL, "%s: the image has no kernel %s: it was compiled for another program, descriptor or library version", what, fn.c_str());
     }

@@ -614,12 +614,13 @@ int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream) {
 // LDS: the staged state + reward scratch, and one [64][d_max] tile + eight slots per wave -- as many waves as fit (each
 // wave takes its share of the agents in turn), at most one per agent and 16; past 4 waves stay within 64 KB (two workgroups
 // per CU).  One function for the launch and for the generator of compiled programs (the wave count is a constant there).
-int rows_geometry(const RowDims &h, bool phys, int *waves, size_t *lds_bytes) {
+int rows_geometry(const RowDims &h, bool phys, int *waves, size_t *lds_bytes, int max_waves) {
   constexpr size_t kLdsCap = 160 * 1024;
   const size_t fixed = sizeof(float) * (size_t)(2 * h.n_entities + 2 * h.n_vel + h.n_agents + kRowPicks + (phys ? 4 * h.n_agents : 0)) * kWave;
   const size_t per_wave = sizeof(float) * (size_t)kWave * ((size_t)h.d_max + kRowSlots);
   if (fixed + per_wave > kLdsCap) return MPE_EUNSUPPORTED;
   int W = h.n_agents < kRowMaxObsWaves ? h.n_agents : kRowMaxObsWaves;
+  if (max_waves > 0 && W > max_waves) W = max_waves;
   while (W > 1 && fixed + (size_t)W * per_wave > (W > 4 ? 64u * 1024u : kLdsCap)) --W;
   *waves = W;
   *lds_bytes = fixed + (size_t)W * per_wave;
@@ -635,7 +636,10 @@ int launch_rows(const MpeBuffers &b, const RowDims &h, const RowTables &host, co
                 const RowEpisode &ep, const int32_t *ops_device, size_t B, hipStream_t stream) {
   int W = 0;
   size_t lds = 0;
-  if (int rc = rows_geometry(h, phys, &W, &lds)) return rc;
+  // (episode mode, mpe_episode_finish, with ONE wave per 64 worlds -- most workgroups only read their flags and leave -- costs
+  //  the same 3.3 us after a step as with W waves: that launch sits on the dependent-launch floor either way, and the step at
+  //  which every world reaches the horizon wants the W waves: profiles/r4_finish_cost.txt)
+  if (int rc = rows_geometry(h, phys, &W, &lds, 0)) return rc;
   // (two waves per agent, rows || reward -- `split` -- measured slower, see rows_body; the kernel keeps the switch for the A/B)
   const unsigned grid = (unsigned)((B + kWave - 1) / kWave);
   const bool nt = rows_nontemporal(h, host, vec4, ep, B);
@@ -654,7 +658,7 @@ int launch_rows_image(void *const fns[4], const MpeBuffers &b, const RowDims &h,
                       const RowEpisode &ep, size_t B, hipStream_t stream) {
   int W = 0;
   size_t lds = 0;
-  if (int rc = rows_geometry(h, phys, &W, &lds)) return rc;
+  if (int rc = rows_geometry(h, phys, &W, &lds, 0)) return rc;
   const bool nt = rows_nontemporal(h, host, vec4, ep, B);
   hipFunction_t fn = static_cast<hipFunction_t>(fns[(phys ? 0 : 2) + (nt ? 0 : 1)]);
   MpeBuffers b_ = b;
