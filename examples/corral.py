@@ -1,7 +1,10 @@
 """A USER scenario written against this package's protocol, twice over (the example of scenario.py / rowspec.py):
 
-    obs_spec / reward_spec      the scenario DESCRIBES its rows and reward terms -> World.step + mpe_rows, two launches per step
+    obs_spec / reward_spec      the scenario DESCRIBES its rows and reward terms -> mpe_step_rows: one launch per step, interpreted,
+    [/ done_spec]               or -- env.compile_program() -- compiled in; with `arena` set, agents that leave it are done and, under
+                                auto_reset, their worlds restart inside the same launch (mpe_step_rows_episode)
     observation / reward        the same rows COMPUTED with torch ops on [B, .] views -> the generic path (~100 launches per step)
+    [/ done]
 
 `make_env("examples/corral.py", batch_size=B)` takes the specs (fused=False: the torch callbacks).  tests/test_rowspec.py holds the
 two against each other; tools/rowspec_rate.py and bench.py (`extra.user_scenario`) time them.
@@ -18,6 +21,7 @@ class Scenario(BaseScenario):
     torch callbacks (the generic path), so that the two can be held against each other."""
 
     landmark_range = 0.9       # reset_world places the posts in [-0.9, 0.9)^2 (read by the device-side resets too)
+    arena = None               # a bound (e.g. 0.95): an agent outside |x|, |y| <= arena is done (None: never, the reference's default)
 
     def make_world(self, batch_size=1, device=None):
         world = World(batch_size, device)
@@ -61,7 +65,15 @@ class Scenario(BaseScenario):
         r.bound(agent, 0).add(-1.0).bound(agent, 1).add(-1.0)
         return r
 
+    def done_spec(self, agent, world):
+        return rowspec.DoneSpec(world, agent).outside(agent, self.arena) if self.arena is not None else None
+
     # the same in torch (generic path)
+    def done(self, agent, world):
+        if self.arena is None:
+            return torch.zeros(world.batch_size, dtype=torch.bool, device=world.device)
+        return (agent.state.p_pos.abs() > self.arena).any(dim=1)
+
     def _gate(self, world):
         pos = torch.stack([l.state.p_pos for l in world.landmarks])           # [3, B, 2]
         g = world.choice_i32[0].long()

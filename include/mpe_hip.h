@@ -277,8 +277,14 @@ enum MpeRowOp {
   MPE_ROW_R_MIN_D2_RANGE = 48,    /* v = min over a in a0 .. a0 + w1 - 1 of |p[a] - p[a1]|^2, in that order     */
   MPE_ROW_R_MIN_D2_TO_RANGE = 49, /* v = min over b in a1 .. a1 + w1 - 1 of |p[a0] - p[b]|^2                     */
   MPE_ROW_R_ADD_IF_HIT_GRID = 50, /* for a in a0 .. a0 + (w1 & 255) - 1, b in a1 .. a1 + (w1 >> 8) - 1: ADD_IF_HIT(a, b, w2) */
-  MPE_ROW_R_ADD_MIN_DIST_GRID = 51 /* for b in a1 .. a1 + (w1 >> 8) - 1: v = sqrt(min over a in a0 .. a0 + (w1 & 255) - 1 of |p[a] - p[b]|^2);
+  MPE_ROW_R_ADD_MIN_DIST_GRID = 51,/* for b in a1 .. a1 + (w1 >> 8) - 1: v = sqrt(min over a in a0 .. a0 + (w1 & 255) - 1 of |p[a] - p[b]|^2);
                                       acc = acc + w2 * v   (simple_spread.py:72-77: minus the distance of the nearest agent, per landmark) */
+  /* ---- done programs (MpeRowProgram.done_begin): Scenario.done of a user scenario (environment.py:132-135: done_callback) as
+   * ordered tests on the same value machine; an agent's done = the OR of its tests (no test: False, the reference's default)  */
+  MPE_ROW_R_ABS_POS = 52,       /* v = |p[a0][a1]|  (coordinate a1 of entity a0)                          */
+  MPE_ROW_R_DONE_IF_GT = 53,    /* done = done or v > w2                                                  */
+  MPE_ROW_R_DONE_IF_LT = 54,    /* done = done or v < w2                                                  */
+  MPE_ROW_R_DONE_IF_HIT = 55    /* done = done or |p[a0] - p[a1]| < size[a0] + size[a1] (strict, exact)   */
 };
 /* Host POD describing one env's programs; the ops live in DEVICE memory the caller owns (uploaded once).               */
 #define MPE_ROWS_HEADER_BYTES 4096 /* >= the kernel-side header (row layout, program ranges, per-entity constants) */
@@ -297,6 +303,8 @@ typedef struct MpeRowProgram {
   int32_t region_entity[2];
   uint32_t all_seeing;        /* bit i: agent i sees everybody (simple_world_comm.py:253: the leader)   */
   void *image;                /* NULL, or what mpe_rows_load_image attached: the program compiled in (owned by the library)       */
+  int32_t done_begin[MPE_ROWS_MAX_ENTITIES + 1]; /* agent i's done ops: [done_begin[i], done_begin[i+1]) -- value ops and DONE_IF_*
+                                                    tests, run after its reward program on a fresh machine; all zero: no done programs */
 } MpeRowProgram;
 /* Checks a program against the descriptor (entity / pick / slot indices, row widths == obs_off): ops_host are the same
  * n_ops x 4 words in HOST memory.  0 or MPE_EINVAL with mpe_last_error() naming the op.                               */
@@ -319,6 +327,15 @@ int mpe_step_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowPro
 int mpe_episode_finish(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowProgram *prog, int64_t B,
                        int32_t *episode_step, int32_t max_episode_steps, float landmark_range, uint64_t seed,
                        uint64_t episode, int64_t world_offset, void *stream);
+/* mpe_step_rows_episode: mpe_step_rows and mpe_episode_finish in ONE launch, for a scenario whose done condition is part of
+ * the program (done_begin) or that ends at the horizon only: the step, every agent's row / reward / done, then -- in the same
+ * workgroup -- the step count, the finished worlds (an agent's done test fired, or max_episode_steps > 0 reached: done = 1 in
+ * every agent's row), and for those reset_world (the draws of mpe_reset(mask, landmark_range, seed, episode, world_offset))
+ * and the rows of the new episode's first state, exactly as the two calls would leave them.  A workgroup without a finished
+ * world is done after one more barrier: an episode end inside the launch costs a step that ends nothing about nothing.    */
+int mpe_step_rows_episode(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowProgram *prog, int64_t B,
+                          int32_t *episode_step, int32_t max_episode_steps, float landmark_range, uint64_t seed,
+                          uint64_t episode, int64_t world_offset, void *stream);
 
 /* ---- a row program COMPILED IN: the interpreter specialised away ---------------------------------------------------------
  * mpe_rows / mpe_step_rows / mpe_episode_finish interpret a program op by op.  For a program that stays the same for the

@@ -54,7 +54,11 @@ def _rows_image_path(header_text):
     """lib/rows_cache/<sha256(header, mpe_rows.hip + its headers, flags)>.hsaco, and the flags"""
     global _rows_sources_digest
     import hashlib
-    flags = [f for f in FLAGS if f not in ("-fPIC", "-save-temps=obj", "-Wall")]
+    _rows_sources_digest = None if os.environ.get("MPE_ROWS_IMAGE_FLAGS") else _rows_sources_digest
+    # (-pragma-unroll-threshold: the op loops of a compiled program MUST unroll -- every op a constant is the whole point -- and
+    #  LLVM refuses `#pragma unroll` past 16 K instructions of pre-folding body, which a 15-op reward program already exceeds)
+    flags = [f for f in FLAGS if f not in ("-fPIC", "-save-temps=obj", "-Wall")] + ["-mllvm", "-pragma-unroll-threshold=16777216"]
+    flags += os.environ.get("MPE_ROWS_IMAGE_FLAGS", "").split()      # (A/B builds of the images: part of the cache key)
     if _rows_sources_digest is None:
         h = hashlib.sha256()
         for f in [os.path.join(CSRC, "mpe_rows.hip")] + [os.path.join(CSRC, x) for x in HEADERS]:

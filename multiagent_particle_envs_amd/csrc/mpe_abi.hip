@@ -451,6 +451,15 @@ static int rows_header(const char *what, const MpeScenarioDesc *d, const MpeRowP
     if (p->rew_begin[i] < prev || p->rew_begin[i] > p->n_ops) return fail(MPE_EINVAL, "%s: rew_begin[%d] = %d out of order / range", what, i, p->rew_begin[i]);
     prev = p->rew_begin[i];
   }
+  bool has_done = false;
+  for (int i = 0; i <= A; ++i) has_done = has_done || p->done_begin[i] != 0;
+  if (has_done) {
+    prev = 0;
+    for (int i = 0; i <= A; ++i) {
+      if (p->done_begin[i] < prev || p->done_begin[i] > p->n_ops) return fail(MPE_EINVAL, "%s: done_begin[%d] = %d out of order / range", what, i, p->done_begin[i]);
+      prev = p->done_begin[i];
+    }
+  }
   if (p->n_regions > 0 && A > 32) return fail(MPE_EUNSUPPORTED, "%s: regions hide agents from each other for A <= 32 (got %d)", what, A);
   std::memset(h, 0, sizeof(*h));
   std::memset(t, 0, sizeof(*t));
@@ -485,6 +494,7 @@ static int rows_header(const char *what, const MpeScenarioDesc *d, const MpeRowP
     t->obs_off[i] = i <= A ? d->obs_off[i] : d->obs_off[A];
     t->obs_begin[i] = i <= A ? p->obs_begin[i] : p->obs_begin[A];
     t->rew_begin[i] = i <= A ? p->rew_begin[i] : p->rew_begin[A];
+    t->done_begin[i] = i <= A ? p->done_begin[i] : p->done_begin[A];
   }
   h->dt = d->dt;
   h->damp = 1.0f - d->damping;
@@ -548,12 +558,25 @@ int mpe_rows_validate(const MpeScenarioDesc *d, const MpeRowProgram *p, const in
     if (width != d->obs_off[i + 1] - d->obs_off[i])
       return fail(MPE_EINVAL, "%s: agent %d's program emits %d columns, desc->obs_off says %d", what, i, width, d->obs_off[i + 1] - d->obs_off[i]);
   }
+  for (int pass = 0; pass < 2; ++pass)      // 0: the reward programs, 1: the done programs (value ops + DONE_IF_* tests, no STORE)
   for (int i = 0; i < A; ++i) {
     bool stored = false;
-    for (int pc = p->rew_begin[i]; pc < p->rew_begin[i + 1]; ++pc) {
+    const int32_t *begin = pass ? p->done_begin : p->rew_begin;
+    for (int pc = begin[i]; pc < begin[i + 1]; ++pc) {
       const int32_t w0 = ops[4 * pc], w1 = ops[4 * pc + 1];
       const int code = w0 & 0xff, a0 = (w0 >> 8) & 0xff, a1 = (w0 >> 16) & 0xff;
+      if (pass && (code == MPE_ROW_R_STORE || code == MPE_ROW_R_ADD_IF_HIT || code == MPE_ROW_R_ADD_IF_HIT_GRID || code == MPE_ROW_R_ADD_MIN_DIST_GRID))
+        return fail(MPE_EINVAL, "%s: done op %d (agent %d): code %d belongs to reward programs", what, pc, i, code);
+      if (!pass && (code == MPE_ROW_R_DONE_IF_GT || code == MPE_ROW_R_DONE_IF_LT || code == MPE_ROW_R_DONE_IF_HIT))
+        return fail(MPE_EINVAL, "%s: reward op %d (agent %d): a DONE_IF test belongs to the done program", what, pc, i);
       switch (code) {
+        case MPE_ROW_R_ABS_POS:
+          if (!ent(a0, false) || a1 > 1) return fail(MPE_EINVAL, "%s: op %d: coordinate %d of entity %d", what, pc, a1, a0);
+          break;
+        case MPE_ROW_R_DONE_IF_HIT:
+          if (!ent(a0, false) || !ent(a1, false)) return fail(MPE_EINVAL, "%s: done op %d: entities %d, %d out of range", what, pc, a0, a1);
+          break;
+        case MPE_ROW_R_DONE_IF_GT: case MPE_ROW_R_DONE_IF_LT: break;
         case MPE_ROW_R_D2: case MPE_ROW_R_MIN_D2: case MPE_ROW_R_ADD_IF_HIT:
           if (!ent(a0, false) || !ent(a1, false)) return fail(MPE_EINVAL, "%s: reward op %d: entities %d, %d out of range", what, pc, a0, a1);
           break;
@@ -592,7 +615,7 @@ int mpe_rows_validate(const MpeScenarioDesc *d, const MpeRowProgram *p, const in
         default: return fail(MPE_EINVAL, "%s: op %d: code %d is not a reward op", what, pc, code);
       }
     }
-    if (p->rew_begin[i + 1] > p->rew_begin[i] && !stored)
+    if (!pass && p->rew_begin[i + 1] > p->rew_begin[i] && !stored)
       return fail(MPE_EINVAL, "%s: agent %d's reward program has no STORE", what, i);
   }
   return 0;
@@ -609,7 +632,7 @@ static uint64_t tables_hash(const mpe::RowTables &tabs) { return fnv1a(kFnvSeed,
 // a program compiled in (mpe_rows_load_image): the module, its four entry points, and what it was compiled for
 struct RowImage {
   hipModule_t module;
-  void *fns[4];            // _ns, _ps, _nr, _pr
+  void *fns[6];            // _ns, _ps, _nr, _pr, _ne, _pe
   mpe::RowDims dims;
   uint64_t tables;
   const int32_t *ops_device;
@@ -680,25 +703,41 @@ int mpe_step_rows(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *
   return rows_call("mpe_step_rows", true, d, b, p, B, nullptr, stream);
 }
 
+static int episode_args(const char *what, int mode, const MpeScenarioDesc *d, const MpeBuffers *b, int32_t *episode_step,
+                        int32_t max_episode_steps, float landmark_range, uint64_t seed, uint64_t episode, int64_t world_offset,
+                        mpe::RowEpisode *ep) {
+  if (!episode_step) return fail(MPE_EINVAL, "%s: episode_step is NULL", what);
+  if (!b || !b->done) return fail(MPE_EINVAL, "%s: bufs->done (the agents' done rows) is NULL", what);
+  if (max_episode_steps < 0) return fail(MPE_EINVAL, "%s: max_episode_steps < 0", what);
+  if (!d) return fail(MPE_EINVAL, "%s: desc is NULL", what);
+  std::memset(ep, 0, sizeof(*ep));
+  ep->enabled = mode;
+  ep->max_steps = max_episode_steps;
+  ep->episode_step = episode_step;
+  ep->landmark_range = landmark_range;
+  ep->n_choices = d->n_choices;
+  for (int k = 0; k < MPE_MAX_CHOICES; ++k) ep->choice_pop[k] = k < d->n_choices ? d->choice_pop[k] : 1;
+  ep->seed = seed;
+  ep->episode = episode;
+  ep->world_offset = (uint64_t)world_offset;
+  return 0;
+}
+
+int mpe_step_rows_episode(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B, int32_t *episode_step,
+                          int32_t max_episode_steps, float landmark_range, uint64_t seed, uint64_t episode, int64_t world_offset,
+                          void *stream) {
+  const char *what = "mpe_step_rows_episode";
+  mpe::RowEpisode ep;
+  if (int rc = episode_args(what, 2, d, b, episode_step, max_episode_steps, landmark_range, seed, episode, world_offset, &ep)) return rc;
+  return rows_call(what, true, d, b, p, B, &ep, stream);
+}
+
 int mpe_episode_finish(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B, int32_t *episode_step,
                        int32_t max_episode_steps, float landmark_range, uint64_t seed, uint64_t episode, int64_t world_offset,
                        void *stream) {
   const char *what = "mpe_episode_finish";
-  if (!episode_step) return fail(MPE_EINVAL, "%s: episode_step is NULL", what);
-  if (!b || !b->done) return fail(MPE_EINVAL, "%s: bufs->done (the rows the step / the done callback wrote) is NULL", what);
-  if (max_episode_steps < 0) return fail(MPE_EINVAL, "%s: max_episode_steps < 0", what);
-  if (!d) return fail(MPE_EINVAL, "%s: desc is NULL", what);
   mpe::RowEpisode ep;
-  std::memset(&ep, 0, sizeof(ep));
-  ep.enabled = 1;
-  ep.max_steps = max_episode_steps;
-  ep.episode_step = episode_step;
-  ep.landmark_range = landmark_range;
-  ep.n_choices = d->n_choices;
-  for (int k = 0; k < MPE_MAX_CHOICES; ++k) ep.choice_pop[k] = k < d->n_choices ? d->choice_pop[k] : 1;
-  ep.seed = seed;
-  ep.episode = episode;
-  ep.world_offset = (uint64_t)world_offset;
+  if (int rc = episode_args(what, 1, d, b, episode_step, max_episode_steps, landmark_range, seed, episode, world_offset, &ep)) return rc;
   MpeBuffers bb = *b;
   bb.rew = nullptr;          // rewards belong to the step that just ran; only rows (and the finished worlds' state) change here
   return rows_call(what, false, d, &bb, p, B, &ep, stream);
@@ -728,6 +767,16 @@ int mpe_rows_static_source(const MpeScenarioDesc *d, const MpeRowProgram *p, con
   put("#define MPE_ROWS_STATIC 1\n#define MPE_ROWS_STATIC_NAME %s\n", name);
   put("#define MPE_ROWS_STATIC_WAVES_ROWS %d\n#define MPE_ROWS_STATIC_WAVES_STEP %d\n", waves[0], waves[1]);
   put("#define MPE_ROWS_STATIC_LDS_ROWS %zu\n#define MPE_ROWS_STATIC_LDS_STEP %zu\n", lds[0], lds[1]);
+  // register budget: as many workgroups per CU as the LDS admits, four at most (65 536 worlds = 1024 workgroups = one round on
+  // 256 CUs): that many times W waves on four SIMDs -- the compiler is told, or it spends registers the workgroup count pays for
+  int occ[2];
+  for (int k = 0; k < 2; ++k) {
+    int wg = (int)((160u * 1024u) / lds[k]);
+    wg = wg > 4 ? 4 : (wg < 1 ? 1 : wg);
+    occ[k] = (wg * waves[k] + 3) / 4;
+    occ[k] = occ[k] > 8 ? 8 : (occ[k] < 1 ? 1 : occ[k]);
+  }
+  put("#define MPE_ROWS_STATIC_OCC_ROWS %d\n#define MPE_ROWS_STATIC_OCC_STEP %d\n", occ[0], occ[1]);
   put("#define MPE_ROWS_STATIC_DIMS { %d, %d, %d, %d, %d, %d, %d, %d, %d, {%d, %d}, 0x%xu, 0x%llxull, 0x%llxull, ", h.n_agents, h.n_entities,
       h.n_vel, h.dim_c, h.collaborative, h.d_max, h.n_picks, h.n_ops, h.n_regions, h.region_entity[0], h.region_entity[1], h.all_seeing,
       (unsigned long long)h.movable, (unsigned long long)h.collide);
@@ -779,8 +828,8 @@ int mpe_rows_load_image(const MpeScenarioDesc *d, MpeRowProgram *p, const int32_
     delete im;
     return fail((int)rc, "%s: hipModuleLoadData: %s", what, hipGetErrorString(rc));
   }
-  static const char *const suffix[4] = {"_ns", "_ps", "_nr", "_pr"};
-  for (int k = 0; k < 4; ++k) {
+  static const char *const suffix[6] = {"_ns", "_ps", "_nr", "_pr", "_ne", "_pe"};
+  for (int k = 0; k < 6; ++k) {
     const std::string fn = std::string(name) + suffix[k];
     hipFunction_t f = nullptr;
     rc = hipModuleGetFunction(&f, im->module, fn.c_str());

@@ -72,7 +72,8 @@ enum {
   ROW_R_D2 = MPE_ROW_R_D2, ROW_R_MIN_D2 = MPE_ROW_R_MIN_D2, ROW_R_D2_PICK = MPE_ROW_R_D2_PICK, ROW_R_MIN_D2_PICK = MPE_ROW_R_MIN_D2_PICK,
   ROW_R_SQRT = MPE_ROW_R_SQRT, ROW_R_BOUND = MPE_ROW_R_BOUND, ROW_R_COMM_ERR = MPE_ROW_R_COMM_ERR, ROW_R_COMM_SUM = MPE_ROW_R_COMM_SUM,
   ROW_R_CONST = MPE_ROW_R_CONST, ROW_R_SAVE = MPE_ROW_R_SAVE, ROW_R_LOAD = MPE_ROW_R_LOAD, ROW_R_ZERO = MPE_ROW_R_ZERO,
-  ROW_R_ADD = MPE_ROW_R_ADD, ROW_R_ADD_IF_HIT = MPE_ROW_R_ADD_IF_HIT, ROW_R_ADD_ACC = MPE_ROW_R_ADD_ACC, ROW_R_STORE = MPE_ROW_R_STORE
+  ROW_R_ADD = MPE_ROW_R_ADD, ROW_R_ADD_IF_HIT = MPE_ROW_R_ADD_IF_HIT, ROW_R_ADD_ACC = MPE_ROW_R_ADD_ACC, ROW_R_STORE = MPE_ROW_R_STORE,
+  ROW_R_ABS_POS = MPE_ROW_R_ABS_POS, ROW_R_DONE_IF_GT = MPE_ROW_R_DONE_IF_GT, ROW_R_DONE_IF_LT = MPE_ROW_R_DONE_IF_LT, ROW_R_DONE_IF_HIT = MPE_ROW_R_DONE_IF_HIT
 };
 // Scalars of a program: kernel arguments (one batch of scalar loads at wave start).
 struct RowDims {
@@ -92,11 +93,12 @@ struct RowTables {
   int32_t obs_off[MPE_ROWS_MAX_ENTITIES + 1];     // prefix sums of the row widths
   int32_t obs_begin[MPE_ROWS_MAX_ENTITIES + 1];   // agent i's observation ops: [obs_begin[i], obs_begin[i + 1])
   int32_t rew_begin[MPE_ROWS_MAX_ENTITIES + 1];   // agent i's reward ops
-  int32_t pad_;
+  int32_t done_begin[MPE_ROWS_MAX_ENTITIES + 1];  // agent i's done ops (all equal: none)
 };
 // episode bookkeeping + masked reset in front of the rows (mpe_episode_finish)
 struct RowEpisode {
-  int32_t enabled;
+  int32_t enabled;               // 0 off; 1 mpe_episode_finish (decide at entry from the done rows, rows only); 2 mpe_step_rows_episode
+                                 // (decide after the step's own done programs, restart inside the launch)
   int32_t max_steps;
   int32_t *episode_step;
   float landmark_range;
@@ -107,7 +109,7 @@ int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream);
 int launch_rows(const MpeBuffers &b, const RowDims &dims, const RowTables &host, const void *tables_device, bool phys, int vec4,
                 const RowEpisode &ep, const int32_t *ops_device, size_t B, hipStream_t stream);
 int rows_geometry(const RowDims &dims, bool phys, int *waves, size_t *lds_bytes, int max_waves);
-int launch_rows_image(void *const fns[4], const MpeBuffers &b, const RowDims &dims, const RowTables &host, bool phys, int vec4,
+int launch_rows_image(void *const fns[6], const MpeBuffers &b, const RowDims &dims, const RowTables &host, bool phys, int vec4,
                       const RowEpisode &ep, size_t B, hipStream_t stream);
 
 }  // namespace mpe

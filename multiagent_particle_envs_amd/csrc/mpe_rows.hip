@@ -120,7 +120,10 @@ __device__ __forceinline__ void agents_of_wave(int first, int stride, int A, F &
   else for (int i = first; i < A; i += stride) f(i);
 }
 
-template <bool NT, bool PHYS, bool STATIC>
+// EP2: the instantiation behind mpe_step_rows_episode (episodes end inside the launch: a second pass of the observation programs
+// for workgroups with a finished world).  Its own instantiation because the loop around the programs costs the plain step
+// 8 % interpreted and up to 38 % compiled in (session r4s27) when it is merely present.
+template <bool NT, bool PHYS, bool STATIC, bool EP2>
 __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode &ep, const RowDims &h_arg,
                                           const uint32_t *__restrict__ const tables, const int32_t vec4, const int32_t split_arg,
                                           const uint32_t *__restrict__ const ops_g, const size_t B) {
@@ -166,12 +169,16 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   float *const S_rew = S_vel + 2 * NV * kWave;            // [A][64]    rewards before the shared sum
   float *const S_slot = S_rew + A * kWave;                // [NW][8][64] the reward programs' value slots, per wave
   int *const S_pick = reinterpret_cast<int *>(S_slot + (size_t)NW * kRowSlots * kWave);   // [4][64]  the per-world picks
-  float *const S_new = reinterpret_cast<float *>(S_pick + kRowPicks * kWave);   // [A][4][64] post-step state (PHYS only)
-  float *const tiles = S_new + (PHYS ? 4 * A * kWave : 0);   // [W][64 * Dmax]
+  // the post-step state of World.step ([A][4][64], PHYS only) and the waves' row tiles ([W][64 * Dmax]) share one region: the
+  // new state has moved into S_pos / S_vel (behind a barrier) before the first tile column is written
+  float *const S_new = reinterpret_cast<float *>(S_pick + kRowPicks * kWave);
+  float *const tiles = S_new;
 
   // ---- episode bookkeeping (mpe_episode_finish): count the step, find the worlds that finished, leave if none did ----------
   bool fin = false;
-  if (ep.enabled) {
+  int cnt2 = 0;          // (mode 2: the step count, read with the state, used after the done programs)
+  if constexpr (EP2) cnt2 = (ep.episode_step + wave_off(w0))[ln] + 1;
+  if (ep.enabled == 1) {
     const int cnt = (ep.episode_step + wave_off(w0))[ln] + 1;
     const bool horizon = ep.max_steps > 0 && cnt >= ep.max_steps;
     fin = horizon;
@@ -317,6 +324,11 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   }
   MPE_RSTAMP(4);      // the post-step state is in LDS
 
+  // Two passes at most: the second only in mode 2 (mpe_step_rows_episode) and only in a workgroup where a world finished --
+  // its worlds restarted, the observation programs run once more on the new episode's first state.  (One copy of the code.)
+  constexpr int kPasses = EP2 ? 2 : 1;
+#pragma nounroll
+  for (int pass = 0; pass < kPasses; ++pass) {
   // ---- observation programs of this wave's agents ------------------------------------------------------------------------
   {
     float *const tile = tiles + (size_t)wave * kWave * h.d_max;
@@ -430,10 +442,12 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
     agents_of_wave<STATIC, PHYS>(is_rows ? wave : A, RW, A, obs_agent);
   }
   MPE_RSTAMP(5);      // observation rows stored
-  if (ep.enabled) return;      // (mpe_episode_finish: rewards and dones belong to the step that just ran)
+  if (ep.enabled == 1 || pass == 1) return;      // (mpe_episode_finish, or the restarted worlds' rows: rewards and dones are the step's)
 
-  // ---- reward programs of this wave's agents -----------------------------------------------------------------------------
-  if (b.rew) {
+  // ---- reward and done programs of this wave's agents ----------------------------------------------------------------------
+  const bool has_done = TI(MPE_TAB(done_begin), A) != TI(MPE_TAB(done_begin), 0);
+  bool dn_wave = false;      // some agent of this wave is done (per world)
+  if (b.rew || (b.done && has_done)) {
     float *const slot = S_slot + (size_t)wave * kRowSlots * kWave;      // this wave's eight value slots
     // min over the run first .. first + n - 1 of |p[q] - o|^2 (flip: |o - p[q]|^2), first to last; four positions per LDS round trip
     auto min_d2_run = [&](int first, int n, float ox, float oy, bool flip) {
@@ -457,6 +471,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
     };
     auto rew_agent = [&](const int i) __attribute__((always_inline)) {
       float acc[2] = {0.f, 0.f}, v = 0.f;
+      bool dn = false;
       const int pc0 = TI(MPE_TAB(rew_begin), i), pc1 = TI(MPE_TAB(rew_begin), i + 1);
       auto rew_op = [&](const int4 op) __attribute__((always_inline)) {
         const int code = uni(op.x & 0xff), a0 = uni((op.x >> 8) & 0xff), a1 = uni((op.x >> 16) & 0xff), a2 = uni((op.x >> 24) & 0xff);
@@ -507,6 +522,13 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
           }
           case ROW_R_ADD_ACC: acc[0] = acc[0] + acc[1]; break;
           case ROW_R_STORE: S_rew[a0 * kWave + lane] = acc[0]; break;
+          // ---- done programs: tests on the value machine, OR-ed (environment.py:132-135: the scenario's done callback) ----------
+          case ROW_R_ABS_POS: v = fabsf(P(a0, a1)); break;
+          case ROW_R_DONE_IF_GT: dn = dn || v > f; break;
+          case ROW_R_DONE_IF_LT: dn = dn || v < f; break;
+          case ROW_R_DONE_IF_HIT:
+            dn = dn || sqrt_lt(sq2d(P(a0, 0) - P(a1, 0), P(a0, 1) - P(a1, 1)), TF(MPE_TAB(size), a0) + TF(MPE_TAB(size), a1));
+            break;
           // ---- range forms ---------------------------------------------------------------------------------------------------
           case ROW_R_MIN_D2_RANGE:        // min over agents a0 .. a0 + n - 1 of |a - p[a1]|^2, first to last
             v = min_d2_run(a0, uni(op.y), P(a1, 0), P(a1, 1), false);
@@ -562,6 +584,19 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
           rew_op(op);
         }
       }
+      // the agent's done program, on a fresh machine
+      const int dc0 = TI(MPE_TAB(done_begin), i), dc1 = TI(MPE_TAB(done_begin), i + 1);
+      if (dc0 < dc1) {
+        acc[0] = acc[1] = v = 0.f;
+        if constexpr (STATIC) {
+#pragma unroll
+          for (int pc = dc0; pc < dc1; ++pc) rew_op(OP(pc));
+        } else {
+          for (int pc = dc0; pc < dc1; ++pc) rew_op(OP(pc));
+        }
+      }
+      if (b.done && live) (b.done + wave_off((size_t)i * B + w0))[ln] = dn ? 1 : 0;
+      dn_wave = dn_wave || dn;
     };
     agents_of_wave<STATIC, PHYS>(rwave, RW, A, rew_agent);
     MPE_RSTAMP(6);    // reward programs done
@@ -573,37 +608,89 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
       for (int a = 1; a < A; ++a) rest += S_rew[a * kWave + lane];
       total = A > 1 ? S_rew[lane] + rest : S_rew[lane];
     }
-    if (live)
+    if (live && b.rew)
       for (int i = rwave; i < A; i += RW) (b.rew + wave_off((size_t)i * B + w0))[ln] = h.collaborative ? total : S_rew[i * kWave + lane];
-  }
-  if (b.done && live)
+  } else if (b.done && live) {
     for (int i = rwave; i < A; i += RW) (b.done + wave_off((size_t)i * B + w0))[ln] = 0;
+  }
+  if constexpr (!EP2) return;
+
+  // ---- mode 2: the episode ends inside the launch (mpe_step_rows_episode = this step + mpe_episode_finish) -----------------
+  // every wave publishes "one of my agents is done", everybody reads everybody's: the same verdict in every wave
+  int *const S_dw = reinterpret_cast<int *>(S_slot);      // [NW][64], the first row of each wave's slots (free by now)
+  S_dw[(size_t)wave * kRowSlots * kWave + lane] = dn_wave ? 1 : 0;
+  __syncthreads();      // (also: every done row of this step is stored and acknowledged before wave 0 may overwrite it below)
+  bool any_done = false;
+  for (int w = 0; w < NW; ++w) any_done = any_done || S_dw[(size_t)w * kRowSlots * kWave + lane] != 0;
+  const bool horizon = ep.max_steps > 0 && cnt2 >= ep.max_steps;
+  fin = (horizon || any_done) && live;
+  if (wave == 0 && live) {
+    (ep.episode_step + wave_off(w0))[ln] = fin ? 0 : cnt2;
+    if (horizon)
+      for (int a = 0; a < A; ++a) (b.done + wave_off((size_t)a * B + w0))[ln] = 1;
+  }
+  if (__builtin_amdgcn_ballot_w64(fin) == 0) return;      // nothing finished among these 64 worlds: the usual case
+  // reset_world for the finished worlds -- the draws of mpe_reset for (seed, world, episode) -- into HBM and the staged state
+  for (int e = wave; e < E; e += NW) {
+    if (fin) {
+      float x, y;
+      reset_draw(ep.seed, gw, ep.episode, e, e < A ? 1.0f : ep.landmark_range, x, y);
+      (b.pos + wave_off((size_t)(2 * e) * B + w0))[ln] = x;
+      (b.pos + wave_off((size_t)(2 * e + 1) * B + w0))[ln] = y;
+      S_pos[(2 * e) * kWave + lane] = x;
+      S_pos[(2 * e + 1) * kWave + lane] = y;
+      if (e < NV && e < A) {
+        (b.vel + wave_off((size_t)(2 * e) * B + w0))[ln] = 0.f;
+        (b.vel + wave_off((size_t)(2 * e + 1) * B + w0))[ln] = 0.f;
+        S_vel[(2 * e) * kWave + lane] = 0.f;
+        S_vel[(2 * e + 1) * kWave + lane] = 0.f;
+      }
+    }
+  }
+  for (int k = wave; k < h.n_picks; k += NW) {
+    if (fin) {
+      const int g = choice_draw(ep.seed, gw, ep.episode, k, ep.choice_pop[k]);
+      (b.choice + wave_off((size_t)k * B + w0))[ln] = g;
+      S_pick[k * kWave + lane] = g;
+    }
+  }
+  if (DC > 0 && b.comm) {
+    for (int a = wave; a < A; a += NW)
+      if (fin)
+        for (int c = 0; c < DC; ++c) (const_cast<float *>(b.comm) + wave_off(((size_t)a * B + w0) * DC))[ln * DC + c] = 0.f;
+  }
+  __syncthreads();
+  }      // (second pass: the observation programs on the restarted worlds' state -- `fin` lanes read their utterances as zero)
 }
 
 #ifndef MPE_ROWS_STATIC
-template <bool NT, bool PHYS>
+template <bool NT, bool PHYS, bool EP2>
 __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpisode ep, const RowDims h,
                                                  const uint32_t *__restrict__ const tables, const int32_t vec4, const int32_t split,
                                                  const uint32_t *__restrict__ const ops_g, const size_t B) {
-  rows_body<NT, PHYS, false>(b, ep, h, tables, vec4, split, ops_g, B);
+  rows_body<NT, PHYS, false, EP2>(b, ep, h, tables, vec4, split, ops_g, B);
 }
 #endif
 
 }  // namespace
 
 #ifdef MPE_ROWS_STATIC
-// the four entry points of a compiled program: <name>_{n,p}{s,r} = {nontemporal, plain} row stores x {step, rows only}
+// the six entry points of a compiled program: <name>_{n,p}{s,r,e} = {nontemporal, plain} row stores x {step, rows only, step with
+// the episode end inside}
 #define MPE_ROWS_CAT2(a, b) a##b
 #define MPE_ROWS_CAT(a, b) MPE_ROWS_CAT2(a, b)
-#define MPE_ROWS_STATIC_KERNEL(suffix, NT, PHYS)                                                                              \
+#define MPE_ROWS_STATIC_KERNEL(suffix, NT, PHYS, EP2)                                                                         \
   extern "C" __global__ void __launch_bounds__(static_waves<PHYS>() * kWave)                                                   \
+      __attribute__((amdgpu_waves_per_eu(PHYS ? MPE_ROWS_STATIC_OCC_STEP : MPE_ROWS_STATIC_OCC_ROWS)))                         \
       MPE_ROWS_CAT(MPE_ROWS_STATIC_NAME, suffix)(const MpeBuffers b, const RowEpisode ep, const int32_t vec4, const size_t B) { \
-    rows_body<NT, PHYS, true>(b, ep, RowDims{}, nullptr, vec4, 0, nullptr, B);                                                 \
+    rows_body<NT, PHYS, true, EP2>(b, ep, RowDims{}, nullptr, vec4, 0, nullptr, B);                                                 \
   }
-MPE_ROWS_STATIC_KERNEL(_ns, true, true)
-MPE_ROWS_STATIC_KERNEL(_ps, false, true)
-MPE_ROWS_STATIC_KERNEL(_nr, true, false)
-MPE_ROWS_STATIC_KERNEL(_pr, false, false)
+MPE_ROWS_STATIC_KERNEL(_ns, true, true, false)
+MPE_ROWS_STATIC_KERNEL(_ps, false, true, false)
+MPE_ROWS_STATIC_KERNEL(_nr, true, false, false)
+MPE_ROWS_STATIC_KERNEL(_pr, false, false, false)
+MPE_ROWS_STATIC_KERNEL(_ne, true, true, true)
+MPE_ROWS_STATIC_KERNEL(_pe, false, true, true)
 #else
 
 int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream) {
@@ -616,20 +703,22 @@ int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream) {
 // per CU).  One function for the launch and for the generator of compiled programs (the wave count is a constant there).
 int rows_geometry(const RowDims &h, bool phys, int *waves, size_t *lds_bytes, int max_waves) {
   constexpr size_t kLdsCap = 160 * 1024;
-  const size_t fixed = sizeof(float) * (size_t)(2 * h.n_entities + 2 * h.n_vel + h.n_agents + kRowPicks + (phys ? 4 * h.n_agents : 0)) * kWave;
-  const size_t per_wave = sizeof(float) * (size_t)kWave * ((size_t)h.d_max + kRowSlots);
-  if (fixed + per_wave > kLdsCap) return MPE_EUNSUPPORTED;
+  const size_t fixed = sizeof(float) * (size_t)(2 * h.n_entities + 2 * h.n_vel + h.n_agents + kRowPicks) * kWave;
+  const size_t new_state = phys ? sizeof(float) * (size_t)(4 * h.n_agents) * kWave : 0;      // shares the tiles' region
+  const size_t tile = sizeof(float) * (size_t)kWave * (size_t)h.d_max, slots = sizeof(float) * (size_t)kWave * kRowSlots;
+  auto need = [&](int w) { return fixed + (size_t)w * slots + ((size_t)w * tile > new_state ? (size_t)w * tile : new_state); };
+  if (need(1) > kLdsCap) return MPE_EUNSUPPORTED;
   int W = h.n_agents < kRowMaxObsWaves ? h.n_agents : kRowMaxObsWaves;
   if (max_waves > 0 && W > max_waves) W = max_waves;
-  while (W > 1 && fixed + (size_t)W * per_wave > (W > 4 ? 64u * 1024u : kLdsCap)) --W;
+  while (W > 1 && need(W) > (W > 4 ? 64u * 1024u : kLdsCap)) --W;
   *waves = W;
-  *lds_bytes = fixed + (size_t)W * per_wave;
+  *lds_bytes = need(W);
   return 0;
 }
 
 static bool rows_nontemporal(const RowDims &h, const RowTables &host, int vec4, const RowEpisode &ep, size_t B) {
   const size_t row_bytes = (size_t)host.obs_off[h.n_agents] * sizeof(float) * B;
-  return row_bytes >= (8u << 20) && vec4 && !ep.enabled;
+  return row_bytes >= (8u << 20) && vec4 && ep.enabled != 1;
 }
 
 int launch_rows(const MpeBuffers &b, const RowDims &h, const RowTables &host, const void *tables_device, bool phys, int vec4,
@@ -643,7 +732,10 @@ int launch_rows(const MpeBuffers &b, const RowDims &h, const RowTables &host, co
   // (two waves per agent, rows || reward -- `split` -- measured slower, see rows_body; the kernel keeps the switch for the A/B)
   const unsigned grid = (unsigned)((B + kWave - 1) / kWave);
   const bool nt = rows_nontemporal(h, host, vec4, ep, B);
-  auto fn = phys ? (nt ? k_rows<true, true> : k_rows<false, true>) : (nt ? k_rows<true, false> : k_rows<false, false>);
+  const bool ep2 = ep.enabled == 2;      // (phys by construction: mpe_step_rows_episode)
+  auto fn = ep2 ? (nt ? k_rows<true, true, true> : k_rows<false, true, true>)
+                : phys ? (nt ? k_rows<true, true, false> : k_rows<false, true, false>)
+                       : (nt ? k_rows<true, false, false> : k_rows<false, false, false>);
   if (lds > 64 * 1024) {
     const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return (int)rc;
@@ -653,14 +745,14 @@ int launch_rows(const MpeBuffers &b, const RowDims &h, const RowTables &host, co
   return (int)hipGetLastError();
 }
 
-// a compiled program (hipModule functions in the order ns, ps, nr, pr): same geometry, no tables, no ops
-int launch_rows_image(void *const fns[4], const MpeBuffers &b, const RowDims &h, const RowTables &host, bool phys, int vec4,
+// a compiled program (hipModule functions in the order ns, ps, nr, pr, ne, pe): same geometry, no tables, no ops
+int launch_rows_image(void *const fns[6], const MpeBuffers &b, const RowDims &h, const RowTables &host, bool phys, int vec4,
                       const RowEpisode &ep, size_t B, hipStream_t stream) {
   int W = 0;
   size_t lds = 0;
   if (int rc = rows_geometry(h, phys, &W, &lds, 0)) return rc;
   const bool nt = rows_nontemporal(h, host, vec4, ep, B);
-  hipFunction_t fn = static_cast<hipFunction_t>(fns[(phys ? 0 : 2) + (nt ? 0 : 1)]);
+  hipFunction_t fn = static_cast<hipFunction_t>(fns[(ep.enabled == 2 ? 4 : phys ? 0 : 2) + (nt ? 0 : 1)]);
   MpeBuffers b_ = b;
   RowEpisode ep_ = ep;
   int32_t vec4_ = vec4;

@@ -304,13 +304,38 @@ class MultiAgentEnv(object):
         self._prog.validate(d)
         return d
 
-    def _program_step(self, desc_ref, bufs_ref, B, st):
+    def _program_step(self, desc_ref, bufs_ref, B, st, probe=False):
         """World.step by the agents' waves, then every agent's row / reward / done from the post-step state by the row
-        programs: ONE launch (`mpe_step_rows`; `two_launch_program = True` keeps mpe_world_step + mpe_rows, the A/B)."""
+        programs: ONE launch (`mpe_step_rows`; `two_launch_program = True` keeps mpe_world_step + mpe_rows, the A/B).
+        With episodes that end on the device (`_episode_in_launch`) the same launch also counts the step, finds the finished
+        worlds -- the program's done tests, the horizon -- and restarts them (`mpe_step_rows_episode`)."""
         L = _abi.lib()
         if self.two_launch_program:
             return L.mpe_world_step(desc_ref, bufs_ref, B, st) or L.mpe_rows(desc_ref, bufs_ref, self._prog.ref, B, st)
+        if not probe and self._episode_in_launch:
+            w = self.world
+            if self.episode_step is None:
+                self.episode_step = torch.zeros(self.batch_size, dtype=torch.int32, device=w.device)
+                self._may_finish.add(self._steps_taken + self.max_episode_steps)
+            # the episode number a restart draws with: one per step where a done test can fire at any step (as mpe_episode_finish
+            # counts), one per step at which some world CAN reach the horizon otherwise (as the masked resets of that path count)
+            counts = self._prog.has_done or (self._steps_taken + 1) in self._may_finish
+            rc = L.mpe_step_rows_episode(desc_ref, bufs_ref, self._prog.ref, B, self.episode_step.data_ptr(), self.max_episode_steps,
+                                         float(getattr(self._scenario, "landmark_range", 1.0)), int(w.seed) & (2 ** 64 - 1),
+                                         int(w._episode), int(w.world_offset), st)
+            if counts:
+                w._episode += 1
+                if hasattr(self._scenario, "_apply"):     # per-world Python state of the scenario (goal colours ...) follows lazily
+                    self._scenario_state_stale = True
+            return rc
         return L.mpe_step_rows(desc_ref, bufs_ref, self._prog.ref, B, st)
+
+    @property
+    def _episode_in_launch(self):
+        """Episodes end INSIDE the step launch: a row-program env with max_episode_steps + auto_reset whose done condition is
+        the program's (a `done_spec`) or the horizon alone -- no Python done callback, no Python rows."""
+        return self._prog is not None and self.fused and self.auto_reset and bool(self.max_episode_steps) and self.finish_launch and \
+            not self.two_launch_program and not self._py_done and not self._py_obs and not self._py_reward
 
     def _attach_program_image(self):
         """After the descriptor of a row-program env was (re)built: bring the compiled image in line with the policy."""
@@ -430,15 +455,16 @@ class MultiAgentEnv(object):
         b.pos, b.vel = pos.data_ptr(), vel.data_ptr()
         b.act, b.ids, b.u = None, self._ids.data_ptr(), None
         st, L = self._stream(), _abi.lib()
+        step = (lambda *a: self._program_step(*a, probe=True)) if self._prog is not None else self._mpe_step
 
         def timed(t, launches=8):
             b.obs = t.data_ptr()
             for _ in range(2):
-                _abi.check(self._mpe_step(self._desc_ref, scratch.bufs_ref, w.batch_size, st), "mpe_step (placement probe)")
+                _abi.check(step(self._desc_ref, scratch.bufs_ref, w.batch_size, st), "mpe_step (placement probe)")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(launches):
-                self._mpe_step(self._desc_ref, scratch.bufs_ref, w.batch_size, st)
+                step(self._desc_ref, scratch.bufs_ref, w.batch_size, st)
             e1.record()
             e1.synchronize()
             return e0.elapsed_time(e1) / launches
@@ -664,6 +690,12 @@ class MultiAgentEnv(object):
         counts some world CAN finish (max_episode_steps after every full, masked or automatic reset) to skip the
         reset launches everywhere else."""
         w = self.world
+        if self._episode_in_launch:      # counted, decided and restarted by the step's own launch (mpe_step_rows_episode)
+            self._steps_taken += 1
+            if self._steps_taken in self._may_finish:
+                self._may_finish.discard(self._steps_taken)
+                self._may_finish.add(self._steps_taken + self.max_episode_steps)
+            return False
         if self.episode_step is None:
             self.episode_step = torch.zeros(self.batch_size, dtype=torch.int32, device=w.device)
             self._may_finish.add(self._steps_taken + self.max_episode_steps)

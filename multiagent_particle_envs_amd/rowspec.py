@@ -232,6 +232,35 @@ class RewardSpec(_Spec):
         return self
 
 
+class DoneSpec(RewardSpec):
+    """One agent's done condition (the reference's `done_callback(agent, world)`, environment.py:132-135) as tests on the
+    reward machine's value register: the value methods of RewardSpec (dist, min_dist, dist2_pick, abs_pos ...) followed by
+    `done_if_gt / done_if_lt`, or `done_if_touching`; the agent is done when ANY test fires.  With `auto_reset` the step, the
+    tests and the restart of the finished worlds are ONE launch (mpe_step_rows_episode)."""
+
+    def abs_pos(self, ent, axis):
+        """v = |coordinate `axis` of `ent`|"""
+        self.ops.append(_op(_abi.MPE_ROW_R_ABS_POS, self._e(ent), int(axis)))
+        return self
+
+    def done_if_gt(self, threshold):
+        self.ops.append(_op(_abi.MPE_ROW_R_DONE_IF_GT, f0=float(threshold)))
+        return self
+
+    def done_if_lt(self, threshold):
+        self.ops.append(_op(_abi.MPE_ROW_R_DONE_IF_LT, f0=float(threshold)))
+        return self
+
+    def done_if_touching(self, a, b):
+        """|a - b| < a.size + b.size (strict, decided exactly as the contact tests of the rewards)"""
+        self.ops.append(_op(_abi.MPE_ROW_R_DONE_IF_HIT, self._e(a), self._e(b)))
+        return self
+
+    def outside(self, ent, bound):
+        """`ent` left the square |x|, |y| <= bound"""
+        return self.abs_pos(ent, 0).done_if_gt(bound).abs_pos(ent, 1).done_if_gt(bound)
+
+
 class Regions(object):
     """Landmarks that hide what is inside them (at most two) and the agents that see everybody anyway: the visibility rule
     of ObsSpec.rel_visible / vel_visible / in_region (simple_world_comm.py:231-261: the forests, the leader)."""
@@ -371,9 +400,9 @@ def fuse_reward(ops):
 class RowProgram(object):
     """The compiled programs of one env: ops on the device + the MpeRowProgram header the C ABI takes."""
 
-    def __init__(self, world, obs_specs, reward_specs, regions=None, fuse=None):
+    def __init__(self, world, obs_specs, reward_specs, regions=None, fuse=None, done_specs=None):
         """fuse: run the peephole pass (runs of per-entity ops -> range forms); False keeps one op per spec call (the A/B);
-        None: the module's FUSE switch."""
+        None: the module's FUSE switch.  done_specs: one DoneSpec (or None: never done) per agent."""
         fuse = FUSE if fuse is None else fuse
         A = len(world.agents)
         if len(world.entities) > _abi.MPE_ROWS_MAX_ENTITIES:
@@ -392,6 +421,15 @@ class RowProgram(object):
             ops += fuse_reward(r.ops) if fuse else r.ops
             ops.append(_op(_abi.MPE_ROW_R_STORE, i))
             rbegin.append(len(ops))
+        dbegin = [0] * (A + 1)
+        self.has_done = bool(done_specs) and any(d is not None and d.ops for d in done_specs)
+        if self.has_done:
+            if len(done_specs) != A:
+                raise _abi.MpeError("one DoneSpec (or None) per agent")
+            dbegin = [len(ops)]
+            for d in done_specs:
+                ops += (fuse_reward(d.ops) if fuse else d.ops) if d is not None else []
+                dbegin.append(len(ops))
         self.n_ops = len(ops)
         flat = [w for op in ops for w in op]
         self.ops_host = (C.c_int32 * max(1, len(flat)))(*flat)
@@ -406,6 +444,8 @@ class RowProgram(object):
             p.obs_begin[i] = begin[min(i, A)]
         for i in range(_abi.MPE_ROWS_MAX_ENTITIES + 1):
             p.rew_begin[i] = rbegin[min(i, A)]
+        for i in range(_abi.MPE_ROWS_MAX_ENTITIES + 1):
+            p.done_begin[i] = dbegin[min(i, A)]
         p.n_vel = world.n_dynamic
         regions = regions or Regions()
         if len(regions.landmarks) > 2:
@@ -473,7 +513,9 @@ def compile_scenario(scenario, world):
     if any(o is None for o in obs) or any(r is None for r in rew):
         return None
     rg = scenario.regions(world) if hasattr(scenario, "regions") else None
-    return RowProgram(world, obs, rew, rg)
+    dsf = getattr(scenario, "done_spec", None)
+    done = [dsf(a, world) for a in world.agents] if dsf is not None else None
+    return RowProgram(world, obs, rew, rg, done_specs=done)
 
 
 # built-in scenarios whose callbacks are written for any team size: where no fused kernel exists for a shape, the env runs

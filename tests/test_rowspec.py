@@ -120,8 +120,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from corral import Scenario as Corral  # noqa: E402
 
 
-def corral_env(B, fused=None, device=None, **kw):
+def corral_env(B, fused=None, device=None, arena=None, **kw):
     sc = Corral()
+    sc.arena = arena
     w = sc.make_world(batch_size=B, device=device) if device else sc.make_world(batch_size=B)
     w.seed = 3
     kw.setdefault("compile_program", False)
@@ -309,6 +310,84 @@ def test_compiled_custom_scenario_equals_the_interpreted_one_and_falls_back_when
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("compiled", [False, True])
+@pytest.mark.parametrize("horizon", [7, 1000])
+def test_episodes_that_end_inside_the_step_launch_equal_step_plus_callback_plus_finish(compiled, horizon):
+    """A done_spec (`arena`: an agent outside the square is done) + auto_reset: mpe_step_rows_episode -- step, done tests,
+    restart of the finished worlds, their new rows in ONE launch -- against the same scenario with the condition as a torch
+    done_callback (mpe_step_rows, the callback, mpe_episode_finish): rows, rewards, dones, counters, state, picks to the bit;
+    with a short horizon both kinds of episode end occur, with a long one only the done tests."""
+    B = 3000
+    a = corral_env(B, arena=0.95, max_episode_steps=horizon, auto_reset=True)
+    b = corral_env(B, max_episode_steps=horizon, auto_reset=True, done_callback=_strayed)
+    assert a._prog.has_done and a._episode_in_launch and not b._prog.has_done and not b._episode_in_launch
+    if compiled:
+        assert a.compile_program() and b.compile_program()
+    rs = np.random.RandomState(5)
+    oa, ob = a.reset(), b.reset()
+    assert all(torch.equal(x, y) for x, y in zip(oa, ob))
+    ended = 0
+    for t in range(1, 25):
+        if t == 9:
+            for e in (a, b):
+                e.world.pos.mul_(0.3)
+        act = rand_actions(a, rs, B)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(a.world.pos, b.world.pos) and torch.equal(a.world.vel, b.world.vel), t
+        assert torch.equal(a.episode_step, b.episode_step) and torch.equal(a.world.choice_i32, b.world.choice_i32), t
+        for i in range(3):
+            assert torch.equal(da[i], db[i]), (t, i, int(da[i].sum()), int(db[i].sum()))
+            assert torch.equal(oa[i], ob[i]), (t, i)
+            assert torch.equal(ra[i], rb[i]), (t, i)
+        ended += int(torch.stack(da).any(dim=0).sum())
+    assert ended > B // 20
+    assert a.program_compiled == compiled
+
+
+@pytest.mark.gpu
+def test_horizon_only_auto_reset_of_a_program_env_runs_in_the_step_launch():
+    """No done condition at all: max_episode_steps + auto_reset of a row-program env is still one launch per step, equal to
+    the separate launches (`finish_launch = False`: tick, masked reset, mpe_rows at the horizon)."""
+    B = 2000
+    a = corral_env(B, max_episode_steps=5, auto_reset=True)
+    b = corral_env(B, max_episode_steps=5, auto_reset=True)
+    b.finish_launch = False
+    assert a._episode_in_launch and not b._episode_in_launch
+    rs = np.random.RandomState(6)
+    a.reset(), b.reset()
+    for t in range(1, 14):
+        act = rand_actions(a, rs, B)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert bool(da[0].all()) == (t % 5 == 0)
+        assert torch.equal(a.world.pos, b.world.pos) and torch.equal(a.episode_step, b.episode_step), t
+        assert all(torch.equal(x, y) for x, y in zip(oa + ra + da, ob + rb + db)), t
+
+
+def test_done_programs_are_validated():
+    sc = Corral()
+    w = sc.make_world(batch_size=2, device="cpu")
+    ag = w.agents
+    obs = [sc.obs_spec(x, w) for x in ag]
+    rew = [sc.reward_spec(x, w) for x in ag]
+    ok = rowspec.RowProgram(w, obs, rew, done_specs=[rowspec.DoneSpec(w, ag[0]).outside(ag[0], 0.9), None,
+                                                     rowspec.DoneSpec(w, ag[2]).dist(ag[2], w.landmarks[0]).done_if_lt(0.1).done_if_touching(ag[2], ag[0])])
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, compile_program=False)
+    ok.validate(env._desc)
+    assert ok.has_done and [ok.struct.done_begin[i] for i in range(4)] == [ok.n_ops - 8, ok.n_ops - 4, ok.n_ops - 4, ok.n_ops]
+    assert not env._prog.has_done and all(env._prog.struct.done_begin[i] == 0 for i in range(65))
+    bad = rowspec.DoneSpec(w, ag[0])
+    bad.add_if_touching(ag[0], ag[1], -1.0)           # a reward term in a done program
+    with pytest.raises(_abi.MpeError, match="belongs to reward programs"):
+        rowspec.RowProgram(w, obs, rew, done_specs=[bad, None, None]).validate(env._desc)
+    worse = sc.reward_spec(ag[0], w)
+    worse.ops.append(rowspec._op(_abi.MPE_ROW_R_DONE_IF_GT, f0=1.0))
+    with pytest.raises(_abi.MpeError, match="belongs to the done program"):
+        rowspec.RowProgram(w, obs, [worse] + rew[1:]).validate(env._desc)
+
+
+@pytest.mark.gpu
 def test_a_cached_image_attaches_itself_and_a_missing_one_does_not_start_hipcc(tmp_path, monkeypatch):
     from multiagent_particle_envs_amd import _build
     warm = corral_env(64)
@@ -348,12 +427,12 @@ def test_static_source_and_image_of_a_program_on_the_cpu():
     name = [l.split()[2] for l in src.splitlines() if l.startswith("#define MPE_ROWS_STATIC_NAME")][0]
     assert name.startswith("mpe_rows_") and len(name) == 9 + 16
     for key in ("MPE_ROWS_STATIC_DIMS", "MPE_ROWS_STATIC_TABLES", "MPE_ROWS_STATIC_OPS", "MPE_ROWS_STATIC_WAVES_STEP", "MPE_ROWS_STATIC_WAVES_ROWS",
-                "MPE_ROWS_STATIC_LDS_STEP", "MPE_ROWS_STATIC_LDS_ROWS"):
+                "MPE_ROWS_STATIC_LDS_STEP", "MPE_ROWS_STATIC_LDS_ROWS", "MPE_ROWS_STATIC_OCC_STEP", "MPE_ROWS_STATIC_OCC_ROWS"):
         assert "#define %s " % key in src
     assert src.count("{") - 3 == env._prog.n_ops + 1          # one {a, b, c, d} per op (+ the dims' region pair)
     from multiagent_particle_envs_amd import _build
     image = _build.compile_rows_image(src)
-    for suffix in ("_ns", "_ps", "_nr", "_pr"):
+    for suffix in ("_ns", "_ps", "_nr", "_pr", "_ne", "_pe"):
         assert (name + suffix).encode() in image
     assert _build.compile_rows_image(src) == image            # cached by content
     env.world.agents[0].size = 0.2

@@ -6,6 +6,10 @@
                   [mpe_step; mpe_episode_finish]               round 4: one more launch, every workgroup leaves after its flags
                   [mpe_step; tick; mask; masked reset; observe] round 3's sequence (mpe_episode_tick, any(), masked_fill, masked
                                                                mpe_reset, full mpe_observe) on every step
+  row programs  the same for a scenario whose done condition is part of its program (examples/corral.py with `arena`: a done_spec):
+                  [mpe_step_rows]                              no episodes
+                  [mpe_step_rows_episode]                      step, done tests, counters, restart of the finished worlds: ONE launch
+                  [mpe_step_rows; mpe_episode_finish]          the two-launch form a Python done callback needs
   from Python   wall time per env.step of the same three configurations (a done callback that is one preallocated all-False
                 row: the callback's own cost is the user's), eager.
 
@@ -121,5 +125,54 @@ def main():
             print("   %-72s %6.2f us   %.2fx" % (label, t, t / base))
 
 
+def programs():
+    import test_rowspec as tr
+    B = 65536
+    L = _abi.lib()
+    for compiled in (False, True):
+        env = tr.corral_env(B, arena=50.0, max_episode_steps=1000000, auto_reset=True)      # (an arena nobody leaves)
+        assert env._prog.has_done and env._episode_in_launch
+        if compiled:
+            assert env.compile_program()
+        env.reset()
+        st = _abi.raw_stream(env.world.device)
+        act = torch.nn.functional.one_hot(torch.randint(0, 5, (env.n, B), device="cuda"), 5).float().contiguous()
+        env.step([act[i] for i in range(env.n)])
+        o = env._sets[0]
+        b = o.bufs
+        b.act, b.ids, b.u = act.data_ptr(), None, None
+        es = env.episode_step.data_ptr()
+        fb = _abi.MpeBuffers()
+        C.memmove(C.byref(fb), C.byref(b), C.sizeof(fb))
+        fb.act = fb.ids = fb.u = None
+        prog = env._prog
+        t0 = event_time(lambda: L.mpe_step_rows(env._desc_ref, o.bufs_ref, prog.ref, B, st))
+        t1 = event_time(lambda: L.mpe_step_rows_episode(env._desc_ref, o.bufs_ref, prog.ref, B, es, 1000000, 0.9, 1, 7, 0, st))
+
+        def pair():
+            L.mpe_step_rows(env._desc_ref, o.bufs_ref, prog.ref, B, st)
+            L.mpe_episode_finish(C.byref(env._desc), C.byref(fb), prog.ref, B, es, 1000000, 0.9, 1, 7, 0, st)
+        t2 = event_time(pair)
+        print("examples/corral.py with a done_spec, program %s   device side, us per step" % ("COMPILED IN" if compiled else "interpreted"))
+        for label, t in (("[mpe_step_rows]", t0), ("[mpe_step_rows_episode]   (episodes end inside the launch)", t1),
+                         ("[mpe_step_rows; mpe_episode_finish]", t2)):
+            print("   %-72s %6.2f us   %.2fx" % (label, t, t / t0))
+        plain = tr.corral_env(B, arena=50.0)
+        if compiled:
+            plain.compile_program()
+        plain.reset()
+        acts = [act[i] for i in range(env.n)]
+        w0 = wall_time(lambda: plain.step(acts))
+        w1 = wall_time(lambda: env.step(acts))
+        cb = tr.corral_env(B, max_episode_steps=1000000, auto_reset=True, done_callback=tr._strayed)
+        if compiled:
+            cb.compile_program()
+        cb.reset()
+        w2 = wall_time(lambda: cb.step(acts))
+        print("   from Python (eager env.step(list)): no episodes %.2f us | done_spec + auto_reset %.2f us (%.2fx) | torch done_callback + auto_reset %.2f us (%.2fx)"
+              % (w0, w1, w1 / w0, w2, w2 / w0))
+
+
 if __name__ == "__main__":
+    programs()
     main()

@@ -71,7 +71,7 @@ def variant(name, B, keep_obs, keep_rew, scenario_kw=None):
     s2 = S2()
     w = s2.make_world(batch_size=B, **(scenario_kw or {}))
     s2.reset_world(w)
-    env = mpe.MultiAgentEnv(w, s2.reset_world, s2.reward, s2.observation)
+    env = mpe.MultiAgentEnv(w, s2.reset_world, s2.reward, s2.observation, compile_program=False)      # interpreted until asked
     env._ensure_buffers()
     return env
 

@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 4, GPU visit 26: S_new shares the tiles' LDS, occupancy targets for the compiled programs; tests, ablation, rates
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}; TAG=${1:-r4s26}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+tools/sessions/_gpu_ok.sh || { echo 'BAD BOX: leaving'; exit 0; }
+timeout 900 python -m pytest tests/test_rowspec.py tests/test_f3_scenarios.py -m gpu -x -q > $O/pytest_rowspec.log 2>&1; echo "rowspec+f3 rc=$?"; tail -4 $O/pytest_rowspec.log | cut -c1-300
+timeout 600 python tools/rows_ablate.py > $O/rows_ablation.txt 2> $O/rows_ablation.err; echo "ablate rc=$?"; cat $O/rows_ablation.txt; grep -v amdgpu.ids $O/rows_ablation.err | tail -5
+SC="corral,simple_spread,simple_tag,simple_adversary:num_agents=4:num_adversaries=2,simple_adversary:num_agents=6:num_adversaries=2,simple_world_comm:num_good_agents=2:num_adversaries=3,simple_world_comm:num_good_agents=3:num_adversaries=5,simple_adversary:num_agents=10:num_adversaries=3,simple_world_comm:num_good_agents=5:num_adversaries=6"
+timeout 900 python tools/rowspec_rate.py --scenarios "$SC" --eager-only --no-generic --compiled > $O/rate.txt 2> $O/rate.err; echo "rate rc=$?"; grep -v "^\[" $O/rate.txt; grep -v amdgpu.ids $O/rate.err | tail -3
