@@ -418,6 +418,8 @@ class MultiAgentEnv(object):
             self._mpe_step = self._program_step
         if self._kind in _abi.COMM_KINDS or (self._prog is not None and w.dim_c > 0):
             self._comm = torch.zeros((A, B, w.dim_c), dtype=torch.float32, device=w.device)
+            self._speak_mask = torch.tensor([0.0 if a.silent else 1.0 for a in w.agents], dtype=torch.float32,
+                                            device=w.device).reshape(A, 1, 1)
         self._act = torch.zeros((A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=w.device)
         self._ids = torch.zeros((A, B), dtype=torch.int32, device=w.device)
         self._sets = [_OutputSet(self, o) for o in self._place_observation_buffers(2)]
@@ -513,6 +515,21 @@ class MultiAgentEnv(object):
         that already has it is used in place (zero copy)."""
         A, B = len(self.agents), self.batch_size
         if self._comm is not None and self._has_speakers:
+            if isinstance(action_n, tuple):
+                # (moves [A,B,5], utterances [A,B,dim_c]) as two device tensors -- the batched form of the reference's per-agent
+                # [move | utterance] rows: the moves are used in place, the utterances land in the comm state with ONE launch (rows
+                # of silent agents are masked to zero) instead of two small copies per agent
+                dc = self.world.dim_c
+                if len(action_n) != 2 or not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                                                 for t in action_n) or \
+                        action_n[0].shape != (A, B, _abi.MPE_ACTION_DIM) or action_n[1].shape != (A, B, dc):
+                    raise _abi.MpeError("a tuple action is (moves [A,B,5], utterances [A,B,dim_c]): two contiguous float32 device tensors "
+                                        "(A = %d, B = %d, dim_c = %d)" % (A, B, dc))
+                torch.mul(action_n[1], self._speak_mask, out=self._comm)
+                act = action_n[0]
+                if self.force_discrete_action:
+                    act = torch.zeros_like(act).scatter_(-1, act.argmax(dim=-1, keepdim=True), 1.0)
+                return act, None
             return self._stage_comm_actions(action_n), None
         if self.discrete_action_input:
             if torch.is_tensor(action_n) and action_n.shape == (A, B) and action_n.dtype == torch.int32 \
@@ -900,6 +917,9 @@ class MultiAgentEnv(object):
         assert len(act) == 0
 
     def _step_generic(self, action_n):
+        if isinstance(action_n, tuple) and len(action_n) == 2 and all(torch.is_tensor(t) and t.dim() == 3 for t in action_n):
+            raise _abi.MpeError("the (moves, utterances) tuple form is decoded by the fused step; this env steps through Python "
+                                "callbacks / another action mode: pass per-agent [move | utterance] rows")
         for i, agent in enumerate(self.agents):
             self._set_action(action_n[i], agent, self.action_space[i])
         self.world.step()

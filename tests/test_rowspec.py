@@ -143,6 +143,47 @@ def rand_actions(env, rs, B):
     return acts
 
 
+def as_tuple(env, acts, B):
+    """The per-agent [move | utterance] rows as the batched pair (moves [A,B,5], utterances [A,B,dim_c]); rows an agent does not
+    have (a speaker that cannot move, a silent listener) are junk on purpose: they must not matter."""
+    dc = env.world.dim_c
+    moves = torch.full((env.n, B, 5), 0.37, device="cuda")
+    words = torch.full((env.n, B, dc), 0.91, device="cuda")
+    for i, agent in enumerate(env.agents):
+        k = 0
+        if agent.movable:
+            moves[i] = acts[i][:, :5]
+            k = 5
+        if not agent.silent:
+            words[i] = acts[i][:, k:k + dc]
+    return moves.contiguous(), words.contiguous()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["simple_speaker_listener", "simple_reference", "simple_crypto", "simple_world_comm"])
+@pytest.mark.parametrize("program", [False, True])
+def test_moves_and_utterances_as_one_pair_of_tensors_equal_the_per_agent_rows(name, program):
+    """env.step((moves, utterances)) -- two device tensors, one staging launch -- against the reference's per-agent
+    [move | utterance] rows (two small copies per agent): rows, rewards, state, comm state to the bit; fused kernels and programs."""
+    B = 2048
+    mk = (lambda: make_spec_env(name, B, seed=2)) if program else (lambda: mpe.make_env(name, batch_size=B, seed=2))
+    a, b = mk(), mk()
+    rs = np.random.RandomState(4)
+    a.reset(), b.reset()
+    for t in range(6):
+        acts = rand_actions(a, rs, B)
+        oa, ra, _, _ = a.step(acts)
+        ob, rb, _, _ = b.step(as_tuple(b, acts, B))
+        assert torch.equal(a.world.pos, b.world.pos) and torch.equal(a.world.vel, b.world.vel), t
+        assert torch.equal(a._comm, b._comm), t
+        assert all(torch.equal(x, y) for x, y in zip(oa + ra, ob + rb)), t
+        for x, y in zip(a.world.agents, b.world.agents):
+            if not x.silent:
+                assert torch.equal(x.state.c, y.state.c)
+    with pytest.raises(_abi.MpeError, match="two contiguous float32 device tensors"):
+        b.step((torch.zeros(2, 2), torch.zeros(2, 2)))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", NINE)
 @pytest.mark.parametrize("B", [1000, 8192])

@@ -50,6 +50,8 @@ def measure(label, env, B, n, out):
     env.reset()
     if env.fused and not env._comm_kind:      # one [A, B, 5] tensor: the zero-copy form
         acts = [torch.stack(a).contiguous() for a in acts]
+    elif env.fused and env._comm_kind:        # (moves, utterances): the batched form of the per-agent [move | utterance] rows
+        acts = [tr.as_tuple(env, a, B) for a in acts]
     r, us = rate(env.step, acts, B, n, env.reset)
     out.append({"what": label + " eager env.step", "env_steps_per_s": r, "us_per_step": us})
     if EAGER_ONLY:
