@@ -598,13 +598,22 @@ class MultiAgentEnv(object):
         # tensors again (one that an earlier step validated; contents rewritten in place), a fully fused non-communication
         # env, nothing flipped since.  One step() then costs the host ~3 us instead of ~7 (the headline kernel takes 5.5: the
         # Python API stops being host-bound).  The tensors are remembered by weak reference: nothing is kept alive.
-        known = self._fast_acts.get(id(action_n))
-        if known is not None and known() is action_n and self._constants_seen == self.world._constants_version and \
+        pair = type(action_n) is tuple and len(action_n) == 2      # (moves, utterances) of a communication scenario
+        known = self._fast_acts.get(id(action_n[0]) if pair else id(action_n))
+        if known is not None and (type(known) is tuple) == pair and \
+                (known[0]() is action_n[0] and known[1]() is action_n[1] if pair else known() is action_n) and \
+                self._constants_seen == self.world._constants_version and \
                 not self._scenario_state_stale and not self.discrete_action_input and self.discrete_action_space and \
                 not self.force_discrete_action and len(self.agents) == len(self.world.agents) and self.fused and \
                 not self.fresh_outputs:
             self._flip ^= 1
             out = self._sets[self._flip]
+            if pair:      # one staging launch: the utterances into the comm state (silent agents' rows masked to zero)
+                torch.mul(action_n[1], self._speak_mask, out=self._comm)
+                for i, agent in enumerate(self.world.agents):
+                    if not agent.silent:
+                        agent.state.c = self._comm[i]
+                action_n = action_n[0]
             p = action_n.data_ptr()
             if out.act_ptr != p:
                 b = out.bufs
@@ -637,6 +646,11 @@ class MultiAgentEnv(object):
             if len(self._fast_acts) >= 64:
                 self._fast_acts.clear()
             self._fast_acts[id(action_n)] = weakref.ref(action_n)
+        elif pair and self._comm_kind and act is action_n[0] and not self.fresh_outputs and not self.numpy_io and \
+                not self.max_episode_steps and not (self._py_obs or self._py_reward or self._py_done or self._py_info):
+            if len(self._fast_acts) >= 64:
+                self._fast_acts.clear()
+            self._fast_acts[id(action_n[0])] = (weakref.ref(action_n[0]), weakref.ref(action_n[1]))
         if self._py_reward:          # the reward is a Python callback: the launch skips its reward stage
             b.rew = None
         rc = self._mpe_step(self._desc_ref, out.bufs_ref, self.batch_size, self._stream())

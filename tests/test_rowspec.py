@@ -182,6 +182,18 @@ def test_moves_and_utterances_as_one_pair_of_tensors_equal_the_per_agent_rows(na
                 assert torch.equal(x.state.c, y.state.c)
     with pytest.raises(_abi.MpeError, match="two contiguous float32 device tensors"):
         b.step((torch.zeros(2, 2), torch.zeros(2, 2)))
+    # the same pair of tensors again, rewritten in place: step()'s short path (one staging launch + the step), same results
+    pair = as_tuple(b, rand_actions(a, rs, B), B)
+    for t in range(5):
+        acts = rand_actions(a, rs, B)
+        fresh = as_tuple(b, acts, B)
+        pair[0].copy_(fresh[0]), pair[1].copy_(fresh[1])
+        oa, ra, _, _ = a.step(acts)
+        ob, rb, _, _ = b.step(pair)
+        assert all(torch.equal(x, y) for x, y in zip(oa + ra, ob + rb)) and torch.equal(a._comm, b._comm), ("short path", t)
+        if t == 2:
+            a.reset(), b.reset()
+    assert id(pair[0]) in b._fast_acts
 
 
 @pytest.mark.gpu
