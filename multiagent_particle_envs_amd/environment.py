@@ -553,6 +553,23 @@ class MultiAgentEnv(object):
             act = torch.zeros_like(act).scatter_(-1, idx, 1.0)
         return act, None
 
+    @staticmethod
+    def _rows_of_one_tensor(action_n, A, B):
+        """The reference's per-agent list, when it is the rows of ONE contiguous float32 [A,B,5] device tensor (a stacked policy
+        output handed over as `[t[i] for i in range(A)]`): that tensor -- no copies -- else None."""
+        if type(action_n) is not list or len(action_n) != A or not torch.is_tensor(action_n[0]):
+            return None
+        base = action_n[0]._base
+        if base is None or base.shape != (A, B, _abi.MPE_ACTION_DIM) or base.dtype != torch.float32 or not base.is_cuda or \
+                not base.is_contiguous():
+            return None
+        off, row = base.storage_offset(), B * _abi.MPE_ACTION_DIM
+        for i, a in enumerate(action_n):
+            if not torch.is_tensor(a) or a._base is not base or a.storage_offset() != off + i * row or \
+                    a.shape != (B, _abi.MPE_ACTION_DIM) or not a.is_contiguous():
+                return None
+        return base
+
     def _stage_comm_actions(self, action_n):
         """Communication scenarios: agent i's action row is [move (5) if movable] + [utterance (dim_c) if not
         silent] (Discrete / MultiDiscrete spaces, environment.py:148-155, 183-190).  The move part goes to
@@ -598,6 +615,10 @@ class MultiAgentEnv(object):
         # tensors again (one that an earlier step validated; contents rewritten in place), a fully fused non-communication
         # env, nothing flipped since.  One step() then costs the host ~3 us instead of ~7 (the headline kernel takes 5.5: the
         # Python API stops being host-bound).  The tensors are remembered by weak reference: nothing is kept alive.
+        if type(action_n) is list and not self._comm_kind:      # the reference's per-agent list ... as the rows of ONE [A,B,5] device
+            base = self._rows_of_one_tensor(action_n, len(self.agents), self.batch_size)      # tensor (a stacked policy output): that
+            if base is not None:                                                           # tensor, no copies -- and the short path
+                action_n = base
         pair = type(action_n) is tuple and len(action_n) == 2      # (moves, utterances) of a communication scenario
         known = self._fast_acts.get(id(action_n[0]) if pair else id(action_n))
         if known is not None and (type(known) is tuple) == pair and \

@@ -869,6 +869,28 @@ def test_step_fast_path_is_the_same_step(name, kw, bench):
     assert all(torch.equal(a, b) for a, b in zip(o_t, keep))
 
 
+def test_a_list_of_the_rows_of_one_tensor_is_used_in_place():
+    """The reference's per-agent list, when it is `[t[0], t[1], ...]` of one [A,B,5] device tensor (a stacked policy output):
+    no staging copies, the short path of the tensor form -- and the very same step as independent per-agent tensors."""
+    B = 640
+    a, b = mpe.make_env("simple_tag", batch_size=B, seed=3), mpe.make_env("simple_tag", batch_size=B, seed=3)
+    A = a.n
+    t = torch.zeros((A, B, 5), device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for k in range(5):
+        t.copy_(torch.rand((A, B, 5), device="cuda", generator=g))
+        oa, ra, _, _ = a.step([t[i] for i in range(A)])                 # rows of one tensor
+        ob, rb, _, _ = b.step([t[i].clone() for i in range(A)])         # independent tensors
+        assert torch.equal(a.world.pos, b.world.pos) and all(torch.equal(x, y) for x, y in zip(oa + ra, ob + rb)), k
+    assert id(t) in a._fast_acts and not b._fast_acts
+    # not the rows of one tensor (another order; a slice of something larger): staged as before, same results
+    big = torch.rand((A + 1, B, 5), device="cuda", generator=g)
+    for rows in ([t[i] for i in reversed(range(A))], [big[i] for i in range(A)]):
+        oa = a.step(rows)[0]
+        ob = b.step([r.clone() for r in rows])[0]
+        assert all(torch.equal(x, y) for x, y in zip(oa, ob))
+
+
 @pytest.mark.parametrize("ids", [False, True])
 def test_step_fast_path_survives_a_rollout_in_between(ids):
     """A RandomRollout writes the env's MpeBuffers (act / ids of BOTH output sets) behind step()'s back: the short path's

@@ -502,6 +502,154 @@ def test_a_program_of_too_many_ops_stays_interpreted():
         env._prog.static_source(env._desc)
 
 
+class _RandomScenario(BaseScenario):
+    """A scenario drawn from a seed: 2-6 agents, 1-5 landmarks, two per-world picks, utterances; every agent's row, reward and
+    done condition a random composition of the spec vocabulary (the peephole fuser and the compiled form must not care)."""
+
+    landmark_range = 0.9
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+        self.A, self.Lm = int(self.rs.randint(2, 7)), int(self.rs.randint(1, 6))
+        self.plan = None
+
+    def make_world(self, batch_size=1, device=None):
+        rs = self.rs
+        world = World(batch_size, device)
+        world.dim_c = 3
+        world.choice_pops = [self.Lm, self.A]
+        world.agents = [Agent() for _ in range(self.A)]
+        for i, a in enumerate(world.agents):
+            a.name, a.collide, a.silent = "agent %d" % i, bool(rs.rand() < 0.8), bool(i % 2)
+            a.size, a.accel, a.max_speed = float(rs.uniform(0.04, 0.15)), float(rs.uniform(2.0, 5.0)), float(rs.uniform(0.8, 1.5))
+        world.landmarks = [Landmark() for _ in range(self.Lm)]
+        for l in world.landmarks:
+            l.collide, l.movable, l.size = bool(rs.rand() < 0.5), False, float(rs.uniform(0.03, 0.2))
+        world.allocate()
+        return world
+
+    def reset_world(self, world, mask=None, seeds=None):
+        idx = world.reset_uniform(self.landmark_range, mask, choices=[self.Lm, self.A], seeds=seeds)
+        if world.choice_i32 is not None:
+            for k in range(2):
+                world.choice_i32[k].copy_(World.merge_choice(world.choice_i32[k].long(), idx[:, k].to(world.device), mask).to(torch.int32))
+
+    def _plan(self, world):
+        if self.plan is None:
+            rs, ag, lm = self.rs, world.agents, world.landmarks
+            ents = world.entities
+            self.plan = []
+            for a in ag:
+                o = rowspec.ObsSpec(world, a)
+                for _ in range(int(rs.randint(2, 7))):
+                    k = int(rs.randint(0, 8))
+                    if k == 0:
+                        o.vel().pos()
+                    elif k == 1:
+                        for e in (lm if rs.rand() < 0.5 else lm[::-1]):      # a run the fuser can take, or a reversed one it cannot
+                            o.rel(e)
+                    elif k == 2:
+                        for b in ag:
+                            if b is not a:
+                                o.rel(b)
+                        for b in ag:
+                            if b is not a:
+                                o.vel(b)
+                    elif k == 3:
+                        o.rel_pick(0, lm).onehot(0, self.Lm, 0.25, 0.75)
+                    elif k == 4:
+                        o.comm(ag[int(rs.randint(0, self.A))])
+                    elif k == 5:
+                        o.const(float(rs.uniform(-1, 1)), float(rs.uniform(-1, 1)), float(rs.uniform(-1, 1)))
+                    elif k == 6:
+                        o.rel(ents[int(rs.randint(0, len(ents)))])
+                    else:
+                        o.onehot(1, self.A, 0.0, 1.0)
+                r = rowspec.RewardSpec(world, a)
+                for _ in range(int(rs.randint(1, 6))):
+                    k = int(rs.randint(0, 7))
+                    if k == 0:
+                        for l in lm:
+                            r.min_dist(ag, l).add(float(rs.choice([-1.0, -0.5])))
+                    elif k == 1:
+                        for b in ag:
+                            if b is not a:
+                                r.add_if_touching(b, a, float(rs.choice([-1.0, -3.0])))
+                    elif k == 2:
+                        r.min_dist2_from(a, lm).add(-0.25, acc=1)
+                    elif k == 3:
+                        r.dist2_pick(a, 0, lm).sqrt().save(3).load(3).add(-1.0)
+                    elif k == 4:
+                        r.bound(a, 0).add(-1.0).bound(a, 1).add(-1.0)
+                    elif k == 5:
+                        for b in ag:
+                            for l in lm:
+                                r.add_if_touching(b, l, 0.5, acc=1)
+                    else:
+                        r.comm_sum(ag[0]).add(0.1).add_acc1()
+                d = None
+                if rs.rand() < 0.6:
+                    d = rowspec.DoneSpec(world, a).outside(a, 0.97)
+                    if rs.rand() < 0.5:
+                        d.min_dist(ag, lm[0]).done_if_lt(0.02).done_if_touching(a, lm[-1])
+                self.plan.append((o, r, d))
+        return self.plan
+
+    def obs_spec(self, agent, world):
+        return self._plan(world)[world.agents.index(agent)][0]
+
+    def reward_spec(self, agent, world):
+        return self._plan(world)[world.agents.index(agent)][1]
+
+    def done_spec(self, agent, world):
+        return self._plan(world)[world.agents.index(agent)][2]
+
+
+def _random_env(seed, B, fuse, **kw):
+    sc = _RandomScenario(seed)
+    w = sc.make_world(batch_size=B)
+    w.seed = seed
+    sc.reset_world(w)
+    keep, rowspec.FUSE = rowspec.FUSE, fuse
+    try:
+        env = mpe.MultiAgentEnv(w, sc.reset_world, None, None, compile_program=False, **kw)
+    finally:
+        rowspec.FUSE = keep
+    env.scenario = sc
+    return env
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_programs_one_op_per_call_vs_range_forms_vs_compiled_in(seed):
+    """Programs nobody wrote by hand: the same random scenario with one op per spec call, with the peephole pass (range / grid
+    forms), and compiled in -- rows, rewards, dones, state, the episode ends inside the launch: all three to the bit."""
+    B = 1500
+    kw = dict(max_episode_steps=6, auto_reset=True)
+    plain, fused, comp = _random_env(seed, B, False, **kw), _random_env(seed, B, True, **kw), _random_env(seed, B, True, **kw)
+    assert plain._prog.n_ops >= fused._prog.n_ops and comp.compile_program()
+    envs = (plain, fused, comp)
+    rs = np.random.RandomState(seed)
+    obs = [e.reset() for e in envs]
+    for o in obs[1:]:
+        assert all(torch.equal(x, y) for x, y in zip(obs[0], o))
+    for t in range(10):
+        if t == 3:
+            for e in envs:
+                e.world.pos.mul_(0.4)
+        act = rand_actions(plain, rs, B)
+        outs = [e.step(act) for e in envs]
+        for e in envs[1:]:
+            assert torch.equal(plain.world.pos, e.world.pos) and torch.equal(plain.episode_step, e.episode_step), (seed, t)
+            assert torch.equal(plain.world.choice_i32, e.world.choice_i32), (seed, t)
+        for k, o in enumerate(outs[1:]):
+            for i in range(plain.n):
+                assert torch.equal(outs[0][0][i], o[0][i]), (seed, t, "obs", k, i)
+                assert torch.equal(outs[0][1][i], o[1][i]), (seed, t, "reward", k, i)
+                assert torch.equal(outs[0][2][i], o[2][i]), (seed, t, "done", k, i)
+    assert comp.program_compiled and not fused.program_compiled
+
+
 def _strayed(agent, world):
     """A done callback: the agent left the arena (any world, any step)."""
     return (agent.state.p_pos.abs() > 0.95).any(dim=1)
