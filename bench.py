@@ -612,7 +612,7 @@ def per_gpu_stats(recs):
     return {"min": v[0], "median": v[len(v) // 2], "max": v[-1], "unit": "env-steps/s per GPU", "ranks": len(v)}
 
 
-def user_scenario_leg(torch, mpe, B, EP):
+def user_scenario_leg(torch, mpe, B, EP, rv, dev):
     """A scenario WITHOUT a kernel of its own (examples/corral.py: 3 agents, 3 posts, a per-world gate), stepped from Python
     through the drop-in API: described by ObsSpec / RewardSpec (World.step + the rows in one launch, mpe_step_rows -- the program
     interpreted, and compiled in) and, beside it, through its torch callbacks (the generic path: ~100 launches per step)."""
@@ -652,6 +652,20 @@ def user_scenario_leg(torch, mpe, B, EP):
                     "path": ("mpe_step_rows, compiled image" if env.program_compiled else "mpe_step_rows, interpreted") if env.fused
                             else "torch callbacks + mpe_world_step"}
         del env
+    # the same scenario through the HEADLINE's protocol (a HIP graph of consecutive mpe_step_rows launches, fresh block-drawn moves
+    # for every step, a device reset every EP steps): the device-bound rate of a user scenario, host out of the loop
+    for key, pol in (("program_graph", False), ("compiled_graph", None)):
+        lg = Leg(mpe, path, 3, B, EP, 0, 1, 0, scenario_kw={"compile_program": pol})
+        if (key == "compiled_graph") != bool(lg.env.program_compiled):
+            raise RuntimeError("user scenario leg %s: program_compiled = %r" % (key, lg.env.program_compiled))
+        d, R, _, r_ = lg.timed(torch, rv, dev, "graph", "fresh", 200, 10, 3, SIDE_REGION_MS)
+        out[key] = {"value": B * 200 * R / d, "unit": "env-steps/s", "ms_per_step": d * 1e3 / (200 * R), "timed_steps": 200 * R,
+                    "repeats": {"min": r_[0], "median": r_[1], "max": r_[2]},
+                    "path": "HIP graph of mpe_step_rows launches (%s), fresh moves per step, reset every %d steps"
+                            % ("compiled image" if lg.env.program_compiled else "interpreted", EP or 25)}
+        lg.release()
+        del lg
+        torch.cuda.empty_cache()
     out["program_over_generic"] = out["program"]["value"] / out["generic"]["value"]
     out["compiled_over_generic"] = out["compiled"]["value"] / out["generic"]["value"]
     return out
@@ -924,7 +938,7 @@ def main():
 
     default_line = solo and args.scenario == "simple_spread" and args.agents == 3 and B == 65536
     if default_line:
-        extra["user_scenario"] = user_scenario_leg(torch, mpe, B, EP)
+        extra["user_scenario"] = user_scenario_leg(torch, mpe, B, EP, rv, dev)
     headline_roof = roofline_entry(leg, k_us, B, args.mode, floor_us, head_timing)
     if default_line:
         leg.release()

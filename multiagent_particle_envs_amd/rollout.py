@@ -31,8 +31,12 @@ class RandomRollout(object):
         measured slower still: 13.0 vs 9.4 us per step; drawing the next BLOCK on a side stream, one fork/join per
         episode (commit d24e237), is slower too: 8.2-8.3 vs 7.3 us per step at B = 65536, 92.9 vs 85.2 at B = 1M --
         concurrent kernels do not overlap usefully on this stack.  The block draw is one 98 MB-write launch per 25 steps.)"""
-        if not env.fused or getattr(env, "_prog", None) is not None:
-            raise _abi.MpeError("RandomRollout drives the fused built-in scenarios (a row-program env steps through env.step / GraphedStep)")
+        if not env.fused:
+            raise _abi.MpeError("RandomRollout drives the device-side step (fused scenarios and row-program envs); this env steps "
+                                "through Python callbacks: use env.step / GraphedStep")
+        self._prog = getattr(env, "_prog", None)      # a row-program env: per-step launches (enqueue / capture) only
+        if self._prog is not None and env.max_episode_steps:
+            raise _abi.MpeError("RandomRollout keeps its own episode clock (episode_len): build the row-program env without max_episode_steps")
         if env._py_obs or env._py_reward or env._py_done or env._py_info:
             raise _abi.MpeError("RandomRollout runs on the device and evaluates the built-in callbacks only: this env has "
                                 "Python observation / reward / done / info callbacks (use env.step, or GraphedStep)")
@@ -107,7 +111,10 @@ class RandomRollout(object):
             out.act_ptr = None      # MultiAgentEnv.step's fast path must not trust its note of what b.act holds
             if self.pool_c is not None:
                 b.comm = self.pool_c[self.t % len(self.pool)].data_ptr()
-            _abi.check(L.mpe_step(C.byref(desc), C.byref(b), B, st), "mpe_step")
+            if self._prog is not None:
+                _abi.check(L.mpe_step_rows(C.byref(desc), C.byref(b), self._prog.ref, B, st), "mpe_step_rows")
+            else:
+                _abi.check(L.mpe_step(C.byref(desc), C.byref(b), B, st), "mpe_step")
             self.t += 1
         if self.pool_c is not None and steps > 0:   # the agents' comm state after the last step = their last words
             env._comm.copy_(self.pool_c[(self.t - 1) % len(self.pool)])
@@ -154,6 +161,9 @@ class RandomRollout(object):
         """One `mpe_rollout_random` launch covering `steps` env steps.  With `trajectory` (a
         Trajectory of at least `steps` blocks) every step's outputs land in their own block;
         without it each step overwrites the env's output set 0."""
+        if self._prog is not None:
+            raise _abi.MpeError("the fused T-step rollout (mpe_rollout_random) covers the built-in scenarios; a row-program env "
+                                "rolls out through per-step launches: enqueue() / capture()")
         if trajectory is None:
             b = self.env._sets[0].bufs
             ret = self.env._sets[0]

@@ -259,8 +259,39 @@ def test_rollout_with_integer_action_ids_equals_env_steps_with_those_ids():
     assert not torch.equal(envs[3].world.pos, ref.world.pos)
 
 
-def test_fused_rollout_is_refused_for_a_row_program_env():
-    env = mpe.make_env("simple_adversary", batch_size=64, num_agents=4, num_adversaries=2)
-    assert env.fused and env._prog is not None
-    with pytest.raises(_abi.MpeError, match="row-program"):
-        RandomRollout(env, episode_len=5)
+@pytest.mark.parametrize("compiled", [False, True])
+def test_a_row_program_env_rolls_out_through_per_step_launches(compiled):
+    """RandomRollout on a row-program env (a team size without a kernel of its own): enqueue() == the same resets, moves and
+    env.step calls by hand; a captured graph replays the same steps; the fused T-step launch stays with the built-ins."""
+    B, T = 768, 12
+    def make():
+        e = mpe.make_env("simple_adversary", batch_size=B, num_agents=4, num_adversaries=2, seed=9, compile_program=False)
+        if compiled:
+            assert e.compile_program()
+        return e
+    a, b, c = make(), make(), make()
+    assert a.fused and a._prog is not None and a.program_compiled == compiled
+    ra, rc = RandomRollout(a, episode_len=5, pool=5, regenerate=True), RandomRollout(c, episode_len=5, pool=5, regenerate=True)
+    out = ra.enqueue(T)
+    # by hand: reset every 5 steps with the rollout's episode numbers, the same block-drawn moves, env.step
+    L = _abi.lib()
+    moves = torch.empty((5, b.n, B, 5), device="cuda")
+    b._ensure_buffers()
+    for t in range(T):
+        if t % 5 == 0:
+            _abi.check(L.mpe_random_actions_block(moves.data_ptr(), None, b.n, B, ra.seed, t, 5, 0, _abi.raw_stream(b.world.device)), "draw")
+            bufs = b._sets[0].bufs
+            _abi.check(L.mpe_reset(C.byref(ra._gen_desc), C.byref(bufs), B, None, ra._lr, ra.seed, t // 5, 0, _abi.raw_stream(b.world.device)), "reset")
+        ob, rb, _, _ = b.step(moves[t % 5].clone())
+    assert torch.equal(a.world.pos, b.world.pos) and torch.equal(a.world.vel, b.world.vel)
+    for i in range(a.n):
+        assert torch.equal(out.obs_n[i], ob[i]) and torch.equal(out.reward_n[i], rb[i]), i
+    g = rc.capture(T)
+    rc.t = 0
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(c.world.pos, a.world.pos) and torch.equal(c.world.vel, a.world.vel)
+    with pytest.raises(_abi.MpeError, match="per-step launches"):
+        ra.fused(5)
+    with pytest.raises(_abi.MpeError, match="episode clock"):
+        RandomRollout(mpe.make_env("simple_adversary", batch_size=64, num_agents=4, num_adversaries=2, max_episode_steps=5), episode_len=5)
