@@ -337,6 +337,17 @@ int mpe_step_rows_episode(const MpeScenarioDesc *desc, const MpeBuffers *bufs, M
                           int32_t *episode_step, int32_t max_episode_steps, float landmark_range, uint64_t seed,
                           uint64_t episode, int64_t world_offset, void *stream);
 
+/* mpe_rollout_rows: mpe_rollout_random for a USER scenario -- T consecutive steps of a row-program env in ONE launch: the worlds'
+ * state stays in LDS, every agent's move is drawn in the kernel (the one-hot row mpe_random_actions_block(seed, step0 + t) would
+ * write), every episode_len global steps (0 = never) every world is reset (mpe_reset(mask = NULL, landmark_range, seed, episode =
+ * (step0 + t) / episode_len, world_offset)); step t's rows / rewards / dones go to trajectory block t of bufs->obs / rew / done
+ * (trajectory != 0: blocks of obs_off[A] * B floats / A * B entries) or over block 0.  Bit-identical to the T launches of
+ * {mpe_reset at the boundaries; mpe_random_actions_block; mpe_step_rows}.  Agents that speak (speakers != 0: their words would have
+ * to be drawn too) are not covered: MPE_EUNSUPPORTED.                                                                          */
+int mpe_rollout_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowProgram *prog, int64_t B, int32_t T,
+                     int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
+                     int32_t trajectory, uint32_t speakers, void *stream);
+
 /* ---- a row program COMPILED IN: the interpreter specialised away ---------------------------------------------------------
  * mpe_rows / mpe_step_rows / mpe_episode_finish interpret a program op by op.  For a program that stays the same for the
  * life of an env the same kernel source can be compiled WITH the program as constants (every op code, entity index, column

@@ -632,7 +632,7 @@ static uint64_t tables_hash(const mpe::RowTables &tabs) { return fnv1a(kFnvSeed,
 // a program compiled in (mpe_rows_load_image): the module, its four entry points, and what it was compiled for
 struct RowImage {
   hipModule_t module;
-  void *fns[6];            // _ns, _ps, _nr, _pr, _ne, _pe
+  void *fns[8];            // _ns, _ps, _nr, _pr, _ne, _pe, _nl, _pl
   mpe::RowDims dims;
   uint64_t tables;
   const int32_t *ops_device;
@@ -661,7 +661,7 @@ static int static_identity(const char *what, const mpe::RowDims &h, const mpe::R
 }
 
 static int rows_call(const char *what, bool phys, const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B,
-                     const mpe::RowEpisode *episode, void *stream) {
+                     const mpe::RowEpisode *episode, void *stream, const mpe::RollArgs *roll = nullptr) {
   static_assert(sizeof(mpe::RowTables) <= MPE_ROWS_HEADER_BYTES, "MPE_ROWS_HEADER_BYTES too small");
   mpe::RowDims h;
   mpe::RowTables tabs;
@@ -672,7 +672,8 @@ static int rows_call(const char *what, bool phys, const MpeScenarioDesc *d, cons
   if (d->n_choices > 0) if (int rc = need(b->choice, what, "choice (the per-world picks of reset_world)")) return rc;
   // (bufs->comm may be NULL: every utterance then reads as zero -- the state of agents that never speak)
   if (phys) {
-    if (int rc = check_actions(b, what)) return rc;
+    if (!roll)
+      if (int rc = check_actions(b, what)) return rc;
     for (int e = d->n_agents; e < d->n_agents + d->n_landmarks; ++e)
       if (d->movable[e]) return fail(MPE_EUNSUPPORTED, "%s: a movable landmark (entity %d) is stepped by mpe_world_step only", what, e);
   }
@@ -687,12 +688,12 @@ static int rows_call(const char *what, bool phys, const MpeScenarioDesc *d, cons
   const uint64_t hash = tables_hash(tabs);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (image_matches(p, h, hash))      // the program compiled in, and still the descriptor it was compiled for
-    return hip_result(mpe::launch_rows_image(static_cast<RowImage *>(p->image)->fns, *b, h, tabs, phys, vec4 ? 1 : 0, ep, (size_t)B, s), what);
+    return hip_result(mpe::launch_rows_image(static_cast<RowImage *>(p->image)->fns, *b, h, tabs, phys, vec4 ? 1 : 0, ep, (size_t)B, s, roll), what);
   if (hash != p->header_hash) {
     if (int rc = mpe::launch_rows_header(tabs, p->header_device, s)) return hip_result(rc, what);
     p->header_hash = hash;
   }
-  return hip_result(mpe::launch_rows(*b, h, tabs, p->header_device, phys, vec4 ? 1 : 0, ep, p->ops_device, (size_t)B, s), what);
+  return hip_result(mpe::launch_rows(*b, h, tabs, p->header_device, phys, vec4 ? 1 : 0, ep, p->ops_device, (size_t)B, s, roll), what);
 }
 
 int mpe_rows(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B, void *stream) {
@@ -721,6 +722,33 @@ static int episode_args(const char *what, int mode, const MpeScenarioDesc *d, co
   ep->episode = episode;
   ep->world_offset = (uint64_t)world_offset;
   return 0;
+}
+
+int mpe_rollout_rows(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B, int32_t T, int32_t episode_len,
+                     float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset, int32_t trajectory, uint32_t speakers,
+                     void *stream) {
+  const char *what = "mpe_rollout_rows";
+  if (T < 0 || episode_len < 0) return fail(MPE_EINVAL, "%s: T, episode_len must be >= 0", what);
+  if (speakers != 0)
+    return fail(MPE_EUNSUPPORTED, "%s: agents that speak (mask 0x%x): their words are not drawn in this kernel; roll out through "
+                "mpe_random_comm + mpe_step_rows per step", what, speakers);
+  if (!d) return fail(MPE_EINVAL, "%s: desc is NULL", what);
+  if (T == 0) return 0;
+  mpe::RollArgs ra;
+  std::memset(&ra, 0, sizeof(ra));
+  ra.T = T;
+  ra.episode_len = episode_len;
+  ra.trajectory = trajectory ? 1 : 0;
+  ra.landmark_range = landmark_range;
+  ra.seed = seed;
+  ra.step0 = step0;
+  ra.world_offset = (uint64_t)world_offset;
+  mpe::RowEpisode ep;      // (off; carries the picks' populations and the world numbering the in-kernel resets draw with)
+  std::memset(&ep, 0, sizeof(ep));
+  ep.n_choices = d->n_choices;
+  for (int k = 0; k < MPE_MAX_CHOICES; ++k) ep.choice_pop[k] = k < d->n_choices ? d->choice_pop[k] : 1;
+  ep.world_offset = (uint64_t)world_offset;
+  return rows_call(what, true, d, b, p, B, &ep, stream, &ra);
 }
 
 int mpe_step_rows_episode(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B, int32_t *episode_step,
@@ -828,8 +856,8 @@ int mpe_rows_load_image(const MpeScenarioDesc *d, MpeRowProgram *p, const int32_
     delete im;
     return fail((int)rc, "%s: hipModuleLoadData: %s", what, hipGetErrorString(rc));
   }
-  static const char *const suffix[6] = {"_ns", "_ps", "_nr", "_pr", "_ne", "_pe"};
-  for (int k = 0; k < 6; ++k) {
+  static const char *const suffix[8] = {"_ns", "_ps", "_nr", "_pr", "_ne", "_pe", "_nl", "_pl"};
+  for (int k = 0; k < 8; ++k) {
     const std::string fn = std::string(name) + suffix[k];
     hipFunction_t f = nullptr;
     rc = hipModuleGetFunction(&f, im->module, fn.c_str());

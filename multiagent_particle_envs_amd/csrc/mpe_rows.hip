@@ -123,10 +123,15 @@ __device__ __forceinline__ void agents_of_wave(int first, int stride, int A, F &
 // EP2: the instantiation behind mpe_step_rows_episode (episodes end inside the launch: a second pass of the observation programs
 // for workgroups with a finished world).  Its own instantiation because the loop around the programs costs the plain step
 // 8 % interpreted and up to 38 % compiled in (session r4s27) when it is merely present.
-template <bool NT, bool PHYS, bool STATIC, bool EP2>
+// ROLL: the instantiation behind mpe_rollout_rows -- T steps per launch with the state resident in LDS, the moves drawn in the
+// kernel (action_draw: the rows mpe_random_actions_block would write), a reset_world of every world at the episode boundaries
+// (mpe_reset's draws), every step's rows / rewards / dones into its own trajectory block or over the same one.  (Its own
+// instantiation for the reason EP2 is one.)
+template <bool NT, bool PHYS, bool STATIC, bool EP2, bool ROLL = false>
 __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode &ep, const RowDims &h_arg,
                                           const uint32_t *__restrict__ const tables, const int32_t vec4, const int32_t split_arg,
-                                          const uint32_t *__restrict__ const ops_g, const size_t B) {
+                                          const uint32_t *__restrict__ const ops_g, const size_t B, const RollArgs &ra = RollArgs{}) {
+  static_assert(!ROLL || (PHYS && !EP2), "a rollout steps the world and keeps its own episode clock");
   // LDS: a launch parameter for the interpreter; a compiled program knows its size (no 64 KB opt-in for module kernels needed)
   float *smem;
   if constexpr (STATIC) {
@@ -199,7 +204,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
 
   // ---- (World.step) this wave's first agent's move leaves for HBM together with the state loads: one memory round trip, not two
   float act_x = 0.f, act_y = 0.f;
-  if constexpr (PHYS) {
+  if constexpr (PHYS && !ROLL) {
     if (is_rows && wave < A && ((h.movable >> wave) & 1ull)) fetch_action_wave(b, B, wave, w0, ln, 1.0f, act_x, act_y);   // raw: scaled by accel below
   }
   // ---- stage the state (finished worlds: reset_world first -- the draws of mpe_reset for (seed, world, episode)) -----------
@@ -268,6 +273,46 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
     return sqrt_lt(sq2d(P(e, 0) - P(f, 0), P(e, 1) - P(f, 1)), TF(MPE_TAB(size), e) + TF(MPE_TAB(size), f));
   };
 
+  // ---- (ROLL) T steps: the output pointers of the current step, the reset at an episode boundary, then the step itself ---------
+  MpeBuffers bo = b;
+  const int T_ = ROLL ? ra.T : 1;
+#pragma nounroll
+  for (int t = 0; t < T_; ++t) {
+  const uint64_t gstep = ra.step0 + (uint64_t)t;
+  if constexpr (ROLL) {
+    if (ra.trajectory && t > 0) {
+      bo.obs += (size_t)TI(MPE_TAB(obs_off), A) * B;
+      if (bo.rew) bo.rew += (size_t)A * B;
+      if (bo.done) bo.done += (size_t)A * B;
+    }
+    if (ra.episode_len > 0 && gstep % (uint64_t)ra.episode_len == 0) {      // (uniform) reset_world of every world
+      const uint64_t episode = gstep / (uint64_t)ra.episode_len;
+      for (int e = wave; e < E; e += NW) {
+        float x, y;
+        reset_draw(ra.seed, gw, episode, e, e < A ? 1.0f : ra.landmark_range, x, y);
+        S_pos[(2 * e) * kWave + lane] = x;
+        S_pos[(2 * e + 1) * kWave + lane] = y;
+        if (live) {
+          (b.pos + wave_off((size_t)(2 * e) * B + w0))[ln] = x;
+          (b.pos + wave_off((size_t)(2 * e + 1) * B + w0))[ln] = y;
+        }
+        if (e < NV && e < A) {
+          S_vel[(2 * e) * kWave + lane] = 0.f;
+          S_vel[(2 * e + 1) * kWave + lane] = 0.f;
+          if (live && !((h.movable >> e) & 1ull)) {      // (movable agents' velocities leave with this step's state)
+            (b.vel + wave_off((size_t)(2 * e) * B + w0))[ln] = 0.f;
+            (b.vel + wave_off((size_t)(2 * e + 1) * B + w0))[ln] = 0.f;
+          }
+        }
+      }
+      for (int k = wave; k < h.n_picks; k += NW) {
+        const int g = choice_draw(ra.seed, gw, episode, k, ep.choice_pop[k]);
+        if (live) (b.choice + wave_off((size_t)k * B + w0))[ln] = g;
+        S_pick[k * kWave + lane] = g;
+      }
+      __syncthreads();
+    }
+  }
   if constexpr (PHYS) {
     // ---- World.step (core.py:117-169) by the agent waves: action force, contacts with every other entity in ascending order
     // (Q9) from the PRE-step positions, integration -- the device functions and the order of the step kernels, so the state
@@ -278,7 +323,11 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
         float mx = P(i, 0), my = P(i, 1), mvx = V(i, 0), mvy = V(i, 1);
         if ((h.movable >> i) & 1ull) {
           float ux, uy;
-          if (i == wave) {         // prefetched at kernel entry; a one-hot row / an id decodes to exact -1 / 0 / +1: scale now
+          if constexpr (ROLL) {    // the one-hot row mpe_random_actions_block would write for (seed, world, step, agent)
+            const int m = action_draw(ra.seed, gw, gstep, i);
+            ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * TF(MPE_TAB(accel), i);
+            uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * TF(MPE_TAB(accel), i);
+          } else if (i == wave) {  // prefetched at kernel entry; a one-hot row / an id decodes to exact -1 / 0 / +1: scale now
             const bool raw = b.act || b.ids;
             ux = raw ? act_x * TF(MPE_TAB(accel), i) : act_x;
             uy = raw ? act_y * TF(MPE_TAB(accel), i) : act_y;
@@ -437,7 +486,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
           obs_op(op);
         }
       }
-      flush_tile<NT>(tile, b.obs + B * (size_t)TI(MPE_TAB(obs_off), i) + w0 * (size_t)D, D, nvalid, lane, vec4 != 0);
+      flush_tile<NT>(tile, bo.obs + B * (size_t)TI(MPE_TAB(obs_off), i) + w0 * (size_t)D, D, nvalid, lane, vec4 != 0);
     };
     agents_of_wave<STATIC, PHYS>(is_rows ? wave : A, RW, A, obs_agent);
   }
@@ -447,7 +496,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   // ---- reward and done programs of this wave's agents ----------------------------------------------------------------------
   const bool has_done = TI(MPE_TAB(done_begin), A) != TI(MPE_TAB(done_begin), 0);
   bool dn_wave = false;      // some agent of this wave is done (per world)
-  if (b.rew || (b.done && has_done)) {
+  if (bo.rew || (bo.done && has_done)) {
     float *const slot = S_slot + (size_t)wave * kRowSlots * kWave;      // this wave's eight value slots
     // min over the run first .. first + n - 1 of |p[q] - o|^2 (flip: |o - p[q]|^2), first to last; four positions per LDS round trip
     auto min_d2_run = [&](int first, int n, float ox, float oy, bool flip) {
@@ -595,7 +644,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
           for (int pc = dc0; pc < dc1; ++pc) rew_op(OP(pc));
         }
       }
-      if (b.done && live) (b.done + wave_off((size_t)i * B + w0))[ln] = dn ? 1 : 0;
+      if (bo.done && live) (bo.done + wave_off((size_t)i * B + w0))[ln] = dn ? 1 : 0;
       dn_wave = dn_wave || dn;
     };
     agents_of_wave<STATIC, PHYS>(rwave, RW, A, rew_agent);
@@ -608,10 +657,14 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
       for (int a = 1; a < A; ++a) rest += S_rew[a * kWave + lane];
       total = A > 1 ? S_rew[lane] + rest : S_rew[lane];
     }
-    if (live && b.rew)
-      for (int i = rwave; i < A; i += RW) (b.rew + wave_off((size_t)i * B + w0))[ln] = h.collaborative ? total : S_rew[i * kWave + lane];
-  } else if (b.done && live) {
-    for (int i = rwave; i < A; i += RW) (b.done + wave_off((size_t)i * B + w0))[ln] = 0;
+    if (live && bo.rew)
+      for (int i = rwave; i < A; i += RW) (bo.rew + wave_off((size_t)i * B + w0))[ln] = h.collaborative ? total : S_rew[i * kWave + lane];
+  } else if (bo.done && live) {
+    for (int i = rwave; i < A; i += RW) (bo.done + wave_off((size_t)i * B + w0))[ln] = 0;
+  }
+  if constexpr (ROLL) {
+    __syncthreads();      // the next step reuses S_rew, the slots and the tiles
+    break;                // (leaves the pass loop; the step loop goes on)
   }
   if constexpr (!EP2) return;
 
@@ -661,6 +714,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   }
   __syncthreads();
   }      // (second pass: the observation programs on the restarted worlds' state -- `fin` lanes read their utterances as zero)
+  }      // (ROLL: the next step)
 }
 
 #ifndef MPE_ROWS_STATIC
@@ -670,13 +724,19 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
                                                  const uint32_t *__restrict__ const ops_g, const size_t B) {
   rows_body<NT, PHYS, false, EP2>(b, ep, h, tables, vec4, split, ops_g, B);
 }
+template <bool NT>
+__global__ void __launch_bounds__(1024) k_rows_roll(const MpeBuffers b, const RowEpisode ep, const RowDims h,
+                                                      const uint32_t *__restrict__ const tables, const int32_t vec4,
+                                                      const uint32_t *__restrict__ const ops_g, const size_t B, const RollArgs ra) {
+  rows_body<NT, true, false, false, true>(b, ep, h, tables, vec4, 0, ops_g, B, ra);
+}
 #endif
 
 }  // namespace
 
 #ifdef MPE_ROWS_STATIC
-// the six entry points of a compiled program: <name>_{n,p}{s,r,e} = {nontemporal, plain} row stores x {step, rows only, step with
-// the episode end inside}
+// the eight entry points of a compiled program: <name>_{n,p}{s,r,e,l} = {nontemporal, plain} row stores x {step, rows only, step
+// with the episode end inside, T-step rollout}
 #define MPE_ROWS_CAT2(a, b) a##b
 #define MPE_ROWS_CAT(a, b) MPE_ROWS_CAT2(a, b)
 #define MPE_ROWS_STATIC_KERNEL(suffix, NT, PHYS, EP2)                                                                         \
@@ -691,6 +751,15 @@ MPE_ROWS_STATIC_KERNEL(_nr, true, false, false)
 MPE_ROWS_STATIC_KERNEL(_pr, false, false, false)
 MPE_ROWS_STATIC_KERNEL(_ne, true, true, true)
 MPE_ROWS_STATIC_KERNEL(_pe, false, true, true)
+#define MPE_ROWS_STATIC_ROLL_KERNEL(suffix, NT)                                                                               \
+  extern "C" __global__ void __launch_bounds__(static_waves<true>() * kWave)                                                   \
+      __attribute__((amdgpu_waves_per_eu(MPE_ROWS_STATIC_OCC_STEP)))                                                           \
+      MPE_ROWS_CAT(MPE_ROWS_STATIC_NAME, suffix)(const MpeBuffers b, const RowEpisode ep, const int32_t vec4, const size_t B,  \
+                                                 const RollArgs ra) {                                                          \
+    rows_body<NT, true, true, false, true>(b, ep, RowDims{}, nullptr, vec4, 0, nullptr, B, ra);                                \
+  }
+MPE_ROWS_STATIC_ROLL_KERNEL(_nl, true)
+MPE_ROWS_STATIC_ROLL_KERNEL(_pl, false)
 #else
 
 int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream) {
@@ -722,7 +791,7 @@ static bool rows_nontemporal(const RowDims &h, const RowTables &host, int vec4, 
 }
 
 int launch_rows(const MpeBuffers &b, const RowDims &h, const RowTables &host, const void *tables_device, bool phys, int vec4,
-                const RowEpisode &ep, const int32_t *ops_device, size_t B, hipStream_t stream) {
+                const RowEpisode &ep, const int32_t *ops_device, size_t B, hipStream_t stream, const RollArgs *roll) {
   int W = 0;
   size_t lds = 0;
   // (episode mode, mpe_episode_finish, with ONE wave per 64 worlds -- most workgroups only read their flags and leave -- costs
@@ -740,24 +809,36 @@ int launch_rows(const MpeBuffers &b, const RowDims &h, const RowTables &host, co
     const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return (int)rc;
   }
+  if (roll) {
+    auto fr = nt ? k_rows_roll<true> : k_rows_roll<false>;
+    if (lds > 64 * 1024) {
+      const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (rc != hipSuccess) return (int)rc;
+    }
+    hipLaunchKernelGGL(fr, dim3(grid), dim3(W * kWave), lds, stream, b, ep, h, reinterpret_cast<const uint32_t *>(tables_device),
+                       (int32_t)vec4, reinterpret_cast<const uint32_t *>(ops_device), B, *roll);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(W * kWave), lds, stream, b, ep, h, reinterpret_cast<const uint32_t *>(tables_device),
                      (int32_t)vec4, (int32_t)0, reinterpret_cast<const uint32_t *>(ops_device), B);
   return (int)hipGetLastError();
 }
 
-// a compiled program (hipModule functions in the order ns, ps, nr, pr, ne, pe): same geometry, no tables, no ops
-int launch_rows_image(void *const fns[6], const MpeBuffers &b, const RowDims &h, const RowTables &host, bool phys, int vec4,
-                      const RowEpisode &ep, size_t B, hipStream_t stream) {
+// a compiled program (hipModule functions in the order ns, ps, nr, pr, ne, pe, nl, pl): same geometry, no tables, no ops
+int launch_rows_image(void *const fns[8], const MpeBuffers &b, const RowDims &h, const RowTables &host, bool phys, int vec4,
+                      const RowEpisode &ep, size_t B, hipStream_t stream, const RollArgs *roll) {
   int W = 0;
   size_t lds = 0;
   if (int rc = rows_geometry(h, phys, &W, &lds, 0)) return rc;
   const bool nt = rows_nontemporal(h, host, vec4, ep, B);
-  hipFunction_t fn = static_cast<hipFunction_t>(fns[(ep.enabled == 2 ? 4 : phys ? 0 : 2) + (nt ? 0 : 1)]);
+  hipFunction_t fn = static_cast<hipFunction_t>(fns[(roll ? 6 : ep.enabled == 2 ? 4 : phys ? 0 : 2) + (nt ? 0 : 1)]);
   MpeBuffers b_ = b;
   RowEpisode ep_ = ep;
   int32_t vec4_ = vec4;
   size_t B_ = B;
-  void *args[] = {&b_, &ep_, &vec4_, &B_};
+  RollArgs ra_;
+  if (roll) ra_ = *roll;
+  void *args[] = {&b_, &ep_, &vec4_, &B_, &ra_};      // (the trailing RollArgs only exists in the rollout entry points)
   const unsigned grid = (unsigned)((B + kWave - 1) / kWave);
   return (int)hipModuleLaunchKernel(fn, grid, 1, 1, (unsigned)(W * kWave), 1, 1, 0u, stream, args, nullptr);      // (its LDS is static)
 }

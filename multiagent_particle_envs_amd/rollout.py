@@ -161,9 +161,9 @@ class RandomRollout(object):
         """One `mpe_rollout_random` launch covering `steps` env steps.  With `trajectory` (a
         Trajectory of at least `steps` blocks) every step's outputs land in their own block;
         without it each step overwrites the env's output set 0."""
-        if self._prog is not None:
-            raise _abi.MpeError("the fused T-step rollout (mpe_rollout_random) covers the built-in scenarios; a row-program env "
-                                "rolls out through per-step launches: enqueue() / capture()")
+        if self._prog is not None and self.speakers:
+            raise _abi.MpeError("the fused T-step rollout of a row-program env (mpe_rollout_rows) draws moves, not words: this env has "
+                                "agents that speak; it rolls out through per-step launches: enqueue() / capture()")
         if trajectory is None:
             b = self.env._sets[0].bufs
             ret = self.env._sets[0]
@@ -174,10 +174,15 @@ class RandomRollout(object):
         b.act = b.ids = b.u = None
         if trajectory is None:
             ret.act_ptr = None      # (as in enqueue: the env's set 0 no longer points at the caller's action tensor)
-        _abi.check(self._L.mpe_rollout_random(C.byref(self._desc), C.byref(b), self.B, int(steps), self.episode_len,
-                                              self._lr, self.seed, self.t, int(self.world.world_offset),
-                                              1 if trajectory is not None else 0, self._stream()),
-                   "mpe_rollout_random")
+        if self._prog is not None:      # a row-program env: the same launch shape, the rows and rewards by its program
+            _abi.check(self._L.mpe_rollout_rows(C.byref(self._desc), C.byref(b), self._prog.ref, self.B, int(steps), self.episode_len,
+                                                self._lr, self.seed, self.t, int(self.world.world_offset),
+                                                1 if trajectory is not None else 0, 0, self._stream()), "mpe_rollout_rows")
+        else:
+            _abi.check(self._L.mpe_rollout_random(C.byref(self._desc), C.byref(b), self.B, int(steps), self.episode_len,
+                                                  self._lr, self.seed, self.t, int(self.world.world_offset),
+                                                  1 if trajectory is not None else 0, self._stream()),
+                       "mpe_rollout_random")
         self.t += steps
         self._mark_stale()
         return ret

@@ -291,7 +291,22 @@ def test_a_row_program_env_rolls_out_through_per_step_launches(compiled):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(c.world.pos, a.world.pos) and torch.equal(c.world.vel, a.world.vel)
-    with pytest.raises(_abi.MpeError, match="per-step launches"):
-        ra.fused(5)
+    # ... and the fused T-step launch (mpe_rollout_rows: state in LDS, moves and resets drawn in the kernel): every step's rows,
+    # rewards and dones in its own trajectory block, the state after the last step -- the per-step launches' to the bit
+    d, e = make(), make()
+    rd, re_ = RandomRollout(d, episode_len=5, pool=5, regenerate=True), RandomRollout(e, episode_len=5, pool=5, regenerate=True)
+    traj = Trajectory(d, T)
+    rd.fused(T, traj)
+    for t in range(T):
+        out_t = re_.enqueue(1)
+        for i in range(d.n):
+            assert torch.equal(traj.obs[t][i], out_t.obs_n[i]), (t, i, float((traj.obs[t][i] - out_t.obs_n[i]).abs().max()))
+            assert torch.equal(traj.rew[t][i], out_t.reward_n[i]), (t, i)
+            assert not traj.done[t][i].any()
+    assert torch.equal(d.world.pos, e.world.pos) and torch.equal(d.world.vel, e.world.vel)
+    assert torch.equal(d.world.choice_i32, e.world.choice_i32)
+    rd.fused(3)                       # without a trajectory: over the env's output set 0; the clock goes on (steps 12, 13, 14)
+    last = re_.enqueue(3)
+    assert torch.equal(d.world.pos, e.world.pos) and all(torch.equal(d._sets[0].obs_n[i], last.obs_n[i]) for i in range(d.n))
     with pytest.raises(_abi.MpeError, match="episode clock"):
         RandomRollout(mpe.make_env("simple_adversary", batch_size=64, num_agents=4, num_adversaries=2, max_episode_steps=5), episode_len=5)

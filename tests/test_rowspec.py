@@ -485,7 +485,7 @@ def test_static_source_and_image_of_a_program_on_the_cpu():
     assert src.count("{") - 3 == env._prog.n_ops + 1          # one {a, b, c, d} per op (+ the dims' region pair)
     from multiagent_particle_envs_amd import _build
     image = _build.compile_rows_image(src)
-    for suffix in ("_ns", "_ps", "_nr", "_pr", "_ne", "_pe"):
+    for suffix in ("_ns", "_ps", "_nr", "_pr", "_ne", "_pe", "_nl", "_pl"):
         assert (name + suffix).encode() in image
     assert _build.compile_rows_image(src) == image            # cached by content
     env.world.agents[0].size = 0.2
