@@ -663,6 +663,12 @@ def user_scenario_leg(torch, mpe, B, EP, rv, dev):
                     "repeats": {"min": r_[0], "median": r_[1], "max": r_[2]},
                     "path": "HIP graph of mpe_step_rows launches (%s), fresh moves per step, reset every %d steps"
                             % ("compiled image" if lg.env.program_compiled else "interpreted", EP or 25)}
+        if key == "compiled_graph":      # ... and as whole episodes per launch (mpe_rollout_rows: the moves drawn in the kernel)
+            d2, R2, _, r2_ = lg.timed(torch, rv, dev, "fused", "resident", 200, 10, 3, SIDE_REGION_MS)
+            out["compiled_fused_rollout"] = {"value": B * 200 * R2 / d2, "unit": "env-steps/s", "us_per_step": d2 * 1e6 / (200 * R2),
+                                             "repeats": {"min": r2_[0], "median": r2_[1], "max": r2_[2]},
+                                             "path": "mpe_rollout_rows (compiled image): %d steps per launch, every step's rows / rewards / dones "
+                                                     "kept in a trajectory" % (EP or 25)}
         lg.release()
         del lg
         torch.cuda.empty_cache()
