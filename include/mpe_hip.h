@@ -342,8 +342,8 @@ int mpe_step_rows_episode(const MpeScenarioDesc *desc, const MpeBuffers *bufs, M
  * write), every episode_len global steps (0 = never) every world is reset (mpe_reset(mask = NULL, landmark_range, seed, episode =
  * (step0 + t) / episode_len, world_offset)); step t's rows / rewards / dones go to trajectory block t of bufs->obs / rew / done
  * (trajectory != 0: blocks of obs_off[A] * B floats / A * B entries) or over block 0.  Bit-identical to the T launches of
- * {mpe_reset at the boundaries; mpe_random_actions_block; mpe_step_rows}.  Agents that speak (speakers != 0: their words would have
- * to be drawn too) are not covered: MPE_EUNSUPPORTED.                                                                          */
+ * {mpe_reset at the boundaries; mpe_random_actions_block; mpe_random_comm; mpe_step_rows}.  speakers: bit a = agent a says a drawn
+ * one-hot word every step (mpe_random_comm's draws); after the launch bufs->comm holds the speakers' last words.               */
 int mpe_rollout_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowProgram *prog, int64_t B, int32_t T,
                      int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
                      int32_t trajectory, uint32_t speakers, void *stream);

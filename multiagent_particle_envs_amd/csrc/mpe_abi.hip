@@ -729,10 +729,12 @@ int mpe_rollout_rows(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgra
                      void *stream) {
   const char *what = "mpe_rollout_rows";
   if (T < 0 || episode_len < 0) return fail(MPE_EINVAL, "%s: T, episode_len must be >= 0", what);
-  if (speakers != 0)
-    return fail(MPE_EUNSUPPORTED, "%s: agents that speak (mask 0x%x): their words are not drawn in this kernel; roll out through "
-                "mpe_random_comm + mpe_step_rows per step", what, speakers);
   if (!d) return fail(MPE_EINVAL, "%s: desc is NULL", what);
+  if (speakers != 0) {
+    if (d->dim_c <= 0) return fail(MPE_EINVAL, "%s: speakers 0x%x but desc->dim_c = %d", what, speakers, d->dim_c);
+    if (d->n_agents < 32 && (speakers >> d->n_agents) != 0) return fail(MPE_EINVAL, "%s: speakers 0x%x names agents beyond %d", what, speakers, d->n_agents);
+    if (int rc = need(b ? b->comm : nullptr, what, "comm (receives the speaking agents' last words)")) return rc;
+  }
   if (T == 0) return 0;
   mpe::RollArgs ra;
   std::memset(&ra, 0, sizeof(ra));
@@ -748,6 +750,7 @@ int mpe_rollout_rows(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgra
   ep.n_choices = d->n_choices;
   for (int k = 0; k < MPE_MAX_CHOICES; ++k) ep.choice_pop[k] = k < d->n_choices ? d->choice_pop[k] : 1;
   ep.world_offset = (uint64_t)world_offset;
+  ep.speakers = speakers;
   return rows_call(what, true, d, b, p, B, &ep, stream, &ra);
 }
 

@@ -104,6 +104,8 @@ struct RowEpisode {
   float landmark_range;
   int32_t n_choices, choice_pop[MPE_MAX_CHOICES];
   uint64_t seed, episode, world_offset;
+  uint32_t speakers;             // (mpe_rollout_rows) bit a: agent a says a drawn word every step
+  uint32_t pad_;
 };
 int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream);
 int launch_rows(const MpeBuffers &b, const RowDims &dims, const RowTables &host, const void *tables_device, bool phys, int vec4,

@@ -176,7 +176,8 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   int *const S_pick = reinterpret_cast<int *>(S_slot + (size_t)NW * kRowSlots * kWave);   // [4][64]  the per-world picks
   // the post-step state of World.step ([A][4][64], PHYS only) and the waves' row tiles ([W][64 * Dmax]) share one region: the
   // new state has moved into S_pos / S_vel (behind a barrier) before the first tile column is written
-  float *const S_new = reinterpret_cast<float *>(S_pick + kRowPicks * kWave);
+  int *const S_word = S_pick + kRowPicks * kWave;      // [A][64] (step layouts) the word each speaking agent says this step (ROLL)
+  float *const S_new = reinterpret_cast<float *>(S_word + (PHYS ? A * kWave : 0));
   float *const tiles = S_new;
 
   // ---- episode bookkeeping (mpe_episode_finish): count the step, find the worlds that finished, leave if none did ----------
@@ -266,7 +267,10 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   auto P = [&](int e, int c) { return S_pos[(2 * e + c) * kWave + lane]; };
   auto V = [&](int e, int c) { return e < NV ? S_vel[(2 * e + c) * kWave + lane] : 0.f; };
   auto pick = [&](int k) { return S_pick[k * kWave + lane]; };
-  auto word = [&](int j, int c) { return (fin || !b.comm) ? 0.f : (b.comm + wave_off(((size_t)j * B + w0) * DC))[ln * DC + c]; };
+  auto word = [&](int j, int c) {
+    if constexpr (ROLL) return ((ep.speakers >> j) & 1u) ? (S_word[j * kWave + lane] == c ? 1.f : 0.f) : 0.f;      // drawn this step / silent
+    else return (fin || !b.comm) ? 0.f : (b.comm + wave_off(((size_t)j * B + w0) * DC))[ln * DC + c];
+  };
   // inside region r (a landmark, e.g. a forest of simple_world_comm.py:231-261): strict |e - region| < size_e + size_region
   auto in_region = [&](int e, int r) {
     const int f = h.region_entity[r];
@@ -312,6 +316,11 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
       }
       __syncthreads();
     }
+  }
+  if constexpr (ROLL) {      // the words of this step (mpe_random_comm's draws); read behind World.step's barriers
+    if (ep.speakers != 0u)
+      for (int a = wave; a < A; a += NW)
+        if ((ep.speakers >> a) & 1u) S_word[a * kWave + lane] = comm_draw(ra.seed, gw, gstep, a, DC);
   }
   if constexpr (PHYS) {
     // ---- World.step (core.py:117-169) by the agent waves: action force, contacts with every other entity in ascending order
@@ -663,7 +672,12 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
     for (int i = rwave; i < A; i += RW) (bo.done + wave_off((size_t)i * B + w0))[ln] = 0;
   }
   if constexpr (ROLL) {
-    __syncthreads();      // the next step reuses S_rew, the slots and the tiles
+    if (t == T_ - 1 && ep.speakers != 0u && b.comm && live)      // the agents' comm state after the last step = their last words
+      for (int a = wave; a < A; a += NW)
+        if ((ep.speakers >> a) & 1u)
+          for (int c = 0; c < DC; ++c)
+            (const_cast<float *>(b.comm) + wave_off(((size_t)a * B + w0) * DC))[ln * DC + c] = S_word[a * kWave + lane] == c ? 1.f : 0.f;
+    __syncthreads();      // the next step reuses S_rew, S_word, the slots and the tiles
     break;                // (leaves the pass loop; the step loop goes on)
   }
   if constexpr (!EP2) return;
@@ -772,7 +786,7 @@ int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream) {
 // per CU).  One function for the launch and for the generator of compiled programs (the wave count is a constant there).
 int rows_geometry(const RowDims &h, bool phys, int *waves, size_t *lds_bytes, int max_waves) {
   constexpr size_t kLdsCap = 160 * 1024;
-  const size_t fixed = sizeof(float) * (size_t)(2 * h.n_entities + 2 * h.n_vel + h.n_agents + kRowPicks) * kWave;
+  const size_t fixed = sizeof(float) * (size_t)(2 * h.n_entities + 2 * h.n_vel + h.n_agents + kRowPicks + (phys ? h.n_agents : 0)) * kWave;
   const size_t new_state = phys ? sizeof(float) * (size_t)(4 * h.n_agents) * kWave : 0;      // shares the tiles' region
   const size_t tile = sizeof(float) * (size_t)kWave * (size_t)h.d_max, slots = sizeof(float) * (size_t)kWave * kRowSlots;
   auto need = [&](int w) { return fixed + (size_t)w * slots + ((size_t)w * tile > new_state ? (size_t)w * tile : new_state); };

@@ -161,9 +161,6 @@ class RandomRollout(object):
         """One `mpe_rollout_random` launch covering `steps` env steps.  With `trajectory` (a
         Trajectory of at least `steps` blocks) every step's outputs land in their own block;
         without it each step overwrites the env's output set 0."""
-        if self._prog is not None and self.speakers:
-            raise _abi.MpeError("the fused T-step rollout of a row-program env (mpe_rollout_rows) draws moves, not words: this env has "
-                                "agents that speak; it rolls out through per-step launches: enqueue() / capture()")
         if trajectory is None:
             b = self.env._sets[0].bufs
             ret = self.env._sets[0]
@@ -177,7 +174,7 @@ class RandomRollout(object):
         if self._prog is not None:      # a row-program env: the same launch shape, the rows and rewards by its program
             _abi.check(self._L.mpe_rollout_rows(C.byref(self._desc), C.byref(b), self._prog.ref, self.B, int(steps), self.episode_len,
                                                 self._lr, self.seed, self.t, int(self.world.world_offset),
-                                                1 if trajectory is not None else 0, 0, self._stream()), "mpe_rollout_rows")
+                                                1 if trajectory is not None else 0, int(self.speakers), self._stream()), "mpe_rollout_rows")
         else:
             _abi.check(self._L.mpe_rollout_random(C.byref(self._desc), C.byref(b), self.B, int(steps), self.episode_len,
                                                   self._lr, self.seed, self.t, int(self.world.world_offset),

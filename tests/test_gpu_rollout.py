@@ -260,6 +260,31 @@ def test_rollout_with_integer_action_ids_equals_env_steps_with_those_ids():
 
 
 @pytest.mark.parametrize("compiled", [False, True])
+def test_fused_rollout_of_a_program_env_whose_leader_speaks(compiled):
+    """simple_world_comm at a team size without a kernel of its own (its leader says a drawn word every step): one
+    mpe_rollout_rows launch == the per-step launches (mpe_random_comm + mpe_step_rows), rows, rewards, state, the comm state."""
+    B, T = 640, 11
+    def make():
+        e = mpe.make_env("simple_world_comm", batch_size=B, num_good_agents=2, num_adversaries=3, seed=4, compile_program=False)
+        if compiled:
+            assert e.compile_program()
+        return e
+    d, e = make(), make()
+    assert d._prog is not None and d._has_speakers
+    rd, re_ = RandomRollout(d, episode_len=4, pool=4, regenerate=True), RandomRollout(e, episode_len=4, pool=4, regenerate=True)
+    assert rd.speakers == 1
+    traj = Trajectory(d, T)
+    rd.fused(T, traj)
+    for t in range(T):
+        out_t = re_.enqueue(1)
+        for i in range(d.n):
+            assert torch.equal(traj.obs[t][i], out_t.obs_n[i]), (t, i, float((traj.obs[t][i] - out_t.obs_n[i]).abs().max()))
+            assert torch.equal(traj.rew[t][i], out_t.reward_n[i]), (t, i)
+    assert torch.equal(d.world.pos, e.world.pos) and torch.equal(d.world.vel, e.world.vel) and torch.equal(d._comm, e._comm)
+    assert float(d._comm[0].sum()) == B and float(d._comm[1:].abs().sum()) == 0.0      # one word per world from the leader, nobody else
+
+
+@pytest.mark.parametrize("compiled", [False, True])
 def test_a_row_program_env_rolls_out_through_per_step_launches(compiled):
     """RandomRollout on a row-program env (a team size without a kernel of its own): enqueue() == the same resets, moves and
     env.step calls by hand; a captured graph replays the same steps; the fused T-step launch stays with the built-ins."""

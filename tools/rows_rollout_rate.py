@@ -38,7 +38,8 @@ def main():
     cases = [("corral", lambda c: tr.corral_env(B, compile_program=c)),
              ("simple_spread as a program", lambda c: tr.make_spec_env("simple_spread", B, compile_program=c)),
              ("simple_adversary(4,2)", lambda c: mpe.make_env("simple_adversary", batch_size=B, num_agents=4, num_adversaries=2, compile_program=c)),
-             ("simple_adversary(6,2)", lambda c: mpe.make_env("simple_adversary", batch_size=B, num_agents=6, num_adversaries=2, compile_program=c))]
+             ("simple_adversary(6,2)", lambda c: mpe.make_env("simple_adversary", batch_size=B, num_agents=6, num_adversaries=2, compile_program=c)),
+             ("simple_world_comm(2,3)", lambda c: mpe.make_env("simple_world_comm", batch_size=B, num_good_agents=2, num_adversaries=3, compile_program=c))]
     for name, make in cases:
         for compiled in (False, True):
             env = make(False)
