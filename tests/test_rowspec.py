@@ -488,6 +488,19 @@ def test_static_source_and_image_of_a_program_on_the_cpu():
     for suffix in ("_ns", "_ps", "_nr", "_pr", "_ne", "_pe", "_nl", "_pl"):
         assert (name + suffix).encode() in image
     assert _build.compile_rows_image(src) == image            # cached by content
+    # the eight entry points of the image keep their registers: no scratch memory (a spilling image would be slower than the interpreter)
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    if os.path.exists(llvm + "clang-offload-bundler"):
+        with tempfile.TemporaryDirectory() as tmp:
+            open(os.path.join(tmp, "i.hsaco"), "wb").write(image)
+            subprocess.check_call([llvm + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + os.path.join(tmp, "i.hsaco"),
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + os.path.join(tmp, "i.elf")])
+            notes = subprocess.check_output([llvm + "llvm-readelf", "--notes", os.path.join(tmp, "i.elf")]).decode()
+        import re
+        kernels = re.findall(r"\.name:\s+(%s_\w+)\n.*?\.private_segment_fixed_size:\s+(\d+)" % name, notes, flags=re.S)
+        assert len(kernels) == 8 and all(int(sz) == 0 for _, sz in kernels), kernels
     env.world.agents[0].size = 0.2
     env.refresh_constants()
     other = env._prog.static_source(env._desc)
