@@ -632,7 +632,7 @@ static uint64_t tables_hash(const mpe::RowTables &tabs) { return fnv1a(kFnvSeed,
 // a program compiled in (mpe_rows_load_image): the module, its four entry points, and what it was compiled for
 struct RowImage {
   hipModule_t module;
-  void *fns[8];            // _ns, _ps, _nr, _pr, _ne, _pe, _nl, _pl
+  void *fns[4];            // _s, _r, _e, _l
   mpe::RowDims dims;
   uint64_t tables;
   const int32_t *ops_device;
@@ -859,8 +859,8 @@ int mpe_rows_load_image(const MpeScenarioDesc *d, MpeRowProgram *p, const int32_
     delete im;
     return fail((int)rc, "%s: hipModuleLoadData: %s", what, hipGetErrorString(rc));
   }
-  static const char *const suffix[8] = {"_ns", "_ps", "_nr", "_pr", "_ne", "_pe", "_nl", "_pl"};
-  for (int k = 0; k < 8; ++k) {
+  static const char *const suffix[4] = {"_s", "_r", "_e", "_l"};
+  for (int k = 0; k < 4; ++k) {
     const std::string fn = std::string(name) + suffix[k];
     hipFunction_t f = nullptr;
     rc = hipModuleGetFunction(&f, im->module, fn.c_str());

@@ -49,14 +49,18 @@ namespace {
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float unif(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 
-template <bool NT>
-__device__ __forceinline__ void flush_tile(const float *tile, float *__restrict__ g, int D, int nvalid, int lane, bool vec4) {
+// (nt: nontemporal 16-byte stores for launches whose rows are 8 MB or more -- a launch-uniform branch, not an instantiation: the
+//  kernels, and the images of compiled programs, exist once instead of twice)
+__device__ __forceinline__ void flush_tile(const float *tile, float *__restrict__ g, int D, int nvalid, int lane, bool vec4, bool nt) {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if (vec4 && nvalid == kWave) {          // a full wave of worlds, aligned segment: 16 D float4 pieces, straight copies
     const int nq = 16 * D;
-    for (int q = lane; q < nq; q += kWave)
-      store_row4<NT ? kRowsNt : kRowsPlain>(g + 4 * q, *reinterpret_cast<const float4 *>(tile + 4 * q));
+    if (nt) {
+      for (int q = lane; q < nq; q += kWave) store_row4<kRowsNt>(g + 4 * q, *reinterpret_cast<const float4 *>(tile + 4 * q));
+    } else {
+      for (int q = lane; q < nq; q += kWave) store_row4<kRowsPlain>(g + 4 * q, *reinterpret_cast<const float4 *>(tile + 4 * q));
+    }
   } else {
     const int nfl = nvalid * D;
     for (int j = lane; j < nfl; j += kWave) g[j] = tile[j];
@@ -127,10 +131,12 @@ __device__ __forceinline__ void agents_of_wave(int first, int stride, int A, F &
 // kernel (action_draw: the rows mpe_random_actions_block would write), a reset_world of every world at the episode boundaries
 // (mpe_reset's draws), every step's rows / rewards / dones into its own trajectory block or over the same one.  (Its own
 // instantiation for the reason EP2 is one.)
-template <bool NT, bool PHYS, bool STATIC, bool EP2, bool ROLL = false>
+template <bool PHYS, bool STATIC, bool EP2, bool ROLL = false>
 __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode &ep, const RowDims &h_arg,
-                                          const uint32_t *__restrict__ const tables, const int32_t vec4, const int32_t split_arg,
+                                          const uint32_t *__restrict__ const tables, const int32_t vec4_nt, const int32_t split_arg,
                                           const uint32_t *__restrict__ const ops_g, const size_t B, const RollArgs &ra = RollArgs{}) {
+  const int32_t vec4 = vec4_nt & 1;      // bit 0: 16-byte row stores are possible; bit 1: make them nontemporal
+  const bool nt = (vec4_nt & 2) != 0;
   static_assert(!ROLL || (PHYS && !EP2), "a rollout steps the world and keeps its own episode clock");
   // LDS: a launch parameter for the interpreter; a compiled program knows its size (no 64 KB opt-in for module kernels needed)
   float *smem;
@@ -385,6 +391,11 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   // Two passes at most: the second only in mode 2 (mpe_step_rows_episode) and only in a workgroup where a world finished --
   // its worlds restarted, the observation programs run once more on the new episode's first state.  (One copy of the code.)
   constexpr int kPasses = EP2 ? 2 : 1;
+  if constexpr (ROLL) {
+    // without a trajectory every step's outputs land on the same block: only the last step's survive, so only the last step
+    // computes and stores them (the state moves on either way)
+    if (!ra.trajectory && t != T_ - 1) continue;
+  }
 #pragma nounroll
   for (int pass = 0; pass < kPasses; ++pass) {
   // ---- observation programs of this wave's agents ------------------------------------------------------------------------
@@ -495,7 +506,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
           obs_op(op);
         }
       }
-      flush_tile<NT>(tile, bo.obs + B * (size_t)TI(MPE_TAB(obs_off), i) + w0 * (size_t)D, D, nvalid, lane, vec4 != 0);
+      flush_tile(tile, bo.obs + B * (size_t)TI(MPE_TAB(obs_off), i) + w0 * (size_t)D, D, nvalid, lane, vec4 != 0, nt);
     };
     agents_of_wave<STATIC, PHYS>(is_rows ? wave : A, RW, A, obs_agent);
   }
@@ -732,48 +743,41 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
 }
 
 #ifndef MPE_ROWS_STATIC
-template <bool NT, bool PHYS, bool EP2>
+template <bool PHYS, bool EP2>
 __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpisode ep, const RowDims h,
-                                                 const uint32_t *__restrict__ const tables, const int32_t vec4, const int32_t split,
+                                                 const uint32_t *__restrict__ const tables, const int32_t vec4_nt, const int32_t split,
                                                  const uint32_t *__restrict__ const ops_g, const size_t B) {
-  rows_body<NT, PHYS, false, EP2>(b, ep, h, tables, vec4, split, ops_g, B);
+  rows_body<PHYS, false, EP2>(b, ep, h, tables, vec4_nt, split, ops_g, B);
 }
-template <bool NT>
 __global__ void __launch_bounds__(1024) k_rows_roll(const MpeBuffers b, const RowEpisode ep, const RowDims h,
-                                                      const uint32_t *__restrict__ const tables, const int32_t vec4,
+                                                      const uint32_t *__restrict__ const tables, const int32_t vec4_nt,
                                                       const uint32_t *__restrict__ const ops_g, const size_t B, const RollArgs ra) {
-  rows_body<NT, true, false, false, true>(b, ep, h, tables, vec4, 0, ops_g, B, ra);
+  rows_body<true, false, false, true>(b, ep, h, tables, vec4_nt, 0, ops_g, B, ra);
 }
 #endif
 
 }  // namespace
 
 #ifdef MPE_ROWS_STATIC
-// the eight entry points of a compiled program: <name>_{n,p}{s,r,e,l} = {nontemporal, plain} row stores x {step, rows only, step
-// with the episode end inside, T-step rollout}
+// the four entry points of a compiled program: <name>_{s,r,e,l} = step, rows only, step with the episode end inside, T-step rollout
 #define MPE_ROWS_CAT2(a, b) a##b
 #define MPE_ROWS_CAT(a, b) MPE_ROWS_CAT2(a, b)
-#define MPE_ROWS_STATIC_KERNEL(suffix, NT, PHYS, EP2)                                                                         \
+#define MPE_ROWS_STATIC_KERNEL(suffix, PHYS, EP2)                                                                             \
   extern "C" __global__ void __launch_bounds__(static_waves<PHYS>() * kWave)                                                   \
       __attribute__((amdgpu_waves_per_eu(PHYS ? MPE_ROWS_STATIC_OCC_STEP : MPE_ROWS_STATIC_OCC_ROWS)))                         \
-      MPE_ROWS_CAT(MPE_ROWS_STATIC_NAME, suffix)(const MpeBuffers b, const RowEpisode ep, const int32_t vec4, const size_t B) { \
-    rows_body<NT, PHYS, true, EP2>(b, ep, RowDims{}, nullptr, vec4, 0, nullptr, B);                                                 \
+      MPE_ROWS_CAT(MPE_ROWS_STATIC_NAME, suffix)(const MpeBuffers b, const RowEpisode ep, const int32_t vec4_nt,              \
+                                                 const size_t B) {                                                             \
+    rows_body<PHYS, true, EP2>(b, ep, RowDims{}, nullptr, vec4_nt, 0, nullptr, B);                                             \
   }
-MPE_ROWS_STATIC_KERNEL(_ns, true, true, false)
-MPE_ROWS_STATIC_KERNEL(_ps, false, true, false)
-MPE_ROWS_STATIC_KERNEL(_nr, true, false, false)
-MPE_ROWS_STATIC_KERNEL(_pr, false, false, false)
-MPE_ROWS_STATIC_KERNEL(_ne, true, true, true)
-MPE_ROWS_STATIC_KERNEL(_pe, false, true, true)
-#define MPE_ROWS_STATIC_ROLL_KERNEL(suffix, NT)                                                                               \
-  extern "C" __global__ void __launch_bounds__(static_waves<true>() * kWave)                                                   \
-      __attribute__((amdgpu_waves_per_eu(MPE_ROWS_STATIC_OCC_STEP)))                                                           \
-      MPE_ROWS_CAT(MPE_ROWS_STATIC_NAME, suffix)(const MpeBuffers b, const RowEpisode ep, const int32_t vec4, const size_t B,  \
-                                                 const RollArgs ra) {                                                          \
-    rows_body<NT, true, true, false, true>(b, ep, RowDims{}, nullptr, vec4, 0, nullptr, B, ra);                                \
-  }
-MPE_ROWS_STATIC_ROLL_KERNEL(_nl, true)
-MPE_ROWS_STATIC_ROLL_KERNEL(_pl, false)
+MPE_ROWS_STATIC_KERNEL(_s, true, false)
+MPE_ROWS_STATIC_KERNEL(_r, false, false)
+MPE_ROWS_STATIC_KERNEL(_e, true, true)
+extern "C" __global__ void __launch_bounds__(static_waves<true>() * kWave)
+    __attribute__((amdgpu_waves_per_eu(MPE_ROWS_STATIC_OCC_STEP)))
+    MPE_ROWS_CAT(MPE_ROWS_STATIC_NAME, _l)(const MpeBuffers b, const RowEpisode ep, const int32_t vec4_nt, const size_t B,
+                                           const RollArgs ra) {
+  rows_body<true, true, false, true>(b, ep, RowDims{}, nullptr, vec4_nt, 0, nullptr, B, ra);
+}
 #else
 
 int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream) {
@@ -816,39 +820,38 @@ int launch_rows(const MpeBuffers &b, const RowDims &h, const RowTables &host, co
   const unsigned grid = (unsigned)((B + kWave - 1) / kWave);
   const bool nt = rows_nontemporal(h, host, vec4, ep, B);
   const bool ep2 = ep.enabled == 2;      // (phys by construction: mpe_step_rows_episode)
-  auto fn = ep2 ? (nt ? k_rows<true, true, true> : k_rows<false, true, true>)
-                : phys ? (nt ? k_rows<true, true, false> : k_rows<false, true, false>)
-                       : (nt ? k_rows<true, false, false> : k_rows<false, false, false>);
+  auto fn = ep2 ? k_rows<true, true> : phys ? k_rows<true, false> : k_rows<false, false>;
+  const int32_t vec4_nt = (vec4 ? 1 : 0) | (nt ? 2 : 0);
   if (lds > 64 * 1024) {
     const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return (int)rc;
   }
   if (roll) {
-    auto fr = nt ? k_rows_roll<true> : k_rows_roll<false>;
+    auto fr = k_rows_roll;
     if (lds > 64 * 1024) {
       const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (rc != hipSuccess) return (int)rc;
     }
     hipLaunchKernelGGL(fr, dim3(grid), dim3(W * kWave), lds, stream, b, ep, h, reinterpret_cast<const uint32_t *>(tables_device),
-                       (int32_t)vec4, reinterpret_cast<const uint32_t *>(ops_device), B, *roll);
+                       vec4_nt, reinterpret_cast<const uint32_t *>(ops_device), B, *roll);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(W * kWave), lds, stream, b, ep, h, reinterpret_cast<const uint32_t *>(tables_device),
-                     (int32_t)vec4, (int32_t)0, reinterpret_cast<const uint32_t *>(ops_device), B);
+                     vec4_nt, (int32_t)0, reinterpret_cast<const uint32_t *>(ops_device), B);
   return (int)hipGetLastError();
 }
 
-// a compiled program (hipModule functions in the order ns, ps, nr, pr, ne, pe, nl, pl): same geometry, no tables, no ops
-int launch_rows_image(void *const fns[8], const MpeBuffers &b, const RowDims &h, const RowTables &host, bool phys, int vec4,
+// a compiled program (hipModule functions in the order s, r, e, l): same geometry, no tables, no ops
+int launch_rows_image(void *const fns[4], const MpeBuffers &b, const RowDims &h, const RowTables &host, bool phys, int vec4,
                       const RowEpisode &ep, size_t B, hipStream_t stream, const RollArgs *roll) {
   int W = 0;
   size_t lds = 0;
   if (int rc = rows_geometry(h, phys, &W, &lds, 0)) return rc;
   const bool nt = rows_nontemporal(h, host, vec4, ep, B);
-  hipFunction_t fn = static_cast<hipFunction_t>(fns[(roll ? 6 : ep.enabled == 2 ? 4 : phys ? 0 : 2) + (nt ? 0 : 1)]);
+  hipFunction_t fn = static_cast<hipFunction_t>(fns[roll ? 3 : ep.enabled == 2 ? 2 : phys ? 0 : 1]);
   MpeBuffers b_ = b;
   RowEpisode ep_ = ep;
-  int32_t vec4_ = vec4;
+  int32_t vec4_ = (vec4 ? 1 : 0) | (nt ? 2 : 0);
   size_t B_ = B;
   RollArgs ra_;
   if (roll) ra_ = *roll;

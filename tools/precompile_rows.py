@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Compile the row programs of the shipped scenarios (and examples/corral.py) in, on any machine with hipcc (no GPU needed):
 fills multiagent_particle_envs_amd/lib/rows_cache/, which travels with the tree, so the first env.compile_program() on the
-GPU box finds its image.    python tools/precompile_rows.py [scenario[:key=value...] ...]"""
+GPU box finds its image.    python tools/precompile_rows.py [--tests] [scenario[:key=value...] ...]
+(--tests: also the programs the GPU tests compile -- the example with an arena, with resized agents, the random programs)"""
 import os
 import sys
 import time
@@ -14,13 +15,52 @@ import test_rowspec as tr  # noqa: E402
 DEFAULT = list(tr.NINE) + ["corral", "simple_adversary:num_agents=4:num_adversaries=2", "simple_adversary:num_agents=6:num_adversaries=2",
                            "simple_world_comm:num_good_agents=2:num_adversaries=3", "simple_world_comm:num_good_agents=3:num_adversaries=5",
                            "simple_adversary:num_agents=10:num_adversaries=3", "simple_world_comm:num_good_agents=5:num_adversaries=6"]
-for spec in (sys.argv[1:] or DEFAULT):
+def test_programs():
+    """The images tests/test_rowspec.py, test_gpu_rollout.py and tools/finish_cost.py would otherwise compile on the GPU box."""
+    envs = []
+    for arena in (0.95, 50.0):
+        envs.append(("corral arena=%g" % arena, tr.corral_env(4, device="cpu", arena=arena)))
+    for who, size in ((0, 0.07),):
+        e = tr.corral_env(4, device="cpu")
+        e.world.agents[who].size = size
+        e.refresh_constants()
+        envs.append(("corral agent %d size %g" % (who, size), e))
+    for seed in range(1, 7):
+        sc = tr._RandomScenario(seed)
+        w = sc.make_world(batch_size=4, device="cpu")
+        w.seed = seed
+        import multiagent_particle_envs_amd as mpe
+        e = mpe.MultiAgentEnv(w, sc.reset_world, None, None, compile_program=False)
+        envs.append(("random program %d" % seed, e))
+    return envs
+
+
+from concurrent.futures import ThreadPoolExecutor  # noqa: E402
+
+jobs = []      # (label, n_ops, header text)
+if "--tests" in sys.argv:
+    jobs += [(label, env._prog.n_ops, env._prog.static_source(env._desc)) for label, env in test_programs()]
+specs = [a for a in sys.argv[1:] if a != "--tests"]
+for spec in (specs or ([] if "--tests" in sys.argv else DEFAULT)):
     parts = spec.split(":")
     kw = {k: int(v) for k, v in (p.split("=") for p in parts[1:])}
     env = tr.corral_env(4, device="cpu") if parts[0] == "corral" else tr.make_spec_env(parts[0], 4, device="cpu", scenario_kw=kw)
+    try:
+        jobs.append((spec, env._prog.n_ops, env._prog.static_source(env._desc)))
+    except _abi.MpeError as err:
+        print("%-60s %4d ops  not compiled: %s" % (spec, env._prog.n_ops, str(err)[:200]))
+
+
+def compile_one(job):
+    label, n_ops, src = job
     t0 = time.time()
     try:
-        image = _build.compile_rows_image(env._prog.static_source(env._desc))
-        print("%-60s %4d ops  %7d bytes  %5.1f s" % (spec, env._prog.n_ops, len(image), time.time() - t0))
-    except (_abi.MpeError, RuntimeError) as err:
-        print("%-60s %4d ops  not compiled: %s" % (spec, env._prog.n_ops, str(err)[:200]))
+        image = _build.compile_rows_image(src)
+        return "%-60s %4d ops  %7d bytes  %5.1f s" % (label, n_ops, len(image), time.time() - t0)
+    except RuntimeError as err:
+        return "%-60s %4d ops  hipcc failed: %s" % (label, n_ops, str(err)[-300:])
+
+
+with ThreadPoolExecutor(max_workers=max(2, (os.cpu_count() or 4) - 1)) as ex:      # one hipcc process per image
+    for line in ex.map(compile_one, jobs):
+        print(line, flush=True)
