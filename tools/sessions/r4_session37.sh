@@ -37,8 +37,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc/$name -o x -- python $R/tools/rowspec_rate.py --scenarios simple_spread --eager-only --no-generic --compiled --steps 60 > $O/pmc_rows_$name.log 2>&1
 done
 cd $R
-python profiles/pmc_summary.py $O/pmc 'k_rows<true, false>' > $O/pmc_rows_spread3_B65536.txt 2>> $O/err.log
-python profiles/pmc_summary.py $O/pmc '_s(' > $O/pmc_rows_compiled_spread3_B65536.txt 2>> $O/err.log
+python profiles/pmc_summary.py $O/pmc 'k_rows<true, true, false>' > $O/pmc_rows_spread3_B65536.txt 2>> $O/err.log
+python profiles/pmc_summary.py $O/pmc '_ns' > $O/pmc_rows_compiled_spread3_B65536.txt 2>> $O/err.log
 for f in $O/pmc_rows_spread3_B65536.txt $O/pmc_rows_compiled_spread3_B65536.txt; do grep "traffic_bytes\|Kernel_Name\|SQ_INSTS_SALU\|SQ_INSTS_VALU\|SQ_WAVE_CYCLES\|SQ_WAIT_ANY\|VGPR" $f | cut -c1-200; done
 rm -rf $O/pmc; rm -f $O/pmc_rows_*.log; tail -3 $O/err.log 2>/dev/null
 timeout 600 python tools/finish_cost.py > $O/finish_cost.txt 2> $O/finish_cost.err; echo "finish_cost rc=$?"; grep "env.step\|from Python" $O/finish_cost.txt | cut -c1-220
