@@ -20,7 +20,8 @@ def main():
     meta = {}
     for f in sorted(glob.glob(root + "/*/x_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if pat in r["Kernel_Name"]:
+            name = r["Kernel_Name"]
+            if (name.endswith(pat[4:]) or name.endswith(pat[4:] + ".kd")) if pat.startswith("end:") else pat in name:      # "end:_s": a suffix
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
                                           "SGPR_Count", "Scratch_Size")}
