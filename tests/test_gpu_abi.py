@@ -249,6 +249,23 @@ def test_concurrent_host_threads_each_on_its_own_stream():
             assert torch.equal(a, b_), shapes[k]
 
 
+def test_a_c_program_writes_a_row_program_and_steps_it(tmp_path):
+    """tests/c/abi_rows_gpu.c: simple_spread as a hand-written row program, from C: mpe_rows_validate + mpe_step_rows against the
+    reference's known answer and, bit for bit, against mpe_step's own kernel -- no Python / torch in the process."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.dirname(_abi.LIB_PATH)
+    exe = str(tmp_path / "abi_rows_gpu")
+    cmd = ["gcc", "-std=c99", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(root, "include"),
+           os.path.join(root, "tests", "c", "abi_rows_gpu.c"), "-o", exe, "-L", lib_dir, "-lmpe_hip", "-L/opt/rocm/lib",
+           "-lamdhip64", "-lm", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "bit for bit" in r.stdout and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr[-500:])
+
+
 def test_a_c_program_steps_the_reference_kat_on_the_gpu(tmp_path):
     """tests/c/abi_gpu.c: hipMalloc + mpe_step from C, no Python / torch in the process -- the library is the product,
     PyTorch is plumbing.  Checks the reference's recorded known-answer step."""
