@@ -663,6 +663,43 @@ def test_random_programs_one_op_per_call_vs_range_forms_vs_compiled_in(seed):
     assert comp.program_compiled and not fused.program_compiled
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_programs_against_the_numpy_oracle_of_the_op_table(seed):
+    """What the kernel computes for a program nobody wrote by hand, against oracle/rowprog.py (the op table restated in NumPy
+    fp64) on the kernel's own post-step state: rows and rewards to 1e-5, dones exactly outside a 2e-6 band around their
+    thresholds, contact-counting rewards outside the same band around contact."""
+    from oracle import rowprog
+    B = 2048
+    env = _random_env(seed, B, True)
+    p = env._prog
+    orc = rowprog.from_program(p.struct, p.ops_host, p.n_ops, env._desc)
+    rs = np.random.RandomState(50 + seed)
+    env.reset()
+    worst = 0.0
+    for t in range(6):
+        if t == 2:
+            env.world.pos.mul_(0.35)
+        obs, rew, done, _ = env.step(rand_actions(env, rs, B))
+        w = env.world
+        pos = w.pos.permute(2, 0, 1).double().cpu().numpy()                    # [B, E, 2]
+        vel = w.vel.permute(2, 0, 1).double().cpu().numpy()
+        comm = env._comm.double().cpu().numpy()                                # [A, B, dim_c]
+        choice = w.choice_i32.cpu().numpy()                                    # [K, B]
+        o64 = orc.observe(pos, vel, comm, choice)
+        r64 = orc.rewards(pos, vel, comm, choice)
+        d64 = orc.dones(pos, vel, comm, choice)
+        ok_r = ~orc.reward_guard(pos, 2e-6, choice)          # (soft contacts leave crowded worlds hovering at contact distance)
+        ok_d = ~orc.done_guard(pos, 2e-6, vel, comm, choice)
+        assert ok_r.mean() > 0.9 and ok_d.mean() > 0.9
+        for i in range(env.n):
+            worst = max(worst, float(np.abs(obs[i].double().cpu().numpy() - o64[i]).max()))
+            e = np.abs(rew[i].double().cpu().numpy() - r64[i]) / np.maximum(1.0, np.abs(r64[i]))
+            worst = max(worst, float(e[ok_r].max()))
+            assert np.array_equal(done[i].cpu().numpy()[ok_d], d64[i][ok_d]), (seed, t, i)
+    assert worst <= 1e-5, (seed, worst)
+
+
 def _strayed(agent, world):
     """A done callback: the agent left the arena (any world, any step)."""
     return (agent.state.p_pos.abs() > 0.95).any(dim=1)
