@@ -259,6 +259,26 @@ def test_rollout_with_integer_action_ids_equals_env_steps_with_those_ids():
     assert not torch.equal(envs[3].world.pos, ref.world.pos)
 
 
+@pytest.mark.parametrize("B", [1, 5, 70, 129])
+def test_program_rollouts_at_batch_sizes_that_do_not_fill_a_wave(B):
+    """Fewer worlds than a wave, and a ragged last workgroup: the fused rollout of a row-program env (interpreted and compiled in)
+    == its per-step launches."""
+    envs = [mpe.make_env("simple_adversary", batch_size=B, num_agents=4, num_adversaries=2, seed=2, compile_program=False) for _ in range(3)]
+    assert envs[2].compile_program()
+    rolls = [RandomRollout(e, episode_len=3, pool=3, regenerate=True) for e in envs]
+    T = 7
+    trajs = [Trajectory(e, T) for e in envs[1:]]
+    rolls[1].fused(T, trajs[0])
+    rolls[2].fused(T, trajs[1])
+    for t in range(T):
+        out = rolls[0].enqueue(1)
+        for tr_ in trajs:
+            for i in range(envs[0].n):
+                assert torch.equal(tr_.obs[t][i], out.obs_n[i]) and torch.equal(tr_.rew[t][i], out.reward_n[i]), (B, t, i)
+    for e in envs[1:]:
+        assert torch.equal(e.world.pos, envs[0].world.pos) and torch.equal(e.world.vel, envs[0].world.vel)
+
+
 @pytest.mark.parametrize("compiled", [False, True])
 def test_fused_rollout_of_a_program_env_whose_leader_speaks(compiled):
     """simple_world_comm at a team size without a kernel of its own (its leader says a drawn word every step): one
