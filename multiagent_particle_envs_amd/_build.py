@@ -30,7 +30,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-save-temps=obj"]
 
 
-STRESS_SOURCES = ("split", "wide")
+STRESS_SOURCES = ("split", "wide", "rows")
 STRESS_VARIANTS = {"stress": ["-DMPE_STRESS_DELAY_WAVE=1"],
                    "stress_racy": ["-DMPE_STRESS_DELAY_WAVE=1", "-DMPE_STRESS_STORE_BEFORE_BARRIER"],
                    # measurement build (tools/device_span.py): every wave of k_split stamps the device wall clock at its

@@ -42,6 +42,20 @@
 #define MPE_RSTAMP(k) do { } while (0)
 #endif
 
+// test builds (libmpe_hip_stress.so / _stress_racy.so, tests/test_gpu_race.py): at each phase boundary one wave of every workgroup --
+// a different one per boundary -- is held back ~30 us, so that its siblings have long moved on: any missing barrier between the
+// phases (staged state / World.step / the new state taking its place / row tiles in the same LDS / the next rollout step) then
+// shows as a changed result.  Not in the product build.
+#ifdef MPE_STRESS_DELAY_WAVE
+#define MPE_ROWS_STRESS(k)                                                              \
+  do {                                                                                  \
+    if (wave == ((MPE_STRESS_DELAY_WAVE) + (k)) % NW)                                   \
+      for (int s_ = 0; s_ < 10; ++s_) __builtin_amdgcn_s_sleep(127);                    \
+  } while (0)
+#else
+#define MPE_ROWS_STRESS(k) do { } while (0)
+#endif
+
 namespace mpe {
 
 namespace {
@@ -167,6 +181,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   const unsigned ln = (unsigned)(live ? lane : nvalid - 1) & 63u;
 
   MPE_RSTAMP(0);
+  MPE_ROWS_STRESS(0);
   // the per-entity tables and the ops: device memory read with scalar loads (uniform addresses) -- staging them in LDS per
   // workgroup measured 7 % slower at 65 536 worlds (one more dependent load + barrier in front of every wave) and halves the
   // waves of the largest programs --, or constants of the image (STATIC)
@@ -323,6 +338,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
       __syncthreads();
     }
   }
+  MPE_ROWS_STRESS(1 + t);
   if constexpr (ROLL) {      // the words of this step (mpe_random_comm's draws); read behind World.step's barriers
     if (ep.speakers != 0u)
       for (int a = wave; a < A; a += NW)
@@ -369,7 +385,9 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
       agents_of_wave<STATIC, PHYS>(is_rows ? wave : A, RW, A, phys_agent);
     }
     MPE_RSTAMP(3);    // World.step of this wave's agents computed
-    __syncthreads();
+#ifndef MPE_STRESS_STORE_BEFORE_BARRIER      // (the negative control of tests/test_gpu_race.py: without this barrier a wave that is done
+    __syncthreads();                         //  replaces the staged positions while a late sibling still computes contacts from them)
+#endif
     for (int i = wave; i < A; i += NW) {
       const float mx = S_new[(4 * i + 0) * kWave + lane], my = S_new[(4 * i + 1) * kWave + lane];
       const float mvx = S_new[(4 * i + 2) * kWave + lane], mvy = S_new[(4 * i + 3) * kWave + lane];
@@ -387,6 +405,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
     __syncthreads();
   }
   MPE_RSTAMP(4);      // the post-step state is in LDS
+  MPE_ROWS_STRESS(2 + t);
 
   // Two passes at most: the second only in mode 2 (mpe_step_rows_episode) and only in a workgroup where a world finished --
   // its worlds restarted, the observation programs run once more on the new episode's first state.  (One copy of the code.)

@@ -12,7 +12,7 @@ import multiagent_particle_envs_amd as mpe
 
 
 def run(name, kw, B, steps):
-    env = mpe.make_env(name, batch_size=B, seed=7, **kw)
+    env = mpe.make_env(name, batch_size=B, seed=7, compile_program=False, **kw)      # (a row program: interpreted by THIS library build)
     assert env.fused
     w = env.world
     A, E = len(w.agents), len(w.entities)
@@ -35,8 +35,29 @@ def run(name, kw, B, steps):
     return h.hexdigest()
 
 
+def run_rollout(name, kw, B, steps):
+    """a row-program env's fused T-step rollout (mpe_rollout_rows): every step's rows and rewards, the final state"""
+    from multiagent_particle_envs_amd.rollout import RandomRollout, Trajectory
+    env = mpe.make_env(name, batch_size=B, seed=7, compile_program=False, **kw)
+    assert env.fused and env._prog is not None
+    rr = RandomRollout(env, episode_len=0, pool=2, regenerate=False)
+    w = env.world
+    rs = np.random.RandomState(3)
+    w.set_state(rs.uniform(-1, 1, (B, len(w.entities), 2)).astype(np.float32) * 0.25, rs.uniform(-0.5, 0.5, (B, len(w.agents), 2)).astype(np.float32))
+    traj = Trajectory(env, steps)
+    rr.fused(steps, traj)
+    h = hashlib.sha256()
+    for x in [w.pos, w.vel, traj.obs_flat, traj.rew]:
+        h.update(x.detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
 if __name__ == "__main__":
     out = {}
-    for name, kw in (("simple_spread", {}), ("simple_tag", {}), ("simple_world_comm", {}), ("simple_spread", {"num_agents": 6})):
-        out["%s%s" % (name, kw.get("num_agents", ""))] = run(name, kw, int(sys.argv[1]), int(sys.argv[2]))
+    import os
+    corral = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "corral.py")   # colliding agents, steps
+    for name, kw in (("simple_spread", {}), ("simple_tag", {}), ("simple_world_comm", {}), ("simple_spread", {"num_agents": 6}),   # through
+                     (corral, {})):                                                                                # its row program (k_rows)
+        out["%s%s" % (os.path.basename(name), kw.get("num_agents", ""))] = run(name, kw, int(sys.argv[1]), int(sys.argv[2]))
+    out["rollout_corral"] = run_rollout(corral, {}, int(sys.argv[1]), int(sys.argv[2]))
     print("RACE_PROBE " + json.dumps(out))

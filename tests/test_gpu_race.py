@@ -5,6 +5,10 @@ one; the stores therefore sit behind the workgroup barrier.  Two checks that do 
     bit-identical results to the normal build -- and the same build with the round-1 ordering (stores in front
     of the barrier, libmpe_hip_stress_racy.so) must NOT: the negative control showing the probe sees the race;
   * split-vs-thread bit identity at 1 048 576 worlds over 100 steps.
+The row-program kernel (csrc/mpe_rows.hip) shares its LDS between phases (the staged state, World.step's new state, the row tiles in
+the same region, the next rollout step): the same two builds hold a different wave back at every phase boundary of a program step and
+of a fused program rollout (examples/corral.py: colliding agents) -- identical results with the barriers, different ones without the
+barrier between World.step and the new state taking the staged one's place.
 """
 import json
 import os
