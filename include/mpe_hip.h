@@ -348,6 +348,16 @@ int mpe_rollout_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRow
                      int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
                      int32_t trajectory, uint32_t speakers, void *stream);
 
+/* mpe_rollout_rows_episode: T consecutive mpe_step_rows_episode steps in ONE launch, the moves (and words) drawn in the kernel as in
+ * mpe_rollout_rows: the episodes end, per world, where the program's done tests or max_episode_steps say -- the finished worlds
+ * restart inside the step that ended them (episode number episode0 + t for step t: one per step, as a caller of
+ * mpe_step_rows_episode counts them), their rows in that step's block are the new episode's first.  episode_step: the worlds'
+ * step counters, read at the start, left as after step T - 1.                                                                  */
+int mpe_rollout_rows_episode(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowProgram *prog, int64_t B, int32_t T,
+                             int32_t *episode_step, int32_t max_episode_steps, float landmark_range, uint64_t seed,
+                             uint64_t step0, uint64_t episode0, int64_t world_offset, int32_t trajectory, uint32_t speakers,
+                             void *stream);
+
 /* ---- a row program COMPILED IN: the interpreter specialised away ---------------------------------------------------------
  * mpe_rows / mpe_step_rows / mpe_episode_finish interpret a program op by op.  For a program that stays the same for the
  * life of an env the same kernel source can be compiled WITH the program as constants (every op code, entity index, column

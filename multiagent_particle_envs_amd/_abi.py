@@ -96,6 +96,9 @@ EXPORTS = {
                                         C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]),
     "mpe_rollout_rows": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.POINTER(MpeRowProgram), C.c_int64, C.c_int32,
                                    C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_uint32, C.c_void_p]),
+    "mpe_rollout_rows_episode": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.POINTER(MpeRowProgram), C.c_int64, C.c_int32,
+                                           C.c_void_p, C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32,
+                                           C.c_uint32, C.c_void_p]),
     "mpe_sizeof_row_program": (C.c_size_t, []),
     "mpe_rows_static_source": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeRowProgram), C.POINTER(C.c_int32), C.c_char_p,
                                          C.c_size_t, C.POINTER(C.c_size_t)]),

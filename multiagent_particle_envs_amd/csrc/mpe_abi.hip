@@ -629,10 +629,10 @@ static uint64_t fnv1a(uint64_t hash, const void *data, size_t n) {
 static constexpr uint64_t kFnvSeed = 1469598103934665603ull;
 static uint64_t tables_hash(const mpe::RowTables &tabs) { return fnv1a(kFnvSeed, &tabs, sizeof(tabs)) | 1ull; }
 
-// a program compiled in (mpe_rows_load_image): the module, its four entry points, and what it was compiled for
+// a program compiled in (mpe_rows_load_image): the module, its five entry points, and what it was compiled for
 struct RowImage {
   hipModule_t module;
-  void *fns[4];            // _s, _r, _e, _l
+  void *fns[5];            // _s, _r, _e, _l, _m
   mpe::RowDims dims;
   uint64_t tables;
   const int32_t *ops_device;
@@ -754,6 +754,31 @@ int mpe_rollout_rows(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgra
   return rows_call(what, true, d, b, p, B, &ep, stream, &ra);
 }
 
+int mpe_rollout_rows_episode(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B, int32_t T,
+                             int32_t *episode_step, int32_t max_episode_steps, float landmark_range, uint64_t seed, uint64_t step0,
+                             uint64_t episode0, int64_t world_offset, int32_t trajectory, uint32_t speakers, void *stream) {
+  const char *what = "mpe_rollout_rows_episode";
+  if (T < 0) return fail(MPE_EINVAL, "%s: T must be >= 0", what);
+  mpe::RowEpisode ep;
+  if (int rc = episode_args(what, 2, d, b, episode_step, max_episode_steps, landmark_range, seed, episode0, world_offset, &ep)) return rc;
+  if (speakers != 0) {
+    if (d->dim_c <= 0) return fail(MPE_EINVAL, "%s: speakers 0x%x but desc->dim_c = %d", what, speakers, d->dim_c);
+    if (int rc = need(b->comm, what, "comm (receives the speaking agents' last words)")) return rc;
+  }
+  if (T == 0) return 0;
+  ep.speakers = speakers;
+  mpe::RollArgs ra;
+  std::memset(&ra, 0, sizeof(ra));
+  ra.T = T;
+  ra.episode_len = 0;      // (no clocked resets: the episodes end where the done programs / the horizon say)
+  ra.trajectory = trajectory ? 1 : 0;
+  ra.landmark_range = landmark_range;
+  ra.seed = seed;
+  ra.step0 = step0;
+  ra.world_offset = (uint64_t)world_offset;
+  return rows_call(what, true, d, b, p, B, &ep, stream, &ra);
+}
+
 int mpe_step_rows_episode(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B, int32_t *episode_step,
                           int32_t max_episode_steps, float landmark_range, uint64_t seed, uint64_t episode, int64_t world_offset,
                           void *stream) {
@@ -859,8 +884,8 @@ int mpe_rows_load_image(const MpeScenarioDesc *d, MpeRowProgram *p, const int32_
     delete im;
     return fail((int)rc, "%s: hipModuleLoadData: %s", what, hipGetErrorString(rc));
   }
-  static const char *const suffix[4] = {"_s", "_r", "_e", "_l"};
-  for (int k = 0; k < 4; ++k) {
+  static const char *const suffix[5] = {"_s", "_r", "_e", "_l", "_m"};
+  for (int k = 0; k < 5; ++k) {
     const std::string fn = std::string(name) + suffix[k];
     hipFunction_t f = nullptr;
     rc = hipModuleGetFunction(&f, im->module, fn.c_str());

@@ -111,7 +111,7 @@ int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream);
 int launch_rows(const MpeBuffers &b, const RowDims &dims, const RowTables &host, const void *tables_device, bool phys, int vec4,
                 const RowEpisode &ep, const int32_t *ops_device, size_t B, hipStream_t stream, const RollArgs *roll = nullptr);
 int rows_geometry(const RowDims &dims, bool phys, int *waves, size_t *lds_bytes, int max_waves);
-int launch_rows_image(void *const fns[4], const MpeBuffers &b, const RowDims &dims, const RowTables &host, bool phys, int vec4,
+int launch_rows_image(void *const fns[5], const MpeBuffers &b, const RowDims &dims, const RowTables &host, bool phys, int vec4,
                       const RowEpisode &ep, size_t B, hipStream_t stream, const RollArgs *roll = nullptr);
 
 }  // namespace mpe

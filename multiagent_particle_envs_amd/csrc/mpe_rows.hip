@@ -144,14 +144,15 @@ __device__ __forceinline__ void agents_of_wave(int first, int stride, int A, F &
 // ROLL: the instantiation behind mpe_rollout_rows -- T steps per launch with the state resident in LDS, the moves drawn in the
 // kernel (action_draw: the rows mpe_random_actions_block would write), a reset_world of every world at the episode boundaries
 // (mpe_reset's draws), every step's rows / rewards / dones into its own trajectory block or over the same one.  (Its own
-// instantiation for the reason EP2 is one.)
+// instantiation for the reason EP2 is one.)  ROLL + EP2 (mpe_rollout_rows_episode): the episodes end where the done programs or
+// the horizon say, per world, inside the rollout -- every step is what mpe_step_rows_episode does.
 template <bool PHYS, bool STATIC, bool EP2, bool ROLL = false>
 __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode &ep, const RowDims &h_arg,
                                           const uint32_t *__restrict__ const tables, const int32_t vec4_nt, const int32_t split_arg,
                                           const uint32_t *__restrict__ const ops_g, const size_t B, const RollArgs &ra = RollArgs{}) {
   const int32_t vec4 = vec4_nt & 1;      // bit 0: 16-byte row stores are possible; bit 1: make them nontemporal
   const bool nt = (vec4_nt & 2) != 0;
-  static_assert(!ROLL || (PHYS && !EP2), "a rollout steps the world and keeps its own episode clock");
+  static_assert(!ROLL || PHYS, "a rollout steps the world");
   // LDS: a launch parameter for the interpreter; a compiled program knows its size (no 64 KB opt-in for module kernels needed)
   float *smem;
   if constexpr (STATIC) {
@@ -203,8 +204,8 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
 
   // ---- episode bookkeeping (mpe_episode_finish): count the step, find the worlds that finished, leave if none did ----------
   bool fin = false;
-  int cnt2 = 0;          // (mode 2: the step count, read with the state, used after the done programs)
-  if constexpr (EP2) cnt2 = (ep.episode_step + wave_off(w0))[ln] + 1;
+  int cnt_now = 0;       // (mode 2: the worlds' step counts, read with the state; every wave keeps the same copy)
+  if constexpr (EP2) cnt_now = (ep.episode_step + wave_off(w0))[ln];
   if (ep.enabled == 1) {
     const int cnt = (ep.episode_step + wave_off(w0))[ln] + 1;
     const bool horizon = ep.max_steps > 0 && cnt >= ep.max_steps;
@@ -289,7 +290,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   auto V = [&](int e, int c) { return e < NV ? S_vel[(2 * e + c) * kWave + lane] : 0.f; };
   auto pick = [&](int k) { return S_pick[k * kWave + lane]; };
   auto word = [&](int j, int c) {
-    if constexpr (ROLL) return ((ep.speakers >> j) & 1u) ? (S_word[j * kWave + lane] == c ? 1.f : 0.f) : 0.f;      // drawn this step / silent
+    if constexpr (ROLL) return (!fin && ((ep.speakers >> j) & 1u)) ? (S_word[j * kWave + lane] == c ? 1.f : 0.f) : 0.f;   // drawn this step / silent / restarted
     else return (fin || !b.comm) ? 0.f : (b.comm + wave_off(((size_t)j * B + w0) * DC))[ln * DC + c];
   };
   // inside region r (a landmark, e.g. a forest of simple_world_comm.py:231-261): strict |e - region| < size_e + size_region
@@ -301,9 +302,12 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   // ---- (ROLL) T steps: the output pointers of the current step, the reset at an episode boundary, then the step itself ---------
   MpeBuffers bo = b;
   const int T_ = ROLL ? ra.T : 1;
-#pragma nounroll
-  for (int t = 0; t < T_; ++t) {
+  // (one step as a lambda: a `return` below ends the step -- the launch, when there is only one)
+  auto one_step = [&](const int t) __attribute__((always_inline)) {
   const uint64_t gstep = ra.step0 + (uint64_t)t;
+  const int cnt2 = cnt_now + 1;
+  const uint64_t episode_now = ep.episode + (ROLL ? (uint64_t)t : 0u);      // (one episode number per step, as the host counts them)
+  if constexpr (ROLL && EP2) fin = false;
   if constexpr (ROLL) {
     if (ra.trajectory && t > 0) {
       bo.obs += (size_t)TI(MPE_TAB(obs_off), A) * B;
@@ -410,10 +414,10 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   // Two passes at most: the second only in mode 2 (mpe_step_rows_episode) and only in a workgroup where a world finished --
   // its worlds restarted, the observation programs run once more on the new episode's first state.  (One copy of the code.)
   constexpr int kPasses = EP2 ? 2 : 1;
-  if constexpr (ROLL) {
+  if constexpr (ROLL && !EP2) {
     // without a trajectory every step's outputs land on the same block: only the last step's survive, so only the last step
-    // computes and stores them (the state moves on either way)
-    if (!ra.trajectory && t != T_ - 1) continue;
+    // computes and stores them (the state moves on either way; with EP2 the done programs decide the restarts: every step runs)
+    if (!ra.trajectory && t != T_ - 1) return;
   }
 #pragma nounroll
   for (int pass = 0; pass < kPasses; ++pass) {
@@ -707,8 +711,6 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
         if ((ep.speakers >> a) & 1u)
           for (int c = 0; c < DC; ++c)
             (const_cast<float *>(b.comm) + wave_off(((size_t)a * B + w0) * DC))[ln * DC + c] = S_word[a * kWave + lane] == c ? 1.f : 0.f;
-    __syncthreads();      // the next step reuses S_rew, S_word, the slots and the tiles
-    break;                // (leaves the pass loop; the step loop goes on)
   }
   if constexpr (!EP2) return;
 
@@ -721,17 +723,18 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   for (int w = 0; w < NW; ++w) any_done = any_done || S_dw[(size_t)w * kRowSlots * kWave + lane] != 0;
   const bool horizon = ep.max_steps > 0 && cnt2 >= ep.max_steps;
   fin = (horizon || any_done) && live;
+  cnt_now = fin ? 0 : cnt2;
   if (wave == 0 && live) {
-    (ep.episode_step + wave_off(w0))[ln] = fin ? 0 : cnt2;
+    (ep.episode_step + wave_off(w0))[ln] = cnt_now;
     if (horizon)
-      for (int a = 0; a < A; ++a) (b.done + wave_off((size_t)a * B + w0))[ln] = 1;
+      for (int a = 0; a < A; ++a) (bo.done + wave_off((size_t)a * B + w0))[ln] = 1;
   }
   if (__builtin_amdgcn_ballot_w64(fin) == 0) return;      // nothing finished among these 64 worlds: the usual case
   // reset_world for the finished worlds -- the draws of mpe_reset for (seed, world, episode) -- into HBM and the staged state
   for (int e = wave; e < E; e += NW) {
     if (fin) {
       float x, y;
-      reset_draw(ep.seed, gw, ep.episode, e, e < A ? 1.0f : ep.landmark_range, x, y);
+      reset_draw(ep.seed, gw, episode_now, e, e < A ? 1.0f : ep.landmark_range, x, y);
       (b.pos + wave_off((size_t)(2 * e) * B + w0))[ln] = x;
       (b.pos + wave_off((size_t)(2 * e + 1) * B + w0))[ln] = y;
       S_pos[(2 * e) * kWave + lane] = x;
@@ -746,7 +749,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   }
   for (int k = wave; k < h.n_picks; k += NW) {
     if (fin) {
-      const int g = choice_draw(ep.seed, gw, ep.episode, k, ep.choice_pop[k]);
+      const int g = choice_draw(ep.seed, gw, episode_now, k, ep.choice_pop[k]);
       (b.choice + wave_off((size_t)k * B + w0))[ln] = g;
       S_pick[k * kWave + lane] = g;
     }
@@ -758,7 +761,12 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   }
   __syncthreads();
   }      // (second pass: the observation programs on the restarted worlds' state -- `fin` lanes read their utterances as zero)
-  }      // (ROLL: the next step)
+  };     // one_step
+#pragma nounroll
+  for (int t = 0; t < T_; ++t) {
+    one_step(t);
+    if constexpr (ROLL) __syncthreads();      // the next step reuses S_rew, S_word, the slots and the tiles
+  }
 }
 
 #ifndef MPE_ROWS_STATIC
@@ -768,17 +776,19 @@ __global__ void __launch_bounds__(1024) k_rows(const MpeBuffers b, const RowEpis
                                                  const uint32_t *__restrict__ const ops_g, const size_t B) {
   rows_body<PHYS, false, EP2>(b, ep, h, tables, vec4_nt, split, ops_g, B);
 }
+template <bool EP2>
 __global__ void __launch_bounds__(1024) k_rows_roll(const MpeBuffers b, const RowEpisode ep, const RowDims h,
                                                       const uint32_t *__restrict__ const tables, const int32_t vec4_nt,
                                                       const uint32_t *__restrict__ const ops_g, const size_t B, const RollArgs ra) {
-  rows_body<true, false, false, true>(b, ep, h, tables, vec4_nt, 0, ops_g, B, ra);
+  rows_body<true, false, EP2, true>(b, ep, h, tables, vec4_nt, 0, ops_g, B, ra);
 }
 #endif
 
 }  // namespace
 
 #ifdef MPE_ROWS_STATIC
-// the four entry points of a compiled program: <name>_{s,r,e,l} = step, rows only, step with the episode end inside, T-step rollout
+// the five entry points of a compiled program: <name>_{s,r,e,l,m} = step, rows only, step with the episode end inside, T-step
+// rollout, T-step rollout with the episode ends inside
 #define MPE_ROWS_CAT2(a, b) a##b
 #define MPE_ROWS_CAT(a, b) MPE_ROWS_CAT2(a, b)
 #define MPE_ROWS_STATIC_KERNEL(suffix, PHYS, EP2)                                                                             \
@@ -791,12 +801,15 @@ __global__ void __launch_bounds__(1024) k_rows_roll(const MpeBuffers b, const Ro
 MPE_ROWS_STATIC_KERNEL(_s, true, false)
 MPE_ROWS_STATIC_KERNEL(_r, false, false)
 MPE_ROWS_STATIC_KERNEL(_e, true, true)
-extern "C" __global__ void __launch_bounds__(static_waves<true>() * kWave)
-    __attribute__((amdgpu_waves_per_eu(MPE_ROWS_STATIC_OCC_STEP)))
-    MPE_ROWS_CAT(MPE_ROWS_STATIC_NAME, _l)(const MpeBuffers b, const RowEpisode ep, const int32_t vec4_nt, const size_t B,
-                                           const RollArgs ra) {
-  rows_body<true, true, false, true>(b, ep, RowDims{}, nullptr, vec4_nt, 0, nullptr, B, ra);
-}
+#define MPE_ROWS_STATIC_ROLL_KERNEL(suffix, EP2)                                                                              \
+  extern "C" __global__ void __launch_bounds__(static_waves<true>() * kWave)                                                   \
+      __attribute__((amdgpu_waves_per_eu(MPE_ROWS_STATIC_OCC_STEP)))                                                           \
+      MPE_ROWS_CAT(MPE_ROWS_STATIC_NAME, suffix)(const MpeBuffers b, const RowEpisode ep, const int32_t vec4_nt,              \
+                                                 const size_t B, const RollArgs ra) {                                          \
+    rows_body<true, true, EP2, true>(b, ep, RowDims{}, nullptr, vec4_nt, 0, nullptr, B, ra);                                   \
+  }
+MPE_ROWS_STATIC_ROLL_KERNEL(_l, false)
+MPE_ROWS_STATIC_ROLL_KERNEL(_m, true)
 #else
 
 int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream) {
@@ -846,7 +859,7 @@ int launch_rows(const MpeBuffers &b, const RowDims &h, const RowTables &host, co
     if (rc != hipSuccess) return (int)rc;
   }
   if (roll) {
-    auto fr = k_rows_roll;
+    auto fr = ep.enabled == 2 ? k_rows_roll<true> : k_rows_roll<false>;
     if (lds > 64 * 1024) {
       const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (rc != hipSuccess) return (int)rc;
@@ -860,14 +873,14 @@ int launch_rows(const MpeBuffers &b, const RowDims &h, const RowTables &host, co
   return (int)hipGetLastError();
 }
 
-// a compiled program (hipModule functions in the order s, r, e, l): same geometry, no tables, no ops
-int launch_rows_image(void *const fns[4], const MpeBuffers &b, const RowDims &h, const RowTables &host, bool phys, int vec4,
+// a compiled program (hipModule functions in the order s, r, e, l, m): same geometry, no tables, no ops
+int launch_rows_image(void *const fns[5], const MpeBuffers &b, const RowDims &h, const RowTables &host, bool phys, int vec4,
                       const RowEpisode &ep, size_t B, hipStream_t stream, const RollArgs *roll) {
   int W = 0;
   size_t lds = 0;
   if (int rc = rows_geometry(h, phys, &W, &lds, 0)) return rc;
   const bool nt = rows_nontemporal(h, host, vec4, ep, B);
-  hipFunction_t fn = static_cast<hipFunction_t>(fns[roll ? 3 : ep.enabled == 2 ? 2 : phys ? 0 : 1]);
+  hipFunction_t fn = static_cast<hipFunction_t>(fns[roll ? (ep.enabled == 2 ? 4 : 3) : ep.enabled == 2 ? 2 : phys ? 0 : 1]);
   MpeBuffers b_ = b;
   RowEpisode ep_ = ep;
   int32_t vec4_ = (vec4 ? 1 : 0) | (nt ? 2 : 0);

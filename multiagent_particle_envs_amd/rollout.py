@@ -34,9 +34,15 @@ class RandomRollout(object):
         if not env.fused:
             raise _abi.MpeError("RandomRollout drives the device-side step (fused scenarios and row-program envs); this env steps "
                                 "through Python callbacks: use env.step / GraphedStep")
-        self._prog = getattr(env, "_prog", None)      # a row-program env: per-step launches (enqueue / capture) only
-        if self._prog is not None and env.max_episode_steps:
-            raise _abi.MpeError("RandomRollout keeps its own episode clock (episode_len): build the row-program env without max_episode_steps")
+        self._prog = getattr(env, "_prog", None)      # a row-program env: mpe_step_rows / mpe_rollout_rows
+        # ... whose episodes end on the device (a done_spec and / or max_episode_steps, auto_reset): the rollout leaves the episode ends
+        # to it -- every step is mpe_step_rows_episode, T of them one mpe_rollout_rows_episode launch; one episode number per step
+        self._in_launch = self._prog is not None and bool(env._episode_in_launch)
+        if self._prog is not None and env.max_episode_steps and not self._in_launch:
+            raise _abi.MpeError("RandomRollout keeps its own episode clock (episode_len): build the row-program env without "
+                                "max_episode_steps, or with auto_reset (the env's done programs / horizon then end the episodes)")
+        if self._in_launch and int(episode_len):
+            raise _abi.MpeError("this env ends its episodes itself (done programs / max_episode_steps with auto_reset): episode_len = 0")
         if env._py_obs or env._py_reward or env._py_done or env._py_info:
             raise _abi.MpeError("RandomRollout runs on the device and evaluates the built-in callbacks only: this env has "
                                 "Python observation / reward / done / info callbacks (use env.step, or GraphedStep)")
@@ -111,7 +117,14 @@ class RandomRollout(object):
             out.act_ptr = None      # MultiAgentEnv.step's fast path must not trust its note of what b.act holds
             if self.pool_c is not None:
                 b.comm = self.pool_c[self.t % len(self.pool)].data_ptr()
-            if self._prog is not None:
+            if self._in_launch:
+                if env.episode_step is None:
+                    env.episode_step = torch.zeros(B, dtype=torch.int32, device=w.device)
+                _abi.check(L.mpe_step_rows_episode(C.byref(desc), C.byref(b), self._prog.ref, B, env.episode_step.data_ptr(),
+                                                   env.max_episode_steps, self._lr, self.seed, int(w._episode), int(w.world_offset), st),
+                           "mpe_step_rows_episode")
+                w._episode += 1
+            elif self._prog is not None:
                 _abi.check(L.mpe_step_rows(C.byref(desc), C.byref(b), self._prog.ref, B, st), "mpe_step_rows")
             else:
                 _abi.check(L.mpe_step(C.byref(desc), C.byref(b), B, st), "mpe_step")
@@ -171,7 +184,16 @@ class RandomRollout(object):
         b.act = b.ids = b.u = None
         if trajectory is None:
             ret.act_ptr = None      # (as in enqueue: the env's set 0 no longer points at the caller's action tensor)
-        if self._prog is not None:      # a row-program env: the same launch shape, the rows and rewards by its program
+        if self._in_launch:             # ... and the episode ends by its done programs / horizon, inside the launch
+            w = self.world
+            if self.env.episode_step is None:
+                self.env.episode_step = torch.zeros(self.B, dtype=torch.int32, device=w.device)
+            _abi.check(self._L.mpe_rollout_rows_episode(C.byref(self._desc), C.byref(b), self._prog.ref, self.B, int(steps),
+                                                        self.env.episode_step.data_ptr(), self.env.max_episode_steps, self._lr, self.seed,
+                                                        self.t, int(w._episode), int(w.world_offset), 1 if trajectory is not None else 0,
+                                                        int(self.speakers), self._stream()), "mpe_rollout_rows_episode")
+            w._episode += int(steps)
+        elif self._prog is not None:    # a row-program env: the same launch shape, the rows and rewards by its program
             _abi.check(self._L.mpe_rollout_rows(C.byref(self._desc), C.byref(b), self._prog.ref, self.B, int(steps), self.episode_len,
                                                 self._lr, self.seed, self.t, int(self.world.world_offset),
                                                 1 if trajectory is not None else 0, int(self.speakers), self._stream()), "mpe_rollout_rows")

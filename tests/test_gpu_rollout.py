@@ -259,6 +259,50 @@ def test_rollout_with_integer_action_ids_equals_env_steps_with_those_ids():
     assert not torch.equal(envs[3].world.pos, ref.world.pos)
 
 
+@pytest.mark.parametrize("compiled", [False, True])
+def test_rollouts_whose_episodes_end_by_the_programs_done_tests(compiled):
+    """examples/corral.py with an arena (a done_spec) + a horizon + auto_reset: ONE mpe_rollout_rows_episode launch for T steps --
+    per world, the episode ends where an agent leaves the arena or the horizon is reached, the world restarts inside that step --
+    against the same T steps as mpe_step_rows_episode launches (RandomRollout.enqueue) and as plain env.step calls with the same
+    block-drawn moves: every step's rows, rewards and dones, the counters, the picks, the state -- to the bit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_rowspec as tr
+    B, T = 1500, 14
+
+    def make():
+        e = tr.corral_env(B, arena=0.95, max_episode_steps=6, auto_reset=True)
+        if compiled:
+            assert e.compile_program()
+        e.reset()
+        return e
+    d, e, f = make(), make(), make()
+    assert d._episode_in_launch and d._prog.has_done and d.program_compiled == compiled
+    rd, re_ = RandomRollout(d, episode_len=0, pool=4, regenerate=True), RandomRollout(e, episode_len=0, pool=4, regenerate=True)
+    traj = Trajectory(d, T)
+    rd.fused(T, traj)
+    L = _abi.lib()
+    moves = torch.empty((4, f.n, B, 5), device="cuda")
+    ended = 0
+    for t in range(T):
+        out_t = re_.enqueue(1)
+        if t % 4 == 0:
+            _abi.check(L.mpe_random_actions_block(moves.data_ptr(), None, f.n, B, rd.seed, t, 4, 0, _abi.raw_stream(f.world.device)), "draw")
+        of, rf, df, _ = f.step(moves[t % 4].clone())
+        for i in range(d.n):
+            assert torch.equal(traj.obs[t][i], out_t.obs_n[i]) and torch.equal(traj.obs[t][i], of[i]), (t, i)
+            assert torch.equal(traj.rew[t][i], out_t.reward_n[i]) and torch.equal(traj.rew[t][i], rf[i]), (t, i)
+            assert torch.equal(traj.done[t][i], out_t.done_n[i]) and torch.equal(traj.done[t][i], df[i]), (t, i)
+        ended += int(traj.done[t].any(dim=0).sum())
+    for x in (e, f):
+        assert torch.equal(d.world.pos, x.world.pos) and torch.equal(d.world.vel, x.world.vel)
+        assert torch.equal(d.episode_step, x.episode_step) and torch.equal(d.world.choice_i32, x.world.choice_i32)
+        assert d.world._episode == x.world._episode
+    assert ended > B            # every world ended at least once (the horizon), many earlier
+    with pytest.raises(_abi.MpeError, match="episode_len = 0"):
+        RandomRollout(make(), episode_len=5)
+
+
 @pytest.mark.parametrize("B", [1, 5, 70, 129])
 def test_program_rollouts_at_batch_sizes_that_do_not_fill_a_wave(B):
     """Fewer worlds than a wave, and a ragged last workgroup: the fused rollout of a row-program env (interpreted and compiled in)

@@ -485,10 +485,10 @@ def test_static_source_and_image_of_a_program_on_the_cpu():
     assert src.count("{") - 3 == env._prog.n_ops + 1          # one {a, b, c, d} per op (+ the dims' region pair)
     from multiagent_particle_envs_amd import _build
     image = _build.compile_rows_image(src)
-    for suffix in ("_s", "_r", "_e", "_l"):
+    for suffix in ("_s", "_r", "_e", "_l", "_m"):
         assert (name + suffix).encode() in image
     assert _build.compile_rows_image(src) == image            # cached by content
-    # the four entry points of the image keep their registers: no scratch memory (a spilling image would be slower than the interpreter)
+    # the five entry points of the image keep their registers: no scratch memory (a spilling image would be slower than the interpreter)
     import subprocess
     import tempfile
     llvm = "/opt/rocm/lib/llvm/bin/"
@@ -500,7 +500,7 @@ def test_static_source_and_image_of_a_program_on_the_cpu():
             notes = subprocess.check_output([llvm + "llvm-readelf", "--notes", os.path.join(tmp, "i.elf")]).decode()
         import re
         kernels = re.findall(r"\.name:\s+(%s_\w+)\n.*?\.private_segment_fixed_size:\s+(\d+)" % name, notes, flags=re.S)
-        assert len(kernels) == 4 and all(int(sz) == 0 for _, sz in kernels), kernels
+        assert len(kernels) == 5 and all(int(sz) == 0 for _, sz in kernels), kernels
     env.world.agents[0].size = 0.2
     env.refresh_constants()
     other = env._prog.static_source(env._desc)
