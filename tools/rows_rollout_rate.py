@@ -55,6 +55,21 @@ def main():
                   % (name, "compiled in" if compiled else "interpreted", per_step, fused_traj, fused_last, env._prog.n_ops))
             del rr, g, traj, env
             torch.cuda.empty_cache()
+    # episodes that end by the program's done tests / the horizon, per world, inside the launch (mpe_rollout_rows_episode)
+    for compiled in (False, True):
+        env = tr.corral_env(B, arena=0.95, max_episode_steps=T, auto_reset=True)
+        if compiled:
+            assert env.compile_program()
+        env.reset()
+        rr = RandomRollout(env, episode_len=0, pool=T, regenerate=True)
+        g = rr.capture(2 * T)
+        per_step = timed(g.replay, 2 * T)
+        traj = Trajectory(env, T)
+        fused_traj = timed(lambda: rr.fused(T, traj), T)
+        print("%-28s %-12s per-step launches %6.2f | fused rollout, trajectory kept %6.2f |   (done_spec + horizon %d + auto_reset: the episodes"
+              " end inside the launches)" % ("corral with an arena", "compiled in" if compiled else "interpreted", per_step, fused_traj, T))
+        del rr, g, traj, env
+        torch.cuda.empty_cache()
     env = mpe.make_env("simple_spread", batch_size=B)
     rr = RandomRollout(env, episode_len=T, pool=T, regenerate=True)
     g = rr.capture(2 * T)
