@@ -105,3 +105,33 @@ def test_the_peephole_pass_does_not_change_what_a_random_program_computes(seed):
     for x, y in zip(o1.dones(pos, vel, comm, choice), o2.dones(pos, vel, comm, choice)):
         assert np.array_equal(x, y)
     assert any(d.any() for d in o1.dones(pos, vel, comm, choice)) or not e1._prog.has_done
+
+
+def test_the_example_scenarios_two_descriptions_agree_on_the_cpu():
+    """examples/corral.py describes its rows / rewards / done condition as specs AND computes them with torch callbacks: the program's
+    value (this oracle, fp64) against the callbacks' (torch, fp32 tensors on the CPU) on random states -- without a GPU."""
+    import torch
+    B = 400
+    env = tr.corral_env(B, device="cpu", arena=0.9)
+    sc, w = env.scenario, env.world
+    orc = oracle_of(env)
+    rs = np.random.RandomState(8)
+    pos = rs.uniform(-1.05, 1.05, (B, 6, 2))
+    pos[::4] *= 0.25
+    vel = rs.uniform(-1, 1, (B, 3, 2))
+    choice = rs.randint(0, 3, (1, B))
+    w.pos.copy_(torch.as_tensor(pos, dtype=torch.float32).permute(1, 2, 0))
+    w.vel.copy_(torch.as_tensor(vel, dtype=torch.float32).permute(1, 2, 0))
+    w.choice_i32.copy_(torch.as_tensor(choice, dtype=torch.int32))
+    p32, v32 = w.pos.permute(2, 0, 1).double().numpy(), w.vel.permute(2, 0, 1).double().numpy()      # the fp32 state both sides see
+    obs, rew, done = orc.observe(p32, v32, None, choice), orc.rewards(p32, v32, None, choice), orc.dones(p32, v32, None, choice)
+    near = orc.reward_guard(p32, 1e-5, choice) | orc.done_guard(p32, 1e-5, v32, None, choice)
+    assert near.mean() < 0.05
+    for i, agent in enumerate(w.agents):
+        o = sc.observation(agent, w).double().numpy()
+        assert o.shape == obs[i].shape and np.abs(o - obs[i]).max() <= 1e-6, (i, np.abs(o - obs[i]).max())
+        r = sc.reward(agent, w).double().numpy()
+        e = np.abs(r - rew[i]) / np.maximum(1.0, np.abs(rew[i]))
+        assert e[~near].max() <= 1e-5, (i, e[~near].max())
+        d = sc.done(agent, w).numpy()
+        assert np.array_equal(d[~near], done[i][~near]) and d.any()
