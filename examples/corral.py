@@ -21,6 +21,8 @@ class Scenario(BaseScenario):
     torch callbacks (the generic path), so that the two can be held against each other."""
 
     landmark_range = 0.9       # reset_world places the posts in [-0.9, 0.9)^2 (read by the device-side resets too)
+    device_reset = True        # reset_world IS world.reset_uniform(landmark_range, choices=choice_pops): finished worlds may be
+                               # restarted by the device-side draw (in the step launch / a rollout) instead of a masked reset_world
     arena = None               # a bound (e.g. 0.95): an agent outside |x|, |y| <= arena is done (None: never, the reference's default)
 
     def make_world(self, batch_size=1, device=None):

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(64) k_rows_header(const RowTables t, RowTables
 // defines, and walks its agents through literal indices: after inlining, every op code, entity index, column and LDS
 // address is a compile-time constant -- the interpreter folds away into straight-line code (the switch, the scalar loads,
 // the loop control), the LDS reads of a program batch up, and what is left is the arithmetic in the same order: the
-// interpreted and the compiled step agree bit for bit (tests/test_gpu_rowspec.py).
+// interpreted and the compiled step agree bit for bit (tests/test_rowspec.py).
 #ifdef MPE_ROWS_STATIC
 template <bool PHYS> constexpr int static_waves() { return PHYS ? MPE_ROWS_STATIC_WAVES_STEP : MPE_ROWS_STATIC_WAVES_ROWS; }
 template <bool PHYS> constexpr int static_lds_floats() { return (PHYS ? MPE_ROWS_STATIC_LDS_STEP : MPE_ROWS_STATIC_LDS_ROWS) / 4; }
@@ -476,7 +476,8 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
             row[col] = s ? V(e, 0) : 0.f; row[col + 1] = s ? V(e, 1) : 0.f; col += 2;
             break;
           }
-          case ROW_OBS_IN_REGION: row[col] = ((inmask >> (2 * e + a1)) & 1ull) ? 1.f : -1.f; col += 1; break;
+          // (inmask holds the agents' bits -- the visibility rule is about agents; any other entity is tested where it is asked for)
+          case ROW_OBS_IN_REGION: row[col] = (e < A ? ((inmask >> (2 * e + a1)) & 1ull) != 0ull : in_region(e, a1)) ? 1.f : -1.f; col += 1; break;
           // ---- range forms: one decode, the entities of a run in an inner loop (two of them in flight per LDS round trip) ----
           case ROW_OBS_REL_RANGE: case ROW_OBS_VEL_RANGE: case ROW_OBS_REL_VIS_RANGE: case ROW_OBS_VEL_VIS_RANGE: {
             const int skip = (uni(op.x >> 24) & 1) ? i : -1;

@@ -133,6 +133,7 @@ class MultiAgentEnv(object):
         self.episode_step = None      # int32 [B] on the device: steps since each world's last reset
         self._steps_taken = 0         # env steps since construction
         self._may_finish = set()      # values of _steps_taken at which some world can reach the horizon
+        self._horizon_clock_lost = False   # a device-side rollout advanced the per-world step counters behind the host's back
         self.numpy_io = bool(numpy_io)
         self.fresh_outputs = bool(fresh_outputs)
         self._step_impl = "split"
@@ -175,13 +176,24 @@ class MultiAgentEnv(object):
         self.finish_launch = True       # done_callback + auto_reset: restart finished worlds in one launch (mpe_episode_finish)
         if sc is None:
             sc = next((getattr(cb, "__self__", None) for cb in (reward_callback, reset_callback) if cb is not None), None)
+
+        def own_or_absent(cb, name):
+            # the scenario's OWN method of that name (whatever class of its MRO defines it), or no callback at all where the
+            # scenario defines none either (a spec-only scenario: make_env passes None) -- never somebody else's function
+            if cb is None:
+                return getattr(sc, name, None) is None
+            return getattr(cb, "__self__", None) is sc and getattr(cb, "__func__", None) is getattr(type(sc), name, None)
         if not own and fused is not False and sc is not None and \
                 len(world.scripted_agents) == 0 and not any(l.movable for l in world.landmarks) and \
                 len(world.entities) <= _abi.MPE_ROWS_MAX_ENTITIES and \
                 not any(a.u_noise or (a.c_noise and not a.silent) for a in world.agents) and world.pos is not None:
             from . import rowspec
             if hasattr(sc, "obs_spec") and hasattr(sc, "reward_spec"):
-                self._prog = rowspec.compile_scenario(sc, world)
+                # the specs stand in for the scenario's own observation / reward -- and only for those: callbacks that are
+                # not this scenario's methods (MultiAgentEnv(world, sc.reset_world, my_reward, my_obs)) are the caller's
+                # rows and rewards and must run (generic path); fused=True with such callbacks is refused below
+                if own_or_absent(observation_callback, "observation") and own_or_absent(reward_callback, "reward"):
+                    self._prog = rowspec.compile_scenario(sc, world)
             elif builtin is not None and kind in rowspec.BUILTIN_PROGRAM_KINDS and is_builtin(observation_callback, "observation") and \
                     is_builtin(reward_callback, "reward") and getattr(reset_callback, "__self__", None) is sc:
                 # a built-in scenario at a team size libmpe_hip.so has no kernel for: its callbacks are N-generic
@@ -196,6 +208,18 @@ class MultiAgentEnv(object):
         self.fused = bool(fused)
         if not self.fused or own:
             self._prog = None
+        # Restarts drawn ON THE DEVICE (inside mpe_step_rows_episode / mpe_episode_finish / the episode rollouts) are
+        # `world.reset_uniform(landmark_range, choices=choice_pops)` and nothing else: agents U[-1,1)^2, landmarks
+        # U[-landmark_range, landmark_range)^2, vel = 0, uniform picks, utterances zeroed.  They never call reset_callback.
+        # So they are taken only where that IS the scenario's reset_world: a built-in scenario's own reset_world, or a
+        # scenario that says so (`device_reset = True`, scenario.py) -- otherwise finished worlds restart through the
+        # masked reset_callback (a scenario with fixed posts, a restricted spawn area or per-world state of its own keeps
+        # its distribution).  rng_mode 'numpy' (compatibility mode: the global np.random stream) never restarts on the device.
+        rs = getattr(reset_callback, "__self__", None)
+        rb = next((c for c in type(rs).__mro__ if c.__module__.startswith(pkg)), None) if rs is not None else None
+        self._uniform_reset = rs is not None and (
+            (rb is not None and getattr(reset_callback, "__func__", None) is rb.__dict__.get("reset_world")) or
+            (bool(getattr(rs, "device_reset", False)) and getattr(reset_callback, "__func__", None) is getattr(type(rs), "reset_world", None)))
         self._has_speakers = any(not a.silent for a in world.agents)
         self._comm_kind = self.fused and (kind in _abi.COMM_KINDS if self._prog is None else self._has_speakers)
         self._scenario = sc
@@ -319,7 +343,10 @@ class MultiAgentEnv(object):
                 self._may_finish.add(self._steps_taken + self.max_episode_steps)
             # the episode number a restart draws with: one per step where a done test can fire at any step (as mpe_episode_finish
             # counts), one per step at which some world CAN reach the horizon otherwise (as the masked resets of that path count)
-            counts = self._prog.has_done or (self._steps_taken + 1) in self._may_finish
+            # (after a device-side rollout drove this env -- RandomRollout counts its steps on the device only -- the host no longer
+            #  knows at which steps a world can reach the horizon: every step then takes a fresh episode number, so that a restart
+            #  never reuses a (seed, world, episode) key)
+            counts = self._prog.has_done or self._horizon_clock_lost or (self._steps_taken + 1) in self._may_finish
             rc = L.mpe_step_rows_episode(desc_ref, bufs_ref, self._prog.ref, B, self.episode_step.data_ptr(), self.max_episode_steps,
                                          float(getattr(self._scenario, "landmark_range", 1.0)), int(w.seed) & (2 ** 64 - 1),
                                          int(w._episode), int(w.world_offset), st)
@@ -335,7 +362,12 @@ class MultiAgentEnv(object):
         """Episodes end INSIDE the step launch: a row-program env with max_episode_steps + auto_reset whose done condition is
         the program's (a `done_spec`) or the horizon alone -- no Python done callback, no Python rows."""
         return self._prog is not None and self.fused and self.auto_reset and bool(self.max_episode_steps) and self.finish_launch and \
-            not self.two_launch_program and not self._py_done and not self._py_obs and not self._py_reward
+            not self.two_launch_program and not self._py_done and not self._py_obs and not self._py_reward and self._device_restart_ok
+
+    @property
+    def _device_restart_ok(self):
+        """Finished worlds may be restarted by the device-side draw (see `_uniform_reset` in __init__)."""
+        return self._uniform_reset and self.world.rng_mode == "device"
 
     def _attach_program_image(self):
         """After the descriptor of a row-program env was (re)built: bring the compiled image in line with the policy."""
@@ -713,7 +745,7 @@ class MultiAgentEnv(object):
         scenario stepping through a kernel of its own -- that scenario's rows as a program (bit-identical to the kernel's,
         tests/test_rowspec.py); None where there is none (more than 64 entities, Python observation rows, `finish_launch`
         switched off)."""
-        if not self.finish_launch or not self.fused or self._py_obs:
+        if not self.finish_launch or not self.fused or self._py_obs or not self._device_restart_ok:
             return None
         if self._prog is not None:
             return self._prog
@@ -723,15 +755,18 @@ class MultiAgentEnv(object):
             if name is not None and len(self.world.entities) <= _abi.MPE_ROWS_MAX_ENTITIES and \
                     not any(l.movable for l in self.world.landmarks):
                 from . import rowspec
-                prog = rowspec.builtin_program(name, self.world)
-                if list(prog.widths) == [self._obs_off[i + 1] - self._obs_off[i] for i in range(len(prog.widths))]:
-                    prog.validate(self._desc)
-                    if self.compile_program_policy is not False and self.world.device.type == "cuda":
-                        try:
-                            prog.compile(self._desc, cached_only=self.compile_program_policy is None)
-                        except _abi.MpeError:
-                            pass
-                    self._finish_prog = prog
+                try:        # (a shape the built-in specs do not cover, regions with A > 32 ...: the mask-reset path, from the first step on)
+                    prog = rowspec.builtin_program(name, self.world)
+                    if list(prog.widths) == [self._obs_off[i + 1] - self._obs_off[i] for i in range(len(prog.widths))]:
+                        prog.validate(self._desc)
+                        if self.compile_program_policy is not False and self.world.device.type == "cuda":
+                            try:
+                                prog.compile(self._desc, cached_only=self.compile_program_policy is None)
+                            except _abi.MpeError:
+                                pass
+                        self._finish_prog = prog
+                except _abi.MpeError:
+                    self._finish_prog = False
         return self._finish_prog or None
 
     def _episode_tick(self, done, out=None):
@@ -810,6 +845,7 @@ class MultiAgentEnv(object):
                 self.episode_step.masked_fill_(torch.as_tensor(mask, device=self.world.device).bool(), 0)
         if mask is None:
             self._may_finish.clear()
+            self._horizon_clock_lost = False     # every world starts an episode now: the host's clock is right again
         self._may_finish.add(self._steps_taken + self.max_episode_steps)
 
     def _observe_into(self, out):

@@ -43,6 +43,10 @@ class RandomRollout(object):
                                 "max_episode_steps, or with auto_reset (the env's done programs / horizon then end the episodes)")
         if self._in_launch and int(episode_len):
             raise _abi.MpeError("this env ends its episodes itself (done programs / max_episode_steps with auto_reset): episode_len = 0")
+        if int(episode_len) and not env._device_restart_ok:
+            raise _abi.MpeError("RandomRollout's episode resets are drawn on the device as world.reset_uniform(landmark_range, "
+                                "choices=choice_pops); this env's reset_world is not known to be that (a built-in scenario, or a "
+                                "scenario with `device_reset = True`, in rng_mode 'device'): use episode_len = 0 and reset it yourself")
         if env._py_obs or env._py_reward or env._py_done or env._py_info:
             raise _abi.MpeError("RandomRollout runs on the device and evaluates the built-in callbacks only: this env has "
                                 "Python observation / reward / done / info callbacks (use env.step, or GraphedStep)")
@@ -148,6 +152,10 @@ class RandomRollout(object):
             out.act_ptr = None
         if env.episode_step is not None and self.episode_len:
             env.episode_step.fill_(self.t % self.episode_len)
+        if self._in_launch:
+            # the per-world step counters moved on the device; the host's note of the steps at which a world can reach the
+            # horizon (env._may_finish) is no longer true: env.step takes a fresh episode number at every step from here on
+            env._horizon_clock_lost = True
 
     def capture(self, steps):
         """Capture `steps` env steps into a HIP graph (torch.cuda.CUDAGraph); replay() re-runs them.

@@ -28,7 +28,7 @@ scenario can say WHAT its rows are instead of computing them:
 row, reward, done) -- whatever the scenario is; no JIT, no generated code: the specs compile to a list of 16-byte ops
 (include/mpe_hip.h, enum MpeRowOp) uploaded once.  Arithmetic happens in program order with the kernels' own device
 functions, so a spec that follows a reference callback's order reproduces it to the fp32 bit; `builtin_specs` below
-holds the nine shipped scenarios written this way (tests/test_gpu_rowspec.py: bit-identical to their fused kernels).
+holds the nine shipped scenarios written this way (tests/test_rowspec.py: bit-identical to their fused kernels).
 
 Entities are named by the objects themselves (`world.agents[k]`, `world.landmarks[k]`) or by index into
 `world.entities`; per-world picks (`agent.goal_a = np.random.choice(world.landmarks)`) by their row of

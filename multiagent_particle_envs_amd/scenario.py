@@ -18,7 +18,15 @@ unmodified, is stepped by one fused launch.  A scenario of your own has two ways
     observation(agent, world) / reward(agent, world)     COMPUTE them with torch ops on [B, .] views: the generic path,
                                                          ~100 small launches per step (GraphedStep replays them as one)
 
-Specs win when a scenario has both (fused=False keeps the Python callbacks).  A file written against the REFERENCE's
+Specs win when a scenario has both (fused=False keeps the Python callbacks) -- they stand in for the scenario's OWN
+observation / reward methods only: callbacks handed to MultiAgentEnv that are not this scenario's methods run as given.
+
+Restarts on the device.  With `auto_reset`, worlds that finish are restarted inside the step launch (row programs) or by
+one small launch behind it (`mpe_episode_finish`), and RandomRollout resets episodes inside its launches; those draws are
+exactly `world.reset_uniform(landmark_range, choices=choice_pops)` (agents U[-1,1)^2, landmarks U[-r,r)^2, vel = 0, uniform
+picks, utterances zeroed) and never call `reset_world`.  They are used for the built-in scenarios' own reset_world and for
+a scenario that declares `device_reset = True` (its reset_world is that placement -- examples/corral.py), in rng_mode
+'device'; any other reset_world (fixed posts, a restricted spawn area, per-world state of its own) is called with a mask.  A file written against the REFERENCE's
 contract (`make_world(self)`, NumPy callbacks) loads unmodified through refstyle.py.
 """
 
@@ -26,6 +34,9 @@ contract (`make_world(self)`, NumPy callbacks) loads unmodified through refstyle
 class BaseScenario(object):
     #: `_abi.MPE_SCN_*` of the fused kernel that implements this scenario's callbacks (None: generic path)
     kind = None
+    #: True: reset_world is `world.reset_uniform(self.landmark_range, mask, choices=world.choice_pops, seeds=seeds)` and nothing
+    #: else that matters -- finished worlds may be restarted by the device-side draw instead of a masked reset_world call
+    device_reset = False
 
     def make_world(self, batch_size=1, device=None):
         """Create the World: agents, landmarks, their constants; end with `world.allocate()`."""

@@ -520,6 +520,7 @@ class _RandomScenario(BaseScenario):
     done condition a random composition of the spec vocabulary (the peephole fuser and the compiled form must not care)."""
 
     landmark_range = 0.9
+    device_reset = True        # (reset_world below is reset_uniform: restarts may be drawn on the device)
 
     def __init__(self, seed):
         self.rs = np.random.RandomState(seed)
@@ -744,3 +745,111 @@ def test_done_callback_auto_reset_in_one_launch_equals_the_separate_launches(nam
         restarted += int(fin.sum())
         assert torch.equal(new.episode_step == 0, fin), t          # exactly the finished worlds restarted their count
     assert 0 < restarted < 16 * B          # some worlds strayed early, most steps most worlds did not finish
+
+
+# ---- whose rows, whose restarts (round 4's review) ------------------------------------------------------------------------------
+def test_callbacks_that_are_not_the_scenarios_own_are_not_replaced_by_its_specs():
+    """The specs stand in for the scenario's OWN observation / reward.  `MultiAgentEnv(world, sc.reset_world, my_reward, my_obs)`
+    with a spec-bearing scenario keeps the caller's callbacks (generic path); asked for fused=True it is refused."""
+    sc = Corral()
+    w = sc.make_world(batch_size=4, device="cpu")
+
+    def my_obs(agent, world):
+        return torch.zeros((world.batch_size, 3))
+
+    def my_reward(agent, world):
+        return torch.ones(world.batch_size)
+    env = mpe.MultiAgentEnv(w, sc.reset_world, my_reward, my_obs)
+    assert env._prog is None and not env.fused and [s.shape[0] for s in env.observation_space] == [3, 3, 3]
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, my_obs)
+    assert env._prog is None and not env.fused
+    with pytest.raises(_abi.MpeError, match="fused=True"):
+        mpe.MultiAgentEnv(w, sc.reset_world, my_reward, my_obs, fused=True)
+    # the scenario's own methods (or none at all, for a spec-only scenario): the program
+    assert mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation)._prog is not None
+    r = _RandomScenario(3)
+    assert mpe.MultiAgentEnv(r.make_world(batch_size=4, device="cpu"), r.reset_world, None, None)._prog is not None
+
+
+def test_device_side_restarts_only_where_reset_world_is_the_uniform_placement():
+    """In-launch / finish-launch restarts draw `reset_uniform` and never call reset_callback: taken for the built-in scenarios'
+    own reset_world and for scenarios that declare `device_reset = True`, in rng_mode 'device' -- a scenario with a reset_world
+    of its own keeps it (masked reset_callback path)."""
+    class FixedPosts(Corral):
+        device_reset = False
+
+        def reset_world(self, world, mask=None, seeds=None):
+            Corral.reset_world(self, world, mask, seeds)       # ... and then something of its own
+
+    kw = dict(max_episode_steps=5, auto_reset=True, compile_program=False)
+    for cls, ok in ((Corral, True), (FixedPosts, False)):
+        sc = cls()
+        w = sc.make_world(batch_size=4, device="cpu")
+        env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, **kw)
+        assert env._prog is not None and env._device_restart_ok == ok and env._episode_in_launch == ok
+        assert (env._finish_program() is not None) == ok
+        w.rng_mode = "numpy"                                    # compatibility mode: the global np.random stream, never the device
+        assert not env._device_restart_ok and not env._episode_in_launch and env._finish_program() is None
+    # a subclass that overrides a built-in scenario's reset_world is on its own too
+    Base = mpe.scenarios.load("simple_tag.py").Scenario
+
+    class Mine(Base):
+        def reset_world(self, world, mask=None, seeds=None):
+            Base.reset_world(self, world, mask, seeds)
+    for cls, ok in ((Base, True), (Mine, False)):
+        sc = cls()
+        w = sc.make_world(batch_size=4, device="cpu")
+        env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, max_episode_steps=5, auto_reset=True)
+        assert env._device_restart_ok == ok
+
+
+class _Wooded(Corral):
+    """corral with post 0 as a region: every entity kind asked whether it is inside (observer, another agent, landmarks)."""
+
+    def regions(self, world):
+        return rowspec.Regions([world.landmarks[0]], [])
+
+    def obs_spec(self, agent, world):
+        o = Corral.obs_spec(self, agent, world)
+        o.in_region(0).in_region(0, world.agents[2]).in_region(0, world.landmarks[1]).in_region(0, world.landmarks[0])
+        return o.in_region(0, world.landmarks[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compiled", [False, True])
+def test_in_region_of_any_entity_against_the_numpy_oracle(compiled):
+    """`ObsSpec.in_region(region, ent)` accepts any entity; the kernel kept the agents' bits only (a landmark always read -1).
+    Rows against oracle/rowprog.py on the kernel's own state, posts pulled together so that landmarks DO overlap the region."""
+    from oracle import rowprog
+    B = 2048
+    sc = _Wooded()
+    w = sc.make_world(batch_size=B)
+    w.seed = 5
+    sc.reset_world(w)
+    env = mpe.MultiAgentEnv(w, sc.reset_world, None, None, compile_program=False)
+    if compiled:
+        assert env.compile_program()
+    p = env._prog
+    orc = rowprog.from_program(p.struct, p.ops_host, p.n_ops, env._desc)
+    rs = np.random.RandomState(9)
+    env.reset()
+    env.world.pos.mul_(0.12)
+    inside = np.zeros(5)
+    for t in range(3):
+        obs, _, _, _ = env.step(rand_actions(env, rs, B))
+        pos = w.pos.permute(2, 0, 1).double().cpu().numpy()
+        vel = w.vel.permute(2, 0, 1).double().cpu().numpy()
+        choice = w.choice_i32.cpu().numpy()
+        o64 = orc.observe(pos, vel, np.zeros((3, B, 0)), choice)
+        d = np.sqrt(((pos - pos[:, 3:4, :]) ** 2).sum(-1))                                              # [B, E]: distance to post 0 (entity 3)
+        size = np.array([e.size for e in w.entities])
+        near = np.abs(d - (size[None, :] + size[3])) < 2e-6                                             # strict-< band (fp32 vs fp64)
+        for i in range(env.n):
+            g, r = obs[i].double().cpu().numpy(), o64[i]
+            assert np.abs(g[:, :-5] - r[:, :-5]).max() <= 1e-5
+            ents = [i, 2, 4, 3, 5]
+            for k, e in enumerate(ents):
+                ok = ~near[:, e]
+                assert np.array_equal(g[ok, -5 + k], r[ok, -5 + k]), (t, i, k)
+                inside[k] += (r[:, -5 + k] > 0).mean()
+    assert inside[3] == 3 * env.n and 0 < inside[2] / (3 * env.n) < 1 and 0 < inside[4] / (3 * env.n) < 1     # post 0 is inside itself; others: both answers occur
