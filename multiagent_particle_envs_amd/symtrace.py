@@ -1,0 +1,1037 @@
+"""Reference-style Scenario files, unmodified, at kernel speed: the file's NumPy callbacks TRACED into row programs.
+
+A reference-style scenario (multiagent/scenario.py:4-10, README "Creating new environments") answers
+`observation(agent, world)` / `reward(agent, world)` with NumPy arithmetic on ONE world's Python objects.  refstyle.py
+runs such a file as it is -- B shadow worlds, the callbacks per world on the host: correct, and 3-5 orders of magnitude
+slower than a kernel.  This module makes the same file fast without touching it:
+
+  trace     the callbacks are called ONCE per agent (per control-flow path) on a shadow world whose state vectors hold
+            symbolic scalars instead of floats (NumPy object arrays: `a - b`, np.square / sum / sqrt / exp, concatenate work
+            unchanged); every arithmetic step becomes a node of an expression graph over the world's state -- positions,
+            velocities, utterances, and the per-world PICKS `reset_world` draws with np.random.choice (a goal landmark, a
+            key: objects chosen per world are proxies whose attributes are selections by the pick).  A Python `if` on a
+            symbolic comparison (`if dist < dist_min: rew -= 1`) forks: the callback is re-run with the decision forced
+            each way and the outcomes merge into select nodes, column by column (conditions are memoised per path, so a
+            test asked twice forks once).  `reset_world` is traced the same way with np.random replaced by a recorder:
+            initial positions as functions of uniform draws and picks.
+  verify    the graphs are evaluated with NumPy (fp64, vectorised over worlds) against the FILE'S OWN callbacks run
+            concretely on random worlds -- states that touch, overlap, leave the arena -- before anything is generated:
+            a callback that keeps hidden state, draws random numbers or does something the tracer does not model is
+            caught here, and the env falls back to the host path of refstyle.py (always correct).
+  generate  each agent's graphs become straight-line device code (`traced_obs` / `traced_rew`: one statement per node,
+            in trace order = the reference's arithmetic order, fp32; `sqrt(x) < r` tests as the library's exact
+            `sqrt_lt`), appended to the generated header of a compiled row program (rowspec.py, csrc/mpe_rows.hip:
+            the ops MPE_ROW_OBS_CODE / MPE_ROW_R_CODE call it): `World.step`, the rows, the rewards -- ONE launch per
+            step, the episode ends / rollouts of row programs included.
+
+What is traced is arithmetic on the state: files whose callbacks read actions, scripted agents, movable landmarks, noise,
+more than MPE_MAX_CHOICES picks, or more control-flow paths than `MAX_PATHS` stay on the host path.
+Nothing here runs on the step path: tracing happens once, at env construction.
+"""
+import contextlib
+import math
+
+import numpy as np
+
+
+class TraceUnsupported(Exception):
+    """The file does something the tracer does not model: the caller falls back to the host path (refstyle.py)."""
+
+
+MAX_PATHS = 8192          # control-flow paths of ONE callback of one agent (every symbolic `if` can double them)
+_CMP = ("lt", "le", "eq", "ne")
+_BOOL_OPS = _CMP + ("not", "and", "or", "bconst")
+
+
+class Node(object):
+    """One value of the expression graph (hash-consed per Graph: structurally equal nodes are the same object)."""
+    __slots__ = ("op", "args", "value", "uid", "is_bool")
+
+    def __repr__(self):
+        if self.op == "const":
+            return repr(self.value)
+        if self.op in ("P", "V", "C", "K", "U"):
+            return "%s%s" % (self.op, list(self.value))
+        return "%s(%s)" % (self.op, ", ".join(repr(a) for a in self.args))
+
+
+class Graph(object):
+    def __init__(self):
+        self.nodes = {}
+        self.count = 0
+
+    def node(self, op, args=(), value=None):
+        key = (op, tuple(a.uid for a in args), value)
+        n = self.nodes.get(key)
+        if n is None:
+            n = Node()
+            n.op, n.args, n.value, n.uid = op, tuple(args), value, self.count
+            n.is_bool = op in _BOOL_OPS or (op == "ite" and args[1].is_bool)
+            self.count += 1
+            self.nodes[key] = n
+        return n
+
+    def const(self, v):
+        if isinstance(v, (bool, np.bool_)):
+            return self.node("bconst", (), bool(v))
+        return self.node("const", (), float(v))
+
+    # ---- constructors with constant folding (fp64, as the reference computes) ------------------------------------------------
+    def unary(self, op, a):
+        if a.op == "const":
+            x = a.value
+            try:
+                v = {"neg": lambda: -x, "abs": lambda: abs(x), "sqrt": lambda: math.sqrt(x), "exp": lambda: math.exp(x),
+                     "log": lambda: math.log(x), "tanh": lambda: math.tanh(x)}[op]()
+            except (ValueError, OverflowError):
+                v = float("nan")
+            return self.const(v)
+        return self.node(op, (a,))
+
+    def binary(self, op, a, b):
+        if a.op == "const" and b.op == "const":
+            x, y = a.value, b.value
+            try:
+                v = {"add": lambda: x + y, "sub": lambda: x - y, "mul": lambda: x * y, "div": lambda: x / y,
+                     "min": lambda: min(x, y), "max": lambda: max(x, y)}[op]()
+            except ZeroDivisionError:
+                v = float("nan") if x == 0 else math.copysign(float("inf"), x)
+            return self.const(v)
+        if op == "sub" and a is b:         # an entity's offset to itself (simple_spread.py:78-81 counts the agent against itself)
+            return self.const(0.0)
+        return self.node(op, (a, b))
+
+    def compare(self, op, a, b):
+        if op == "gt":
+            op, a, b = "lt", b, a
+        elif op == "ge":
+            op, a, b = "le", b, a
+        if a.op == "const" and b.op == "const":
+            x, y = a.value, b.value
+            return self.const({"lt": x < y, "le": x <= y, "eq": x == y, "ne": x != y}[op])
+        return self.node(op, (a, b))
+
+    def lnot(self, a):
+        if a.op == "bconst":
+            return self.const(not a.value)
+        if a.op == "not":
+            return a.args[0]
+        return self.node("not", (a,))
+
+    def logical(self, op, a, b):
+        if a.op == "bconst":
+            return (b if a.value else a) if op == "and" else (a if a.value else b)
+        if b.op == "bconst":
+            return (a if b.value else b) if op == "and" else (b if b.value else a)
+        if a is b:
+            return a
+        return self.node(op, (a, b))
+
+    def ite(self, c, a, b):
+        if a is b:
+            return a
+        if c.op == "bconst":
+            return a if c.value else b
+        if a.is_bool != b.is_bool:
+            a, b = self.as_float(a), self.as_float(b)
+        if a.is_bool and a.op == "bconst" and b.op == "bconst":     # ite(c, True, False) is c
+            return c if a.value else self.lnot(c)
+        return self.node("ite", (c, a, b))
+
+    def as_float(self, a):
+        if not a.is_bool:
+            return a
+        if a.op == "bconst":
+            return self.const(1.0 if a.value else 0.0)
+        return self.node("ite", (a, self.const(1.0), self.const(0.0)))
+
+    def select(self, k, vals):
+        """vals[pick k]: a per-world pick selects one of len(vals) values."""
+        vals = list(vals)
+        if all(v is vals[0] for v in vals):
+            return vals[0]
+        if any(v.is_bool for v in vals):
+            vals = [self.as_float(v) for v in vals]
+        return self.node("sel", (k,) + tuple(vals))
+
+
+# ---- symbolic scalars: what a shadow world's state vectors hold while a callback is traced ----------------------------------
+class _Ctx(object):
+    graph = None
+    tracer = None
+    need_pick = None
+
+
+def _lift(x):
+    """anything a callback can combine with a Sym -> Node"""
+    if isinstance(x, Sym):
+        return x.n
+    if isinstance(x, SymBool):
+        return _Ctx.graph.as_float(x.n)
+    if isinstance(x, (bool, np.bool_)):
+        return _Ctx.graph.const(1.0 if x else 0.0)
+    if isinstance(x, (int, float, np.integer, np.floating)):
+        return _Ctx.graph.const(float(x))
+    if isinstance(x, np.ndarray) and x.ndim == 0:
+        return _lift(x.item())
+    raise TraceUnsupported("a symbolic value combined with %r" % type(x).__name__)
+
+
+class Sym(object):
+    """A real number that depends on the world's state."""
+    __slots__ = ("n",)
+
+    def __init__(self, n):
+        self.n = n
+
+    def _b(self, op, o, swap=False):
+        try:
+            a, b = self.n, _lift(o)
+        except TraceUnsupported:
+            return NotImplemented
+        return Sym(_Ctx.graph.binary(op, b, a) if swap else _Ctx.graph.binary(op, a, b))
+
+    def __add__(self, o): return self._b("add", o)
+    def __radd__(self, o): return self._b("add", o, True)
+    def __sub__(self, o): return self._b("sub", o)
+    def __rsub__(self, o): return self._b("sub", o, True)
+    def __mul__(self, o): return self._b("mul", o)
+    def __rmul__(self, o): return self._b("mul", o, True)
+    def __truediv__(self, o): return self._b("div", o)
+    def __rtruediv__(self, o): return self._b("div", o, True)
+    def __neg__(self): return Sym(_Ctx.graph.unary("neg", self.n))
+    def __pos__(self): return self
+    def __abs__(self): return Sym(_Ctx.graph.unary("abs", self.n))
+
+    def __pow__(self, o):
+        if isinstance(o, (int, float, np.integer, np.floating)):
+            if o == 2:
+                return self * self
+            if o == 1:
+                return self
+            if o == 0.5:
+                return self.sqrt()
+            if o == 3:
+                return self * self * self
+        raise TraceUnsupported("power with exponent %r" % (o,))
+
+    # the methods NumPy's object-dtype ufunc loops look for: np.sqrt(x) -> x.sqrt(), np.exp, np.log, np.tanh, np.square ...
+    def sqrt(self): return Sym(_Ctx.graph.unary("sqrt", self.n))
+    def exp(self): return Sym(_Ctx.graph.unary("exp", self.n))
+    def log(self): return Sym(_Ctx.graph.unary("log", self.n))
+    def tanh(self): return Sym(_Ctx.graph.unary("tanh", self.n))
+    def conjugate(self): return self
+
+    def _c(self, op, o):
+        try:
+            return SymBool(_Ctx.graph.compare(op, self.n, _lift(o)))
+        except TraceUnsupported:
+            return NotImplemented
+
+    def __lt__(self, o): return self._c("lt", o)
+    def __le__(self, o): return self._c("le", o)
+    def __gt__(self, o): return self._c("gt", o)
+    def __ge__(self, o): return self._c("ge", o)
+    def __eq__(self, o): return self._c("eq", o)
+    def __ne__(self, o): return self._c("ne", o)
+    __hash__ = object.__hash__
+
+    def __bool__(self):          # truth of a number: x != 0
+        return bool(SymBool(_Ctx.graph.compare("ne", self.n, _Ctx.graph.const(0.0))))
+
+    def __float__(self):
+        raise TraceUnsupported("a state-dependent value was converted to a Python float (float() / int() / formatting)")
+
+    __int__ = __index__ = __float__
+
+    def __repr__(self):
+        return "Sym(%r)" % (self.n,)
+
+
+class NeedConcretePick(Exception):
+    """A per-world pick is used where Python needs a concrete value (an array index, a branch of reset_world): the trace is
+    repeated once per value of that pick and the outcomes are merged by a selection on it."""
+
+    def __init__(self, k):
+        Exception.__init__(self, "pick %d" % k)
+        self.k = k
+
+
+class SymPickInt(Sym):
+    """An integer attribute of a randomly chosen object (`goal.index`): a number like any Sym; used as an INDEX it cannot stay
+    symbolic."""
+    __slots__ = ("k",)
+
+    def __init__(self, n, k):
+        Sym.__init__(self, n)
+        self.k = k
+
+    def __index__(self):
+        _Ctx.need_pick = self.k        # (NumPy turns whatever an __index__ raises into IndexError: the request travels beside it)
+        raise NeedConcretePick(self.k)
+
+    __int__ = __index__
+    __hash__ = object.__hash__
+
+    def _i(self, op, o, swap=False):
+        r = Sym._b(self, op, o, swap)
+        if r is not NotImplemented and isinstance(o, (int, np.integer)) and not isinstance(o, (bool, np.bool_)):
+            return SymPickInt(r.n, self.k)       # goal.index + 1 is still an integer of that pick
+        return r
+
+    def __add__(self, o): return self._i("add", o)
+    def __radd__(self, o): return self._i("add", o, True)
+    def __sub__(self, o): return self._i("sub", o)
+    def __rsub__(self, o): return self._i("sub", o, True)
+    def __mul__(self, o): return self._i("mul", o)
+    def __rmul__(self, o): return self._i("mul", o, True)
+
+
+class SymBool(object):
+    """A truth value that depends on the world's state.  Asking for its truth (`if`, `and`, `not`, bool()) FORKS the trace."""
+    __slots__ = ("n",)
+
+    def __init__(self, n):
+        self.n = n
+
+    def __bool__(self):
+        if self.n.op == "bconst":
+            return self.n.value
+        if _Ctx.tracer is None:
+            raise TraceUnsupported("a state-dependent condition outside a traced callback")
+        return _Ctx.tracer.decide(self.n)
+
+    def __invert__(self): return SymBool(_Ctx.graph.lnot(self.n))
+    def __and__(self, o): return SymBool(_Ctx.graph.logical("and", self.n, _blift(o)))
+    def __or__(self, o): return SymBool(_Ctx.graph.logical("or", self.n, _blift(o)))
+    __rand__, __ror__ = __and__, __or__
+
+    def __eq__(self, o):
+        if isinstance(o, (bool, np.bool_)):
+            return self if o else ~self
+        return NotImplemented
+
+    __hash__ = object.__hash__
+
+    # arithmetic on a truth value (`hits += touching(a, b)`): 1.0 / 0.0
+    def _f(self): return Sym(_Ctx.graph.as_float(self.n))
+    def __add__(self, o): return self._f() + o
+    def __radd__(self, o): return o + self._f()
+    def __sub__(self, o): return self._f() - o
+    def __rsub__(self, o): return o - self._f()
+    def __mul__(self, o): return self._f() * o
+    def __rmul__(self, o): return o * self._f()
+
+    def __repr__(self):
+        return "SymBool(%r)" % (self.n,)
+
+
+def _blift(x):
+    if isinstance(x, SymBool):
+        return x.n
+    if isinstance(x, (bool, np.bool_)):
+        return _Ctx.graph.const(bool(x))
+    raise TraceUnsupported("a symbolic condition combined with %r" % type(x).__name__)
+
+
+def sym_min(*args, **kw):
+    """`min` as the traced file sees it (injected into the module's globals): a MIN node instead of one fork per comparison."""
+    return _minmax("min", min, args, kw)
+
+
+def sym_max(*args, **kw):
+    return _minmax("max", max, args, kw)
+
+
+def _minmax(op, builtin, args, kw):
+    if kw:
+        return builtin(*args, **kw)
+    items = list(args[0]) if len(args) == 1 else list(args)
+    if not any(isinstance(x, (Sym, SymBool)) for x in items):
+        return builtin(items)
+    acc = _lift(items[0])
+    for x in items[1:]:
+        acc = _Ctx.graph.binary(op, acc, _lift(x))     # min(a, b) of Python: a if a <= b ... the same value for numbers
+    return Sym(acc)
+
+
+def sym_any(it):
+    items = list(it)
+    if not any(isinstance(x, SymBool) for x in items):
+        return any(items)
+    acc = _Ctx.graph.const(False)
+    for x in items:
+        acc = _Ctx.graph.logical("or", acc, _blift(x) if isinstance(x, (SymBool, bool, np.bool_)) else SymBool(_lift(x)).n)
+    return SymBool(acc)
+
+
+def sym_all(it):
+    items = list(it)
+    if not any(isinstance(x, SymBool) for x in items):
+        return all(items)
+    acc = _Ctx.graph.const(True)
+    for x in items:
+        acc = _Ctx.graph.logical("and", acc, _blift(x))
+    return SymBool(acc)
+
+
+_INJECTED = {"min": sym_min, "max": sym_max, "any": sym_any, "all": sym_all}
+
+
+# ---- control flow: every path of a callback, merged -------------------------------------------------------------------------
+class Tracer(object):
+    """Runs a callback once per control-flow path.  `decide` answers a symbolic condition: by the forced prefix while it
+    lasts, then True; the conditions met and the answers given are the path.  `explore` flips the answers depth-first and
+    merges the outcomes into select nodes."""
+
+    def __init__(self, graph, max_paths=None):
+        self.g = graph
+        self.max_paths = MAX_PATHS if max_paths is None else max_paths
+        self.paths = 0
+
+    def decide(self, n):
+        neg = False
+        if n.op == "not":
+            n, neg = n.args[0], True
+        d = self.memo.get(n)
+        if d is None:
+            d = self.prefix[len(self.decs)] if len(self.decs) < len(self.prefix) else True
+            self.conds.append(n)
+            self.decs.append(d)
+            self.memo[n] = d
+        return (not d) if neg else d
+
+    def _run(self, fn, prefix):
+        self.paths += 1
+        if self.paths > self.max_paths:
+            raise TraceUnsupported("more than %d control-flow paths in one callback (a symbolic `if` per entity in a large team?)"
+                                   % self.max_paths)
+        self.prefix, self.conds, self.decs, self.memo = prefix, [], [], {}
+        keep, _Ctx.tracer = _Ctx.tracer, self
+        try:
+            out = fn()
+        finally:
+            _Ctx.tracer = keep
+        if self.decs[:len(prefix)] != prefix:
+            raise TraceUnsupported("the callback is not deterministic (a re-run took another path)")
+        return out, self.conds, self.decs
+
+    def explore(self, fn, normalise):
+        """-> the merged outcome: `normalise(raw)` turns one path's return value into a list of Nodes (same length on every
+        path)."""
+        def build(prefix):
+            raw, conds, decs = self._run(fn, prefix)
+            res = normalise(raw)
+            for d in range(len(conds) - 1, len(prefix) - 1, -1):
+                other = build(decs[:d] + [False])
+                if len(other) != len(res):
+                    raise TraceUnsupported("the callback returns %d values on one path and %d on another" % (len(res), len(other)))
+                res = [self.g.ite(conds[d], a, b) for a, b in zip(res, other)]
+            return res
+        return build([])
+
+
+# ---- np.random while reset_world is traced (or replayed concretely) ---------------------------------------------------------
+class PickProxy(object):
+    """What `np.random.choice(objects)` returns while reset_world is traced: every attribute is the selection, by the pick, of
+    that attribute over the population; an assignment lands on whichever object the pick names."""
+
+    def __init__(self, k_node, population):
+        object.__setattr__(self, "_k", k_node)
+        object.__setattr__(self, "_pop", list(population))
+
+    def __getattr__(self, name):
+        k, pop = object.__getattribute__(self, "_k"), object.__getattribute__(self, "_pop")
+        try:
+            vals = [getattr(o, name) for o in pop]
+        except AttributeError:
+            raise TraceUnsupported("attribute %r of a randomly chosen object: not every candidate has it" % name)
+        return _select_values(k, vals, name)
+
+    def __setattr__(self, name, value):
+        k, pop = object.__getattribute__(self, "_k"), object.__getattribute__(self, "_pop")
+        g = _Ctx.graph
+        for i, o in enumerate(pop):
+            if not hasattr(o, name) or getattr(o, name) is None:
+                raise TraceUnsupported("assignment to attribute %r of a randomly chosen object whose candidates do not all have a "
+                                       "value for it yet" % name)
+            old = getattr(o, name)
+            hit = g.compare("eq", k, g.const(float(i)))
+            new_a, old_a = np.asarray(value, dtype=object), np.asarray(old, dtype=object)
+            if new_a.shape != old_a.shape:
+                raise TraceUnsupported("assignment to attribute %r of a randomly chosen object changes its shape" % name)
+            flat = [Sym(g.ite(hit, _lift(a), _lift(b))) for a, b in zip(new_a.reshape(-1), old_a.reshape(-1))]
+            merged = np.empty(len(flat), dtype=object)
+            merged[:] = flat
+            setattr(o, name, merged.reshape(old_a.shape) if old_a.ndim else flat[0])
+
+
+def _select_values(k, vals, name):
+    g = _Ctx.graph
+    if all(v is vals[0] for v in vals):
+        return vals[0]
+    if all(isinstance(v, (int, bool, np.integer, np.bool_)) for v in vals):
+        return SymPickInt(g.select(k, [_lift(v) for v in vals]), k.value[0])
+    if all(isinstance(v, (int, float, bool, np.integer, np.floating, np.bool_, Sym)) for v in vals):
+        return Sym(g.select(k, [_lift(v) for v in vals]))
+    if all(isinstance(v, np.ndarray) for v in vals):
+        if len(set(v.shape for v in vals)) != 1:
+            raise TraceUnsupported("attribute %r of a randomly chosen object has different shapes" % name)
+        out = np.empty(vals[0].size, dtype=object)
+        out[:] = [Sym(g.select(k, [_lift(v.reshape(-1)[j]) for v in vals])) for j in range(vals[0].size)]
+        return out.reshape(vals[0].shape)
+    if all(v is None for v in vals):
+        return None
+    if any(isinstance(v, (np.ndarray, int, float, Sym, str)) or v is None for v in vals):
+        raise TraceUnsupported("attribute %r of a randomly chosen object mixes kinds of values" % name)
+    return PickProxy(k, vals)          # objects (entity.state ...): select further down
+
+
+class _Recorder(object):
+    """np.random for a traced reset_world: uniform draws become U inputs, choices become picks."""
+
+    def __init__(self, graph, forced=None):
+        self.g = graph
+        self.forced = dict(forced or {})      # pick number -> the value it has in THIS trace (see NeedConcretePick)
+        self.draws = []           # ("uniform", lo, hi, n) | ("choice", population size)  in call order: the file's random stream
+        self.n_u = 0
+        self.pops = []
+
+    def uniform(self, low=0.0, high=1.0, size=None):
+        if isinstance(low, (Sym, np.ndarray)) or isinstance(high, (Sym, np.ndarray)):
+            raise TraceUnsupported("np.random.uniform with array / state-dependent bounds")
+        n = 1 if size is None else int(np.prod(size))
+        lo, hi = float(low), float(high)
+        self.draws.append(("uniform", lo, hi, n))
+        vals = []
+        for _ in range(n):
+            u = self.g.node("U", (), (self.n_u,))
+            self.n_u += 1
+            # NumPy: low + (high - low) * random_sample()
+            vals.append(Sym(self.g.binary("add", self.g.const(lo), self.g.binary("mul", self.g.const(hi - lo), u))))
+        if size is None:
+            return vals[0]
+        out = np.empty(n, dtype=object)
+        out[:] = vals
+        return out.reshape(size)
+
+    def choice(self, a, size=None, replace=True, p=None):
+        if size is not None or p is not None:
+            raise TraceUnsupported("np.random.choice with size / p")
+        pop = list(range(a)) if isinstance(a, (int, np.integer)) else list(a)
+        if len(pop) == 0:
+            raise TraceUnsupported("np.random.choice of an empty population")
+        idx = len(self.pops)
+        k = self.g.node("K", (), (idx,))
+        self.pops.append(len(pop))
+        self.draws.append(("choice", len(pop)))
+        if idx in self.forced:
+            return pop[self.forced[idx]]
+        if all(isinstance(v, (int, np.integer)) for v in pop):
+            return SymPickInt(self.g.select(k, [self.g.const(float(v)) for v in pop]), idx)
+        if all(isinstance(v, (int, float, np.integer, np.floating)) for v in pop):
+            return Sym(self.g.select(k, [self.g.const(float(v)) for v in pop]))
+        return PickProxy(k, pop)
+
+    def randint(self, low, high=None, size=None, dtype=int):
+        if size is not None:
+            raise TraceUnsupported("np.random.randint with size")
+        lo, hi = (0, low) if high is None else (low, high)
+        return self.choice(list(range(int(lo), int(hi))))
+
+    def _unsupported(self, name):
+        def f(*a, **k):
+            raise TraceUnsupported("np.random.%s in reset_world" % name)
+        return f
+
+
+class _Replayer(object):
+    """np.random for a CONCRETE run of reset_world with prescribed outcomes (the verification of a trace, and seeded resets)."""
+
+    def __init__(self, uniforms, picks):
+        self.u, self.k = list(uniforms), list(picks)
+        self.iu = self.ik = 0
+
+    def uniform(self, low=0.0, high=1.0, size=None):
+        n = 1 if size is None else int(np.prod(size))
+        r = np.array(self.u[self.iu:self.iu + n], np.float64)
+        self.iu += n
+        v = low + (high - low) * r
+        return float(v[0]) if size is None else v.reshape(size)
+
+    def choice(self, a, size=None, replace=True, p=None):
+        pop = list(range(a)) if isinstance(a, (int, np.integer)) else list(a)
+        i = int(self.k[self.ik])
+        self.ik += 1
+        return pop[i]
+
+    def randint(self, low, high=None, size=None, dtype=int):
+        lo, hi = (0, low) if high is None else (low, high)
+        return self.choice(list(range(int(lo), int(hi))))
+
+
+_RANDOM_NAMES = ("uniform", "choice", "randint")
+_RANDOM_REFUSED = ("rand", "randn", "random", "random_sample", "normal", "shuffle", "permutation", "sample", "standard_normal",
+                   "exponential", "beta", "gamma", "seed", "binomial", "poisson")
+
+
+@contextlib.contextmanager
+def patched_random(impl):
+    """np.random.{uniform, choice, randint} answered by `impl` (a _Recorder / _Replayer); everything else that draws raises."""
+    saved = {}
+    for name in _RANDOM_NAMES + _RANDOM_REFUSED:
+        if hasattr(np.random, name):
+            saved[name] = getattr(np.random, name)
+    try:
+        for name in _RANDOM_NAMES:
+            setattr(np.random, name, getattr(impl, name))
+        for name in _RANDOM_REFUSED:
+            if name in saved:
+                def refuse(*a, _n=name, **k):
+                    raise TraceUnsupported("np.random.%s in a traced callback" % _n)
+                setattr(np.random, name, refuse)
+        yield
+    finally:
+        for name, f in saved.items():
+            setattr(np.random, name, f)
+
+
+@contextlib.contextmanager
+def injected_builtins(scenario):
+    """min / max / any / all as the file's module sees them while it is traced (one node instead of a fork per comparison)."""
+    import types
+    pkg = __name__.rsplit(".", 1)[0]
+    spaces = []          # the global namespaces the scenario's methods (and its base classes') resolve names in
+    for klass in type(scenario).__mro__:
+        if klass.__module__ == "builtins" or klass.__module__.startswith(pkg + "."):
+            continue
+        for f in klass.__dict__.values():
+            f = getattr(f, "__func__", f)
+            if isinstance(f, types.FunctionType) and not any(f.__globals__ is d for d in spaces):
+                spaces.append(f.__globals__)
+    saved = [(d, name, d.get(name, _MISSING)) for d in spaces for name in _INJECTED]
+    try:
+        for d in spaces:
+            d.update(_INJECTED)
+        yield
+    finally:
+        for d, name, old in saved:
+            if old is _MISSING:
+                d.pop(name, None)
+            else:
+                d[name] = old
+
+
+_MISSING = object()
+
+
+# ---- the trace of one scenario ----------------------------------------------------------------------------------------------
+def _obj_vec(nodes):
+    out = np.empty(len(nodes), dtype=object)
+    out[:] = [Sym(n) for n in nodes]
+    return out
+
+
+def _flatten(raw):
+    """One path's return value of `observation` -> list of Nodes."""
+    if raw is None:
+        raise TraceUnsupported("observation returned None")
+    arr = np.asarray(raw, dtype=object).reshape(-1) if not isinstance(raw, (Sym, SymBool)) else [raw]
+    return [_lift(x) for x in arr]
+
+
+def _scalar(raw):
+    if isinstance(raw, np.ndarray):
+        if raw.size != 1:
+            raise TraceUnsupported("reward returned an array of %d values" % raw.size)
+        raw = raw.reshape(-1)[0]
+    if raw is None:
+        raise TraceUnsupported("reward returned None")
+    return [_lift(raw)]
+
+
+def _truth(raw):
+    if isinstance(raw, SymBool):
+        return [raw.n]
+    if isinstance(raw, (bool, np.bool_)):
+        return [_Ctx.graph.const(bool(raw))]
+    if isinstance(raw, Sym):
+        return [_Ctx.graph.compare("ne", raw.n, _Ctx.graph.const(0.0))]
+    if isinstance(raw, (int, float, np.integer, np.floating)):
+        return [_Ctx.graph.const(bool(raw))]
+    raise TraceUnsupported("done returned %r" % type(raw).__name__)
+
+
+class Traced(object):
+    """What tracing a reference-style scenario yields: per-agent graphs over the state + the reset program.
+
+      obs[i]        list of Nodes: agent i's observation row, column by column
+      rew[i]        Node: agent i's reward
+      done[i]       Node (bool) or None
+      reset_pos     [E][2] Nodes over U (uniform draws in [0,1)) and K (picks): reset_world's positions
+      reset_vel     [E][2] Nodes;  reset_c: [A][dim_c] Nodes
+      draws         reset_world's random stream, in call order: ("uniform", lo, hi, n) | ("choice", n)
+      pops          population size of every pick
+    """
+
+    def __init__(self):
+        self.graph = Graph()
+
+
+def _entity_lists(world):
+    return list(world.agents), list(world.agents) + list(world.landmarks)
+
+
+def _trace_once(scenario, t, forced, want_done, max_paths):
+    """One pass: make_world, reset_world with np.random recorded (picks in `forced` take their given value), the callbacks over
+    the symbolic state.  -> dict of node lists."""
+    g = t.graph
+    world = scenario.make_world()            # (make_world ends with a concrete reset_world: the reference's own contract)
+    agents, ents = _entity_lists(world)
+    A, E, dp, dc = len(agents), len(ents), int(world.dim_p), int(world.dim_c)
+    if dp != 2:
+        raise TraceUnsupported("dim_p = %d" % dp)
+    if any(a.action_callback is not None for a in agents):
+        raise TraceUnsupported("scripted agents (action_callback)")
+    if any(l.movable for l in world.landmarks):
+        raise TraceUnsupported("movable landmarks")
+    if any(a.u_noise or (a.c_noise and not a.silent) for a in agents):
+        raise TraceUnsupported("action / communication noise")
+    t.world, t.A, t.E, t.dim_c = world, A, E, dc
+    # ---- reset_world, symbolically ------------------------------------------------------------------------------------------
+    rec = _Recorder(g, forced)
+    with patched_random(rec), injected_builtins(scenario):
+        _, conds, _ = Tracer(g, 1)._run(lambda: scenario.reset_world(world), [])
+    if conds:      # reset_world branches on what it drew: on a pick -> one trace per value of that pick; on anything else: not modelled
+        ks = sorted(n.value[0] for n in topo(conds[:1]) if n.op == "K")
+        if ks and "U" not in inputs_of(conds[:1]):
+            raise NeedConcretePick(ks[0])
+        raise TraceUnsupported("reset_world branches on a random number it drew")
+    out = {"draws": rec.draws, "pops": rec.pops, "n_u": rec.n_u}
+
+    def vec(v, n, what):
+        if v is None:
+            raise TraceUnsupported("%s is None after reset_world" % what)
+        a = np.asarray(v, dtype=object).reshape(-1)
+        if a.size != n:
+            raise TraceUnsupported("%s has %d components, expected %d" % (what, a.size, n))
+        return [_lift(x) for x in a]
+    out["reset_pos"] = [x for k, e in enumerate(ents) for x in vec(e.state.p_pos, 2, "p_pos of %s" % (e.name or "entity %d" % k))]
+    out["reset_vel"] = [x for e in ents for x in (vec(e.state.p_vel, 2, "p_vel") if e.state.p_vel is not None else [g.const(0.0)] * 2)]
+    out["reset_c"] = [x for a in agents for x in (vec(a.state.c, dc, "state.c") if (dc and a.state.c is not None) else [g.const(0.0)] * dc)]
+    # ---- the state as inputs -------------------------------------------------------------------------------------------------
+    for k, e in enumerate(ents):
+        e.state.p_pos = _obj_vec([g.node("P", (), (k, 0)), g.node("P", (), (k, 1))])
+        if k < A and e.movable:
+            e.state.p_vel = _obj_vec([g.node("V", (), (k, 0)), g.node("V", (), (k, 1))])
+        else:
+            e.state.p_vel = np.zeros(2)          # (never integrated: core.py:160)
+    for i, a in enumerate(agents):
+        # core.py:171-177: a silent agent's utterance is zeros; a speaking one's is its last communication action
+        a.state.c = np.zeros(dc) if (a.silent or dc == 0) else _obj_vec([g.node("C", (), (i, c)) for c in range(dc)])
+        a.action.u = None
+        a.action.c = None
+    # ---- the callbacks, every path -------------------------------------------------------------------------------------------
+    out["obs"], out["rew"], out["done"] = [], [], []
+    paths = {"obs": [], "rew": [], "done": []}
+    with patched_random(_Recorder(g)._refusing()), injected_builtins(scenario):
+        for a in agents:
+            tr = Tracer(g, max_paths)
+            out["obs"].append(tr.explore(lambda: scenario.observation(a, world), _flatten))
+            paths["obs"].append(tr.paths)
+            tr = Tracer(g, max_paths)
+            out["rew"].append(tr.explore(lambda: scenario.reward(a, world), _scalar))
+            paths["rew"].append(tr.paths)
+            if want_done and hasattr(scenario, "done"):
+                tr = Tracer(g, max_paths)
+                out["done"].append(tr.explore(lambda: scenario.done(a, world), _truth))
+                paths["done"].append(tr.paths)
+            else:
+                out["done"].append([])
+    out["paths"] = paths
+    out["collaborative"] = bool(getattr(world, "collaborative", False))
+    return out
+
+
+_MAX_ENUMERATED = 64      # traces per scenario when picks have to be enumerated (product of their population sizes)
+
+
+def trace(scenario, want_done=False, max_paths=None):
+    """Trace `scenario` (a reference-style Scenario object: make_world(self), reset_world(self, world), NumPy callbacks).
+    Raises TraceUnsupported when the file is outside what the tracer models."""
+    import itertools
+    t = Traced()
+    g = t.graph
+    keep_g, _Ctx.graph = _Ctx.graph, g
+    rng_state = np.random.get_state()
+    try:
+        enumerated, pops = [], None
+        while True:
+            _Ctx.need_pick = None
+            try:
+                combos = list(itertools.product(*[range(pops[k]) for k in enumerated])) if enumerated else [()]
+                runs = {c: _trace_once(scenario, t, dict(zip(enumerated, c)), want_done, max_paths) for c in combos}
+                break
+            except Exception as e:
+                if not isinstance(e, NeedConcretePick) and _Ctx.need_pick is None:
+                    raise
+                need = e.k if isinstance(e, NeedConcretePick) else _Ctx.need_pick
+                _Ctx.need_pick = None
+                e = NeedConcretePick(need)
+                if e.k in enumerated:
+                    raise TraceUnsupported("pick %d is needed concretely although it is fixed" % e.k)
+                if pops is None:
+                    pops = _pick_populations(scenario, g)
+                enumerated.append(e.k)
+                n = 1
+                for k in enumerated:
+                    n *= pops[k]
+                if n > _MAX_ENUMERATED:
+                    raise TraceUnsupported("picks %s are used as concrete values: %d traces" % (enumerated, n))
+        first = runs[combos[0]]
+        for r in runs.values():
+            if r["draws"] != first["draws"] or [len(o) for o in r["obs"]] != [len(o) for o in first["obs"]]:
+                raise TraceUnsupported("reset_world's random stream (or a row width) depends on a pick")
+
+        def merged(key, sub=None):
+            """select over the enumerated picks, innermost = last enumerated"""
+            def rec(prefix, depth):
+                if depth == len(enumerated):
+                    r = runs[tuple(prefix)][key]
+                    return r if sub is None else r[sub]
+                k = enumerated[depth]
+                branches = [rec(prefix + [v], depth + 1) for v in range(pops[k])]
+                kn = g.node("K", (), (k,))
+                return [g.select(kn, [b[j] for b in branches]) for j in range(len(branches[0]))]
+            return rec([], 0)
+        t.draws, t.pops, t.n_u = first["draws"], first["pops"], first["n_u"]
+        A, E, dc = t.A, t.E, t.dim_c
+        flat = merged("reset_pos")
+        t.reset_pos = [flat[2 * e:2 * e + 2] for e in range(E)]
+        flat = merged("reset_vel")
+        t.reset_vel = [flat[2 * e:2 * e + 2] for e in range(E)]
+        flat = merged("reset_c")
+        t.reset_c = [flat[dc * i:dc * i + dc] for i in range(A)]
+        t.obs = [merged("obs", i) for i in range(A)]
+        t.rew = [merged("rew", i)[0] for i in range(A)]
+        t.done = [(merged("done", i)[0] if first["done"][i] else None) for i in range(A)]
+        t.paths = first["paths"]
+        t.enumerated = list(enumerated)
+        t.collaborative = first["collaborative"]
+        for what, roots in (("observation", [n for row in t.obs for n in row]), ("reward", t.rew), ("done", [d for d in t.done if d is not None])):
+            if "U" in inputs_of(roots):
+                raise TraceUnsupported("%s depends on a random number reset_world drew and did not store in the state" % what)
+        return t
+    except TraceUnsupported:
+        raise
+    except Exception as e:       # the file did something a symbolic value cannot do: that is a reason to fall back, not a crash
+        raise TraceUnsupported("%s: %s" % (type(e).__name__, e))
+    finally:
+        _Ctx.graph = keep_g
+        np.random.set_state(rng_state)
+
+
+def _pick_populations(scenario, g):
+    """Population size of every np.random.choice of reset_world, found by a pass in which every pick is answered concretely."""
+    class _Sizes(_Recorder):
+        def choice(self, a, size=None, replace=True, p=None):
+            pop = list(range(a)) if isinstance(a, (int, np.integer)) else list(a)
+            self.pops.append(len(pop))
+            return pop[0]
+    rec = _Sizes(g)
+    with patched_random(rec):
+        world = scenario.make_world()
+        rec.pops = []
+        scenario.reset_world(world)
+    return list(rec.pops)
+
+
+def _refusing(self):
+    """A recorder that refuses every draw (callbacks other than reset_world must not draw)."""
+    def refuse(*a, **k):
+        raise TraceUnsupported("a callback other than reset_world draws random numbers")
+    r = _Recorder(self.g)
+    r.uniform = r.choice = r.randint = refuse
+    return r
+
+
+_Recorder._refusing = _refusing
+
+
+def topo(roots):
+    """Nodes reachable from `roots`, arguments before users (trace order where it matters: uid order is creation order)."""
+    seen, order, stack = set(), [], [(r, False) for r in reversed(list(roots))]
+    while stack:
+        n, done = stack.pop()
+        if done:
+            order.append(n)
+            continue
+        if n.uid in seen:
+            continue
+        seen.add(n.uid)
+        stack.append((n, True))
+        for a in reversed(n.args):
+            if a.uid not in seen:
+                stack.append((a, False))
+    return order
+
+
+def inputs_of(roots):
+    return set(n.op for n in topo(roots) if n.op in ("P", "V", "C", "K", "U"))
+
+
+# ---- evaluation with NumPy (fp64 by default), vectorised over worlds: the verification, the CPU tests, host-side resets ------
+def evaluate(roots, B, P=None, V=None, Cw=None, K=None, U=None, dtype=np.float64):
+    """Values of `roots` for B worlds: P [B, E, 2], V [B, E, 2], Cw [B, A, dim_c], K [B, n_picks] (ints), U [B, n_draws]."""
+    val = {}
+    one = np.ones(B, dtype)
+    with np.errstate(all="ignore"):
+        for n in topo(roots):
+            a = [val[x.uid] for x in n.args]
+            op = n.op
+            if op == "const":
+                v = one * dtype(n.value)
+            elif op == "bconst":
+                v = np.full(B, n.value, bool)
+            elif op == "P":
+                v = P[:, n.value[0], n.value[1]].astype(dtype)
+            elif op == "V":
+                v = V[:, n.value[0], n.value[1]].astype(dtype)
+            elif op == "C":
+                v = Cw[:, n.value[0], n.value[1]].astype(dtype)
+            elif op == "K":
+                v = K[:, n.value[0]].astype(dtype)
+            elif op == "U":
+                v = U[:, n.value[0]].astype(dtype)
+            elif op == "add":
+                v = a[0] + a[1]
+            elif op == "sub":
+                v = a[0] - a[1]
+            elif op == "mul":
+                v = a[0] * a[1]
+            elif op == "div":
+                v = a[0] / a[1]
+            elif op == "min":
+                v = np.where(a[1] < a[0], a[1], a[0])      # Python's min(a, b): b only if b < a
+            elif op == "max":
+                v = np.where(a[1] > a[0], a[1], a[0])
+            elif op == "neg":
+                v = -a[0]
+            elif op == "abs":
+                v = np.abs(a[0])
+            elif op == "sqrt":
+                v = np.sqrt(a[0])
+            elif op == "exp":
+                v = np.exp(a[0])
+            elif op == "log":
+                v = np.log(a[0])
+            elif op == "tanh":
+                v = np.tanh(a[0])
+            elif op == "lt":
+                v = a[0] < a[1]
+            elif op == "le":
+                v = a[0] <= a[1]
+            elif op == "eq":
+                v = a[0] == a[1]
+            elif op == "ne":
+                v = a[0] != a[1]
+            elif op == "not":
+                v = ~a[0]
+            elif op == "and":
+                v = a[0] & a[1]
+            elif op == "or":
+                v = a[0] | a[1]
+            elif op == "ite":
+                v = np.where(a[0], a[1], a[2])
+            elif op == "sel":
+                k = a[0].astype(np.int64)
+                v = np.choose(np.clip(k, 0, len(a) - 2), a[1:])
+            else:
+                raise ValueError("node %r" % op)
+            val[n.uid] = v
+    return [val[r.uid] for r in roots]
+
+
+# ---- verification: the graphs against the file's own callbacks, run concretely -------------------------------------------------
+def _concrete_reset(scenario, world, u, k):
+    with patched_random(_Replayer(u, k)):
+        scenario.reset_world(world)
+
+
+def random_states(t, R, rs, spread=1.0):
+    """R random worlds' post-step states: clustered enough that contacts, overlaps and arena exits all occur."""
+    scale = rs.choice([0.15, 0.4, 1.0, 1.3], size=(R, 1, 1)) * spread
+    P = rs.uniform(-1.0, 1.0, (R, t.E, 2)) * scale
+    V = rs.uniform(-1.3, 1.3, (R, t.E, 2))
+    V[:, t.A:] = 0.0
+    Cw = np.zeros((R, t.A, max(t.dim_c, 1)))
+    if t.dim_c:
+        words = rs.randint(0, t.dim_c + 1, (R, t.A))           # == dim_c: says nothing (zeros)
+        for c in range(t.dim_c):
+            Cw[:, :, c] = (words == c) * rs.choice([1.0, 0.5], size=(R, t.A))
+    return P, V, Cw[:, :, :t.dim_c] if t.dim_c else Cw[:, :, :0]
+
+
+def verify(scenario, t, worlds=96, seed=0, tol=1e-9):
+    """Evaluate the trace with NumPy (fp64) on `worlds` random worlds and compare with the file's own reset_world / observation /
+    reward / done run concretely on the same worlds.  Returns the largest scaled difference; raises TraceUnsupported when the
+    trace does not reproduce the file (hidden state, randomness, something the tracer mis-models)."""
+    rs = np.random.RandomState(seed)
+    R = int(worlds)
+    rng_state = np.random.get_state()
+    try:
+        cw = scenario.make_world()
+    finally:
+        np.random.set_state(rng_state)
+    agents, ents = _entity_lists(cw)
+    U = rs.uniform(0.0, 1.0, (R, max(t.n_u, 1)))
+    K = np.stack([rs.randint(0, n, R) for n in t.pops], axis=1) if t.pops else np.zeros((R, 0), np.int64)
+    P, V, Cw = random_states(t, R, rs)
+    worst = 0.0
+
+    def cmp(what, got, want):
+        nonlocal worst
+        got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+        both_nan = np.isnan(got) & np.isnan(want)
+        err = np.where(both_nan, 0.0, np.abs(got - want) / np.maximum(1.0, np.abs(want)))
+        if not np.all(err <= tol):
+            raise TraceUnsupported("the trace does not reproduce the file's %s (scaled difference %.3e): hidden state, randomness, "
+                                   "or an operation the tracer does not model" % (what, float(np.nanmax(err))))
+        worst = max(worst, float(err.max()) if err.size else 0.0)
+    flat_pos = [n for e in t.reset_pos for n in e]
+    flat_vel = [n for e in t.reset_vel for n in e]
+    flat_c = [n for a in t.reset_c for n in a]
+    rp = np.stack(evaluate(flat_pos, R, K=K, U=U), axis=1).reshape(R, t.E, 2)
+    rv = np.stack(evaluate(flat_vel, R, K=K, U=U), axis=1).reshape(R, t.E, 2)
+    rc = np.stack(evaluate(flat_c, R, K=K, U=U), axis=1).reshape(R, t.A, t.dim_c) if flat_c else np.zeros((R, t.A, 0))
+    roots = [n for row in t.obs for n in row] + list(t.rew) + [d for d in t.done if d is not None]
+    vals = evaluate(roots, R, P=P, V=V, Cw=Cw, K=K, U=U)
+    widths = [len(row) for row in t.obs]
+    off = np.cumsum([0] + widths)
+    obs_eval = [np.stack(vals[off[i]:off[i + 1]], axis=1) if widths[i] else np.zeros((R, 0)) for i in range(t.A)]
+    rew_eval = vals[off[-1]:off[-1] + t.A]
+    done_eval, q = [], off[-1] + t.A
+    for d in t.done:
+        done_eval.append(vals[q] if d is not None else None)
+        q += d is not None
+    for r in range(R):
+        _concrete_reset(scenario, cw, U[r], K[r])
+        cmp("reset_world positions", [e.state.p_pos for e in ents], rp[r])
+        cmp("reset_world velocities", [np.zeros(2) if e.state.p_vel is None else e.state.p_vel for e in ents], rv[r])
+        if t.dim_c:
+            cmp("reset_world utterances", [np.zeros(t.dim_c) if a.state.c is None else a.state.c for a in agents], rc[r])
+        for k, e in enumerate(ents):
+            e.state.p_pos = P[r, k].copy()
+            e.state.p_vel = V[r, k].copy()
+        for i, a in enumerate(agents):
+            a.state.c = np.zeros(t.dim_c) if a.silent else Cw[r, i].copy()
+        for i, a in enumerate(agents):
+            o = np.asarray(scenario.observation(a, cw), np.float64).reshape(-1)
+            if o.shape[0] != widths[i]:
+                raise TraceUnsupported("observation of agent %d has %d columns concretely, %d traced" % (i, o.shape[0], widths[i]))
+            cmp("observation (agent %d)" % i, o, obs_eval[i][r])
+            cmp("reward (agent %d)" % i, float(scenario.reward(a, cw)), rew_eval[i][r])
+            if t.done[i] is not None:
+                if bool(scenario.done(a, cw)) != bool(done_eval[i][r]):
+                    raise TraceUnsupported("the trace does not reproduce the file's done (agent %d)" % i)
+    return worst
