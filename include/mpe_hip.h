@@ -40,7 +40,8 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 3 /* layout of the two structs below + meaning of existing entry points; new entry points are additive */
+#define MPE_ABI_VERSION 4 /* layout of the structs below + meaning of existing entry points; new entry points are additive
+                             (4: MpeRowProgram.traced) */
 #define MPE_MAX_ENTITIES 512 /* agents + landmarks per world */
 #define MPE_ACTION_DIM 5     /* Discrete(dim_p*2+1), environment.py:45 */
 #define MPE_MAX_CHOICES 4    /* np.random.choice draws a reset_world makes before the positions */
@@ -284,7 +285,17 @@ enum MpeRowOp {
   MPE_ROW_R_ABS_POS = 52,       /* v = |p[a0][a1]|  (coordinate a1 of entity a0)                          */
   MPE_ROW_R_DONE_IF_GT = 53,    /* done = done or v > w2                                                  */
   MPE_ROW_R_DONE_IF_LT = 54,    /* done = done or v < w2                                                  */
-  MPE_ROW_R_DONE_IF_HIT = 55    /* done = done or |p[a0] - p[a1]| < size[a0] + size[a1] (strict, exact)   */
+  MPE_ROW_R_DONE_IF_HIT = 55,   /* done = done or |p[a0] - p[a1]| < size[a0] + size[a1] (strict, exact)   */
+  /* ---- TRACED code (a program compiled in only, prog->traced = 1): the op calls a device function that the caller appended
+   * to the generated header of mpe_rows_static_source -- `mpe::traced_obs(i, row, P, V, W, K)` writes the w1 columns of agent i's
+   * row, `mpe::traced_rew(i, P, V, W, K)` / `traced_done` return its reward / done -- where P(e, c) / V(e, c) read the staged
+   * post-step position / velocity of entity e, W(j, c) agent j's utterance, K(k) the per-world pick k.  This is how an unmodified
+   * reference-style Scenario file (multiagent/scenario.py:4-10: NumPy callbacks) runs in the step launch: its callbacks traced
+   * into expression graphs (multiagent_particle_envs_amd/symtrace.py), one statement per arithmetic step.  w2 / w3 carry a hash
+   * of the appended source (it is part of the program's identity: image name, cache key).                                   */
+  MPE_ROW_OBS_CODE = 16,        /* observation program: w1 columns written by traced_obs (agent = the program's)           */
+  MPE_ROW_R_CODE = 56,          /* reward program: acc0 = traced_rew                                                       */
+  MPE_ROW_R_DONE_CODE = 57      /* done program: done = done or traced_done                                                */
 };
 /* Host POD describing one env's programs; the ops live in DEVICE memory the caller owns (uploaded once).               */
 #define MPE_ROWS_HEADER_BYTES 4096 /* >= the kernel-side header (row layout, program ranges, per-entity constants) */
@@ -305,6 +316,9 @@ typedef struct MpeRowProgram {
   void *image;                /* NULL, or what mpe_rows_load_image attached: the program compiled in (owned by the library)       */
   int32_t done_begin[MPE_ROWS_MAX_ENTITIES + 1]; /* agent i's done ops: [done_begin[i], done_begin[i+1]) -- value ops and DONE_IF_*
                                                     tests, run after its reward program on a fresh machine; all zero: no done programs */
+  int32_t traced;             /* 1: the program contains *_CODE ops -- it runs compiled in ONLY (an entry point called without a
+                                 matching image returns MPE_EUNSUPPORTED instead of interpreting); 0 otherwise                  */
+  int32_t pad_;
 } MpeRowProgram;
 /* Checks a program against the descriptor (entity / pick / slot indices, row widths == obs_off): ops_host are the same
  * n_ops x 4 words in HOST memory.  0 or MPE_EINVAL with mpe_last_error() naming the op.                               */
@@ -363,7 +377,9 @@ int mpe_rollout_rows_episode(const MpeScenarioDesc *desc, const MpeBuffers *bufs
  * life of an env the same kernel source can be compiled WITH the program as constants (every op code, entity index, column
  * and per-entity constant a literal): the interpreter folds into straight-line code in the same arithmetic order -- results
  * bit-identical to the interpreted launch, at about the cost of a hand-fused kernel.  Three steps, each plain C:
- *   1. mpe_rows_static_source writes a generated header (a few #defines: name, dims, tables, ops) into `buf`;
+ *   1. mpe_rows_static_source writes a generated header (a few #defines: name, dims, tables, ops) into `buf`
+ *      (a traced program: the caller appends `#define MPE_ROWS_TRACED 1`, `#include "mpe_internal.h"` and its
+ *      mpe::traced_obs / traced_rew / traced_done templates -- symtrace.hip_source writes exactly that);
  *   2. the caller compiles csrc/mpe_rows.hip with it:  hipcc --genco --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off
  *      -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=14 -include <header> -I include -I csrc mpe_rows.hip -o prog.hsaco
  *      (multiagent_particle_envs_amd/_build.py: compile_rows_image does exactly this and caches by content);

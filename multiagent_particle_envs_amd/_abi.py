@@ -6,7 +6,7 @@ library handle (`lib()`), and every compute entry point needs device pointers.
 import ctypes as C
 import os
 
-MPE_ABI_VERSION = 3
+MPE_ABI_VERSION = 4
 MPE_MAX_ENTITIES = 512
 MPE_ACTION_DIM = 5
 MPE_SCN_GENERIC, MPE_SCN_SIMPLE, MPE_SCN_SPREAD, MPE_SCN_TAG, MPE_SCN_ADVERSARY, MPE_SCN_PUSH = 0, 1, 2, 3, 4, 5
@@ -22,6 +22,7 @@ MPE_ROWS_HEADER_BYTES = 4096
 (MPE_ROW_OBS_REL_RANGE, MPE_ROW_OBS_VEL_RANGE, MPE_ROW_OBS_REL_VIS_RANGE, MPE_ROW_OBS_VEL_VIS_RANGE, MPE_ROW_OBS_CONST_N) = range(11, 16)
 MPE_ROW_R_MIN_D2_RANGE, MPE_ROW_R_MIN_D2_TO_RANGE, MPE_ROW_R_ADD_IF_HIT_GRID, MPE_ROW_R_ADD_MIN_DIST_GRID = 48, 49, 50, 51
 MPE_ROW_R_ABS_POS, MPE_ROW_R_DONE_IF_GT, MPE_ROW_R_DONE_IF_LT, MPE_ROW_R_DONE_IF_HIT = 52, 53, 54, 55
+MPE_ROW_OBS_CODE, MPE_ROW_R_CODE, MPE_ROW_R_DONE_CODE = 16, 56, 57      # traced code (symtrace.py): compiled-in programs only
 (MPE_ROW_R_D2, MPE_ROW_R_MIN_D2, MPE_ROW_R_D2_PICK, MPE_ROW_R_MIN_D2_PICK, MPE_ROW_R_SQRT, MPE_ROW_R_BOUND, MPE_ROW_R_COMM_ERR,
  MPE_ROW_R_COMM_SUM, MPE_ROW_R_CONST, MPE_ROW_R_SAVE, MPE_ROW_R_LOAD, MPE_ROW_R_ZERO, MPE_ROW_R_ADD, MPE_ROW_R_ADD_IF_HIT,
  MPE_ROW_R_ADD_ACC, MPE_ROW_R_STORE) = range(32, 48)
@@ -59,7 +60,7 @@ class MpeRowProgram(C.Structure):
         ("ops_device", C.c_void_p), ("header_device", C.c_void_p), ("header_hash", C.c_uint64), ("n_ops", C.c_int32), ("obs_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)),
         ("rew_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)), ("n_vel", C.c_int32), ("n_regions", C.c_int32),
         ("region_entity", C.c_int32 * 2), ("all_seeing", C.c_uint32), ("image", C.c_void_p),
-        ("done_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)),
+        ("done_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)), ("traced", C.c_int32), ("pad_", C.c_int32),
     ]
 
 

@@ -512,6 +512,7 @@ int mpe_rows_validate(const MpeScenarioDesc *d, const MpeRowProgram *p, const in
   if (p->n_ops > 0 && !ops) return fail(MPE_EINVAL, "%s: ops_host is NULL", what);
   const int A = d->n_agents, E = A + d->n_landmarks;
   auto ent = [&](int a, bool self_ok) { return (self_ok && a == MPE_ROW_SELF) || (a >= 0 && a < E); };
+  bool code_ops = false;
   for (int i = 0; i < A; ++i) {
     int width = 0;
     for (int pc = p->obs_begin[i]; pc < p->obs_begin[i + 1]; ++pc) {
@@ -551,6 +552,11 @@ int mpe_rows_validate(const MpeScenarioDesc *d, const MpeRowProgram *p, const in
         case MPE_ROW_OBS_IN_REGION:
           if (!ent(a0, true) || a1 >= p->n_regions) return fail(MPE_EINVAL, "%s: op %d (agent %d): region %d of %d", what, pc, i, a1, p->n_regions);
           width += 1;
+          break;
+        case MPE_ROW_OBS_CODE:
+          if (w1 < 0 || w1 > 4096) return fail(MPE_EINVAL, "%s: op %d (agent %d): traced code writing %d columns", what, pc, i, w1);
+          width += w1;
+          code_ops = true;
           break;
         default: return fail(MPE_EINVAL, "%s: op %d (agent %d): code %d is not an observation op", what, pc, i, code);
       }
@@ -612,12 +618,23 @@ int mpe_rows_validate(const MpeScenarioDesc *d, const MpeRowProgram *p, const in
           break;
         }
         case MPE_ROW_R_SQRT: case MPE_ROW_R_CONST: case MPE_ROW_R_ZERO: case MPE_ROW_R_ADD: case MPE_ROW_R_ADD_ACC: break;
+        case MPE_ROW_R_CODE:
+          if (pass) return fail(MPE_EINVAL, "%s: done op %d (agent %d): R_CODE belongs to reward programs", what, pc, i);
+          code_ops = true;
+          break;
+        case MPE_ROW_R_DONE_CODE:
+          if (!pass) return fail(MPE_EINVAL, "%s: reward op %d (agent %d): R_DONE_CODE belongs to the done program", what, pc, i);
+          code_ops = true;
+          break;
         default: return fail(MPE_EINVAL, "%s: op %d: code %d is not a reward op", what, pc, code);
       }
     }
     if (!pass && p->rew_begin[i + 1] > p->rew_begin[i] && !stored)
       return fail(MPE_EINVAL, "%s: agent %d's reward program has no STORE", what, i);
   }
+  if (code_ops != (p->traced != 0))
+    return fail(MPE_EINVAL, "%s: prog->traced = %d but the program %s *_CODE ops (a traced program runs compiled in only and says so)",
+                what, p->traced, code_ops ? "contains" : "has no");
   return 0;
 }
 
@@ -689,6 +706,9 @@ static int rows_call(const char *what, bool phys, const MpeScenarioDesc *d, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (image_matches(p, h, hash))      // the program compiled in, and still the descriptor it was compiled for
     return hip_result(mpe::launch_rows_image(static_cast<RowImage *>(p->image)->fns, *b, h, tabs, phys, vec4 ? 1 : 0, ep, (size_t)B, s, roll), what);
+  if (p->traced)      // *_CODE ops exist as code of the image only: nothing to interpret
+    return fail(MPE_EUNSUPPORTED, "%s: a traced program runs compiled in only -- no image is attached, or the descriptor is not the "
+                "one it was compiled for (mpe_rows_static_source + the traced source -> hipcc --genco -> mpe_rows_load_image)", what);
   if (hash != p->header_hash) {
     if (int rc = mpe::launch_rows_header(tabs, p->header_device, s)) return hip_result(rc, what);
     p->header_hash = hash;

@@ -73,7 +73,8 @@ enum {
   ROW_R_SQRT = MPE_ROW_R_SQRT, ROW_R_BOUND = MPE_ROW_R_BOUND, ROW_R_COMM_ERR = MPE_ROW_R_COMM_ERR, ROW_R_COMM_SUM = MPE_ROW_R_COMM_SUM,
   ROW_R_CONST = MPE_ROW_R_CONST, ROW_R_SAVE = MPE_ROW_R_SAVE, ROW_R_LOAD = MPE_ROW_R_LOAD, ROW_R_ZERO = MPE_ROW_R_ZERO,
   ROW_R_ADD = MPE_ROW_R_ADD, ROW_R_ADD_IF_HIT = MPE_ROW_R_ADD_IF_HIT, ROW_R_ADD_ACC = MPE_ROW_R_ADD_ACC, ROW_R_STORE = MPE_ROW_R_STORE,
-  ROW_R_ABS_POS = MPE_ROW_R_ABS_POS, ROW_R_DONE_IF_GT = MPE_ROW_R_DONE_IF_GT, ROW_R_DONE_IF_LT = MPE_ROW_R_DONE_IF_LT, ROW_R_DONE_IF_HIT = MPE_ROW_R_DONE_IF_HIT
+  ROW_R_ABS_POS = MPE_ROW_R_ABS_POS, ROW_R_DONE_IF_GT = MPE_ROW_R_DONE_IF_GT, ROW_R_DONE_IF_LT = MPE_ROW_R_DONE_IF_LT, ROW_R_DONE_IF_HIT = MPE_ROW_R_DONE_IF_HIT,
+  ROW_OBS_CODE = MPE_ROW_OBS_CODE, ROW_R_CODE = MPE_ROW_R_CODE, ROW_R_DONE_CODE = MPE_ROW_R_DONE_CODE
 };
 // Scalars of a program: kernel arguments (one batch of scalar loads at wave start).
 struct RowDims {

@@ -516,6 +516,10 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
             col += a1;
             break;
           }
+#ifdef MPE_ROWS_TRACED
+          // a reference-style file's observation(agent, world), traced (symtrace.py): straight-line code over the staged state
+          case ROW_OBS_CODE: traced_obs(i, row + col, P, V, word, pick); col += uni(op.y); break;
+#endif
           default: break;
         }
       };
@@ -622,6 +626,10 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
           case ROW_R_DONE_IF_HIT:
             dn = dn || sqrt_lt(sq2d(P(a0, 0) - P(a1, 0), P(a0, 1) - P(a1, 1)), TF(MPE_TAB(size), a0) + TF(MPE_TAB(size), a1));
             break;
+#ifdef MPE_ROWS_TRACED
+          case ROW_R_CODE: acc[0] = traced_rew(i, P, V, word, pick); break;
+          case ROW_R_DONE_CODE: dn = dn || traced_done(i, P, V, word, pick); break;
+#endif
           // ---- range forms ---------------------------------------------------------------------------------------------------
           case ROW_R_MIN_D2_RANGE:        // min over agents a0 .. a0 + n - 1 of |a - p[a1]|^2, first to last
             v = min_d2_run(a0, uni(op.y), P(a1, 0), P(a1, 1), false);

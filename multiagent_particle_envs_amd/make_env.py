@@ -9,16 +9,19 @@
                                                              # new: done at the horizon + device-side auto-reset
 
     env = make_env('/path/to/my_scenario.py')                # a REFERENCE-STYLE scenario file, unmodified (`from multiagent.core
-    env = make_env('/path/to/my_scenario.py', batch_size=256)  # import World ...`, make_world(self), NumPy callbacks): the file's
-                                                             # callbacks run per world on the host over the device physics
-                                                             # (refstyle.py: the compatibility / migration path, slow by construction)
+    env = make_env('/path/to/my_scenario.py', batch_size=65536)  # import World ...`, make_world(self), NumPy callbacks): batched,
+                                                             # the file's callbacks are TRACED into a compiled row program
+                                                             # (symtrace.py: one launch per step; env.traced) -- or, where a file
+                                                             # is outside what the tracer models / traced=False / one world, run
+                                                             # per world on the host over the device physics (refstyle.py)
 
 Everything on the step path runs in libmpe_hip.so on a HIP device; there is no CPU fallback.
 """
 
 
 def make_env(scenario_name, benchmark=False, batch_size=None, device=None, seed=0, fresh_outputs=False,
-             fused=None, max_episode_steps=None, auto_reset=False, probe_placement=True, compile_program=None, **scenario_kwargs):
+             fused=None, max_episode_steps=None, auto_reset=False, probe_placement=True, compile_program=None, traced=None,
+             **scenario_kwargs):
     from .environment import MultiAgentEnv
     from . import scenarios
 
@@ -30,7 +33,8 @@ def make_env(scenario_name, benchmark=False, batch_size=None, device=None, seed=
             raise TypeError("a reference-style scenario takes no scenario kwargs and has no fused kernel (got %r, fused=%r)"
                             % (sorted(scenario_kwargs), fused))
         return refstyle.make_ref_env(scenario, benchmark=benchmark, batch_size=batch_size, device=device, seed=seed,
-                                     max_episode_steps=max_episode_steps, auto_reset=auto_reset)
+                                     max_episode_steps=max_episode_steps, auto_reset=auto_reset, traced=traced,
+                                     fresh_outputs=fresh_outputs)
     compat = batch_size is None
     world = scenario.make_world(batch_size=1 if compat else int(batch_size), device=device, **scenario_kwargs)
     world.seed = seed

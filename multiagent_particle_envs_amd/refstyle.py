@@ -247,6 +247,168 @@ class RefScenarioAdapter(object):
         return _stack_info(vals, self)
 
 
+# ---- the fast path: the file's callbacks traced into a compiled row program (symtrace.py) ----------------------------------
+def _mirror_entity(src, dst, is_agent):
+    dst.name = src.name
+    dst.size, dst.movable, dst.collide = float(src.size), bool(src.movable), bool(src.collide)
+    dst.max_speed, dst.accel, dst.initial_mass = src.max_speed, src.accel, float(src.mass)
+    dst.density, dst.color = getattr(src, "density", 25.0), None
+    if is_agent:
+        dst.silent, dst.blind = bool(src.silent), bool(getattr(src, "blind", False))
+        dst.u_noise, dst.c_noise, dst.u_range = src.u_noise, src.c_noise, getattr(src, "u_range", 1.0)
+    return dst
+
+
+class TracedRefScenario(object):
+    """A reference-style Scenario presented to MultiAgentEnv as a row-program scenario of this package's protocol: its
+    `observation` / `reward` (/ `done`) were traced into expression graphs (symtrace.trace), verified against the file's own
+    callbacks, and are compiled into the step kernel as straight-line code -- `env.step` is ONE launch, no host callbacks, no
+    per-world Python objects.  `reset_world` is the traced reset: drawn on the device where it is the uniform placement of
+    `World.reset_uniform` (all nine reference files), else evaluated with NumPy for all worlds at once and uploaded;
+    `reset(seeds=...)` replays the file's own random stream per world (the reference's `np.random.seed(s); env.reset()`)."""
+    kind = None
+    reference_style = True
+    traced_style = True
+
+    def __init__(self, scenario, traced):
+        self.scenario, self.t = scenario, traced
+        self.landmark_range, self.device_reset = self._uniform_pattern()
+        self._source = None
+
+    # ---- reset_world ------------------------------------------------------------------------------------------------------
+    def _uniform_pattern(self):
+        """(landmark_range, True) when the traced reset_world is `World.reset_uniform`'s placement: every agent uniform on
+        [-1, 1)^2, every landmark on [-r, r)^2 with one r, from draws of their own; zero velocities and utterances."""
+        t = self.t
+        used, r_lm = set(), None
+        for e in range(t.E):
+            for c in range(2):
+                n = t.reset_pos[e][c]
+                # lo + (hi - lo) * U
+                if not (n.op == "add" and n.args[0].op == "const" and n.args[1].op == "mul" and n.args[1].args[0].op == "const" and
+                        n.args[1].args[1].op == "U"):
+                    return 1.0, False
+                lo, span, u = n.args[0].value, n.args[1].args[0].value, n.args[1].args[1].value[0]
+                if u in used or lo >= 0 or abs(span + 2 * lo) > 1e-12 * abs(lo):
+                    return 1.0, False
+                used.add(u)
+                r = -lo
+                if e < t.A:
+                    if r != 1.0:
+                        return 1.0, False
+                elif r_lm is None:
+                    r_lm = r
+                elif r != r_lm:
+                    return 1.0, False
+        zeros = all(n.op == "const" and n.value == 0.0 for v in t.reset_vel for n in v) and \
+            all(n.op == "const" and n.value == 0.0 for v in t.reset_c for n in v)
+        return (1.0 if r_lm is None else float(r_lm)), bool(zeros)
+
+    def make_world(self, batch_size=1, device=None):
+        t, w0 = self.t, self.t.world
+        world = World(batch_size, device)
+        for k in _WORLD_KEYS:
+            setattr(world, k, getattr(w0, k))
+        world.collaborative = bool(t.collaborative)
+        if hasattr(w0, "discrete_action"):
+            world.discrete_action = w0.discrete_action
+        world.choice_pops = list(t.pops)
+        world.agents = [_mirror_entity(a, Agent(), True) for a in w0.agents]
+        world.landmarks = [_mirror_entity(l, Landmark(), False) for l in w0.landmarks]
+        world.allocate()
+        return world
+
+    def _merge_picks(self, world, idx, mask):
+        if world.choice_i32 is None or not self.t.pops:
+            return
+        for k in range(len(self.t.pops)):
+            world.choice_i32[k].copy_(World.merge_choice(world.choice_i32[k].long(), idx[:, k].to(world.device), mask).to(torch.int32))
+
+    def reset_world(self, world, mask=None, seeds=None):
+        t, B = self.t, world.batch_size
+        if seeds is None and self.device_reset and world.rng_mode == "device":
+            idx = world.reset_uniform(self.landmark_range, mask, choices=list(t.pops))
+            self._merge_picks(world, idx, mask)
+            return
+        # the traced reset program evaluated for all worlds at once (fp64), then one upload
+        m = None if mask is None else torch.as_tensor(mask).cpu().numpy().astype(bool).reshape(-1)
+        U = np.zeros((B, max(t.n_u, 1)))
+        K = np.zeros((B, len(t.pops)), np.int64)
+        if seeds is not None:      # the file's own random stream per world: np.random.seed(s); reset_world(world)
+            assert len(seeds) == B
+            for b in range(B):
+                if m is not None and not m[b]:
+                    continue
+                rs, iu, ik = np.random.RandomState(int(seeds[b])), 0, 0
+                for d in t.draws:
+                    if d[0] == "uniform":
+                        U[b, iu:iu + d[3]] = rs.random_sample(d[3])       # uniform(lo, hi, n) = lo + (hi - lo) * random_sample(n)
+                        iu += d[3]
+                    else:
+                        K[b, ik] = rs.randint(0, d[1])                    # == np.random.choice(list of n) (same stream)
+                        ik += 1
+        else:
+            if world.rng_mode == "numpy":
+                rs = np.random
+            else:
+                rs = np.random.RandomState([int(world.seed) & 0x7FFFFFFF, int(world._episode) & 0x7FFFFFFF, int(world.world_offset) & 0x7FFFFFFF])
+                world._episode += 1
+            U = rs.random_sample(U.shape)
+            for k, n in enumerate(t.pops):
+                K[:, k] = rs.randint(0, n, B)
+        from . import symtrace
+        flat = [n for e in t.reset_pos for n in e] + [n for e in t.reset_vel for n in e]
+        vals = symtrace.evaluate(flat, B, K=K, U=U)
+        pos = np.stack(vals[:2 * t.E], axis=1).reshape(B, t.E, 2)
+        vel = np.stack(vals[2 * t.E:], axis=1).reshape(B, t.E, 2)
+        if m is not None:
+            old_p, old_v = world.get_state(all_entities=True)
+            pos = np.where(m[:, None, None], pos, old_p)
+            vel = np.where(m[:, None, None], vel, old_v)
+        world.set_state(pos, vel)
+        self._merge_picks(world, torch.as_tensor(K), mask)
+
+    # ---- the row program ------------------------------------------------------------------------------------------------------
+    def row_source(self, world):
+        if self._source is None:
+            from . import symtrace
+            self._source = symtrace.hip_source(self.t)
+        return self._source
+
+    def _hash(self, world):
+        import hashlib
+        return int.from_bytes(hashlib.sha256(self.row_source(world).encode()).digest()[:8], "little")
+
+    def obs_spec(self, agent, world):
+        from . import rowspec
+        i = world.agents.index(agent)
+        return rowspec.ObsSpec(world, agent).code(len(self.t.obs[i]), self._hash(world))
+
+    def reward_spec(self, agent, world):
+        from . import rowspec
+        return rowspec.RewardSpec(world, agent).code(self._hash(world))
+
+    def done_spec(self, agent, world):
+        from . import rowspec
+        i = world.agents.index(agent)
+        if self.t.done[i] is None:
+            return None
+        return rowspec.DoneSpec(world, agent).code(self._hash(world))
+
+
+def trace_ref_scenario(scenario, want_done=False, verify_worlds=64):
+    """symtrace.trace + symtrace.verify -> TracedRefScenario; raises symtrace.TraceUnsupported (with the reason) when the
+    file is outside what the tracer models or the trace does not reproduce the file's own callbacks."""
+    from . import symtrace
+    t = symtrace.trace(scenario, want_done=want_done)
+    if len(t.pops) > _abi.MPE_MAX_CHOICES:
+        raise symtrace.TraceUnsupported("reset_world makes %d np.random.choice draws (at most %d per-world picks)" % (len(t.pops), _abi.MPE_MAX_CHOICES))
+    if t.E > _abi.MPE_ROWS_MAX_ENTITIES:
+        raise symtrace.TraceUnsupported("%d entities (row programs cover %d)" % (t.E, _abi.MPE_ROWS_MAX_ENTITIES))
+    t.verified = symtrace.verify(scenario, t, worlds=verify_worlds)
+    return TracedRefScenario(scenario, t)
+
+
 def _is_num(x):
     return isinstance(x, (int, float, bool, np.integer, np.floating, np.bool_)) or (isinstance(x, np.ndarray) and x.ndim == 0)
 
@@ -262,11 +424,39 @@ def _stack_info(vals, ad):
 
 
 def make_ref_env(scenario, benchmark=False, batch_size=None, device=None, seed=0, max_episode_steps=None, auto_reset=False,
-                 done_callback=False):
+                 done_callback=False, traced=None, fresh_outputs=False, verbose=False):
     """make_env for a reference-style Scenario object (make_env.py:36-43): one world with NumPy in / NumPy out when
-    `batch_size` is None -- the reference's own use, np.random stream included --, B worlds with [B, .] tensors otherwise."""
+    `batch_size` is None -- the reference's own use, np.random stream included --, B worlds with [B, .] tensors otherwise.
+
+    traced (batched envs on a HIP device): None -- trace the file's callbacks into a compiled row program when that works
+    (one launch per step; `env.traced` says whether, `env.trace_fallback` why not), else the host path; True -- trace or
+    raise; False -- always the host path (B shadow worlds, the file's callbacks per world)."""
     from .environment import MultiAgentEnv
     compat = batch_size is None
+    why = None
+    if traced is not False and not compat and not benchmark:
+        from . import symtrace
+        try:
+            want_done = bool(done_callback) and hasattr(scenario, "done")
+            ts = trace_ref_scenario(scenario, want_done=want_done)
+            world = ts.make_world(int(batch_size), device)
+            if not world.pos.is_cuda:
+                raise symtrace.TraceUnsupported("traced programs run compiled in on a HIP device (this world is on %s)" % world.device)
+            world.seed = seed
+            world.rng_mode = "device"
+            ts.reset_world(world)
+            env = MultiAgentEnv(world, ts.reset_world, None, None, None, None, fresh_outputs=fresh_outputs, fused=True,
+                                max_episode_steps=max_episode_steps, auto_reset=auto_reset, compile_program=True)
+            env.scenario, env.ref_scenario, env.traced, env.trace_fallback = ts, scenario, True, None
+            return env
+        except (symtrace.TraceUnsupported, _abi.MpeError, RuntimeError) as e:
+            if traced:
+                raise
+            why = "%s: %s" % (type(e).__name__, e)
+            if verbose:
+                print("reference-style scenario on the host path (%s)" % why)
+    elif traced:
+        raise _abi.MpeError("traced=True needs batch_size (a batched env) and benchmark=False")
     ad = RefScenarioAdapter(scenario, 1 if compat else int(batch_size), device, host_outputs=compat)
     world = ad.world
     world.seed = seed
@@ -280,4 +470,5 @@ def make_ref_env(scenario, benchmark=False, batch_size=None, device=None, seed=0
     env.scenario = ad
     env.ref_scenario = scenario
     env.ref_worlds = ad.shadows          # the file's own world objects, one per world, kept current after every step / reset
+    env.traced, env.trace_fallback = False, why
     return env

@@ -49,6 +49,12 @@ def _f2i(x):
     return struct.unpack("<i", struct.pack("<f", float(x)))[0]
 
 
+def _code_op(code, w1, source_hash):
+    h = int(source_hash) & (2 ** 64 - 1)
+    lo, hi = h & 0xFFFFFFFF, h >> 32
+    return (int(code), int(w1), lo - (1 << 32) if lo >= 1 << 31 else lo, hi - (1 << 32) if hi >= 1 << 31 else hi)
+
+
 def _op(code, a0=0, a1=0, a2=0, w1=0, f0=0.0, f1=0.0):
     for v in (code, a0, a1, a2):
         if not 0 <= int(v) <= 255:
@@ -143,6 +149,12 @@ class ObsSpec(_Spec):
     def vel_visible(self, agent):
         return self._emit(_op(_abi.MPE_ROW_OBS_VEL_VIS, self._a(agent)), 2)
 
+    def code(self, width, source_hash):
+        """`width` columns written by traced device code (symtrace.py: a reference-style file's observation callback as
+        straight-line code appended to the compiled program; `source_hash`: 64 bits of that source, part of the program's
+        identity).  Programs with code ops run compiled in only."""
+        return self._emit(_code_op(_abi.MPE_ROW_OBS_CODE, int(width), source_hash), int(width))
+
     def in_region(self, region, ent=None):
         """+1 / -1: is the entity (default: the observer) inside region number `region` -- 1 column."""
         return self._emit(_op(_abi.MPE_ROW_OBS_IN_REGION, self._e(ent, True), int(region)), 1)
@@ -232,6 +244,15 @@ class RewardSpec(_Spec):
         return self
 
 
+def _reward_code(self, source_hash):
+    """acc0 = the traced reward (symtrace.py); see ObsSpec.code"""
+    self.ops.append(_code_op(_abi.MPE_ROW_R_CODE, 0, source_hash))
+    return self
+
+
+RewardSpec.code = _reward_code
+
+
 class DoneSpec(RewardSpec):
     """One agent's done condition (the reference's `done_callback(agent, world)`, environment.py:132-135) as tests on the
     reward machine's value register: the value methods of RewardSpec (dist, min_dist, dist2_pick, abs_pos ...) followed by
@@ -249,6 +270,11 @@ class DoneSpec(RewardSpec):
 
     def done_if_lt(self, threshold):
         self.ops.append(_op(_abi.MPE_ROW_R_DONE_IF_LT, f0=float(threshold)))
+        return self
+
+    def code(self, source_hash):
+        """done = done or the traced done callback (symtrace.py)"""
+        self.ops.append(_code_op(_abi.MPE_ROW_R_DONE_CODE, 0, source_hash))
         return self
 
     def done_if_touching(self, a, b):
@@ -400,10 +426,12 @@ def fuse_reward(ops):
 class RowProgram(object):
     """The compiled programs of one env: ops on the device + the MpeRowProgram header the C ABI takes."""
 
-    def __init__(self, world, obs_specs, reward_specs, regions=None, fuse=None, done_specs=None):
+    def __init__(self, world, obs_specs, reward_specs, regions=None, fuse=None, done_specs=None, source=None):
         """fuse: run the peephole pass (runs of per-entity ops -> range forms); False keeps one op per spec call (the A/B);
-        None: the module's FUSE switch.  done_specs: one DoneSpec (or None: never done) per agent."""
+        None: the module's FUSE switch.  done_specs: one DoneSpec (or None: never done) per agent.  source: the device
+        functions the program's code ops call (symtrace.hip_source), appended to the generated header of the compiled form."""
         fuse = FUSE if fuse is None else fuse
+        self.source = source
         A = len(world.agents)
         if len(world.entities) > _abi.MPE_ROWS_MAX_ENTITIES:
             raise _abi.MpeError("row programs cover at most %d entities" % _abi.MPE_ROWS_MAX_ENTITIES)
@@ -458,6 +486,11 @@ class RowProgram(object):
         for a in regions.all_seeing:
             mask |= 1 << (a if isinstance(a, int) else next(k for k, e in enumerate(world.agents) if e is a))
         p.all_seeing = mask
+        codes = (_abi.MPE_ROW_OBS_CODE, _abi.MPE_ROW_R_CODE, _abi.MPE_ROW_R_DONE_CODE)
+        p.traced = 1 if any((op[0] & 0xFF) in codes for op in ops) else 0
+        if p.traced and not source:
+            raise _abi.MpeError("a program with code ops needs the source of the functions they call")
+        self.traced = bool(p.traced)
         self.struct = p
         self.ref = C.byref(p)
 
@@ -472,7 +505,7 @@ class RowProgram(object):
         _abi.check(L.mpe_rows_static_source(C.byref(desc), self.ref, self.ops_host, None, 0, C.byref(need)), "mpe_rows_static_source")
         buf = C.create_string_buffer(need.value)
         _abi.check(L.mpe_rows_static_source(C.byref(desc), self.ref, self.ops_host, buf, need.value, None), "mpe_rows_static_source")
-        return buf.value.decode()
+        return buf.value.decode() + (self.source or "")
 
     def compile(self, desc, verbose=False, cached_only=False):
         """Compile the program in for THIS descriptor (hipcc --genco, cached by content under lib/rows_cache/) and attach it:
@@ -515,7 +548,8 @@ def compile_scenario(scenario, world):
     rg = scenario.regions(world) if hasattr(scenario, "regions") else None
     dsf = getattr(scenario, "done_spec", None)
     done = [dsf(a, world) for a in world.agents] if dsf is not None else None
-    return RowProgram(world, obs, rew, rg, done_specs=done)
+    src = scenario.row_source(world) if hasattr(scenario, "row_source") else None
+    return RowProgram(world, obs, rew, rg, done_specs=done, source=src)
 
 
 # built-in scenarios whose callbacks are written for any team size: where no fused kernel exists for a shape, the env runs

@@ -1035,3 +1035,132 @@ def verify(scenario, t, worlds=96, seed=0, tol=1e-9):
                 if bool(scenario.done(a, cw)) != bool(done_eval[i][r]):
                     raise TraceUnsupported("the trace does not reproduce the file's done (agent %d)" % i)
     return worst
+
+
+# ---- device code: one statement per node, in trace order ------------------------------------------------------------------------
+def _f32_literal(v):
+    v = float(np.float32(v))
+    if v != v:
+        return "__builtin_nanf(\"\")"
+    if v in (float("inf"), float("-inf")):
+        return ("-" if v < 0 else "") + "__builtin_inff()"
+    return "%sf" % float(v).hex()          # C++17 hexadecimal floating literal: the fp32 value, exactly
+
+
+def _emit(roots, lines, names):
+    """Append statements computing `roots` to `lines`; `names`: uid -> expression (variable name or literal) so far."""
+    def ref(n):
+        return names[n.uid]
+    for n in topo(roots):
+        if n.uid in names:
+            continue
+        op, a = n.op, n.args
+        var = ("b%d" if n.is_bool else "t%d") % n.uid
+        if op == "const":
+            names[n.uid] = _f32_literal(n.value)
+            continue
+        if op == "bconst":
+            names[n.uid] = "true" if n.value else "false"
+            continue
+        if op == "P":
+            e = "P(%d, %d)" % n.value
+        elif op == "V":
+            e = "V(%d, %d)" % n.value
+        elif op == "C":
+            e = "W(%d, %d)" % n.value
+        elif op == "K":
+            lines.append("      const int k%d = K(%d);" % (n.uid, n.value[0]))
+            e = "(float)k%d" % n.uid
+        elif op == "U":
+            raise TraceUnsupported("a uniform draw in device code")
+        elif op in ("add", "sub", "mul", "div"):
+            e = "%s %s %s" % (ref(a[0]), {"add": "+", "sub": "-", "mul": "*", "div": "/"}[op], ref(a[1]))
+        elif op == "min":
+            e = "(%s < %s ? %s : %s)" % (ref(a[1]), ref(a[0]), ref(a[1]), ref(a[0]))        # Python's min(a, b): b only if b < a
+        elif op == "max":
+            e = "(%s > %s ? %s : %s)" % (ref(a[1]), ref(a[0]), ref(a[1]), ref(a[0]))
+        elif op == "neg":
+            e = "-%s" % ref(a[0])
+        elif op == "abs":
+            e = "fabsf(%s)" % ref(a[0])
+        elif op == "sqrt":
+            e = "fast_sqrt(%s)" % ref(a[0])
+        elif op == "exp":
+            e = "__builtin_amdgcn_exp2f(%s * 1.44269504088896341f)" % ref(a[0])
+        elif op == "log":
+            e = "(__builtin_amdgcn_logf(%s) * 0.693147180559945309f)" % ref(a[0])
+        elif op == "tanh":
+            e = "tanhf(%s)" % ref(a[0])
+        elif op in ("lt", "le"):
+            # `np.sqrt(np.sum(np.square(d))) < r`, the reference's contact test (simple_tag.py:69-73): decided as NumPy's float32
+            # rounding sequence would (sqrt_lt: exact, without the correctly rounded sqrt outside a 1e-6 band around r)
+            if op == "lt" and a[0].op == "sqrt":
+                e = "sqrt_lt(%s, %s)" % (ref(a[0].args[0]), ref(a[1]))
+            elif a[0].op == "sqrt" or a[1].op == "sqrt":
+                l = "sqrtf(%s)" % ref(a[0].args[0]) if a[0].op == "sqrt" else ref(a[0])
+                r = "sqrtf(%s)" % ref(a[1].args[0]) if a[1].op == "sqrt" else ref(a[1])
+                e = "%s %s %s" % (l, "<" if op == "lt" else "<=", r)
+            else:
+                e = "%s %s %s" % (ref(a[0]), "<" if op == "lt" else "<=", ref(a[1]))
+        elif op in ("eq", "ne"):
+            e = "%s %s %s" % (ref(a[0]), "==" if op == "eq" else "!=", ref(a[1]))
+        elif op == "not":
+            e = "!%s" % ref(a[0])
+        elif op in ("and", "or"):
+            e = "%s %s %s" % (ref(a[0]), "&&" if op == "and" else "||", ref(a[1]))
+        elif op == "ite":
+            e = "%s ? %s : %s" % (ref(a[0]), ref(a[1]), ref(a[2]))
+        elif op == "sel":
+            kn = a[0]
+            kv = "k%d" % kn.uid if kn.op == "K" else "(int)%s" % ref(kn)
+            e = ref(a[-1])
+            for j in range(len(a) - 2, 0, -1):
+                e = "%s == %d ? %s : (%s)" % (kv, j - 1, ref(a[j]), e)
+        else:
+            raise TraceUnsupported("no device code for node %r" % op)
+        lines.append("      const %s %s = %s;" % ("bool" if n.is_bool else "float", var, e))
+        names[n.uid] = var
+    return [names[r.uid] for r in roots]
+
+
+def hip_source(t):
+    """The device functions of a trace: what is appended to the generated header of the compiled row program (the kernel calls
+    them through the ops MPE_ROW_OBS_CODE / R_CODE / R_DONE_CODE).  P, V, W, K are the kernel's accessors of the staged state."""
+    out = ["", "// ---- traced callbacks (symtrace.py): one statement per arithmetic step of the file's NumPy code, in its order ----",
+           "#define MPE_ROWS_TRACED 1", '#include "mpe_internal.h"', "namespace mpe {", "namespace {",
+           "template <class FP, class FV, class FW, class FK>",
+           "__device__ __forceinline__ void traced_obs(const int i, float *const row, const FP &P, const FV &V, const FW &W, const FK &K) {",
+           "  switch (i) {"]
+    for i, row in enumerate(t.obs):
+        lines, names = [], {}
+        vals = _emit(row, lines, names)
+        out.append("    case %d: {" % i)
+        out += lines
+        out += ["      row[%d] = %s;" % (j, v) for j, v in enumerate(vals)]
+        out.append("    } break;")
+    out += ["    default: break;", "  }", "}",
+            "template <class FP, class FV, class FW, class FK>",
+            "__device__ __forceinline__ float traced_rew(const int i, const FP &P, const FV &V, const FW &W, const FK &K) {",
+            "  switch (i) {"]
+    for i, r in enumerate(t.rew):
+        lines, names = [], {}
+        v = _emit([r], lines, names)[0]
+        out.append("    case %d: {" % i)
+        out += lines
+        out.append("      return %s;" % v)
+        out.append("    }")
+    out += ["    default: return 0.f;", "  }", "}",
+            "template <class FP, class FV, class FW, class FK>",
+            "__device__ __forceinline__ bool traced_done(const int i, const FP &P, const FV &V, const FW &W, const FK &K) {",
+            "  switch (i) {"]
+    for i, d in enumerate(t.done):
+        if d is None:
+            continue
+        lines, names = [], {}
+        v = _emit([d], lines, names)[0]
+        out.append("    case %d: {" % i)
+        out += lines
+        out.append("      return %s;" % v)
+        out.append("    }")
+    out += ["    default: return false;", "  }", "}", "}  // namespace", "}  // namespace mpe", ""]
+    return "\n".join(out)

@@ -1,0 +1,94 @@
+"""Reference-style scenario files (tests/refstyle/*.py, or any path): the traced path (symtrace.py: the file's callbacks compiled
+into the step kernel) against the host path (refstyle.py: the callbacks per world on the host) -- agreement and env-steps/s."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import multiagent_particle_envs_amd as mpe  # noqa: E402
+
+
+def actions(env, rs, B, dev):
+    acts = []
+    for a in env.agents:
+        parts = []
+        if a.movable:
+            parts.append(np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=B)])
+        if not a.silent:
+            parts.append(np.eye(env.world.dim_c, dtype=np.float32)[rs.randint(0, env.world.dim_c, size=B)])
+        acts.append(torch.as_tensor(np.concatenate(parts, axis=1)).to(dev))
+    return acts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("files", nargs="*")
+    ap.add_argument("--check-worlds", type=int, default=256)
+    ap.add_argument("--worlds", type=int, default=65536)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--host-worlds", type=int, default=256)
+    args = ap.parse_args()
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = args.files or [os.path.join(here, "..", "tests", "refstyle", f) for f in ("herd.py", "relay.py", "patrol.py")]
+    dev = torch.device("cuda", 0)
+    for path in files:
+        name = os.path.basename(path)
+        t0 = time.time()
+        a = mpe.make_env(path, batch_size=args.check_worlds, seed=1)
+        t_build = time.time() - t0
+        if not a.traced:
+            print("%-24s host path only: %s" % (name, a.trace_fallback))
+            continue
+        b = mpe.make_env(path, batch_size=args.check_worlds, seed=1, traced=False)
+        rs = np.random.RandomState(0)
+        seeds = list(range(100, 100 + args.check_worlds))
+        oa, ob = a.reset(seeds=seeds), b.reset(seeds=seeds)
+        worst = max(float((x.double() - y.double()).abs().max()) for x, y in zip(oa, ob))
+        for t in range(12):
+            if t == 4:      # crowd the worlds: contacts
+                pa, va = a.world.get_state(all_entities=True)
+                a.world.set_state(pa * 0.3, va)
+                b.world.set_state(pa * 0.3, va)
+            act = actions(a, rs, args.check_worlds, dev)
+            (oa, ra, da, _), (ob, rb, db, _) = a.step(act), b.step(act)
+            pa, _ = a.world.get_state()
+            pb, _ = b.world.get_state()
+            assert np.array_equal(pa, pb), "state"
+            for x, y in zip(oa, ob):
+                worst = max(worst, float(((x.double() - y.double()).abs() / y.double().abs().clamp(min=1.0)).max()))
+            for x, y in zip(ra, rb):
+                e = (x.double() - y.double()).abs() / y.double().abs().clamp(min=1.0)
+                worst = max(worst, float(e.max()))
+        # rates
+        big = mpe.make_env(path, batch_size=args.worlds, seed=2)
+        act = [actions(big, rs, args.worlds, dev) for _ in range(4)]
+        big.reset()
+        for k in range(10):
+            big.step(act[k % 4])
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for k in range(args.steps):
+            big.step(act[k % 4])
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / args.steps
+        hb = mpe.make_env(path, batch_size=args.host_worlds, seed=2, traced=False)
+        hact = actions(hb, rs, args.host_worlds, dev)
+        hb.reset()
+        hb.step(hact)
+        t0 = time.time()
+        for k in range(3):
+            hb.step(hact)
+        torch.cuda.synchronize()
+        hdt = (time.time() - t0) / 3
+        print("%-24s traced == host path within %.2e over 12 steps x %d worlds; build (trace + verify + hipcc) %.1f s; traced: %.2f us per "
+              "env.step at %d worlds = %.3g env-steps/s; host path: %.1f ms per step at %d worlds = %.3g env-steps/s  (x %.0f)"
+              % (name, worst, args.check_worlds, t_build, dt * 1e6, args.worlds, args.worlds / dt, hdt * 1e3, args.host_worlds,
+                 args.host_worlds / hdt, (args.worlds / dt) / (args.host_worlds / hdt)))
+
+
+if __name__ == "__main__":
+    main()
