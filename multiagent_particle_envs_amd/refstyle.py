@@ -23,6 +23,7 @@ seed -- and the migration path: a scenario that matters gets rewritten against t
 RewardSpec, rowspec.py) and runs 3-5 orders of magnitude faster.  The physics never runs on the CPU either way.
 """
 import inspect
+import os
 
 import numpy as np
 import torch
@@ -396,17 +397,78 @@ class TracedRefScenario(object):
         return rowspec.DoneSpec(world, agent).code(self._hash(world))
 
 
-def trace_ref_scenario(scenario, want_done=False, verify_worlds=64):
+def _trace_cache_path(scenario, want_done):
+    """lib/rows_cache/trace_<sha256 of the scenario's source files + the tracer's>.json, or None when the sources cannot be read."""
+    import hashlib
+    import inspect
+    from . import _build, symtrace
+    h = hashlib.sha256(b"trace format 1, done %d;" % int(bool(want_done)))
+    try:
+        files = [inspect.getsourcefile(symtrace)]
+        for klass in type(scenario).__mro__:
+            if klass.__module__ not in ("builtins",) and not klass.__module__.startswith(__name__.rsplit(".", 1)[0] + "."):
+                f = inspect.getsourcefile(klass)
+                if f not in files:
+                    files.append(f)
+        for f in files:
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    except (TypeError, OSError):
+        return None
+    return os.path.join(_build.ROWS_CACHE, "trace_%s.json" % h.hexdigest()[:32])
+
+
+def trace_ref_scenario(scenario, want_done=False, verify_worlds=64, cache=True):
     """symtrace.trace + symtrace.verify -> TracedRefScenario; raises symtrace.TraceUnsupported (with the reason) when the
-    file is outside what the tracer models or the trace does not reproduce the file's own callbacks."""
+    file is outside what the tracer models or the trace does not reproduce the file's own callbacks.  The trace is cached by
+    the content of the file (simple_world_comm's 4096 paths per agent take seconds); the verification runs every time."""
+    import json
     from . import symtrace
-    t = symtrace.trace(scenario, want_done=want_done)
+    path = _trace_cache_path(scenario, want_done) if cache else None
+    t = None
+    if path is not None and os.path.exists(path):
+        try:
+            with open(path) as fh:
+                t = symtrace.from_dict(json.load(fh))
+        except (ValueError, KeyError, symtrace.TraceUnsupported):
+            t = None
+    if t is None:
+        t = symtrace.trace(scenario, want_done=want_done)
+        if path is not None:
+            try:
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                tmp = path + ".tmp%d" % os.getpid()
+                with open(tmp, "w") as fh:
+                    json.dump(symtrace.to_dict(t), fh, separators=(",", ":"))
+                os.replace(tmp, path)
+            except OSError:
+                pass
     if len(t.pops) > _abi.MPE_MAX_CHOICES:
         raise symtrace.TraceUnsupported("reset_world makes %d np.random.choice draws (at most %d per-world picks)" % (len(t.pops), _abi.MPE_MAX_CHOICES))
     if t.E > _abi.MPE_ROWS_MAX_ENTITIES:
         raise symtrace.TraceUnsupported("%d entities (row programs cover %d)" % (t.E, _abi.MPE_ROWS_MAX_ENTITIES))
     t.verified = symtrace.verify(scenario, t, worlds=verify_worlds)
     return TracedRefScenario(scenario, t)
+
+
+def make_traced_env(ts, batch_size, device=None, seed=0, max_episode_steps=None, auto_reset=False, fresh_outputs=False):
+    """The env of a TracedRefScenario (or of a symtrace.Traced / its to_dict() data: a trace made elsewhere)."""
+    from . import symtrace
+    from .environment import MultiAgentEnv
+    if isinstance(ts, dict):
+        ts = symtrace.from_dict(ts)
+    if isinstance(ts, symtrace.Traced):
+        ts = TracedRefScenario(None, ts)
+    world = ts.make_world(int(batch_size), device)
+    if not world.pos.is_cuda:
+        raise symtrace.TraceUnsupported("traced programs run compiled in on a HIP device (this world is on %s)" % world.device)
+    world.seed = seed
+    world.rng_mode = "device"
+    ts.reset_world(world)
+    env = MultiAgentEnv(world, ts.reset_world, None, None, None, None, fresh_outputs=fresh_outputs, fused=True,
+                        max_episode_steps=max_episode_steps, auto_reset=auto_reset, compile_program=True)
+    env.scenario, env.ref_scenario, env.traced, env.trace_fallback = ts, ts.scenario, True, None
+    return env
 
 
 def _is_num(x):
@@ -439,16 +501,8 @@ def make_ref_env(scenario, benchmark=False, batch_size=None, device=None, seed=0
         try:
             want_done = bool(done_callback) and hasattr(scenario, "done")
             ts = trace_ref_scenario(scenario, want_done=want_done)
-            world = ts.make_world(int(batch_size), device)
-            if not world.pos.is_cuda:
-                raise symtrace.TraceUnsupported("traced programs run compiled in on a HIP device (this world is on %s)" % world.device)
-            world.seed = seed
-            world.rng_mode = "device"
-            ts.reset_world(world)
-            env = MultiAgentEnv(world, ts.reset_world, None, None, None, None, fresh_outputs=fresh_outputs, fused=True,
-                                max_episode_steps=max_episode_steps, auto_reset=auto_reset, compile_program=True)
-            env.scenario, env.ref_scenario, env.traced, env.trace_fallback = ts, scenario, True, None
-            return env
+            return make_traced_env(ts, batch_size, device=device, seed=seed, max_episode_steps=max_episode_steps,
+                                   auto_reset=auto_reset, fresh_outputs=fresh_outputs)
         except (symtrace.TraceUnsupported, _abi.MpeError, RuntimeError) as e:
             if traced:
                 raise

@@ -678,6 +678,73 @@ class Traced(object):
         self.graph = Graph()
 
 
+# ---- a trace as plain data (JSON): cached beside the compiled images; test fixtures of the reference's own nine files ----------
+_ENT_KEYS = ("name", "size", "movable", "collide", "max_speed", "accel", "initial_mass", "density")
+_AGT_KEYS = ("silent", "blind", "u_noise", "c_noise", "u_range")
+_WLD_KEYS = ("dim_c", "dim_p", "dim_color", "dt", "damping", "contact_force", "contact_margin")
+
+
+def to_dict(t):
+    g = t.graph
+    nodes = sorted(g.nodes.values(), key=lambda n: n.uid)
+    assert [n.uid for n in nodes] == list(range(len(nodes)))
+    w = t.world
+
+    def ent(e, agent):
+        d = {k: getattr(e, k, None) for k in _ENT_KEYS}
+        if agent:
+            d.update({k: getattr(e, k, None) for k in _AGT_KEYS})
+        return d
+    return {"format": 1,
+            "nodes": [[n.op, [a.uid for a in n.args], list(n.value) if isinstance(n.value, tuple) else n.value] for n in nodes],
+            "obs": [[n.uid for n in row] for row in t.obs], "rew": [n.uid for n in t.rew],
+            "done": [None if d is None else d.uid for d in t.done],
+            "reset_pos": [[n.uid for n in e] for e in t.reset_pos], "reset_vel": [[n.uid for n in e] for e in t.reset_vel],
+            "reset_c": [[n.uid for n in a] for a in t.reset_c],
+            "draws": [list(d) for d in t.draws], "pops": list(t.pops), "n_u": t.n_u, "A": t.A, "E": t.E, "dim_c": t.dim_c,
+            "collaborative": bool(t.collaborative), "paths": t.paths, "enumerated": list(getattr(t, "enumerated", [])),
+            "world": {k: getattr(w, k) for k in _WLD_KEYS},
+            "discrete_action": getattr(w, "discrete_action", None),
+            "agents": [ent(a, True) for a in w.agents], "landmarks": [ent(l, False) for l in w.landmarks]}
+
+
+def from_dict(d):
+    """The inverse of to_dict: a Traced whose `world` is a world of compat.core objects carrying the recorded constants."""
+    from .compat import core as ccore
+    if d.get("format") != 1:
+        raise TraceUnsupported("trace data of another format")
+    t = Traced()
+    g = t.graph
+    nodes = []
+    for op, args, value in d["nodes"]:
+        n = g.node(op, tuple(nodes[a] for a in args), tuple(value) if isinstance(value, list) else value)
+        if n.uid != len(nodes):
+            raise TraceUnsupported("trace data is not in creation order")
+        nodes.append(n)
+    t.obs = [[nodes[u] for u in row] for row in d["obs"]]
+    t.rew = [nodes[u] for u in d["rew"]]
+    t.done = [None if u is None else nodes[u] for u in d["done"]]
+    t.reset_pos = [[nodes[u] for u in e] for e in d["reset_pos"]]
+    t.reset_vel = [[nodes[u] for u in e] for e in d["reset_vel"]]
+    t.reset_c = [[nodes[u] for u in a] for a in d["reset_c"]]
+    t.draws = [tuple(x) for x in d["draws"]]
+    t.pops, t.n_u, t.A, t.E, t.dim_c = list(d["pops"]), d["n_u"], d["A"], d["E"], d["dim_c"]
+    t.collaborative, t.paths, t.enumerated = d["collaborative"], d["paths"], d["enumerated"]
+    w = ccore.World()
+    for k, v in d["world"].items():
+        setattr(w, k, v)
+    if d.get("discrete_action") is not None:
+        w.discrete_action = d["discrete_action"]
+    w.collaborative = t.collaborative
+    for spec, klass, dst in [(x, ccore.Agent, w.agents) for x in d["agents"]] + [(x, ccore.Landmark, w.landmarks) for x in d["landmarks"]]:
+        e = klass()
+        for k, v in spec.items():
+            setattr(e, k, v)
+        dst.append(e)
+    t.world = w
+    return t
+
+
 def _entity_lists(world):
     return list(world.agents), list(world.agents) + list(world.landmarks)
 

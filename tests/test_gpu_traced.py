@@ -1,0 +1,189 @@
+"""Reference-style Scenario files on the traced path (symtrace.py -> a compiled row program with code ops, csrc/mpe_rows.hip):
+`make_env('<file>.py', batch_size=B)` steps in ONE launch, the file's NumPy callbacks compiled into the kernel.
+
+  * the reference's own nine files: their COMMITTED traces (tests/golden/traced_*.json -- the GPU box has no reference tree;
+    tests/test_symtrace.py holds them to the files and to the goldens on the CPU) run on the device against the goldens the
+    reference's env recorded: seeded resets, per-world picks, every step's rows / rewards / state at 1e-5;
+  * the fixture files of tests/refstyle/ traced here, against their reference-recorded goldens and against the HOST path
+    (refstyle.py: the same file's callbacks per world) on the same worlds;
+  * episode ends / rollouts of row programs carry over; a traced program without its image refuses to run.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import multiagent_particle_envs_amd as mpe
+from multiagent_particle_envs_amd import _abi, refstyle, symtrace
+from multiagent_particle_envs_amd.rollout import RandomRollout
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURES = os.path.join(HERE, "refstyle")
+GOLDEN = os.path.join(HERE, "golden")
+NINE = ["simple", "simple_spread", "simple_tag", "simple_adversary", "simple_push", "simple_speaker_listener", "simple_reference",
+        "simple_crypto", "simple_world_comm"]
+TOL = 1e-5
+
+
+def close(a, b, what, tol=TOL):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    assert np.all(err <= tol), "%s: max scaled err %.3e" % (what, float(err.max()))
+    return float(err.max()) if err.size else 0.0
+
+
+def actions_of(g, t, n, dev):
+    if "act" in g:
+        return [torch.as_tensor(g["act"][t][:, i], dtype=torch.float32).to(dev) for i in range(n)]
+    return [torch.as_tensor(g["act%d" % i][t], dtype=torch.float32).to(dev) for i in range(n)]
+
+
+def replay(env, g, dev):
+    """Seeded reset, then every recorded step teacher-forced from the reference's state."""
+    n, W = env.n, g["rew"].shape[1]
+    T = g["rew"].shape[0]
+    none = torch.zeros(W, dtype=torch.bool, device=dev)
+    obs = env.reset(seeds=[int(s) for s in g["seeds"]])
+    pos, _ = env.world.get_state()
+    same = np.all(np.abs(pos - g["pos0"]) <= 1e-6, axis=(1, 2))
+    if "staged" in g:
+        assert same[~g["staged"]].all() and (~g["staged"]).sum() >= W // 8, "the seeded reset does not reproduce the reference's"
+    else:
+        assert same.sum() >= W // 2, "the seeded reset does not reproduce the reference's"
+    if "choice" in g and g["choice"].shape[1]:
+        assert np.array_equal(env.world.choice_i32.cpu().numpy().T, g["choice"])
+    worst = 0.0
+    for i in range(n):
+        worst = max(worst, close(obs[i][torch.as_tensor(same)], g["obs_reset%d" % i][same], "obs_reset%d" % i))
+    env.world.set_state(g["pos0"], g["vel0"])
+    obs = env.reset(mask=none)                       # (nothing is reset: the rows of the staged state)
+    for i in range(n):
+        worst = max(worst, close(obs[i], g["obs_reset%d" % i], "rows of the staged reset state, agent %d" % i))
+    for t in range(T):
+        env.world.set_state(g["pos0"] if t == 0 else g["pos"][t - 1], g["vel0"] if t == 0 else g["vel"][t - 1])
+        obs, rew, done, info = env.step(actions_of(g, t, n, dev))
+        pos, vel = env.world.get_state()
+        worst = max(worst, close(pos, g["pos"][t], "pos t=%d" % t), close(vel, g["vel"][t][:, :vel.shape[1]], "vel t=%d" % t))
+        for i in range(n):
+            worst = max(worst, close(obs[i], g["obs%d" % i][t], "obs%d t=%d" % (i, t)))
+            worst = max(worst, close(rew[i], g["rew"][t][:, i], "rew%d t=%d" % (i, t)))
+            assert not bool(done[i].any())
+    return worst
+
+
+@pytest.mark.parametrize("name", NINE)
+def test_committed_traces_of_the_nine_reference_files_on_the_device(name, golden):
+    with open(os.path.join(GOLDEN, "traced_%s.json" % name)) as fh:
+        data = json.load(fh)
+    g = golden(name if name in ("simple", "simple_spread", "simple_tag") else "f3_" + name)
+    W = g["rew"].shape[1]
+    env = refstyle.make_traced_env(data, W)
+    assert env.traced and env.fused and env._prog.traced and env.program_compiled
+    assert [s.shape[0] for s in env.observation_space] == [g["obs_reset%d" % i].shape[1] for i in range(env.n)]
+    replay(env, g, "cuda")
+
+
+@pytest.mark.parametrize("name", ["herd", "relay"])
+def test_fixture_files_traced_against_reference_goldens_and_the_host_path(name, golden):
+    path = os.path.join(FIXTURES, name + ".py")
+    g = golden("refstyle_" + name)
+    W = g["rew"].shape[1]
+    env = mpe.make_env(path, batch_size=W)
+    assert env.traced and env.trace_fallback is None and env.program_compiled
+    assert type(env.ref_scenario).__module__.startswith("mpe_user_scenario_")
+    replay(env, g, "cuda")
+    # ... and against the same file on the host path, free-running on more worlds (crowded at t = 3: contacts)
+    B = 600
+    a, b = mpe.make_env(path, batch_size=B, seed=5), mpe.make_env(path, batch_size=B, seed=5, traced=False)
+    assert a.traced and not b.traced and not b.fused
+    seeds = list(range(1000, 1000 + B))
+    oa, ob = a.reset(seeds=seeds), b.reset(seeds=seeds)
+    rs = np.random.RandomState(0)
+    for t in range(8):
+        if t == 3:
+            p, v = a.world.get_state(all_entities=True)
+            a.world.set_state(p * 0.25, v)
+            b.world.set_state(p * 0.25, v)
+        act = []
+        for ag in a.agents:
+            parts = ([np.eye(5, dtype=np.float32)[rs.randint(0, 5, B)]] if ag.movable else []) + \
+                ([np.eye(a.world.dim_c, dtype=np.float32)[rs.randint(0, a.world.dim_c, B)]] if not ag.silent else [])
+            act.append(torch.as_tensor(np.concatenate(parts, axis=1)).cuda())
+        (oa, ra, _, _), (ob, rb, _, _) = a.step(act), b.step(act)
+        assert np.array_equal(a.world.get_state()[0], b.world.get_state()[0])          # the same physics launch family: bit-identical
+        for i in range(a.n):
+            close(oa[i], ob[i].cpu().numpy(), "obs%d t=%d vs the host path" % (i, t))
+            close(ra[i], rb[i].cpu().numpy(), "rew%d t=%d vs the host path" % (i, t))
+
+
+def test_a_traced_program_runs_compiled_in_only():
+    env = mpe.make_env(os.path.join(FIXTURES, "relay.py"), batch_size=64)
+    act = [torch.zeros((64, 4), device="cuda"), torch.zeros((64, 9), device="cuda")]
+    env.reset()
+    env.step(act)
+    env._prog.unload()
+    with pytest.raises(_abi.MpeError, match="compiled in only"):
+        env.step(act)
+    env.compile_program()
+    env.step(act)
+    # the file that cannot be traced still runs (host path), and says why
+    env = mpe.make_env(os.path.join(FIXTURES, "patrol.py"), batch_size=4)
+    assert not env.traced and "scripted agents" in env.trace_fallback
+    with pytest.raises(symtrace.TraceUnsupported):
+        mpe.make_env(os.path.join(FIXTURES, "patrol.py"), batch_size=4, traced=True)
+
+
+def test_episode_ends_of_traced_envs():
+    """relay's reset_world is World.reset_uniform's placement: with auto_reset the episodes end and restart INSIDE the step launch;
+    herd places its agents in [-0.8, 0.8)^2: finished worlds go through the traced reset_world (masked), not the device draw."""
+    W = 256
+    rs = np.random.RandomState(1)
+    for name, in_launch in (("relay", True), ("herd", False)):
+        env = mpe.make_env(os.path.join(FIXTURES, name + ".py"), batch_size=W, max_episode_steps=3, auto_reset=True)
+        assert env.traced and env._episode_in_launch == in_launch and env._device_restart_ok == in_launch
+        env.reset()
+        p0 = env.world.get_state()[0].copy()
+        for t in range(1, 4):
+            act = []
+            for ag in env.agents:
+                parts = ([np.eye(5, dtype=np.float32)[rs.randint(1, 5, W)]] if ag.movable else []) + \
+                    ([np.eye(env.world.dim_c, dtype=np.float32)[rs.randint(0, env.world.dim_c, W)]] if not ag.silent else [])
+                act.append(torch.as_tensor(np.concatenate(parts, axis=1)).cuda())
+            obs, rew, done, _ = env.step(act)
+            assert bool(done[0].all()) == (t == 3)
+        pos, vel = env.world.get_state()
+        assert np.all(vel == 0) and not np.allclose(pos, p0)              # every world restarted
+        A = len(env.world.agents)
+        assert np.abs(pos[:, :A]).max() < (1.0 if in_launch else 0.8)     # ... by ITS reset_world's placement
+        if not in_launch:
+            assert np.abs(pos[:, :A]).max() > 0.7
+        # the rows of the restarted worlds are the new episode's first: the agent's own position columns say so
+        own = obs[1 if name == "herd" else 0]
+        if name == "herd":
+            assert np.allclose(own[:, 2:4].cpu().numpy(), pos[:, 1], atol=1e-6)
+
+
+def test_fused_rollout_of_a_traced_env_equals_its_per_step_launches():
+    B, T = 2048, 12
+    path = os.path.join(FIXTURES, "relay.py")
+    a, b = mpe.make_env(path, batch_size=B, seed=9), mpe.make_env(path, batch_size=B, seed=9)
+    ra, rb = RandomRollout(a, episode_len=5, pool=5, regenerate=True), RandomRollout(b, episode_len=5, pool=5, regenerate=True)
+    ra.enqueue(T)
+    rb.fused(T)
+    torch.cuda.synchronize()
+    assert torch.equal(a.world.pos, b.world.pos) and torch.equal(a.world.vel, b.world.vel)
+    assert torch.equal(a.world.choice_i32, b.world.choice_i32)
+    oa, ob = a._sets[(T - 1) & 1], b._sets[0]
+    for x, y in zip(oa.obs_n, ob.obs_n):
+        assert torch.equal(x, y)
+    assert torch.equal(oa.rew, ob.rew)
+    # herd's reset_world is not the device draw: a rollout that would reset episodes on the device refuses, with the reason
+    h = mpe.make_env(os.path.join(FIXTURES, "herd.py"), batch_size=64)
+    with pytest.raises(_abi.MpeError, match="reset_uniform"):
+        RandomRollout(h, episode_len=5)
+    RandomRollout(h, episode_len=0).enqueue(3)

@@ -299,7 +299,7 @@ def test_auto_reset_runs_the_files_reset_world_for_finished_worlds():
     """max_episode_steps + auto_reset on a reference-style env: the worlds that reach the horizon are reset by the FILE's
     reset_world (masked), the others keep stepping."""
     W = 8
-    env = mpe.make_env(os.path.join(FIXTURES, "relay.py"), batch_size=W, max_episode_steps=3, auto_reset=True)
+    env = mpe.make_env(os.path.join(FIXTURES, "relay.py"), batch_size=W, max_episode_steps=3, auto_reset=True, traced=False)
     env.reset(seeds=list(range(W)))
     targets = [w.target for w in env.ref_worlds]
     rs = np.random.RandomState(0)

@@ -1,0 +1,318 @@
+"""symtrace.py: reference-style Scenario files traced into expression graphs -- CPU only (the device side: tests/test_gpu_traced.py).
+
+  * the tracer itself on small scenarios written here: forks on symbolic conditions merged into selects, picks as proxies and
+    enumerated where Python needs them concretely, what is refused and why, and that np.random / the file's builtins are left as
+    they were;
+  * the fixture files of tests/refstyle/ and -- in the build container -- the reference's nine files, loaded by path, unmodified:
+    the trace reproduces the file's own reset_world / observation / reward on random worlds (fp64, to the last bit);
+  * the COMMITTED traces of the nine (tests/golden/traced_*.json, tests/golden/gen_traced.py) evaluated with NumPy on the states
+    the reference's own env recorded (tests/golden/*.npz) against the rows and rewards it recorded -- no reference tree needed;
+  * the generated device code compiles (hipcc --genco needs no GPU).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import multiagent_particle_envs_amd as mpe
+from multiagent_particle_envs_amd import compat, refstyle, symtrace
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURES = os.path.join(HERE, "refstyle")
+GOLDEN = os.path.join(HERE, "golden")
+REF_SCENARIOS = "/root/reference/multiagent/scenarios"
+NINE = ["simple", "simple_spread", "simple_tag", "simple_adversary", "simple_push", "simple_speaker_listener", "simple_reference",
+        "simple_crypto", "simple_world_comm"]
+
+compat.install()
+from multiagent.core import World, Agent, Landmark  # noqa: E402
+from multiagent.scenario import BaseScenario  # noqa: E402
+
+
+class _Base(BaseScenario):
+    """Two agents, two landmarks, everything default; subclasses override what a test is about."""
+
+    def make_world(self):
+        world = World()
+        world.dim_c = 2
+        world.agents = [Agent() for _ in range(2)]
+        for i, a in enumerate(world.agents):
+            a.name, a.silent, a.size = "agent %d" % i, i == 0, 0.1
+        world.landmarks = [Landmark() for _ in range(2)]
+        for i, l in enumerate(world.landmarks):
+            l.name, l.movable, l.collide = "landmark %d" % i, False, False
+        self.reset_world(world)
+        return world
+
+    def reset_world(self, world):
+        for a in world.agents:
+            a.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            a.state.p_vel = np.zeros(world.dim_p)
+            a.state.c = np.zeros(world.dim_c)
+        for l in world.landmarks:
+            l.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            l.state.p_vel = np.zeros(world.dim_p)
+
+    def reward(self, agent, world):
+        return -np.sum(np.square(agent.state.p_pos - world.landmarks[0].state.p_pos))
+
+    def observation(self, agent, world):
+        return np.concatenate([agent.state.p_vel] + [l.state.p_pos - agent.state.p_pos for l in world.landmarks])
+
+
+def test_forks_on_symbolic_conditions_merge_into_selects():
+    class S(_Base):
+        def reward(self, agent, world):
+            rew = 0
+            for l in world.landmarks:
+                d = np.sqrt(np.sum(np.square(agent.state.p_pos - l.state.p_pos)))
+                if d < 0.5:                       # a Python `if` on the state
+                    rew -= 1
+                    if d < 0.2:                   # ... nested
+                        rew -= d * 10
+                elif abs(agent.state.p_pos[0]) > 0.9 or not (agent.state.p_pos[1] < 0.9):
+                    rew += 0.25
+            return rew + min(agent.state.p_vel[0], 0.3) + max([agent.state.p_vel[1], -0.1, 0.0])
+    sc = S()
+    t = symtrace.trace(sc)
+    assert t.paths["rew"][0] > 4 and t.paths["obs"] == [1, 1]            # control flow was explored; min / max did not fork
+    assert symtrace.verify(sc, t, worlds=256) == 0.0
+    ops = set(n.op for n in symtrace.topo(t.rew))
+    assert "ite" in ops and "min" in ops and "max" in ops and "lt" in ops
+
+
+def test_a_condition_asked_twice_forks_once():
+    class S(_Base):
+        def near(self, a, b):
+            return True if np.sqrt(np.sum(np.square(a.state.p_pos - b.state.p_pos))) < 0.3 else False
+
+        def observation(self, agent, world):
+            flags = [np.array([1.0]) if self.near(agent, l) else np.array([-1.0]) for l in world.landmarks]
+            again = [np.array([2.0]) if self.near(agent, l) else np.array([0.0]) for l in world.landmarks]
+            return np.concatenate([agent.state.p_pos] + flags + again)
+    sc = S()
+    t = symtrace.trace(sc)
+    assert t.paths["obs"] == [4, 4] and symtrace.verify(sc, t) == 0.0
+
+
+def test_picks_are_proxies_and_are_enumerated_where_python_needs_them_concretely():
+    class S(_Base):
+        def reset_world(self, world):
+            _Base.reset_world(self, world)
+            for i, l in enumerate(world.landmarks):
+                l.color = np.array([0.1, 0.1, 0.1])
+                l.index = i
+            goal = np.random.choice(world.landmarks)         # an object chosen per world
+            goal.color = np.array([0.9, 0.1, 0.1])           # a write through the choice
+            for a in world.agents:
+                a.goal = goal
+                a.tint = np.zeros(3)
+                a.tint[goal.index + 1] = 1.0                 # the choice as an array index: one trace per value
+            world.flag = int(np.random.randint(0, 3))        # a number chosen per world, used as a Python int
+
+        def reward(self, agent, world):
+            return -np.sqrt(np.sum(np.square(agent.state.p_pos - agent.goal.state.p_pos))) - 0.1 * world.flag
+
+        def observation(self, agent, world):
+            return np.concatenate([agent.goal.state.p_pos - agent.state.p_pos, agent.goal.color, agent.tint] +
+                                  [l.color for l in world.landmarks] + [world.agents[1].state.c])
+    sc = S()
+    t = symtrace.trace(sc)
+    assert t.pops == [2, 3] and sorted(t.enumerated) == [0, 1]
+    assert [d[0] for d in t.draws].count("choice") == 2
+    assert symtrace.verify(sc, t, worlds=200) == 0.0
+    assert "sel" in set(n.op for row in t.obs for n in symtrace.topo(row))
+    # the same as data
+    t2 = symtrace.from_dict(json.loads(json.dumps(symtrace.to_dict(t))))
+    assert symtrace.hip_source(t2) == symtrace.hip_source(t) and symtrace.verify(sc, t2) == 0.0
+
+
+def test_what_the_tracer_refuses_and_why():
+    class Hidden(_Base):          # state the trace cannot see: every call answers differently
+        calls = 0
+
+        def reward(self, agent, world):
+            Hidden.calls += 1
+            return float(Hidden.calls)
+
+    class Draws(_Base):
+        def observation(self, agent, world):
+            return np.concatenate([agent.state.p_pos, np.random.uniform(-1, 1, 1)])
+
+    class Scripted(_Base):
+        def make_world(self):
+            w = _Base.make_world(self)
+            w.agents[1].action_callback = lambda a, wo: None
+            return w
+
+    class ReadsAction(_Base):
+        def reward(self, agent, world):
+            return -np.sum(np.square(agent.action.u))
+
+    class Unstored(_Base):        # a random number reset_world drew and kept outside the state
+        def reset_world(self, world):
+            _Base.reset_world(self, world)
+            world.bonus = np.random.uniform(0, 1)
+
+        def reward(self, agent, world):
+            return world.bonus
+
+    class Explodes(_Base):
+        def reward(self, agent, world):
+            rew = 0
+            for k in range(40):
+                if agent.state.p_pos[0] * (k + 1) < 0.01 * k:
+                    rew += 1
+            return rew
+
+    class Concretises(_Base):
+        def reward(self, agent, world):
+            return float(agent.state.p_pos[0])
+
+    for cls, why in ((Draws, "draws random numbers"), (Scripted, "scripted agents"), (ReadsAction, "TypeError|NoneType"),
+                     (Unstored, "did not store in the state"), (Explodes, "control-flow paths"), (Concretises, "Python float")):
+        with pytest.raises(symtrace.TraceUnsupported, match=why):
+            symtrace.trace(cls(), max_paths=512 if cls is Explodes else None)
+    sc = Hidden()
+    with pytest.raises(symtrace.TraceUnsupported, match="does not reproduce"):
+        symtrace.verify(sc, symtrace.trace(sc))
+
+
+def test_tracing_leaves_numpy_random_and_the_files_namespace_as_they_were():
+    sc = mpe.scenarios.load(os.path.join(FIXTURES, "herd.py")).Scenario()
+    space = type(sc).reward.__globals__
+    np.random.seed(123)
+    before = np.random.get_state()[1].copy()
+    fns = (np.random.uniform, np.random.choice, np.random.randint, np.random.randn)
+    t = symtrace.trace(sc)
+    symtrace.verify(sc, t)
+    assert (np.random.uniform, np.random.choice, np.random.randint, np.random.randn) == fns
+    assert np.array_equal(np.random.get_state()[1], before)                   # the caller's stream was not consumed
+    assert "min" not in space and "any" not in space                          # the injected builtins are gone again
+    with pytest.raises(symtrace.TraceUnsupported):                            # ... also after a refused trace
+        symtrace.trace(mpe.scenarios.load(os.path.join(FIXTURES, "patrol.py")).Scenario())
+    assert (np.random.uniform, np.random.choice) == fns[:2]
+
+
+@pytest.mark.parametrize("name", ["herd", "relay"])
+def test_fixture_files_trace_and_reproduce_their_own_callbacks(name):
+    sc = mpe.scenarios.load(os.path.join(FIXTURES, name + ".py")).Scenario()
+    ts = refstyle.trace_ref_scenario(sc, cache=False)
+    assert ts.t.verified == 0.0
+    assert symtrace.verify(sc, ts.t, worlds=300, seed=7) == 0.0
+    # herd places its agents in [-0.8, 0.8)^2: not World.reset_uniform's placement; relay's is
+    assert ts.device_reset == (name == "relay") and ts.landmark_range == (0.9 if name == "relay" else 1.0)
+
+
+def test_patrol_stays_on_the_host_path_with_the_reason():
+    sc = mpe.scenarios.load(os.path.join(FIXTURES, "patrol.py")).Scenario()
+    with pytest.raises(symtrace.TraceUnsupported, match="scripted agents"):
+        refstyle.trace_ref_scenario(sc, cache=False)
+    env = mpe.make_env(os.path.join(FIXTURES, "patrol.py"), batch_size=2, device="cpu")
+    assert not env.traced and "scripted agents" in env.trace_fallback
+    with pytest.raises(symtrace.TraceUnsupported):
+        mpe.make_env(os.path.join(FIXTURES, "patrol.py"), batch_size=2, device="cpu", traced=True)
+    # a CPU world never takes the traced path (its program runs compiled in on a HIP device): the host path, with the reason
+    env = mpe.make_env(os.path.join(FIXTURES, "herd.py"), batch_size=2, device="cpu")
+    assert not env.traced and "HIP device" in env.trace_fallback
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SCENARIOS), reason="the reference tree exists in the build container only")
+@pytest.mark.parametrize("name", NINE)
+def test_the_nine_reference_files_trace_and_reproduce_their_own_callbacks(name):
+    """The file as shipped, loaded by path: reset_world, every agent's observation and reward as graphs == the file's own NumPy
+    code on random worlds, bit for bit in fp64; and the committed trace (what the GPU box runs) is this trace."""
+    path = os.path.join(REF_SCENARIOS, name + ".py")
+    before = open(path, "rb").read()
+    sc = mpe.scenarios.load(path).Scenario()
+    t = symtrace.trace(sc)
+    assert symtrace.verify(sc, t, worlds=200, seed=3) == 0.0
+    assert open(path, "rb").read() == before
+    with open(os.path.join(GOLDEN, "traced_%s.json" % name)) as fh:
+        committed = symtrace.from_dict(json.load(fh))
+    assert symtrace.hip_source(committed) == symtrace.hip_source(t), "tests/golden/traced_%s.json is stale: python tests/golden/gen_traced.py" % name
+    assert symtrace.verify(sc, committed, worlds=50, seed=4) == 0.0
+
+
+def _golden_states(g, t_, tr):
+    """(P [W, E, 2], V [W, E, 2], Cw [W, A, dim_c], K [W, picks]) of recorded step t_ (None: the reset state)."""
+    pos = g["pos0"] if t_ is None else g["pos"][t_]
+    vel = g["vel0"] if t_ is None else g["vel"][t_]
+    W = pos.shape[0]
+    V = np.zeros((W, tr.E, 2))
+    V[:, :vel.shape[1]] = vel
+    Cw = np.zeros((W, tr.A, tr.dim_c))
+    if t_ is not None and tr.dim_c:
+        for i in range(tr.A):
+            if "c%d" % i in g:
+                Cw[:, i] = g["c%d" % i][t_][:, :tr.dim_c]
+    K = g["choice"].astype(np.int64) if "choice" in g and g["choice"].shape[1] else np.zeros((W, len(tr.pops)), np.int64)
+    return pos.astype(np.float64), V, Cw, K
+
+
+@pytest.mark.parametrize("name", NINE)
+def test_committed_traces_of_the_nine_against_the_reference_goldens(name, golden):
+    """No reference tree, no GPU: the committed graphs evaluated (NumPy, fp64) on the states the reference's own env recorded give
+    the rows and rewards it recorded -- per step, per world, per agent -- and its seeded resets."""
+    with open(os.path.join(GOLDEN, "traced_%s.json" % name)) as fh:
+        tr = symtrace.from_dict(json.load(fh))
+    g = golden(name if name in ("simple", "simple_spread", "simple_tag") else "f3_" + name)
+    T, W, A = g["rew"].shape
+    assert A == tr.A
+    worst = 0.0
+    shared = bool(tr.collaborative)
+    for t_ in [None] + list(range(T)):
+        P, V, Cw, K = _golden_states(g, t_, tr)
+        roots = [n for row in tr.obs for n in row] + list(tr.rew)
+        vals = symtrace.evaluate(roots, W, P=P, V=V, Cw=Cw, K=K)
+        off = np.cumsum([0] + [len(r) for r in tr.obs])
+        for i in range(A):
+            want = g["obs_reset%d" % i] if t_ is None else g["obs%d" % i][t_]
+            got = np.stack(vals[off[i]:off[i + 1]], axis=1)
+            worst = max(worst, float(np.abs(got - want).max()))
+        if t_ is not None:
+            rew = np.stack(vals[off[-1]:], axis=1)               # [W, A]
+            if shared:                                            # environment.py:100-102
+                rew = np.repeat(rew.sum(axis=1, keepdims=True), A, axis=1)
+            worst = max(worst, float((np.abs(rew - g["rew"][t_]) / np.maximum(1.0, np.abs(g["rew"][t_]))).max()))
+    assert worst <= 1e-9, worst
+    # the seeded reset: the file's own random stream replayed per world (np.random.seed(s); env.reset())
+    ts = refstyle.TracedRefScenario(None, tr)
+    U = np.zeros((W, max(tr.n_u, 1)))
+    K = np.zeros((W, len(tr.pops)), np.int64)
+    for b in range(W):
+        rs, iu, ik = np.random.RandomState(int(g["seeds"][b])), 0, 0
+        for d in tr.draws:
+            if d[0] == "uniform":
+                U[b, iu:iu + d[3]] = rs.random_sample(d[3])
+                iu += d[3]
+            else:
+                K[b, ik] = rs.randint(0, d[1])
+                ik += 1
+    pos = np.stack(symtrace.evaluate([n for e in tr.reset_pos for n in e], W, K=K, U=U), axis=1).reshape(W, tr.E, 2)
+    same = np.all(np.abs(pos - g["pos0"]) <= 1e-12, axis=(1, 2))      # (the recorders squeeze / stage some worlds after the reset)
+    if "staged" in g:
+        assert same[~g["staged"]].all() and (~g["staged"]).sum() >= W // 8
+    else:
+        assert same.sum() >= W // 2
+    if "choice" in g and g["choice"].shape[1]:
+        assert np.array_equal(K, g["choice"])
+    assert ts.device_reset                                            # the nine all place uniformly: device-side restarts apply
+
+
+def test_generated_device_code_compiles():
+    """symtrace.hip_source appended to the generated header of the program: hipcc --genco accepts it (no GPU needed)."""
+    from multiagent_particle_envs_amd import _build
+    sc = mpe.scenarios.load(os.path.join(FIXTURES, "relay.py")).Scenario()
+    ts = refstyle.trace_ref_scenario(sc)
+    w = ts.make_world(4, "cpu")
+    env = mpe.MultiAgentEnv(w, ts.reset_world, None, None, compile_program=False)
+    assert env._prog is not None and env._prog.traced and env._prog.struct.traced == 1 and env.fused
+    src = env._prog.static_source(env._desc)
+    assert "MPE_ROWS_TRACED" in src and "traced_obs" in src and "sqrt_lt" not in src.split("traced_obs")[0]
+    assert len(_build.compile_rows_image(src)) > 10000
+    # a program with code ops but no source is refused on the host already
+    from multiagent_particle_envs_amd import rowspec, _abi
+    with pytest.raises(_abi.MpeError, match="needs the source"):
+        rowspec.RowProgram(w, [ts.obs_spec(a, w) for a in w.agents], [ts.reward_spec(a, w) for a in w.agents])

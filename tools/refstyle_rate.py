@@ -24,6 +24,16 @@ def actions(env, rs, B, dev):
     return acts
 
 
+def fast_actions(env, rs, B, dev):
+    """The batched input forms of env.step: one [A, B, 5] tensor of moves (+ one [A, B, dim_c] tensor of utterances)."""
+    A, dc = env.n, int(env.world.dim_c)
+    moves = torch.as_tensor(np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=(A, B))]).to(dev)
+    if all(a.silent for a in env.agents):
+        return moves
+    words = torch.as_tensor(np.eye(dc, dtype=np.float32)[rs.randint(0, dc, size=(A, B))]).to(dev)
+    return (moves, words)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("files", nargs="*")
@@ -65,7 +75,7 @@ def main():
                 worst = max(worst, float(e.max()))
         # rates
         big = mpe.make_env(path, batch_size=args.worlds, seed=2)
-        act = [actions(big, rs, args.worlds, dev) for _ in range(4)]
+        act = [fast_actions(big, rs, args.worlds, dev) for _ in range(4)]
         big.reset()
         for k in range(10):
             big.step(act[k % 4])
@@ -75,6 +85,31 @@ def main():
             big.step(act[k % 4])
         torch.cuda.synchronize()
         dt = (time.time() - t0) / args.steps
+        # the device-bound rates: a HIP graph of consecutive step launches with fresh block-drawn moves (bench.py's protocol), and
+        # whole episodes per launch (mpe_rollout_rows)
+        from multiagent_particle_envs_amd.rollout import RandomRollout, Trajectory
+        EP = 25 if big._device_restart_ok else 0
+        roll = RandomRollout(big, episode_len=EP, pool=25, regenerate=True)
+        n = 500
+        graph = roll.capture(n)
+        graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(4):
+            graph.replay()
+        torch.cuda.synchronize()
+        gdt = (time.time() - t0) / (4 * n)
+        traj = Trajectory(big, 25)
+        roll.fused(25, traj)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(40):
+            roll.fused(25, traj)
+        torch.cuda.synchronize()
+        fdt = (time.time() - t0) / (40 * 25)
+        print("%-24s graph of step launches (fresh moves%s): %.2f us per step = %.3g env-steps/s; %d-step rollouts in one launch "
+              "(trajectory kept): %.2f us per step = %.3g env-steps/s" % (name, ", reset every 25 steps" if EP else ", no resets: reset_world "
+              "is not the device draw", gdt * 1e6, args.worlds / gdt, 25, fdt * 1e6, args.worlds / fdt))
         hb = mpe.make_env(path, batch_size=args.host_worlds, seed=2, traced=False)
         hact = actions(hb, rs, args.host_worlds, dev)
         hb.reset()
