@@ -677,6 +677,73 @@ def user_scenario_leg(torch, mpe, B, EP, rv, dev):
     return out
 
 
+def reference_style_leg(torch, mpe, B, EP, rv, dev):
+    """An UNMODIFIED reference-style scenario file (tests/refstyle/convoy.py: `from multiagent.core import ...`, make_world(self),
+    NumPy per-world callbacks with Python `if`s on the state, a per-world pick) through make_env(path, batch_size=B): its callbacks
+    traced into a compiled row program (symtrace.py) -- one launch per step -- beside the host path (refstyle.py: the same file's
+    callbacks per world on the host over the device physics)."""
+    path = os.path.join(ROOT, "tests", "refstyle", "convoy.py")
+    out = {"what": "tests/refstyle/convoy.py, a reference-style scenario file loaded unmodified (4 agents, 4 landmarks, a per-world goal; "
+                   "rewards with contact tests and distance bands as Python ifs): `traced` = make_env(path, batch_size=%d), the file's "
+                   "NumPy callbacks traced into the step kernel, env.step / env.reset every %d steps from Python; `traced_graph` = the "
+                   "headline's protocol (HIP graph of step launches, fresh moves per step, device resets); `traced_fused_rollout` = whole "
+                   "episodes per launch; `host_path` = traced=False: B shadow worlds, the callbacks per world on the host" % (B, EP or 25)}
+    t0 = time.perf_counter()
+    env = mpe.make_env(path, batch_size=B)
+    out["build_s"] = time.perf_counter() - t0      # trace + verification against the file + hipcc (cached by content: 0.x s when warm)
+    if not env.traced:
+        raise RuntimeError("reference-style leg: not traced (%s)" % env.trace_fallback)
+    out["trace"] = {"graph_nodes": env.scenario.t.graph.count, "paths": env.scenario.t.paths, "picks": list(env.scenario.t.pops),
+                    "verified_max_diff_vs_file": env.scenario.t.verified, "device_reset": bool(env.scenario.device_reset)}
+    g = torch.Generator(device="cpu").manual_seed(0)
+    acts = [torch.nn.functional.one_hot(torch.randint(0, 5, (env.n, B), generator=g), 5).float().cuda() for _ in range(4)]
+    n = 2000
+    env.reset()
+    for k in range(20):
+        env.step(acts[k % 4])
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for k in range(n):
+            if k % (EP or 25) == 0:
+                env.reset()
+            env.step(acts[k % 4])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out["traced"] = {"value": B * n / best, "unit": "env-steps/s", "us_per_step": best / n * 1e6, "steps": n,
+                     "path": "mpe_step_rows, compiled image with the file's callbacks as code"}
+    del env
+    lg = Leg(mpe, path, 4, B, EP, 0, 1, 0)
+    d, R, _, r_ = lg.timed(torch, rv, dev, "graph", "fresh", 200, 10, 3, SIDE_REGION_MS)
+    out["traced_graph"] = {"value": B * 200 * R / d, "unit": "env-steps/s", "ms_per_step": d * 1e3 / (200 * R), "timed_steps": 200 * R,
+                           "repeats": {"min": r_[0], "median": r_[1], "max": r_[2]},
+                           "path": "HIP graph of mpe_step_rows launches (compiled image), fresh moves per step, reset every %d steps" % (EP or 25)}
+    d2, R2, _, r2_ = lg.timed(torch, rv, dev, "fused", "resident", 200, 10, 3, SIDE_REGION_MS)
+    out["traced_fused_rollout"] = {"value": B * 200 * R2 / d2, "unit": "env-steps/s", "us_per_step": d2 * 1e6 / (200 * R2),
+                                   "repeats": {"min": r2_[0], "median": r2_[1], "max": r2_[2]},
+                                   "path": "mpe_rollout_rows (compiled image): %d steps per launch, every step's rows / rewards / dones kept" % (EP or 25)}
+    lg.release()
+    del lg
+    torch.cuda.empty_cache()
+    HB = 256
+    henv = mpe.make_env(path, batch_size=HB, traced=False)
+    hact = acts[0][:, :HB].contiguous()
+    hact = [hact[i] for i in range(henv.n)]
+    henv.reset()
+    henv.step(hact)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        henv.step(hact)
+    torch.cuda.synchronize()
+    hdt = (time.perf_counter() - t0) / 3
+    out["host_path"] = {"value": HB / hdt, "unit": "env-steps/s", "ms_per_step": hdt * 1e3, "worlds": HB,
+                        "path": "refstyle.RefScenarioAdapter: mpe_world_step + the file's callbacks per world on the host"}
+    out["traced_over_host_path"] = out["traced"]["value"] / out["host_path"]["value"]
+    return out
+
+
 def box_fingerprint(torch, dev, smi=True):
     """What this rank's GPU is and how the box is set up: device properties from the runtime, clocks / power cap /
     partition modes / driver from rocm-smi when it answers (C4's 20 % box-to-box spread, DESIGN 2.7, needs a label)."""
@@ -945,6 +1012,7 @@ def main():
     default_line = solo and args.scenario == "simple_spread" and args.agents == 3 and B == 65536
     if default_line:
         extra["user_scenario"] = user_scenario_leg(torch, mpe, B, EP, rv, dev)
+        extra["reference_style_file"] = reference_style_leg(torch, mpe, B, EP, rv, dev)
     headline_roof = roofline_entry(leg, k_us, B, args.mode, floor_us, head_timing)
     if default_line:
         leg.release()

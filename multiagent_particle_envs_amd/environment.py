@@ -248,7 +248,8 @@ class MultiAgentEnv(object):
                 obs_dims = [int(observation_callback(agent, self.world).shape[-1]) for agent in self.agents]
         else:
             self._desc = None
-            obs_dims = [int(observation_callback(agent, self.world).shape[-1]) for agent in self.agents]
+            # (no observation callback: the reference's _get_obs returns an empty row, environment.py:120-123)
+            obs_dims = [int(self._get_obs(agent).shape[-1]) for agent in self.agents]
         for agent, obs_dim in zip(self.agents, obs_dims):
             total_action_space = []
             if self.discrete_action_space:

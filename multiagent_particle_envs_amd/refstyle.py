@@ -331,7 +331,38 @@ class TracedRefScenario(object):
             idx = world.reset_uniform(self.landmark_range, mask, choices=list(t.pops))
             self._merge_picks(world, idx, mask)
             return
-        # the traced reset program evaluated for all worlds at once (fp64), then one upload
+        from . import symtrace
+        flat = [n for e in t.reset_pos for n in e] + [n for e in t.reset_vel for n in e]
+        if seeds is None and world.rng_mode == "device" and world.pos.is_cuda:
+            # not reset_uniform's placement (a restricted spawn area, positions that depend on a pick ...): the traced reset
+            # program drawn and evaluated with torch ops for all worlds at once -- ~50 small launches, nothing leaves the device
+            dev = world.device
+            gen = torch.Generator(device=dev)
+            gen.manual_seed((int(world.seed) * 1000003 + int(world._episode) * 7919 + int(world.world_offset)) & (2 ** 63 - 1))
+            world._episode += 1
+            U = torch.rand((max(t.n_u, 1), B), generator=gen, device=dev)
+            K = torch.stack([torch.randint(0, n, (B,), generator=gen, device=dev) for n in t.pops]) if t.pops else \
+                torch.zeros((0, B), dtype=torch.int64, device=dev)
+            vals = symtrace.evaluate_torch(flat, B, K=K, U=U, device=dev)
+            pos = torch.stack(vals[:2 * t.E]).reshape(t.E, 2, B)
+            vel = torch.stack(vals[2 * t.E:]).reshape(t.E, 2, B)
+            if mask is None:
+                world.pos.copy_(pos)
+                world._vel_all.copy_(vel)
+            else:
+                mk = torch.as_tensor(mask, device=dev).bool().reshape(1, 1, B)
+                world.pos.copy_(torch.where(mk, pos, world.pos))
+                world._vel_all.copy_(torch.where(mk, vel, world._vel_all))
+            for a in world.agents:      # every reset_world of the reference zeroes the utterances (traced: reset_c, zeros or not modelled)
+                if torch.is_tensor(a.state.c) and a.state.c.numel():
+                    if mask is None:
+                        a.state.c.zero_()
+                    else:
+                        a.state.c.mul_((~torch.as_tensor(mask, device=dev).bool()).to(a.state.c.dtype)[:, None])
+            self._merge_picks(world, K.t(), mask)
+            return
+        # the traced reset program evaluated for all worlds at once (fp64) on the host, then one upload: seeded resets (the file's
+        # own random stream per world) and compatibility modes
         m = None if mask is None else torch.as_tensor(mask).cpu().numpy().astype(bool).reshape(-1)
         U = np.zeros((B, max(t.n_u, 1)))
         K = np.zeros((B, len(t.pops)), np.int64)
@@ -357,8 +388,6 @@ class TracedRefScenario(object):
             U = rs.random_sample(U.shape)
             for k, n in enumerate(t.pops):
                 K[:, k] = rs.randint(0, n, B)
-        from . import symtrace
-        flat = [n for e in t.reset_pos for n in e] + [n for e in t.reset_vel for n in e]
         vals = symtrace.evaluate(flat, B, K=K, U=U)
         pos = np.stack(vals[:2 * t.E], axis=1).reshape(B, t.E, 2)
         vel = np.stack(vals[2 * t.E:], axis=1).reshape(B, t.E, 2)

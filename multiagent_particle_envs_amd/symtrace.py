@@ -948,7 +948,16 @@ def inputs_of(roots):
 
 
 # ---- evaluation with NumPy (fp64 by default), vectorised over worlds: the verification, the CPU tests, host-side resets ------
-def evaluate(roots, B, P=None, V=None, Cw=None, K=None, U=None, dtype=np.float64):
+def decision_margin(roots, B, **state):
+    """Per world: how far the nearest of the graph's comparisons is from flipping -- min over its lt / le / eq / ne nodes of
+    |lhs - rhs| (fp64).  Outputs of an fp32 evaluation can legitimately differ from the fp64 one where this is ~1e-6: tests
+    compare outside such a band (as the contact-count tests of the fused kernels do)."""
+    margin = np.full(B, np.inf)
+    evaluate(roots, B, _margin=margin, **state)
+    return margin
+
+
+def evaluate(roots, B, P=None, V=None, Cw=None, K=None, U=None, dtype=np.float64, _margin=None):
     """Values of `roots` for B worlds: P [B, E, 2], V [B, E, 2], Cw [B, A, dim_c], K [B, n_picks] (ints), U [B, n_draws]."""
     val = {}
     one = np.ones(B, dtype)
@@ -994,6 +1003,9 @@ def evaluate(roots, B, P=None, V=None, Cw=None, K=None, U=None, dtype=np.float64
                 v = np.log(a[0])
             elif op == "tanh":
                 v = np.tanh(a[0])
+            elif op in _CMP and _margin is not None and not any(x.op == "K" or x.op == "sel" for x in n.args):
+                np.minimum(_margin, np.where(np.isfinite(a[0] - a[1]), np.abs(a[0] - a[1]), np.inf), out=_margin)
+                v = {"lt": a[0] < a[1], "le": a[0] <= a[1], "eq": a[0] == a[1], "ne": a[0] != a[1]}[op]
             elif op == "lt":
                 v = a[0] < a[1]
             elif op == "le":
@@ -1102,6 +1114,58 @@ def verify(scenario, t, worlds=96, seed=0, tol=1e-9):
                 if bool(scenario.done(a, cw)) != bool(done_eval[i][r]):
                     raise TraceUnsupported("the trace does not reproduce the file's done (agent %d)" % i)
     return worst
+
+
+def evaluate_torch(roots, B, K=None, U=None, P=None, V=None, Cw=None, device=None):
+    """`evaluate` with torch ops on `device` (fp32): a traced reset_world that is not World.reset_uniform's placement is drawn
+    and evaluated for all worlds at once without leaving the device.  K [n_picks, B] int64, U [n_draws, B]; -> list of [B] tensors."""
+    import torch
+    val = {}
+
+    def full(x, dtype=torch.float32):
+        return torch.full((B,), x, dtype=dtype, device=device)
+    for n in topo(roots):
+        a = [val[x.uid] for x in n.args]
+        op = n.op
+        if op == "const":
+            v = full(float(n.value))
+        elif op == "bconst":
+            v = full(bool(n.value), torch.bool)
+        elif op == "U":
+            v = U[n.value[0]]
+        elif op == "K":
+            v = K[n.value[0]].to(torch.float32)
+        elif op == "P":
+            v = P[n.value[0], n.value[1]]
+        elif op == "V":
+            v = V[n.value[0], n.value[1]]
+        elif op == "C":
+            v = Cw[n.value[0]][:, n.value[1]]
+        elif op in ("add", "sub", "mul", "div"):
+            v = {"add": torch.add, "sub": torch.sub, "mul": torch.mul, "div": torch.div}[op](a[0], a[1])
+        elif op == "min":
+            v = torch.where(a[1] < a[0], a[1], a[0])
+        elif op == "max":
+            v = torch.where(a[1] > a[0], a[1], a[0])
+        elif op in ("neg", "abs", "sqrt", "exp", "log", "tanh"):
+            v = getattr(torch, op)(a[0])
+        elif op in _CMP:
+            v = {"lt": torch.lt, "le": torch.le, "eq": torch.eq, "ne": torch.ne}[op](a[0], a[1])
+        elif op == "not":
+            v = ~a[0]
+        elif op == "and":
+            v = a[0] & a[1]
+        elif op == "or":
+            v = a[0] | a[1]
+        elif op == "ite":
+            v = torch.where(a[0], a[1], a[2])
+        elif op == "sel":
+            k = a[0].to(torch.int64).clamp(0, len(a) - 2)
+            v = torch.stack([x.to(torch.float32) for x in a[1:]], dim=0).gather(0, k[None, :])[0]
+        else:
+            raise ValueError("node %r" % op)
+        val[n.uid] = v
+    return [val[r.uid] for r in roots]
 
 
 # ---- device code: one statement per node, in trace order ------------------------------------------------------------------------

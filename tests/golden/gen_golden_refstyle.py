@@ -30,7 +30,7 @@ warnings.filterwarnings("ignore")
 from multiagent.environment import MultiAgentEnv  # noqa: E402  (the reference's env, environment.py:9)
 
 FIXTURES = os.path.join(os.path.dirname(HERE), "refstyle")
-NAMES = ("herd", "relay", "patrol")
+NAMES = ("herd", "relay", "patrol", "convoy")
 
 
 def load(name):
@@ -107,7 +107,8 @@ def record(name, seeds, T):
 
 
 def main():
-    for name in NAMES:
+    only = sys.argv[1:]
+    for name in (only or NAMES):
         data = record(name, list(range(500, 512)), 12)
         np.savez(os.path.join(HERE, "refstyle_%s.npz" % name), **data)
         print(name, {k: v.shape for k, v in data.items() if k in ("rew", "pos", "obs0", "info0")},

@@ -53,6 +53,7 @@ def replay(env, g, dev):
     same = np.all(np.abs(pos - g["pos0"]) <= 1e-6, axis=(1, 2))
     if "staged" in g:
         assert same[~g["staged"]].all() and (~g["staged"]).sum() >= W // 8, "the seeded reset does not reproduce the reference's"
+        same = same & ~g["staged"]           # (a staged world may have kept its positions and been given velocities)
     else:
         assert same.sum() >= W // 2, "the seeded reset does not reproduce the reference's"
     if "choice" in g and g["choice"].shape[1]:
@@ -69,9 +70,23 @@ def replay(env, g, dev):
         obs, rew, done, info = env.step(actions_of(g, t, n, dev))
         pos, vel = env.world.get_state()
         worst = max(worst, close(pos, g["pos"][t], "pos t=%d" % t), close(vel, g["vel"][t][:, :vel.shape[1]], "vel t=%d" % t))
+        # fp32 kernel against the fp64 reference: worlds within 2e-6 of one of the file's own thresholds (contact tests ...) may
+        # take the other branch; compared outside that band (found from the trace, on the reference's recorded state)
+        tr = env.scenario.t
+        V = np.zeros((W, tr.E, 2))
+        V[:, :g["vel"][t].shape[1]] = g["vel"][t]
+        Cw = np.zeros((W, tr.A, tr.dim_c))
+        for i in range(tr.A):
+            if tr.dim_c and "c%d" % i in g:
+                Cw[:, i] = g["c%d" % i][t][:, :tr.dim_c]
+        K = g["choice"].astype(np.int64) if "choice" in g and g["choice"].shape[1] else np.zeros((W, len(tr.pops)), np.int64)
+        roots = [x for row in tr.obs for x in row] + list(tr.rew)
+        ok = symtrace.decision_margin(roots, W, P=g["pos"][t].astype(np.float64), V=V, Cw=Cw, K=K) > 2e-6
+        assert ok.mean() >= 0.95, ok.mean()
+        okt = torch.as_tensor(ok)
         for i in range(n):
-            worst = max(worst, close(obs[i], g["obs%d" % i][t], "obs%d t=%d" % (i, t)))
-            worst = max(worst, close(rew[i], g["rew"][t][:, i], "rew%d t=%d" % (i, t)))
+            worst = max(worst, close(obs[i][okt], g["obs%d" % i][t][ok], "obs%d t=%d" % (i, t)))
+            worst = max(worst, close(rew[i][okt], g["rew"][t][:, i][ok], "rew%d t=%d" % (i, t)))
             assert not bool(done[i].any())
     return worst
 
@@ -88,7 +103,7 @@ def test_committed_traces_of_the_nine_reference_files_on_the_device(name, golden
     replay(env, g, "cuda")
 
 
-@pytest.mark.parametrize("name", ["herd", "relay"])
+@pytest.mark.parametrize("name", ["herd", "relay", "convoy"])
 def test_fixture_files_traced_against_reference_goldens_and_the_host_path(name, golden):
     path = os.path.join(FIXTURES, name + ".py")
     g = golden("refstyle_" + name)
@@ -116,9 +131,24 @@ def test_fixture_files_traced_against_reference_goldens_and_the_host_path(name, 
             act.append(torch.as_tensor(np.concatenate(parts, axis=1)).cuda())
         (oa, ra, _, _), (ob, rb, _, _) = a.step(act), b.step(act)
         assert np.array_equal(a.world.get_state()[0], b.world.get_state()[0])          # the same physics launch family: bit-identical
+        # the host path evaluates the file in fp64, the kernel in fp32: a world within 2e-6 of one of the file's OWN thresholds
+        # (a contact test, `gap < 0.25`) may take the other branch -- compared outside that band, as the contact counts of the
+        # fused kernels are; the band is found from the trace itself
+        tr = a.scenario.t
+        P, V = a.world.get_state(all_entities=True)
+        Cw = np.zeros((B, tr.A, tr.dim_c))
+        if tr.dim_c:
+            for i, ag in enumerate(a.world.agents):
+                if not ag.silent:
+                    Cw[:, i] = a._comm[i].cpu().numpy()
+        K = a.world.choice_i32.cpu().numpy().T if tr.pops else np.zeros((B, 0), np.int64)
+        roots = [n for row in tr.obs for n in row] + list(tr.rew)
+        ok = symtrace.decision_margin(roots, B, P=P.astype(np.float64), V=V.astype(np.float64), Cw=Cw, K=K) > 2e-6
+        assert ok.mean() > 0.9
+        okt = torch.as_tensor(ok)
         for i in range(a.n):
-            close(oa[i], ob[i].cpu().numpy(), "obs%d t=%d vs the host path" % (i, t))
-            close(ra[i], rb[i].cpu().numpy(), "rew%d t=%d vs the host path" % (i, t))
+            close(oa[i][okt], ob[i].cpu().numpy()[ok], "obs%d t=%d vs the host path" % (i, t))
+            close(ra[i][okt], rb[i].cpu().numpy()[ok], "rew%d t=%d vs the host path" % (i, t))
 
 
 def test_a_traced_program_runs_compiled_in_only():

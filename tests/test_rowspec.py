@@ -765,6 +765,9 @@ def test_callbacks_that_are_not_the_scenarios_own_are_not_replaced_by_its_specs(
     assert env._prog is None and not env.fused
     with pytest.raises(_abi.MpeError, match="fused=True"):
         mpe.MultiAgentEnv(w, sc.reset_world, my_reward, my_obs, fused=True)
+    # no callbacks at all although the scenario has some: the reference's env then yields empty rows and zero rewards -- so does this
+    env = mpe.MultiAgentEnv(w, sc.reset_world, None, None)
+    assert env._prog is None and not env.fused and [s.shape[0] for s in env.observation_space] == [0, 0, 0]
     # the scenario's own methods (or none at all, for a spec-only scenario): the program
     assert mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation)._prog is not None
     r = _RandomScenario(3)
@@ -826,7 +829,7 @@ def test_in_region_of_any_entity_against_the_numpy_oracle(compiled):
     w = sc.make_world(batch_size=B)
     w.seed = 5
     sc.reset_world(w)
-    env = mpe.MultiAgentEnv(w, sc.reset_world, None, None, compile_program=False)
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, compile_program=False)
     if compiled:
         assert env.compile_program()
     p = env._prog

@@ -195,14 +195,14 @@ def test_tracing_leaves_numpy_random_and_the_files_namespace_as_they_were():
     assert (np.random.uniform, np.random.choice) == fns[:2]
 
 
-@pytest.mark.parametrize("name", ["herd", "relay"])
+@pytest.mark.parametrize("name", ["herd", "relay", "convoy"])
 def test_fixture_files_trace_and_reproduce_their_own_callbacks(name):
     sc = mpe.scenarios.load(os.path.join(FIXTURES, name + ".py")).Scenario()
     ts = refstyle.trace_ref_scenario(sc, cache=False)
     assert ts.t.verified == 0.0
     assert symtrace.verify(sc, ts.t, worlds=300, seed=7) == 0.0
     # herd places its agents in [-0.8, 0.8)^2: not World.reset_uniform's placement; relay's is
-    assert ts.device_reset == (name == "relay") and ts.landmark_range == (0.9 if name == "relay" else 1.0)
+    assert ts.device_reset == (name != "herd") and ts.landmark_range == (1.0 if name == "herd" else 0.9)
 
 
 def test_patrol_stays_on_the_host_path_with_the_reason():
@@ -316,3 +316,31 @@ def test_generated_device_code_compiles():
     from multiagent_particle_envs_amd import rowspec, _abi
     with pytest.raises(_abi.MpeError, match="needs the source"):
         rowspec.RowProgram(w, [ts.obs_spec(a, w) for a in w.agents], [ts.reward_spec(a, w) for a in w.agents])
+
+
+def test_the_torch_evaluator_of_a_reset_program_agrees_with_the_numpy_one():
+    """A reset_world that is not World.reset_uniform's placement (herd: agents on [-0.8, 0.8)^2) is drawn and evaluated with torch
+    ops on the device (symtrace.evaluate_torch): the same graph, the same numbers as the NumPy evaluation (fp32 vs fp64)."""
+    import torch
+    sc = mpe.scenarios.load(os.path.join(FIXTURES, "herd.py")).Scenario()
+    t = symtrace.trace(sc)
+    B = 300
+    rs = np.random.RandomState(0)
+    U = rs.rand(B, t.n_u)
+    K = np.stack([rs.randint(0, n, B) for n in t.pops], axis=1)
+    flat = [n for e in t.reset_pos for n in e] + [n for e in t.reset_vel for n in e]
+    a = np.stack(symtrace.evaluate(flat, B, K=K, U=U))
+    b = torch.stack(symtrace.evaluate_torch(flat, B, K=torch.as_tensor(K).t(), U=torch.as_tensor(U, dtype=torch.float32).t(), device="cpu"))
+    assert np.abs(a - b.numpy()).max() <= 2e-7 and np.abs(a[:2 * t.A]).max() < 0.8 and np.abs(a[:2 * t.A]).max() > 0.75
+    # graphs with picks, selections and comparisons too (observation / reward graphs of a scenario with picks)
+    sc = mpe.scenarios.load(os.path.join(FIXTURES, "convoy.py")).Scenario()
+    t = symtrace.trace(sc)
+    P, V, Cw = symtrace.random_states(t, B, rs)
+    K = np.stack([rs.randint(0, n, B) for n in t.pops], axis=1)
+    roots = [n for row in t.obs for n in row] + list(t.rew)
+    a = np.stack(symtrace.evaluate(roots, B, P=P.astype(np.float32).astype(np.float64), V=V.astype(np.float32).astype(np.float64), Cw=Cw, K=K))
+    tp = torch.as_tensor(P, dtype=torch.float32).permute(1, 2, 0)
+    tv = torch.as_tensor(V, dtype=torch.float32).permute(1, 2, 0)
+    b = torch.stack([x.to(torch.float32) for x in symtrace.evaluate_torch(roots, B, K=torch.as_tensor(K).t(), P=tp, V=tv, device="cpu")]).numpy()
+    ok = symtrace.decision_margin(roots, B, P=P, V=V, Cw=Cw, K=K) > 1e-5
+    assert ok.mean() > 0.9 and (np.abs(a - b)[:, ok] / np.maximum(1.0, np.abs(a[:, ok]))).max() <= 1e-5

@@ -32,6 +32,17 @@ def test_programs():
         import multiagent_particle_envs_amd as mpe
         e = mpe.MultiAgentEnv(w, sc.reset_world, None, None, compile_program=False)
         envs.append(("random program %d" % seed, e))
+    # reference-style files on the traced path (symtrace.py): the fixtures, and the committed traces of the reference's nine
+    import json
+    from multiagent_particle_envs_amd import refstyle, symtrace, scenarios
+    import multiagent_particle_envs_amd as mpe
+    for name in ("herd", "relay", "convoy"):
+        ts = refstyle.trace_ref_scenario(scenarios.load(os.path.join(ROOT, "tests", "refstyle", name + ".py")).Scenario())
+        envs.append(("traced " + name, mpe.MultiAgentEnv(ts.make_world(4, "cpu"), ts.reset_world, None, None, compile_program=False)))
+    for name in tr.NINE:
+        with open(os.path.join(ROOT, "tests", "golden", "traced_%s.json" % name)) as fh:
+            ts = refstyle.TracedRefScenario(None, symtrace.from_dict(json.load(fh)))
+        envs.append(("traced reference " + name, mpe.MultiAgentEnv(ts.make_world(4, "cpu"), ts.reset_world, None, None, compile_program=False)))
     return envs
 
 

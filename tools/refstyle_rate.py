@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--host-worlds", type=int, default=256)
     args = ap.parse_args()
     here = os.path.dirname(os.path.abspath(__file__))
-    files = args.files or [os.path.join(here, "..", "tests", "refstyle", f) for f in ("herd.py", "relay.py", "patrol.py")]
+    files = args.files or [os.path.join(here, "..", "tests", "refstyle", f) for f in ("herd.py", "relay.py", "convoy.py", "patrol.py")]
     dev = torch.device("cuda", 0)
     for path in files:
         name = os.path.basename(path)
