@@ -950,7 +950,7 @@ def inputs_of(roots):
 # ---- evaluation with NumPy (fp64 by default), vectorised over worlds: the verification, the CPU tests, host-side resets ------
 def decision_margin(roots, B, **state):
     """Per world: how far the nearest of the graph's comparisons is from flipping -- min over its lt / le / eq / ne nodes of
-    |lhs - rhs| (fp64).  Outputs of an fp32 evaluation can legitimately differ from the fp64 one where this is ~1e-6: tests
+    |lhs - rhs| (fp64; the ordering tests `<` / `<=` -- equality tests compare exact data).  Outputs of an fp32 evaluation can legitimately differ from the fp64 one where this is ~1e-6: tests
     compare outside such a band (as the contact-count tests of the fused kernels do)."""
     margin = np.full(B, np.inf)
     evaluate(roots, B, _margin=margin, **state)
@@ -1003,7 +1003,8 @@ def evaluate(roots, B, P=None, V=None, Cw=None, K=None, U=None, dtype=np.float64
                 v = np.log(a[0])
             elif op == "tanh":
                 v = np.tanh(a[0])
-            elif op in _CMP and _margin is not None and not any(x.op == "K" or x.op == "sel" for x in n.args):
+            elif op in ("lt", "le") and _margin is not None and not any(x.op == "K" or x.op == "sel" for x in n.args):
+                # (== / != are tests on exact data -- an utterance that is all zeros, simple_crypto.py:104 -- and hold in fp32 as in fp64)
                 np.minimum(_margin, np.where(np.isfinite(a[0] - a[1]), np.abs(a[0] - a[1]), np.inf), out=_margin)
                 v = {"lt": a[0] < a[1], "le": a[0] <= a[1], "eq": a[0] == a[1], "ne": a[0] != a[1]}[op]
             elif op == "lt":

@@ -217,3 +217,73 @@ def test_fused_rollout_of_a_traced_env_equals_its_per_step_launches():
     with pytest.raises(_abi.MpeError, match="reset_uniform"):
         RandomRollout(h, episode_len=5)
     RandomRollout(h, episode_len=0).enqueue(3)
+
+
+def test_a_traced_done_callback_ends_episodes_inside_the_step_launch():
+    """A reference-style Scenario with a `done(agent, world)` (the reference's done_callback, environment.py:132-135), asked for with
+    done_callback=True: traced like the other callbacks, it becomes the program's done test -- with auto_reset the step, the test
+    and the restart of the finished worlds are one launch -- and agrees with the host path's done rows."""
+    from multiagent_particle_envs_amd import compat
+    compat.install()
+    from multiagent.core import World, Agent, Landmark
+    from multiagent.scenario import BaseScenario
+
+    class Fence(BaseScenario):
+        def make_world(self):
+            world = World()
+            world.agents = [Agent() for _ in range(2)]
+            for i, a in enumerate(world.agents):
+                a.name, a.silent, a.size, a.accel = "agent %d" % i, True, 0.08, 4.0
+            world.landmarks = [Landmark()]
+            world.landmarks[0].name, world.landmarks[0].collide, world.landmarks[0].movable, world.landmarks[0].size = "post", False, False, 0.1
+            self.reset_world(world)
+            return world
+
+        def reset_world(self, world):
+            for a in world.agents:
+                a.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+                a.state.p_vel = np.zeros(world.dim_p)
+                a.state.c = np.zeros(world.dim_c)
+            world.landmarks[0].state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            world.landmarks[0].state.p_vel = np.zeros(world.dim_p)
+
+        def reward(self, agent, world):
+            return -np.sqrt(np.sum(np.square(agent.state.p_pos - world.landmarks[0].state.p_pos)))
+
+        def observation(self, agent, world):
+            return np.concatenate([agent.state.p_vel, agent.state.p_pos, world.landmarks[0].state.p_pos - agent.state.p_pos])
+
+        def done(self, agent, world):
+            if abs(agent.state.p_pos[0]) > 1.05 or abs(agent.state.p_pos[1]) > 1.05:
+                return True
+            return bool(np.sqrt(np.sum(np.square(agent.state.p_pos - world.landmarks[0].state.p_pos))) < 0.12)
+
+    B = 4096
+    a = refstyle.make_ref_env(Fence(), batch_size=B, seed=1, done_callback=True)
+    b = refstyle.make_ref_env(Fence(), batch_size=B, seed=1, done_callback=True, traced=False)
+    assert a.traced and a._prog.has_done and not b.traced
+    seeds = list(range(B))
+    a.reset(seeds=seeds)
+    b.reset(seeds=seeds)
+    rs = np.random.RandomState(0)
+    seen = 0
+    for t in range(6):
+        act = torch.as_tensor(np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=(2, B))]).cuda()
+        (_, _, da, _), (_, _, db, _) = a.step(act), b.step([act[0], act[1]])
+        tr = a.scenario.t
+        P, V = a.world.get_state(all_entities=True)
+        ok = symtrace.decision_margin([d for d in tr.done], B, P=P.astype(np.float64), V=V.astype(np.float64), Cw=np.zeros((B, 2, 0)),
+                                      K=np.zeros((B, 0), np.int64)) > 2e-6
+        for i in range(2):
+            assert np.array_equal(da[i].cpu().numpy()[ok], db[i].cpu().numpy()[ok]), (t, i)
+            seen += int(da[i].sum())
+    assert seen > 20                                                   # worlds did finish (walked out / reached the post)
+    # with auto_reset the finished worlds restart inside the launch (the reset is World.reset_uniform's placement)
+    c = refstyle.make_ref_env(Fence(), batch_size=B, seed=1, done_callback=True, max_episode_steps=50, auto_reset=True)
+    assert c.traced and c._episode_in_launch
+    c.reset(seeds=seeds)
+    rs = np.random.RandomState(0)
+    for t in range(6):
+        act = torch.as_tensor(np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=(2, B))]).cuda()
+        _, _, dc, _ = c.step(act)
+    assert int(c.episode_step.max()) == 6 and int((c.episode_step < 6).sum()) > 10      # some worlds restarted on the way
