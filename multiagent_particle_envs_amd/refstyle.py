@@ -436,7 +436,7 @@ def _trace_cache_path(scenario, want_done):
         files = [inspect.getsourcefile(symtrace)]
         for klass in type(scenario).__mro__:
             if klass.__module__ not in ("builtins",) and not klass.__module__.startswith(__name__.rsplit(".", 1)[0] + "."):
-                f = inspect.getsourcefile(klass)
+                f = symtrace.source_file(klass)
                 if f not in files:
                     files.append(f)
         for f in files:

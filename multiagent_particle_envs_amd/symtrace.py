@@ -378,6 +378,350 @@ def sym_all(it):
 _INJECTED = {"min": sym_min, "max": sym_max, "any": sym_any, "all": sym_all}
 
 
+# ---- predication: `if`s that only assign, conditional expressions, early returns and and / or / not WITHOUT forking ---------------
+# Forking doubles the paths with every symbolic `if`: a reward that tests every other agent (`if self.is_collision(a, agent):
+# rew -= 1`, simple_spread.py:78-81) has 2^(N-1) of them.  Most such `if`s only choose between VALUES, and a value can be chosen
+# without leaving the path: the file is re-compiled (its own source, a copy of its module; the file itself is not touched) with
+#     X if T else Y                      ->  select(T, X, Y)                 when T is symbolic
+#     if T: a = ..; b += ..  [else: ..]  ->  both branches run, a and b become select(T, then-value, else-value)
+#     if T: return X   ... return Z      ->  return select(T, X, ... Z)
+#     A and B, A or B, not A             ->  logical nodes
+# whenever the test is symbolic, and exactly the original statement when it is an ordinary Python value; anything else (a branch that
+# appends, continues, calls for side effects) still forks.  The twin is only TRACED; what the trace is verified against -- and what
+# the host path runs -- is the original file's code.
+_UNSET = object()
+
+
+class _CannotMerge(Exception):
+    pass
+
+
+def _is_symbolic(x):
+    return isinstance(x, (Sym, SymBool))
+
+
+def _truth_node(t):
+    if isinstance(t, SymBool):
+        return t.n
+    return _Ctx.graph.compare("ne", t.n, _Ctx.graph.const(0.0))
+
+
+def _select_any(t, a, b):
+    """the value `a if t else b` for a symbolic t, when a and b are values that can be merged"""
+    g = _Ctx.graph
+    if a is b:
+        return a
+    if a is _UNSET or b is _UNSET:
+        raise _CannotMerge()
+    c = _truth_node(t)
+    boolish = (bool, np.bool_, SymBool)
+    if isinstance(a, boolish) and isinstance(b, boolish):
+        return SymBool(g.ite(c, _blift(a), _blift(b)))
+    scalar = (int, float, bool, np.integer, np.floating, np.bool_, Sym, SymBool)
+    if isinstance(a, scalar) and isinstance(b, scalar):
+        return Sym(g.ite(c, _lift(a), _lift(b)))
+    if isinstance(a, np.ndarray) and isinstance(b, (np.ndarray, list, tuple)) or isinstance(b, np.ndarray) and isinstance(a, (list, tuple)):
+        aa, bb = np.asarray(a, dtype=object), np.asarray(b, dtype=object)
+        if aa.shape != bb.shape:
+            raise _CannotMerge()
+        out = np.empty(aa.size, dtype=object)
+        out[:] = [_select_any(t, x, y) for x, y in zip(aa.reshape(-1), bb.reshape(-1))]
+        return out.reshape(aa.shape)
+    if isinstance(a, (list, tuple)) and type(a) is type(b) and len(a) == len(b):
+        return type(a)(_select_any(t, x, y) for x, y in zip(a, b))
+    if a is None or b is None or type(a) is not type(b):
+        raise _CannotMerge()
+    try:
+        if a == b:
+            return a
+    except Exception:
+        pass
+    raise _CannotMerge()
+
+
+def _p_ifexp(t, fa, fb):
+    if not _is_symbolic(t):
+        return fa() if t else fb()
+    try:
+        return _select_any(t, fa(), fb())
+    except _CannotMerge:
+        return fa() if bool(t) else fb()          # (forks)
+
+
+def _p_and(*fs):
+    acc = fs[0]()
+    for f in fs[1:]:
+        if not _is_symbolic(acc):
+            if not acc:
+                return acc
+            acc = f()
+            continue
+        nxt = f()                                   # (no short circuit on a symbolic left side: the operands are expressions)
+        if isinstance(nxt, (bool, np.bool_, SymBool)) or _is_symbolic(nxt):
+            acc = SymBool(_Ctx.graph.logical("and", _truth_node(acc), _blift(nxt) if not isinstance(nxt, Sym) else _truth_node(nxt)))
+        else:
+            acc = nxt if bool(acc) else acc
+    return acc
+
+
+def _p_or(*fs):
+    acc = fs[0]()
+    for f in fs[1:]:
+        if not _is_symbolic(acc):
+            if acc:
+                return acc
+            acc = f()
+            continue
+        nxt = f()
+        if isinstance(nxt, (bool, np.bool_, SymBool)) or _is_symbolic(nxt):
+            acc = SymBool(_Ctx.graph.logical("or", _truth_node(acc), _blift(nxt) if not isinstance(nxt, Sym) else _truth_node(nxt)))
+        else:
+            acc = acc if bool(acc) else nxt
+    return acc
+
+
+def _p_not(x):
+    if isinstance(x, SymBool):
+        return ~x
+    if isinstance(x, Sym):
+        return SymBool(_Ctx.graph.lnot(_truth_node(x)))
+    return not x
+
+
+def _p_snap(x):
+    """the value of a target as it is now (a list that a branch may append to: a copy)"""
+    return list(x) if type(x) is list else x
+
+
+_PREDICATION_HELPERS = {"_mpe_snap": _p_snap, "_mpe_sym": _is_symbolic, "_mpe_sel": _select_any, "_mpe_ifexp": _p_ifexp, "_mpe_and": _p_and,
+                        "_mpe_or": _p_or, "_mpe_not": _p_not, "_MPE_UNSET": _UNSET, "_mpe_CannotMerge": _CannotMerge}
+
+
+def _predicate_tree(tree):
+    import ast
+
+    counter = [0]
+
+    def lam(expr):
+        return ast.Lambda(args=ast.arguments(posonlyargs=[], args=[], vararg=None, kwonlyargs=[], kw_defaults=[], kwarg=None, defaults=[]),
+                          body=expr)
+
+    def call(name, *args):
+        return ast.Call(func=ast.Name(id=name, ctx=ast.Load()), args=list(args), keywords=[])
+
+    def simple_target(t):
+        if isinstance(t, ast.Name):
+            return True
+        if isinstance(t, ast.Subscript):       # in_forest[0] = ...: an element of something that exists
+            return isinstance(t.value, ast.Name) and isinstance(t.slice, (ast.Constant, ast.Name))
+        return False
+
+    def is_append(st):
+        return isinstance(st, ast.Expr) and isinstance(st.value, ast.Call) and isinstance(st.value.func, ast.Attribute) and \
+            st.value.func.attr == "append" and isinstance(st.value.func.value, ast.Name) and len(st.value.args) == 1 and \
+            not st.value.keywords
+
+    def assign_only(stmts):
+        """statements that only assign to local names / constant-indexed elements, or append to local lists (ifs of such,
+        recursively)"""
+        for st in stmts:
+            if isinstance(st, ast.Pass) or is_append(st):
+                continue
+            if isinstance(st, ast.Assign) and len(st.targets) == 1 and simple_target(st.targets[0]):
+                continue
+            if isinstance(st, ast.AugAssign) and simple_target(st.target):
+                continue
+            if isinstance(st, ast.If) and assign_only(st.body) and assign_only(st.orelse):
+                continue
+            return False
+        return True
+
+    def targets_of(stmts, out):
+        import copy
+        for st in stmts:
+            if isinstance(st, ast.Assign):
+                t = st.targets[0]
+            elif isinstance(st, ast.AugAssign):
+                t = st.target
+            elif isinstance(st, ast.If):
+                targets_of(st.body, out)
+                targets_of(st.orelse, out)
+                continue
+            elif is_append(st):
+                t = ast.Name(id=st.value.func.value.id, ctx=ast.Store())      # the list itself is the value that changes
+            else:
+                continue
+            key = ast.dump(t)
+            if key not in out:
+                out[key] = copy.deepcopy(t)
+        return out
+
+    def as_load(t):
+        import copy
+        t = copy.deepcopy(t)
+        for n in ast.walk(t):
+            if hasattr(n, "ctx"):
+                n.ctx = ast.Load()
+        return t
+
+    def as_store(t):
+        import copy
+        t = copy.deepcopy(t)
+        t.ctx = ast.Store()
+        return t
+
+    class T(ast.NodeTransformer):
+        def visit_IfExp(self, node):
+            self.generic_visit(node)
+            return call("_mpe_ifexp", node.test, lam(node.body), lam(node.orelse))
+
+        def visit_BoolOp(self, node):
+            self.generic_visit(node)
+            return call("_mpe_and" if isinstance(node.op, ast.And) else "_mpe_or", *[lam(v) for v in node.values])
+
+        def visit_UnaryOp(self, node):
+            self.generic_visit(node)
+            if isinstance(node.op, ast.Not):
+                return call("_mpe_not", node.operand)
+            return node
+
+        def _returns_chain(self, stmts):
+            """[if T: return X]* return Z  ->  the expression select(T, X, ...Z), or None"""
+            if len(stmts) == 1 and isinstance(stmts[0], ast.Return) and stmts[0].value is not None:
+                return stmts[0].value
+            st = stmts[0] if stmts else None
+            if isinstance(st, ast.If) and not st.orelse and len(st.body) == 1 and isinstance(st.body[0], ast.Return) and \
+                    st.body[0].value is not None and len(stmts) > 1:
+                rest = self._returns_chain(stmts[1:])
+                if rest is not None:
+                    return call("_mpe_ifexp", st.test, lam(st.body[0].value), lam(rest))
+            return None
+
+        def _block(self, stmts):
+            """a statement list: early-return chains at its end become one return"""
+            out = []
+            for k, st in enumerate(stmts):
+                if isinstance(st, ast.If) and not st.orelse and len(st.body) == 1 and isinstance(st.body[0], ast.Return):
+                    chain = self._returns_chain(stmts[k:])
+                    if chain is not None:
+                        out.append(ast.Return(value=chain))
+                        return out
+                out.append(st)
+            return out
+
+        def visit_FunctionDef(self, node):
+            self.generic_visit(node)
+            node.body = self._block(node.body)
+            return node
+
+        def visit_If(self, node):
+            ok = assign_only(node.body) and assign_only(node.orelse)        # (judged on the file's own statements ...)
+            tg = list(targets_of(node.body + node.orelse, {}).values()) if ok else []
+            self.generic_visit(node)                                        # (... the nested ifs inside are predicated first)
+            if not ok:
+                return node
+            k = counter[0]
+            counter[0] += 1
+            tv = "_mpe_t%d" % k
+            stmts = [ast.Assign(targets=[ast.Name(id=tv, ctx=ast.Store())], value=node.test)]
+            plain = ast.If(test=ast.Name(id=tv, ctx=ast.Load()), body=node.body, orelse=node.orelse)
+            sym = []
+            # snapshot (a name that does not exist yet: UNSET)
+            for j, t in enumerate(tg):
+                sv = "_mpe_s%d_%d" % (k, j)
+                sym.append(ast.Try(body=[ast.Assign(targets=[ast.Name(id=sv, ctx=ast.Store())], value=call("_mpe_snap", as_load(t)))],
+                                   handlers=[ast.ExceptHandler(type=ast.Tuple(elts=[ast.Name(id="NameError", ctx=ast.Load()),
+                                                                                     ast.Name(id="IndexError", ctx=ast.Load()),
+                                                                                     ast.Name(id="KeyError", ctx=ast.Load())], ctx=ast.Load()),
+                                                               name=None,
+                                                               body=[ast.Assign(targets=[ast.Name(id=sv, ctx=ast.Store())],
+                                                                                value=ast.Name(id="_MPE_UNSET", ctx=ast.Load()))])],
+                                   orelse=[], finalbody=[]))
+            import copy
+
+            def grab(prefix):
+                res = []
+                for j, t in enumerate(tg):
+                    res.append(ast.Try(body=[ast.Assign(targets=[ast.Name(id="%s%d_%d" % (prefix, k, j), ctx=ast.Store())], value=call("_mpe_snap", as_load(t)))],
+                                       handlers=[ast.ExceptHandler(type=ast.Name(id="NameError", ctx=ast.Load()), name=None,
+                                                                   body=[ast.Assign(targets=[ast.Name(id="%s%d_%d" % (prefix, k, j), ctx=ast.Store())],
+                                                                                    value=ast.Name(id="_MPE_UNSET", ctx=ast.Load()))])],
+                                       orelse=[], finalbody=[]))
+                return res
+
+            def restore():
+                res = []
+                for j, t in enumerate(tg):
+                    sv = "_mpe_s%d_%d" % (k, j)
+                    # (a name that did not exist is left as the branch left it: it is UNSET in the snapshot and cannot merge unless both
+                    #  branches define it)
+                    gone = [ast.Pass()]
+                    if isinstance(t, ast.Name):      # a name the branch created: it does not exist on the other side
+                        gone = [ast.Try(body=[ast.Delete(targets=[ast.Name(id=t.id, ctx=ast.Del())])],
+                                        handlers=[ast.ExceptHandler(type=ast.Name(id="NameError", ctx=ast.Load()), name=None, body=[ast.Pass()])],
+                                        orelse=[], finalbody=[])]
+                    res.append(ast.If(test=ast.Compare(left=ast.Name(id=sv, ctx=ast.Load()), ops=[ast.IsNot()],
+                                                       comparators=[ast.Name(id="_MPE_UNSET", ctx=ast.Load())]),
+                                      body=[ast.Assign(targets=[as_store(t)], value=call("_mpe_snap", ast.Name(id=sv, ctx=ast.Load())))],
+                                      orelse=gone))
+                return res
+            merged = []
+            for j, t in enumerate(tg):
+                merged.append(ast.Assign(targets=[as_store(t)],
+                                         value=call("_mpe_sel", ast.Name(id=tv, ctx=ast.Load()), ast.Name(id="_mpe_a%d_%d" % (k, j), ctx=ast.Load()),
+                                                    ast.Name(id="_mpe_b%d_%d" % (k, j), ctx=ast.Load()))))
+            sym += copy.deepcopy(node.body) + grab("_mpe_a") + restore() + (copy.deepcopy(node.orelse) or [ast.Pass()]) + grab("_mpe_b")
+            # merge -- or, where a value cannot be merged (defined on one side only, objects): put the state back and fork
+            sym.append(ast.Try(body=merged,
+                               handlers=[ast.ExceptHandler(type=ast.Name(id="_mpe_CannotMerge", ctx=ast.Load()), name=None,
+                                                           body=restore() + [copy.deepcopy(plain)])],
+                               orelse=[], finalbody=[]))
+            stmts.append(ast.If(test=call("_mpe_sym", ast.Name(id=tv, ctx=ast.Load())), body=sym, orelse=[plain]))
+            return stmts
+
+    tree = T().visit(tree)
+    ast.fix_missing_locations(tree)
+    return tree
+
+
+def source_file(klass):
+    """The file a class was defined in, through its methods' code objects (a scenario file executed by path is in no sys.modules,
+    so inspect.getsourcefile does not find it)."""
+    import inspect
+    import types
+    for f in klass.__dict__.values():
+        f = getattr(f, "__func__", f)
+        if isinstance(f, types.FunctionType):
+            return f.__code__.co_filename
+    return inspect.getsourcefile(klass)
+
+
+def predicated_twin(scenario):
+    """A twin of `scenario` whose class was re-compiled from its own source with value-only control flow predicated (above); the
+    twin shares the scenario's instance attributes.  Raises TraceUnsupported when the source is not available / does not recompile."""
+    import ast
+    import inspect
+    import sys
+    klass = type(scenario)
+    try:
+        path = source_file(klass)
+        with open(path) as fh:
+            source = fh.read()
+        tree = _predicate_tree(ast.parse(source, filename=path))
+        code = compile(tree, path, "exec")
+        space = {"__name__": klass.__module__ + "__predicated", "__file__": path}
+        space.update(_PREDICATION_HELPERS)
+        exec(code, space)
+        twin_class = space[klass.__name__]
+    except TraceUnsupported:
+        raise
+    except Exception as e:
+        raise TraceUnsupported("the file's source could not be re-compiled for predication (%s: %s)" % (type(e).__name__, e))
+    twin = twin_class.__new__(twin_class)
+    twin.__dict__.update(scenario.__dict__)
+    return twin
+
+
 # ---- control flow: every path of a callback, merged -------------------------------------------------------------------------
 class Tracer(object):
     """Runs a callback once per control-flow path.  `decide` answers a symbolic condition: by the forced prefix while it
@@ -823,9 +1167,29 @@ def _trace_once(scenario, t, forced, want_done, max_paths):
 _MAX_ENUMERATED = 64      # traces per scenario when picks have to be enumerated (product of their population sizes)
 
 
-def trace(scenario, want_done=False, max_paths=None):
+def trace(scenario, want_done=False, max_paths=None, predicate=True):
     """Trace `scenario` (a reference-style Scenario object: make_world(self), reset_world(self, world), NumPy callbacks).
-    Raises TraceUnsupported when the file is outside what the tracer models."""
+    Raises TraceUnsupported when the file is outside what the tracer models.  predicate: trace a twin of the scenario whose
+    value-only control flow does not fork (predicated_twin); where that twin cannot be built or traced, the scenario itself."""
+    if predicate:
+        try:
+            t = _trace(predicated_twin(scenario), want_done, max_paths)
+            t.predicated = True
+            return t
+        except TraceUnsupported as e:
+            first = e
+        try:
+            t = _trace(scenario, want_done, max_paths)
+        except TraceUnsupported as e:
+            raise TraceUnsupported("%s (with predicated control flow: %s)" % (e, first))
+        t.predicated = False
+        return t
+    t = _trace(scenario, want_done, max_paths)
+    t.predicated = False
+    return t
+
+
+def _trace(scenario, want_done=False, max_paths=None):
     import itertools
     t = Traced()
     g = t.graph

@@ -344,3 +344,97 @@ def test_the_torch_evaluator_of_a_reset_program_agrees_with_the_numpy_one():
     b = torch.stack([x.to(torch.float32) for x in symtrace.evaluate_torch(roots, B, K=torch.as_tensor(K).t(), P=tp, V=tv, device="cpu")]).numpy()
     ok = symtrace.decision_margin(roots, B, P=P, V=V, Cw=Cw, K=K) > 1e-5
     assert ok.mean() > 0.9 and (np.abs(a - b)[:, ok] / np.maximum(1.0, np.abs(a[:, ok]))).max() <= 1e-5
+
+
+# ---- predication: value-only control flow without forks (symtrace.predicated_twin) --------------------------------------------------
+_PREDICATION_FILE = '''
+import numpy as np
+from multiagent.core import World, Agent, Landmark
+from multiagent.scenario import BaseScenario
+
+
+class Scenario(BaseScenario):
+    def make_world(self):
+        world = World()
+        world.dim_c = 2
+        world.agents = [Agent() for _ in range(N_AGENTS)]
+        for i, a in enumerate(world.agents):
+            a.name, a.silent, a.size, a.lead = "agent %d" % i, True, 0.08, i == 0
+        world.landmarks = [Landmark() for _ in range(2)]
+        for l in world.landmarks:
+            l.movable, l.collide, l.size = False, False, 0.1
+        self.reset_world(world)
+        return world
+
+    def reset_world(self, world):
+        for e in world.agents + world.landmarks:
+            e.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            e.state.p_vel = np.zeros(world.dim_p)
+        for a in world.agents:
+            a.state.c = np.zeros(world.dim_c)
+
+    def touching(self, a, b):
+        return True if np.sqrt(np.sum(np.square(a.state.p_pos - b.state.p_pos))) < a.size + b.size else False      # a conditional expression
+
+    def band(self, x):                      # early returns
+        if x < 0.2:
+            return 0
+        if x < 0.5:
+            return (x - 0.2) * 3
+        return min(np.exp(x - 0.5), 2.0)
+
+    def reward(self, agent, world):
+        rew = 0
+        for other in world.agents:          # an `if` per other agent that only assigns: 2^(N-1) paths when it forks
+            if other is not agent and self.touching(other, agent):
+                rew -= 1
+        x = abs(agent.state.p_pos[0])
+        if x > 0.9:                         # if / elif / else of assignments; `bonus` exists on every branch
+            bonus = -x
+        elif x > 0.5 and not agent.lead:
+            bonus = 0.25
+        else:
+            bonus = 0.0
+        if agent.state.p_pos[1] > 0.3:      # a name that exists on ONE side only: cannot be merged, this `if` forks
+            extra = 1.0
+            rew += extra
+        return rew + bonus - self.band(abs(agent.state.p_pos[1]))
+
+    def observation(self, agent, world):
+        seen, flags = [], [np.array([-1.0]), np.array([-1.0])]
+        for k, l in enumerate(world.landmarks):
+            if self.touching(agent, l) or agent.lead:       # branches that APPEND, and an element assignment
+                seen.append(l.state.p_pos - agent.state.p_pos)
+                flags[k] = np.array([1.0])
+            else:
+                seen.append([0, 0])
+        return np.concatenate([agent.state.p_vel, agent.state.p_pos] + seen + flags)
+'''
+
+
+@pytest.mark.parametrize("n_agents", [3, 14])
+def test_value_only_control_flow_is_predicated_not_forked(tmp_path, n_agents):
+    path = tmp_path / ("predication_%d.py" % n_agents)
+    path.write_text(_PREDICATION_FILE.replace("N_AGENTS", str(n_agents)))
+    sc = mpe.scenarios.load(str(path)).Scenario()
+    t = symtrace.trace(sc)
+    assert t.predicated and t.paths["obs"] == [1] * n_agents and t.paths["rew"] == [2] * n_agents      # (the one `if` that cannot merge)
+    assert symtrace.verify(sc, t, worlds=300) == 0.0
+    if n_agents == 3:          # the forking trace of the same file: more paths, the same function
+        f = symtrace.trace(sc, predicate=False)
+        assert not f.predicated and f.paths["rew"][0] > 20 and f.paths["obs"][1] == 4 and symtrace.verify(sc, f, worlds=300) == 0.0
+    else:                      # 13 other agents: 2^13 paths per agent for the forking tracer -- refused; predicated: instant
+        with pytest.raises(symtrace.TraceUnsupported, match="control-flow paths"):
+            symtrace.trace(sc, predicate=False)
+
+
+def test_the_fixtures_and_committed_traces_hardly_fork():
+    for name in ("herd", "relay", "convoy"):
+        sc = mpe.scenarios.load(os.path.join(FIXTURES, name + ".py")).Scenario()
+        t = symtrace.trace(sc)
+        assert t.predicated and max(t.paths["obs"] + t.paths["rew"]) == 1, (name, t.paths)
+    for name in NINE:
+        with open(os.path.join(GOLDEN, "traced_%s.json" % name)) as fh:
+            paths = json.load(fh)["paths"]
+        # (simple_crypto compares utterances element by element through NumPy's `==` and `continue`s: that still forks)
+        assert max(paths["obs"] + paths["rew"]) == (256 if name == "simple_crypto" else 1), (name, paths)
