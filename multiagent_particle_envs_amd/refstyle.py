@@ -275,6 +275,8 @@ class TracedRefScenario(object):
         self.scenario, self.t = scenario, traced
         self.landmark_range, self.device_reset = self._uniform_pattern()
         self._source = None
+        self._info = None          # benchmark_data's program, built when first asked for
+        self._env = None           # weak reference to the env (its utterance buffer), set by make_traced_env
 
     # ---- reset_world ------------------------------------------------------------------------------------------------------
     def _uniform_pattern(self):
@@ -425,13 +427,29 @@ class TracedRefScenario(object):
             return None
         return rowspec.DoneSpec(world, agent).code(self._hash(world))
 
+    # ---- benchmark_data (make_env(..., benchmark=True)): traced too, evaluated by one more launch after the step -------------
+    def benchmark_data(self, agent, world):
+        """The file's benchmark_data(agent, world) for all worlds: the info graphs run as a second row program over the post-step
+        state (one `mpe_rows` launch per step, issued when the env asks for the first agent's), delivered in the file's own
+        structure.  (With auto_reset, a world that restarted in this step reports its new episode's first state.)"""
+        if self.t.info is None:
+            return {}
+        i = world.agents.index(agent)
+        if self._info is None:
+            self._info = _InfoProgram(self, world)
+        if i == 0:
+            env = self._env() if self._env is not None else None
+            comm = getattr(env, "_comm", None) if env is not None else None
+            self._info.launch(world, comm, _abi.raw_stream(world.device))
+        return self._info.deliver(i, self.t.info_desc[i], world.batch_size)
+
 
 def _trace_cache_path(scenario, want_done):
     """lib/rows_cache/trace_<sha256 of the scenario's source files + the tracer's>.json, or None when the sources cannot be read."""
     import hashlib
     import inspect
     from . import _build, symtrace
-    h = hashlib.sha256(b"trace format 1, done %d;" % int(bool(want_done)))
+    h = hashlib.sha256(("trace format 1, %r;" % (want_done,)).encode())
     try:
         files = [inspect.getsourcefile(symtrace)]
         for klass in type(scenario).__mro__:
@@ -447,13 +465,86 @@ def _trace_cache_path(scenario, want_done):
     return os.path.join(_build.ROWS_CACHE, "trace_%s.json" % h.hexdigest()[:32])
 
 
-def trace_ref_scenario(scenario, want_done=False, verify_worlds=64, cache=True):
+class _InfoProgram(object):
+    """benchmark_data of a traced scenario as a second row program: its "rows" are the info values (one launch of mpe_rows after
+    the step), delivered in the structure the file returns -- numbers as [B] tensors (ints / bools as int32), arrays as [B, n],
+    tuples as tuples."""
+
+    def __init__(self, ts, world, compile=True):
+        import ctypes as C
+        import hashlib
+        from . import rowspec, symtrace
+        t = ts.t
+
+        class _T(object):
+            pass
+        ti = _T()
+        ti.obs, ti.rew, ti.done = t.info, [t.graph.const(0.0)] * t.A, [None] * t.A
+        self.source = symtrace.hip_source(ti)
+        h = int.from_bytes(hashlib.sha256(self.source.encode()).digest()[:8], "little")
+        self.widths = [len(row) for row in t.info]
+        obs = [rowspec.ObsSpec(world, a).code(self.widths[i], h) if self.widths[i] else rowspec.ObsSpec(world, a)
+               for i, a in enumerate(world.agents)]
+        rew = [rowspec.RewardSpec(world, a) for a in world.agents]
+        if not any(self.widths):
+            self.prog = None
+            return
+        self.prog = rowspec.RowProgram(world, obs, rew, source=self.source)
+        src = world.scenario_desc(_abi.MPE_SCN_GENERIC)
+        d = _abi.MpeScenarioDesc()
+        C.memmove(C.byref(d), C.byref(src), C.sizeof(d))
+        off = [0]
+        for wd in self.widths:
+            off.append(off[-1] + wd)
+        for i, o in enumerate(off):
+            d.obs_off[i] = o
+        d.collaborative = 0
+        self.desc, self.off = d, off
+        self.prog.validate(d)
+        if compile:
+            self.prog.compile(d)
+        self.rows = torch.zeros(off[-1] * world.batch_size, dtype=torch.float32, device=world.device)
+
+    def launch(self, world, comm, stream):
+        import ctypes as C
+        if self.prog is None:
+            return
+        b = _abi.MpeBuffers()
+        b.pos, b.vel, b.obs = world.pos.data_ptr(), world.vel.data_ptr(), self.rows.data_ptr()
+        if world.choice_i32 is not None:
+            b.choice = world.choice_i32.data_ptr()
+        if comm is not None:
+            b.comm = comm.data_ptr()
+        _abi.check(_abi.lib().mpe_rows(C.byref(self.desc), C.byref(b), self.prog.ref, world.batch_size, stream), "mpe_rows (benchmark_data)")
+
+    def deliver(self, i, desc, B):
+        if self.prog is None or not self.widths[i]:
+            return {}
+        rows = self.rows[self.off[i] * B: self.off[i + 1] * B].view(B, self.widths[i])
+        pos = [0]
+
+        def build(d):
+            if d[0] == "none":
+                return {}
+            if d[0] == "s":
+                col = rows[:, pos[0]]
+                pos[0] += 1
+                return col.round().to(torch.int32) if d[1] == "i" else col.clone()
+            if d[0] == "a":
+                blk = rows[:, pos[0]:pos[0] + d[1]]
+                pos[0] += d[1]
+                return blk.round().to(torch.int32) if d[2] == "i" else blk.clone()
+            return tuple(build(x) for x in d[1])
+        return build(desc)
+
+
+def trace_ref_scenario(scenario, want_done=False, verify_worlds=64, cache=True, want_info=False):
     """symtrace.trace + symtrace.verify -> TracedRefScenario; raises symtrace.TraceUnsupported (with the reason) when the
     file is outside what the tracer models or the trace does not reproduce the file's own callbacks.  The trace is cached by
     the content of the file (simple_world_comm's 4096 paths per agent take seconds); the verification runs every time."""
     import json
     from . import symtrace
-    path = _trace_cache_path(scenario, want_done) if cache else None
+    path = _trace_cache_path(scenario, (bool(want_done), bool(want_info))) if cache else None
     t = None
     if path is not None and os.path.exists(path):
         try:
@@ -462,7 +553,7 @@ def trace_ref_scenario(scenario, want_done=False, verify_worlds=64, cache=True):
         except (ValueError, KeyError, symtrace.TraceUnsupported):
             t = None
     if t is None:
-        t = symtrace.trace(scenario, want_done=want_done)
+        t = symtrace.trace(scenario, want_done=want_done, want_info=want_info)
         if path is not None:
             try:
                 os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -480,7 +571,7 @@ def trace_ref_scenario(scenario, want_done=False, verify_worlds=64, cache=True):
     return TracedRefScenario(scenario, t)
 
 
-def make_traced_env(ts, batch_size, device=None, seed=0, max_episode_steps=None, auto_reset=False, fresh_outputs=False):
+def make_traced_env(ts, batch_size, device=None, seed=0, max_episode_steps=None, auto_reset=False, fresh_outputs=False, benchmark=False):
     """The env of a TracedRefScenario (or of a symtrace.Traced / its to_dict() data: a trace made elsewhere)."""
     from . import symtrace
     from .environment import MultiAgentEnv
@@ -494,9 +585,14 @@ def make_traced_env(ts, batch_size, device=None, seed=0, max_episode_steps=None,
     world.seed = seed
     world.rng_mode = "device"
     ts.reset_world(world)
-    env = MultiAgentEnv(world, ts.reset_world, None, None, None, None, fresh_outputs=fresh_outputs, fused=True,
+    info_cb = ts.benchmark_data if benchmark and ts.t.info is not None else None
+    env = MultiAgentEnv(world, ts.reset_world, None, None, info_cb, None, fresh_outputs=fresh_outputs, fused=True,
                         max_episode_steps=max_episode_steps, auto_reset=auto_reset, compile_program=True)
     env.scenario, env.ref_scenario, env.traced, env.trace_fallback = ts, ts.scenario, True, None
+    import weakref
+    ts._env = weakref.ref(env)
+    if info_cb is not None:
+        ts.benchmark_data(world.agents[0], world)      # (build and compile the info program now, not at the first step)
     return env
 
 
@@ -521,17 +617,19 @@ def make_ref_env(scenario, benchmark=False, batch_size=None, device=None, seed=0
 
     traced (batched envs on a HIP device): None -- trace the file's callbacks into a compiled row program when that works
     (one launch per step; `env.traced` says whether, `env.trace_fallback` why not), else the host path; True -- trace or
-    raise; False -- always the host path (B shadow worlds, the file's callbacks per world)."""
+    raise; False -- always the host path (B shadow worlds, the file's callbacks per world).  benchmark=True: the file's
+    benchmark_data is traced as well (one more launch per step); on the host path it is evaluated per world."""
     from .environment import MultiAgentEnv
     compat = batch_size is None
     why = None
-    if traced is not False and not compat and not benchmark:
+    if traced is not False and not compat:
         from . import symtrace
         try:
             want_done = bool(done_callback) and hasattr(scenario, "done")
-            ts = trace_ref_scenario(scenario, want_done=want_done)
+            want_info = bool(benchmark) and hasattr(scenario, "benchmark_data")
+            ts = trace_ref_scenario(scenario, want_done=want_done, want_info=want_info)
             return make_traced_env(ts, batch_size, device=device, seed=seed, max_episode_steps=max_episode_steps,
-                                   auto_reset=auto_reset, fresh_outputs=fresh_outputs)
+                                   auto_reset=auto_reset, fresh_outputs=fresh_outputs, benchmark=want_info)
         except (symtrace.TraceUnsupported, _abi.MpeError, RuntimeError) as e:
             if traced:
                 raise
@@ -539,7 +637,7 @@ def make_ref_env(scenario, benchmark=False, batch_size=None, device=None, seed=0
             if verbose:
                 print("reference-style scenario on the host path (%s)" % why)
     elif traced:
-        raise _abi.MpeError("traced=True needs batch_size (a batched env) and benchmark=False")
+        raise _abi.MpeError("traced=True needs batch_size (a batched env)")
     ad = RefScenarioAdapter(scenario, 1 if compat else int(batch_size), device, host_outputs=compat)
     world = ad.world
     world.seed = seed

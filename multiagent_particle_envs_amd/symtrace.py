@@ -1006,6 +1006,48 @@ def _truth(raw):
     raise TraceUnsupported("done returned %r" % type(raw).__name__)
 
 
+def _describe_info(raw):
+    """The shape of what benchmark_data returns, from a CONCRETE call: ("s", kind) a number, ("a", n, kind) an array of n numbers,
+    ("t", [..]) a tuple, ("none",) an empty dict; kind "i" (ints / bools: delivered as int32) or "f"."""
+    if isinstance(raw, dict) and not raw:
+        return ("none",)
+    if isinstance(raw, (bool, np.bool_, int, np.integer)):
+        return ("s", "i")
+    if isinstance(raw, (float, np.floating)):
+        return ("s", "f")
+    if isinstance(raw, np.ndarray):
+        if raw.ndim == 0:
+            return ("s", "i" if raw.dtype.kind in "iub" else "f")
+        return ("a", int(raw.size), "i" if raw.dtype.kind in "iub" else "f")
+    if isinstance(raw, (tuple, list)):
+        return ("t", [_describe_info(x) for x in raw])
+    raise TraceUnsupported("benchmark_data returns %r" % type(raw).__name__)
+
+
+def _info_width(desc):
+    return {"none": 0, "s": 1}.get(desc[0], None) if desc[0] in ("none", "s") else (desc[1] if desc[0] == "a" else sum(_info_width(d) for d in desc[1]))
+
+
+def _flatten_info(raw, desc):
+    """One path's return value of benchmark_data -> list of Nodes, in the order of `desc`."""
+    if desc[0] == "none":
+        if not (isinstance(raw, dict) and not raw):
+            raise TraceUnsupported("benchmark_data returns different structures on different paths")
+        return []
+    if desc[0] == "s":
+        if isinstance(raw, np.ndarray):
+            raw = raw.reshape(-1)[0]
+        return [_lift(raw)]
+    if desc[0] == "a":
+        a = np.asarray(raw, dtype=object).reshape(-1)
+        if a.size != desc[1]:
+            raise TraceUnsupported("benchmark_data returns arrays of different sizes on different paths")
+        return [_lift(x) for x in a]
+    if not isinstance(raw, (tuple, list)) or len(raw) != len(desc[1]):
+        raise TraceUnsupported("benchmark_data returns different structures on different paths")
+    return [n for x, d in zip(raw, desc[1]) for n in _flatten_info(x, d)]
+
+
 class Traced(object):
     """What tracing a reference-style scenario yields: per-agent graphs over the state + the reset program.
 
@@ -1046,6 +1088,8 @@ def to_dict(t):
             "reset_pos": [[n.uid for n in e] for e in t.reset_pos], "reset_vel": [[n.uid for n in e] for e in t.reset_vel],
             "reset_c": [[n.uid for n in a] for a in t.reset_c],
             "draws": [list(d) for d in t.draws], "pops": list(t.pops), "n_u": t.n_u, "A": t.A, "E": t.E, "dim_c": t.dim_c,
+            "info": None if getattr(t, "info", None) is None else [[n.uid for n in row] for row in t.info],
+            "info_desc": getattr(t, "info_desc", None),
             "collaborative": bool(t.collaborative), "paths": t.paths, "enumerated": list(getattr(t, "enumerated", [])),
             "world": {k: getattr(w, k) for k in _WLD_KEYS},
             "discrete_action": getattr(w, "discrete_action", None),
@@ -1071,6 +1115,10 @@ def from_dict(d):
     t.reset_pos = [[nodes[u] for u in e] for e in d["reset_pos"]]
     t.reset_vel = [[nodes[u] for u in e] for e in d["reset_vel"]]
     t.reset_c = [[nodes[u] for u in a] for a in d["reset_c"]]
+    def tup(x):
+        return tuple(tup(y) if isinstance(y, list) and y and isinstance(y[0], str) else ([tup(z) for z in y] if isinstance(y, list) else y) for y in x)
+    t.info = None if d.get("info") is None else [[nodes[u] for u in row] for row in d["info"]]
+    t.info_desc = None if d.get("info_desc") is None else [tup(x) for x in d["info_desc"]]
     t.draws = [tuple(x) for x in d["draws"]]
     t.pops, t.n_u, t.A, t.E, t.dim_c = list(d["pops"]), d["n_u"], d["A"], d["E"], d["dim_c"]
     t.collaborative, t.paths, t.enumerated = d["collaborative"], d["paths"], d["enumerated"]
@@ -1093,7 +1141,7 @@ def _entity_lists(world):
     return list(world.agents), list(world.agents) + list(world.landmarks)
 
 
-def _trace_once(scenario, t, forced, want_done, max_paths):
+def _trace_once(scenario, t, forced, want_done, max_paths, want_info=False):
     """One pass: make_world, reset_world with np.random recorded (picks in `forced` take their given value), the callbacks over
     the symbolic state.  -> dict of node lists."""
     g = t.graph
@@ -1109,6 +1157,12 @@ def _trace_once(scenario, t, forced, want_done, max_paths):
     if any(a.u_noise or (a.c_noise and not a.silent) for a in agents):
         raise TraceUnsupported("action / communication noise")
     t.world, t.A, t.E, t.dim_c = world, A, E, dc
+    info_desc = None
+    if want_info:      # what benchmark_data returns (numbers? tuples? ints?), from a concrete call on the world make_world left
+        for a in agents:
+            a.action.c = np.zeros(dc)
+            a.action.u = np.zeros(dp)
+        info_desc = [_describe_info(scenario.benchmark_data(a, world)) for a in agents]
     # ---- reset_world, symbolically ------------------------------------------------------------------------------------------
     rec = _Recorder(g, forced)
     with patched_random(rec), injected_builtins(scenario):
@@ -1159,6 +1213,11 @@ def _trace_once(scenario, t, forced, want_done, max_paths):
                 paths["done"].append(tr.paths)
             else:
                 out["done"].append([])
+            if want_info:
+                tr = Tracer(g, max_paths)
+                d = info_desc[len(out["info"])] if "info" in out else info_desc[0]
+                out.setdefault("info", []).append(tr.explore(lambda: scenario.benchmark_data(a, world), lambda raw: _flatten_info(raw, d)))
+    out["info_desc"] = info_desc
     out["paths"] = paths
     out["collaborative"] = bool(getattr(world, "collaborative", False))
     return out
@@ -1167,29 +1226,29 @@ def _trace_once(scenario, t, forced, want_done, max_paths):
 _MAX_ENUMERATED = 64      # traces per scenario when picks have to be enumerated (product of their population sizes)
 
 
-def trace(scenario, want_done=False, max_paths=None, predicate=True):
+def trace(scenario, want_done=False, max_paths=None, predicate=True, want_info=False):
     """Trace `scenario` (a reference-style Scenario object: make_world(self), reset_world(self, world), NumPy callbacks).
     Raises TraceUnsupported when the file is outside what the tracer models.  predicate: trace a twin of the scenario whose
     value-only control flow does not fork (predicated_twin); where that twin cannot be built or traced, the scenario itself."""
     if predicate:
         try:
-            t = _trace(predicated_twin(scenario), want_done, max_paths)
+            t = _trace(predicated_twin(scenario), want_done, max_paths, want_info)
             t.predicated = True
             return t
         except TraceUnsupported as e:
             first = e
         try:
-            t = _trace(scenario, want_done, max_paths)
+            t = _trace(scenario, want_done, max_paths, want_info)
         except TraceUnsupported as e:
-            raise TraceUnsupported("%s (with predicated control flow: %s)" % (e, first))
+            raise TraceUnsupported(str(e) if str(e) == str(first) else "%s (with predicated control flow: %s)" % (e, first))
         t.predicated = False
         return t
-    t = _trace(scenario, want_done, max_paths)
+    t = _trace(scenario, want_done, max_paths, want_info)
     t.predicated = False
     return t
 
 
-def _trace(scenario, want_done=False, max_paths=None):
+def _trace(scenario, want_done=False, max_paths=None, want_info=False):
     import itertools
     t = Traced()
     g = t.graph
@@ -1201,7 +1260,7 @@ def _trace(scenario, want_done=False, max_paths=None):
             _Ctx.need_pick = None
             try:
                 combos = list(itertools.product(*[range(pops[k]) for k in enumerated])) if enumerated else [()]
-                runs = {c: _trace_once(scenario, t, dict(zip(enumerated, c)), want_done, max_paths) for c in combos}
+                runs = {c: _trace_once(scenario, t, dict(zip(enumerated, c)), want_done, max_paths, want_info) for c in combos}
                 break
             except Exception as e:
                 if not isinstance(e, NeedConcretePick) and _Ctx.need_pick is None:
@@ -1246,10 +1305,17 @@ def _trace(scenario, want_done=False, max_paths=None):
         t.obs = [merged("obs", i) for i in range(A)]
         t.rew = [merged("rew", i)[0] for i in range(A)]
         t.done = [(merged("done", i)[0] if first["done"][i] else None) for i in range(A)]
+        t.info, t.info_desc = None, None
+        if want_info:
+            if any(r["info_desc"] != first["info_desc"] for r in runs.values()):
+                raise TraceUnsupported("the structure of benchmark_data depends on a pick")
+            t.info = [merged("info", i) for i in range(A)]
+            t.info_desc = first["info_desc"]
         t.paths = first["paths"]
         t.enumerated = list(enumerated)
         t.collaborative = first["collaborative"]
-        for what, roots in (("observation", [n for row in t.obs for n in row]), ("reward", t.rew), ("done", [d for d in t.done if d is not None])):
+        for what, roots in (("observation", [n for row in t.obs for n in row]), ("reward", t.rew), ("done", [d for d in t.done if d is not None]),
+                            ("benchmark_data", [n for row in (t.info or []) for n in row])):
             if "U" in inputs_of(roots):
                 raise TraceUnsupported("%s depends on a random number reset_world drew and did not store in the state" % what)
         return t
@@ -1458,6 +1524,9 @@ def verify(scenario, t, worlds=96, seed=0, tol=1e-9):
     for d in t.done:
         done_eval.append(vals[q] if d is not None else None)
         q += d is not None
+    info_eval = None
+    if getattr(t, "info", None) is not None:
+        info_eval = [evaluate(row, R, P=P, V=V, Cw=Cw, K=K, U=U) if row else [] for row in t.info]
     for r in range(R):
         _concrete_reset(scenario, cw, U[r], K[r])
         cmp("reset_world positions", [e.state.p_pos for e in ents], rp[r])
@@ -1478,7 +1547,23 @@ def verify(scenario, t, worlds=96, seed=0, tol=1e-9):
             if t.done[i] is not None:
                 if bool(scenario.done(a, cw)) != bool(done_eval[i][r]):
                     raise TraceUnsupported("the trace does not reproduce the file's done (agent %d)" % i)
+            if getattr(t, "info", None) is not None:
+                raw = scenario.benchmark_data(a, cw)
+                if _describe_info(raw) != t.info_desc[i]:
+                    raise TraceUnsupported("benchmark_data of agent %d changes its structure from world to world" % i)
+                want = [float(x) for x in _concrete_info(raw, t.info_desc[i])]
+                cmp("benchmark_data (agent %d)" % i, want, [info_eval[i][k][r] for k in range(len(want))])
     return worst
+
+
+def _concrete_info(raw, desc):
+    if desc[0] == "none":
+        return []
+    if desc[0] == "s":
+        return [np.asarray(raw).reshape(-1)[0]]
+    if desc[0] == "a":
+        return list(np.asarray(raw).reshape(-1))
+    return [v for x, d in zip(raw, desc[1]) for v in _concrete_info(x, d)]
 
 
 def evaluate_torch(roots, B, K=None, U=None, P=None, V=None, Cw=None, device=None):

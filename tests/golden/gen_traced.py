@@ -23,14 +23,18 @@ def main():
     from multiagent_particle_envs_amd import symtrace
     for name in NINE:
         sc = mpe.scenarios.load(os.path.join(REF, name + ".py")).Scenario()
-        t = symtrace.trace(sc)
+        try:          # with benchmark_data where the file's works (simple_speaker_listener.py:61 references an undefined name, Q19)
+            t = symtrace.trace(sc, want_info=hasattr(sc, "benchmark_data"))
+        except symtrace.TraceUnsupported:
+            t = symtrace.trace(sc)
         worst = symtrace.verify(sc, t, worlds=128)
         d = symtrace.to_dict(t)
         d["source"] = "symtrace.trace(%s/%s.py), verified against the file's own callbacks on 128 random worlds (max scaled difference %.1e)" % (REF, name, worst)
         out = os.path.join(HERE, "traced_%s.json" % name)
         with open(out, "w") as fh:
             json.dump(d, fh, separators=(",", ":"))
-        print("%-26s %5d nodes, %6d bytes, paths obs %s rew %s" % (name, len(d["nodes"]), os.path.getsize(out), t.paths["obs"], t.paths["rew"]))
+        print("%-26s %5d nodes, %6d bytes, paths obs %s rew %s, benchmark_data %s" % (name, len(d["nodes"]), os.path.getsize(out), t.paths["obs"], t.paths["rew"],
+                                                                                         "-" if t.info is None else t.info_desc[0]))
 
 
 if __name__ == "__main__":

@@ -43,7 +43,35 @@ def actions_of(g, t, n, dev):
     return [torch.as_tensor(g["act%d" % i][t], dtype=torch.float32).to(dev) for i in range(n)]
 
 
-def replay(env, g, dev):
+def check_info(name, info, g, t, ok):
+    """benchmark_data of the traced env (make_env(..., benchmark=True): one more launch per step) against what the reference's env
+    recorded: integer outputs exactly (outside the decision-margin band), numbers at 1e-5."""
+    vals = info["n"]
+    if name == "simple_spread":
+        for i, v in enumerate(vals):
+            for k, key in enumerate(("info_rew", "info_collisions", "info_min_dists", "info_occupied")):
+                if k in (1, 3):
+                    assert v[k].dtype == torch.int32 and np.array_equal(v[k].cpu().numpy()[ok], g[key][t][:, i][ok].astype(np.int64)), (key, t, i)
+                else:
+                    close(v[k][torch.as_tensor(ok)], g[key][t][:, i][ok], "%s t=%d" % (key, t))
+    elif name in ("simple_tag", "simple_world_comm"):
+        for i, v in enumerate(vals):
+            assert v.dtype == torch.int32 and np.array_equal(v.cpu().numpy()[ok], g["info_collisions"][t][:, i][ok].astype(np.int64)), (t, i)
+    elif name == "simple_adversary":
+        close(vals[0], g["info_adv"][t][:, 0], "info_adv t=%d" % t)
+        for j in (1, 2):
+            for k in range(3):
+                close(vals[j][k], g["info_good"][t][:, j - 1, k], "info_good t=%d" % t)
+    elif name == "herd":
+        for i, v in enumerate(vals):
+            close(v[0][torch.as_tensor(ok)], g["info0"][t][:, i][ok], "info rew")
+            assert v[1].dtype == torch.int32 and np.array_equal(v[1].cpu().numpy()[ok], g["info1"][t][:, i][ok].astype(np.int64))
+    else:
+        return False
+    return True
+
+
+def replay(env, g, dev, name=None):
     """Seeded reset, then every recorded step teacher-forced from the reference's state."""
     n, W = env.n, g["rew"].shape[1]
     T = g["rew"].shape[0]
@@ -88,6 +116,9 @@ def replay(env, g, dev):
             worst = max(worst, close(obs[i][okt], g["obs%d" % i][t][ok], "obs%d t=%d" % (i, t)))
             worst = max(worst, close(rew[i][okt], g["rew"][t][:, i][ok], "rew%d t=%d" % (i, t)))
             assert not bool(done[i].any())
+        if name is not None and tr.info is not None:
+            ok_i = symtrace.decision_margin([x for row in tr.info for x in row], W, P=g["pos"][t].astype(np.float64), V=V, Cw=Cw, K=K) > 2e-6
+            check_info(name, info, g, t, ok & ok_i)
     return worst
 
 
@@ -97,10 +128,11 @@ def test_committed_traces_of_the_nine_reference_files_on_the_device(name, golden
         data = json.load(fh)
     g = golden(name if name in ("simple", "simple_spread", "simple_tag") else "f3_" + name)
     W = g["rew"].shape[1]
-    env = refstyle.make_traced_env(data, W)
+    env = refstyle.make_traced_env(data, W, benchmark=True)
     assert env.traced and env.fused and env._prog.traced and env.program_compiled
     assert [s.shape[0] for s in env.observation_space] == [g["obs_reset%d" % i].shape[1] for i in range(env.n)]
-    replay(env, g, "cuda")
+    assert (env.info_callback is not None) == (name in ("simple_spread", "simple_tag", "simple_adversary", "simple_crypto", "simple_world_comm"))
+    replay(env, g, "cuda", name)
 
 
 @pytest.mark.parametrize("name", ["herd", "relay", "convoy"])
@@ -108,13 +140,13 @@ def test_fixture_files_traced_against_reference_goldens_and_the_host_path(name, 
     path = os.path.join(FIXTURES, name + ".py")
     g = golden("refstyle_" + name)
     W = g["rew"].shape[1]
-    env = mpe.make_env(path, batch_size=W)
+    env = mpe.make_env(path, batch_size=W, benchmark=True)
     assert env.traced and env.trace_fallback is None and env.program_compiled
     assert type(env.ref_scenario).__module__.startswith("mpe_user_scenario_")
-    replay(env, g, "cuda")
+    replay(env, g, "cuda", name)
     # ... and against the same file on the host path, free-running on more worlds (crowded at t = 3: contacts)
     B = 600
-    a, b = mpe.make_env(path, batch_size=B, seed=5), mpe.make_env(path, batch_size=B, seed=5, traced=False)
+    a, b = mpe.make_env(path, batch_size=B, seed=5, benchmark=True), mpe.make_env(path, batch_size=B, seed=5, traced=False, benchmark=True)
     assert a.traced and not b.traced and not b.fused
     seeds = list(range(1000, 1000 + B))
     oa, ob = a.reset(seeds=seeds), b.reset(seeds=seeds)
@@ -129,7 +161,7 @@ def test_fixture_files_traced_against_reference_goldens_and_the_host_path(name, 
             parts = ([np.eye(5, dtype=np.float32)[rs.randint(0, 5, B)]] if ag.movable else []) + \
                 ([np.eye(a.world.dim_c, dtype=np.float32)[rs.randint(0, a.world.dim_c, B)]] if not ag.silent else [])
             act.append(torch.as_tensor(np.concatenate(parts, axis=1)).cuda())
-        (oa, ra, _, _), (ob, rb, _, _) = a.step(act), b.step(act)
+        (oa, ra, _, ia), (ob, rb, _, ib) = a.step(act), b.step(act)
         assert np.array_equal(a.world.get_state()[0], b.world.get_state()[0])          # the same physics launch family: bit-identical
         # the host path evaluates the file in fp64, the kernel in fp32: a world within 2e-6 of one of the file's OWN thresholds
         # (a contact test, `gap < 0.25`) may take the other branch -- compared outside that band, as the contact counts of the
@@ -149,6 +181,15 @@ def test_fixture_files_traced_against_reference_goldens_and_the_host_path(name, 
         for i in range(a.n):
             close(oa[i][okt], ob[i].cpu().numpy()[ok], "obs%d t=%d vs the host path" % (i, t))
             close(ra[i][okt], rb[i].cpu().numpy()[ok], "rew%d t=%d vs the host path" % (i, t))
+        if tr.info is not None:      # benchmark_data in the file's own structure (herd: (reward, hits) per agent; hits as int32)
+            ok_i = ok & (symtrace.decision_margin([x for row in tr.info for x in row], B, P=P.astype(np.float64), V=V.astype(np.float64), Cw=Cw, K=K) > 2e-6)
+            for va, vb in zip(ia["n"], ib["n"]):
+                assert isinstance(va, tuple) and len(va) == len(vb)
+                for xa, xb in zip(va, vb):
+                    assert xa.dtype == xb.dtype and xa.shape == xb.shape
+                    close(xa[torch.as_tensor(ok_i)], xb.cpu().numpy()[ok_i], "benchmark_data t=%d vs the host path" % t)
+        else:
+            assert ia["n"] == ib["n"] == [{}] * a.n
 
 
 def test_a_traced_program_runs_compiled_in_only():

@@ -166,7 +166,7 @@ def _info_checker(name, g, W):
 
 
 def _make_fixture_env(name, W, dev):
-    env = mpe.make_env(os.path.join(FIXTURES, name + ".py"), benchmark=True, batch_size=W, device=dev)
+    env = mpe.make_env(os.path.join(FIXTURES, name + ".py"), benchmark=True, batch_size=W, device=dev, traced=False)
     if name == "patrol":            # the recorder passed Scenario.done as done_callback (the reference's make_env passes none)
         env.done_callback = env.scenario.done
     return env

@@ -226,7 +226,11 @@ def test_the_nine_reference_files_trace_and_reproduce_their_own_callbacks(name):
     path = os.path.join(REF_SCENARIOS, name + ".py")
     before = open(path, "rb").read()
     sc = mpe.scenarios.load(path).Scenario()
-    t = symtrace.trace(sc)
+    try:          # (as tests/golden/gen_traced.py: with benchmark_data where the file's works)
+        t = symtrace.trace(sc, want_info=hasattr(sc, "benchmark_data"))
+    except symtrace.TraceUnsupported:
+        t = symtrace.trace(sc)
+    assert (t.info is not None) == (name in ("simple_spread", "simple_tag", "simple_adversary", "simple_crypto", "simple_world_comm"))
     assert symtrace.verify(sc, t, worlds=200, seed=3) == 0.0
     assert open(path, "rb").read() == before
     with open(os.path.join(GOLDEN, "traced_%s.json" % name)) as fh:
@@ -271,8 +275,18 @@ def test_committed_traces_of_the_nine_against_the_reference_goldens(name, golden
             want = g["obs_reset%d" % i] if t_ is None else g["obs%d" % i][t_]
             got = np.stack(vals[off[i]:off[i + 1]], axis=1)
             worst = max(worst, float(np.abs(got - want).max()))
+        if t_ is not None and tr.info is not None and name in ("simple_spread", "simple_tag", "simple_world_comm"):
+            # benchmark_data as the reference's env recorded it (ints exactly)
+            keys = ("info_rew", "info_collisions", "info_min_dists", "info_occupied") if name == "simple_spread" else ("info_collisions",)
+            for i in range(A):
+                iv = symtrace.evaluate(tr.info[i], W, P=P, V=V, Cw=Cw, K=K)
+                for k, key in enumerate(keys):
+                    if "collisions" in key or "occupied" in key:
+                        assert np.array_equal(iv[k], g[key][t_][:, i]), (key, t_, i)
+                    else:
+                        assert np.abs(iv[k] - g[key][t_][:, i]).max() <= 1e-9
         if t_ is not None:
-            rew = np.stack(vals[off[-1]:], axis=1)               # [W, A]
+            rew = np.stack(vals[off[-1]:off[-1] + A], axis=1)               # [W, A]
             if shared:                                            # environment.py:100-102
                 rew = np.repeat(rew.sum(axis=1, keepdims=True), A, axis=1)
             worst = max(worst, float((np.abs(rew - g["rew"][t_]) / np.maximum(1.0, np.abs(g["rew"][t_]))).max()))

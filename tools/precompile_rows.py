@@ -36,13 +36,23 @@ def test_programs():
     import json
     from multiagent_particle_envs_amd import refstyle, symtrace, scenarios
     import multiagent_particle_envs_amd as mpe
+    class _Info(object):      # (benchmark_data's program of a traced scenario: a second image)
+        def __init__(self, ts):
+            ip = refstyle._InfoProgram(ts, ts.make_world(4, "cpu"), compile=False)
+            self._prog, self._desc = ip.prog, ip.desc
     for name in ("herd", "relay", "convoy"):
-        ts = refstyle.trace_ref_scenario(scenarios.load(os.path.join(ROOT, "tests", "refstyle", name + ".py")).Scenario())
-        envs.append(("traced " + name, mpe.MultiAgentEnv(ts.make_world(4, "cpu"), ts.reset_world, None, None, compile_program=False)))
+        sc = scenarios.load(os.path.join(ROOT, "tests", "refstyle", name + ".py")).Scenario()
+        for info in ((False, True) if hasattr(sc, "benchmark_data") else (False,)):
+            ts = refstyle.trace_ref_scenario(sc, want_info=info)
+            envs.append(("traced " + name, mpe.MultiAgentEnv(ts.make_world(4, "cpu"), ts.reset_world, None, None, compile_program=False)))
+            if info:
+                envs.append(("traced %s benchmark_data" % name, _Info(ts)))
     for name in tr.NINE:
         with open(os.path.join(ROOT, "tests", "golden", "traced_%s.json" % name)) as fh:
             ts = refstyle.TracedRefScenario(None, symtrace.from_dict(json.load(fh)))
         envs.append(("traced reference " + name, mpe.MultiAgentEnv(ts.make_world(4, "cpu"), ts.reset_world, None, None, compile_program=False)))
+        if ts.t.info is not None:
+            envs.append(("traced reference %s benchmark_data" % name, _Info(ts)))
     return envs
 
 
