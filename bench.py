@@ -716,6 +716,14 @@ def reference_style_leg(torch, mpe, B, EP, rv, dev):
                      "path": "mpe_step_rows, compiled image with the file's callbacks as code"}
     del env
     lg = Leg(mpe, path, 4, B, EP, 0, 1, 0)
+    k_us = lg.kernel_time_us(torch, "graph")
+    _, bytes_step, _, _ = lg.geometry()
+    out["roofline"] = {"bound": "hbm", "kernel": "mpe_rows_<hash>_s (k_rows, compiled image with the traced callbacks)", "kernel_us_per_launch": k_us,
+                       "algorithmic_bytes_per_env_step": bytes_step, "algorithmic_bytes_per_launch": bytes_step * B,
+                       "achieved": bytes_step * B / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": bytes_step * B / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel_timing": lg.last_kernel_timing,
+                       "note": "algorithmic bytes as the headline's (state + one-hot moves in, state + rows + rewards + dones out); kernel time = "
+                               "two-point slope of graphs of dependent launches, resident moves, no resets"}
     d, R, _, r_ = lg.timed(torch, rv, dev, "graph", "fresh", 200, 10, 3, SIDE_REGION_MS)
     out["traced_graph"] = {"value": B * 200 * R / d, "unit": "env-steps/s", "ms_per_step": d * 1e3 / (200 * R), "timed_steps": 200 * R,
                            "repeats": {"min": r_[0], "median": r_[1], "max": r_[2]},

@@ -34,6 +34,65 @@ def fast_actions(env, rs, B, dev):
     return (moves, words)
 
 
+def device_rates(env, worlds, n=500):
+    """(us per step as a HIP graph of step launches with fresh moves [+ resets], us per step as 25-step rollouts with a trajectory)"""
+    from multiagent_particle_envs_amd.rollout import RandomRollout, Trajectory
+    EP = 25 if env._device_restart_ok else 0
+    roll = RandomRollout(env, episode_len=EP, pool=25, regenerate=True)
+    graph = roll.capture(n)
+    graph.replay()
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        t0 = time.time()
+        for _ in range(4):
+            graph.replay()
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / (4 * n)
+        best = dt if best is None else min(best, dt)
+    traj = Trajectory(env, 25)
+    roll.fused(25, traj)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(40):
+        roll.fused(25, traj)
+    torch.cuda.synchronize()
+    return best * 1e6, (time.time() - t0) / (40 * 25) * 1e6, EP
+
+
+def special(args):
+    import json
+    from multiagent_particle_envs_amd import refstyle
+    here = os.path.dirname(os.path.abspath(__file__))
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(0)
+    envs = []
+    for name in args.json:
+        with open(os.path.join(here, "..", "tests", "golden", "traced_%s.json" % name)) as fh:
+            envs.append(("%s.py (the reference's file, traced)" % name, refstyle.make_traced_env(json.load(fh), args.worlds), name))
+    for path in args.files:
+        e = mpe.make_env(path, batch_size=args.worlds)
+        assert e.traced, e.trace_fallback
+        envs.append((os.path.basename(path) + " (traced)", e, None))
+    if args.profile_steps:
+        for label, env, _ in envs:
+            act = [fast_actions(env, rs, args.worlds, dev) for _ in range(4)]
+            env.reset()
+            for k in range(args.profile_steps):
+                env.step(act[k % 4])
+            torch.cuda.synchronize()
+            print("%-44s %d eager env.step calls at %d worlds" % (label, args.profile_steps, args.worlds))
+        return
+    for label, env, name in envs:
+        g, f, EP = device_rates(env, args.worlds)
+        line = "%-44s graph of step launches: %.2f us per step = %.3g env-steps/s; 25-step rollouts: %.2f us per step" % (label, g, args.worlds / (g * 1e-6), f)
+        if name is not None:
+            b = mpe.make_env(name, batch_size=args.worlds)
+            g2, f2, _ = device_rates(b, args.worlds)
+            line += "   | built-in %s (hand-fused kernel): %.2f / %.2f us  (traced / fused: %.2f / %.2f)" % (name, g2, f2, g / g2, f / f2)
+        print(line)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("files", nargs="*")
@@ -41,7 +100,14 @@ def main():
     ap.add_argument("--worlds", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--host-worlds", type=int, default=256)
+    ap.add_argument("--json", action="append", default=[], metavar="NAME",
+                    help="a committed trace of one of the reference's nine files (tests/golden/traced_NAME.json): its graph-protocol and "
+                         "rollout rates beside the built-in scenario of that name (the hand-fused kernel)")
+    ap.add_argument("--profile-steps", type=int, default=0,
+                    help="only: build the traced env(s) at --worlds and run this many eager env.step calls (for rocprofv3)")
     args = ap.parse_args()
+    if args.json or args.profile_steps:
+        return special(args)
     here = os.path.dirname(os.path.abspath(__file__))
     files = args.files or [os.path.join(here, "..", "tests", "refstyle", f) for f in ("herd.py", "relay.py", "convoy.py", "patrol.py")]
     dev = torch.device("cuda", 0)
