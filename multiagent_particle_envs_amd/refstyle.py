@@ -460,7 +460,9 @@ def _trace_cache_path(scenario, want_done):
         for f in files:
             with open(f, "rb") as fh:
                 h.update(fh.read())
-    except (TypeError, OSError):
+        import pickle
+        h.update(pickle.dumps(sorted(scenario.__dict__.items())))      # a scenario parametrised through its attributes: part of the key
+    except Exception:      # (sources not readable, attributes that do not pickle: no cache)
         return None
     return os.path.join(_build.ROWS_CACHE, "trace_%s.json" % h.hexdigest()[:32])
 
@@ -550,7 +552,8 @@ def trace_ref_scenario(scenario, want_done=False, verify_worlds=64, cache=True, 
         try:
             with open(path) as fh:
                 t = symtrace.from_dict(json.load(fh))
-        except (ValueError, KeyError, symtrace.TraceUnsupported):
+            symtrace.verify(scenario, t, worlds=8)        # (a stale or foreign cache entry: traced afresh)
+        except Exception:
             t = None
     if t is None:
         t = symtrace.trace(scenario, want_done=want_done, want_info=want_info)

@@ -82,7 +82,7 @@ class Graph(object):
             x = a.value
             try:
                 v = {"neg": lambda: -x, "abs": lambda: abs(x), "sqrt": lambda: math.sqrt(x), "exp": lambda: math.exp(x),
-                     "log": lambda: math.log(x), "tanh": lambda: math.tanh(x)}[op]()
+                     "log": lambda: math.log(x), "tanh": lambda: math.tanh(x), "sin": lambda: math.sin(x), "cos": lambda: math.cos(x)}[op]()
             except (ValueError, OverflowError):
                 v = float("nan")
             return self.const(v)
@@ -93,7 +93,7 @@ class Graph(object):
             x, y = a.value, b.value
             try:
                 v = {"add": lambda: x + y, "sub": lambda: x - y, "mul": lambda: x * y, "div": lambda: x / y,
-                     "min": lambda: min(x, y), "max": lambda: max(x, y)}[op]()
+                     "min": lambda: min(x, y), "max": lambda: max(x, y), "atan2": lambda: math.atan2(x, y)}[op]()
             except ZeroDivisionError:
                 v = float("nan") if x == 0 else math.copysign(float("inf"), x)
             return self.const(v)
@@ -220,6 +220,9 @@ class Sym(object):
     def exp(self): return Sym(_Ctx.graph.unary("exp", self.n))
     def log(self): return Sym(_Ctx.graph.unary("log", self.n))
     def tanh(self): return Sym(_Ctx.graph.unary("tanh", self.n))
+    def sin(self): return Sym(_Ctx.graph.unary("sin", self.n))
+    def cos(self): return Sym(_Ctx.graph.unary("cos", self.n))
+    def arctan2(self, o): return self._b("atan2", o)
     def conjugate(self): return self
 
     def _c(self, op, o):
@@ -914,6 +917,72 @@ class _Replayer(object):
         return self.choice(list(range(int(lo), int(hi))))
 
 
+# ---- NumPy functions whose object-dtype loops would ask symbolic comparisons for their truth (one fork per element) ---------------
+def _has_sym(*xs):
+    for x in xs:
+        if isinstance(x, (Sym, SymBool)):
+            return True
+        if isinstance(x, np.ndarray) and x.dtype == object and any(isinstance(v, (Sym, SymBool)) for v in x.reshape(-1)):
+            return True
+        if isinstance(x, (list, tuple)) and _has_sym(*x):
+            return True
+    return False
+
+
+def _elementwise(f, *xs):
+    arrs = np.broadcast_arrays(*[np.asarray(x, dtype=object) for x in xs])
+    if arrs[0].ndim == 0:
+        return f(*[a.item() for a in arrs])
+    out = np.empty(arrs[0].size, dtype=object)
+    out[:] = [f(*vals) for vals in zip(*[a.reshape(-1) for a in arrs])]
+    return out.reshape(arrs[0].shape)
+
+
+def _numpy_patches():
+    o_max, o_min, o_clip, o_amin, o_amax, o_where = np.maximum, np.minimum, np.clip, np.amin, np.amax, np.where
+
+    def maximum(a, b, *args, **kw):
+        if args or kw or not _has_sym(a, b):
+            return o_max(a, b, *args, **kw)
+        return _elementwise(lambda x, y: sym_max(x, y), a, b)
+
+    def minimum(a, b, *args, **kw):
+        if args or kw or not _has_sym(a, b):
+            return o_min(a, b, *args, **kw)
+        return _elementwise(lambda x, y: sym_min(x, y), a, b)
+
+    def clip(a, a_min=None, a_max=None, *args, **kw):
+        if args or kw or not _has_sym(a, a_min, a_max):
+            return o_clip(a, a_min, a_max, *args, **kw)
+        r = a
+        if a_min is not None:
+            r = maximum(r, a_min)
+        if a_max is not None:
+            r = minimum(r, a_max)
+        return r
+
+    def amin(a, axis=None, *args, **kw):
+        if axis is not None or args or kw or not _has_sym(a):
+            return o_amin(a, axis, *args, **kw)
+        return sym_min(list(np.asarray(a, dtype=object).reshape(-1)))
+
+    def amax(a, axis=None, *args, **kw):
+        if axis is not None or args or kw or not _has_sym(a):
+            return o_amax(a, axis, *args, **kw)
+        return sym_max(list(np.asarray(a, dtype=object).reshape(-1)))
+
+    def where(c, *rest):
+        if len(rest) != 2 or not _has_sym(c):
+            return o_where(c, *rest)
+
+        def pick(t, x, y):
+            if isinstance(t, (bool, np.bool_)):
+                return x if t else y
+            return _select_any(t, x, y)
+        return _elementwise(pick, c, rest[0], rest[1])
+    return {"maximum": maximum, "minimum": minimum, "clip": clip, "amin": amin, "amax": amax, "min": amin, "max": amax, "where": where}
+
+
 _RANDOM_NAMES = ("uniform", "choice", "randint")
 _RANDOM_REFUSED = ("rand", "randn", "random", "random_sample", "normal", "shuffle", "permutation", "sample", "standard_normal",
                    "exponential", "beta", "gamma", "seed", "binomial", "poisson")
@@ -926,7 +995,11 @@ def patched_random(impl):
     for name in _RANDOM_NAMES + _RANDOM_REFUSED:
         if hasattr(np.random, name):
             saved[name] = getattr(np.random, name)
+    patches = _numpy_patches() if isinstance(impl, _Recorder) else {}      # (a symbolic run: max / min / clip / where without forks)
+    saved_np = {name: getattr(np, name) for name in patches}
     try:
+        for name, f in patches.items():
+            setattr(np, name, f)
         for name in _RANDOM_NAMES:
             setattr(np.random, name, getattr(impl, name))
         for name in _RANDOM_REFUSED:
@@ -938,6 +1011,8 @@ def patched_random(impl):
     finally:
         for name, f in saved.items():
             setattr(np.random, name, f)
+        for name, f in saved_np.items():
+            setattr(np, name, f)
 
 
 @contextlib.contextmanager
@@ -1115,10 +1190,10 @@ def from_dict(d):
     t.reset_pos = [[nodes[u] for u in e] for e in d["reset_pos"]]
     t.reset_vel = [[nodes[u] for u in e] for e in d["reset_vel"]]
     t.reset_c = [[nodes[u] for u in a] for a in d["reset_c"]]
-    def tup(x):
-        return tuple(tup(y) if isinstance(y, list) and y and isinstance(y[0], str) else ([tup(z) for z in y] if isinstance(y, list) else y) for y in x)
+    def desc(x):          # JSON lists back into the descriptors of _describe_info: ("t", [descriptors]) | ("s", kind) | ("a", n, kind) | ("none",)
+        return ("t", [desc(y) for y in x[1]]) if x[0] == "t" else tuple(x)
     t.info = None if d.get("info") is None else [[nodes[u] for u in row] for row in d["info"]]
-    t.info_desc = None if d.get("info_desc") is None else [tup(x) for x in d["info_desc"]]
+    t.info_desc = None if d.get("info_desc") is None else [desc(x) for x in d["info_desc"]]
     t.draws = [tuple(x) for x in d["draws"]]
     t.pops, t.n_u, t.A, t.E, t.dim_c = list(d["pops"]), d["n_u"], d["A"], d["E"], d["dim_c"]
     t.collaborative, t.paths, t.enumerated = d["collaborative"], d["paths"], d["enumerated"]
@@ -1433,6 +1508,12 @@ def evaluate(roots, B, P=None, V=None, Cw=None, K=None, U=None, dtype=np.float64
                 v = np.log(a[0])
             elif op == "tanh":
                 v = np.tanh(a[0])
+            elif op == "sin":
+                v = np.sin(a[0])
+            elif op == "cos":
+                v = np.cos(a[0])
+            elif op == "atan2":
+                v = np.arctan2(a[0], a[1])
             elif op in ("lt", "le") and _margin is not None and not any(x.op == "K" or x.op == "sel" for x in n.args):
                 # (== / != are tests on exact data -- an utterance that is all zeros, simple_crypto.py:104 -- and hold in fp32 as in fp64)
                 np.minimum(_margin, np.where(np.isfinite(a[0] - a[1]), np.abs(a[0] - a[1]), np.inf), out=_margin)
@@ -1597,8 +1678,10 @@ def evaluate_torch(roots, B, K=None, U=None, P=None, V=None, Cw=None, device=Non
             v = torch.where(a[1] < a[0], a[1], a[0])
         elif op == "max":
             v = torch.where(a[1] > a[0], a[1], a[0])
-        elif op in ("neg", "abs", "sqrt", "exp", "log", "tanh"):
+        elif op in ("neg", "abs", "sqrt", "exp", "log", "tanh", "sin", "cos"):
             v = getattr(torch, op)(a[0])
+        elif op == "atan2":
+            v = torch.atan2(a[0], a[1])
         elif op in _CMP:
             v = {"lt": torch.lt, "le": torch.le, "eq": torch.eq, "ne": torch.ne}[op](a[0], a[1])
         elif op == "not":
@@ -1670,8 +1753,10 @@ def _emit(roots, lines, names):
             e = "__builtin_amdgcn_exp2f(%s * 1.44269504088896341f)" % ref(a[0])
         elif op == "log":
             e = "(__builtin_amdgcn_logf(%s) * 0.693147180559945309f)" % ref(a[0])
-        elif op == "tanh":
-            e = "tanhf(%s)" % ref(a[0])
+        elif op in ("tanh", "sin", "cos"):
+            e = "%sf(%s)" % (op, ref(a[0]))
+        elif op == "atan2":
+            e = "atan2f(%s, %s)" % (ref(a[0]), ref(a[1]))
         elif op in ("lt", "le"):
             # `np.sqrt(np.sum(np.square(d))) < r`, the reference's contact test (simple_tag.py:69-73): decided as NumPy's float32
             # rounding sequence would (sqrt_lt: exact, without the correctly rounded sqrt outside a 1e-6 band around r)

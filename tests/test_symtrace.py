@@ -452,3 +452,31 @@ def test_the_fixtures_and_committed_traces_hardly_fork():
             paths = json.load(fh)["paths"]
         # (simple_crypto compares utterances element by element through NumPy's `==` and `continue`s: that still forks)
         assert max(paths["obs"] + paths["rew"]) == (256 if name == "simple_crypto" else 1), (name, paths)
+
+
+def test_numpy_idioms_of_user_scenarios_trace_without_forks():
+    """What user files write instead of the reference's sqrt(sum(square())): np.linalg.norm, np.dot, np.mean, np.clip, np.maximum /
+    minimum, np.min / max, np.where, trigonometry -- traced as nodes (no fork per element) and reproduced exactly."""
+    class S(_Base):
+        def reward(self, agent, world):
+            d = [np.linalg.norm(agent.state.p_pos - l.state.p_pos) for l in world.landmarks]
+            spread = np.mean([np.dot(a.state.p_vel, a.state.p_vel) for a in world.agents])
+            heading = np.arctan2(agent.state.p_vel[1], agent.state.p_vel[0] + 1e-3)
+            wall = np.sum(np.maximum(np.abs(agent.state.p_pos) - 0.9, 0.0))
+            return -np.min(d) + 0.1 * np.max(d) - spread - 2.0 * wall + 0.01 * np.cos(heading) + np.sin(agent.state.p_pos[0]) * 0.0 \
+                + float(np.where(np.array([True]), 1.0, 2.0)[0]) * 0.0 + np.sum(np.where(agent.state.p_pos > 0.5, agent.state.p_pos, 0.0))
+
+        def observation(self, agent, world):
+            rel = np.clip(world.landmarks[0].state.p_pos - agent.state.p_pos, -0.5, 0.5)
+            return np.concatenate([agent.state.p_vel, np.minimum(agent.state.p_pos, 0.8), rel, np.tanh(agent.state.p_vel)])
+    sc = S()
+    t = symtrace.trace(sc)
+    # (the only forks: `p_pos > 0.5` -- NumPy's own `>` on an object array asks each element's comparison for its truth)
+    assert t.paths["obs"] == [1, 1] and t.paths["rew"] == [4, 4]
+    assert symtrace.verify(sc, t, worlds=300) <= 1e-15
+    ops = set(n.op for n in symtrace.topo(t.rew + [n for row in t.obs for n in row]))
+    assert {"min", "max", "atan2", "cos", "tanh", "ite"} <= ops
+    # ... and as device code
+    src = symtrace.hip_source(t)
+    assert "atan2f(" in src and "cosf(" in src and "tanhf(" in src
+    assert np.maximum is not None and np.maximum(1, 2) == 2 and np.clip(5, 0, 1) == 1          # NumPy is itself again
