@@ -788,7 +788,10 @@ class MultiAgentEnv(object):
             self.episode_step = torch.zeros(self.batch_size, dtype=torch.int32, device=w.device)
             self._may_finish.add(self._steps_taken + self.max_episode_steps)
         self._steps_taken += 1
-        if self.done_callback is not None and self.auto_reset and out is not None and self._finish_program() is not None:
+        # a world can end at ANY step: a Python done_callback, or the program's own done tests where the restart cannot happen in
+        # the step launch (a reset_world that is not the device-side draw: `_device_restart_ok`)
+        ends_any_step = self.done_callback is not None or (self._prog is not None and self._prog.has_done)
+        if ends_any_step and self.auto_reset and out is not None and self._finish_program() is not None:
             # a done_callback can end a world at ANY step.  ONE launch (mpe_episode_finish) counts the step, finds the worlds
             # some agent's done row (or the horizon) flagged, restarts exactly those -- reset_world's draws, counters, comm
             # state -- and rewrites their observation rows; a workgroup of 64 worlds none of which finished returns after
@@ -811,8 +814,9 @@ class MultiAgentEnv(object):
         _abi.check(_abi.lib().mpe_episode_tick(self.episode_step.data_ptr(), done.data_ptr(), done.shape[0],
                                                self.batch_size, self.max_episode_steps, 1 if self.auto_reset else 0,
                                                self._stream()), "mpe_episode_tick")
-        if self.done_callback is not None and self.auto_reset:
-            # (shapes without a row program -- more than 64 entities -- and the generic path: the same in separate launches)
+        if ends_any_step and self.auto_reset:
+            # (shapes without a row program -- more than 64 entities --, the generic path, and scenarios whose reset_world is
+            #  their own -- `device_reset` not declared: the same in separate launches, the restart through reset_callback)
             # a done_callback can end a world at ANY step: restart every world some agent (or the horizon) flagged,
             # at every step, and restart its step counter too (the tick only clears it at the horizon).
             # Cost, knowingly paid: a masked reset_callback, a comm fill and (the caller's) mpe_observe relaunch on EVERY

@@ -856,3 +856,39 @@ def test_in_region_of_any_entity_against_the_numpy_oracle(compiled):
                 assert np.array_equal(g[ok, -5 + k], r[ok, -5 + k]), (t, i, k)
                 inside[k] += (r[:, -5 + k] > 0).mean()
     assert inside[3] == 3 * env.n and 0 < inside[2] / (3 * env.n) < 1 and 0 < inside[4] / (3 * env.n) < 1     # post 0 is inside itself; others: both answers occur
+
+
+@pytest.mark.gpu
+def test_done_programs_restart_through_reset_world_where_it_is_not_the_device_draw():
+    """A scenario with a done_spec whose reset_world is its OWN (no `device_reset`): with auto_reset the worlds its done tests flag
+    are restarted at that step through the masked reset_callback -- the scenario's placement, not the device's uniform one."""
+    class Pens(Corral):
+        device_reset = False
+        arena = 0.95
+
+        def reset_world(self, world, mask=None, seeds=None):
+            Corral.reset_world(self, world, mask, seeds)
+            keep = None if mask is None else ~torch.as_tensor(mask, device=world.device).bool()
+            new = world.pos[:3] * 0.25                           # agents start near the middle: [-0.25, 0.25)^2
+            world.pos[:3] = new if keep is None else torch.where(keep[None, None, :], world.pos[:3], new)
+    B = 2048
+    sc = Pens()
+    w = sc.make_world(batch_size=B)
+    w.seed = 11
+    sc.reset_world(w)
+    env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, max_episode_steps=1000, auto_reset=True, compile_program=False)
+    assert env._prog.has_done and not env._device_restart_ok and not env._episode_in_launch
+    env.reset()
+    assert float(env.world.pos[:3].abs().max()) < 0.25
+    act = torch.zeros((3, B, 5), device="cuda")
+    act[:, :, 1] = 1.0                                            # everybody accelerates in +x: they all leave the arena
+    restarted = 0
+    for t in range(40):
+        obs, rew, done, _ = env.step(act)
+        fin = done[0] | done[1] | done[2]
+        if bool(fin.any()):
+            restarted += int(fin.sum())
+            assert bool((env.episode_step[fin] == 0).all()) and bool((env.episode_step[~fin] > 0).all())
+            assert float(env.world.pos[:3][:, :, fin].abs().max()) < 0.25          # ITS placement, at the step the test fired
+            assert float(env.world.vel[:3][:, :, fin].abs().max()) == 0.0
+    assert restarted >= B                                          # every world left at least once
