@@ -9,11 +9,13 @@ slower than a kernel.  This module makes the same file fast without touching it:
             symbolic scalars instead of floats (NumPy object arrays: `a - b`, np.square / sum / sqrt / exp, concatenate work
             unchanged); every arithmetic step becomes a node of an expression graph over the world's state -- positions,
             velocities, utterances, and the per-world PICKS `reset_world` draws with np.random.choice (a goal landmark, a
-            key: objects chosen per world are proxies whose attributes are selections by the pick).  A Python `if` on a
-            symbolic comparison (`if dist < dist_min: rew -= 1`) forks: the callback is re-run with the decision forced
+            key: objects chosen per world are proxies whose attributes are selections by the pick).  Control flow on the
+            state (`if dist < dist_min: rew -= 1`): what only chooses between VALUES -- conditional expressions, `if`s that
+            assign or append, early returns, and / or / not -- is predicated into select nodes by re-compiling a copy of the
+            file's source (predicated_twin); any other symbolic `if` forks: the callback is re-run with the decision forced
             each way and the outcomes merge into select nodes, column by column (conditions are memoised per path, so a
             test asked twice forks once).  `reset_world` is traced the same way with np.random replaced by a recorder:
-            initial positions as functions of uniform draws and picks.
+            initial positions as functions of uniform draws and picks; `benchmark_data` and `done` on request.
   verify    the graphs are evaluated with NumPy (fp64, vectorised over worlds) against the FILE'S OWN callbacks run
             concretely on random worlds -- states that touch, overlap, leave the arena -- before anything is generated:
             a callback that keeps hidden state, draws random numbers or does something the tracer does not model is
@@ -26,7 +28,9 @@ slower than a kernel.  This module makes the same file fast without touching it:
 
 What is traced is arithmetic on the state: files whose callbacks read actions, scripted agents, movable landmarks, noise,
 more than MPE_MAX_CHOICES picks, or more control-flow paths than `MAX_PATHS` stay on the host path.
-Nothing here runs on the step path: tracing happens once, at env construction.
+Nothing here runs on the step path: tracing happens once, at env construction -- and while it does, np.random's drawing functions,
+a few NumPy functions (maximum / minimum / clip / min / max / where) and the traced file's min / max / any / all are replaced
+process-wide (restored afterwards, the caller's random stream untouched): construct envs from one thread.
 """
 import contextlib
 import math
@@ -886,10 +890,15 @@ class _Recorder(object):
         lo, hi = (0, low) if high is None else (low, high)
         return self.choice(list(range(int(lo), int(hi))))
 
-    def _unsupported(self, name):
-        def f(*a, **k):
-            raise TraceUnsupported("np.random.%s in reset_world" % name)
-        return f
+
+
+class _NoDraws(_Recorder):
+    """np.random while observation / reward / done / benchmark_data are traced: those callbacks must not draw."""
+
+    def _refuse(self, *a, **k):
+        raise TraceUnsupported("a callback other than reset_world draws random numbers")
+
+    uniform = choice = randint = _refuse
 
 
 class _Replayer(object):
@@ -1274,7 +1283,7 @@ def _trace_once(scenario, t, forced, want_done, max_paths, want_info=False):
     # ---- the callbacks, every path -------------------------------------------------------------------------------------------
     out["obs"], out["rew"], out["done"] = [], [], []
     paths = {"obs": [], "rew": [], "done": []}
-    with patched_random(_Recorder(g)._refusing()), injected_builtins(scenario):
+    with patched_random(_NoDraws(g)), injected_builtins(scenario):
         for a in agents:
             tr = Tracer(g, max_paths)
             out["obs"].append(tr.explore(lambda: scenario.observation(a, world), _flatten))
@@ -1418,16 +1427,6 @@ def _pick_populations(scenario, g):
     return list(rec.pops)
 
 
-def _refusing(self):
-    """A recorder that refuses every draw (callbacks other than reset_world must not draw)."""
-    def refuse(*a, **k):
-        raise TraceUnsupported("a callback other than reset_world draws random numbers")
-    r = _Recorder(self.g)
-    r.uniform = r.choice = r.randint = refuse
-    return r
-
-
-_Recorder._refusing = _refusing
 
 
 def topo(roots):
