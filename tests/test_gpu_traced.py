@@ -123,7 +123,7 @@ def replay(env, g, dev, name=None):
 
 
 @pytest.mark.parametrize("name", NINE)
-def test_committed_traces_of_the_nine_reference_files_on_the_device(name, golden):
+def test_committed_traces_of_the_nine_reference_files_on_the_device(name, golden, record_parity):
     with open(os.path.join(GOLDEN, "traced_%s.json" % name)) as fh:
         data = json.load(fh)
     g = golden(name if name in ("simple", "simple_spread", "simple_tag") else "f3_" + name)
@@ -132,18 +132,22 @@ def test_committed_traces_of_the_nine_reference_files_on_the_device(name, golden
     assert env.traced and env.fused and env._prog.traced and env.program_compiled
     assert [s.shape[0] for s in env.observation_space] == [g["obs_reset%d" % i].shape[1] for i in range(env.n)]
     assert (env.info_callback is not None) == (name in ("simple_spread", "simple_tag", "simple_adversary", "simple_crypto", "simple_world_comm"))
-    replay(env, g, "cuda", name)
+    worst = replay(env, g, "cuda", name)
+    record_parity("traced_" + name, {"what": "the reference's %s.py traced into the step kernel, against the goldens its own env recorded"
+                                            % name, "worlds": W, "steps": int(g["rew"].shape[0]), "max_scaled_err": worst})
 
 
 @pytest.mark.parametrize("name", ["herd", "relay", "convoy"])
-def test_fixture_files_traced_against_reference_goldens_and_the_host_path(name, golden):
+def test_fixture_files_traced_against_reference_goldens_and_the_host_path(name, golden, record_parity):
     path = os.path.join(FIXTURES, name + ".py")
     g = golden("refstyle_" + name)
     W = g["rew"].shape[1]
     env = mpe.make_env(path, batch_size=W, benchmark=True)
     assert env.traced and env.trace_fallback is None and env.program_compiled
     assert type(env.ref_scenario).__module__.startswith("mpe_user_scenario_")
-    replay(env, g, "cuda", name)
+    worst = replay(env, g, "cuda", name)
+    record_parity("traced_fixture_" + name, {"what": "tests/refstyle/%s.py traced, against goldens recorded by the reference's env" % name,
+                                             "worlds": W, "steps": int(g["rew"].shape[0]), "max_scaled_err": worst})
     # ... and against the same file on the host path, free-running on more worlds (crowded at t = 3: contacts)
     B = 600
     a, b = mpe.make_env(path, batch_size=B, seed=5, benchmark=True), mpe.make_env(path, batch_size=B, seed=5, traced=False, benchmark=True)
