@@ -278,6 +278,21 @@ class TracedRefScenario(object):
         self._info = None          # benchmark_data's program, built when first asked for
         self._env = None           # weak reference to the env (its utterance buffer), set by make_traced_env
 
+    def report(self):
+        """One paragraph: what was traced and how it runs."""
+        t = self.t
+        ops = sorted(set(n.op for row in t.obs for n in row) | set(n.op for n in t.rew))
+        return ("traced: %d agents, %d landmarks, dim_c %d; observation widths %s; %d graph nodes; control-flow paths per callback: obs %s, "
+                "reward %s%s (%s); per-world picks of reset_world: %s; reset_world %s; verified against the file's own callbacks: max "
+                "difference %s" % (
+                    t.A, t.E - t.A, t.dim_c, [len(r) for r in t.obs], t.graph.count, t.paths["obs"], t.paths["rew"],
+                    ", done %s" % t.paths["done"] if t.paths.get("done") else "",
+                    "value-only control flow predicated" if getattr(t, "predicated", False) else "by forking", list(t.pops) or "none",
+                    "is World.reset_uniform's placement (landmarks on [-%g, %g)^2): restarts are drawn on the device, inside the step launch"
+                    % (self.landmark_range, self.landmark_range) if self.device_reset else
+                    "is the file's own placement: evaluated with torch ops on the device for all worlds at once",
+                    getattr(t, "verified", "not run")))
+
     # ---- reset_world ------------------------------------------------------------------------------------------------------
     def _uniform_pattern(self):
         """(landmark_range, True) when the traced reset_world is `World.reset_uniform`'s placement: every agent uniform on

@@ -1174,6 +1174,7 @@ def to_dict(t):
             "draws": [list(d) for d in t.draws], "pops": list(t.pops), "n_u": t.n_u, "A": t.A, "E": t.E, "dim_c": t.dim_c,
             "info": None if getattr(t, "info", None) is None else [[n.uid for n in row] for row in t.info],
             "info_desc": getattr(t, "info_desc", None),
+            "predicated": bool(getattr(t, "predicated", False)),
             "collaborative": bool(t.collaborative), "paths": t.paths, "enumerated": list(getattr(t, "enumerated", [])),
             "world": {k: getattr(w, k) for k in _WLD_KEYS},
             "discrete_action": getattr(w, "discrete_action", None),
@@ -1206,6 +1207,7 @@ def from_dict(d):
     t.draws = [tuple(x) for x in d["draws"]]
     t.pops, t.n_u, t.A, t.E, t.dim_c = list(d["pops"]), d["n_u"], d["A"], d["E"], d["dim_c"]
     t.collaborative, t.paths, t.enumerated = d["collaborative"], d["paths"], d["enumerated"]
+    t.predicated = bool(d.get("predicated", False))
     w = ccore.World()
     for k, v in d["world"].items():
         setattr(w, k, v)
