@@ -293,6 +293,52 @@ class TracedRefScenario(object):
                     "is the file's own placement: evaluated with torch ops on the device for all worlds at once",
                     getattr(t, "verified", "not run")))
 
+    def spot_check(self, env, obs_n, reward_n, worlds=64, band=2e-6):
+        """After `obs_n, reward_n, _, _ = env.step(...)`: run the FILE'S OWN callbacks on the env's current state for a sample of
+        worlds (on the host, concretely) and compare with what the kernel delivered.  Returns (max scaled difference, worlds
+        checked); worlds within `band` of one of the file's own thresholds are skipped (fp32 vs fp64: either branch is right).
+        A check on live data, for trust -- the trace was already verified against the file on random worlds when it was made."""
+        from . import symtrace
+        if self.scenario is None:
+            raise _abi.MpeError("spot_check needs the scenario object (this env was built from trace data)")
+        t, sc, w = self.t, self.scenario, env.world
+        B = w.batch_size
+        pos, vel = w.get_state(all_entities=True)
+        picks = w.choice_i32.cpu().numpy() if t.pops else np.zeros((0, B), np.int64)
+        Cw = np.zeros((B, t.A, t.dim_c))
+        for i, a in enumerate(w.agents):
+            if t.dim_c and not a.silent and env._comm is not None:
+                Cw[:, i] = env._comm[i].cpu().numpy()
+        margin = symtrace.decision_margin([n for row in t.obs for n in row] + list(t.rew), B, P=pos.astype(np.float64),
+                                          V=vel.astype(np.float64), Cw=Cw, K=picks.T)
+        state = np.random.get_state()
+        try:
+            cw = sc.make_world()
+        finally:
+            np.random.set_state(state)
+        shared = bool(t.collaborative)
+        worst, checked = 0.0, 0
+        for b in np.linspace(0, B - 1, num=min(int(worlds), B)).astype(int):
+            if margin[b] <= band:
+                continue
+            with symtrace.patched_random(symtrace._Replayer(np.zeros(max(t.n_u, 1)), picks[:, b])):
+                sc.reset_world(cw)
+            for k, e in enumerate(list(cw.agents) + list(cw.landmarks)):
+                e.state.p_pos, e.state.p_vel = pos[b, k].astype(np.float64), vel[b, k].astype(np.float64)
+            for i, a in enumerate(cw.agents):
+                a.state.c = np.zeros(t.dim_c) if a.silent else Cw[b, i].copy()
+            rews = []
+            for i, a in enumerate(cw.agents):
+                o = np.asarray(sc.observation(a, cw), np.float64).reshape(-1)
+                worst = max(worst, float(np.abs(obs_n[i][b].detach().cpu().numpy() - o).max()) if o.size else 0.0)
+                rews.append(float(sc.reward(a, cw)))
+            if shared:
+                rews = [sum(rews)] * len(rews)
+            for i, r in enumerate(rews):
+                worst = max(worst, abs(float(reward_n[i][b]) - r) / max(1.0, abs(r)))
+            checked += 1
+        return worst, checked
+
     # ---- reset_world ------------------------------------------------------------------------------------------------------
     def _uniform_pattern(self):
         """(landmark_range, True) when the traced reset_world is `World.reset_uniform`'s placement: every agent uniform on

@@ -1398,6 +1398,16 @@ def _trace(scenario, want_done=False, max_paths=None, want_info=False):
             t.info = [merged("info", i) for i in range(A)]
             t.info_desc = first["info_desc"]
         t.paths = first["paths"]
+        # B worlds share ONE set of physics constants (they step in one launch): a make_world that randomises them per call cannot
+        # be batched -- per-world randomness belongs in reset_world (refstyle.RefScenarioAdapter refuses the same)
+        np.random.seed(12345)
+        other = scenario.make_world()
+
+        def consts(w):
+            return ([tuple(getattr(e, k, None) for k in _ENT_KEYS[1:]) for e in list(w.agents) + list(w.landmarks)],
+                    [tuple(getattr(a, k, None) for k in _AGT_KEYS) for a in w.agents], tuple(getattr(w, k) for k in _WLD_KEYS))
+        if consts(other) != consts(t.world):
+            raise TraceUnsupported("make_world() builds worlds with different entity counts or physics constants from call to call")
         t.enumerated = list(enumerated)
         t.collaborative = first["collaborative"]
         for what, roots in (("observation", [n for row in t.obs for n in row]), ("reward", t.rew), ("done", [d for d in t.done if d is not None]),

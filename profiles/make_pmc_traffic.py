@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 # key -> (file under profiles/, the bench.py command the passes profiled)
 SOURCES = {
-    "simple_spread_A3_L3_B65536": ("r4_pmc_spread3_B65536.txt", "bench.py --mode eager --protocol resident"),
+    "simple_spread_A3_L3_B65536": ("r5_pmc_spread3_B65536.txt", "bench.py --mode eager --protocol resident"),
     "simple_spread_A3_L3_B1048576": ("r4_pmc_spread3_B1M.txt", "bench.py --mode eager --protocol resident --batch 1048576"),
     "simple_tag_A4_L2_B16384": ("r4_pmc_tag_B16384.txt", "bench.py --mode eager --protocol resident --scenario simple_tag --batch 16384"),
     "simple_spread_A64_L64_B4096": ("r4_pmc_spread64_B4096.txt", "bench.py --mode eager --protocol resident --agents 64 --batch 4096"),

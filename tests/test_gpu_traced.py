@@ -194,6 +194,9 @@ def test_fixture_files_traced_against_reference_goldens_and_the_host_path(name, 
                     close(xa[torch.as_tensor(ok_i)], xb.cpu().numpy()[ok_i], "benchmark_data t=%d vs the host path" % t)
         else:
             assert ia["n"] == ib["n"] == [{}] * a.n
+    # ... and the check a user can run on live data: the file's own callbacks on the env's current state, a sample of worlds
+    worst, checked = a.scenario.spot_check(a, oa, ra, worlds=120)
+    assert worst <= TOL and checked >= 90, (worst, checked)
 
 
 def test_a_traced_program_runs_compiled_in_only():

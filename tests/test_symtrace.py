@@ -170,7 +170,13 @@ def test_what_the_tracer_refuses_and_why():
         def reward(self, agent, world):
             return float(agent.state.p_pos[0])
 
-    for cls, why in ((Draws, "draws random numbers"), (Scripted, "scripted agents"), (ReadsAction, "TypeError|NoneType"),
+    class RandomSizes(_Base):     # per-world randomness in make_world: the B worlds of a batch share their physics constants
+        def make_world(self):
+            w = _Base.make_world(self)
+            w.agents[0].size = float(np.random.uniform(0.05, 0.2))
+            return w
+
+    for cls, why in ((RandomSizes, "different entity counts or physics constants"), (Draws, "draws random numbers"), (Scripted, "scripted agents"), (ReadsAction, "TypeError|NoneType"),
                      (Unstored, "did not store in the state"), (Explodes, "control-flow paths"), (Concretises, "Python float")):
         with pytest.raises(symtrace.TraceUnsupported, match=why):
             symtrace.trace(cls(), max_paths=512 if cls is Explodes else None)
