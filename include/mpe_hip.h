@@ -41,7 +41,7 @@ extern "C" {
 #endif
 
 #define MPE_ABI_VERSION 4 /* layout of the structs below + meaning of existing entry points; new entry points are additive
-                             (4: MpeRowProgram.traced) */
+                             (4: MpeRowProgram.traced, reset_boxes) */
 #define MPE_MAX_ENTITIES 512 /* agents + landmarks per world */
 #define MPE_ACTION_DIM 5     /* Discrete(dim_p*2+1), environment.py:45 */
 #define MPE_MAX_CHOICES 4    /* np.random.choice draws a reset_world makes before the positions */
@@ -316,6 +316,12 @@ typedef struct MpeRowProgram {
   void *image;                /* NULL, or what mpe_rows_load_image attached: the program compiled in (owned by the library)       */
   int32_t done_begin[MPE_ROWS_MAX_ENTITIES + 1]; /* agent i's done ops: [done_begin[i], done_begin[i+1]) -- value ops and DONE_IF_*
                                                     tests, run after its reward program on a fresh machine; all zero: no done programs */
+  int32_t reset_boxes;        /* 1: reset_world places entity e uniformly in its own box -- x in [reset_box[e][0], + reset_box[e][1]),
+                                 y in [reset_box[e][2], + reset_box[e][3]) (`np.random.uniform(lo, hi, dim_p)` per entity: a restricted
+                                 spawn area, landmarks off-centre) -- for every restart the library draws for this program (in-launch
+                                 episode ends, rollouts, mpe_episode_finish, mpe_reset_rows); 0: agents on [-1,1)^2, landmarks on
+                                 [-landmark_range, landmark_range)^2 (the reference's nine scenarios)                               */
+  float reset_box[MPE_ROWS_MAX_ENTITIES][4];   /* lo_x, span_x, lo_y, span_y per entity                                            */
   int32_t traced;             /* 1: the program contains *_CODE ops -- it runs compiled in ONLY (an entry point called without a
                                  matching image returns MPE_EUNSUPPORTED instead of interpreting); 0 otherwise                  */
   int32_t pad_;
@@ -327,6 +333,12 @@ int mpe_rows_validate(const MpeScenarioDesc *desc, const MpeRowProgram *prog, co
  * :113-115 after a reset): obs rows, rew (shared sum when desc->collaborative), done = 0.  desc->kind is ignored (GENERIC
  * is what a user scenario has); reads pos, vel, comm, choice; bufs->rew / done may be NULL.                            */
 int mpe_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowProgram *prog, int64_t B, void *stream);
+/* mpe_reset_rows: mpe_reset with the PROGRAM's placement -- prog->reset_boxes ? its per-entity boxes : (agents [-1,1)^2, landmarks
+ * [-landmark_range, landmark_range)^2) -- the same draws, keyed by (seed, world_offset + b, episode, entity), that the in-kernel
+ * restarts of this program make: a rollout's per-step form {mpe_reset_rows at the boundaries; moves; mpe_step_rows} stays
+ * bit-identical to mpe_rollout_rows whatever the placement.                                                              */
+int mpe_reset_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, const MpeRowProgram *prog, int64_t B, const uint8_t *mask,
+                   float landmark_range, uint64_t seed, uint64_t episode, int64_t world_offset, void *stream);
 /* mpe_step_rows: one MultiAgentEnv.step of a user scenario in ONE launch -- _set_action + World.step (environment.py:144-181,
  * core.py:117-177; exactly one of bufs->act / ids / u, no movable landmarks: those go through mpe_world_step) by the
  * agents' waves, then the row programs on the post-step state as in mpe_rows.  State bit-identical to mpe_world_step's.  */

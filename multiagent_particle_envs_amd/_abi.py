@@ -60,7 +60,8 @@ class MpeRowProgram(C.Structure):
         ("ops_device", C.c_void_p), ("header_device", C.c_void_p), ("header_hash", C.c_uint64), ("n_ops", C.c_int32), ("obs_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)),
         ("rew_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)), ("n_vel", C.c_int32), ("n_regions", C.c_int32),
         ("region_entity", C.c_int32 * 2), ("all_seeing", C.c_uint32), ("image", C.c_void_p),
-        ("done_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)), ("traced", C.c_int32), ("pad_", C.c_int32),
+        ("done_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)), ("reset_boxes", C.c_int32),
+        ("reset_box", (C.c_float * 4) * MPE_ROWS_MAX_ENTITIES), ("traced", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -82,6 +83,8 @@ EXPORTS = {
     "mpe_integrate_state": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
     "mpe_reset": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p, C.c_float,
                             C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]),
+    "mpe_reset_rows": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.POINTER(MpeRowProgram), C.c_int64, C.c_void_p,
+                                 C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]),
     "mpe_random_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64,
                                      C.c_int64, C.c_void_p]),
     "mpe_random_actions_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64,

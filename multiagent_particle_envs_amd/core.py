@@ -332,7 +332,16 @@ class World(object):
         return n
 
     # ---- reset_world bodies shared by the built-in scenarios ---------------------------------------
-    def reset_uniform(self, landmark_range=1.0, mask=None, choices=None, seeds=None, redraw=None):
+    def reset_boxes(self, boxes, mask=None, choices=None, seeds=None):
+        """reset_uniform with a placement box per entity: `boxes[e] = (lo_x, hi_x, lo_y, hi_y)` -- entity e's position is
+        `np.random.uniform(lo, hi)` per coordinate (a restricted spawn area, landmarks off-centre).  On the device the draws are
+        `mpe_reset_rows`' -- the ones a row program with the same `reset_boxes` (rowspec.RowProgram, Scenario.reset_boxes) makes
+        for its in-launch restarts and rollouts."""
+        if len(boxes) != len(self.entities):
+            raise _abi.MpeError("reset_boxes: one (lo_x, hi_x, lo_y, hi_y) per entity")
+        return self.reset_uniform(1.0, mask, choices, seeds, boxes=[tuple(float(v) for v in b) for b in boxes])
+
+    def reset_uniform(self, landmark_range=1.0, mask=None, choices=None, seeds=None, redraw=None, boxes=None):
         """Scenario.reset_world for the shipped scenarios (simple_spread.py:38-45, simple_tag.py:46-54,
         simple.py:33-39, ...): agents ~ U[-1,1)^2, landmarks ~ U[-r,r)^2, vel = 0, comm state c = 0.
         `choices` = [n_0, n_1, ...]: the `np.random.choice` draws the scenario makes BEFORE the positions
@@ -365,6 +374,9 @@ class World(object):
                 for k, n in enumerate(choices):
                     idx_np[b, k] = rs.randint(0, n)        # == np.random.choice(list of n) (same stream)
                 for e in list(range(E)) + list(redraw or []):
+                    if boxes is not None:
+                        pos[b, e] = (rs.uniform(boxes[e][0], boxes[e][1]), rs.uniform(boxes[e][2], boxes[e][3]))
+                        continue
                     r = 1.0 if e < A else landmark_range
                     pos[b, e] = rs.uniform(-r, +r, self.dim_p)
                 vel[b] = 0.0
@@ -384,10 +396,19 @@ class World(object):
             if mask is not None:
                 mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
                 mptr = C.c_void_p(mask.data_ptr())
-            _abi.check(_abi.lib().mpe_reset(C.byref(desc), C.byref(bufs), B, mptr, float(landmark_range),
-                                            int(self.seed) & (2 ** 64 - 1), int(self._episode), int(self.world_offset),
-                                            _abi.raw_stream(self.device)),
-                       "mpe_reset")
+            if boxes is not None:
+                p = _abi.MpeRowProgram()
+                p.reset_boxes = 1
+                for e, (lx, hx, ly, hy) in enumerate(boxes):
+                    p.reset_box[e][0], p.reset_box[e][1], p.reset_box[e][2], p.reset_box[e][3] = lx, hx - lx, ly, hy - ly
+                _abi.check(_abi.lib().mpe_reset_rows(C.byref(desc), C.byref(bufs), C.byref(p), B, mptr, 1.0,
+                                                     int(self.seed) & (2 ** 64 - 1), int(self._episode), int(self.world_offset),
+                                                     _abi.raw_stream(self.device)), "mpe_reset_rows")
+            else:
+                _abi.check(_abi.lib().mpe_reset(C.byref(desc), C.byref(bufs), B, mptr, float(landmark_range),
+                                                int(self.seed) & (2 ** 64 - 1), int(self._episode), int(self.world_offset),
+                                                _abi.raw_stream(self.device)),
+                           "mpe_reset")
             if choices:
                 idx = drawn.t().long()
             self._episode += 1

@@ -357,6 +357,27 @@ int mpe_reset(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, const ui
                                       static_cast<hipStream_t>(stream)), what);
 }
 
+int mpe_reset_rows(const MpeScenarioDesc *d, const MpeBuffers *b, const MpeRowProgram *p, int64_t B, const uint8_t *mask,
+                   float landmark_range, uint64_t seed, uint64_t episode, int64_t world_offset, void *stream) {
+  const char *what = "mpe_reset_rows";
+  if (!p) return fail(MPE_EINVAL, "%s: prog is NULL", what);
+  if (!p->reset_boxes) return mpe_reset(d, b, B, mask, landmark_range, seed, episode, world_offset, stream);
+  if (int rc = check_desc(d, what)) return rc;
+  if (int rc = check_state(b, B, what)) return rc;
+  if (d->n_agents + d->n_landmarks > MPE_ROWS_MAX_ENTITIES) return fail(MPE_EINVAL, "%s: more than %d entities", what, MPE_ROWS_MAX_ENTITIES);
+  if (d->n_choices > 0 && b->choice == nullptr)
+    return fail(MPE_EINVAL, "%s: desc->n_choices = %d but bufs->choice is NULL", what, d->n_choices);
+  if (B == 0) return 0;
+  int32_t pop[MPE_MAX_CHOICES] = {1, 1, 1, 1};
+  for (int k = 0; k < d->n_choices; ++k) pop[k] = d->choice_pop[k];
+  mpe::ResetBoxes boxes;
+  std::memset(&boxes, 0, sizeof(boxes));
+  for (int e = 0; e < d->n_agents + d->n_landmarks; ++e)
+    for (int k = 0; k < 4; ++k) boxes.box[e][k] = p->reset_box[e][k];
+  return hip_result(mpe::launch_reset_box(d->n_agents, d->n_landmarks, *b, (size_t)B, mask, boxes, seed, episode,
+                                          (uint64_t)world_offset, d->n_choices, pop, static_cast<hipStream_t>(stream)), what);
+}
+
 int mpe_random_actions_block(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed, uint64_t step0,
                              int32_t T, int64_t world_offset, void *stream) {
   const char *what = "mpe_random_actions_block";
@@ -496,6 +517,10 @@ static int rows_header(const char *what, const MpeScenarioDesc *d, const MpeRowP
     t->rew_begin[i] = i <= A ? p->rew_begin[i] : p->rew_begin[A];
     t->done_begin[i] = i <= A ? p->done_begin[i] : p->done_begin[A];
   }
+  h->reset_boxes = p->reset_boxes ? 1 : 0;
+  if (p->reset_boxes)
+    for (int e = 0; e < E; ++e)
+      for (int k = 0; k < 4; ++k) t->reset_box[e][k] = p->reset_box[e][k];
   h->dt = d->dt;
   h->damp = 1.0f - d->damping;
   h->cforce = d->contact_force;
@@ -857,8 +882,8 @@ int mpe_rows_static_source(const MpeScenarioDesc *d, const MpeRowProgram *p, con
       h.n_vel, h.dim_c, h.collaborative, h.d_max, h.n_picks, h.n_ops, h.n_regions, h.region_entity[0], h.region_entity[1], h.all_seeing,
       (unsigned long long)h.movable, (unsigned long long)h.collide);
   put("__builtin_bit_cast(float, 0x%08xu), __builtin_bit_cast(float, 0x%08xu), __builtin_bit_cast(float, 0x%08xu), "
-      "__builtin_bit_cast(float, 0x%08xu), __builtin_bit_cast(float, 0x%08xu) }\n", fbits(h.dt), fbits(h.damp), fbits(h.cforce),
-      fbits(h.cmargin), fbits(h.cmargin_inv));
+      "__builtin_bit_cast(float, 0x%08xu), __builtin_bit_cast(float, 0x%08xu), %d }\n", fbits(h.dt), fbits(h.damp), fbits(h.cforce),
+      fbits(h.cmargin), fbits(h.cmargin_inv), h.reset_boxes);
   out += "#define MPE_ROWS_STATIC_TABLES { ";
   const uint32_t *tw = reinterpret_cast<const uint32_t *>(&tabs);
   for (size_t k = 0; k < sizeof(tabs) / 4; ++k) put("0x%xu,%s", tw[k], k % 16 == 15 ? " \\\n  " : " ");

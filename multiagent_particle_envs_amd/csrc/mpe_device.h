@@ -274,6 +274,23 @@ __host__ __device__ inline void reset_draw(uint64_t seed, uint64_t b, uint64_t e
   if (e & 1) { x = uniform_pm(o.z, r); y = uniform_pm(o.w, r); }
   else       { x = uniform_pm(o.x, r); y = uniform_pm(o.y, r); }
 }
+// The same draw placed in an entity's own BOX: x = lo_x + span_x * u, y = lo_y + span_y * u' (np.random.uniform(lo, hi) is
+// lo + (hi - lo) * random_sample()) -- a reset_world that places agents in a smaller area, landmarks off-centre ...
+// (row programs with MpeRowProgram.reset_boxes; the symmetric placement above keeps its own rounding sequence)
+__host__ __device__ inline void reset_draw_box(uint64_t seed, uint64_t b, uint64_t ep, int e, float lo_x, float span_x,
+                                               float lo_y, float span_y, float &x, float &y) {
+  U4 c;
+  c.x = (uint32_t)b;
+  c.y = (uint32_t)(b >> 32) ^ (uint32_t)(ep >> 32);
+  c.z = (uint32_t)(e >> 1);
+  c.w = kStreamReset ^ (uint32_t)ep;
+  const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t bx = (e & 1) ? o.z : o.x, by = (e & 1) ? o.w : o.y;
+  const float ux = (float)(bx >> 8) * (1.0f / 16777216.0f), uy = (float)(by >> 8) * (1.0f / 16777216.0f);
+  const float px = span_x * ux, py = span_y * uy;
+  x = lo_x + px;
+  y = lo_y + py;
+}
 // Per-world pick k of reset_world (np.random.choice among n, e.g. the goal landmark) for episode `ep`.
 __host__ __device__ inline int choice_draw(uint64_t seed, uint64_t b, uint64_t ep, int k, int n) {
   U4 c;

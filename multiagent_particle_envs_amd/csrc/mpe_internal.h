@@ -35,6 +35,9 @@ int launch_wide(bool phys, bool out, const WideDesc &d, const MpeBuffers &b, siz
 int launch_reset(int A, int L, const MpeBuffers &b, size_t B, const uint8_t *mask, float landmark_range,
                  uint64_t seed, uint64_t episode, uint64_t world_offset, int n_choices, const int32_t *pop,
                  hipStream_t stream);
+struct ResetBoxes { float box[MPE_ROWS_MAX_ENTITIES][4]; };
+int launch_reset_box(int A, int L, const MpeBuffers &b, size_t B, const uint8_t *mask, const ResetBoxes &boxes, uint64_t seed,
+                     uint64_t episode, uint64_t world_offset, int n_choices, const int32_t *pop, hipStream_t stream);
 int launch_episode_tick(int32_t *episode_step, uint8_t *done, int A, size_t B, int max_steps, int clear_finished,
                         hipStream_t stream);
 int launch_random_actions(float *act, int32_t *ids, int A, size_t B, uint64_t seed, uint64_t step0, int T,
@@ -86,6 +89,7 @@ struct RowDims {
   uint32_t all_seeing;
   uint64_t movable, collide;     // bit e
   float dt, damp, cforce, cmargin, cmargin_inv;
+  int32_t reset_boxes;           // 1: restarts place entity e in RowTables.reset_box[e] (else: agents [-1,1)^2, landmarks [-r,r)^2)
 };
 // Tables of a program: DEVICE memory (uploaded by launch_rows_header whenever their content changes), read by scalar loads;
 // a compiled program (MPE_ROWS_STATIC) carries them as constants.
@@ -95,6 +99,7 @@ struct RowTables {
   int32_t obs_begin[MPE_ROWS_MAX_ENTITIES + 1];   // agent i's observation ops: [obs_begin[i], obs_begin[i + 1])
   int32_t rew_begin[MPE_ROWS_MAX_ENTITIES + 1];   // agent i's reward ops
   int32_t done_begin[MPE_ROWS_MAX_ENTITIES + 1];  // agent i's done ops (all equal: none)
+  float reset_box[MPE_ROWS_MAX_ENTITIES][4];      // lo_x, span_x, lo_y, span_y of entity e's reset placement (RowDims.reset_boxes)
 };
 // episode bookkeeping + masked reset in front of the rows (mpe_episode_finish)
 struct RowEpisode {

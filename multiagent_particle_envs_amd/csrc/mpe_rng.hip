@@ -121,6 +121,37 @@ int launch_episode_tick(int32_t *episode_step, uint8_t *done, int A, size_t B, i
   return (int)hipGetLastError();
 }
 
+// mpe_reset_rows with per-entity boxes (a row program's reset placement): the draws the in-kernel restarts of k_rows make
+__global__ void __launch_bounds__(kBlock)
+k_reset_box(float *__restrict__ pos, float *__restrict__ vel, const uint8_t *__restrict__ mask, size_t B, int A, int E,
+            const ResetBoxes boxes, uint64_t seed, uint64_t episode, uint64_t world_offset, int32_t *__restrict__ choice,
+            int n_choices, int pop0, int pop1, int pop2, int pop3) {
+  const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = blockIdx.y;
+  if (w >= B) return;
+  if (mask && !mask[w]) return;
+  float x, y;
+  reset_draw_box(seed, world_offset + w, episode, e, boxes.box[e][0], boxes.box[e][1], boxes.box[e][2], boxes.box[e][3], x, y);
+  pos[(size_t)(2 * e) * B + w] = x;
+  pos[(size_t)(2 * e + 1) * B + w] = y;
+  if (e < A) {
+    vel[(size_t)(2 * e) * B + w] = 0.f;
+    vel[(size_t)(2 * e + 1) * B + w] = 0.f;
+  }
+  if (e == 0 && choice) {
+    const int pop[MPE_MAX_CHOICES] = {pop0, pop1, pop2, pop3};
+    for (int k = 0; k < n_choices; ++k) choice[(size_t)k * B + w] = choice_draw(seed, world_offset + w, episode, k, pop[k]);
+  }
+}
+
+int launch_reset_box(int A, int L, const MpeBuffers &b, size_t B, const uint8_t *mask, const ResetBoxes &boxes, uint64_t seed,
+                     uint64_t episode, uint64_t world_offset, int n_choices, const int32_t *pop, hipStream_t stream) {
+  const dim3 grid((unsigned)((B + kBlock - 1) / kBlock), (unsigned)(A + L));
+  hipLaunchKernelGGL(k_reset_box, grid, dim3(kBlock), 0, stream, b.pos, b.vel, mask, B, A, A + L, boxes, seed, episode, world_offset,
+                     n_choices > 0 ? b.choice : nullptr, n_choices, pop[0], pop[1], pop[2], pop[3]);
+  return (int)hipGetLastError();
+}
+
 int launch_reset(int A, int L, const MpeBuffers &b, size_t B, const uint8_t *mask, float landmark_range,
                  uint64_t seed, uint64_t episode, uint64_t world_offset, int n_choices, const int32_t *pop,
                  hipStream_t stream) {

@@ -224,6 +224,15 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
     if (!any) return;
   }
   const uint64_t gw = ep.world_offset + w0 + ln;
+  // reset_world's placement of entity e: the program's own boxes (MpeRowProgram.reset_boxes), else agents on [-1,1)^2 and landmarks
+  // on [-range, range)^2 (launch-uniform choice; a constant in a compiled program)
+  auto place = [&](uint64_t seed, uint64_t episode, int e, float range, float &x, float &y) {
+    if (h.reset_boxes)
+      reset_draw_box(seed, gw, episode, e, TF(MPE_TAB(reset_box), 4 * e), TF(MPE_TAB(reset_box), 4 * e + 1),
+                     TF(MPE_TAB(reset_box), 4 * e + 2), TF(MPE_TAB(reset_box), 4 * e + 3), x, y);
+    else
+      reset_draw(seed, gw, episode, e, e < A ? 1.0f : range, x, y);
+  };
 
   // ---- (World.step) this wave's first agent's move leaves for HBM together with the state loads: one memory round trip, not two
   float act_x = 0.f, act_y = 0.f;
@@ -252,7 +261,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
       const int e = k ? e1 : e0;
       if (k && !two) break;
       if (fin) {
-        reset_draw(ep.seed, gw, ep.episode, e, e < A ? 1.0f : ep.landmark_range, x[k], y[k]);
+        place(ep.seed, ep.episode, e, ep.landmark_range, x[k], y[k]);
         (b.pos + wave_off((size_t)(2 * e) * B + w0))[ln] = x[k];
         (b.pos + wave_off((size_t)(2 * e + 1) * B + w0))[ln] = y[k];
         if (e < NV && e < A) {
@@ -318,7 +327,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
       const uint64_t episode = gstep / (uint64_t)ra.episode_len;
       for (int e = wave; e < E; e += NW) {
         float x, y;
-        reset_draw(ra.seed, gw, episode, e, e < A ? 1.0f : ra.landmark_range, x, y);
+        place(ra.seed, episode, e, ra.landmark_range, x, y);
         S_pos[(2 * e) * kWave + lane] = x;
         S_pos[(2 * e + 1) * kWave + lane] = y;
         if (live) {
@@ -743,7 +752,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   for (int e = wave; e < E; e += NW) {
     if (fin) {
       float x, y;
-      reset_draw(ep.seed, gw, episode_now, e, e < A ? 1.0f : ep.landmark_range, x, y);
+      place(ep.seed, episode_now, e, ep.landmark_range, x, y);
       (b.pos + wave_off((size_t)(2 * e) * B + w0))[ln] = x;
       (b.pos + wave_off((size_t)(2 * e + 1) * B + w0))[ln] = y;
       S_pos[(2 * e) * kWave + lane] = x;

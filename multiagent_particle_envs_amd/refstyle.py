@@ -273,7 +273,7 @@ class TracedRefScenario(object):
 
     def __init__(self, scenario, traced):
         self.scenario, self.t = scenario, traced
-        self.landmark_range, self.device_reset = self._uniform_pattern()
+        self.landmark_range, self.device_reset, self._boxes = self._uniform_pattern()
         self._source = None
         self._info = None          # benchmark_data's program, built when first asked for
         self._env = None           # weak reference to the env (its utterance buffer), set by make_traced_env
@@ -288,8 +288,10 @@ class TracedRefScenario(object):
                     t.A, t.E - t.A, t.dim_c, [len(r) for r in t.obs], t.graph.count, t.paths["obs"], t.paths["rew"],
                     ", done %s" % t.paths["done"] if t.paths.get("done") else "",
                     "value-only control flow predicated" if getattr(t, "predicated", False) else "by forking", list(t.pops) or "none",
-                    "is World.reset_uniform's placement (landmarks on [-%g, %g)^2): restarts are drawn on the device, inside the step launch"
-                    % (self.landmark_range, self.landmark_range) if self.device_reset else
+                    ("is World.reset_uniform's placement (landmarks on [-%g, %g)^2): restarts are drawn on the device, inside the step launch"
+                     % (self.landmark_range, self.landmark_range) if self._boxes is None else
+                     "places every entity uniformly in a box of its own: restarts are drawn on the device, inside the step launch")
+                    if self.device_reset else
                     "is the file's own placement: evaluated with torch ops on the device for all worlds at once",
                     getattr(t, "verified", "not run")))
 
@@ -341,32 +343,42 @@ class TracedRefScenario(object):
 
     # ---- reset_world ------------------------------------------------------------------------------------------------------
     def _uniform_pattern(self):
-        """(landmark_range, True) when the traced reset_world is `World.reset_uniform`'s placement: every agent uniform on
-        [-1, 1)^2, every landmark on [-r, r)^2 with one r, from draws of their own; zero velocities and utterances."""
+        """(landmark_range, device_reset, boxes): how the traced reset_world places the entities.  Every coordinate a uniform draw of
+        its own (`np.random.uniform(lo, hi, dim_p)` per entity), zero velocities and utterances -> restarts can be drawn on the
+        device: as World.reset_uniform's placement (agents on [-1,1)^2, every landmark on [-r,r)^2 with one r: boxes None -- all
+        nine reference files) or in per-entity boxes [(lo_x, hi_x, lo_y, hi_y)] (a restricted spawn area ...).  Anything else
+        (positions that depend on a pick or on each other): (1.0, False, None) -- evaluated with torch ops at reset time."""
         t = self.t
-        used, r_lm = set(), None
+        used, boxes = set(), []
         for e in range(t.E):
+            box = []
             for c in range(2):
                 n = t.reset_pos[e][c]
                 # lo + (hi - lo) * U
                 if not (n.op == "add" and n.args[0].op == "const" and n.args[1].op == "mul" and n.args[1].args[0].op == "const" and
                         n.args[1].args[1].op == "U"):
-                    return 1.0, False
+                    return 1.0, False, None
                 lo, span, u = n.args[0].value, n.args[1].args[0].value, n.args[1].args[1].value[0]
-                if u in used or lo >= 0 or abs(span + 2 * lo) > 1e-12 * abs(lo):
-                    return 1.0, False
+                if u in used or span < 0:
+                    return 1.0, False, None
                 used.add(u)
-                r = -lo
-                if e < t.A:
-                    if r != 1.0:
-                        return 1.0, False
-                elif r_lm is None:
-                    r_lm = r
-                elif r != r_lm:
-                    return 1.0, False
+                box += [lo, lo + span]
+            boxes.append(tuple(box))
         zeros = all(n.op == "const" and n.value == 0.0 for v in t.reset_vel for n in v) and \
             all(n.op == "const" and n.value == 0.0 for v in t.reset_c for n in v)
-        return (1.0 if r_lm is None else float(r_lm)), bool(zeros)
+        if not zeros:
+            return 1.0, False, None
+
+        def sym(b, r):
+            return all(abs(x - y) <= 1e-12 * max(1.0, abs(r)) for x, y in zip(b, (-r, r, -r, r)))
+        r_lm = boxes[t.A][1] if t.E > t.A else 1.0
+        if all(sym(b, 1.0) for b in boxes[:t.A]) and r_lm > 0 and all(sym(b, r_lm) for b in boxes[t.A:]):
+            return float(r_lm), True, None
+        return 1.0, True, boxes
+
+    def reset_boxes(self, world):
+        """rowspec.compile_scenario: the per-entity placement boxes of the program's restarts (None: the reference's placement)"""
+        return self._boxes
 
     def make_world(self, batch_size=1, device=None):
         t, w0 = self.t, self.t.world
@@ -390,8 +402,13 @@ class TracedRefScenario(object):
 
     def reset_world(self, world, mask=None, seeds=None):
         t, B = self.t, world.batch_size
-        if seeds is None and self.device_reset and world.rng_mode == "device":
-            idx = world.reset_uniform(self.landmark_range, mask, choices=list(t.pops))
+        if seeds is None and self.device_reset and world.rng_mode == "device" and world.pos.is_cuda:
+            if self._boxes is None:
+                idx = world.reset_uniform(self.landmark_range, mask, choices=list(t.pops))
+            else:
+                idx = world.reset_boxes(self._boxes, mask, choices=list(t.pops))
+            if idx is None:
+                idx = torch.zeros((B, 0), dtype=torch.long, device=world.device)
             self._merge_picks(world, idx, mask)
             return
         from . import symtrace

@@ -111,8 +111,12 @@ class RandomRollout(object):
                 self._fill_pool(self.t // len(self.pool) * len(self.pool), st)
             if self.episode_len and self.t % self.episode_len == 0:
                 b = env._sets[0].bufs
-                _abi.check(L.mpe_reset(C.byref(self._gen_desc), C.byref(b), B, None, self._lr, self.seed,
-                                       self.t // self.episode_len, int(w.world_offset), st), "mpe_reset")
+                if self._prog is not None:      # the program's own placement (MpeRowProgram.reset_boxes), as its in-launch restarts draw it
+                    _abi.check(L.mpe_reset_rows(C.byref(self._gen_desc), C.byref(b), self._prog.ref, B, None, self._lr, self.seed,
+                                                self.t // self.episode_len, int(w.world_offset), st), "mpe_reset_rows")
+                else:
+                    _abi.check(L.mpe_reset(C.byref(self._gen_desc), C.byref(b), B, None, self._lr, self.seed,
+                                           self.t // self.episode_len, int(w.world_offset), st), "mpe_reset")
             out = env._sets[self.t & 1]
             b = out.bufs
             move = self.pool[self.t % len(self.pool)].data_ptr()

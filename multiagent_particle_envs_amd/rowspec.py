@@ -426,10 +426,13 @@ def fuse_reward(ops):
 class RowProgram(object):
     """The compiled programs of one env: ops on the device + the MpeRowProgram header the C ABI takes."""
 
-    def __init__(self, world, obs_specs, reward_specs, regions=None, fuse=None, done_specs=None, source=None):
+    def __init__(self, world, obs_specs, reward_specs, regions=None, fuse=None, done_specs=None, source=None, reset_boxes=None):
         """fuse: run the peephole pass (runs of per-entity ops -> range forms); False keeps one op per spec call (the A/B);
         None: the module's FUSE switch.  done_specs: one DoneSpec (or None: never done) per agent.  source: the device
-        functions the program's code ops call (symtrace.hip_source), appended to the generated header of the compiled form."""
+        functions the program's code ops call (symtrace.hip_source), appended to the generated header of the compiled form.
+        reset_boxes: one (lo_x, hi_x, lo_y, hi_y) per entity -- reset_world places entity e uniformly in that box
+        (`np.random.uniform(lo, hi, dim_p)`); every restart the library draws for this program (episode ends inside the launch,
+        rollouts, mpe_reset_rows) then uses it.  None: the reference's placement (agents [-1,1)^2, landmarks [-r,r)^2)."""
         fuse = FUSE if fuse is None else fuse
         self.source = source
         A = len(world.agents)
@@ -486,6 +489,15 @@ class RowProgram(object):
         for a in regions.all_seeing:
             mask |= 1 << (a if isinstance(a, int) else next(k for k, e in enumerate(world.agents) if e is a))
         p.all_seeing = mask
+        p.reset_boxes = 0
+        if reset_boxes is not None:
+            if len(reset_boxes) != len(world.entities):
+                raise _abi.MpeError("reset_boxes: one (lo_x, hi_x, lo_y, hi_y) per entity")
+            p.reset_boxes = 1
+            for e, (lx, hx, ly, hy) in enumerate(reset_boxes):
+                if not (hx >= lx and hy >= ly):
+                    raise _abi.MpeError("reset_boxes: entity %d has an empty box" % e)
+                p.reset_box[e][0], p.reset_box[e][1], p.reset_box[e][2], p.reset_box[e][3] = lx, hx - lx, ly, hy - ly
         codes = (_abi.MPE_ROW_OBS_CODE, _abi.MPE_ROW_R_CODE, _abi.MPE_ROW_R_DONE_CODE)
         p.traced = 1 if any((op[0] & 0xFF) in codes for op in ops) else 0
         if p.traced and not source:
@@ -549,7 +561,8 @@ def compile_scenario(scenario, world):
     dsf = getattr(scenario, "done_spec", None)
     done = [dsf(a, world) for a in world.agents] if dsf is not None else None
     src = scenario.row_source(world) if hasattr(scenario, "row_source") else None
-    return RowProgram(world, obs, rew, rg, done_specs=done, source=src)
+    boxes = scenario.reset_boxes(world) if callable(getattr(scenario, "reset_boxes", None)) else None
+    return RowProgram(world, obs, rew, rg, done_specs=done, source=src, reset_boxes=boxes)
 
 
 # built-in scenarios whose callbacks are written for any team size: where no fused kernel exists for a shape, the env runs

@@ -26,8 +26,11 @@ one small launch behind it (`mpe_episode_finish`), and RandomRollout resets epis
 exactly `world.reset_uniform(landmark_range, choices=choice_pops)` (agents U[-1,1)^2, landmarks U[-r,r)^2, vel = 0, uniform
 picks, utterances zeroed) and never call `reset_world`.  They are used for the built-in scenarios' own reset_world and for
 a scenario that declares `device_reset = True` (its reset_world is that placement -- examples/corral.py), in rng_mode
-'device'; any other reset_world (fixed posts, a restricted spawn area, per-world state of its own) is called with a mask.  A file written against the REFERENCE's
-contract (`make_world(self)`, NumPy callbacks) loads unmodified through refstyle.py.
+'device'; any other reset_world (fixed posts, per-world state of its own) is called with a mask.  A restricted spawn area is
+still a device-side draw: `reset_boxes(world) -> [(lo_x, hi_x, lo_y, hi_y) per entity]` beside `device_reset = True` makes the
+program's restarts place every entity uniformly in its own box, and `world.reset_boxes(boxes, mask, choices, seeds)` is the
+matching reset_world (the same draws).  A file written against the REFERENCE's contract (`make_world(self)`, NumPy callbacks)
+loads unmodified through refstyle.py -- traced into the step kernel (symtrace.py) where that is possible.
 """
 
 

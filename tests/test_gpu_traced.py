@@ -217,11 +217,11 @@ def test_a_traced_program_runs_compiled_in_only():
 
 
 def test_episode_ends_of_traced_envs():
-    """relay's reset_world is World.reset_uniform's placement: with auto_reset the episodes end and restart INSIDE the step launch;
-    herd places its agents in [-0.8, 0.8)^2: finished worlds go through the traced reset_world (masked), not the device draw."""
+    """relay's reset_world is World.reset_uniform's placement, herd places its agents in [-0.8, 0.8)^2 -- a box per entity: either
+    way the episodes end and restart INSIDE the step launch, by the file's own placement."""
     W = 256
     rs = np.random.RandomState(1)
-    for name, in_launch in (("relay", True), ("herd", False)):
+    for name, in_launch in (("relay", True), ("herd", True)):
         env = mpe.make_env(os.path.join(FIXTURES, name + ".py"), batch_size=W, max_episode_steps=3, auto_reset=True)
         assert env.traced and env._episode_in_launch == in_launch and env._device_restart_ok == in_launch
         env.reset()
@@ -237,18 +237,21 @@ def test_episode_ends_of_traced_envs():
         pos, vel = env.world.get_state()
         assert np.all(vel == 0) and not np.allclose(pos, p0)              # every world restarted
         A = len(env.world.agents)
-        assert np.abs(pos[:, :A]).max() < (1.0 if in_launch else 0.8)     # ... by ITS reset_world's placement
-        if not in_launch:
-            assert np.abs(pos[:, :A]).max() > 0.7
+        assert np.abs(pos[:, :A]).max() < (0.8 if name == "herd" else 1.0)     # ... by ITS reset_world's placement
+        if name == "herd":
+            assert np.abs(pos[:, :A]).max() > 0.7 and np.abs(pos[:, A:]).max() > 0.9
         # the rows of the restarted worlds are the new episode's first: the agent's own position columns say so
         own = obs[1 if name == "herd" else 0]
         if name == "herd":
             assert np.allclose(own[:, 2:4].cpu().numpy(), pos[:, 1], atol=1e-6)
 
 
-def test_fused_rollout_of_a_traced_env_equals_its_per_step_launches():
+@pytest.mark.parametrize("name", ["relay", "herd"])
+def test_fused_rollout_of_a_traced_env_equals_its_per_step_launches(name):
+    """... whatever the placement of its resets: herd's per-entity boxes are drawn by mpe_reset_rows at the episode boundaries of
+    the per-step form and inside the kernel in the fused form -- the same draws."""
     B, T = 2048, 12
-    path = os.path.join(FIXTURES, "relay.py")
+    path = os.path.join(FIXTURES, name + ".py")
     a, b = mpe.make_env(path, batch_size=B, seed=9), mpe.make_env(path, batch_size=B, seed=9)
     ra, rb = RandomRollout(a, episode_len=5, pool=5, regenerate=True), RandomRollout(b, episode_len=5, pool=5, regenerate=True)
     ra.enqueue(T)
@@ -260,11 +263,62 @@ def test_fused_rollout_of_a_traced_env_equals_its_per_step_launches():
     for x, y in zip(oa.obs_n, ob.obs_n):
         assert torch.equal(x, y)
     assert torch.equal(oa.rew, ob.rew)
-    # herd's reset_world is not the device draw: a rollout that would reset episodes on the device refuses, with the reason
-    h = mpe.make_env(os.path.join(FIXTURES, "herd.py"), batch_size=64)
+    if name == "herd":
+        A = len(a.world.agents)
+        assert float(a.world.pos[:A].abs().max()) < 1.6 and a.scenario.reset_boxes(a.world) is not None
+
+
+def test_a_reset_world_that_is_not_a_box_per_entity_is_evaluated_on_the_device_at_reset_time():
+    """Positions that depend on a per-world pick (agents spawn on the side of the arena the pick names): no device-side draw fits;
+    the traced reset program is drawn and evaluated with torch ops for all (masked) worlds at once, the episodes restart through
+    the masked reset_callback, and a rollout that would reset on the device refuses with the reason."""
+    from multiagent_particle_envs_amd import compat
+    compat.install()
+    from multiagent.core import World, Agent, Landmark
+    from multiagent.scenario import BaseScenario
+
+    class Sides(BaseScenario):
+        def make_world(self):
+            world = World()
+            world.agents = [Agent() for _ in range(2)]
+            for i, a in enumerate(world.agents):
+                a.name, a.silent, a.size = "agent %d" % i, True, 0.05
+            world.landmarks = [Landmark()]
+            world.landmarks[0].name, world.landmarks[0].collide, world.landmarks[0].movable = "flag", False, False
+            self.reset_world(world)
+            return world
+
+        def reset_world(self, world):
+            world.side = np.random.choice([-1.0, 1.0])
+            for a in world.agents:
+                a.state.p_pos = np.random.uniform(-0.2, +0.2, world.dim_p) + np.array([0.6, 0.0]) * world.side
+                a.state.p_vel = np.zeros(world.dim_p)
+                a.state.c = np.zeros(world.dim_c)
+            world.landmarks[0].state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            world.landmarks[0].state.p_vel = np.zeros(world.dim_p)
+
+        def reward(self, agent, world):
+            return -np.sum(np.square(agent.state.p_pos - world.landmarks[0].state.p_pos)) + 0.1 * world.side * agent.state.p_pos[0]
+
+        def observation(self, agent, world):
+            return np.concatenate([agent.state.p_vel, agent.state.p_pos, world.landmarks[0].state.p_pos - agent.state.p_pos, [world.side]])
+
+    B = 1024
+    env = refstyle.make_ref_env(Sides(), batch_size=B, seed=2, max_episode_steps=4, auto_reset=True)
+    assert env.traced and not env.scenario.device_reset and not env._episode_in_launch
+    obs = env.reset()
+    side = obs[0][:, 6].cpu().numpy()
+    x = env.world.get_state()[0][:, :2, 0]
+    assert set(np.unique(side)) == {-1.0, 1.0} and np.all(np.abs(x - 0.6 * side[:, None]) < 0.2 + 1e-6)
+    act = torch.zeros((2, B, 5), device="cuda")
+    for t in range(1, 5):
+        obs, rew, done, _ = env.step(act)
+        assert bool(done[0].all()) == (t == 4)
+    x = env.world.get_state()[0][:, :2, 0]
+    side2 = obs[0][:, 6].cpu().numpy()
+    assert np.all(np.abs(x - 0.6 * side2[:, None]) < 0.2 + 1e-6) and (side2 != side).mean() > 0.3      # restarted, by ITS placement
     with pytest.raises(_abi.MpeError, match="reset_uniform"):
-        RandomRollout(h, episode_len=5)
-    RandomRollout(h, episode_len=0).enqueue(3)
+        RandomRollout(refstyle.make_ref_env(Sides(), batch_size=64), episode_len=5)
 
 
 def test_a_traced_done_callback_ends_episodes_inside_the_step_launch():

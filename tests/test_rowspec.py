@@ -892,3 +892,61 @@ def test_done_programs_restart_through_reset_world_where_it_is_not_the_device_dr
             assert float(env.world.pos[:3][:, :, fin].abs().max()) < 0.25          # ITS placement, at the step the test fired
             assert float(env.world.vel[:3][:, :, fin].abs().max()) == 0.0
     assert restarted >= B                                          # every world left at least once
+
+
+@pytest.mark.gpu
+def test_reset_boxes_a_restricted_spawn_area_restarts_inside_the_launch():
+    """`device_reset = True` + `reset_boxes(world)`: a scenario whose agents start in [-0.25, 0.25)^2 and whose posts start in the
+    right half of the arena -- its reset_world is `world.reset_boxes(...)`, and the program's in-launch restarts, its rollouts'
+    resets and mpe_reset_rows all make the same draws."""
+    boxes = [(-0.25, 0.25, -0.25, 0.25)] * 3 + [(0.2, 0.9, -0.9, 0.9)] * 3
+
+    class Yard(Corral):
+        device_reset = True
+        arena = 0.95
+
+        def reset_boxes(self, world):
+            return boxes
+
+        def reset_world(self, world, mask=None, seeds=None):
+            idx = world.reset_boxes(boxes, mask, choices=[3], seeds=seeds)
+            if world.choice_i32 is not None:
+                world.choice_i32[0].copy_(World.merge_choice(world.choice_i32[0].long(), idx[:, 0].to(world.device), mask).to(torch.int32))
+
+    def make(B, **kw):
+        sc = Yard()
+        w = sc.make_world(batch_size=B)
+        w.seed = 21
+        sc.reset_world(w)
+        env = mpe.MultiAgentEnv(w, sc.reset_world, sc.reward, sc.observation, compile_program=False, **kw)
+        env.scenario = sc
+        return env
+    B = 4096
+    env = make(B, max_episode_steps=1000, auto_reset=True)
+    assert env._prog.struct.reset_boxes == 1 and env._device_restart_ok and env._episode_in_launch
+    env.reset()
+    p = env.world.pos
+    assert float(p[:3].abs().max()) < 0.25 and float(p[3:, 0].min()) >= 0.2 and float(p[3:, 0].max()) < 0.9 and float(p[3:, 1].abs().max()) < 0.9
+    act = torch.zeros((3, B, 5), device="cuda")
+    act[:, :, 1] = 1.0
+    restarted = 0
+    for t in range(40):
+        obs, rew, done, _ = env.step(act)
+        fin = done[0] | done[1] | done[2]
+        if bool(fin.any()):
+            restarted += int(fin.sum())
+            assert float(env.world.pos[:3][:, :, fin].abs().max()) < 0.25 and float(env.world.pos[3:, 0][:, fin].min()) >= 0.2
+            assert bool((env.episode_step[fin] == 0).all())
+    assert restarted >= B
+    # the host-side seeded form places in the same boxes
+    env.reset(seeds=list(range(B)))
+    assert float(env.world.pos[:3].abs().max()) < 0.25 and float(env.world.pos[3:, 0].min()) >= 0.2
+    # rollouts: the fused launch (resets drawn in the kernel) == per-step launches with mpe_reset_rows at the boundaries, to the bit
+    from multiagent_particle_envs_amd.rollout import RandomRollout
+    a, b = make(2048), make(2048)
+    ra, rb = RandomRollout(a, episode_len=4, pool=4, regenerate=True), RandomRollout(b, episode_len=4, pool=4, regenerate=True)
+    ra.enqueue(11)
+    rb.fused(11)
+    torch.cuda.synchronize()
+    assert torch.equal(a.world.pos, b.world.pos) and torch.equal(a.world.vel, b.world.vel) and torch.equal(a.world.choice_i32, b.world.choice_i32)
+    assert torch.equal(a._sets[(11 - 1) & 1].obs, b._sets[0].obs)

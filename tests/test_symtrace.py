@@ -207,8 +207,12 @@ def test_fixture_files_trace_and_reproduce_their_own_callbacks(name):
     ts = refstyle.trace_ref_scenario(sc, cache=False)
     assert ts.t.verified == 0.0
     assert symtrace.verify(sc, ts.t, worlds=300, seed=7) == 0.0
-    # herd places its agents in [-0.8, 0.8)^2: not World.reset_uniform's placement; relay's is
-    assert ts.device_reset == (name != "herd") and ts.landmark_range == (1.0 if name == "herd" else 0.9)
+    # every coordinate a uniform draw of its own: restarts can be drawn on the device -- relay / convoy as World.reset_uniform's
+    # placement, herd (agents on [-0.8, 0.8)^2) in per-entity boxes
+    assert ts.device_reset and ts.landmark_range == (1.0 if name == "herd" else 0.9)
+    assert (ts.reset_boxes(None) is None) == (name != "herd")
+    if name == "herd":
+        assert ts.reset_boxes(None)[0] == (-0.8, 0.8, -0.8, 0.8) and ts.reset_boxes(None)[3] == (-1.0, 1.0, -1.0, 1.0)
 
 
 def test_patrol_stays_on_the_host_path_with_the_reason():
