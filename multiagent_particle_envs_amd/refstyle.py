@@ -649,7 +649,9 @@ def trace_ref_scenario(scenario, want_done=False, verify_worlds=64, cache=True, 
     if t.E > _abi.MPE_ROWS_MAX_ENTITIES:
         raise symtrace.TraceUnsupported("%d entities (row programs cover %d)" % (t.E, _abi.MPE_ROWS_MAX_ENTITIES))
     t.verified = symtrace.verify(scenario, t, worlds=verify_worlds)
-    return TracedRefScenario(scenario, t)
+    ts = TracedRefScenario(scenario, t)
+    ts.row_source(None)          # (generated now: a program too large for straight-line code is refused here, with the reason)
+    return ts
 
 
 def make_traced_env(ts, batch_size, device=None, seed=0, max_episode_steps=None, auto_reset=False, fresh_outputs=False, benchmark=False):

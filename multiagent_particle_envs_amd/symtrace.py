@@ -1840,4 +1840,13 @@ def hip_source(t):
         out.append("      return %s;" % v)
         out.append("    }")
     out += ["    default: return false;", "  }", "}", "}  // namespace", "}  // namespace mpe", ""]
+    # straight-line code: every agent's functions spell out their whole graph (a reward that visits every agent-landmark pair is
+    # N^2 statements per agent, N^3 per program) -- past a size the compiler takes minutes (N = 16 cooperative navigation: 35 K
+    # statements, 2 minutes of hipcc, a 1.6 MB image).  Larger programs are refused: the file runs on the host path, and teams of
+    # that size are what the built-in kernels / looped row programs are for.
+    import os
+    limit = int(os.environ.get("MPE_TRACE_MAX_STATEMENTS", "60000"))
+    if len(out) > limit:
+        raise TraceUnsupported("the traced program is %d statements of straight-line device code (limit %d, MPE_TRACE_MAX_STATEMENTS): "
+                               "too large a team for per-agent generated code" % (len(out), limit))
     return "\n".join(out)

@@ -452,6 +452,21 @@ def test_value_only_control_flow_is_predicated_not_forked(tmp_path, n_agents):
             symtrace.trace(sc, predicate=False)
 
 
+def test_a_team_too_large_for_straight_line_code_is_refused_with_the_reason(tmp_path, monkeypatch):
+    """Every agent's functions spell out their whole graph: N^3 statements for a reward that visits every agent-landmark pair.
+    Past MPE_TRACE_MAX_STATEMENTS the file stays on the host path (the trace itself is instant and exact)."""
+    path = tmp_path / "big_team.py"
+    path.write_text(_PREDICATION_FILE.replace("N_AGENTS", "12"))
+    sc = mpe.scenarios.load(str(path)).Scenario()
+    ts = refstyle.trace_ref_scenario(sc, cache=False)
+    n = len(ts.row_source(None).splitlines())
+    monkeypatch.setenv("MPE_TRACE_MAX_STATEMENTS", str(n // 2))
+    with pytest.raises(symtrace.TraceUnsupported, match="statements of straight-line device code"):
+        refstyle.trace_ref_scenario(sc, cache=False)
+    env = mpe.make_env(str(path), batch_size=2, device="cpu")
+    assert not env.traced and "straight-line" in env.trace_fallback
+
+
 def test_the_fixtures_and_committed_traces_hardly_fork():
     for name in ("herd", "relay", "convoy"):
         sc = mpe.scenarios.load(os.path.join(FIXTURES, name + ".py")).Scenario()

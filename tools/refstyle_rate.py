@@ -60,6 +60,76 @@ def device_rates(env, worlds, n=500):
     return best * 1e6, (time.time() - t0) / (40 * 25) * 1e6, EP
 
 
+_NAV = '''
+import numpy as np
+from multiagent.core import World, Agent, Landmark
+from multiagent.scenario import BaseScenario
+
+
+class Scenario(BaseScenario):
+    """cooperative navigation against the reference's contract, N agents and N landmarks (what a user gets who raises N in a copy
+    of the reference's scenario; np.linalg.norm instead of sqrt(sum(square())))"""
+    def make_world(self):
+        world = World()
+        world.dim_c = 2
+        world.collaborative = True
+        world.agents = [Agent() for _ in range(N_)]
+        for i, agent in enumerate(world.agents):
+            agent.name, agent.collide, agent.silent, agent.size = "agent %d" % i, True, True, 0.15
+        world.landmarks = [Landmark() for _ in range(N_)]
+        for i, lm in enumerate(world.landmarks):
+            lm.name, lm.collide, lm.movable = "landmark %d" % i, False, False
+        self.reset_world(world)
+        return world
+
+    def reset_world(self, world):
+        for e in world.agents + world.landmarks:
+            e.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            e.state.p_vel = np.zeros(world.dim_p)
+        for a in world.agents:
+            a.state.c = np.zeros(world.dim_c)
+
+    def reward(self, agent, world):
+        rew = 0
+        for lm in world.landmarks:
+            rew -= min(np.linalg.norm(a.state.p_pos - lm.state.p_pos) for a in world.agents)
+        for a in world.agents:
+            if np.linalg.norm(a.state.p_pos - agent.state.p_pos) < a.size + agent.size:
+                rew -= 1
+        return rew
+
+    def observation(self, agent, world):
+        lms = [lm.state.p_pos - agent.state.p_pos for lm in world.landmarks]
+        others = [o.state.p_pos - agent.state.p_pos for o in world.agents if o is not agent]
+        return np.concatenate([agent.state.p_vel, agent.state.p_pos] + lms + others + [np.zeros(2 * (len(world.agents) - 1))])
+'''
+
+
+def team_sizes(args):
+    """How far straight-line traced code carries: N x N cooperative navigation as a reference-style file."""
+    import tempfile
+    for n in args.nav:
+        path = os.path.join(tempfile.gettempdir(), "mpe_nav%d.py" % n)
+        with open(path, "w") as fh:
+            fh.write(_NAV.replace("N_", str(n)))
+        t0 = time.time()
+        env = mpe.make_env(path, batch_size=args.worlds)
+        build = time.time() - t0
+        if not env.traced:
+            print("N=%-3d host path: %s" % (n, env.trace_fallback))
+            continue
+        t = env.scenario.t
+        g, f, _ = device_rates(env, args.worlds, n=200)
+        b = mpe.make_env("simple_spread", batch_size=args.worlds, num_agents=n)
+        g2, f2, _ = device_rates(b, args.worlds, n=200)
+        print("N=%-3d traced: build %.1f s (trace + verify + hipcc%s), %d graph nodes, %d statements; graph protocol %.2f us per step = %.3g "
+              "env-steps/s, 25-step rollouts %.2f us per step   | built-in simple_spread N=%d (%s): %.2f / %.2f us  (traced / built-in: %.2f / %.2f)"
+              % (n, build, "" if build > 2 else ": cached", t.graph.count, len(env.scenario.row_source(env.world).splitlines()), g,
+                 args.worlds / (g * 1e-6), f, n, b.step_impl if hasattr(b, "step_impl") else "", g2, f2, g / g2, f / f2))
+        del env, b
+        torch.cuda.empty_cache()
+
+
 def special(args):
     import json
     from multiagent_particle_envs_amd import refstyle
@@ -103,9 +173,14 @@ def main():
     ap.add_argument("--json", action="append", default=[], metavar="NAME",
                     help="a committed trace of one of the reference's nine files (tests/golden/traced_NAME.json): its graph-protocol and "
                          "rollout rates beside the built-in scenario of that name (the hand-fused kernel)")
+    ap.add_argument("--nav", action="append", type=int, default=[], metavar="N",
+                    help="cooperative navigation with N agents and N landmarks written as a reference-style file (generated into /tmp): "
+                         "trace / compile times and rates beside the built-in simple_spread at that size")
     ap.add_argument("--profile-steps", type=int, default=0,
                     help="only: build the traced env(s) at --worlds and run this many eager env.step calls (for rocprofv3)")
     args = ap.parse_args()
+    if args.nav:
+        return team_sizes(args)
     if args.json or args.profile_steps:
         return special(args)
     here = os.path.dirname(os.path.abspath(__file__))
