@@ -123,9 +123,9 @@ def team_sizes(args):
         b = mpe.make_env("simple_spread", batch_size=args.worlds, num_agents=n)
         g2, f2, _ = device_rates(b, args.worlds, n=200)
         print("N=%-3d traced: build %.1f s (trace + verify + hipcc%s), %d graph nodes, %d statements; graph protocol %.2f us per step = %.3g "
-              "env-steps/s, 25-step rollouts %.2f us per step   | built-in simple_spread N=%d (%s): %.2f / %.2f us  (traced / built-in: %.2f / %.2f)"
+              "env-steps/s, 25-step rollouts %.2f us per step   | built-in simple_spread N=%d : %.2f / %.2f us  (traced / built-in: %.2f / %.2f)"
               % (n, build, "" if build > 2 else ": cached", t.graph.count, len(env.scenario.row_source(env.world).splitlines()), g,
-                 args.worlds / (g * 1e-6), f, n, b.step_impl if hasattr(b, "step_impl") else "", g2, f2, g / g2, f / f2))
+                 args.worlds / (g * 1e-6), f, n, g2, f2, g / g2, f / f2))
         del env, b
         torch.cuda.empty_cache()
 
