@@ -1800,6 +1800,33 @@ def _emit(roots, lines, names):
     return [names[r.uid] for r in roots]
 
 
+def _device_form(g, roots):
+    """The graphs as they are GENERATED (what is verified and evaluated on the host stays the trace itself): the smallest / largest
+    of several distances as ONE square root -- min(sqrt(a), sqrt(b)) == sqrt(min(a, b)), the form the hand-written kernels use
+    (`fast_sqrt(min_d2_run(...))`): a reward that takes, per landmark, the distance of the nearest of N agents evaluates N square
+    roots (quarter-rate instructions) instead of N^2."""
+    memo = {}
+
+    def rebuild(n):
+        r = memo.get(n.uid)
+        if r is not None:
+            return r
+        args = tuple(rebuild(a) for a in n.args)
+        if n.op in ("min", "max") and args[0].op == "sqrt" and args[1].op == "sqrt":
+            r = g.unary("sqrt", g.binary(n.op, args[0].args[0], args[1].args[0]))
+        elif all(a is b for a, b in zip(args, n.args)):
+            r = n
+        else:
+            r = g.node(n.op, args, n.value)
+        memo[n.uid] = r
+        return r
+    # (iteratively deep graphs: accumulation chains of a few hundred nodes -- within Python's recursion limit for the program sizes
+    #  hip_source accepts; topo order makes every argument available before its user)
+    for n in topo(roots):
+        rebuild(n)
+    return [memo[r.uid] for r in roots]
+
+
 def hip_source(t):
     """The device functions of a trace: what is appended to the generated header of the compiled row program (the kernel calls
     them through the ops MPE_ROW_OBS_CODE / R_CODE / R_DONE_CODE).  P, V, W, K are the kernel's accessors of the staged state."""
@@ -1808,9 +1835,11 @@ def hip_source(t):
            "template <class FP, class FV, class FW, class FK>",
            "__device__ __forceinline__ void traced_obs(const int i, float *const row, const FP &P, const FV &V, const FW &W, const FK &K) {",
            "  switch (i) {"]
+    g = getattr(t, "graph", None)
+    form = (lambda roots: _device_form(g, roots)) if g is not None else (lambda roots: list(roots))
     for i, row in enumerate(t.obs):
         lines, names = [], {}
-        vals = _emit(row, lines, names)
+        vals = _emit(form(row), lines, names)
         out.append("    case %d: {" % i)
         out += lines
         out += ["      row[%d] = %s;" % (j, v) for j, v in enumerate(vals)]
@@ -1821,7 +1850,7 @@ def hip_source(t):
             "  switch (i) {"]
     for i, r in enumerate(t.rew):
         lines, names = [], {}
-        v = _emit([r], lines, names)[0]
+        v = _emit(form([r]), lines, names)[0]
         out.append("    case %d: {" % i)
         out += lines
         out.append("      return %s;" % v)
