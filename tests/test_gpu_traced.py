@@ -389,3 +389,87 @@ def test_a_traced_done_callback_ends_episodes_inside_the_step_launch():
         act = torch.as_tensor(np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=(2, B))]).cuda()
         _, _, dc, _ = c.step(act)
     assert int(c.episode_step.max()) == 6 and int((c.episode_step < 6).sum()) > 10      # some worlds restarted on the way
+
+
+def test_every_node_kind_as_device_code_against_the_numpy_evaluation_of_the_trace():
+    """A scenario that uses every kind of node the tracer knows (arithmetic, division, abs, min / max, sqrt, exp, log, tanh, sin, cos,
+    atan2, comparisons and selects, picks, utterances, np.where / clip / maximum): the kernel's rows and rewards against the fp64
+    NumPy evaluation of the same graphs on the kernel's own state."""
+    from multiagent_particle_envs_amd import compat
+    compat.install()
+    from multiagent.core import World, Agent, Landmark
+    from multiagent.scenario import BaseScenario
+
+    class Zoo(BaseScenario):
+        def make_world(self):
+            world = World()
+            world.dim_c = 3
+            world.agents = [Agent() for _ in range(3)]
+            for i, a in enumerate(world.agents):
+                a.name, a.silent, a.size, a.max_speed = "agent %d" % i, i != 1, 0.06 + 0.02 * i, 1.2
+            world.landmarks = [Landmark() for _ in range(2)]
+            for l in world.landmarks:
+                l.movable, l.collide, l.size = False, False, 0.1
+            self.reset_world(world)
+            return world
+
+        def reset_world(self, world):
+            world.mode = np.random.choice([0.5, 1.0, 2.0])
+            world.target = np.random.choice(world.landmarks)
+            for e in world.agents + world.landmarks:
+                e.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+                e.state.p_vel = np.zeros(world.dim_p)
+            for a in world.agents:
+                a.state.c = np.zeros(world.dim_c)
+
+        def reward(self, agent, world):
+            d = agent.state.p_pos - world.target.state.p_pos
+            r = np.sqrt(np.sum(np.square(d)))
+            speed = np.linalg.norm(agent.state.p_vel)
+            ang = np.arctan2(d[1], d[0] + 1e-2)
+            rew = -world.mode * r + 0.1 * np.cos(ang) - 0.05 * np.sin(2.0 * ang) + np.tanh(speed) / (1.0 + r)
+            rew += 0.01 * np.log(1.0 + r * r) - np.exp(-3.0 * r) + max(abs(d[0]), abs(d[1])) * 0.2 - min(r, 0.7)
+            rew -= np.sum(np.clip(np.abs(agent.state.p_pos) - 0.9, 0.0, 0.5))
+            rew += 0.3 * np.sum(world.agents[1].state.c * np.array([1.0, -2.0, 0.5]))
+            if r < agent.size + world.target.size:
+                rew += 2.0
+            elif r > 1.5:
+                rew -= (r - 1.5) ** 2
+            return rew
+
+        def observation(self, agent, world):
+            d = world.target.state.p_pos - agent.state.p_pos
+            near = np.where(np.abs(d) < 0.5, d, np.sign(1.0) * 0.5 * np.ones(2))
+            return np.concatenate([agent.state.p_vel / (1.0 + np.linalg.norm(agent.state.p_vel)), np.maximum(agent.state.p_pos, -0.5),
+                                   d, near, [world.mode], world.agents[1].state.c, [np.exp(-np.dot(d, d))]])
+
+    B = 8192
+    env = refstyle.make_ref_env(Zoo(), batch_size=B, seed=4)
+    assert env.traced, env.trace_fallback
+    tr = env.scenario.t
+    ops = set(n.op for n in symtrace.topo([x for row in tr.obs for x in row] + list(tr.rew)))
+    assert {"add", "sub", "mul", "div", "abs", "min", "max", "sqrt", "exp", "log", "tanh", "sin", "cos", "atan2", "lt", "ite", "sel"} <= ops, ops
+    env.reset()
+    rs = np.random.RandomState(3)
+    worst = 0.0
+    for t in range(5):
+        if t == 2:
+            env.world.pos.mul_(0.3)
+        moves = torch.as_tensor(np.eye(5, dtype=np.float32)[rs.randint(0, 5, size=(3, B))]).cuda()
+        words = torch.as_tensor(rs.uniform(0, 1, size=(3, B, 3)).astype(np.float32)).cuda()
+        obs, rew, _, _ = env.step((moves, words))
+        P, V = env.world.get_state(all_entities=True)
+        Cw = np.zeros((B, 3, 3))
+        Cw[:, 1] = env._comm[1].cpu().numpy()
+        K = env.world.choice_i32.cpu().numpy().T
+        st = dict(P=P.astype(np.float64), V=V.astype(np.float64), Cw=Cw, K=K)
+        roots = [x for row in tr.obs for x in row] + list(tr.rew)
+        vals = symtrace.evaluate(roots, B, **st)
+        ok = symtrace.decision_margin(roots, B, **st) > 2e-6
+        assert ok.mean() > 0.97
+        off = np.cumsum([0] + [len(r) for r in tr.obs])
+        for i in range(3):
+            want = np.stack(vals[off[i]:off[i + 1]], axis=1)
+            worst = max(worst, close(obs[i][torch.as_tensor(ok)], want[ok], "obs%d t=%d" % (i, t)))
+            worst = max(worst, close(rew[i][torch.as_tensor(ok)], vals[off[-1] + i][ok], "rew%d t=%d" % (i, t)))
+    assert worst <= TOL
