@@ -288,8 +288,8 @@ enum MpeRowOp {
   MPE_ROW_R_DONE_IF_HIT = 55,   /* done = done or |p[a0] - p[a1]| < size[a0] + size[a1] (strict, exact)   */
   /* ---- TRACED code (a program compiled in only, prog->traced = 1): the op calls a device function that the caller appended
    * to the generated header of mpe_rows_static_source -- `mpe::traced_obs(i, row, P, V, W, K)` writes the w1 columns of agent i's
-   * row, `mpe::traced_rew(i, P, V, W, K)` / `traced_done` return its reward / done -- where P(e, c) / V(e, c) read the staged
-   * post-step position / velocity of entity e, W(j, c) agent j's utterance, K(k) the per-world pick k.  This is how an unmodified
+   * row, `mpe::traced_rew(i, P, V, W, K, S)` / `traced_done(i, P, V, W, K)` return its reward / done -- where P(e, c) / V(e, c) read the staged
+   * post-step position / velocity of entity e, W(j, c) agent j's utterance, K(k) the per-world pick k, S(k) shared value k (n_shared).  This is how an unmodified
    * reference-style Scenario file (multiagent/scenario.py:4-10: NumPy callbacks) runs in the step launch: its callbacks traced
    * into expression graphs (multiagent_particle_envs_amd/symtrace.py), one statement per arithmetic step.  w2 / w3 carry a hash
    * of the appended source (it is part of the program's identity: image name, cache key).                                   */
@@ -322,9 +322,12 @@ typedef struct MpeRowProgram {
                                  episode ends, rollouts, mpe_episode_finish, mpe_reset_rows); 0: agents on [-1,1)^2, landmarks on
                                  [-landmark_range, landmark_range)^2 (the reference's nine scenarios)                               */
   float reset_box[MPE_ROWS_MAX_ENTITIES][4];   /* lo_x, span_x, lo_y, span_y per entity                                            */
+  int32_t n_shared;           /* traced programs: how many values the appended `mpe::traced_shared(k, out, P, V, W, K)` computes -- parts of
+                                 the agents' reward graphs that several agents share (the distance of the nearest agent to every
+                                 landmark in a cooperative reward): evaluated ONCE per world, the tasks dealt to the workgroup's waves,
+                                 parked in LDS, read by traced_rew through its accessor S(k).  0: none (<= 64)                      */
   int32_t traced;             /* 1: the program contains *_CODE ops -- it runs compiled in ONLY (an entry point called without a
                                  matching image returns MPE_EUNSUPPORTED instead of interpreting); 0 otherwise                  */
-  int32_t pad_;
 } MpeRowProgram;
 /* Checks a program against the descriptor (entity / pick / slot indices, row widths == obs_off): ops_host are the same
  * n_ops x 4 words in HOST memory.  0 or MPE_EINVAL with mpe_last_error() naming the op.                               */

@@ -61,7 +61,7 @@ class MpeRowProgram(C.Structure):
         ("rew_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)), ("n_vel", C.c_int32), ("n_regions", C.c_int32),
         ("region_entity", C.c_int32 * 2), ("all_seeing", C.c_uint32), ("image", C.c_void_p),
         ("done_begin", C.c_int32 * (MPE_ROWS_MAX_ENTITIES + 1)), ("reset_boxes", C.c_int32),
-        ("reset_box", (C.c_float * 4) * MPE_ROWS_MAX_ENTITIES), ("traced", C.c_int32), ("pad_", C.c_int32),
+        ("reset_box", (C.c_float * 4) * MPE_ROWS_MAX_ENTITIES), ("n_shared", C.c_int32), ("traced", C.c_int32),
     ]
 
 

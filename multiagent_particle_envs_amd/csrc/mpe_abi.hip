@@ -517,6 +517,9 @@ static int rows_header(const char *what, const MpeScenarioDesc *d, const MpeRowP
     t->rew_begin[i] = i <= A ? p->rew_begin[i] : p->rew_begin[A];
     t->done_begin[i] = i <= A ? p->done_begin[i] : p->done_begin[A];
   }
+  if (p->n_shared < 0 || p->n_shared > 64 || (p->n_shared > 0 && !p->traced))
+    return fail(MPE_EINVAL, "%s: prog->n_shared = %d (0..64, traced programs only)", what, p->n_shared);
+  h->n_shared = p->n_shared;
   h->reset_boxes = p->reset_boxes ? 1 : 0;
   if (p->reset_boxes)
     for (int e = 0; e < E; ++e)
@@ -882,8 +885,8 @@ int mpe_rows_static_source(const MpeScenarioDesc *d, const MpeRowProgram *p, con
       h.n_vel, h.dim_c, h.collaborative, h.d_max, h.n_picks, h.n_ops, h.n_regions, h.region_entity[0], h.region_entity[1], h.all_seeing,
       (unsigned long long)h.movable, (unsigned long long)h.collide);
   put("__builtin_bit_cast(float, 0x%08xu), __builtin_bit_cast(float, 0x%08xu), __builtin_bit_cast(float, 0x%08xu), "
-      "__builtin_bit_cast(float, 0x%08xu), __builtin_bit_cast(float, 0x%08xu), %d }\n", fbits(h.dt), fbits(h.damp), fbits(h.cforce),
-      fbits(h.cmargin), fbits(h.cmargin_inv), h.reset_boxes);
+      "__builtin_bit_cast(float, 0x%08xu), __builtin_bit_cast(float, 0x%08xu), %d, %d }\n", fbits(h.dt), fbits(h.damp), fbits(h.cforce),
+      fbits(h.cmargin), fbits(h.cmargin_inv), h.reset_boxes, h.n_shared);
   out += "#define MPE_ROWS_STATIC_TABLES { ";
   const uint32_t *tw = reinterpret_cast<const uint32_t *>(&tabs);
   for (size_t k = 0; k < sizeof(tabs) / 4; ++k) put("0x%xu,%s", tw[k], k % 16 == 15 ? " \\\n  " : " ");

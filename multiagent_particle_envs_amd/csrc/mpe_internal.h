@@ -90,6 +90,7 @@ struct RowDims {
   uint64_t movable, collide;     // bit e
   float dt, damp, cforce, cmargin, cmargin_inv;
   int32_t reset_boxes;           // 1: restarts place entity e in RowTables.reset_box[e] (else: agents [-1,1)^2, landmarks [-r,r)^2)
+  int32_t n_shared;              // traced programs: values several agents' rewards share, computed once per world (traced_shared)
 };
 // Tables of a program: DEVICE memory (uploaded by launch_rows_header whenever their content changes), read by scalar loads;
 // a compiled program (MPE_ROWS_STATIC) carries them as constants.

@@ -199,7 +199,9 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   // the post-step state of World.step ([A][4][64], PHYS only) and the waves' row tiles ([W][64 * Dmax]) share one region: the
   // new state has moved into S_pos / S_vel (behind a barrier) before the first tile column is written
   int *const S_word = S_pick + kRowPicks * kWave;      // [A][64] (step layouts) the word each speaking agent says this step (ROLL)
-  float *const S_new = reinterpret_cast<float *>(S_word + (PHYS ? A * kWave : 0));
+  // (traced programs) values several agents' rewards share: [n_shared][64], computed once per world ahead of the observation programs
+  float *const S_shared = reinterpret_cast<float *>(S_word + (PHYS ? A * kWave : 0));
+  float *const S_new = S_shared + (size_t)h.n_shared * kWave;
   float *const tiles = S_new;
 
   // ---- episode bookkeeping (mpe_episode_finish): count the step, find the worlds that finished, leave if none did ----------
@@ -298,6 +300,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   auto P = [&](int e, int c) { return S_pos[(2 * e + c) * kWave + lane]; };
   auto V = [&](int e, int c) { return e < NV ? S_vel[(2 * e + c) * kWave + lane] : 0.f; };
   auto pick = [&](int k) { return S_pick[k * kWave + lane]; };
+  auto shared = [&](int k) { return S_shared[k * kWave + lane]; };
   auto word = [&](int j, int c) {
     if constexpr (ROLL) return (!fin && ((ep.speakers >> j) & 1u)) ? (S_word[j * kWave + lane] == c ? 1.f : 0.f) : 0.f;   // drawn this step / silent / restarted
     else return (fin || !b.comm) ? 0.f : (b.comm + wave_off(((size_t)j * B + w0) * DC))[ln * DC + c];
@@ -428,6 +431,15 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
     // computes and stores them (the state moves on either way; with EP2 the done programs decide the restarts: every step runs)
     if (!ra.trajectory && t != T_ - 1) return;
   }
+#ifdef MPE_ROWS_TRACED
+  // ---- (traced programs) what several agents' rewards share, once per world: the tasks dealt to the waves, parked in LDS; the
+  // observation programs run before anybody reads them (a barrier in front of the reward programs)
+  if (h.n_shared > 0 && ep.enabled != 1 && bo.rew) {
+    auto shared_task = [&](const int k) __attribute__((always_inline)) { traced_shared(k, S_shared + k * kWave + lane, P, V, word, pick); };
+    if constexpr (STATIC) static_agents_of_wave<0, static_waves<PHYS>(), static_dims().n_shared>(wave, shared_task);
+    else for (int k = wave; k < h.n_shared; k += NW) shared_task(k);
+  }
+#endif
 #pragma nounroll
   for (int pass = 0; pass < kPasses; ++pass) {
   // ---- observation programs of this wave's agents ------------------------------------------------------------------------
@@ -549,6 +561,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   }
   MPE_RSTAMP(5);      // observation rows stored
   if (ep.enabled == 1 || pass == 1) return;      // (mpe_episode_finish, or the restarted worlds' rows: rewards and dones are the step's)
+  if (h.n_shared > 0 && bo.rew) __syncthreads();      // (launch-uniform) the shared values are complete
 
   // ---- reward and done programs of this wave's agents ----------------------------------------------------------------------
   const bool has_done = TI(MPE_TAB(done_begin), A) != TI(MPE_TAB(done_begin), 0);
@@ -636,7 +649,7 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
             dn = dn || sqrt_lt(sq2d(P(a0, 0) - P(a1, 0), P(a0, 1) - P(a1, 1)), TF(MPE_TAB(size), a0) + TF(MPE_TAB(size), a1));
             break;
 #ifdef MPE_ROWS_TRACED
-          case ROW_R_CODE: acc[0] = traced_rew(i, P, V, word, pick); break;
+          case ROW_R_CODE: acc[0] = traced_rew(i, P, V, word, pick, shared); break;
           case ROW_R_DONE_CODE: dn = dn || traced_done(i, P, V, word, pick); break;
 #endif
           // ---- range forms ---------------------------------------------------------------------------------------------------
@@ -840,7 +853,7 @@ int launch_rows_header(const RowTables &t, void *dst, hipStream_t stream) {
 // per CU).  One function for the launch and for the generator of compiled programs (the wave count is a constant there).
 int rows_geometry(const RowDims &h, bool phys, int *waves, size_t *lds_bytes, int max_waves) {
   constexpr size_t kLdsCap = 160 * 1024;
-  const size_t fixed = sizeof(float) * (size_t)(2 * h.n_entities + 2 * h.n_vel + h.n_agents + kRowPicks + (phys ? h.n_agents : 0)) * kWave;
+  const size_t fixed = sizeof(float) * (size_t)(2 * h.n_entities + 2 * h.n_vel + h.n_agents + kRowPicks + (phys ? h.n_agents : 0) + h.n_shared) * kWave;
   const size_t new_state = phys ? sizeof(float) * (size_t)(4 * h.n_agents) * kWave : 0;      // shares the tiles' region
   const size_t tile = sizeof(float) * (size_t)kWave * (size_t)h.d_max, slots = sizeof(float) * (size_t)kWave * kRowSlots;
   auto need = [&](int w) { return fixed + (size_t)w * slots + ((size_t)w * tile > new_state ? (size_t)w * tile : new_state); };

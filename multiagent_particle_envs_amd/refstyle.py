@@ -485,6 +485,11 @@ class TracedRefScenario(object):
             self._source = symtrace.hip_source(self.t)
         return self._source
 
+    def row_shared(self, world):
+        """how many values the source's traced_shared computes once per world (symtrace.shared_tasks)"""
+        self.row_source(world)
+        return int(getattr(self.t, "n_shared", 0))
+
     def _hash(self, world):
         import hashlib
         return int.from_bytes(hashlib.sha256(self.row_source(world).encode()).digest()[:8], "little")

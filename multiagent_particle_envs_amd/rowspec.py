@@ -426,7 +426,8 @@ def fuse_reward(ops):
 class RowProgram(object):
     """The compiled programs of one env: ops on the device + the MpeRowProgram header the C ABI takes."""
 
-    def __init__(self, world, obs_specs, reward_specs, regions=None, fuse=None, done_specs=None, source=None, reset_boxes=None):
+    def __init__(self, world, obs_specs, reward_specs, regions=None, fuse=None, done_specs=None, source=None, reset_boxes=None,
+                 n_shared=0):
         """fuse: run the peephole pass (runs of per-entity ops -> range forms); False keeps one op per spec call (the A/B);
         None: the module's FUSE switch.  done_specs: one DoneSpec (or None: never done) per agent.  source: the device
         functions the program's code ops call (symtrace.hip_source), appended to the generated header of the compiled form.
@@ -503,6 +504,7 @@ class RowProgram(object):
         if p.traced and not source:
             raise _abi.MpeError("a program with code ops needs the source of the functions they call")
         self.traced = bool(p.traced)
+        p.n_shared = int(n_shared) if p.traced else 0      # (values the traced source's traced_shared computes once per world)
         self.struct = p
         self.ref = C.byref(p)
 
@@ -562,7 +564,8 @@ def compile_scenario(scenario, world):
     done = [dsf(a, world) for a in world.agents] if dsf is not None else None
     src = scenario.row_source(world) if hasattr(scenario, "row_source") else None
     boxes = scenario.reset_boxes(world) if callable(getattr(scenario, "reset_boxes", None)) else None
-    return RowProgram(world, obs, rew, rg, done_specs=done, source=src, reset_boxes=boxes)
+    n_shared = scenario.row_shared(world) if callable(getattr(scenario, "row_shared", None)) else 0
+    return RowProgram(world, obs, rew, rg, done_specs=done, source=src, reset_boxes=boxes, n_shared=n_shared)
 
 
 # built-in scenarios whose callbacks are written for any team size: where no fused kernel exists for a shape, the env runs

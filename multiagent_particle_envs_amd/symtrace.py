@@ -1459,6 +1459,26 @@ def topo(roots):
     return order
 
 
+def _topo_stop(roots, stop):
+    """topo(roots) that does not descend below the nodes in `stop` (they are inputs there)"""
+    seen, order, stack = set(), [], [(r, False) for r in reversed(list(roots))]
+    while stack:
+        n, done = stack.pop()
+        if done:
+            order.append(n)
+            continue
+        if n.uid in seen:
+            continue
+        seen.add(n.uid)
+        stack.append((n, True))
+        if n.uid in stop:
+            continue
+        for a in reversed(n.args):
+            if a.uid not in seen:
+                stack.append((a, False))
+    return order
+
+
 def inputs_of(roots):
     return set(n.op for n in topo(roots) if n.op in ("P", "V", "C", "K", "U"))
 
@@ -1722,14 +1742,20 @@ def _f32_literal(v):
     return "%sf" % float(v).hex()          # C++17 hexadecimal floating literal: the fp32 value, exactly
 
 
-def _emit(roots, lines, names):
-    """Append statements computing `roots` to `lines`; `names`: uid -> expression (variable name or literal) so far."""
+def _emit(roots, lines, names, shared=None):
+    """Append statements computing `roots` to `lines`; `names`: uid -> expression (variable name or literal) so far; `shared`:
+    uid -> slot of the values traced_shared has computed (read through S instead of being recomputed)."""
     def ref(n):
         return names[n.uid]
-    for n in topo(roots):
+    stop = set(shared or ())
+    for n in _topo_stop(roots, stop):
         if n.uid in names:
             continue
         op, a = n.op, n.args
+        if n.uid in stop:
+            lines.append("      const float t%d = S(%d);" % (n.uid, shared[n.uid]))
+            names[n.uid] = "t%d" % n.uid
+            continue
         var = ("b%d" if n.is_bool else "t%d") % n.uid
         if op == "const":
             names[n.uid] = _f32_literal(n.value)
@@ -1827,7 +1853,68 @@ def _device_form(g, roots):
     return [memo[r.uid] for r in roots]
 
 
-def hip_source(t):
+_SHARE_MIN_COST = 8          # a value worth a trip through LDS
+_SHARE_MIN_SAVING = 300      # statements per world saved, below which the extra phase (tasks, a barrier) is not worth having
+_SHARE_MAX = 64
+
+
+def shared_tasks(rew_roots, n_waves):
+    """Which parts of the agents' reward graphs to compute ONCE per world (traced_shared) instead of once per agent: the reference's
+    cooperative rewards are the same expression for every agent up to a few agent-specific terms (simple_spread.py:72-82: the
+    distance of the nearest agent to every landmark, then the agent's own collisions), and each agent's wave would evaluate all of
+    it.  Top-down from every reward root: a node used by two agents or more whose cone is not trivial becomes a task if it is
+    small enough to leave work for every wave (else its arguments are looked at, and the node itself is recomputed by each agent
+    from their values); nothing is shared unless it saves a few hundred statements per world.  -> list of task nodes."""
+    roots = list(rew_roots)
+    if len(roots) < 2:
+        return []
+    users = {}
+    for i, r in enumerate(roots):
+        for n in topo([r]):
+            users.setdefault(n.uid, set()).add(i)
+    leaves = ("const", "bconst", "P", "V", "C", "K", "U")
+    memo = {}
+
+    class _Cost(object):          # statements a node stands for: the operations in its cone, each counted once
+        def __getitem__(self, uid):
+            return memo[uid]
+
+    def cone(n):
+        c = memo.get(n.uid)
+        if c is None:
+            c = memo[n.uid] = sum(1 for x in topo([n]) if x.op not in leaves)
+        return c
+    cost = _Cost()
+    per_agent = max(cone(r) for r in roots)
+    c_max = max(32, per_agent // max(1, n_waves))
+    while True:
+        tasks, seen = [], set()
+
+        def descend(n):
+            if n.uid in seen:
+                return
+            seen.add(n.uid)
+            if len(users[n.uid]) >= 2 and not n.is_bool and n.op not in leaves and _SHARE_MIN_COST <= cone(n) <= c_max:
+                tasks.append(n)
+                return
+            for a in n.args:
+                descend(a)
+        import sys
+        limit = sys.getrecursionlimit()
+        sys.setrecursionlimit(max(limit, 20000))
+        try:
+            for r in roots:
+                descend(r)
+        finally:
+            sys.setrecursionlimit(limit)
+        if len(tasks) <= _SHARE_MAX:
+            break
+        c_max *= 2
+    saving = sum(cost[n.uid] * (len(users[n.uid]) - 1) for n in tasks)
+    return tasks if saving >= _SHARE_MIN_SAVING else []
+
+
+def hip_source(t, n_waves=None):
     """The device functions of a trace: what is appended to the generated header of the compiled row program (the kernel calls
     them through the ops MPE_ROW_OBS_CODE / R_CODE / R_DONE_CODE).  P, V, W, K are the kernel's accessors of the staged state."""
     out = ["", "// ---- traced callbacks (symtrace.py): one statement per arithmetic step of the file's NumPy code, in its order ----",
@@ -1837,6 +1924,10 @@ def hip_source(t):
            "  switch (i) {"]
     g = getattr(t, "graph", None)
     form = (lambda roots: _device_form(g, roots)) if g is not None else (lambda roots: list(roots))
+    rew_roots = form(list(t.rew))
+    tasks = shared_tasks(rew_roots, n_waves if n_waves else min(len(t.rew), 16)) if getattr(t, "share", True) else []
+    shared = {n.uid: k for k, n in enumerate(tasks)}
+    t.n_shared = len(tasks)
     for i, row in enumerate(t.obs):
         lines, names = [], {}
         vals = _emit(form(row), lines, names)
@@ -1845,12 +1936,24 @@ def hip_source(t):
         out += ["      row[%d] = %s;" % (j, v) for j, v in enumerate(vals)]
         out.append("    } break;")
     out += ["    default: break;", "  }", "}",
+            "// what several agents' rewards share, once per world: task k's value into its LDS slot (read back through S(k))",
             "template <class FP, class FV, class FW, class FK>",
-            "__device__ __forceinline__ float traced_rew(const int i, const FP &P, const FV &V, const FW &W, const FK &K) {",
-            "  switch (i) {"]
-    for i, r in enumerate(t.rew):
+            "__device__ __forceinline__ void traced_shared(const int k, float *const out, const FP &P, const FV &V, const FW &W, const FK &K) {",
+            "  switch (k) {"]
+    for k, n in enumerate(tasks):
         lines, names = [], {}
-        v = _emit(form([r]), lines, names)[0]
+        v = _emit([n], lines, names)[0]
+        out.append("    case %d: {" % k)
+        out += lines
+        out.append("      out[0] = %s;" % v)
+        out.append("    } break;")
+    out += ["    default: break;", "  }", "}",
+            "template <class FP, class FV, class FW, class FK, class FS>",
+            "__device__ __forceinline__ float traced_rew(const int i, const FP &P, const FV &V, const FW &W, const FK &K, const FS &S) {",
+            "  switch (i) {"]
+    for i, r in enumerate(rew_roots):
+        lines, names = [], {}
+        v = _emit([r], lines, names, shared)[0]
         out.append("    case %d: {" % i)
         out += lines
         out.append("      return %s;" % v)
