@@ -561,7 +561,9 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
   }
   MPE_RSTAMP(5);      // observation rows stored
   if (ep.enabled == 1 || pass == 1) return;      // (mpe_episode_finish, or the restarted worlds' rows: rewards and dones are the step's)
+#ifndef MPE_STRESS_NO_SHARED_BARRIER      // (the negative control of tests/test_gpu_race.py: without it a late wave's shared values are read before they exist)
   if (h.n_shared > 0 && bo.rew) __syncthreads();      // (launch-uniform) the shared values are complete
+#endif
 
   // ---- reward and done programs of this wave's agents ----------------------------------------------------------------------
   const bool has_done = TI(MPE_TAB(done_begin), A) != TI(MPE_TAB(done_begin), 0);

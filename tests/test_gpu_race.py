@@ -94,3 +94,67 @@ def test_rollout_and_scenario_suites_pass_under_the_delayed_wave_build():
                        capture_output=True, text=True, env=env, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+_NAV6 = '''
+import numpy as np
+from multiagent.core import World, Agent, Landmark
+from multiagent.scenario import BaseScenario
+
+
+class Scenario(BaseScenario):
+    def make_world(self):
+        world = World()
+        world.collaborative = True
+        world.agents = [Agent() for _ in range(6)]
+        for i, agent in enumerate(world.agents):
+            agent.name, agent.collide, agent.silent, agent.size = "agent %d" % i, True, True, 0.15
+        world.landmarks = [Landmark() for _ in range(6)]
+        for i, lm in enumerate(world.landmarks):
+            lm.name, lm.collide, lm.movable = "landmark %d" % i, False, False
+        self.reset_world(world)
+        return world
+
+    def reset_world(self, world):
+        for e in world.agents + world.landmarks:
+            e.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            e.state.p_vel = np.zeros(world.dim_p)
+        for a in world.agents:
+            a.state.c = np.zeros(world.dim_c)
+
+    def reward(self, agent, world):
+        rew = 0
+        for lm in world.landmarks:
+            rew -= min(np.linalg.norm(a.state.p_pos - lm.state.p_pos) for a in world.agents)
+        for a in world.agents:
+            if a is not agent and np.linalg.norm(a.state.p_pos - agent.state.p_pos) < a.size + agent.size:
+                rew -= 1
+        return rew
+
+    def observation(self, agent, world):
+        return np.concatenate([agent.state.p_vel, agent.state.p_pos] + [lm.state.p_pos - agent.state.p_pos for lm in world.landmarks])
+'''
+
+
+def test_shared_reward_values_wait_for_a_late_wave(tmp_path):
+    """A traced program computes what its agents' rewards share once per world: the tasks are dealt to the workgroup's waves, the
+    values cross through LDS, ONE barrier stands between the writers and the readers.  The program's image compiled with one wave
+    of every workgroup held back ~30 us at the phase boundary in front of the shared tasks (MPE_STRESS_DELAY_WAVE) gives the same
+    bits; the same build without that barrier does not."""
+    path = tmp_path / "nav6.py"
+    path.write_text(_NAV6)
+
+    def run(flags):
+        env = dict(os.environ)
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        env.pop("MPE_ROWS_IMAGE_FLAGS", None)
+        if flags:
+            env["MPE_ROWS_IMAGE_FLAGS"] = flags
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_race_probe_traced.py"), str(path), "4096", "4"],
+                           capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("RACE_PROBE ")][-1][len("RACE_PROBE "):])
+    normal = run(None)
+    assert normal["n_shared"] == 6
+    assert run("-DMPE_STRESS_DELAY_WAVE=1") == normal, "a late wave changed the results: shared values were read before they were written"
+    assert run("-DMPE_STRESS_DELAY_WAVE=1 -DMPE_STRESS_NO_SHARED_BARRIER")["sha"] != normal["sha"], "negative control failed: the probe cannot see the race"

@@ -58,9 +58,33 @@ def test_programs():
 
 from concurrent.futures import ThreadPoolExecutor  # noqa: E402
 
+if "--race-variant" in sys.argv:
+    # (internal) the traced 6-agent navigation program of tests/test_gpu_race.py compiled with the flags in MPE_ROWS_IMAGE_FLAGS
+    import tempfile
+    import test_gpu_race as tg
+    from multiagent_particle_envs_amd import refstyle, scenarios
+    import multiagent_particle_envs_amd as mpe
+    path = os.path.join(tempfile.mkdtemp(), "nav6.py")
+    with open(path, "w") as fh:
+        fh.write(tg._NAV6)
+    ts = refstyle.trace_ref_scenario(scenarios.load(path).Scenario())
+    env = mpe.MultiAgentEnv(ts.make_world(4, "cpu"), ts.reset_world, None, None, compile_program=False)
+    t0 = time.time()
+    img = _build.compile_rows_image(env._prog.static_source(env._desc))
+    print("race variant %-60r %8d bytes %6.1f s" % (os.environ.get("MPE_ROWS_IMAGE_FLAGS", ""), len(img), time.time() - t0))
+    sys.exit(0)
+
 jobs = []      # (label, n_ops, header text)
 if "--tests" in sys.argv:
     jobs += [(label, env._prog.n_ops, env._prog.static_source(env._desc)) for label, env in test_programs()]
+if "--tests" in sys.argv:      # the three builds of the race test's traced program (flags are part of the cache key: one process each)
+    import subprocess
+    for flags in ("", "-DMPE_STRESS_DELAY_WAVE=1", "-DMPE_STRESS_DELAY_WAVE=1 -DMPE_STRESS_NO_SHARED_BARRIER"):
+        e = dict(os.environ)
+        e.pop("MPE_ROWS_IMAGE_FLAGS", None)
+        if flags:
+            e["MPE_ROWS_IMAGE_FLAGS"] = flags
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--race-variant"], env=e, check=True)
 specs = [a for a in sys.argv[1:] if a != "--tests"]
 for spec in (specs or ([] if "--tests" in sys.argv else DEFAULT)):
     parts = spec.split(":")
