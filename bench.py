@@ -1019,8 +1019,14 @@ def main():
 
     default_line = solo and args.scenario == "simple_spread" and args.agents == 3 and B == 65536
     if default_line:
-        extra["user_scenario"] = user_scenario_leg(torch, mpe, B, EP, rv, dev)
-        extra["reference_style_file"] = reference_style_leg(torch, mpe, B, EP, rv, dev)
+        # (secondary legs: a failure there -- no hipcc on the box for the compiled programs, say -- is reported in the entry and
+        #  never costs the run its headline line)
+        for key, leg_fn in (("user_scenario", user_scenario_leg), ("reference_style_file", reference_style_leg)):
+            try:
+                extra[key] = leg_fn(torch, mpe, B, EP, rv, dev)
+            except Exception as e:
+                extra[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+                torch.cuda.synchronize()
     headline_roof = roofline_entry(leg, k_us, B, args.mode, floor_us, head_timing)
     if default_line:
         leg.release()

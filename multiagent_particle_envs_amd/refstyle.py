@@ -718,7 +718,7 @@ def make_ref_env(scenario, benchmark=False, batch_size=None, device=None, seed=0
             ts = trace_ref_scenario(scenario, want_done=want_done, want_info=want_info)
             return make_traced_env(ts, batch_size, device=device, seed=seed, max_episode_steps=max_episode_steps,
                                    auto_reset=auto_reset, fresh_outputs=fresh_outputs, benchmark=want_info)
-        except (symtrace.TraceUnsupported, _abi.MpeError, RuntimeError) as e:
+        except (symtrace.TraceUnsupported, _abi.MpeError, RuntimeError, OSError) as e:      # (OSError: no hipcc on this machine)
             if traced:
                 raise
             why = "%s: %s" % (type(e).__name__, e)
