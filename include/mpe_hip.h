@@ -336,7 +336,9 @@ int mpe_rows_validate(const MpeScenarioDesc *desc, const MpeRowProgram *prog, co
  * :113-115 after a reset): obs rows, rew (shared sum when desc->collaborative), done = 0.  desc->kind is ignored (GENERIC
  * is what a user scenario has); reads pos, vel, comm, choice; bufs->rew / done may be NULL.                            */
 int mpe_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowProgram *prog, int64_t B, void *stream);
-/* mpe_reset_rows: mpe_reset with the PROGRAM's placement -- prog->reset_boxes ? its per-entity boxes : (agents [-1,1)^2, landmarks
+/* mpe_reset_rows: Scenario.reset_world of a USER scenario (README "Creating new environments"; the shape of simple_tag.py:39-54:
+ * `entity.state.p_pos = np.random.uniform(lo, hi, world.dim_p)` per entity, zero velocities and utterances, np.random.choice picks)
+ * -- mpe_reset with the PROGRAM's placement -- prog->reset_boxes ? its per-entity boxes : (agents [-1,1)^2, landmarks
  * [-landmark_range, landmark_range)^2) -- the same draws, keyed by (seed, world_offset + b, episode, entity), that the in-kernel
  * restarts of this program make: a rollout's per-step form {mpe_reset_rows at the boundaries; moves; mpe_step_rows} stays
  * bit-identical to mpe_rollout_rows whatever the placement.                                                              */
