@@ -505,3 +505,70 @@ def test_numpy_idioms_of_user_scenarios_trace_without_forks():
     src = symtrace.hip_source(t)
     assert "atan2f(" in src and "cosf(" in src and "tanhf(" in src
     assert np.maximum is not None and np.maximum(1, 2) == 2 and np.clip(5, 0, 1) == 1          # NumPy is itself again
+
+
+def _host_run_generated(tr, P, V, Cw, K, tmp_path, tag):
+    """The generated device functions compiled for the host (tests/c/traced_host.cpp) and run on the given states -> (rows per agent,
+    rewards [B, A], dones [B, A])."""
+    import subprocess
+    src = symtrace.hip_source(tr)
+    body = src.split('#include "mpe_internal.h"', 1)[1]                # (the device headers stay out: plain C++ stand-ins in the harness)
+    gen = tmp_path / ("gen_%s.h" % tag)
+    gen.write_text(body)
+    exe = tmp_path / ("traced_host_%s" % tag)
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-DMPE_HOST_TRACED_SOURCE=\"%s\"" % gen,
+                        os.path.join(HERE, "c", "traced_host.cpp"), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    B = P.shape[0]
+    widths = [len(row) for row in tr.obs]
+    with open(tmp_path / ("in_%s.bin" % tag), "wb") as fh:
+        fh.write(np.array([B, tr.E, tr.A, tr.dim_c, len(tr.pops), int(getattr(tr, "n_shared", 0))] + widths, np.int32).tobytes())
+        fh.write(P.astype(np.float32).tobytes())
+        fh.write(V.astype(np.float32).tobytes())
+        if tr.dim_c:
+            fh.write(Cw.astype(np.float32).tobytes())
+        if tr.pops:
+            fh.write(K.astype(np.int32).tobytes())
+    r = subprocess.run([str(exe), str(tmp_path / ("in_%s.bin" % tag)), str(tmp_path / ("out_%s.bin" % tag))], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    out = np.fromfile(tmp_path / ("out_%s.bin" % tag), np.float32).reshape(B, sum(widths) + 2 * tr.A)
+    off = np.cumsum([0] + widths)
+    return [out[:, off[i]:off[i + 1]] for i in range(tr.A)], out[:, off[-1]:off[-1] + tr.A], out[:, off[-1] + tr.A:]
+
+
+@pytest.mark.parametrize("name", ["convoy", "relay", "simple_tag", "simple_world_comm", "simple_crypto", "nav8"])
+def test_generated_code_on_the_host_against_the_numpy_evaluation(name, tmp_path):
+    """The code GENERATOR without a GPU: traced_obs / traced_shared / traced_rew as symtrace.hip_source writes them, compiled with
+    g++ (plain-C++ stand-ins for the device intrinsics) and run on random worlds, against the fp64 NumPy evaluation of the same
+    graphs -- fixtures, committed traces of the reference's files, and an 8-agent cooperative-navigation file whose shared reward
+    terms go through traced_shared."""
+    if name in ("convoy", "relay"):
+        tr = symtrace.trace(mpe.scenarios.load(os.path.join(FIXTURES, name + ".py")).Scenario())
+    elif name == "nav8":
+        path = tmp_path / "nav8.py"
+        path.write_text(_PREDICATION_FILE.replace("N_AGENTS", "8").replace(
+            "        rew = 0\n        for other in world.agents:",
+            "        rew = 0\n        for l in world.landmarks:\n            rew -= min(np.linalg.norm(a.state.p_pos - l.state.p_pos) for a in world.agents)\n"
+            "        for other in world.agents:"))
+        tr = symtrace.trace(mpe.scenarios.load(str(path)).Scenario())
+    else:
+        with open(os.path.join(GOLDEN, "traced_%s.json" % name)) as fh:
+            tr = symtrace.from_dict(json.load(fh))
+    B = 3000
+    rs = np.random.RandomState(8)
+    P, V, Cw = symtrace.random_states(tr, B, rs)
+    P, V, Cw = P.astype(np.float32).astype(np.float64), V.astype(np.float32).astype(np.float64), Cw.astype(np.float32).astype(np.float64)
+    K = np.stack([rs.randint(0, n, B) for n in tr.pops], axis=1) if tr.pops else np.zeros((B, 0), np.int64)
+    rows, rew, _ = _host_run_generated(tr, P, V, Cw, K, tmp_path, name)
+    if name == "nav8":
+        assert tr.n_shared >= 2                                          # the shared phase is part of what ran
+    roots = [n for row in tr.obs for n in row] + list(tr.rew)
+    vals = symtrace.evaluate(roots, B, P=P, V=V, Cw=Cw, K=K)
+    ok = symtrace.decision_margin(roots, B, P=P, V=V, Cw=Cw, K=K) > 2e-6
+    assert ok.mean() > 0.85
+    off = np.cumsum([0] + [len(r) for r in tr.obs])
+    for i in range(tr.A):
+        want = np.stack(vals[off[i]:off[i + 1]], axis=1) if off[i + 1] > off[i] else np.zeros((B, 0))
+        assert (np.abs(rows[i][ok] - want[ok]) / np.maximum(1.0, np.abs(want[ok]))).max(initial=0.0) <= 1e-5, (name, "obs", i)
+        w = vals[off[-1] + i]
+        assert (np.abs(rew[ok, i] - w[ok]) / np.maximum(1.0, np.abs(w[ok]))).max() <= 1e-5, (name, "rew", i)
