@@ -876,6 +876,10 @@ def main():
         sys.exit(launch_ranks(args))
 
     t_start = time.time()
+    timeline = {}          # seconds since the start at which each part of the run was done (config.timeline_s): where a slow run lost its time
+
+    def done_at(name):
+        timeline[name] = round(time.time() - t_start, 1)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = env_world
@@ -954,6 +958,7 @@ def main():
             solo_rate = B * K * R1 / d1
         rv.barrier()
     dt, R, ev_ms, rate = leg.timed(torch, rv, dev, args.mode, args.protocol, K, W, args.repeats, args.region_ms)
+    done_at("headline_timed_region")
     k_us = leg.kernel_time_us(torch, args.mode)
     head_timing = leg.last_kernel_timing
     head_probe = leg.env.placement_probe
@@ -1017,6 +1022,7 @@ def main():
             "value": B * nh / dth, "unit": "env-steps/s", "ms_per_step": dth * 1e3 / nh,
             "pcie_bytes_per_env_step": io_bytes, "pcie_GBps": B * nh * io_bytes / dth / 1e9}
 
+    done_at("headline_side_legs")
     default_line = solo and args.scenario == "simple_spread" and args.agents == 3 and B == 65536
     if default_line:
         # (secondary legs: a failure there -- no hipcc on the box for the compiled programs, say -- is reported in the entry and
@@ -1027,6 +1033,7 @@ def main():
             except Exception as e:
                 extra[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
                 torch.cuda.synchronize()
+            done_at(key)
     headline_roof = roofline_entry(leg, k_us, B, args.mode, floor_us, head_timing)
     if default_line:
         leg.release()
@@ -1043,6 +1050,7 @@ def main():
         big.release()
         del big
         torch.cuda.empty_cache()
+        done_at("hbm_resident")
         # ---- BASELINE.json's other single-GPU configs, each in a process of its own ------------------------------------
         # (a leg measured after the 1M leg in THIS process reads 15-25 % slower on the launch-bound configs than the same
         #  leg in a fresh process -- 4.07-4.32 vs 3.45 us for C3, not thermal: a fresh process started right after this
@@ -1051,6 +1059,7 @@ def main():
         for key, scn, ag, bb, kk in CONFIG_LEGS:
             cfgs[key] = config_leg_subprocess(key, args, floor_us, local)
         extra["configs"] = cfgs
+        done_at("configs_in_their_own_processes")
 
     # ---- per-rank records: which GPU each rank drove, its own rate and kernel time (gathered over the bookkeeping group) ----
     box = box_fingerprint(torch, dev, smi=(rank == 0))
@@ -1109,7 +1118,7 @@ def main():
                                    "job; value_over_n_times_rank0_solo = value / (n_gpus x that rate)",
                            "rank0_solo_env_steps_per_s": solo_rate,
                            "value_over_n_times_rank0_solo": (B * K * R * world / dt) / (world * solo_rate)},
-                       "wall_s_since_start": time.time() - t_start,
+                       "wall_s_since_start": time.time() - t_start, "timeline_s": timeline,
                        "placement_probe": head_probe},
             "roofline": headline_roof,
             "repeats": stats(rate),
