@@ -1285,8 +1285,10 @@ def _trace_once(scenario, t, forced, want_done, max_paths, want_info=False):
     # ---- the callbacks, every path -------------------------------------------------------------------------------------------
     out["obs"], out["rew"], out["done"] = [], [], []
     paths = {"obs": [], "rew": [], "done": []}
+    if want_info:
+        out["info"] = []
     with patched_random(_NoDraws(g)), injected_builtins(scenario):
-        for a in agents:
+        for i, a in enumerate(agents):
             tr = Tracer(g, max_paths)
             out["obs"].append(tr.explore(lambda: scenario.observation(a, world), _flatten))
             paths["obs"].append(tr.paths)
@@ -1301,8 +1303,7 @@ def _trace_once(scenario, t, forced, want_done, max_paths, want_info=False):
                 out["done"].append([])
             if want_info:
                 tr = Tracer(g, max_paths)
-                d = info_desc[len(out["info"])] if "info" in out else info_desc[0]
-                out.setdefault("info", []).append(tr.explore(lambda: scenario.benchmark_data(a, world), lambda raw: _flatten_info(raw, d)))
+                out["info"].append(tr.explore(lambda: scenario.benchmark_data(a, world), lambda raw: _flatten_info(raw, info_desc[i])))
     out["info_desc"] = info_desc
     out["paths"] = paths
     out["collaborative"] = bool(getattr(world, "collaborative", False))
