@@ -176,6 +176,12 @@ int mpe_integrate_state(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int
  *   several GPUs (rank r owns worlds [r*B, (r+1)*B)) draws exactly what one big batch would.     */
 int mpe_reset(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, const uint8_t *mask,
               float landmark_range, uint64_t seed, uint64_t episode, int64_t world_offset, void *stream);
+/* mpe_reset_random_actions_block: mpe_reset(mask = NULL, ..., episode) AND mpe_random_actions_block(act, ids, ..., step0, T) in
+ * ONE launch -- the episode boundary of a synthetic-policy rollout (Scenario.reset_world, then the moves of the episode's T steps:
+ * what a caller of the reference does between `env.reset()` and the first `env.step()`); the same draws as the two calls.      */
+int mpe_reset_random_actions_block(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, float landmark_range,
+                                   uint64_t episode, float *act, int32_t *ids, uint64_t seed, uint64_t step0, int32_t T,
+                                   int64_t world_offset, void *stream);
 /* Uniform random moves: one-hot rows into act [A][B][5] and/or ids [A][B] (either may be NULL). */
 int mpe_random_actions(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed,
                        uint64_t step, int64_t world_offset, void *stream);

@@ -83,6 +83,8 @@ EXPORTS = {
     "mpe_integrate_state": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p]),
     "mpe_reset": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_void_p, C.c_float,
                             C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]),
+    "mpe_reset_random_actions_block": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_float, C.c_uint64,
+                                                 C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int64, C.c_void_p]),
     "mpe_reset_rows": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.POINTER(MpeRowProgram), C.c_int64, C.c_void_p,
                                  C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]),
     "mpe_random_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64,

@@ -378,6 +378,24 @@ int mpe_reset_rows(const MpeScenarioDesc *d, const MpeBuffers *b, const MpeRowPr
                                           (uint64_t)world_offset, d->n_choices, pop, static_cast<hipStream_t>(stream)), what);
 }
 
+int mpe_reset_random_actions_block(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, float landmark_range, uint64_t episode,
+                                   float *act, int32_t *ids, uint64_t seed, uint64_t step0, int32_t T, int64_t world_offset,
+                                   void *stream) {
+  const char *what = "mpe_reset_random_actions_block";
+  if (int rc = check_desc(d, what)) return rc;
+  if (int rc = check_state(b, B, what)) return rc;
+  if (d->n_choices > 0 && b->choice == nullptr)
+    return fail(MPE_EINVAL, "%s: desc->n_choices = %d but bufs->choice is NULL", what, d->n_choices);
+  if (!act && !ids) return fail(MPE_EINVAL, "%s: act and ids are both NULL", what);
+  if (T < 1 || T > 65535) return fail(MPE_EINVAL, "%s: T = %d (the reset rides on the block's first step: 1..65535)", what, T);
+  if (B == 0) return 0;
+  int32_t pop[MPE_MAX_CHOICES] = {1, 1, 1, 1};
+  for (int k = 0; k < d->n_choices; ++k) pop[k] = d->choice_pop[k];
+  return hip_result(mpe::launch_reset_random_actions(d->n_agents, d->n_landmarks, *b, (size_t)B, landmark_range, episode,
+                                                     d->n_choices, pop, act, ids, seed, step0, T, (uint64_t)world_offset,
+                                                     static_cast<hipStream_t>(stream)), what);
+}
+
 int mpe_random_actions_block(float *act, int32_t *ids, int32_t n_agents, int64_t B, uint64_t seed, uint64_t step0,
                              int32_t T, int64_t world_offset, void *stream) {
   const char *what = "mpe_random_actions_block";

@@ -40,6 +40,9 @@ int launch_reset_box(int A, int L, const MpeBuffers &b, size_t B, const uint8_t 
                      uint64_t episode, uint64_t world_offset, int n_choices, const int32_t *pop, hipStream_t stream);
 int launch_episode_tick(int32_t *episode_step, uint8_t *done, int A, size_t B, int max_steps, int clear_finished,
                         hipStream_t stream);
+int launch_reset_random_actions(int A, int L, const MpeBuffers &b, size_t B, float landmark_range, uint64_t episode, int n_choices,
+                                const int32_t *pop, float *act, int32_t *ids, uint64_t seed, uint64_t step0, int T,
+                                uint64_t world_offset, hipStream_t stream);
 int launch_random_actions(float *act, int32_t *ids, int A, size_t B, uint64_t seed, uint64_t step0, int T,
                           uint64_t world_offset, hipStream_t stream);
 

@@ -6,6 +6,7 @@
 // (seed, world, episode, entity) gives every world its own reproducible stream with no state in
 // HBM and no ordering between worlds (seed-exact parity resets are uploaded from the host instead).
 #include "mpe_internal.h"
+#include <cstring>
 
 namespace mpe {
 
@@ -42,9 +43,19 @@ k_reset(float *__restrict__ pos, float *__restrict__ vel, const uint8_t *__restr
 // arrives by a wave shuffle).  Step s writes the s-th consecutive [A][B][5] / [A][B] tensor.
 // (The same run as 80 16-byte pieces -- two store instructions per agent instead of five -- is SLOWER: 21.8 vs 20.4 us for the
 // 98 MB block of 25 steps at 65 536 worlds, round 4 session 33: five whole-line 256-byte wave stores beat 1024 + 256.)
+// (with `rs.enabled`: the launch ALSO is mpe_reset(mask = NULL) -- an episode boundary of a rollout that draws its next block of
+//  moves there: the waves of the block's first step and first agent quad place their 64 worlds' entities, the draws k_reset makes,
+//  one launch instead of two in front of the episode's first step)
+struct ResetWithDraw {
+  float *pos, *vel;
+  int32_t *choice;
+  int32_t enabled, E, n_choices, pop[MPE_MAX_CHOICES];
+  float landmark_range;
+  uint64_t episode;
+};
 __global__ void __launch_bounds__(kBlock)
 k_random_actions(float *__restrict__ act, int32_t *__restrict__ ids, size_t B, int A, uint64_t seed, uint64_t step0,
-                 uint64_t world_offset) {
+                 uint64_t world_offset, const ResetWithDraw rs) {
   const int lane = threadIdx.x & (kWave - 1);
   const size_t w0 = ((size_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * kWave;   // wave-uniform
   if (w0 >= B) return;
@@ -53,6 +64,20 @@ k_random_actions(float *__restrict__ act, int32_t *__restrict__ ids, size_t B, i
   const int nvalid = (B - w0) < (size_t)kWave ? (int)(B - w0) : kWave;
   const size_t w = w0 + (size_t)(lane < nvalid ? lane : nvalid - 1);
   const uint64_t gw = world_offset + w;
+  if (rs.enabled && blockIdx.z == 0 && q == 0 && lane < nvalid) {   // (launch-uniform flag; block-uniform position)
+    for (int e = 0; e < rs.E; ++e) {
+      float x, y;
+      reset_draw(seed, gw, rs.episode, e, e < A ? 1.0f : rs.landmark_range, x, y);
+      rs.pos[(size_t)(2 * e) * B + w] = x;
+      rs.pos[(size_t)(2 * e + 1) * B + w] = y;
+      if (e < A) {
+        rs.vel[(size_t)(2 * e) * B + w] = 0.f;
+        rs.vel[(size_t)(2 * e + 1) * B + w] = 0.f;
+      }
+    }
+    if (rs.choice)
+      for (int k = 0; k < rs.n_choices; ++k) rs.choice[(size_t)k * B + w] = choice_draw(seed, gw, rs.episode, k, rs.pop[k]);
+  }
   U4 c;
   c.x = (uint32_t)gw;
   c.y = (uint32_t)(gw >> 32) ^ (uint32_t)(step >> 32);
@@ -165,7 +190,29 @@ int launch_random_actions(float *act, int32_t *ids, int A, size_t B, uint64_t se
                           uint64_t world_offset, hipStream_t stream) {
   const size_t per_block = (size_t)(kBlock / kWave) * kWave;
   const dim3 grid((unsigned)((B + per_block - 1) / per_block), (unsigned)((A + 3) / 4), (unsigned)T);
-  hipLaunchKernelGGL(k_random_actions, grid, dim3(kBlock), 0, stream, act, ids, B, A, seed, step0, world_offset);
+  ResetWithDraw rs;
+  std::memset(&rs, 0, sizeof(rs));
+  hipLaunchKernelGGL(k_random_actions, grid, dim3(kBlock), 0, stream, act, ids, B, A, seed, step0, world_offset, rs);
+  return (int)hipGetLastError();
+}
+
+int launch_reset_random_actions(int A, int L, const MpeBuffers &b, size_t B, float landmark_range, uint64_t episode, int n_choices,
+                                const int32_t *pop, float *act, int32_t *ids, uint64_t seed, uint64_t step0, int T,
+                                uint64_t world_offset, hipStream_t stream) {
+  const size_t per_block = (size_t)(kBlock / kWave) * kWave;
+  const dim3 grid((unsigned)((B + per_block - 1) / per_block), (unsigned)((A + 3) / 4), (unsigned)T);
+  ResetWithDraw rs;
+  std::memset(&rs, 0, sizeof(rs));
+  rs.pos = b.pos;
+  rs.vel = b.vel;
+  rs.choice = n_choices > 0 ? b.choice : nullptr;
+  rs.enabled = 1;
+  rs.E = A + L;
+  rs.n_choices = n_choices;
+  for (int k = 0; k < MPE_MAX_CHOICES; ++k) rs.pop[k] = pop[k];
+  rs.landmark_range = landmark_range;
+  rs.episode = episode;
+  hipLaunchKernelGGL(k_random_actions, grid, dim3(kBlock), 0, stream, act, ids, B, A, seed, step0, world_offset, rs);
   return (int)hipGetLastError();
 }
 

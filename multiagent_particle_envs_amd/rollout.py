@@ -12,6 +12,7 @@ Three ways to issue it:
            moves drawn in-kernel (bit-identical to the pool's), outputs still written every step
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -52,6 +53,7 @@ class RandomRollout(object):
                                 "Python observation / reward / done / info callbacks (use env.step, or GraphedStep)")
         self.env = env
         self.world = env.world
+        self.fuse_reset_and_draw = not os.environ.get("MPE_NO_FUSED_RESET_DRAW")      # (False: the two launches, the A/B)
         self.episode_len = int(episode_len)
         self.seed = int(env.world.seed if seed is None else seed) & (2 ** 64 - 1)
         env._ensure_buffers()
@@ -107,9 +109,24 @@ class RandomRollout(object):
         L, desc, B = self._L, self._desc, self.B
         st = self._stream()
         for _ in range(steps):
-            if self.regenerate and self.t // len(self.pool) != self._pool_block:   # entering a block the pool does not hold
+            refill = self.regenerate and self.t // len(self.pool) != self._pool_block   # entering a block the pool does not hold
+            boundary = bool(self.episode_len) and self.t % self.episode_len == 0
+            if refill and boundary and self.fuse_reset_and_draw and self.t % len(self.pool) == 0 and \
+                    (self._prog is None or not self._prog.struct.reset_boxes):
+                # an episode starts where a block of moves starts: reset_world and the block's moves in ONE launch (the same draws
+                # as mpe_reset + mpe_random_actions_block; one dependent launch less in front of every episode)
+                _abi.check(L.mpe_reset_random_actions_block(
+                    C.byref(self._gen_desc), C.byref(env._sets[0].bufs), B, self._lr, self.t // self.episode_len,
+                    None if self.action_ids else self.pool_t.data_ptr(), self.pool_t.data_ptr() if self.action_ids else None,
+                    self.seed, int(self.t), len(self.pool), int(w.world_offset), st), "mpe_reset_random_actions_block")
+                if self.pool_c is not None:
+                    _abi.check(L.mpe_random_comm(self.pool_c.data_ptr(), self.A, B, int(w.dim_c), self.speakers, self.seed, int(self.t),
+                                                 len(self.pool), int(w.world_offset), st), "mpe_random_comm")
+                self._pool_block = self.t // len(self.pool)
+                refill = boundary = False
+            if refill:
                 self._fill_pool(self.t // len(self.pool) * len(self.pool), st)
-            if self.episode_len and self.t % self.episode_len == 0:
+            if boundary:
                 b = env._sets[0].bufs
                 if self._prog is not None:      # the program's own placement (MpeRowProgram.reset_boxes), as its in-launch restarts draw it
                     _abi.check(L.mpe_reset_rows(C.byref(self._gen_desc), C.byref(b), self._prog.ref, B, None, self._lr, self.seed,

@@ -399,3 +399,24 @@ def test_a_row_program_env_rolls_out_through_per_step_launches(compiled):
     assert torch.equal(d.world.pos, e.world.pos) and all(torch.equal(d._sets[0].obs_n[i], last.obs_n[i]) for i in range(d.n))
     with pytest.raises(_abi.MpeError, match="episode clock"):
         RandomRollout(mpe.make_env("simple_adversary", batch_size=64, num_agents=4, num_adversaries=2, max_episode_steps=5), episode_len=5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", [("simple_spread", {}), ("simple_adversary", {}), ("simple_reference", {})])
+def test_reset_and_move_block_in_one_launch_equals_the_two_launches(name, kw):
+    """An episode that starts where a block of moves starts: `mpe_reset_random_actions_block` (reset_world + the block's moves, one
+    launch) against `mpe_reset` + `mpe_random_actions_block` -- the same draws, so the same worlds, moves and outputs, bit for bit."""
+    B, T = 3000, 60
+    envs = [mpe.make_env(name, batch_size=B, seed=4, **kw) for _ in range(2)]
+    rolls = [RandomRollout(e, episode_len=25, pool=25, regenerate=True) for e in envs]
+    rolls[1].fuse_reset_and_draw = False
+    for r in rolls:
+        r.enqueue(T)
+    torch.cuda.synchronize()
+    a, b = envs
+    assert torch.equal(a.world.pos, b.world.pos) and torch.equal(a.world.vel, b.world.vel)
+    assert torch.equal(rolls[0].pool_t, rolls[1].pool_t)
+    if a.world.choice_i32 is not None:
+        assert torch.equal(a.world.choice_i32, b.world.choice_i32)
+    for s_ in range(2):
+        assert torch.equal(a._sets[s_].obs, b._sets[s_].obs) and torch.equal(a._sets[s_].rew, b._sets[s_].rew)
