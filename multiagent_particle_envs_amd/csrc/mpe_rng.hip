@@ -98,7 +98,11 @@ k_random_actions(float *__restrict__ act, int32_t *__restrict__ ids, size_t B, i
       for (int k = 0; k < MPE_ACTION_DIM; ++k) {
         const int f = kWave * k + lane, wl = f / MPE_ACTION_DIM, comp = f - wl * MPE_ACTION_DIM;
         const int ms = __shfl(m, wl, kWave);
+#ifdef MPE_ACT_BLOCK_NT      // A/B (round 5): nontemporal stores for the block of moves -- measured, not adopted (profiles/r5_act_block_nt_ab.txt)
+        if (wl < nvalid) __builtin_nontemporal_store((comp == ms) ? 1.f : 0.f, &run[f]);
+#else
         if (wl < nvalid) run[f] = (comp == ms) ? 1.f : 0.f;
+#endif
       }
     }
   }

@@ -10,7 +10,7 @@ python -m $P._build > /dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=14 "$@" \
     -c $P/csrc/mpe_$STEM.hip -o $P/build/mpe_${STEM}_ab_$TAG.o
 OBJS=""
-for s in abi narrow split wide rng; do
+for s in abi narrow split wide rng rows; do
   if [ $s == $STEM ]; then OBJS="$OBJS $P/build/mpe_${STEM}_ab_$TAG.o"; else OBJS="$OBJS $P/build/mpe_$s.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/lib/libmpe_hip_ab_$TAG.so $OBJS
