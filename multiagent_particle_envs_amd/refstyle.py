@@ -264,9 +264,11 @@ class TracedRefScenario(object):
     """A reference-style Scenario presented to MultiAgentEnv as a row-program scenario of this package's protocol: its
     `observation` / `reward` (/ `done`) were traced into expression graphs (symtrace.trace), verified against the file's own
     callbacks, and are compiled into the step kernel as straight-line code -- `env.step` is ONE launch, no host callbacks, no
-    per-world Python objects.  `reset_world` is the traced reset: drawn on the device where it is the uniform placement of
-    `World.reset_uniform` (all nine reference files), else evaluated with NumPy for all worlds at once and uploaded;
-    `reset(seeds=...)` replays the file's own random stream per world (the reference's `np.random.seed(s); env.reset()`)."""
+    per-world Python objects.  `reset_world` is the traced reset: drawn on the device where every coordinate is a uniform draw
+    of its own -- `World.reset_uniform`'s placement (all nine reference files) or a box per entity (`reset_boxes`: a restricted
+    spawn area); then the episodes also end and restart inside the step launch -- else drawn and evaluated with torch ops on the
+    device for all worlds at once; `reset(seeds=...)` replays the file's own random stream per world (the reference's
+    `np.random.seed(s); env.reset()`).  `benchmark_data` (make_env(..., benchmark=True)) runs as a second program."""
     kind = None
     reference_style = True
     traced_style = True
@@ -281,7 +283,6 @@ class TracedRefScenario(object):
     def report(self):
         """One paragraph: what was traced and how it runs."""
         t = self.t
-        ops = sorted(set(n.op for row in t.obs for n in row) | set(n.op for n in t.rew))
         return ("traced: %d agents, %d landmarks, dim_c %d; observation widths %s; %d graph nodes; control-flow paths per callback: obs %s, "
                 "reward %s%s (%s); per-world picks of reset_world: %s; reset_world %s; verified against the file's own callbacks: max "
                 "difference %s" % (
