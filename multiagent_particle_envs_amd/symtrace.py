@@ -718,7 +718,8 @@ def predicated_twin(scenario):
         code = compile(tree, path, "exec")
         space = {"__name__": klass.__module__ + "__predicated", "__file__": path}
         space.update(_PREDICATION_HELPERS)
-        exec(code, space)
+        with patched_math():
+            exec(code, space)
         twin_class = space[klass.__name__]
     except TraceUnsupported:
         raise
@@ -992,6 +993,55 @@ def _numpy_patches():
     return {"maximum": maximum, "minimum": minimum, "clip": clip, "amin": amin, "amax": amax, "min": amin, "max": amax, "where": where}
 
 
+# ---- the math module: its functions take floats (a symbolic value would be asked for its __float__) -------------------------------
+def _math_wrappers():
+    def unary(name, sym):
+        orig = getattr(math, name)
+
+        def f(x):
+            return sym(x if isinstance(x, Sym) else Sym(_Ctx.graph.as_float(x.n))) if isinstance(x, (Sym, SymBool)) else orig(x)
+        f.__name__ = name
+        return f
+
+    def binary(name, sym):
+        orig = getattr(math, name)
+
+        def f(x, y):
+            if isinstance(x, (Sym, SymBool)) or isinstance(y, (Sym, SymBool)):
+                return sym(Sym(_lift(x)), Sym(_lift(y)))
+            return orig(x, y)
+        f.__name__ = name
+        return f
+    return {"sqrt": unary("sqrt", lambda x: x.sqrt()), "exp": unary("exp", lambda x: x.exp()), "log": unary("log", lambda x: x.log()),
+            "tanh": unary("tanh", lambda x: x.tanh()), "sin": unary("sin", lambda x: x.sin()), "cos": unary("cos", lambda x: x.cos()),
+            "fabs": unary("fabs", lambda x: abs(x)), "atan2": binary("atan2", lambda x, y: x.arctan2(y)),
+            "hypot": binary("hypot", lambda x, y: (x * x + y * y).sqrt()), "pow": binary("pow", lambda x, y: x ** (y.n.value if y.n.op == "const" else y))}
+
+
+_MATH_WRAPPERS = None
+
+
+@contextlib.contextmanager
+def patched_math():
+    """math.sqrt / exp / log / tanh / sin / cos / fabs / atan2 / hypot / pow accept symbolic values while a file is traced (and
+    while its source is re-executed for predication: `from math import sqrt` then binds the wrapper, which is the original
+    function for ordinary numbers)."""
+    global _MATH_WRAPPERS
+    if _MATH_WRAPPERS is None:
+        _MATH_WRAPPERS = _math_wrappers()
+    saved = {name: getattr(math, name) for name in _MATH_WRAPPERS}
+    if any(saved[name] is _MATH_WRAPPERS[name] for name in saved):      # (already patched: nested use)
+        yield
+        return
+    try:
+        for name, f in _MATH_WRAPPERS.items():
+            setattr(math, name, f)
+        yield
+    finally:
+        for name, f in saved.items():
+            setattr(math, name, f)
+
+
 _RANDOM_NAMES = ("uniform", "choice", "randint")
 _RANDOM_REFUSED = ("rand", "randn", "random", "random_sample", "normal", "shuffle", "permutation", "sample", "standard_normal",
                    "exponential", "beta", "gamma", "seed", "binomial", "poisson")
@@ -1006,6 +1056,8 @@ def patched_random(impl):
             saved[name] = getattr(np.random, name)
     patches = _numpy_patches() if isinstance(impl, _Recorder) else {}      # (a symbolic run: max / min / clip / where without forks)
     saved_np = {name: getattr(np, name) for name in patches}
+    mathctx = patched_math() if isinstance(impl, _Recorder) else contextlib.nullcontext()
+    mathctx.__enter__()
     try:
         for name, f in patches.items():
             setattr(np, name, f)
@@ -1022,6 +1074,7 @@ def patched_random(impl):
             setattr(np.random, name, f)
         for name, f in saved_np.items():
             setattr(np, name, f)
+        mathctx.__exit__(None, None, None)
 
 
 @contextlib.contextmanager

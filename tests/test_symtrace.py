@@ -572,3 +572,55 @@ def test_generated_code_on_the_host_against_the_numpy_evaluation(name, tmp_path)
         assert (np.abs(rows[i][ok] - want[ok]) / np.maximum(1.0, np.abs(want[ok]))).max(initial=0.0) <= 1e-5, (name, "obs", i)
         w = vals[off[-1] + i]
         assert (np.abs(rew[ok, i] - w[ok]) / np.maximum(1.0, np.abs(w[ok]))).max() <= 1e-5, (name, "rew", i)
+
+
+_MATH_FILE = '''
+import math
+from math import exp, hypot
+import numpy as np
+from multiagent.core import World, Agent, Landmark
+from multiagent.scenario import BaseScenario
+
+
+class Scenario(BaseScenario):
+    def make_world(self):
+        world = World()
+        world.agents = [Agent() for _ in range(2)]
+        for i, a in enumerate(world.agents):
+            a.name, a.silent = "agent %d" % i, True
+        world.landmarks = [Landmark()]
+        world.landmarks[0].movable, world.landmarks[0].collide = False, False
+        self.reset_world(world)
+        return world
+
+    def reset_world(self, world):
+        for e in world.agents + world.landmarks:
+            e.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            e.state.p_vel = np.zeros(world.dim_p)
+        for a in world.agents:
+            a.state.c = np.zeros(world.dim_c)
+
+    def reward(self, agent, world):
+        dx = agent.state.p_pos[0] - world.landmarks[0].state.p_pos[0]
+        dy = agent.state.p_pos[1] - world.landmarks[0].state.p_pos[1]
+        d = math.sqrt(dx * dx + dy * dy)
+        return -hypot(dx, dy) - exp(-d) + 0.1 * math.cos(math.atan2(dy, dx + 1e-2)) + math.tanh(d) * math.fabs(dx) + math.log(1.0 + d) \\
+            + math.sqrt(4.0) * 0.0
+
+    def observation(self, agent, world):
+        return np.concatenate([agent.state.p_vel, agent.state.p_pos, world.landmarks[0].state.p_pos - agent.state.p_pos])
+'''
+
+
+def test_the_math_module_accepts_symbolic_values_while_a_file_is_traced(tmp_path):
+    """`math.sqrt(dx * dx + dy * dy)`, `from math import exp, hypot`: the math module's functions take floats; while a file is traced
+    (and while its source is re-executed for predication) they are wrappers that build nodes for symbolic arguments."""
+    import math
+    path = tmp_path / "mathy.py"
+    path.write_text(_MATH_FILE)
+    sc = mpe.scenarios.load(str(path)).Scenario()
+    before = (math.sqrt, math.exp, math.atan2)
+    t = symtrace.trace(sc)
+    assert (math.sqrt, math.exp, math.atan2) == before and math.sqrt(9.0) == 3.0
+    assert t.predicated and symtrace.verify(sc, t, worlds=200) <= 1e-15
+    assert {"sqrt", "exp", "cos", "atan2", "tanh", "log", "abs"} <= set(n.op for n in symtrace.topo(t.rew))
