@@ -723,8 +723,10 @@ def make_ref_env(scenario, benchmark=False, batch_size=None, device=None, seed=0
             if traced:
                 raise
             why = "%s: %s" % (type(e).__name__, e)
-            if verbose:
-                print("reference-style scenario on the host path (%s)" % why)
+            if verbose or int(batch_size) >= 1024:      # (a large batch on the host path is orders of magnitude slower: say so once)
+                import warnings
+                warnings.warn("reference-style scenario on the HOST path -- its callbacks run per world in Python (%s); "
+                              "env.trace_fallback holds the reason" % why, RuntimeWarning, stacklevel=3)
     elif traced:
         raise _abi.MpeError("traced=True needs batch_size (a batched env)")
     ad = RefScenarioAdapter(scenario, 1 if compat else int(batch_size), device, host_outputs=compat)
