@@ -47,6 +47,12 @@ _CMP = ("lt", "le", "eq", "ne")
 _BOOL_OPS = _CMP + ("not", "and", "or", "bconst")
 
 
+def _np_mod(x, y):
+    """x % y as NumPy answers it for floats (the sign of the divisor; nan for y == 0 where Python raises)."""
+    with np.errstate(all="ignore"):
+        return float(np.mod(np.float64(x), np.float64(y)))
+
+
 class Node(object):
     """One value of the expression graph (hash-consed per Graph: structurally equal nodes are the same object)."""
     __slots__ = ("op", "args", "value", "uid", "is_bool")
@@ -86,7 +92,8 @@ class Graph(object):
             x = a.value
             try:
                 v = {"neg": lambda: -x, "abs": lambda: abs(x), "sqrt": lambda: math.sqrt(x), "exp": lambda: math.exp(x),
-                     "log": lambda: math.log(x), "tanh": lambda: math.tanh(x), "sin": lambda: math.sin(x), "cos": lambda: math.cos(x)}[op]()
+                     "log": lambda: math.log(x), "tanh": lambda: math.tanh(x), "sin": lambda: math.sin(x), "cos": lambda: math.cos(x),
+                     "floor": lambda: float(math.floor(x)), "rint": lambda: float(np.rint(x))}[op]()
             except (ValueError, OverflowError):
                 v = float("nan")
             return self.const(v)
@@ -97,9 +104,12 @@ class Graph(object):
             x, y = a.value, b.value
             try:
                 v = {"add": lambda: x + y, "sub": lambda: x - y, "mul": lambda: x * y, "div": lambda: x / y,
-                     "min": lambda: min(x, y), "max": lambda: max(x, y), "atan2": lambda: math.atan2(x, y)}[op]()
+                     "min": lambda: min(x, y), "max": lambda: max(x, y), "atan2": lambda: math.atan2(x, y),
+                     "pow": lambda: math.pow(x, y), "mod": lambda: _np_mod(x, y)}[op]()
             except ZeroDivisionError:
-                v = float("nan") if x == 0 else math.copysign(float("inf"), x)
+                v = float("nan") if (x == 0 or op == "mod") else math.copysign(float("inf"), x)
+            except (ValueError, OverflowError):
+                v = float("nan")
             return self.const(v)
         if op == "sub" and a is b:         # an entity's offset to itself (simple_spread.py:78-81 counts the agent against itself)
             return self.const(0.0)
@@ -181,6 +191,10 @@ def _lift(x):
     raise TraceUnsupported("a symbolic value combined with %r" % type(x).__name__)
 
 
+def _select_nodes(c, a, b):
+    return _Ctx.graph.ite(c, a, b)
+
+
 class Sym(object):
     """A real number that depends on the world's state."""
     __slots__ = ("n",)
@@ -217,7 +231,41 @@ class Sym(object):
                 return self.sqrt()
             if o == 3:
                 return self * self * self
-        raise TraceUnsupported("power with exponent %r" % (o,))
+        return self._b("pow", o)          # (any other exponent, or a symbolic one: pow() as C computes it)
+
+    def __rpow__(self, o): return self._b("pow", o, True)
+    def __mod__(self, o): return self._b("mod", o)
+    def __rmod__(self, o): return self._b("mod", o, True)
+
+    def __floordiv__(self, o):
+        q = self._b("div", o)
+        return q if q is NotImplemented else q.floor()
+
+    def __rfloordiv__(self, o):
+        q = self._b("div", o, True)
+        return q if q is NotImplemented else q.floor()
+
+    # rounding: floor / ceil / rint are what math.floor, math.ceil, np.floor, np.ceil, np.rint, np.round and round() ask for
+    def floor(self): return Sym(_Ctx.graph.unary("floor", self.n))
+    def ceil(self): return -((-self).floor())
+    def rint(self): return Sym(_Ctx.graph.unary("rint", self.n))
+    def trunc(self): return Sym(_select_nodes(_Ctx.graph.compare("lt", self.n, _Ctx.graph.const(0.0)), self.ceil().n, self.floor().n))
+    __floor__, __ceil__, __trunc__ = floor, ceil, trunc
+
+    def __round__(self, ndigits=None):      # (as np.round computes it: rint(x * 10^n) / 10^n -- round-half-even like Python's)
+        if not ndigits:
+            return self.rint()
+        k = 10.0 ** int(ndigits)
+        return (self * k).rint() / k
+
+    def sign(self):
+        g = _Ctx.graph
+        zero = g.const(0.0)
+        return Sym(_select_nodes(g.compare("lt", zero, self.n), g.const(1.0), _select_nodes(g.compare("lt", self.n, zero), g.const(-1.0), zero)))
+
+    def hypot(self, o): return (self * self + Sym(_lift(o)) * Sym(_lift(o))).sqrt()
+    def square(self): return self * self
+    def reciprocal(self): return 1.0 / self
 
     # the methods NumPy's object-dtype ufunc loops look for: np.sqrt(x) -> x.sqrt(), np.exp, np.log, np.tanh, np.square ...
     def sqrt(self): return Sym(_Ctx.graph.unary("sqrt", self.n))
@@ -382,7 +430,47 @@ def sym_all(it):
     return SymBool(acc)
 
 
-_INJECTED = {"min": sym_min, "max": sym_max, "any": sym_any, "all": sym_all}
+class _NumberMeta(type):
+    """isinstance(x, float) / issubclass(.., float) in the traced file keep answering as for the builtin type."""
+    def __instancecheck__(cls, x):
+        return isinstance(x, cls.__mro__[1])
+
+    def __subclasscheck__(cls, k):
+        return issubclass(k, cls.__mro__[1])
+
+
+class sym_float(float, metaclass=_NumberMeta):
+    """`float` as the traced file sees it: float(x) of a state-dependent number is that number, of a state-dependent truth value
+    1.0 / 0.0 (`float(dist < r)`); anything else is the builtin's answer."""
+    def __new__(cls, x=0.0):
+        if isinstance(x, Sym):
+            return x
+        if isinstance(x, SymBool):
+            return x._f()
+        if isinstance(x, np.ndarray) and x.dtype == object and x.size == 1:
+            return sym_float(x.reshape(-1)[0])
+        return float(x)
+
+
+class sym_int(int, metaclass=_NumberMeta):
+    """`int`: int(truth value) -> 1.0 / 0.0 as a number of the graph, int(number) -> truncated towards zero."""
+    def __new__(cls, x=0, *base):
+        if isinstance(x, Sym) and not isinstance(x, SymPickInt):
+            return x.trunc()
+        if isinstance(x, SymBool):
+            return x._f()
+        if isinstance(x, np.ndarray) and x.dtype == object and x.size == 1 and not base:
+            return sym_int(x.reshape(-1)[0])
+        return int(x, *base)
+
+
+def sym_round(x, ndigits=None):
+    if isinstance(x, Sym):
+        return x.__round__(ndigits)
+    return round(x) if ndigits is None else round(x, ndigits)
+
+
+_INJECTED = {"min": sym_min, "max": sym_max, "any": sym_any, "all": sym_all, "float": sym_float, "int": sym_int, "round": sym_round}
 
 
 # ---- predication: `if`s that only assign, conditional expressions, early returns and and / or / not WITHOUT forking ---------------
@@ -990,7 +1078,61 @@ def _numpy_patches():
                 return x if t else y
             return _select_any(t, x, y)
         return _elementwise(pick, c, rest[0], rest[1])
-    return {"maximum": maximum, "minimum": minimum, "clip": clip, "amin": amin, "amax": amax, "min": amin, "max": amax, "where": where}
+    out = {"maximum": maximum, "minimum": minimum, "clip": clip, "amin": amin, "amax": amax, "min": amin, "max": amax, "where": where}
+
+    # ---- elementwise functions: NumPy's object loops call a METHOD of each element (x.sqrt()), which the plain Python floats that
+    # share an array with symbolic values do not have; np.sign orders its argument against 0 (one fork per element)
+    def unary(name, method):
+        orig = getattr(np, name)
+
+        def one(v):
+            if isinstance(v, SymBool):
+                v = v._f()
+            if isinstance(v, Sym):
+                m = getattr(v, method, None)
+                if m is None:
+                    raise TraceUnsupported("np.%s of a state-dependent value" % name)
+                return m()
+            return orig(v)
+
+        def f(x, *args, **kw):
+            if args or kw or not (isinstance(x, (Sym, SymBool)) or (isinstance(x, np.ndarray) and x.dtype == object)
+                                  or (isinstance(x, (list, tuple)) and _has_sym(x))):
+                return orig(x, *args, **kw)
+            if not _has_sym(x):                       # numbers that only happen to sit in an object array
+                return orig(np.asarray(x, dtype=np.float64)).astype(object)
+            return _elementwise(one, x)
+        f.__name__ = name
+        return f
+    for name, method in [("sqrt", "sqrt"), ("exp", "exp"), ("log", "log"), ("tanh", "tanh"), ("sin", "sin"), ("cos", "cos"),
+                         ("floor", "floor"), ("ceil", "ceil"), ("rint", "rint"), ("trunc", "trunc"), ("sign", "sign"),
+                         ("fabs", "__abs__"), ("square", "square"), ("reciprocal", "reciprocal")] + \
+                        [(n, None) for n in ("arctan", "arcsin", "arccos", "sinh", "cosh", "log1p", "expm1", "log2", "log10", "cbrt",
+                                             "isfinite", "isnan", "isinf", "degrees", "radians")]:
+        out[name] = unary(name, method or "_no_such_method_")
+
+    # ---- constructors: `o = np.zeros(4); o[:2] = agent.state.p_pos` needs an array that can hold symbolic values
+    def ctor(name, like):
+        orig = getattr(np, name)
+
+        def f(*args, **kw):
+            dt = kw.get("dtype", None)
+            if dt is sym_int:
+                kw["dtype"] = dt = int
+            if dt is None and like and args and isinstance(args[0], np.ndarray) and args[0].dtype.kind != "f":
+                return orig(*args, **kw)              # (zeros_like an integer / object array keeps its kind)
+            positional_dtype = len(args) > (2 if name in ("full", "full_like") else 1) and not like
+            if positional_dtype or not (dt is None or dt is sym_float or dt is float or dt is np.float64 or dt is object):
+                return orig(*args, **kw)
+            kw.pop("dtype", None)
+            r = orig(*args, **kw)
+            return r.astype(object) if r.dtype.kind == "f" else r
+        f.__name__ = name
+        return f
+    for name, like in [("zeros", False), ("ones", False), ("empty", False), ("full", False),
+                       ("zeros_like", True), ("ones_like", True), ("empty_like", True), ("full_like", True)]:
+        out[name] = ctor(name, like)
+    return out
 
 
 # ---- the math module: its functions take floats (a symbolic value would be asked for its __float__) -------------------------------
@@ -1599,6 +1741,21 @@ def evaluate(roots, B, P=None, V=None, Cw=None, K=None, U=None, dtype=np.float64
                 v = np.cos(a[0])
             elif op == "atan2":
                 v = np.arctan2(a[0], a[1])
+            elif op == "pow":
+                v = np.power(a[0], a[1])
+            elif op == "mod":
+                v = np.mod(a[0], a[1])
+                if _margin is not None:      # (the wrap: where a / b passes an integer)
+                    q = a[0] / a[1]
+                    f = q - np.floor(q)
+                    d = np.minimum(f, 1.0 - f) * np.abs(a[1])
+                    np.minimum(_margin, np.where(np.isfinite(d), d, np.inf), out=_margin)
+            elif op in ("floor", "rint"):
+                v = np.floor(a[0]) if op == "floor" else np.rint(a[0])
+                if _margin is not None:      # how far the argument is from the next step of the staircase
+                    f = a[0] - np.floor(a[0])
+                    d = np.minimum(f, 1.0 - f) if op == "floor" else np.abs(f - 0.5)
+                    np.minimum(_margin, np.where(np.isfinite(d), d, np.inf), out=_margin)
             elif op in ("lt", "le") and _margin is not None and not any(x.op == "K" or x.op == "sel" for x in n.args):
                 # (== / != are tests on exact data -- an utterance that is all zeros, simple_crypto.py:104 -- and hold in fp32 as in fp64)
                 np.minimum(_margin, np.where(np.isfinite(a[0] - a[1]), np.abs(a[0] - a[1]), np.inf), out=_margin)
@@ -1767,6 +1924,14 @@ def evaluate_torch(roots, B, K=None, U=None, P=None, V=None, Cw=None, device=Non
             v = getattr(torch, op)(a[0])
         elif op == "atan2":
             v = torch.atan2(a[0], a[1])
+        elif op == "pow":
+            v = torch.pow(a[0], a[1])
+        elif op == "mod":
+            v = torch.remainder(a[0], a[1])
+        elif op == "floor":
+            v = torch.floor(a[0])
+        elif op == "rint":
+            v = torch.round(a[0])
         elif op in _CMP:
             v = {"lt": torch.lt, "le": torch.le, "eq": torch.eq, "ne": torch.ne}[op](a[0], a[1])
         elif op == "not":
@@ -1848,6 +2013,13 @@ def _emit(roots, lines, names, shared=None):
             e = "%sf(%s)" % (op, ref(a[0]))
         elif op == "atan2":
             e = "atan2f(%s, %s)" % (ref(a[0]), ref(a[1]))
+        elif op == "pow":
+            e = "powf(%s, %s)" % (ref(a[0]), ref(a[1]))
+        elif op in ("floor", "rint"):
+            e = "%sf(%s)" % (op, ref(a[0]))
+        elif op == "mod":      # NumPy's / Python's %: fmod, moved to the divisor's sign
+            lines.append("      const float m%d = fmodf(%s, %s);" % (n.uid, ref(a[0]), ref(a[1])))
+            e = "(m%d != 0.0f && ((m%d < 0.0f) != (%s < 0.0f))) ? m%d + %s : m%d" % (n.uid, n.uid, ref(a[1]), n.uid, ref(a[1]), n.uid)
         elif op in ("lt", "le"):
             # `np.sqrt(np.sum(np.square(d))) < r`, the reference's contact test (simple_tag.py:69-73): decided as NumPy's float32
             # rounding sequence would (sqrt_lt: exact, without the correctly rounded sqrt outside a 1e-6 band around r)

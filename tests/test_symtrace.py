@@ -168,7 +168,7 @@ def test_what_the_tracer_refuses_and_why():
 
     class Concretises(_Base):
         def reward(self, agent, world):
-            return float(agent.state.p_pos[0])
+            return float("%.3f" % agent.state.p_pos[0])       # (float(x) alone is traced: the file sees a `float` that lets x through)
 
     class RandomSizes(_Base):     # per-world randomness in make_world: the B worlds of a batch share their physics constants
         def make_world(self):
@@ -201,7 +201,7 @@ def test_tracing_leaves_numpy_random_and_the_files_namespace_as_they_were():
     assert (np.random.uniform, np.random.choice) == fns[:2]
 
 
-@pytest.mark.parametrize("name", ["herd", "relay", "convoy"])
+@pytest.mark.parametrize("name", ["herd", "relay", "convoy", "survey"])
 def test_fixture_files_trace_and_reproduce_their_own_callbacks(name):
     sc = mpe.scenarios.load(os.path.join(FIXTURES, name + ".py")).Scenario()
     ts = refstyle.trace_ref_scenario(sc, cache=False)
@@ -209,7 +209,7 @@ def test_fixture_files_trace_and_reproduce_their_own_callbacks(name):
     assert symtrace.verify(sc, ts.t, worlds=300, seed=7) == 0.0
     # every coordinate a uniform draw of its own: restarts can be drawn on the device -- relay / convoy as World.reset_uniform's
     # placement, herd (agents on [-0.8, 0.8)^2) in per-entity boxes
-    assert ts.device_reset and ts.landmark_range == (1.0 if name == "herd" else 0.9)
+    assert ts.device_reset and ts.landmark_range == {"herd": 1.0, "survey": 0.8}.get(name, 0.9)
     assert (ts.reset_boxes(None) is None) == (name != "herd")
     if name == "herd":
         assert ts.reset_boxes(None)[0] == (-0.8, 0.8, -0.8, 0.8) and ts.reset_boxes(None)[3] == (-1.0, 1.0, -1.0, 1.0)
@@ -468,7 +468,7 @@ def test_a_team_too_large_for_straight_line_code_is_refused_with_the_reason(tmp_
 
 
 def test_the_fixtures_and_committed_traces_hardly_fork():
-    for name in ("herd", "relay", "convoy"):
+    for name in ("herd", "relay", "convoy", "survey"):
         sc = mpe.scenarios.load(os.path.join(FIXTURES, name + ".py")).Scenario()
         t = symtrace.trace(sc)
         assert t.predicated and max(t.paths["obs"] + t.paths["rew"]) == 1, (name, t.paths)
@@ -507,6 +507,73 @@ def test_numpy_idioms_of_user_scenarios_trace_without_forks():
     assert np.maximum is not None and np.maximum(1, 2) == 2 and np.clip(5, 0, 1) == 1          # NumPy is itself again
 
 
+def test_rows_filled_slice_by_slice_rounding_and_number_conversions_trace():
+    """`row = np.zeros(n); row[:2] = agent.state.p_pos` (a float array cannot hold symbolic values: np.zeros / ones / empty / full
+    give object arrays while a file is traced), np.floor / ceil / rint / round / sign / mod / power / hypot, float(test) /
+    int(test) / int(x), a plain number sharing an array with symbolic ones under np.sqrt -- reproduced exactly, no fork."""
+    import math
+
+    class S(_Base):
+        def reward(self, agent, world):
+            d = [np.hypot(*(agent.state.p_pos - l.state.p_pos)) for l in world.landmarks]
+            near = min(d)
+            score = 0.25 * int(near < 0.3) + float(near > 1.0) - np.round(near, 1) + round(near * 3.0) * 0.01
+            mixed = np.sqrt(np.array([near + 1.0, 4.0]))             # (traced: an object array whose 4.0 is a Python float without .sqrt())
+            score += mixed[0] * 0.0 + (mixed[1] - 2.0)
+            score += int(agent.state.p_pos[0] * 3.0) * 0.1 + math.ceil(agent.state.p_pos[1]) * 0.01 + 2.0 ** agent.state.p_vel[0] * 0.0
+            assert isinstance(0.5, float) and isinstance(3, int) and not isinstance(3, float) and float("2.5") == 2.5 and int("7") == 7
+            return score - (agent.state.p_pos[0] // 0.5) * 0.01
+
+        def observation(self, agent, world):
+            row = np.zeros(12)
+            row[0:2] = agent.state.p_pos
+            row[2:4] = np.floor(agent.state.p_pos * 4.0) / 4.0
+            row[4:6] = np.mod(agent.state.p_pos + 1.0, 0.5)
+            row[6:8] = np.sign(agent.state.p_vel + 0.1) * np.power(np.abs(agent.state.p_pos), 1.5)
+            row[8:10] = np.rint(agent.state.p_pos * 2.0) + np.ceil(agent.state.p_pos) + np.trunc(agent.state.p_pos * 3.0)
+            rest = np.ones(2) * 0.5 + np.full(2, 0.25) + np.zeros_like(agent.state.p_vel) + np.empty(2) * 0.0
+            row[10:12] = rest + np.square(agent.state.p_vel) + np.exp(np.zeros(2)) - np.sqrt(np.ones(2))
+            return row
+    sc = S()
+    before = (np.zeros, np.sqrt, np.floor, np.sign, np.full)
+    t = symtrace.trace(sc)
+    assert (np.zeros, np.sqrt, np.floor, np.sign, np.full) == before and np.zeros(2).dtype == np.float64 and float is not symtrace.sym_float
+    assert "float" not in type(sc).reward.__globals__ or type(sc).reward.__globals__["float"] is float
+    assert max(t.paths["obs"] + t.paths["rew"]) == 1
+    assert symtrace.verify(sc, t, worlds=400) == 0.0
+    ops = set(n.op for n in symtrace.topo(t.rew + [n for row in t.obs for n in row]))
+    assert {"floor", "rint", "mod", "pow"} <= ops
+    src = symtrace.hip_source(t)
+    assert "floorf(" in src and "rintf(" in src and "fmodf(" in src and "powf(" in src
+    # the staircase functions count as decisions: worlds near a step are found by decision_margin (compared outside the band)
+    B = 4000
+    P, V, Cw = symtrace.random_states(t, B, np.random.RandomState(3))
+    roots = [n for row in t.obs for n in row]
+    m = symtrace.decision_margin(roots, B, P=P, V=V, Cw=Cw)
+    near = m < 1e-3
+    assert 0 < near.sum() < B // 4
+    a = np.stack(symtrace.evaluate(roots, B, P=P, V=V, Cw=Cw), axis=1)
+    b = np.stack(symtrace.evaluate(roots, B, P=P.astype(np.float32), V=V.astype(np.float32), Cw=Cw, dtype=np.float32), axis=1)
+    assert np.abs(a - b)[m > 2e-6].max() < 1e-5
+
+
+def test_what_is_still_not_modelled_falls_back_with_the_reason():
+    class Heavy(_Base):
+        def observation(self, agent, world):
+            return np.heaviside(agent.state.p_pos, 0.5)
+
+    class Close(_Base):
+        def reward(self, agent, world):
+            return 1.0 if np.allclose(agent.state.p_pos, world.landmarks[0].state.p_pos, atol=0.1) else 0.0
+
+    class Arc(_Base):
+        def reward(self, agent, world):
+            return float(np.arcsin(np.clip(agent.state.p_pos[0], -1, 1)))
+    for cls, why in ((Heavy, "heaviside"), (Close, "isfinite"), (Arc, "arcsin of a state-dependent value")):
+        with pytest.raises(symtrace.TraceUnsupported, match=why):
+            symtrace.trace(cls())
+
+
 def _host_run_generated(tr, P, V, Cw, K, tmp_path, tag):
     """The generated device functions compiled for the host (tests/c/traced_host.cpp) and run on the given states -> (rows per agent,
     rewards [B, A], dones [B, A])."""
@@ -536,13 +603,13 @@ def _host_run_generated(tr, P, V, Cw, K, tmp_path, tag):
     return [out[:, off[i]:off[i + 1]] for i in range(tr.A)], out[:, off[-1]:off[-1] + tr.A], out[:, off[-1] + tr.A:]
 
 
-@pytest.mark.parametrize("name", ["convoy", "relay", "simple_tag", "simple_world_comm", "simple_crypto", "nav8"])
+@pytest.mark.parametrize("name", ["convoy", "relay", "survey", "simple_tag", "simple_world_comm", "simple_crypto", "nav8"])
 def test_generated_code_on_the_host_against_the_numpy_evaluation(name, tmp_path):
     """The code GENERATOR without a GPU: traced_obs / traced_shared / traced_rew as symtrace.hip_source writes them, compiled with
     g++ (plain-C++ stand-ins for the device intrinsics) and run on random worlds, against the fp64 NumPy evaluation of the same
     graphs -- fixtures, committed traces of the reference's files, and an 8-agent cooperative-navigation file whose shared reward
     terms go through traced_shared."""
-    if name in ("convoy", "relay"):
+    if name in ("convoy", "relay", "survey"):
         tr = symtrace.trace(mpe.scenarios.load(os.path.join(FIXTURES, name + ".py")).Scenario())
     elif name == "nav8":
         path = tmp_path / "nav8.py"
