@@ -410,23 +410,32 @@ def _minmax(op, builtin, args, kw):
     return Sym(acc)
 
 
+def _truthy(x):
+    """the truth of one element as a node: a truth value itself, a number != 0"""
+    if isinstance(x, SymBool):
+        return x.n
+    if isinstance(x, Sym):
+        return _Ctx.graph.compare("ne", x.n, _Ctx.graph.const(0.0))
+    return _Ctx.graph.const(bool(x))
+
+
 def sym_any(it):
     items = list(it)
-    if not any(isinstance(x, SymBool) for x in items):
+    if not any(isinstance(x, (Sym, SymBool)) for x in items):
         return any(items)
     acc = _Ctx.graph.const(False)
     for x in items:
-        acc = _Ctx.graph.logical("or", acc, _blift(x) if isinstance(x, (SymBool, bool, np.bool_)) else SymBool(_lift(x)).n)
+        acc = _Ctx.graph.logical("or", acc, _truthy(x))
     return SymBool(acc)
 
 
 def sym_all(it):
     items = list(it)
-    if not any(isinstance(x, SymBool) for x in items):
+    if not any(isinstance(x, (Sym, SymBool)) for x in items):
         return all(items)
     acc = _Ctx.graph.const(True)
     for x in items:
-        acc = _Ctx.graph.logical("and", acc, _blift(x))
+        acc = _Ctx.graph.logical("and", acc, _truthy(x))
     return SymBool(acc)
 
 
@@ -507,7 +516,9 @@ def _select_any(t, a, b):
     if a is b:
         return a
     if a is _UNSET or b is _UNSET:
-        raise _CannotMerge()
+        # a name only ONE branch creates (`adv_l1 = ...` inside an else:, simple_crypto.py:112): a correct program reads it only
+        # where that branch ran, so its value on the other side is nobody's business -- it keeps the one it has
+        return b if a is _UNSET else a
     c = _truth_node(t)
     boolish = (bool, np.bool_, SymBool)
     if isinstance(a, boolish) and isinstance(b, boolish):
@@ -588,7 +599,32 @@ def _p_snap(x):
     return list(x) if type(x) is list else x
 
 
-_PREDICATION_HELPERS = {"_mpe_snap": _p_snap, "_mpe_sym": _is_symbolic, "_mpe_sel": _select_any, "_mpe_ifexp": _p_ifexp, "_mpe_and": _p_and,
+def _p_cmp(op, a, b):
+    """`a < b` (one operator) as the twin evaluates it: arrays that hold symbolic values are compared element by element into an
+    array of truth values -- NumPy's own `<` on an object array stores bools, i.e. asks every element's comparison for its truth
+    (one fork per element).  Anything else: the operator itself."""
+    import operator
+    f = getattr(operator, op)
+    if ((isinstance(a, np.ndarray) and a.dtype == object) or (isinstance(b, np.ndarray) and b.dtype == object)) and _has_sym(a, b):
+        mirrored = {"lt": "gt", "le": "ge", "gt": "lt", "ge": "le", "eq": "eq", "ne": "ne"}[op]
+
+        def one(x, y):
+            if isinstance(y, (Sym, SymBool)) and not isinstance(x, (Sym, SymBool)):
+                return getattr(operator, mirrored)(y, x)
+            return f(x, y)
+        return _elementwise(one, a, b)
+    return f(a, b)
+
+
+def _p_method(name, obj, *args, **kw):
+    """`x.min(axis=0)`, `x.any()`, `x.clip(lo, hi)`: the METHODS of an array that holds symbolic values answered by the functions
+    np.min / np.any / np.clip as they are while a file is traced (_numpy_patches); any other object: its own method."""
+    if isinstance(obj, np.ndarray) and obj.dtype == object and _has_sym(obj):
+        return getattr(np, name)(obj, *args, **kw)
+    return getattr(obj, name)(*args, **kw)
+
+
+_PREDICATION_HELPERS = {"_mpe_cmp": _p_cmp, "_mpe_method": _p_method, "_mpe_snap": _p_snap, "_mpe_sym": _is_symbolic, "_mpe_sel": _select_any, "_mpe_ifexp": _p_ifexp, "_mpe_and": _p_and,
                         "_mpe_or": _p_or, "_mpe_not": _p_not, "_MPE_UNSET": _UNSET, "_mpe_CannotMerge": _CannotMerge}
 
 
@@ -680,29 +716,73 @@ def _predicate_tree(tree):
                 return call("_mpe_not", node.operand)
             return node
 
+        def visit_Compare(self, node):
+            self.generic_visit(node)
+            names = {ast.Lt: "lt", ast.LtE: "le", ast.Gt: "gt", ast.GtE: "ge", ast.Eq: "eq", ast.NotEq: "ne"}
+            if len(node.ops) == 1 and type(node.ops[0]) in names:
+                return call("_mpe_cmp", ast.Constant(value=names[type(node.ops[0])]), node.left, node.comparators[0])
+            if len(node.ops) > 1 and all(type(o) in names for o in node.ops) and \
+                    not any(isinstance(n, (ast.Call, ast.NamedExpr, ast.Await, ast.Yield)) for m in node.comparators[:-1] for n in ast.walk(m)):
+                import copy          # a < x < b with a plain middle operand (evaluating it twice changes nothing): a < x and x < b
+                terms = [node.left] + list(node.comparators)
+                return call("_mpe_and", *[lam(call("_mpe_cmp", ast.Constant(value=names[type(o)]), copy.deepcopy(terms[k]), copy.deepcopy(terms[k + 1])))
+                                          for k, o in enumerate(node.ops)])
+            return node          # (`is`, `in`, chains through calls: as written)
+
+        def visit_Call(self, node):
+            self.generic_visit(node)
+            if isinstance(node.func, ast.Attribute) and node.func.attr in ("min", "max", "any", "all", "clip") and \
+                    not any(isinstance(a, ast.Starred) for a in node.args) and not any(k.arg is None for k in node.keywords):
+                return ast.Call(func=ast.Name(id="_mpe_method", ctx=ast.Load()),
+                                args=[ast.Constant(value=node.func.attr), node.func.value] + list(node.args), keywords=list(node.keywords))
+            return node
+
         def _returns_chain(self, stmts):
-            """[if T: return X]* return Z  ->  the expression select(T, X, ...Z), or None"""
+            """A block that consists of nothing but tests and returns -- `if T: return X` ... `return Z`, also nested (`if T: if U:
+            return X; return Y` / elif / else) -- as the expression select(T, X, ... Z); None for anything else."""
             if len(stmts) == 1 and isinstance(stmts[0], ast.Return) and stmts[0].value is not None:
                 return stmts[0].value
             st = stmts[0] if stmts else None
-            if isinstance(st, ast.If) and not st.orelse and len(st.body) == 1 and isinstance(st.body[0], ast.Return) and \
-                    st.body[0].value is not None and len(stmts) > 1:
-                rest = self._returns_chain(stmts[1:])
-                if rest is not None:
-                    return call("_mpe_ifexp", st.test, lam(st.body[0].value), lam(rest))
+            if isinstance(st, ast.If):
+                then = self._returns_chain(st.body)
+                if then is not None:
+                    rest = self._returns_chain(list(st.orelse) + list(stmts[1:]))
+                    if rest is not None:
+                        return call("_mpe_ifexp", st.test, lam(then), lam(rest))
             return None
 
         def _block(self, stmts):
             """a statement list: early-return chains at its end become one return"""
             out = []
             for k, st in enumerate(stmts):
-                if isinstance(st, ast.If) and not st.orelse and len(st.body) == 1 and isinstance(st.body[0], ast.Return):
+                if isinstance(st, ast.If):
                     chain = self._returns_chain(stmts[k:])
                     if chain is not None:
                         out.append(ast.Return(value=chain))
                         return out
                 out.append(st)
             return out
+
+        def _decontinue(self, stmts):
+            """`if T: continue [else: E]` followed by the rest of a loop body  ->  `if not T: [E] <rest>` (the same program; the rest
+            can then be predicated where it only assigns: simple_crypto.py:104-113)"""
+            for k, st in enumerate(stmts):
+                if isinstance(st, ast.If) and len(st.body) == 1 and isinstance(st.body[0], ast.Continue):
+                    rest = self._decontinue(list(st.orelse) + list(stmts[k + 1:]))          # (`else:` of a continue: the rest, too)
+                    if not rest:
+                        return list(stmts[:k]) + [ast.Expr(value=st.test)]
+                    return list(stmts[:k]) + [ast.If(test=ast.UnaryOp(op=ast.Not(), operand=st.test), body=rest, orelse=[])]
+            return list(stmts)
+
+        def visit_For(self, node):
+            node.body = self._decontinue(node.body)
+            self.generic_visit(node)
+            return node
+
+        def visit_While(self, node):
+            node.body = self._decontinue(node.body)
+            self.generic_visit(node)
+            return node
 
         def visit_FunctionDef(self, node):
             self.generic_visit(node)
@@ -1059,15 +1139,44 @@ def _numpy_patches():
             r = minimum(r, a_max)
         return r
 
-    def amin(a, axis=None, *args, **kw):
-        if axis is not None or args or kw or not _has_sym(a):
-            return o_amin(a, axis, *args, **kw)
-        return sym_min(list(np.asarray(a, dtype=object).reshape(-1)))
+    def reduce(a, axis, keepdims, f):
+        a = np.asarray(a, dtype=object)
+        if axis is None:
+            r = f(list(a.reshape(-1)))
+            if keepdims:
+                out = np.empty((1,) * a.ndim, dtype=object)
+                out.reshape(-1)[0] = r
+                return out
+            return r
+        if not isinstance(axis, (int, np.integer)):
+            raise TraceUnsupported("a reduction of symbolic values over several axes")
+        ax = int(axis) % a.ndim
+        moved = np.moveaxis(a, ax, -1)
+        rows = moved.reshape(-1, moved.shape[-1])
+        out = np.empty(rows.shape[0], dtype=object)
+        for k in range(rows.shape[0]):
+            out[k] = f(list(rows[k]))
+        out = out.reshape(moved.shape[:-1])
+        if keepdims:
+            out = np.expand_dims(out, ax)
+        return out if out.ndim else out.item()
 
-    def amax(a, axis=None, *args, **kw):
-        if axis is not None or args or kw or not _has_sym(a):
-            return o_amax(a, axis, *args, **kw)
-        return sym_max(list(np.asarray(a, dtype=object).reshape(-1)))
+    def reducer(orig, f):
+        def g(a, axis=None, *args, **kw):
+            keep = kw.pop("keepdims", False) if set(kw) <= {"keepdims"} else None
+            if args or kw or keep is None or not _has_sym(a):
+                if keep:
+                    kw["keepdims"] = keep
+                return orig(a, axis, *args, **kw)
+            return reduce(a, axis, keep, f)
+        return g
+    amin, amax = reducer(o_amin, sym_min), reducer(o_amax, sym_max)
+    o_any, o_all, o_count = np.any, np.all, np.count_nonzero
+
+    def count_nonzero(a, axis=None, **kw):
+        if kw or not _has_sym(a):
+            return o_count(a, axis, **kw)
+        return reduce(a, axis, False, lambda xs: sum(Sym(_Ctx.graph.as_float(_truthy(x))) for x in xs))
 
     def where(c, *rest):
         if len(rest) != 2 or not _has_sym(c):
@@ -1078,7 +1187,8 @@ def _numpy_patches():
                 return x if t else y
             return _select_any(t, x, y)
         return _elementwise(pick, c, rest[0], rest[1])
-    out = {"maximum": maximum, "minimum": minimum, "clip": clip, "amin": amin, "amax": amax, "min": amin, "max": amax, "where": where}
+    out = {"maximum": maximum, "minimum": minimum, "clip": clip, "amin": amin, "amax": amax, "min": amin, "max": amax, "where": where,
+           "any": reducer(o_any, sym_any), "all": reducer(o_all, sym_all), "count_nonzero": count_nonzero}
 
     # ---- elementwise functions: NumPy's object loops call a METHOD of each element (x.sqrt()), which the plain Python floats that
     # share an array with symbolic values do not have; np.sign orders its argument against 0 (one fork per element)
@@ -2023,11 +2133,13 @@ def _emit(roots, lines, names, shared=None):
         elif op in ("lt", "le"):
             # `np.sqrt(np.sum(np.square(d))) < r`, the reference's contact test (simple_tag.py:69-73): decided as NumPy's float32
             # rounding sequence would (sqrt_lt: exact, without the correctly rounded sqrt outside a 1e-6 band around r)
-            if op == "lt" and a[0].op == "sqrt":
+            # (a square root that traced_shared computed is read through S: its argument does not exist here)
+            own = [x.op == "sqrt" and x.uid not in stop for x in a]
+            if op == "lt" and own[0]:
                 e = "sqrt_lt(%s, %s)" % (ref(a[0].args[0]), ref(a[1]))
-            elif a[0].op == "sqrt" or a[1].op == "sqrt":
-                l = "sqrtf(%s)" % ref(a[0].args[0]) if a[0].op == "sqrt" else ref(a[0])
-                r = "sqrtf(%s)" % ref(a[1].args[0]) if a[1].op == "sqrt" else ref(a[1])
+            elif own[0] or own[1]:
+                l = "sqrtf(%s)" % ref(a[0].args[0]) if own[0] else ref(a[0])
+                r = "sqrtf(%s)" % ref(a[1].args[0]) if own[1] else ref(a[1])
                 e = "%s %s %s" % (l, "<" if op == "lt" else "<=", r)
             else:
                 e = "%s %s %s" % (ref(a[0]), "<" if op == "lt" else "<=", ref(a[1]))

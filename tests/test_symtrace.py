@@ -201,15 +201,16 @@ def test_tracing_leaves_numpy_random_and_the_files_namespace_as_they_were():
     assert (np.random.uniform, np.random.choice) == fns[:2]
 
 
-@pytest.mark.parametrize("name", ["herd", "relay", "convoy", "survey"])
+@pytest.mark.parametrize("name", ["herd", "relay", "convoy", "survey", "mesh"])
 def test_fixture_files_trace_and_reproduce_their_own_callbacks(name):
     sc = mpe.scenarios.load(os.path.join(FIXTURES, name + ".py")).Scenario()
     ts = refstyle.trace_ref_scenario(sc, cache=False)
-    assert ts.t.verified == 0.0
-    assert symtrace.verify(sc, ts.t, worlds=300, seed=7) == 0.0
+    ulp = 1e-15 if name == "mesh" else 0.0          # (np.linalg.norm of a matrix along an axis sums in NumPy's own order: one ulp)
+    assert ts.t.verified <= ulp
+    assert symtrace.verify(sc, ts.t, worlds=300, seed=7) <= ulp
     # every coordinate a uniform draw of its own: restarts can be drawn on the device -- relay / convoy as World.reset_uniform's
     # placement, herd (agents on [-0.8, 0.8)^2) in per-entity boxes
-    assert ts.device_reset and ts.landmark_range == {"herd": 1.0, "survey": 0.8}.get(name, 0.9)
+    assert ts.device_reset and ts.landmark_range == {"herd": 1.0, "survey": 0.8, "mesh": 1.0}.get(name, 0.9)
     assert (ts.reset_boxes(None) is None) == (name != "herd")
     if name == "herd":
         assert ts.reset_boxes(None)[0] == (-0.8, 0.8, -0.8, 0.8) and ts.reset_boxes(None)[3] == (-1.0, 1.0, -1.0, 1.0)
@@ -419,10 +420,13 @@ class Scenario(BaseScenario):
             bonus = 0.25
         else:
             bonus = 0.0
-        if agent.state.p_pos[1] > 0.3:      # a name that exists on ONE side only: cannot be merged, this `if` forks
+        if agent.state.p_pos[1] > 0.3:      # a name only this branch creates: merged (it keeps its value on the other side)
             extra = 1.0
             rew += extra
-        return rew + bonus - self.band(abs(agent.state.p_pos[1]))
+        label = None
+        if agent.state.p_pos[0] > 0.95:     # a string or None: nothing to select between, this `if` forks
+            label = "edge"
+        return rew + bonus - self.band(abs(agent.state.p_pos[1])) + (0.125 if label else 0.0)
 
     def observation(self, agent, world):
         seen, flags = [], [np.array([-1.0]), np.array([-1.0])]
@@ -452,6 +456,88 @@ def test_value_only_control_flow_is_predicated_not_forked(tmp_path, n_agents):
             symtrace.trace(sc, predicate=False)
 
 
+_VECTOR_FILE = '''
+import numpy as np
+from multiagent.core import World, Agent, Landmark
+from multiagent.scenario import BaseScenario
+
+
+class Scenario(BaseScenario):
+    """Written by somebody who thinks in arrays: distance matrices, comparisons of whole arrays, reductions along an axis."""
+    def make_world(self):
+        world = World()
+        world.agents = [Agent() for _ in range(N_AGENTS)]
+        for i, a in enumerate(world.agents):
+            a.name, a.silent, a.size = "agent %d" % i, True, 0.08
+        world.landmarks = [Landmark() for _ in range(N_AGENTS)]
+        for l in world.landmarks:
+            l.movable, l.collide, l.size = False, False, 0.1
+        self.reset_world(world)
+        return world
+
+    def reset_world(self, world):
+        for e in world.agents + world.landmarks:
+            e.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            e.state.p_vel = np.zeros(world.dim_p)
+        for a in world.agents:
+            a.state.c = np.zeros(world.dim_c)
+
+    def zone(self, p):                      # nested early returns
+        if abs(p[0]) < 0.5:
+            if abs(p[1]) < 0.5:
+                return 2.0
+            return 1.0
+        elif abs(p[0]) < 0.8:
+            return 0.5
+        else:
+            return 0.0
+
+    def reward(self, agent, world):
+        X = np.array([a.state.p_pos for a in world.agents])
+        Y = np.array([l.state.p_pos for l in world.landmarks])
+        D = np.sqrt(((X[:, None, :] - Y[None, :, :]) ** 2).sum(-1))          # [agents, landmarks]
+        rew = -D.min(axis=0).sum()                                           # the nearest agent of every landmark
+        rew += 0.1 * (D < 0.2).sum() + 0.05 * np.count_nonzero(D.min(axis=1) < 0.1)
+        if (D.min(axis=0) < 0.15).all():
+            rew += 5.0
+        if np.any(np.abs(X) > 0.95):
+            rew -= 1.0
+        for a in world.agents:
+            if a is agent:
+                continue
+            gap = np.linalg.norm(a.state.p_pos - agent.state.p_pos)
+            if gap > 0.5:
+                continue
+            rew -= 0.5 - gap
+        if -0.25 < agent.state.p_pos[0] < 0.25:
+            rew += 0.01
+        return rew + self.zone(agent.state.p_pos) * 0.01
+
+    def observation(self, agent, world):
+        Y = np.array([l.state.p_pos for l in world.landmarks]) - agent.state.p_pos
+        near = np.linalg.norm(Y, axis=1) < 0.6
+        return np.concatenate([agent.state.p_vel, agent.state.p_pos, (Y * near[:, None]).reshape(-1), Y.max(axis=0), np.clip(Y, -0.5, 0.5).min(axis=0)])
+'''
+
+
+@pytest.mark.parametrize("n_agents", [3, 8])
+def test_array_comparisons_axis_reductions_continue_and_nested_returns_do_not_fork(tmp_path, n_agents):
+    """`D < 0.2` on an array (NumPy's own `<` stores bools: one fork per element), `D.min(axis=0)` / `.all()` / `.any()` as
+    METHODS, `if T: continue`, nested early returns, `a < x < b`: predicated in the twin -- one path whatever the team size; the
+    forking trace of the same file is refused already at N = 3 (more than 8192 paths)."""
+    path = tmp_path / ("vector_%d.py" % n_agents)
+    path.write_text(_VECTOR_FILE.replace("N_AGENTS", str(n_agents)))
+    sc = mpe.scenarios.load(str(path)).Scenario()
+    t = symtrace.trace(sc)
+    assert t.predicated and t.paths["obs"] == [1] * n_agents and t.paths["rew"] == [1] * n_agents
+    assert symtrace.verify(sc, t, worlds=200) <= 1e-15
+    with pytest.raises(symtrace.TraceUnsupported, match="control-flow paths"):      # (2^9 for `D < 0.2` alone at N = 3)
+        symtrace.trace(sc, predicate=False)
+    if n_agents == 8:
+        ts = refstyle.trace_ref_scenario(sc, cache=False)          # ... and it fits the kernel: the shared reward once per world
+        assert ts.t.n_shared >= 2 and len(ts.row_source(None).splitlines()) < 6000
+
+
 def test_a_team_too_large_for_straight_line_code_is_refused_with_the_reason(tmp_path, monkeypatch):
     """Every agent's functions spell out their whole graph: N^3 statements for a reward that visits every agent-landmark pair.
     Past MPE_TRACE_MAX_STATEMENTS the file stays on the host path (the trace itself is instant and exact)."""
@@ -468,15 +554,16 @@ def test_a_team_too_large_for_straight_line_code_is_refused_with_the_reason(tmp_
 
 
 def test_the_fixtures_and_committed_traces_hardly_fork():
-    for name in ("herd", "relay", "convoy", "survey"):
+    for name in ("herd", "relay", "convoy", "survey", "mesh"):
         sc = mpe.scenarios.load(os.path.join(FIXTURES, name + ".py")).Scenario()
         t = symtrace.trace(sc)
         assert t.predicated and max(t.paths["obs"] + t.paths["rew"]) == 1, (name, t.paths)
     for name in NINE:
         with open(os.path.join(GOLDEN, "traced_%s.json" % name)) as fh:
             paths = json.load(fh)["paths"]
-        # (simple_crypto compares utterances element by element through NumPy's `==` and `continue`s: that still forks)
-        assert max(paths["obs"] + paths["rew"]) == (256 if name == "simple_crypto" else 1), (name, paths)
+        # (simple_crypto.py:104-113 -- `if (a.state.c == np.zeros(dim_c)).all(): continue / else:` -- forked 256 ways before array
+        #  comparisons, `.all()` and `continue` were predicated)
+        assert max(paths["obs"] + paths["rew"]) == 1, (name, paths)
 
 
 def test_numpy_idioms_of_user_scenarios_trace_without_forks():
@@ -603,7 +690,7 @@ def _host_run_generated(tr, P, V, Cw, K, tmp_path, tag):
     return [out[:, off[i]:off[i + 1]] for i in range(tr.A)], out[:, off[-1]:off[-1] + tr.A], out[:, off[-1] + tr.A:]
 
 
-@pytest.mark.parametrize("name", ["convoy", "relay", "survey", "simple_tag", "simple_world_comm", "simple_crypto", "nav8"])
+@pytest.mark.parametrize("name", ["convoy", "relay", "survey", "simple_tag", "simple_world_comm", "simple_crypto", "nav8", "vector8"])
 def test_generated_code_on_the_host_against_the_numpy_evaluation(name, tmp_path):
     """The code GENERATOR without a GPU: traced_obs / traced_shared / traced_rew as symtrace.hip_source writes them, compiled with
     g++ (plain-C++ stand-ins for the device intrinsics) and run on random worlds, against the fp64 NumPy evaluation of the same
@@ -618,6 +705,10 @@ def test_generated_code_on_the_host_against_the_numpy_evaluation(name, tmp_path)
             "        rew = 0\n        for l in world.landmarks:\n            rew -= min(np.linalg.norm(a.state.p_pos - l.state.p_pos) for a in world.agents)\n"
             "        for other in world.agents:"))
         tr = symtrace.trace(mpe.scenarios.load(str(path)).Scenario())
+    elif name == "vector8":          # (comparisons of square roots that the shared phase computed)
+        path = tmp_path / "vector8.py"
+        path.write_text(_VECTOR_FILE.replace("N_AGENTS", "8"))
+        tr = symtrace.trace(mpe.scenarios.load(str(path)).Scenario())
     else:
         with open(os.path.join(GOLDEN, "traced_%s.json" % name)) as fh:
             tr = symtrace.from_dict(json.load(fh))
@@ -627,7 +718,7 @@ def test_generated_code_on_the_host_against_the_numpy_evaluation(name, tmp_path)
     P, V, Cw = P.astype(np.float32).astype(np.float64), V.astype(np.float32).astype(np.float64), Cw.astype(np.float32).astype(np.float64)
     K = np.stack([rs.randint(0, n, B) for n in tr.pops], axis=1) if tr.pops else np.zeros((B, 0), np.int64)
     rows, rew, _ = _host_run_generated(tr, P, V, Cw, K, tmp_path, name)
-    if name == "nav8":
+    if name in ("nav8", "vector8"):
         assert tr.n_shared >= 2                                          # the shared phase is part of what ran
     roots = [n for row in tr.obs for n in row] + list(tr.rew)
     vals = symtrace.evaluate(roots, B, P=P, V=V, Cw=Cw, K=K)
