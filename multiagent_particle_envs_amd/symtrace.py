@@ -398,7 +398,48 @@ def sym_max(*args, **kw):
     return _minmax("max", max, args, kw)
 
 
+def first_extreme(xs, op):
+    """The index of the first smallest (op "min") / largest element of `xs`, which hold symbolic values: ONE decision per
+    candidate -- `x_k` beats everything before it strictly and everything after it weakly -- i.e. N paths for N elements, where
+    NumPy's / Python's running comparison would fork 2^(N-1) ways."""
+    xs = list(xs)
+    for k in range(len(xs) - 1):
+        if op == "min":
+            c = sym_all([xs[k] < xs[j] for j in range(k)] + [xs[k] <= xs[j] for j in range(k + 1, len(xs))])
+        else:
+            c = sym_all([xs[k] > xs[j] for j in range(k)] + [xs[k] >= xs[j] for j in range(k + 1, len(xs))])
+        if c:          # (forks)
+            return k
+    return len(xs) - 1
+
+
+def sorted_values(xs):
+    """`xs` (symbolic values among them) in ascending order WITHOUT a decision: a network of compare-exchanges (min, max) --
+    N (N - 1) / 2 of them; the VALUES of a sort do not depend on how ties are broken."""
+    xs = [x if isinstance(x, Sym) else Sym(_lift(x)) for x in xs]
+    n = len(xs)
+    for rnd in range(n):                              # odd-even transposition sort
+        for k in range(rnd % 2, n - 1, 2):
+            a, b = xs[k], xs[k + 1]
+            xs[k], xs[k + 1] = sym_min(a, b), sym_max(a, b)
+    return xs
+
+
+def sym_sorted(it, key=None, reverse=False):
+    items = list(it)
+    if key is None and any(isinstance(x, (Sym, SymBool)) for x in items):
+        out = sorted_values(items)
+        return out[::-1] if reverse else out
+    return sorted(items, key=key, reverse=reverse)          # (objects by a symbolic key: a genuine N!-way decision -- forks)
+
+
 def _minmax(op, builtin, args, kw):
+    if set(kw) == {"key"} and len(args) == 1:          # min(world.landmarks, key=lambda l: dist(agent, l)): the OBJECT whose key is smallest
+        items = list(args[0])
+        keys = [kw["key"](x) for x in items]
+        if items and any(isinstance(k, (Sym, SymBool)) for k in keys):
+            return items[first_extreme(keys, op)]
+        return builtin(items, key=lambda x, _k=dict((id(x), k) for x, k in zip(items, keys)): _k[id(x)]) if items else builtin(items, **kw)
     if kw:
         return builtin(*args, **kw)
     items = list(args[0]) if len(args) == 1 else list(args)
@@ -479,7 +520,8 @@ def sym_round(x, ndigits=None):
     return round(x) if ndigits is None else round(x, ndigits)
 
 
-_INJECTED = {"min": sym_min, "max": sym_max, "any": sym_any, "all": sym_all, "float": sym_float, "int": sym_int, "round": sym_round}
+_INJECTED = {"min": sym_min, "max": sym_max, "any": sym_any, "all": sym_all, "float": sym_float, "int": sym_int, "round": sym_round,
+             "sorted": sym_sorted}
 
 
 # ---- predication: `if`s that only assign, conditional expressions, early returns and and / or / not WITHOUT forking ---------------
@@ -619,6 +661,14 @@ def _p_cmp(op, a, b):
 def _p_method(name, obj, *args, **kw):
     """`x.min(axis=0)`, `x.any()`, `x.clip(lo, hi)`: the METHODS of an array that holds symbolic values answered by the functions
     np.min / np.any / np.clip as they are while a file is traced (_numpy_patches); any other object: its own method."""
+    if name == "sort":          # in place: a list of numbers (`dists.sort()`), an array along its last axis
+        if type(obj) is list and not args and set(kw) <= {"reverse"} and _has_sym(obj):
+            obj[:] = sym_sorted(obj, reverse=kw.get("reverse", False))
+            return None
+        if isinstance(obj, np.ndarray) and obj.dtype == object and not args and not kw and _has_sym(obj):
+            obj[...] = np.sort(obj)
+            return None
+        return obj.sort(*args, **kw)
     if isinstance(obj, np.ndarray) and obj.dtype == object and _has_sym(obj):
         return getattr(np, name)(obj, *args, **kw)
     return getattr(obj, name)(*args, **kw)
@@ -731,7 +781,7 @@ def _predicate_tree(tree):
 
         def visit_Call(self, node):
             self.generic_visit(node)
-            if isinstance(node.func, ast.Attribute) and node.func.attr in ("min", "max", "any", "all", "clip") and \
+            if isinstance(node.func, ast.Attribute) and node.func.attr in ("min", "max", "any", "all", "clip", "argmin", "argmax", "sort") and \
                     not any(isinstance(a, ast.Starred) for a in node.args) and not any(k.arg is None for k in node.keywords):
                 return ast.Call(func=ast.Name(id="_mpe_method", ctx=ast.Load()),
                                 args=[ast.Constant(value=node.func.attr), node.func.value] + list(node.args), keywords=list(node.keywords))
@@ -1173,6 +1223,34 @@ def _numpy_patches():
     amin, amax = reducer(o_amin, sym_min), reducer(o_amax, sym_max)
     o_any, o_all, o_count = np.any, np.all, np.count_nonzero
 
+    o_sort, o_argsort = np.sort, np.argsort
+
+    def sort(a, axis=-1, *args, **kw):
+        if args or kw or not _has_sym(a):
+            return o_sort(a, axis, *args, **kw)
+        a = np.asarray(a, dtype=object)
+        if axis is None:
+            a, axis = a.reshape(-1), 0
+        moved = np.moveaxis(a, axis, -1)
+        rows = moved.reshape(-1, moved.shape[-1])
+        out = np.empty(rows.shape, dtype=object)
+        for k in range(rows.shape[0]):
+            out[k, :] = sorted_values(list(rows[k]))
+        return np.moveaxis(out.reshape(moved.shape), -1, axis)
+
+    def argsort(a, axis=-1, *args, **kw):
+        if args or kw or not _has_sym(a) or np.ndim(a) != 1:
+            return o_argsort(a, axis, *args, **kw)
+        xs = list(np.asarray(a, dtype=object))
+        return np.array(sorted(range(len(xs)), key=lambda i: xs[i]), dtype=np.int64)          # (the ORDER is a decision: forks)
+
+    def arg_extreme(orig, op):
+        def g(a, axis=None, *args, **kw):
+            if axis is not None or args or kw or not _has_sym(a):
+                return orig(a, axis, *args, **kw)
+            return first_extreme(np.asarray(a, dtype=object).reshape(-1), op)
+        return g
+
     def count_nonzero(a, axis=None, **kw):
         if kw or not _has_sym(a):
             return o_count(a, axis, **kw)
@@ -1188,7 +1266,8 @@ def _numpy_patches():
             return _select_any(t, x, y)
         return _elementwise(pick, c, rest[0], rest[1])
     out = {"maximum": maximum, "minimum": minimum, "clip": clip, "amin": amin, "amax": amax, "min": amin, "max": amax, "where": where,
-           "any": reducer(o_any, sym_any), "all": reducer(o_all, sym_all), "count_nonzero": count_nonzero}
+           "any": reducer(o_any, sym_any), "all": reducer(o_all, sym_all), "count_nonzero": count_nonzero,
+           "argmin": arg_extreme(np.argmin, "min"), "argmax": arg_extreme(np.argmax, "max"), "sort": sort, "argsort": argsort}
 
     # ---- elementwise functions: NumPy's object loops call a METHOD of each element (x.sqrt()), which the plain Python floats that
     # share an array with symbolic values do not have; np.sign orders its argument against 0 (one fork per element)

@@ -538,6 +538,60 @@ def test_array_comparisons_axis_reductions_continue_and_nested_returns_do_not_fo
         assert ts.t.n_shared >= 2 and len(ts.row_source(None).splitlines()) < 6000
 
 
+_NEAREST_FILE = '''
+import numpy as np
+from multiagent.core import World, Agent, Landmark
+from multiagent.scenario import BaseScenario
+
+
+class Scenario(BaseScenario):
+    def make_world(self):
+        world = World()
+        world.agents = [Agent() for _ in range(3)]
+        for i, a in enumerate(world.agents):
+            a.name, a.silent = "agent %d" % i, True
+        world.landmarks = [Landmark() for _ in range(7)]
+        for l in world.landmarks:
+            l.movable, l.collide = False, False
+        self.reset_world(world)
+        return world
+
+    def reset_world(self, world):
+        for e in world.agents + world.landmarks:
+            e.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            e.state.p_vel = np.zeros(world.dim_p)
+        for a in world.agents:
+            a.state.c = np.zeros(world.dim_c)
+
+    def reward(self, agent, world):
+        target = min(world.landmarks, key=lambda l: np.sum(np.square(l.state.p_pos - agent.state.p_pos)))      # the OBJECT
+        return -np.linalg.norm(target.state.p_pos - agent.state.p_pos)
+
+    def observation(self, agent, world):
+        d = [np.linalg.norm(l.state.p_pos - agent.state.p_pos) for l in world.landmarks]
+        k = int(np.argmin(d))                                                   # an index
+        ranked = sorted(d)                                                      # values in order: no decision at all
+        others = [np.linalg.norm(a.state.p_pos - agent.state.p_pos) for a in world.agents if a is not agent]
+        others.sort(reverse=True)
+        return np.concatenate([agent.state.p_pos, world.landmarks[k].state.p_pos - agent.state.p_pos, ranked[:3], np.sort(np.array(d))[-2:], others])
+'''
+
+
+def test_nearest_of_n_is_n_paths_and_sorted_values_need_no_decision(tmp_path):
+    """np.argmin / `min(objects, key=...)`: which element is smallest is a decision with N outcomes -- N paths (one test per candidate),
+    where the running comparison of NumPy / Python forks 2^(N-1) ways; the VALUES of sorted() / np.sort / list.sort() come out of a
+    network of min / max pairs: no decision."""
+    path = tmp_path / "nearest.py"
+    path.write_text(_NEAREST_FILE)
+    sc = mpe.scenarios.load(str(path)).Scenario()
+    t = symtrace.trace(sc)
+    assert t.predicated and t.paths["obs"] == [7] * 3 and t.paths["rew"] == [7] * 3
+    assert symtrace.verify(sc, t, worlds=300) <= 1e-15
+    f = symtrace.trace(sc, predicate=False)          # (without the twin: list.sort() is Python's own -- it forks; the functions do not)
+    assert f.paths["rew"] == [7] * 3 and f.paths["obs"] == [14] * 3 and symtrace.verify(sc, f, worlds=100) <= 1e-15
+    assert sorted([3, 1, 2]) == [1, 2, 3] and np.argmin([3, 1, 2]) == 1
+
+
 def test_a_team_too_large_for_straight_line_code_is_refused_with_the_reason(tmp_path, monkeypatch):
     """Every agent's functions spell out their whole graph: N^3 statements for a reward that visits every agent-landmark pair.
     Past MPE_TRACE_MAX_STATEMENTS the file stays on the host path (the trace itself is instant and exact)."""
