@@ -1085,6 +1085,15 @@ class _Recorder(object):
         out[:] = vals
         return out.reshape(size)
 
+    # rand / random / random_sample: the [0, 1) draws uniform() itself scales -- the same stream, value for value
+    def random_sample(self, size=None):
+        return self.uniform(0.0, 1.0, size)
+
+    def rand(self, *dims):
+        return self.uniform(0.0, 1.0, dims if dims else None)
+
+    random = ranf = sample = random_sample
+
     def choice(self, a, size=None, replace=True, p=None):
         if size is not None or p is not None:
             raise TraceUnsupported("np.random.choice with size / p")
@@ -1117,7 +1126,7 @@ class _NoDraws(_Recorder):
     def _refuse(self, *a, **k):
         raise TraceUnsupported("a callback other than reset_world draws random numbers")
 
-    uniform = choice = randint = _refuse
+    uniform = choice = randint = random_sample = rand = random = ranf = sample = _refuse
 
 
 class _Replayer(object):
@@ -1133,6 +1142,14 @@ class _Replayer(object):
         self.iu += n
         v = low + (high - low) * r
         return float(v[0]) if size is None else v.reshape(size)
+
+    def random_sample(self, size=None):
+        return self.uniform(0.0, 1.0, size)
+
+    def rand(self, *dims):
+        return self.uniform(0.0, 1.0, dims if dims else None)
+
+    random = ranf = sample = random_sample
 
     def choice(self, a, size=None, replace=True, p=None):
         pop = list(range(a)) if isinstance(a, (int, np.integer)) else list(a)
@@ -1373,14 +1390,15 @@ def patched_math():
             setattr(math, name, f)
 
 
-_RANDOM_NAMES = ("uniform", "choice", "randint")
-_RANDOM_REFUSED = ("rand", "randn", "random", "random_sample", "normal", "shuffle", "permutation", "sample", "standard_normal",
+_RANDOM_NAMES = ("uniform", "choice", "randint", "rand", "random", "random_sample", "ranf", "sample")
+_RANDOM_REFUSED = ("randn", "normal", "shuffle", "permutation", "standard_normal",
                    "exponential", "beta", "gamma", "seed", "binomial", "poisson")
 
 
 @contextlib.contextmanager
 def patched_random(impl):
-    """np.random.{uniform, choice, randint} answered by `impl` (a _Recorder / _Replayer); everything else that draws raises."""
+    """np.random.{uniform, rand, random, random_sample, choice, randint} answered by `impl` (a _Recorder / _Replayer); everything
+    else that draws raises."""
     saved = {}
     for name in _RANDOM_NAMES + _RANDOM_REFUSED:
         if hasattr(np.random, name):

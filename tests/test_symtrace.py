@@ -592,6 +592,36 @@ def test_nearest_of_n_is_n_paths_and_sorted_values_need_no_decision(tmp_path):
     assert sorted([3, 1, 2]) == [1, 2, 3] and np.argmin([3, 1, 2]) == 1
 
 
+def test_rand_and_random_sample_are_the_draws_uniform_scales():
+    """`np.random.rand(2) * 2 - 1`, `np.random.random()`: [0, 1) draws of the same stream uniform() takes its numbers from -- traced as
+    U inputs, and a seeded reset replays them value for value (np.random.seed(s); reset_world(world) of the file itself)."""
+    class S(_Base):
+        def reset_world(self, world):
+            for a in world.agents:
+                a.state.p_pos = np.random.rand(world.dim_p) * 2.0 - 1.0
+                a.state.p_vel = np.zeros(world.dim_p)
+                a.state.c = np.zeros(world.dim_c)
+            for l in world.landmarks:
+                l.state.p_pos = np.array([np.random.random() - 0.5, np.random.uniform(-0.3, 0.3)]) + np.random.random_sample(2) * 0.1
+                l.state.p_vel = np.zeros(world.dim_p)
+    sc = S()
+    t = symtrace.trace(sc)
+    assert symtrace.verify(sc, t, worlds=100) <= 1e-15
+    assert [d[0] for d in t.draws] == ["uniform"] * len(t.draws) and t.n_u == 2 * len(sc.make_world().agents) + 4 * len(sc.make_world().landmarks)
+    world = sc.make_world()
+    flat = [n for e in t.reset_pos for n in e]
+    for seed in (3, 77):
+        np.random.seed(seed)
+        sc.reset_world(world)
+        want = np.concatenate([e.state.p_pos for e in world.agents + world.landmarks])
+        rs, U, iu = np.random.RandomState(seed), np.zeros((1, t.n_u)), 0
+        for d in t.draws:          # (as refstyle.TracedRefScenario.reset_world replays a seed)
+            U[0, iu:iu + d[3]] = rs.random_sample(d[3])
+            iu += d[3]
+        got = np.array([v[0] for v in symtrace.evaluate(flat, 1, U=U, K=np.zeros((1, 0), np.int64))])
+        assert np.array_equal(got, want)
+
+
 def test_a_team_too_large_for_straight_line_code_is_refused_with_the_reason(tmp_path, monkeypatch):
     """Every agent's functions spell out their whole graph: N^3 statements for a reward that visits every agent-landmark pair.
     Past MPE_TRACE_MAX_STATEMENTS the file stays on the host path (the trace itself is instant and exact)."""
