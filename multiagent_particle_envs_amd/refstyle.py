@@ -349,17 +349,28 @@ class TracedRefScenario(object):
         device: as World.reset_uniform's placement (agents on [-1,1)^2, every landmark on [-r,r)^2 with one r: boxes None -- all
         nine reference files) or in per-entity boxes [(lo_x, hi_x, lo_y, hi_y)] (a restricted spawn area ...).  Anything else
         (positions that depend on a pick or on each other): (1.0, False, None) -- evaluated with torch ops at reset time."""
+        from . import symtrace
         t = self.t
         used, boxes = set(), []
         for e in range(t.E):
             box = []
             for c in range(2):
                 n = t.reset_pos[e][c]
-                # lo + (hi - lo) * U
-                if not (n.op == "add" and n.args[0].op == "const" and n.args[1].op == "mul" and n.args[1].args[0].op == "const" and
-                        n.args[1].args[1].op == "U"):
-                    return 1.0, False, None
-                lo, span, u = n.args[0].value, n.args[1].args[0].value, n.args[1].args[1].value[0]
+                # lo + (hi - lo) * U, as np.random.uniform(lo, hi) is traced ...
+                if n.op == "add" and n.args[0].op == "const" and n.args[1].op == "mul" and n.args[1].args[0].op == "const" and \
+                        n.args[1].args[1].op == "U":
+                    lo, span, u = n.args[0].value, n.args[1].args[0].value, n.args[1].args[1].value[0]
+                else:      # ... or any other way of writing an affine function of ONE draw (`np.random.rand(2) * 2 - 1`, `0.5 - rand()`)
+                    us = [x for x in symtrace.topo([n]) if x.op in ("U", "K", "P", "V", "C")]
+                    if len(us) != 1 or us[0].op != "U":
+                        return 1.0, False, None
+                    u = us[0].value[0]
+                    probe = np.zeros((5, max(t.n_u, 1)))
+                    probe[:, u] = (0.0, 0.25, 0.5, 0.75, 1.0)
+                    f = symtrace.evaluate([n], 5, U=probe, K=np.zeros((5, len(t.pops)), np.int64))[0]
+                    if not np.all(np.isfinite(f)) or np.abs(f - (f[0] + (f[4] - f[0]) * probe[:, u])).max() > 1e-12 * max(1.0, np.abs(f).max()):
+                        return 1.0, False, None
+                    lo, span = float(min(f[0], f[4])), float(abs(f[4] - f[0]))      # (a falling line: the same distribution)
                 if u in used or span < 0:
                     return 1.0, False, None
                 used.add(u)

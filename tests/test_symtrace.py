@@ -620,6 +620,22 @@ def test_rand_and_random_sample_are_the_draws_uniform_scales():
             iu += d[3]
         got = np.array([v[0] for v in symtrace.evaluate(flat, 1, U=U, K=np.zeros((1, 0), np.int64))])
         assert np.array_equal(got, want)
+    # an affine function of ONE draw per coordinate, however it is written, is a box the device can draw restarts in; a coordinate
+    # that mixes two draws (the landmarks here) is not
+    ts = refstyle.TracedRefScenario(sc, t)
+    assert ts._uniform_pattern() == (1.0, False, None)
+
+    class Boxes(S):
+        def reset_world(self, world):
+            S.reset_world(self, world)
+            for k, l in enumerate(world.landmarks):
+                l.state.p_pos = np.array([0.5 - np.random.rand(), np.random.random() * 0.4 + 0.1 * k])
+    sc = Boxes()
+    t = symtrace.trace(sc)
+    assert symtrace.verify(sc, t, worlds=50) <= 1e-15
+    rng, dev, boxes = refstyle.TracedRefScenario(sc, t)._uniform_pattern()
+    assert dev and boxes is not None and boxes[0] == (-1.0, 1.0, -1.0, 1.0)
+    assert np.allclose(boxes[t.A], (-0.5, 0.5, 0.0, 0.4)) and np.allclose(boxes[t.A + 1], (-0.5, 0.5, 0.1, 0.5))
 
 
 def test_a_team_too_large_for_straight_line_code_is_refused_with_the_reason(tmp_path, monkeypatch):
