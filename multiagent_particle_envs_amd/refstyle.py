@@ -293,6 +293,8 @@ class TracedRefScenario(object):
                      % (self.landmark_range, self.landmark_range) if self._boxes is None else
                      "places every entity uniformly in a box of its own: restarts are drawn on the device, inside the step launch")
                     if self.device_reset else
+                    ("is not a formula of its draws (%s): the file's own reset_world runs on the host, once per world that restarts"
+                     % t.host_reset) if getattr(t, "host_reset", None) else
                     "is the file's own placement: evaluated with torch ops on the device for all worlds at once",
                     getattr(t, "verified", "not run")))
 
@@ -324,8 +326,9 @@ class TracedRefScenario(object):
         for b in np.linspace(0, B - 1, num=min(int(worlds), B)).astype(int):
             if margin[b] <= band:
                 continue
-            with symtrace.patched_random(symtrace._Replayer(np.zeros(max(t.n_u, 1)), picks[:, b])):
-                sc.reset_world(cw)
+            if not getattr(t, "host_reset", None):      # (the picks of world b in place; a host reset has none the callbacks could read)
+                with symtrace.patched_random(symtrace._Replayer(np.zeros(max(t.n_u, 1)), picks[:, b])):
+                    sc.reset_world(cw)
             for k, e in enumerate(list(cw.agents) + list(cw.landmarks)):
                 e.state.p_pos, e.state.p_vel = pos[b, k].astype(np.float64), vel[b, k].astype(np.float64)
             for i, a in enumerate(cw.agents):
@@ -351,6 +354,8 @@ class TracedRefScenario(object):
         (positions that depend on a pick or on each other): (1.0, False, None) -- evaluated with torch ops at reset time."""
         from . import symtrace
         t = self.t
+        if getattr(t, "host_reset", None):      # not a program at all: the file's own reset_world, per world, at reset time
+            return 1.0, False, None
         used, boxes = set(), []
         for e in range(t.E):
             box = []
@@ -424,6 +429,8 @@ class TracedRefScenario(object):
             self._merge_picks(world, idx, mask)
             return
         from . import symtrace
+        if getattr(t, "host_reset", None):
+            return self._host_reset(world, mask, seeds)
         flat = [n for e in t.reset_pos for n in e] + [n for e in t.reset_vel for n in e]
         if seeds is None and world.rng_mode == "device" and world.pos.is_cuda:
             # not reset_uniform's placement (a restricted spawn area, positions that depend on a pick ...): the traced reset
@@ -489,6 +496,47 @@ class TracedRefScenario(object):
             vel = np.where(m[:, None, None], vel, old_v)
         world.set_state(pos, vel)
         self._merge_picks(world, torch.as_tensor(K), mask)
+
+    def _host_reset(self, world, mask, seeds):
+        """reset_world of a file whose placement is not a formula of its draws (rejection sampling, shuffles, normal draws): the
+        file's OWN reset_world, run on the host on one shadow world, once per world that restarts -- np.random seeded per world
+        (`seeds`: the reference's `np.random.seed(s); env.reset()`; else from (env seed, episode, world)) --, the positions,
+        velocities and utterances it leaves uploaded in one copy.  Only resets pay for this; steps stay one launch."""
+        t, B, sc = self.t, world.batch_size, self.scenario
+        if sc is None:
+            raise _abi.MpeError("this trace's reset_world runs on the host (%s): it needs the scenario file, not only trace data" % t.host_reset)
+        m = np.ones(B, bool) if mask is None else torch.as_tensor(mask).cpu().numpy().astype(bool).reshape(-1)
+        pos, vel = (np.array(x, np.float64) for x in world.get_state(all_entities=True))
+        keep = world.rng_mode != "numpy"          # (numpy mode: the process-global stream is consumed, as the reference does)
+        state = np.random.get_state() if keep else None
+        try:
+            if getattr(self, "_shadow", None) is None:
+                self._shadow = sc.make_world()
+            cw = self._shadow
+            ents = list(cw.agents) + list(cw.landmarks)
+            utter = np.zeros((B, t.A, max(t.dim_c, 1)))
+            for b in np.flatnonzero(m):
+                if seeds is not None:
+                    np.random.seed(int(seeds[b]) & 0xFFFFFFFF)
+                elif keep:
+                    np.random.seed([int(world.seed) & 0x7FFFFFFF, int(world._episode) & 0x7FFFFFFF, (int(world.world_offset) + int(b)) & 0x7FFFFFFF])
+                sc.reset_world(cw)
+                for k, e in enumerate(ents):
+                    pos[b, k] = np.asarray(e.state.p_pos, np.float64).reshape(2)
+                    vel[b, k] = 0.0 if e.state.p_vel is None else np.asarray(e.state.p_vel, np.float64).reshape(2)
+                for i, a in enumerate(cw.agents):
+                    if t.dim_c and a.state.c is not None:
+                        utter[b, i, :t.dim_c] = np.asarray(a.state.c, np.float64).reshape(-1)[:t.dim_c]
+        finally:
+            if keep:
+                np.random.set_state(state)
+        world._episode += 1
+        world.set_state(pos, vel)
+        mt = torch.as_tensor(m, device=world.device)
+        for i, a in enumerate(world.agents):
+            if torch.is_tensor(a.state.c) and a.state.c.numel():
+                new = torch.as_tensor(utter[:, i, :a.state.c.shape[-1]], dtype=a.state.c.dtype, device=world.device)
+                a.state.c.copy_(torch.where(mt[:, None], new, a.state.c))
 
     # ---- the row program ------------------------------------------------------------------------------------------------------
     def row_source(self, world):

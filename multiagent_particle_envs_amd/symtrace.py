@@ -43,6 +43,7 @@ class TraceUnsupported(Exception):
 
 
 MAX_PATHS = 8192          # control-flow paths of ONE callback of one agent (every symbolic `if` can double them)
+MAX_DECISIONS = 4096      # symbolic decisions on ONE path
 _CMP = ("lt", "le", "eq", "ne")
 _BOOL_OPS = _CMP + ("not", "and", "or", "bconst")
 
@@ -954,9 +955,10 @@ class Tracer(object):
     lasts, then True; the conditions met and the answers given are the path.  `explore` flips the answers depth-first and
     merges the outcomes into select nodes."""
 
-    def __init__(self, graph, max_paths=None):
+    def __init__(self, graph, max_paths=None, max_decisions=None):
         self.g = graph
         self.max_paths = MAX_PATHS if max_paths is None else max_paths
+        self.max_decisions = MAX_DECISIONS if max_decisions is None else max_decisions
         self.paths = 0
 
     def decide(self, n):
@@ -965,6 +967,9 @@ class Tracer(object):
             n, neg = n.args[0], True
         d = self.memo.get(n)
         if d is None:
+            if len(self.decs) >= self.max_decisions:      # `while <state-dependent test>:` never ends when every new test is answered True
+                raise TraceUnsupported("more than %d state-dependent decisions on one path (a loop that runs while a state-dependent "
+                                       "condition holds?)" % self.max_decisions)
             d = self.prefix[len(self.decs)] if len(self.decs) < len(self.prefix) else True
             self.conds.append(n)
             self.decs.append(d)
@@ -1535,6 +1540,8 @@ def _flatten_info(raw, desc):
 
 
 class Traced(object):
+    host_reset = None          # why reset_world is not a traced program but the file's own Python, run per world (None: it is traced)
+
     """What tracing a reference-style scenario yields: per-agent graphs over the state + the reset program.
 
       obs[i]        list of Nodes: agent i's observation row, column by column
@@ -1576,7 +1583,7 @@ def to_dict(t):
             "draws": [list(d) for d in t.draws], "pops": list(t.pops), "n_u": t.n_u, "A": t.A, "E": t.E, "dim_c": t.dim_c,
             "info": None if getattr(t, "info", None) is None else [[n.uid for n in row] for row in t.info],
             "info_desc": getattr(t, "info_desc", None),
-            "predicated": bool(getattr(t, "predicated", False)),
+            "predicated": bool(getattr(t, "predicated", False)), "host_reset": getattr(t, "host_reset", None),
             "collaborative": bool(t.collaborative), "paths": t.paths, "enumerated": list(getattr(t, "enumerated", [])),
             "world": {k: getattr(w, k) for k in _WLD_KEYS},
             "discrete_action": getattr(w, "discrete_action", None),
@@ -1610,6 +1617,7 @@ def from_dict(d):
     t.pops, t.n_u, t.A, t.E, t.dim_c = list(d["pops"]), d["n_u"], d["A"], d["E"], d["dim_c"]
     t.collaborative, t.paths, t.enumerated = d["collaborative"], d["paths"], d["enumerated"]
     t.predicated = bool(d.get("predicated", False))
+    t.host_reset = d.get("host_reset")
     w = ccore.World()
     for k, v in d["world"].items():
         setattr(w, k, v)
@@ -1653,14 +1661,28 @@ def _trace_once(scenario, t, forced, want_done, max_paths, want_info=False):
         info_desc = [_describe_info(scenario.benchmark_data(a, world)) for a in agents]
     # ---- reset_world, symbolically ------------------------------------------------------------------------------------------
     rec = _Recorder(g, forced)
-    with patched_random(rec), injected_builtins(scenario):
-        _, conds, _ = Tracer(g, 1)._run(lambda: scenario.reset_world(world), [])
-    if conds:      # reset_world branches on what it drew: on a pick -> one trace per value of that pick; on anything else: not modelled
-        ks = sorted(n.value[0] for n in topo(conds[:1]) if n.op == "K")
-        if ks and "U" not in inputs_of(conds[:1]):
-            raise NeedConcretePick(ks[0])
-        raise TraceUnsupported("reset_world branches on a random number it drew")
-    out = {"draws": rec.draws, "pops": rec.pops, "n_u": rec.n_u}
+    host_reset = None
+    try:
+        with patched_random(rec), injected_builtins(scenario):
+            _, conds, _ = Tracer(g, 1, max_decisions=64)._run(lambda: scenario.reset_world(world), [])
+        if conds:      # reset_world branches on what it drew: on a pick -> one trace per value of that pick; on anything else: not modelled
+            ks = sorted(n.value[0] for n in topo(conds[:1]) if n.op == "K")
+            if ks and "U" not in inputs_of(conds[:1]):
+                raise NeedConcretePick(ks[0])
+            raise TraceUnsupported("reset_world branches on a random number it drew")
+    except NeedConcretePick:
+        raise
+    except Exception as e:
+        # A reset_world that is not a FORMULA of its draws -- rejection sampling (`while too_close: draw again`), shuffles, normal
+        # draws -- is no reason to give up the callbacks: it stays what it is, Python run per world at reset time (host_reset), and
+        # only observation / reward / done are traced.  Whatever it leaves outside the state vectors that the callbacks then read
+        # (a goal picked per world) makes the verification fail, and the file falls back as before.
+        if forced or _Ctx.need_pick is not None:
+            raise
+        host_reset = "%s: %s" % (type(e).__name__, e) if not isinstance(e, TraceUnsupported) else str(e)
+        rec = _Recorder(g, forced)
+        scenario.reset_world(world)          # (concretely: the world is whole again; _trace restores the caller's np.random stream)
+    out = {"draws": rec.draws, "pops": rec.pops, "n_u": rec.n_u, "host_reset": host_reset}
 
     def vec(v, n, what):
         if v is None:
@@ -1672,6 +1694,7 @@ def _trace_once(scenario, t, forced, want_done, max_paths, want_info=False):
     out["reset_pos"] = [x for k, e in enumerate(ents) for x in vec(e.state.p_pos, 2, "p_pos of %s" % (e.name or "entity %d" % k))]
     out["reset_vel"] = [x for e in ents for x in (vec(e.state.p_vel, 2, "p_vel") if e.state.p_vel is not None else [g.const(0.0)] * 2)]
     out["reset_c"] = [x for a in agents for x in (vec(a.state.c, dc, "state.c") if (dc and a.state.c is not None) else [g.const(0.0)] * dc)]
+    # (host_reset: the constants of ONE concrete reset -- placeholders, never evaluated)
     # ---- the state as inputs -------------------------------------------------------------------------------------------------
     for k, e in enumerate(ents):
         e.state.p_pos = _obj_vec([g.node("P", (), (k, 0)), g.node("P", (), (k, 1))])
@@ -1784,6 +1807,7 @@ def _trace(scenario, want_done=False, max_paths=None, want_info=False):
                 return [g.select(kn, [b[j] for b in branches]) for j in range(len(branches[0]))]
             return rec([], 0)
         t.draws, t.pops, t.n_u = first["draws"], first["pops"], first["n_u"]
+        t.host_reset = first.get("host_reset")
         A, E, dc = t.A, t.E, t.dim_c
         flat = merged("reset_pos")
         t.reset_pos = [flat[2 * e:2 * e + 2] for e in range(E)]
@@ -2058,11 +2082,19 @@ def verify(scenario, t, worlds=96, seed=0, tol=1e-9):
     if getattr(t, "info", None) is not None:
         info_eval = [evaluate(row, R, P=P, V=V, Cw=Cw, K=K, U=U) if row else [] for row in t.info]
     for r in range(R):
-        _concrete_reset(scenario, cw, U[r], K[r])
-        cmp("reset_world positions", [e.state.p_pos for e in ents], rp[r])
-        cmp("reset_world velocities", [np.zeros(2) if e.state.p_vel is None else e.state.p_vel for e in ents], rv[r])
-        if t.dim_c:
-            cmp("reset_world utterances", [np.zeros(t.dim_c) if a.state.c is None else a.state.c for a in agents], rc[r])
+        if getattr(t, "host_reset", None):      # the file's own reset_world, run as it is (what it hides from the state shows below)
+            rng_state = np.random.get_state()
+            try:
+                np.random.seed(int(rs.randint(0, 2 ** 31 - 1)))
+                scenario.reset_world(cw)
+            finally:
+                np.random.set_state(rng_state)
+        else:
+            _concrete_reset(scenario, cw, U[r], K[r])
+            cmp("reset_world positions", [e.state.p_pos for e in ents], rp[r])
+            cmp("reset_world velocities", [np.zeros(2) if e.state.p_vel is None else e.state.p_vel for e in ents], rv[r])
+            if t.dim_c:
+                cmp("reset_world utterances", [np.zeros(t.dim_c) if a.state.c is None else a.state.c for a in agents], rc[r])
         for k, e in enumerate(ents):
             e.state.p_pos = P[r, k].copy()
             e.state.p_vel = V[r, k].copy()

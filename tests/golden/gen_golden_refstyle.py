@@ -30,7 +30,7 @@ warnings.filterwarnings("ignore")
 from multiagent.environment import MultiAgentEnv  # noqa: E402  (the reference's env, environment.py:9)
 
 FIXTURES = os.path.join(os.path.dirname(HERE), "refstyle")
-NAMES = ("herd", "relay", "patrol", "convoy", "survey", "mesh")
+NAMES = ("herd", "relay", "patrol", "convoy", "survey", "mesh", "scatter")
 
 
 def load(name):

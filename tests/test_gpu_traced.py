@@ -137,7 +137,7 @@ def test_committed_traces_of_the_nine_reference_files_on_the_device(name, golden
                                             % name, "worlds": W, "steps": int(g["rew"].shape[0]), "max_scaled_err": worst})
 
 
-@pytest.mark.parametrize("name", ["herd", "relay", "convoy", "survey", "mesh"])
+@pytest.mark.parametrize("name", ["herd", "relay", "convoy", "survey", "mesh", "scatter"])
 def test_fixture_files_traced_against_reference_goldens_and_the_host_path(name, golden, record_parity):
     path = os.path.join(FIXTURES, name + ".py")
     g = golden("refstyle_" + name)

@@ -147,7 +147,7 @@ def test_loader_tells_the_two_contracts_apart():
         mpe.make_env(os.path.join(FIXTURES, "herd.py"), batch_size=2, device="cpu", num_agents=5)
 
 
-FIX = ["herd", "relay", "patrol", "convoy", "survey", "mesh"]
+FIX = ["herd", "relay", "patrol", "convoy", "survey", "mesh", "scatter"]
 
 
 def _info_checker(name, g, W):

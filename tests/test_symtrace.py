@@ -14,6 +14,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 import multiagent_particle_envs_amd as mpe
 from multiagent_particle_envs_amd import compat, refstyle, symtrace
@@ -214,6 +215,63 @@ def test_fixture_files_trace_and_reproduce_their_own_callbacks(name):
     assert (ts.reset_boxes(None) is None) == (name != "herd")
     if name == "herd":
         assert ts.reset_boxes(None)[0] == (-0.8, 0.8, -0.8, 0.8) and ts.reset_boxes(None)[3] == (-1.0, 1.0, -1.0, 1.0)
+
+
+def test_a_reset_world_that_is_not_a_formula_of_its_draws_runs_on_the_host_and_the_callbacks_are_still_traced():
+    """tests/refstyle/scatter.py places entities by rejection sampling (`while` the spot is taken: draw again) and draws normal
+    velocities: tracing reset_world would never end / is refused.  The trace keeps observation and reward (verified as always)
+    and marks reset_world as the file's own Python, run per restarting world with np.random seeded per world -- a seeded reset
+    is the reference's `np.random.seed(s); env.reset()` value for value."""
+    sc = mpe.scenarios.load(os.path.join(FIXTURES, "scatter.py")).Scenario()
+    np.random.seed(11)
+    before = np.random.get_state()[1].copy()
+    ts = refstyle.trace_ref_scenario(sc, cache=False)
+    t = ts.t
+    assert np.array_equal(np.random.get_state()[1], before)
+    assert t.host_reset and "state-dependent decisions" in t.host_reset and t.pops == [] and t.n_u == 0
+    assert t.verified <= 1e-15 and symtrace.verify(sc, t, worlds=150, seed=3) <= 1e-15
+    assert not ts.device_reset and ts.reset_boxes(None) is None and "runs on the host" in ts.report()
+    B = 16
+    w = ts.make_world(B, "cpu")
+    w.seed, w.rng_mode = 0, "device"
+    seeds = list(range(900, 900 + B))
+    ts.reset_world(w, None, seeds)
+    P, V = w.get_state(all_entities=True)
+    cw = sc.make_world()
+    for b, s in enumerate(seeds):
+        np.random.seed(s)
+        sc.reset_world(cw)
+        ents = cw.agents + cw.landmarks
+        assert np.abs(P[b] - np.array([e.state.p_pos for e in ents])).max() < 1e-6
+        assert np.abs(V[b] - np.array([e.state.p_vel for e in ents])).max() < 1e-6
+    gaps = np.linalg.norm(P[:, :, None, :] - P[:, None, :, :], axis=-1) + 10.0 * np.eye(P.shape[1])
+    assert gaps.min() >= 0.3 - 1e-6                                   # the file's own invariant: nobody spawns on anybody
+    # a masked restart touches only the masked worlds; without seeds the stream is (env seed, episode, world): reproducible, and the
+    # caller's np.random stream is left alone
+    mask = torch.zeros(B, dtype=torch.bool)
+    mask[3] = mask[7] = True
+    np.random.seed(11)
+    ts.reset_world(w, mask, None)
+    assert np.array_equal(np.random.get_state()[1], before)
+    P2, _ = w.get_state(all_entities=True)
+    changed = np.abs(P2 - P).max(axis=(1, 2)) > 0
+    assert changed.tolist() == mask.tolist()
+    # as data: the flag travels; a trace without its file cannot reset
+    t2 = symtrace.from_dict(json.loads(json.dumps(symtrace.to_dict(t))))
+    assert t2.host_reset == t.host_reset
+    with pytest.raises(RuntimeError, match="needs the scenario file"):
+        refstyle.TracedRefScenario(None, t2).reset_world(w, None, None)
+
+
+def test_a_loop_on_a_state_dependent_condition_in_a_callback_is_refused_not_run_forever():
+    class Halving(_Base):
+        def reward(self, agent, world):
+            d = abs(agent.state.p_pos[0]) + 1.0
+            while d > 0.1:
+                d = d * 0.5
+            return d
+    with pytest.raises(symtrace.TraceUnsupported, match="state-dependent decisions on one path"):
+        symtrace.trace(Halving())
 
 
 def test_patrol_stays_on_the_host_path_with_the_reason():
@@ -654,7 +712,7 @@ def test_a_team_too_large_for_straight_line_code_is_refused_with_the_reason(tmp_
 
 
 def test_the_fixtures_and_committed_traces_hardly_fork():
-    for name in ("herd", "relay", "convoy", "survey", "mesh"):
+    for name in ("herd", "relay", "convoy", "survey", "mesh", "scatter"):
         sc = mpe.scenarios.load(os.path.join(FIXTURES, name + ".py")).Scenario()
         t = symtrace.trace(sc)
         assert t.predicated and max(t.paths["obs"] + t.paths["rew"]) == 1, (name, t.paths)

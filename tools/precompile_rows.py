@@ -40,7 +40,7 @@ def test_programs():
         def __init__(self, ts):
             ip = refstyle._InfoProgram(ts, ts.make_world(4, "cpu"), compile=False)
             self._prog, self._desc = ip.prog, ip.desc
-    for name in ("herd", "relay", "convoy", "survey", "mesh"):
+    for name in ("herd", "relay", "convoy", "survey", "mesh", "scatter"):
         sc = scenarios.load(os.path.join(ROOT, "tests", "refstyle", name + ".py")).Scenario()
         for info in ((False, True) if hasattr(sc, "benchmark_data") else (False,)):
             ts = refstyle.trace_ref_scenario(sc, want_info=info)
