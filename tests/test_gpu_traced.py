@@ -321,6 +321,40 @@ def test_a_reset_world_that_is_not_a_box_per_entity_is_evaluated_on_the_device_a
         RandomRollout(refstyle.make_ref_env(Sides(), batch_size=64), episode_len=5)
 
 
+def test_a_reset_world_that_cannot_be_traced_runs_on_the_host_at_reset_time_while_steps_stay_one_launch():
+    """tests/refstyle/scatter.py: rejection sampling + normal draws in reset_world.  The env is traced (observation / reward in
+    the step kernel), restarts go through the file's own reset_world per finished world; the spawn invariant of the file (nobody
+    within 0.3 of anybody) holds after the first reset and after every automatic restart."""
+    path = os.path.join(FIXTURES, "scatter.py")
+    B = 512
+    env = mpe.make_env(path, batch_size=B, seed=4, max_episode_steps=3, auto_reset=True)
+    assert env.traced and env.scenario.t.host_reset and not env.scenario.device_reset and not env._episode_in_launch
+
+    def clear(pos):
+        gaps = np.linalg.norm(pos[:, :, None, :] - pos[:, None, :, :], axis=-1) + 10.0 * np.eye(pos.shape[1])
+        return gaps.min(axis=(1, 2))
+    env.reset()
+    p0, v0 = env.world.get_state(all_entities=True)
+    assert clear(p0).min() >= 0.3 - 1e-6 and 0.02 < np.abs(v0[:, :3]).mean() < 0.08 and np.all(v0[:, 3:] == 0)      # randn * 0.05
+    act = [torch.as_tensor(np.eye(5, dtype=np.float32)[np.full(B, 1 + i)]).cuda() for i in range(env.n)]
+    for t in range(1, 4):
+        obs, rew, done, _ = env.step(act)
+        assert bool(done[0].all()) == (t == 3)
+    p1, v1 = env.world.get_state(all_entities=True)
+    assert clear(p1).min() >= 0.3 - 1e-6 and (np.abs(p1 - p0).max(axis=(1, 2)) > 1e-3).mean() > 0.99          # restarted by ITS placement
+    worst, checked = env.scenario.spot_check(env, obs, rew, worlds=64)
+    assert worst <= TOL and checked >= 40
+    # the same seeds, the same worlds -- and another env seed, other worlds
+    again = mpe.make_env(path, batch_size=B, seed=4)
+    again.reset()
+    assert np.array_equal(again.world.get_state(all_entities=True)[0], p0)
+    other = mpe.make_env(path, batch_size=B, seed=5)
+    other.reset()
+    assert np.abs(other.world.get_state(all_entities=True)[0] - p0).max() > 0.1
+    with pytest.raises(_abi.MpeError, match="reset_uniform"):
+        RandomRollout(mpe.make_env(path, batch_size=64), episode_len=5)
+
+
 def test_a_traced_done_callback_ends_episodes_inside_the_step_launch():
     """A reference-style Scenario with a `done(agent, world)` (the reference's done_callback, environment.py:132-135), asked for with
     done_callback=True: traced like the other callbacks, it becomes the program's done test -- with auto_reset the step, the test

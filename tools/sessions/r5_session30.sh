@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 5, GPU visit 30 (reset_world that cannot be traced runs on the host, the callbacks stay traced: tests/refstyle/scatter.py):
+# the full GPU suite (+ parity_r5.json), smoke(), scatter.py traced vs its host path
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}; TAG=${1:-r5s30}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+tools/sessions/_gpu_ok.sh || { echo 'BAD BOX: leaving'; exit 0; }
+export TMPDIR=/tmp
+rm -f $R/gpurun_out/parity_r5.json
+( time timeout 1200 python -m pytest tests -m gpu -q --durations=4 > $O/pytest.log 2>&1 ) 2> $O/pytest.time; echo "pytest rc=$?"; tail -9 $O/pytest.log | cut -c1-300; grep real $O/pytest.time
+cp $R/gpurun_out/parity_r5.json $O/ 2>/dev/null
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2
+( time timeout 400 python tools/refstyle_rate.py tests/refstyle/scatter.py 2>&1 | grep -v amdgpu.ids > $O/refstyle_rate_scatter.txt ) 2> $O/rate.time; tail -4 $O/refstyle_rate_scatter.txt | cut -c1-330; grep real $O/rate.time
+ls $O
+exit 0
