@@ -713,7 +713,14 @@ def trace_ref_scenario(scenario, want_done=False, verify_worlds=64, cache=True, 
         raise symtrace.TraceUnsupported("reset_world makes %d np.random.choice draws (at most %d per-world picks)" % (len(t.pops), _abi.MPE_MAX_CHOICES))
     if t.E > _abi.MPE_ROWS_MAX_ENTITIES:
         raise symtrace.TraceUnsupported("%d entities (row programs cover %d)" % (t.E, _abi.MPE_ROWS_MAX_ENTITIES))
-    t.verified = symtrace.verify(scenario, t, worlds=verify_worlds)
+    try:
+        t.verified = symtrace.verify(scenario, t, worlds=verify_worlds)
+    except symtrace.TraceUnsupported as e:
+        if getattr(t, "host_reset", None):      # (say which reset it was: what such a reset keeps outside the state vectors cannot be followed)
+            raise symtrace.TraceUnsupported("%s [reset_world could not be traced (%s) and was run as it is: whatever it draws per world and "
+                                            "keeps outside the entities' state vectors -- a goal, a role -- is hidden state to the trace]"
+                                            % (e, t.host_reset))
+        raise
     ts = TracedRefScenario(scenario, t)
     ts.row_source(None)          # (generated now: a program too large for straight-line code is refused here, with the reason)
     return ts
