@@ -326,7 +326,14 @@ class TracedRefScenario(object):
         for b in np.linspace(0, B - 1, num=min(int(worlds), B)).astype(int):
             if margin[b] <= band:
                 continue
-            if not getattr(t, "host_reset", None):      # (the picks of world b in place; a host reset has none the callbacks could read)
+            if getattr(t, "host_reset", None):          # (the picks of world b in place: the file's own reset, its choices answered)
+                state = np.random.get_state()
+                try:
+                    with symtrace.logged_picks(symtrace.PickLogger(forced=picks[:, b])):
+                        sc.reset_world(cw)
+                finally:
+                    np.random.set_state(state)
+            else:
                 with symtrace.patched_random(symtrace._Replayer(np.zeros(max(t.n_u, 1)), picks[:, b])):
                     sc.reset_world(cw)
             for k, e in enumerate(list(cw.agents) + list(cw.landmarks)):
@@ -515,12 +522,18 @@ class TracedRefScenario(object):
             cw = self._shadow
             ents = list(cw.agents) + list(cw.landmarks)
             utter = np.zeros((B, t.A, max(t.dim_c, 1)))
+            K = np.zeros((B, len(t.pops)), np.int64)
+            from . import symtrace
             for b in np.flatnonzero(m):
                 if seeds is not None:
                     np.random.seed(int(seeds[b]) & 0xFFFFFFFF)
                 elif keep:
                     np.random.seed([int(world.seed) & 0x7FFFFFFF, int(world._episode) & 0x7FFFFFFF, (int(world.world_offset) + int(b)) & 0x7FFFFFFF])
-                sc.reset_world(cw)
+                with symtrace.logged_picks(symtrace.PickLogger()) as lg:      # (np.random.choice as NumPy's own, its outcomes noted)
+                    sc.reset_world(cw)
+                if len(lg.log) != len(t.pops):
+                    raise _abi.MpeError("reset_world of world %d made %d picks, the trace has %d" % (b, len(lg.log), len(t.pops)))
+                K[b] = lg.log
                 for k, e in enumerate(ents):
                     pos[b, k] = np.asarray(e.state.p_pos, np.float64).reshape(2)
                     vel[b, k] = 0.0 if e.state.p_vel is None else np.asarray(e.state.p_vel, np.float64).reshape(2)
@@ -537,6 +550,7 @@ class TracedRefScenario(object):
             if torch.is_tensor(a.state.c) and a.state.c.numel():
                 new = torch.as_tensor(utter[:, i, :a.state.c.shape[-1]], dtype=a.state.c.dtype, device=world.device)
                 a.state.c.copy_(torch.where(mt[:, None], new, a.state.c))
+        self._merge_picks(world, torch.as_tensor(K), mask)
 
     # ---- the row program ------------------------------------------------------------------------------------------------------
     def row_source(self, world):

@@ -34,6 +34,7 @@ process-wide (restored afterwards, the caller's random stream untouched): constr
 """
 import contextlib
 import math
+import sys
 
 import numpy as np
 
@@ -1134,6 +1135,62 @@ class _NoDraws(_Recorder):
     uniform = choice = randint = random_sample = rand = random = ranf = sample = _refuse
 
 
+class _HybridRecorder(_Recorder):
+    """np.random for a reset_world that is not a formula of its draws (host_reset): its NUMBERS are drawn for real -- the
+    rejection loop ends, randn / shuffle are what they are -- while its PICKS (np.random.choice / randint) stay symbolic, so that
+    what the callbacks read through a picked object (`world.goal = np.random.choice(world.landmarks)`) is traced as a selection
+    by a per-world pick as for any other file.  Built OUTSIDE patched_random: it keeps the real functions."""
+    all_draws = True
+
+    def __init__(self, graph, forced=None):
+        _Recorder.__init__(self, graph, forced)
+        self.real = {name: getattr(np.random, name) for name in ("uniform", "rand", "random", "random_sample", "ranf", "sample")}
+
+    def uniform(self, *a, **k): return self.real["uniform"](*a, **k)
+    def rand(self, *a, **k): return self.real["rand"](*a, **k)
+    def random(self, *a, **k): return self.real["random"](*a, **k)
+    def random_sample(self, *a, **k): return self.real["random_sample"](*a, **k)
+    def ranf(self, *a, **k): return self.real["ranf"](*a, **k)
+    def sample(self, *a, **k): return self.real["sample"](*a, **k)
+
+
+class PickLogger(object):
+    """np.random.choice / randint of a reset_world run CONCRETELY (a host reset): answered from the real stream -- choice(seq) is
+    seq[randint(0, len(seq))], as NumPy's own -- or from `forced`, and logged: the picks of that world, in call order."""
+
+    def __init__(self, forced=None):
+        self.real_randint, self.log, self.forced = np.random.randint, [], None if forced is None else [int(x) for x in forced]
+
+    def choice(self, a, size=None, replace=True, p=None):
+        if size is not None or p is not None:
+            raise TraceUnsupported("np.random.choice with size / p")
+        pop = list(range(a)) if isinstance(a, (int, np.integer)) else list(a)
+        if self.forced is not None:
+            if len(self.log) >= len(self.forced):
+                raise TraceUnsupported("reset_world makes more picks than were traced")
+            i = self.forced[len(self.log)]
+        else:
+            i = int(self.real_randint(0, len(pop)))
+        self.log.append(i)
+        return pop[i]
+
+    def randint(self, low, high=None, size=None, dtype=int):
+        if size is not None:
+            raise TraceUnsupported("np.random.randint with size")
+        lo, hi = (0, low) if high is None else (low, high)
+        return self.choice(list(range(int(lo), int(hi))))
+
+
+@contextlib.contextmanager
+def logged_picks(logger):
+    saved = (np.random.choice, np.random.randint)
+    np.random.choice, np.random.randint = logger.choice, logger.randint
+    try:
+        yield logger
+    finally:
+        np.random.choice, np.random.randint = saved
+
+
 class _Replayer(object):
     """np.random for a CONCRETE run of reset_world with prescribed outcomes (the verification of a trace, and seeded resets)."""
 
@@ -1322,7 +1379,19 @@ def _numpy_patches():
                                              "isfinite", "isnan", "isinf", "degrees", "radians")]:
         out[name] = unary(name, method or "_no_such_method_")
 
-    # ---- constructors: `o = np.zeros(4); o[:2] = agent.state.p_pos` needs an array that can hold symbolic values
+    return out
+
+
+_CTOR_NAMES = (("zeros", False), ("ones", False), ("empty", False), ("full", False),
+               ("zeros_like", True), ("ones_like", True), ("empty_like", True), ("full_like", True))
+
+
+def _ctor_patches():
+    """`o = np.zeros(4); o[:2] = agent.state.p_pos` needs an array that can hold symbolic values: np.zeros / ones / empty / full
+    (_like) giving object arrays where the file did not ask for another dtype.  NOT patched into the numpy module: compiled
+    library code (numpy.random's Cython, scipy) fills what np.empty(n) returns through a C pointer and would write doubles over
+    object pointers.  Only the FILE sees them -- injected_builtins binds its `np` to a proxy (and its `from numpy import zeros`
+    names to these functions) while it is traced."""
     def ctor(name, like):
         orig = getattr(np, name)
 
@@ -1333,17 +1402,34 @@ def _numpy_patches():
             if dt is None and like and args and isinstance(args[0], np.ndarray) and args[0].dtype.kind != "f":
                 return orig(*args, **kw)              # (zeros_like an integer / object array keeps its kind)
             positional_dtype = len(args) > (2 if name in ("full", "full_like") else 1) and not like
-            if positional_dtype or not (dt is None or dt is sym_float or dt is float or dt is np.float64 or dt is object):
+            if positional_dtype or not (dt is None or dt is sym_float or dt is object):
                 return orig(*args, **kw)
             kw.pop("dtype", None)
             r = orig(*args, **kw)
             return r.astype(object) if r.dtype.kind == "f" else r
         f.__name__ = name
         return f
-    for name, like in [("zeros", False), ("ones", False), ("empty", False), ("full", False),
-                       ("zeros_like", True), ("ones_like", True), ("empty_like", True), ("full_like", True)]:
-        out[name] = ctor(name, like)
-    return out
+    return {name: ctor(name, like) for name, like in _CTOR_NAMES}
+
+
+class _NumpyProxy(object):
+    """What the traced file's `np` is bound to: numpy, with the constructors of _ctor_patches."""
+
+    def __init__(self, real, over):
+        object.__setattr__(self, "_real", real)
+        object.__setattr__(self, "_over", over)
+
+    def __getattr__(self, name):
+        over = object.__getattribute__(self, "_over")
+        if name in over:
+            return over[name]
+        return getattr(object.__getattribute__(self, "_real"), name)
+
+    def __setattr__(self, name, value):
+        setattr(object.__getattribute__(self, "_real"), name, value)
+
+    def __dir__(self):
+        return dir(object.__getattribute__(self, "_real"))
 
 
 # ---- the math module: its functions take floats (a symbolic value would be asked for its __float__) -------------------------------
@@ -1417,7 +1503,7 @@ def patched_random(impl):
             setattr(np, name, f)
         for name in _RANDOM_NAMES:
             setattr(np.random, name, getattr(impl, name))
-        for name in _RANDOM_REFUSED:
+        for name in (() if getattr(impl, "all_draws", False) else _RANDOM_REFUSED):
             if name in saved:
                 def refuse(*a, _n=name, **k):
                     raise TraceUnsupported("np.random.%s in a traced callback" % _n)
@@ -1433,7 +1519,8 @@ def patched_random(impl):
 
 @contextlib.contextmanager
 def injected_builtins(scenario):
-    """min / max / any / all as the file's module sees them while it is traced (one node instead of a fork per comparison)."""
+    """min / max / any / all / float / int / round / sorted -- and numpy's array constructors (_ctor_patches) -- as the file's module
+    sees them while it is traced."""
     import types
     pkg = __name__.rsplit(".", 1)[0]
     spaces = []          # the global namespaces the scenario's methods (and its base classes') resolve names in
@@ -1445,9 +1532,27 @@ def injected_builtins(scenario):
             if isinstance(f, types.FunctionType) and not any(f.__globals__ is d for d in spaces):
                 spaces.append(f.__globals__)
     saved = [(d, name, d.get(name, _MISSING)) for d in spaces for name in _INJECTED]
+    ctors = _ctor_patches()
+    by_original = {getattr(np, name): f for name, f in ctors.items()}
+    proxy = _NumpyProxy(np, ctors)
+    for d in spaces:          # the file's `np` (however it is spelt) and its `from numpy import zeros` names
+        for name, v in list(d.items()):
+            if name in _INJECTED:
+                continue
+            if v is np:
+                saved.append((d, name, v))
+            elif callable(v) and not isinstance(v, type):
+                try:
+                    hit = v in by_original
+                except TypeError:
+                    hit = False
+                if hit:
+                    saved.append((d, name, v))
     try:
         for d in spaces:
             d.update(_INJECTED)
+        for d, name, old in saved[len(spaces) * len(_INJECTED):]:
+            d[name] = proxy if old is np else by_original[old]
         yield
     finally:
         for d, name, old in saved:
@@ -1660,9 +1765,7 @@ def _trace_once(scenario, t, forced, want_done, max_paths, want_info=False):
             a.action.u = np.zeros(dp)
         info_desc = [_describe_info(scenario.benchmark_data(a, world)) for a in agents]
     # ---- reset_world, symbolically ------------------------------------------------------------------------------------------
-    rec = _Recorder(g, forced)
-    host_reset = None
-    try:
+    def attempt(rec):
         with patched_random(rec), injected_builtins(scenario):
             _, conds, _ = Tracer(g, 1, max_decisions=64)._run(lambda: scenario.reset_world(world), [])
         if conds:      # reset_world branches on what it drew: on a pick -> one trace per value of that pick; on anything else: not modelled
@@ -1670,18 +1773,30 @@ def _trace_once(scenario, t, forced, want_done, max_paths, want_info=False):
             if ks and "U" not in inputs_of(conds[:1]):
                 raise NeedConcretePick(ks[0])
             raise TraceUnsupported("reset_world branches on a random number it drew")
+    rec = _Recorder(g, forced)
+    host_reset = None
+    try:
+        attempt(rec)
     except NeedConcretePick:
         raise
     except Exception as e:
         # A reset_world that is not a FORMULA of its draws -- rejection sampling (`while too_close: draw again`), shuffles, normal
         # draws -- is no reason to give up the callbacks: it stays what it is, Python run per world at reset time (host_reset), and
-        # only observation / reward / done are traced.  Whatever it leaves outside the state vectors that the callbacks then read
-        # (a goal picked per world) makes the verification fail, and the file falls back as before.
-        if forced or _Ctx.need_pick is not None:
+        # only observation / reward / done are traced.  Its picks are still followed (_HybridRecorder); whatever else it leaves
+        # outside the state vectors that the callbacks then read makes the verification fail, and the file falls back as before.
+        if _Ctx.need_pick is not None:
             raise
         host_reset = "%s: %s" % (type(e).__name__, e) if not isinstance(e, TraceUnsupported) else str(e)
-        rec = _Recorder(g, forced)
-        scenario.reset_world(world)          # (concretely: the world is whole again; _trace restores the caller's np.random stream)
+        rec = _HybridRecorder(g, forced)
+        try:
+            attempt(rec)
+        except NeedConcretePick:
+            raise
+        except Exception:
+            if _Ctx.need_pick is not None:
+                raise
+            rec = _Recorder(g, forced)           # (not even with its numbers drawn for real: no picks, everything concrete)
+            scenario.reset_world(world)          # (the world is whole again; _trace restores the caller's np.random stream)
     out = {"draws": rec.draws, "pops": rec.pops, "n_u": rec.n_u, "host_reset": host_reset}
 
     def vec(v, n, what):
@@ -1853,17 +1968,24 @@ def _trace(scenario, want_done=False, max_paths=None, want_info=False):
 
 def _pick_populations(scenario, g):
     """Population size of every np.random.choice of reset_world, found by a pass in which every pick is answered concretely."""
-    class _Sizes(_Recorder):
-        def choice(self, a, size=None, replace=True, p=None):
-            pop = list(range(a)) if isinstance(a, (int, np.integer)) else list(a)
-            self.pops.append(len(pop))
-            return pop[0]
-    rec = _Sizes(g)
-    with patched_random(rec):
-        world = scenario.make_world()
-        rec.pops = []
-        scenario.reset_world(world)
-    return list(rec.pops)
+    def sizes(base):
+        class _Sizes(base):
+            def choice(self, a, size=None, replace=True, p=None):
+                pop = list(range(a)) if isinstance(a, (int, np.integer)) else list(a)
+                self.pops.append(len(pop))
+                return pop[0]
+        rec = _Sizes(g)
+        with patched_random(rec):
+            world = scenario.make_world()
+            rec.pops = []
+            scenario.reset_world(world)
+        return list(rec.pops)
+    try:
+        return sizes(_Recorder)
+    except NeedConcretePick:
+        raise
+    except Exception:
+        return sizes(_HybridRecorder)          # (a host reset: its numbers drawn for real)
 
 
 
@@ -2052,6 +2174,19 @@ def verify(scenario, t, worlds=96, seed=0, tol=1e-9):
     K = np.stack([rs.randint(0, n, R) for n in t.pops], axis=1) if t.pops else np.zeros((R, 0), np.int64)
     P, V, Cw = random_states(t, R, rs)
     worst = 0.0
+    if getattr(t, "host_reset", None):          # the picks of a host reset are whatever its own run draws: one run per world to learn them
+        host_seeds = rs.randint(0, 2 ** 31 - 1, R)
+        rng_state = np.random.get_state()
+        try:
+            for r in range(R):
+                np.random.seed(int(host_seeds[r]))
+                with logged_picks(PickLogger()) as lg:
+                    scenario.reset_world(cw)
+                if len(lg.log) != len(t.pops):
+                    raise TraceUnsupported("reset_world makes %d picks in one world and %d in another" % (len(t.pops), len(lg.log)))
+                K[r] = lg.log
+        finally:
+            np.random.set_state(rng_state)
 
     def cmp(what, got, want):
         nonlocal worst
@@ -2082,11 +2217,12 @@ def verify(scenario, t, worlds=96, seed=0, tol=1e-9):
     if getattr(t, "info", None) is not None:
         info_eval = [evaluate(row, R, P=P, V=V, Cw=Cw, K=K, U=U) if row else [] for row in t.info]
     for r in range(R):
-        if getattr(t, "host_reset", None):      # the file's own reset_world, run as it is (what it hides from the state shows below)
+        if getattr(t, "host_reset", None):      # the file's own reset_world, run as it is with world r's picks (what else it hides shows below)
             rng_state = np.random.get_state()
             try:
-                np.random.seed(int(rs.randint(0, 2 ** 31 - 1)))
-                scenario.reset_world(cw)
+                np.random.seed(int(host_seeds[r]))
+                with logged_picks(PickLogger(forced=K[r])):
+                    scenario.reset_world(cw)
             finally:
                 np.random.set_state(rng_state)
         else:

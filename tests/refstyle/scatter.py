@@ -2,10 +2,11 @@
 of multiagent/scenario.py:4-10 and the README's "Creating new environments" -- `from multiagent.core import ...`,
 `make_world(self)`, `reset_world(self, world)`, NumPy per-world `reward` / `observation`.
 
-scatter: three agents each claim the nearest of three (solid) beacons.  Its reset_world is NOT a formula of its random draws:
-entities are placed by REJECTION sampling (`while` the spot is taken: draw again -- a data-dependent number of draws), and the
-agents start with a small normal-distributed velocity.  Such a reset cannot be traced into a program; it stays what it is -- Python,
-run per world at reset time -- while observation and reward are traced into the step kernel as for any other file.
+scatter: three agents each claim the nearest of three (solid) beacons; agent 0, the courier, must reach the beacon that was picked
+for this world.  Its reset_world is NOT a formula of its random draws: entities are placed by REJECTION sampling (`while` the spot
+is taken: draw again -- a data-dependent number of draws), and the agents start with a small normal-distributed velocity.  Such a
+reset cannot be traced into a program; it stays what it is -- Python, run per world at reset time, its np.random.choice followed as
+a per-world pick -- while observation and reward are traced into the step kernel as for any other file.
 """
 import numpy as np
 from multiagent.core import World, Agent, Landmark
@@ -20,6 +21,7 @@ class Scenario(BaseScenario):
         world.agents = [Agent() for _ in range(3)]
         for i, agent in enumerate(world.agents):
             agent.name = "agent %d" % i
+            agent.courier = i == 0
             agent.collide = True
             agent.silent = True
             agent.size = 0.08
@@ -33,6 +35,7 @@ class Scenario(BaseScenario):
         return world
 
     def reset_world(self, world):
+        world.goal = np.random.choice(world.landmarks)
         placed = []
         for entity in world.landmarks + world.agents:
             entity.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
@@ -46,7 +49,7 @@ class Scenario(BaseScenario):
 
     def reward(self, agent, world):
         dists = [np.linalg.norm(agent.state.p_pos - beacon.state.p_pos) for beacon in world.landmarks]
-        rew = -min(dists)
+        rew = -np.linalg.norm(agent.state.p_pos - world.goal.state.p_pos) if agent.courier else -min(dists)
         for other in world.agents:
             if other is not agent and np.linalg.norm(other.state.p_pos - agent.state.p_pos) < other.size + agent.size:
                 rew -= 1.0
@@ -55,4 +58,4 @@ class Scenario(BaseScenario):
     def observation(self, agent, world):
         beacons = [beacon.state.p_pos - agent.state.p_pos for beacon in world.landmarks]
         others = [other.state.p_pos - agent.state.p_pos for other in world.agents if other is not agent]
-        return np.concatenate([agent.state.p_vel, agent.state.p_pos] + beacons + others)
+        return np.concatenate([agent.state.p_vel, agent.state.p_pos] + beacons + others + [world.goal.state.p_pos - agent.state.p_pos])

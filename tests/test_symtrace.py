@@ -219,8 +219,8 @@ def test_fixture_files_trace_and_reproduce_their_own_callbacks(name):
 
 def test_a_reset_world_that_is_not_a_formula_of_its_draws_runs_on_the_host_and_the_callbacks_are_still_traced():
     """tests/refstyle/scatter.py places entities by rejection sampling (`while` the spot is taken: draw again) and draws normal
-    velocities: tracing reset_world would never end / is refused.  The trace keeps observation and reward (verified as always)
-    and marks reset_world as the file's own Python, run per restarting world with np.random seeded per world -- a seeded reset
+    velocities: tracing reset_world would never end / is refused.  The trace keeps observation and reward (verified as always),
+    follows `world.goal = np.random.choice(world.landmarks)` as a per-world pick, and marks reset_world as the file's own Python, run per restarting world with np.random seeded per world -- a seeded reset
     is the reference's `np.random.seed(s); env.reset()` value for value."""
     sc = mpe.scenarios.load(os.path.join(FIXTURES, "scatter.py")).Scenario()
     np.random.seed(11)
@@ -228,7 +228,8 @@ def test_a_reset_world_that_is_not_a_formula_of_its_draws_runs_on_the_host_and_t
     ts = refstyle.trace_ref_scenario(sc, cache=False)
     t = ts.t
     assert np.array_equal(np.random.get_state()[1], before)
-    assert t.host_reset and "state-dependent decisions" in t.host_reset and t.pops == [] and t.n_u == 0
+    assert t.host_reset and "state-dependent decisions" in t.host_reset and t.n_u == 0
+    assert t.pops == [3] and t.draws == [("choice", 3)]          # world.goal = np.random.choice(world.landmarks): still followed as a pick
     assert t.verified <= 1e-15 and symtrace.verify(sc, t, worlds=150, seed=3) <= 1e-15
     assert not ts.device_reset and ts.reset_boxes(None) is None and "runs on the host" in ts.report()
     B = 16
@@ -244,6 +245,7 @@ def test_a_reset_world_that_is_not_a_formula_of_its_draws_runs_on_the_host_and_t
         ents = cw.agents + cw.landmarks
         assert np.abs(P[b] - np.array([e.state.p_pos for e in ents])).max() < 1e-6
         assert np.abs(V[b] - np.array([e.state.p_vel for e in ents])).max() < 1e-6
+        assert int(w.choice_i32[0][b]) == cw.landmarks.index(cw.goal)          # ... and the pick of that world is the file's
     gaps = np.linalg.norm(P[:, :, None, :] - P[:, None, :, :], axis=-1) + 10.0 * np.eye(P.shape[1])
     assert gaps.min() >= 0.3 - 1e-6                                   # the file's own invariant: nobody spawns on anybody
     # a masked restart touches only the masked worlds; without seeds the stream is (env seed, episode, world): reproducible, and the
@@ -800,6 +802,35 @@ def test_rows_filled_slice_by_slice_rounding_and_number_conversions_trace():
     a = np.stack(symtrace.evaluate(roots, B, P=P, V=V, Cw=Cw), axis=1)
     b = np.stack(symtrace.evaluate(roots, B, P=P.astype(np.float32), V=V.astype(np.float32), Cw=Cw, dtype=np.float32), axis=1)
     assert np.abs(a - b)[m > 2e-6].max() < 1e-5
+
+
+def test_array_constructors_are_the_files_own_and_compiled_library_code_keeps_numpys():
+    """The object-array constructors are bound in the FILE's namespace (its `np` is a proxy while it is traced), not patched into
+    numpy: numpy.random's compiled code fills what np.empty(n) returns through a C pointer -- with an object array there it wrote
+    doubles over object pointers (a segmentation fault when a host reset first called the real np.random.randn under the patches)."""
+    seen = {}
+
+    class S(_Base):
+        def observation(self, agent, world):
+            fixed = np.random.RandomState(7).rand(2)               # compiled code allocating through numpy's own np.empty
+            row = np.zeros(6)                                      # the file's: can hold symbolic values
+            seen["row"], seen["fixed"], seen["np"] = row.dtype, fixed.dtype, type(np).__name__
+            row[0:2] = agent.state.p_pos
+            row[2:4] = fixed
+            row[4:6] = np.ones_like(fixed) * agent.state.p_vel
+            return row
+    sc = S()
+    t = symtrace.trace(sc)
+    assert symtrace.verify(sc, t, worlds=50) == 0.0
+    assert seen["row"] == np.float64 and seen["np"] == "module"          # (the last call was verify's concrete one: numpy itself)
+    seen.clear()
+    with symtrace.injected_builtins(sc):
+        row = S.observation.__globals__["np"].zeros(3)
+        assert row.dtype == object and type(S.observation.__globals__["np"]).__name__ == "_NumpyProxy"
+        import sys
+        numpy = sys.modules["numpy"]          # (this test module IS the file here: its own `np` is the proxy right now)
+        assert numpy.zeros(3).dtype == numpy.float64 and numpy.random.RandomState(1).randn(4).dtype == numpy.float64      # numpy: untouched
+    assert S.observation.__globals__["np"] is np
 
 
 def test_what_is_still_not_modelled_falls_back_with_the_reason():
