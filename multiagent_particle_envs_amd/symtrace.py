@@ -11,11 +11,14 @@ slower than a kernel.  This module makes the same file fast without touching it:
             velocities, utterances, and the per-world PICKS `reset_world` draws with np.random.choice (a goal landmark, a
             key: objects chosen per world are proxies whose attributes are selections by the pick).  Control flow on the
             state (`if dist < dist_min: rew -= 1`): what only chooses between VALUES -- conditional expressions, `if`s that
-            assign or append, early returns, and / or / not -- is predicated into select nodes by re-compiling a copy of the
+            assign or append, early returns, `if T: continue`, and / or / not, comparisons of whole arrays and their reducing
+            methods (`D < 0.2`, `D.min(axis=0)`, `.all()`) -- is predicated into select nodes by re-compiling a copy of the
             file's source (predicated_twin); any other symbolic `if` forks: the callback is re-run with the decision forced
             each way and the outcomes merge into select nodes, column by column (conditions are memoised per path, so a
             test asked twice forks once).  `reset_world` is traced the same way with np.random replaced by a recorder:
-            initial positions as functions of uniform draws and picks; `benchmark_data` and `done` on request.
+            initial positions as functions of uniform draws and picks; a reset_world that is no formula of its draws
+            (rejection sampling, randn, shuffle) stays the file's own Python, run per restarting world at reset time
+            (`Traced.host_reset`), its picks still followed; `benchmark_data` and `done` on request.
   verify    the graphs are evaluated with NumPy (fp64, vectorised over worlds) against the FILE'S OWN callbacks run
             concretely on random worlds -- states that touch, overlap, leave the arena -- before anything is generated:
             a callback that keeps hidden state, draws random numbers or does something the tracer does not model is
@@ -29,8 +32,11 @@ slower than a kernel.  This module makes the same file fast without touching it:
 What is traced is arithmetic on the state: files whose callbacks read actions, scripted agents, movable landmarks, noise,
 more than MPE_MAX_CHOICES picks, or more control-flow paths than `MAX_PATHS` stay on the host path.
 Nothing here runs on the step path: tracing happens once, at env construction -- and while it does, np.random's drawing functions,
-a few NumPy functions (maximum / minimum / clip / min / max / where) and the traced file's min / max / any / all are replaced
-process-wide (restored afterwards, the caller's random stream untouched): construct envs from one thread.
+the math module's functions and the NumPy functions whose object-dtype loops cannot take symbolic values (maximum / minimum / clip /
+min / max / where / any / all / sort / argmin / sqrt / exp / floor / sign ...: each is NumPy's own for ordinary numbers) are replaced
+process-wide, and the traced file's own namespace sees min / max / any / all / float / int / round / sorted and numpy's array
+constructors (np.zeros ...: through a proxy bound to its `np`; numpy itself keeps its own) that let symbolic values through --
+all restored afterwards, the caller's random stream untouched: construct envs from one thread.
 """
 import contextlib
 import math
