@@ -288,7 +288,9 @@ class TracedRefScenario(object):
                 "difference %s" % (
                     t.A, t.E - t.A, t.dim_c, [len(r) for r in t.obs], t.graph.count, t.paths["obs"], t.paths["rew"],
                     ", done %s" % t.paths["done"] if t.paths.get("done") else "",
-                    "value-only control flow predicated" if getattr(t, "predicated", False) else "by forking", list(t.pops) or "none",
+                    "value-only control flow predicated" if getattr(t, "predicated", False) else "by forking",
+                    (str(list(t.pops[:t.real_picks()]) or "none") +
+                     (" (+ %d random numbers it keeps outside the state and the callbacks read: per-world parameters)" % len(t.params) if getattr(t, "params", ()) else "")),
                     ("is World.reset_uniform's placement (landmarks on [-%g, %g)^2): restarts are drawn on the device, inside the step launch"
                      % (self.landmark_range, self.landmark_range) if self._boxes is None else
                      "places every entity uniformly in a box of its own: restarts are drawn on the device, inside the step launch")
@@ -334,7 +336,10 @@ class TracedRefScenario(object):
                 finally:
                     np.random.set_state(state)
             else:
-                with symtrace.patched_random(symtrace._Replayer(np.zeros(max(t.n_u, 1)), picks[:, b])):
+                u = np.zeros(max(t.n_u, 1))
+                for j, idx in enumerate(getattr(t, "params", ())):          # (the draws the callbacks read: what their slots carry)
+                    u[idx] = float(picks[t.real_picks() + j, b]) / symtrace.PARAM_POP
+                with symtrace.patched_random(symtrace._Replayer(u, picks[:, b])):
                     sc.reset_world(cw)
             for k, e in enumerate(list(cw.agents) + list(cw.landmarks)):
                 e.state.p_pos, e.state.p_vel = pos[b, k].astype(np.float64), vel[b, k].astype(np.float64)
@@ -390,7 +395,7 @@ class TracedRefScenario(object):
             boxes.append(tuple(box))
         zeros = all(n.op == "const" and n.value == 0.0 for v in t.reset_vel for n in v) and \
             all(n.op == "const" and n.value == 0.0 for v in t.reset_c for n in v)
-        if not zeros:
+        if not zeros or used & set(getattr(t, "params", ())):          # (a draw the callbacks read that ALSO places an entity: one source for both)
             return 1.0, False, None
 
         def sym(b, r):
@@ -449,6 +454,8 @@ class TracedRefScenario(object):
             U = torch.rand((max(t.n_u, 1), B), generator=gen, device=dev)
             K = torch.stack([torch.randint(0, n, (B,), generator=gen, device=dev) for n in t.pops]) if t.pops else \
                 torch.zeros((0, B), dtype=torch.int64, device=dev)
+            for j, idx in enumerate(getattr(t, "params", ())):      # the draws the callbacks read travel in the slots after the picks
+                K[t.real_picks() + j] = (U[idx].double() * symtrace.PARAM_POP).floor().to(torch.int64).clamp_(0, symtrace.PARAM_POP - 1)
             vals = symtrace.evaluate_torch(flat, B, K=K, U=U, device=dev)
             pos = torch.stack(vals[:2 * t.E]).reshape(t.E, 2, B)
             vel = torch.stack(vals[2 * t.E:]).reshape(t.E, 2, B)
@@ -492,8 +499,10 @@ class TracedRefScenario(object):
                 rs = np.random.RandomState([int(world.seed) & 0x7FFFFFFF, int(world._episode) & 0x7FFFFFFF, int(world.world_offset) & 0x7FFFFFFF])
                 world._episode += 1
             U = rs.random_sample(U.shape)
-            for k, n in enumerate(t.pops):
+            for k, n in enumerate(t.pops[:t.real_picks()]):
                 K[:, k] = rs.randint(0, n, B)
+        for j, idx in enumerate(getattr(t, "params", ())):
+            K[:, t.real_picks() + j] = np.clip(np.floor(U[:, idx] * symtrace.PARAM_POP), 0, symtrace.PARAM_POP - 1).astype(np.int64)
         vals = symtrace.evaluate(flat, B, K=K, U=U)
         pos = np.stack(vals[:2 * t.E], axis=1).reshape(B, t.E, 2)
         vel = np.stack(vals[2 * t.E:], axis=1).reshape(B, t.E, 2)
@@ -531,9 +540,9 @@ class TracedRefScenario(object):
                     np.random.seed([int(world.seed) & 0x7FFFFFFF, int(world._episode) & 0x7FFFFFFF, (int(world.world_offset) + int(b)) & 0x7FFFFFFF])
                 with symtrace.logged_picks(symtrace.PickLogger()) as lg:      # (np.random.choice as NumPy's own, its outcomes noted)
                     sc.reset_world(cw)
-                if len(lg.log) != len(t.pops):
-                    raise _abi.MpeError("reset_world of world %d made %d picks, the trace has %d" % (b, len(lg.log), len(t.pops)))
-                K[b] = lg.log
+                if len(lg.log) != t.real_picks():
+                    raise _abi.MpeError("reset_world of world %d made %d picks, the trace has %d" % (b, len(lg.log), t.real_picks()))
+                K[b, :t.real_picks()] = lg.log
                 for k, e in enumerate(ents):
                     pos[b, k] = np.asarray(e.state.p_pos, np.float64).reshape(2)
                     vel[b, k] = 0.0 if e.state.p_vel is None else np.asarray(e.state.p_vel, np.float64).reshape(2)

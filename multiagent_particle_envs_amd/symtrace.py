@@ -51,6 +51,8 @@ class TraceUnsupported(Exception):
 
 MAX_PATHS = 8192          # control-flow paths of ONE callback of one agent (every symbolic `if` can double them)
 MAX_DECISIONS = 4096      # symbolic decisions on ONE path
+PARAM_POP = 1 << 24       # a uniform draw the callbacks read (a goal kept as coordinates, not as an entity): a "pick" among 2^24 values
+MAX_SLOTS = 4             # per-world pick slots of the ABI (MPE_MAX_CHOICES): picks + such parameters
 _CMP = ("lt", "le", "eq", "ne")
 _BOOL_OPS = _CMP + ("not", "and", "or", "bconst")
 
@@ -1652,6 +1654,12 @@ def _flatten_info(raw, desc):
 
 class Traced(object):
     host_reset = None          # why reset_world is not a traced program but the file's own Python, run per world (None: it is traced)
+    params = ()                # uniform draws of reset_world that the CALLBACKS read (hidden per-world numbers): their U indices; they
+    #                            occupy the pick slots after the real picks -- pops[n_picks + j] == PARAM_POP, value k = floor(u * 2^24)
+    n_picks = None             # how many of `pops` are np.random.choice picks (None: all of them)
+
+    def real_picks(self):
+        return len(self.pops) if self.n_picks is None else self.n_picks
 
     """What tracing a reference-style scenario yields: per-agent graphs over the state + the reset program.
 
@@ -1695,6 +1703,7 @@ def to_dict(t):
             "info": None if getattr(t, "info", None) is None else [[n.uid for n in row] for row in t.info],
             "info_desc": getattr(t, "info_desc", None),
             "predicated": bool(getattr(t, "predicated", False)), "host_reset": getattr(t, "host_reset", None),
+            "params": list(getattr(t, "params", ())), "n_picks": getattr(t, "n_picks", None),
             "collaborative": bool(t.collaborative), "paths": t.paths, "enumerated": list(getattr(t, "enumerated", [])),
             "world": {k: getattr(w, k) for k in _WLD_KEYS},
             "discrete_action": getattr(w, "discrete_action", None),
@@ -1729,6 +1738,7 @@ def from_dict(d):
     t.collaborative, t.paths, t.enumerated = d["collaborative"], d["paths"], d["enumerated"]
     t.predicated = bool(d.get("predicated", False))
     t.host_reset = d.get("host_reset")
+    t.params, t.n_picks = list(d.get("params") or ()), d.get("n_picks")
     w = ccore.World()
     for k, v in d["world"].items():
         setattr(w, k, v)
@@ -1958,10 +1968,33 @@ def _trace(scenario, want_done=False, max_paths=None, want_info=False):
             raise TraceUnsupported("make_world() builds worlds with different entity counts or physics constants from call to call")
         t.enumerated = list(enumerated)
         t.collaborative = first["collaborative"]
-        for what, roots in (("observation", [n for row in t.obs for n in row]), ("reward", t.rew), ("done", [d for d in t.done if d is not None]),
-                            ("benchmark_data", [n for row in (t.info or []) for n in row])):
-            if "U" in inputs_of(roots):
-                raise TraceUnsupported("%s depends on a random number reset_world drew and did not store in the state" % what)
+        # A random NUMBER reset_world drew and kept outside the state vectors (`world.goal_pos = np.random.uniform(-1, 1, 2)`: a goal that
+        # is coordinates, not an entity) which the callbacks read: a per-world parameter.  It travels in a pick slot -- a "pick" among
+        # 2^24 values, k = floor(u * 2^24), read back as k * 2^-24 (what a float32 uniform draw is) -- so that seeded resets, device
+        # restarts and the kernel's K accessor serve it like any pick.
+        groups = [[n for row in t.obs for n in row], list(t.rew), [d for d in t.done if d is not None], [n for row in (t.info or []) for n in row]]
+        used = sorted({n.value[0] for roots in groups for n in topo(roots) if n.op == "U"})
+        if used:
+            if len(t.pops) + len(used) > MAX_SLOTS:
+                raise TraceUnsupported("the callbacks read %d random numbers reset_world drew and kept outside the state, next to %d picks "
+                                       "(at most %d per-world slots)" % (len(used), len(t.pops), MAX_SLOTS))
+            t.n_picks, t.params = len(t.pops), list(used)
+            slot = {}
+            for j, u in enumerate(used):
+                k = g.node("K", (), (t.n_picks + j,))
+                slot[g.node("U", (), (u,)).uid] = g.binary("mul", k, g.const(1.0 / PARAM_POP))
+            t.pops = list(t.pops) + [PARAM_POP] * len(used)
+            memo = dict(slot)
+            for n in topo([n for roots in groups for n in roots]):          # (arguments come before their users)
+                if n.uid in memo:
+                    continue
+                args = tuple(memo[a.uid] for a in n.args)
+                memo[n.uid] = n if all(a is b for a, b in zip(args, n.args)) else g.node(n.op, args, n.value)
+            t.obs = [[memo[n.uid] for n in row] for row in t.obs]
+            t.rew = [memo[n.uid] for n in t.rew]
+            t.done = [None if d is None else memo[d.uid] for d in t.done]
+            if t.info is not None:
+                t.info = [[memo[n.uid] for n in row] for row in t.info]
         return t
     except TraceUnsupported:
         raise
@@ -2178,6 +2211,8 @@ def verify(scenario, t, worlds=96, seed=0, tol=1e-9):
     agents, ents = _entity_lists(cw)
     U = rs.uniform(0.0, 1.0, (R, max(t.n_u, 1)))
     K = np.stack([rs.randint(0, n, R) for n in t.pops], axis=1) if t.pops else np.zeros((R, 0), np.int64)
+    for j, u in enumerate(getattr(t, "params", ())):          # the draws the callbacks read: the value their pick slot carries
+        U[:, u] = K[:, t.real_picks() + j] / float(PARAM_POP)
     P, V, Cw = random_states(t, R, rs)
     worst = 0.0
     if getattr(t, "host_reset", None):          # the picks of a host reset are whatever its own run draws: one run per world to learn them
@@ -2188,9 +2223,9 @@ def verify(scenario, t, worlds=96, seed=0, tol=1e-9):
                 np.random.seed(int(host_seeds[r]))
                 with logged_picks(PickLogger()) as lg:
                     scenario.reset_world(cw)
-                if len(lg.log) != len(t.pops):
-                    raise TraceUnsupported("reset_world makes %d picks in one world and %d in another" % (len(t.pops), len(lg.log)))
-                K[r] = lg.log
+                if len(lg.log) != t.real_picks():
+                    raise TraceUnsupported("reset_world makes %d picks in one world and %d in another" % (t.real_picks(), len(lg.log)))
+                K[r, :t.real_picks()] = lg.log
         finally:
             np.random.set_state(rng_state)
 

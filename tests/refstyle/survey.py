@@ -5,7 +5,9 @@ of multiagent/scenario.py:4-10 and the README's "Creating new environments" -- `
 survey: three drones map three sites.  Written the way scenario authors write when they are NOT thinking of a tracer: the
 observation is filled into a preallocated `np.zeros` row slice by slice, positions are quantised to a grid (`np.floor`), wrapped
 (`%`), offsets are compressed (`np.sign(d) * np.abs(d) ** 1.5`), flags are built with `float(test)` / `int(test)`, distances
-with `np.hypot` / `math.hypot`, rewards rounded with `np.round`.  Everybody is silent; the reward is shared.
+with `np.hypot` / `math.hypot`, rewards rounded with `np.round`.  The rally point of a world is drawn in reset_world and kept as plain
+coordinates on the world object (`world.rally`) -- not an entity, not in anybody's state vector -- and read by both callbacks.
+Everybody is silent; the reward is shared.
 """
 import math
 
@@ -37,6 +39,7 @@ class Scenario(BaseScenario):
         return world
 
     def reset_world(self, world):
+        world.rally = np.random.uniform(-0.5, +0.5, world.dim_p)
         for agent in world.agents:
             agent.color = np.array([0.35, 0.35, 0.85])
             agent.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
@@ -61,11 +64,12 @@ class Scenario(BaseScenario):
             for b in world.agents:
                 if a is not b:
                     rew -= 0.5 * float(self.touching(a, b))
+        rew -= 0.1 * np.linalg.norm(agent.state.p_pos - world.rally)
         return rew
 
     def observation(self, agent, world):
         n = len(world.landmarks)
-        row = np.zeros(2 + 2 + 2 + 2 * n + 2)
+        row = np.zeros(2 + 2 + 2 + 2 * n + 2 + 2)
         row[0:2] = agent.state.p_vel
         row[2:4] = np.floor(agent.state.p_pos * GRID) / GRID           # the grid cell the drone is over
         row[4:6] = (agent.state.p_pos + 1.0) % (1.0 / GRID) * GRID      # where in that cell, 0 .. 1
@@ -75,6 +79,7 @@ class Scenario(BaseScenario):
         # (thresholds on POSITIONS: velocities under one-hot moves sit exactly on round numbers -- 0.5 after one step from rest --
         #  where an fp32 and an fp64 evaluation may legitimately land on different sides)
         home = np.hypot(agent.state.p_pos[0], agent.state.p_pos[1])
-        row[-2] = float(home > 0.5)
-        row[-1] = math.floor(home * 10.0) / 10.0
+        row[-4] = float(home > 0.5)
+        row[-3] = math.floor(home * 10.0) / 10.0
+        row[-2:] = world.rally - agent.state.p_pos
         return row

@@ -108,6 +108,8 @@ def replay(env, g, dev, name=None):
             if tr.dim_c and "c%d" % i in g:
                 Cw[:, i] = g["c%d" % i][t][:, :tr.dim_c]
         K = g["choice"].astype(np.int64) if "choice" in g and g["choice"].shape[1] else np.zeros((W, len(tr.pops)), np.int64)
+        if getattr(tr, "params", ()):          # (random numbers the callbacks read: they sit in the env's pick slots since the seeded reset)
+            K = env.world.choice_i32.cpu().numpy().T.astype(np.int64)
         roots = [x for row in tr.obs for x in row] + list(tr.rew)
         ok = symtrace.decision_margin(roots, W, P=g["pos"][t].astype(np.float64), V=V, Cw=Cw, K=K) > 2e-6
         assert ok.mean() >= 0.95, ok.mean()

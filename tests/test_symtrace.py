@@ -151,13 +151,13 @@ def test_what_the_tracer_refuses_and_why():
         def reward(self, agent, world):
             return -np.sum(np.square(agent.action.u))
 
-    class Unstored(_Base):        # a random number reset_world drew and kept outside the state
+    class Unstored(_Base):        # random numbers reset_world drew and kept outside the state: up to 4 travel as per-world parameters
         def reset_world(self, world):
             _Base.reset_world(self, world)
-            world.bonus = np.random.uniform(0, 1)
+            world.bonus = np.random.uniform(0, 1, 5)
 
         def reward(self, agent, world):
-            return world.bonus
+            return float(np.sum(world.bonus))
 
     class Explodes(_Base):
         def reward(self, agent, world):
@@ -178,7 +178,7 @@ def test_what_the_tracer_refuses_and_why():
             return w
 
     for cls, why in ((RandomSizes, "different entity counts or physics constants"), (Draws, "draws random numbers"), (Scripted, "scripted agents"), (ReadsAction, "TypeError|NoneType"),
-                     (Unstored, "did not store in the state"), (Explodes, "control-flow paths"), (Concretises, "Python float")):
+                     (Unstored, "kept outside the state"), (Explodes, "control-flow paths"), (Concretises, "Python float")):
         with pytest.raises(symtrace.TraceUnsupported, match=why):
             symtrace.trace(cls(), max_paths=512 if cls is Explodes else None)
     sc = Hidden()
@@ -206,7 +206,7 @@ def test_tracing_leaves_numpy_random_and_the_files_namespace_as_they_were():
 def test_fixture_files_trace_and_reproduce_their_own_callbacks(name):
     sc = mpe.scenarios.load(os.path.join(FIXTURES, name + ".py")).Scenario()
     ts = refstyle.trace_ref_scenario(sc, cache=False)
-    ulp = 1e-15 if name == "mesh" else 0.0          # (np.linalg.norm of a matrix along an axis sums in NumPy's own order: one ulp)
+    ulp = 1e-15 if name in ("mesh", "survey") else 0.0          # (np.linalg.norm sums in its own order -- BLAS dot, pairwise: one ulp)
     assert ts.t.verified <= ulp
     assert symtrace.verify(sc, ts.t, worlds=300, seed=7) <= ulp
     # every coordinate a uniform draw of its own: restarts can be drawn on the device -- relay / convoy as World.reset_uniform's
@@ -650,6 +650,65 @@ def test_nearest_of_n_is_n_paths_and_sorted_values_need_no_decision(tmp_path):
     f = symtrace.trace(sc, predicate=False)          # (without the twin: list.sort() is Python's own -- it forks; the functions do not)
     assert f.paths["rew"] == [7] * 3 and f.paths["obs"] == [14] * 3 and symtrace.verify(sc, f, worlds=100) <= 1e-15
     assert sorted([3, 1, 2]) == [1, 2, 3] and np.argmin([3, 1, 2]) == 1
+
+
+def test_random_numbers_kept_outside_the_state_travel_as_per_world_parameters():
+    """`world.goal_pos = np.random.uniform(-0.8, 0.8, 2)` -- a goal that is coordinates, not an entity -- read by the callbacks: each
+    such draw occupies a pick slot (a "pick" among 2^24 values, read back as k * 2^-24), so seeded resets, device restarts and the
+    kernel's pick accessor serve it like any pick."""
+    class S(_Base):
+        def reset_world(self, world):
+            world.mark = np.random.choice(world.landmarks)
+            world.goal_pos = np.random.uniform(-0.8, +0.8, world.dim_p)
+            _Base.reset_world(self, world)
+            world.pace = np.random.uniform(0.5, 1.5)
+
+        def reward(self, agent, world):
+            return -np.linalg.norm(agent.state.p_pos - world.goal_pos) * world.pace - 0.1 * np.linalg.norm(agent.state.p_pos - world.mark.state.p_pos)
+
+        def observation(self, agent, world):
+            return np.concatenate([agent.state.p_pos, world.goal_pos - agent.state.p_pos])
+    sc = S()
+    ts = refstyle.trace_ref_scenario(sc, cache=False)
+    t = ts.t
+    n_lm = len(sc.make_world().landmarks)
+    assert t.real_picks() == 1 and t.pops == [n_lm] + [symtrace.PARAM_POP] * 3 and len(t.params) == 3 and t.verified <= 1e-15
+    assert "U" not in symtrace.inputs_of([n for row in t.obs for n in row] + list(t.rew))          # the callbacks read pick slots
+    assert ts.device_reset and "per-world parameters" in ts.report()                               # none of the three places an entity
+    t2 = symtrace.from_dict(json.loads(json.dumps(symtrace.to_dict(t))))
+    assert t2.params == t.params and t2.real_picks() == 1 and symtrace.hip_source(t2) == symtrace.hip_source(t)
+    assert "K(1)" in symtrace.hip_source(t) and "K(3)" in symtrace.hip_source(t)
+    # a seeded reset: the file's own stream; what the callbacks then see is the file's numbers to 24 bits
+    B = 12
+    w = ts.make_world(B, "cpu")
+    w.seed, w.rng_mode = 0, "device"
+    seeds = list(range(300, 300 + B))
+    ts.reset_world(w, None, seeds)
+    P, V = w.get_state(all_entities=True)
+    K = w.choice_i32.cpu().numpy().T
+    roots = [n for row in t.obs for n in row] + list(t.rew)
+    vals = symtrace.evaluate(roots, B, P=P.astype(np.float64), V=V.astype(np.float64), Cw=np.zeros((B, t.A, t.dim_c)), K=K)
+    cw = sc.make_world()
+    for b, s in enumerate(seeds):
+        np.random.seed(s)
+        sc.reset_world(cw)
+        assert K[b, 0] == cw.landmarks.index(cw.mark)
+        for k, e in enumerate(cw.agents + cw.landmarks):
+            assert np.abs(e.state.p_pos - P[b, k]).max() < 1e-6
+            e.state.p_pos = P[b, k].astype(np.float64)
+        want = np.concatenate([sc.observation(a, cw) for a in cw.agents] + [[sc.reward(a, cw)] for a in cw.agents])
+        assert np.abs(np.array([v[b] for v in vals]) - want).max() < 5e-7
+    # a draw that the callbacks read AND that places an entity: one source for both, so no device-side restart draw
+    class Both(_Base):
+        def reset_world(self, world):
+            _Base.reset_world(self, world)
+            world.spot = np.random.uniform(-1, +1, world.dim_p)
+            world.landmarks[0].state.p_pos = world.spot
+
+        def reward(self, agent, world):
+            return -np.linalg.norm(agent.state.p_pos - world.spot)
+    tb = refstyle.trace_ref_scenario(Both(), cache=False)
+    assert len(tb.t.params) == 2 and not tb.device_reset
 
 
 def test_rand_and_random_sample_are_the_draws_uniform_scales():
