@@ -103,7 +103,7 @@ class Graph(object):
             try:
                 v = {"neg": lambda: -x, "abs": lambda: abs(x), "sqrt": lambda: math.sqrt(x), "exp": lambda: math.exp(x),
                      "log": lambda: math.log(x), "tanh": lambda: math.tanh(x), "sin": lambda: math.sin(x), "cos": lambda: math.cos(x),
-                     "floor": lambda: float(math.floor(x)), "rint": lambda: float(np.rint(x))}[op]()
+                     "floor": lambda: float(math.floor(x)), "rint": lambda: float(np.rint(x)), "f32": lambda: float(np.float32(x))}[op]()
             except (ValueError, OverflowError):
                 v = float("nan")
             return self.const(v)
@@ -273,6 +273,10 @@ class Sym(object):
         zero = g.const(0.0)
         return Sym(_select_nodes(g.compare("lt", zero, self.n), g.const(1.0), _select_nodes(g.compare("lt", self.n, zero), g.const(-1.0), zero)))
 
+    def f32(self): return Sym(_Ctx.graph.unary("f32", self.n))          # .astype(np.float32): rounded to single precision
+    def isnan(self): return SymBool(_Ctx.graph.compare("ne", self.n, self.n))
+    def isinf(self): return SymBool(_Ctx.graph.compare("eq", _Ctx.graph.unary("abs", self.n), _Ctx.graph.const(float("inf"))))
+    def isfinite(self): return SymBool(_Ctx.graph.compare("lt", _Ctx.graph.unary("abs", self.n), _Ctx.graph.const(float("inf"))))
     def hypot(self, o): return (self * self + Sym(_lift(o)) * Sym(_lift(o))).sqrt()
     def square(self): return self * self
     def reciprocal(self): return 1.0 / self
@@ -679,9 +683,33 @@ def _p_method(name, obj, *args, **kw):
             obj[...] = np.sort(obj)
             return None
         return obj.sort(*args, **kw)
+    if name == "astype":        # obs.astype(np.float32): NumPy would ask every element for its __float__
+        if isinstance(obj, np.ndarray) and obj.dtype == object and _has_sym(obj) and len(args) == 1 and not kw:
+            return _as_dtype(obj, args[0])
+        return obj.astype(*args, **kw)
     if isinstance(obj, np.ndarray) and obj.dtype == object and _has_sym(obj):
         return getattr(np, name)(obj, *args, **kw)
     return getattr(obj, name)(*args, **kw)
+
+
+def _as_dtype(arr, dtype):
+    """an array that holds symbolic values, "converted": to float32 -> rounded to single precision (a node); to float64 / float /
+    object -> itself; to an integer type -> truncated"""
+    if dtype in (sym_float, float, object) or dtype is np.float64:
+        return arr.copy()
+    if dtype is sym_int:
+        dtype = int
+    try:
+        dt = np.dtype(dtype)
+    except TypeError:
+        raise TraceUnsupported("astype(%r) of state-dependent values" % (dtype,))
+    if dt == np.float64 or dt == object:
+        return arr.copy()
+    if dt == np.float32:
+        return _elementwise(lambda x: Sym(_lift(x)).f32(), arr)
+    if dt.kind in "iu":
+        return _elementwise(lambda x: Sym(_lift(x)).trunc() if isinstance(x, (Sym, SymBool)) else int(x), arr)
+    raise TraceUnsupported("astype(%s) of state-dependent values" % dt)
 
 
 _PREDICATION_HELPERS = {"_mpe_cmp": _p_cmp, "_mpe_method": _p_method, "_mpe_snap": _p_snap, "_mpe_sym": _is_symbolic, "_mpe_sel": _select_any, "_mpe_ifexp": _p_ifexp, "_mpe_and": _p_and,
@@ -791,7 +819,7 @@ def _predicate_tree(tree):
 
         def visit_Call(self, node):
             self.generic_visit(node)
-            if isinstance(node.func, ast.Attribute) and node.func.attr in ("min", "max", "any", "all", "clip", "argmin", "argmax", "sort") and \
+            if isinstance(node.func, ast.Attribute) and node.func.attr in ("min", "max", "any", "all", "clip", "argmin", "argmax", "sort", "astype") and \
                     not any(isinstance(a, ast.Starred) for a in node.args) and not any(k.arg is None for k in node.keywords):
                 return ast.Call(func=ast.Name(id="_mpe_method", ctx=ast.Load()),
                                 args=[ast.Constant(value=node.func.attr), node.func.value] + list(node.args), keywords=list(node.keywords))
@@ -812,7 +840,9 @@ def _predicate_tree(tree):
             return None
 
         def _block(self, stmts):
-            """a statement list: early-return chains at its end become one return"""
+            """a function body: early-return chains at its end become one return; `if T: return X` followed by more statements
+            that end in the function's only other return becomes `if T: r = X / else: <the statements>, r = Z` + `return r` (which
+            visit_If then predicates where the statements only assign)"""
             out = []
             for k, st in enumerate(stmts):
                 if isinstance(st, ast.If):
@@ -820,8 +850,30 @@ def _predicate_tree(tree):
                     if chain is not None:
                         out.append(ast.Return(value=chain))
                         return out
+                    if not st.orelse and len(st.body) == 1 and isinstance(st.body[0], ast.Return) and st.body[0].value is not None:
+                        rest = self._block(list(stmts[k + 1:]))
+                        if rest and isinstance(rest[-1], ast.Return) and rest[-1].value is not None and not self._returns_inside(rest[:-1]):
+                            rv = "_mpe_ret%d" % counter[0]
+                            counter[0] += 1
+
+                            def setr(value):
+                                return ast.Assign(targets=[ast.Name(id=rv, ctx=ast.Store())], value=value)
+                            out.append(ast.If(test=st.test, body=[setr(st.body[0].value)], orelse=rest[:-1] + [setr(rest[-1].value)]))
+                            out.append(ast.Return(value=ast.Name(id=rv, ctx=ast.Load())))
+                            return out
                 out.append(st)
             return out
+
+        def _returns_inside(self, stmts):
+            todo = list(stmts)
+            while todo:
+                n = todo.pop()
+                if isinstance(n, (ast.Return, ast.Yield, ast.YieldFrom)):
+                    return True
+                if isinstance(n, (ast.FunctionDef, ast.Lambda, ast.ClassDef)):
+                    continue
+                todo.extend(ast.iter_child_nodes(n))
+            return False
 
         def _decontinue(self, stmts):
             """`if T: continue [else: E]` followed by the rest of a loop body  ->  `if not T: [E] <rest>` (the same program; the rest
@@ -845,8 +897,8 @@ def _predicate_tree(tree):
             return node
 
         def visit_FunctionDef(self, node):
+            node.body = self._block(node.body)          # (on the file's own statements: what it builds is then visited like the rest)
             self.generic_visit(node)
-            node.body = self._block(node.body)
             return node
 
         def visit_If(self, node):
@@ -1352,7 +1404,31 @@ def _numpy_patches():
                 return x if t else y
             return _select_any(t, x, y)
         return _elementwise(pick, c, rest[0], rest[1])
+    maximum.reduce = lambda a, axis=0, **kw: amax(a, axis, **kw)          # (np.minimum.reduce(d): the ufunc's method)
+    minimum.reduce = lambda a, axis=0, **kw: amin(a, axis, **kw)
+    o_isclose, o_allclose = np.isclose, np.allclose
+
+    def isclose(a, b, rtol=1e-05, atol=1e-08, equal_nan=False):
+        if equal_nan or not _has_sym(a, b):
+            return o_isclose(a, b, rtol=rtol, atol=atol, equal_nan=equal_nan)
+        return _elementwise(lambda x, y: abs(Sym(_lift(x)) - Sym(_lift(y))) <= atol + rtol * abs(Sym(_lift(y))), a, b)
+
+    def allclose(a, b, rtol=1e-05, atol=1e-08, equal_nan=False):
+        if equal_nan or not _has_sym(a, b):
+            return o_allclose(a, b, rtol=rtol, atol=atol, equal_nan=equal_nan)
+        r = isclose(a, b, rtol, atol)
+        return sym_all(list(np.asarray(r, dtype=object).reshape(-1)))
+    o_array_equal = np.array_equal
+
+    def array_equal(a, b, *args, **kw):
+        if args or kw or not _has_sym(a, b):
+            return o_array_equal(a, b, *args, **kw)
+        aa, bb = np.asarray(a, dtype=object), np.asarray(b, dtype=object)
+        if aa.shape != bb.shape:
+            return False
+        return sym_all([x == y for x, y in zip(aa.reshape(-1), bb.reshape(-1))])
     out = {"maximum": maximum, "minimum": minimum, "clip": clip, "amin": amin, "amax": amax, "min": amin, "max": amax, "where": where,
+           "isclose": isclose, "allclose": allclose, "array_equal": array_equal,
            "any": reducer(o_any, sym_any), "all": reducer(o_all, sym_all), "count_nonzero": count_nonzero,
            "argmin": arg_extreme(np.argmin, "min"), "argmax": arg_extreme(np.argmax, "max"), "sort": sort, "argsort": argsort}
 
@@ -1383,8 +1459,9 @@ def _numpy_patches():
     for name, method in [("sqrt", "sqrt"), ("exp", "exp"), ("log", "log"), ("tanh", "tanh"), ("sin", "sin"), ("cos", "cos"),
                          ("floor", "floor"), ("ceil", "ceil"), ("rint", "rint"), ("trunc", "trunc"), ("sign", "sign"),
                          ("fabs", "__abs__"), ("square", "square"), ("reciprocal", "reciprocal")] + \
+                        [("isfinite", "isfinite"), ("isnan", "isnan"), ("isinf", "isinf")] + \
                         [(n, None) for n in ("arctan", "arcsin", "arccos", "sinh", "cosh", "log1p", "expm1", "log2", "log10", "cbrt",
-                                             "isfinite", "isnan", "isinf", "degrees", "radians")]:
+                                             "degrees", "radians")]:
         out[name] = unary(name, method or "_no_such_method_")
 
     return out
@@ -1417,7 +1494,31 @@ def _ctor_patches():
             return r.astype(object) if r.dtype.kind == "f" else r
         f.__name__ = name
         return f
-    return {name: ctor(name, like) for name, like in _CTOR_NAMES}
+    out = {name: ctor(name, like) for name, like in _CTOR_NAMES}
+
+    def with_dtype(name):          # np.array(parts, dtype=np.float32), np.asarray(row, dtype=np.float32)
+        orig = getattr(np, name)
+
+        def f(a, dtype=None, *args, **kw):
+            if dtype is None or args or not _has_sym(a):
+                return orig(a, dtype, *args, **kw) if dtype is not None else orig(a, *args, **kw)
+            return _as_dtype(orig(a, dtype=object, **kw), dtype)
+        f.__name__ = name
+        return f
+    out["array"], out["asarray"] = with_dtype("array"), with_dtype("asarray")
+
+    def scalar(orig, conv):
+        class _Scalar(orig):          # np.float32(x) of a symbolic x; isinstance(v, np.float32) keeps working
+            def __new__(cls, x=0, *args):
+                if isinstance(x, (Sym, SymBool)) and not args:
+                    return conv(Sym(_lift(x)))
+                if isinstance(x, np.ndarray) and x.dtype == object and _has_sym(x) and not args:
+                    return _as_dtype(x, orig)
+                return orig(x, *args)
+        _Scalar.__name__ = orig.__name__
+        return _Scalar
+    out["float32"], out["float64"] = scalar(np.float32, lambda x: x.f32()), scalar(np.float64, lambda x: x)
+    return out
 
 
 class _NumpyProxy(object):
@@ -2142,6 +2243,8 @@ def evaluate(roots, B, P=None, V=None, Cw=None, K=None, U=None, dtype=np.float64
                     f = q - np.floor(q)
                     d = np.minimum(f, 1.0 - f) * np.abs(a[1])
                     np.minimum(_margin, np.where(np.isfinite(d), d, np.inf), out=_margin)
+            elif op == "f32":
+                v = a[0].astype(np.float32).astype(a[0].dtype)
             elif op in ("floor", "rint"):
                 v = np.floor(a[0]) if op == "floor" else np.rint(a[0])
                 if _margin is not None:      # how far the argument is from the next step of the staircase
@@ -2197,12 +2300,17 @@ def random_states(t, R, rs, spread=1.0):
     return P, V, Cw[:, :, :t.dim_c] if t.dim_c else Cw[:, :, :0]
 
 
-def verify(scenario, t, worlds=96, seed=0, tol=1e-9):
+def verify(scenario, t, worlds=96, seed=0, tol=None):
     """Evaluate the trace with NumPy (fp64) on `worlds` random worlds and compare with the file's own reset_world / observation /
     reward / done run concretely on the same worlds.  Returns the largest scaled difference; raises TraceUnsupported when the
     trace does not reproduce the file (hidden state, randomness, something the tracer mis-models)."""
     rs = np.random.RandomState(seed)
     R = int(worlds)
+    if tol is None:
+        # a file that computes in float32 (np.float32(x) * y, arrays of dtype float32) rounds after every operation; the graph rounds
+        # where the file converts (f32 nodes) and computes in double in between: single-precision noise, not a modelling error
+        every = [n for row in t.obs for n in row] + list(t.rew) + [n for row in (getattr(t, "info", None) or []) for n in row]
+        tol = 2e-6 if any(n.op == "f32" for n in topo(every)) else 1e-9
     rng_state = np.random.get_state()
     try:
         cw = scenario.make_world()
@@ -2344,6 +2452,8 @@ def evaluate_torch(roots, B, K=None, U=None, P=None, V=None, Cw=None, device=Non
             v = torch.pow(a[0], a[1])
         elif op == "mod":
             v = torch.remainder(a[0], a[1])
+        elif op == "f32":
+            v = a[0]
         elif op == "floor":
             v = torch.floor(a[0])
         elif op == "rint":
@@ -2431,6 +2541,9 @@ def _emit(roots, lines, names, shared=None):
             e = "atan2f(%s, %s)" % (ref(a[0]), ref(a[1]))
         elif op == "pow":
             e = "powf(%s, %s)" % (ref(a[0]), ref(a[1]))
+        elif op == "f32":          # (the device computes in single precision anyway)
+            names[n.uid] = ref(a[0])
+            continue
         elif op in ("floor", "rint"):
             e = "%sf(%s)" % (op, ref(a[0]))
         elif op == "mod":      # NumPy's / Python's %: fmod, moved to the divisor's sign

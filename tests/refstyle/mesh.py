@@ -66,4 +66,5 @@ class Scenario(BaseScenario):
     def observation(self, agent, world):
         Y = np.array([l.state.p_pos for l in world.landmarks]) - agent.state.p_pos
         near = np.linalg.norm(Y, axis=1) < 0.6
-        return np.concatenate([agent.state.p_vel, agent.state.p_pos, (Y * near[:, None]).reshape(-1), Y.max(axis=0), np.clip(Y, -0.5, 0.5).min(axis=0)])
+        row = np.concatenate([agent.state.p_vel, agent.state.p_pos, (Y * near[:, None]).reshape(-1), Y.max(axis=0), np.clip(Y, -0.5, 0.5).min(axis=0)])
+        return row.astype(np.float32)          # (the gym habit: observations in single precision)

@@ -892,6 +892,72 @@ def test_array_constructors_are_the_files_own_and_compiled_library_code_keeps_nu
     assert S.observation.__globals__["np"] is np
 
 
+_FLOAT32_FILE = '''
+import numpy as np
+from multiagent.core import World, Agent, Landmark
+from multiagent.scenario import BaseScenario
+
+
+class Scenario(BaseScenario):
+    def make_world(self):
+        world = World()
+        world.agents = [Agent() for _ in range(2)]
+        for i, a in enumerate(world.agents):
+            a.name, a.silent = "agent %d" % i, True
+        world.landmarks = [Landmark() for _ in range(3)]
+        for l in world.landmarks:
+            l.movable, l.collide = False, False
+        self.reset_world(world)
+        return world
+
+    def reset_world(self, world):
+        for e in world.agents + world.landmarks:
+            e.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            e.state.p_vel = np.zeros(world.dim_p)
+        for a in world.agents:
+            a.state.c = np.zeros(world.dim_c)
+
+    def reward(self, agent, world):
+        d = np.array([np.linalg.norm(agent.state.p_pos - l.state.p_pos) for l in world.landmarks], dtype=np.float32)
+        if np.isnan(d).any() or not np.all(np.isfinite(d)):
+            return 0.0
+        bonus = 1.0 if np.allclose(agent.state.p_pos, world.landmarks[0].state.p_pos, atol=0.2) else 0.0
+        same = 0.5 if np.array_equal(agent.state.p_pos, world.landmarks[1].state.p_pos) else 0.0
+        return float(-np.minimum.reduce(d) + np.float32(0.1) * np.float32(d[1]) + bonus + same)
+
+    def observation(self, agent, world):
+        parts = [agent.state.p_vel, agent.state.p_pos] + [l.state.p_pos - agent.state.p_pos for l in world.landmarks]
+        return np.concatenate(parts).astype(np.float32)          # the gym habit
+'''
+
+
+def test_float32_observations_and_nan_guards(tmp_path):
+    """`np.concatenate(parts).astype(np.float32)`, `np.array(..., dtype=np.float32)`, `np.float32(x)`: a node that rounds to single
+    precision (exactly what the file computes; a no-op on the device, which is fp32 anyway); np.isnan / isfinite guards,
+    np.allclose, np.array_equal, np.minimum.reduce: nodes, no fork."""
+    path = tmp_path / "float32.py"
+    path.write_text(_FLOAT32_FILE)
+    sc = mpe.scenarios.load(str(path)).Scenario()
+    t = symtrace.trace(sc)
+    assert t.predicated and max(t.paths["obs"] + t.paths["rew"]) == 1
+    # the observation (converted once, at the end) bit for bit; the reward, which the file computes IN float32 (rounded after every
+    # operation where the graph rounds only at the conversions), to single-precision noise
+    assert symtrace.verify(sc, t, worlds=200) < 1e-7
+    ops = set(n.op for n in symtrace.topo(t.rew + [n for row in t.obs for n in row]))
+    assert "f32" in ops
+    src = symtrace.hip_source(t)
+    assert "f32" not in src.split("traced_obs", 1)[1]                   # (no code for it)
+    B = 2000
+    P, V, Cw = symtrace.random_states(t, B, np.random.RandomState(1))
+    rows, rew, _ = _host_run_generated(t, P.astype(np.float32).astype(np.float64), V.astype(np.float32).astype(np.float64), Cw, np.zeros((B, 0), np.int64), tmp_path, "f32")
+    roots = [n for row in t.obs for n in row] + list(t.rew)
+    Pf, Vf = P.astype(np.float32).astype(np.float64), V.astype(np.float32).astype(np.float64)
+    vals = symtrace.evaluate(roots, B, P=Pf, V=Vf, Cw=Cw, K=np.zeros((B, 0), np.int64))
+    ok = symtrace.decision_margin(roots, B, P=Pf, V=Vf, Cw=Cw, K=np.zeros((B, 0), np.int64)) > 2e-6
+    want = np.stack(vals[:len(t.obs[0])], axis=1)
+    assert np.abs(rows[0][ok] - want[ok]).max() <= 1e-5 and np.abs(rew[ok, 0] - vals[-2][ok]).max() <= 1e-5
+
+
 def test_what_is_still_not_modelled_falls_back_with_the_reason():
     class Heavy(_Base):
         def observation(self, agent, world):
@@ -899,12 +965,12 @@ def test_what_is_still_not_modelled_falls_back_with_the_reason():
 
     class Close(_Base):
         def reward(self, agent, world):
-            return 1.0 if np.allclose(agent.state.p_pos, world.landmarks[0].state.p_pos, atol=0.1) else 0.0
+            return float(np.sum(np.isclose(agent.state.p_pos, world.landmarks[0].state.p_pos, equal_nan=True)))
 
     class Arc(_Base):
         def reward(self, agent, world):
             return float(np.arcsin(np.clip(agent.state.p_pos[0], -1, 1)))
-    for cls, why in ((Heavy, "heaviside"), (Close, "isfinite"), (Arc, "arcsin of a state-dependent value")):
+    for cls, why in ((Heavy, "heaviside"), (Close, "isfinite|isnan"), (Arc, "arcsin of a state-dependent value")):
         with pytest.raises(symtrace.TraceUnsupported, match=why):
             symtrace.trace(cls())
 
