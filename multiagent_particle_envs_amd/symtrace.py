@@ -983,6 +983,45 @@ def source_file(klass):
     return inspect.getsourcefile(klass)
 
 
+def _twin_neighbours(space, path):
+    """The user's own helper modules next to the file (`import helpers`, `from helpers import dist`), predicated the same way:
+    the twin's namespace gets twins of those modules / of the functions it imported from them (one level; a helper that cannot
+    be re-compiled stays as it is -- its `if`s then fork)."""
+    import ast
+    import os
+    import types
+    home = os.path.dirname(os.path.abspath(path))
+    pkg = __name__.rsplit(".", 1)[0]
+    twins = {}
+
+    def twin_of(g):
+        f = g.get("__file__")
+        if not (isinstance(f, str) and os.path.abspath(f).startswith(home + os.sep)) or g.get("__name__", "").startswith(pkg + ".") \
+                or os.path.abspath(f) == os.path.abspath(path):
+            return None
+        if id(g) not in twins:
+            try:
+                with open(f) as fh:
+                    tree = _predicate_tree(ast.parse(fh.read(), filename=f))
+                m = types.ModuleType(g.get("__name__", "helper") + "__predicated")
+                m.__dict__.update({"__file__": f})
+                m.__dict__.update(_PREDICATION_HELPERS)
+                exec(compile(tree, f, "exec"), m.__dict__)
+                twins[id(g)] = m
+            except Exception:
+                twins[id(g)] = None
+        return twins[id(g)]
+    for name, v in list(space.items()):
+        if isinstance(v, types.ModuleType):
+            m = twin_of(v.__dict__)
+            if m is not None:
+                space[name] = m
+        elif isinstance(v, types.FunctionType) and v.__globals__ is not space:
+            m = twin_of(v.__globals__)
+            if m is not None and isinstance(getattr(m, v.__name__, None), types.FunctionType):
+                space[name] = getattr(m, v.__name__)
+
+
 def predicated_twin(scenario):
     """A twin of `scenario` whose class was re-compiled from its own source with value-only control flow predicated (above); the
     twin shares the scenario's instance attributes.  Raises TraceUnsupported when the source is not available / does not recompile."""
@@ -1000,6 +1039,7 @@ def predicated_twin(scenario):
         space.update(_PREDICATION_HELPERS)
         with patched_math():
             exec(code, space)
+            _twin_neighbours(space, path)
         twin_class = space[klass.__name__]
     except TraceUnsupported:
         raise
@@ -1640,6 +1680,21 @@ def injected_builtins(scenario):
             f = getattr(f, "__func__", f)
             if isinstance(f, types.FunctionType) and not any(f.__globals__ is d for d in spaces):
                 spaces.append(f.__globals__)
+    # ... and the user's own helper modules next to the file (`import helpers`, `from helpers import dist`): the same names there
+    try:
+        import os
+        home = os.path.dirname(os.path.abspath(source_file(type(scenario))))
+    except Exception:
+        home = None
+    if home:
+        def neighbour(d):
+            f = d.get("__file__")
+            return isinstance(f, str) and os.path.abspath(f).startswith(home + os.sep) and not d.get("__name__", "").startswith(pkg + ".")
+        for d in list(spaces):
+            for v in list(d.values()):
+                g = v.__dict__ if isinstance(v, types.ModuleType) else getattr(getattr(v, "__func__", v), "__globals__", None)
+                if isinstance(g, dict) and neighbour(g) and not any(g is x for x in spaces):
+                    spaces.append(g)
     saved = [(d, name, d.get(name, _MISSING)) for d in spaces for name in _INJECTED]
     ctors = _ctor_patches()
     by_original = {getattr(np, name): f for name, f in ctors.items()}

@@ -958,6 +958,107 @@ def test_float32_observations_and_nan_guards(tmp_path):
     assert np.abs(rows[0][ok] - want[ok]).max() <= 1e-5 and np.abs(rew[ok, 0] - vals[-2][ok]).max() <= 1e-5
 
 
+_HELPERS_MODULE = '''import numpy as np
+
+def dist(a, b):
+    return np.sqrt(np.sum(np.square(a.state.p_pos - b.state.p_pos)))
+
+def penalty(d):
+    if d < 0.2:
+        return 1.0
+    return 0.0
+
+def row_of(agent, world):
+    out = np.zeros(4)
+    out[:2] = agent.state.p_pos
+    out[2:] = agent.state.p_vel
+    return out
+'''
+
+_STRUCTURED_FILE = '''import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+from multiagent.core import World, Agent, Landmark
+from multiagent.scenario import BaseScenario
+import helpers
+from helpers import dist
+
+RADIUS = 0.3
+
+
+def inside(p, r=RADIUS):
+    if abs(p[0]) < r and abs(p[1]) < r:
+        return True
+    return False
+
+
+class Base(BaseScenario):
+    n_agents = 3
+
+    def make_world(self):
+        world = World()
+        world.agents = [Agent() for _ in range(self.n_agents)]
+        for i, a in enumerate(world.agents):
+            a.name, a.silent = "agent %d" % i, True
+        world.landmarks = [Landmark() for _ in range(2)]
+        for l in world.landmarks:
+            l.movable, l.collide = False, False
+        self.reset_world(world)
+        return world
+
+    def reset_world(self, world):
+        for e in world.agents + world.landmarks:
+            e.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            e.state.p_vel = np.zeros(world.dim_p)
+        for a in world.agents:
+            a.state.c = np.zeros(world.dim_c)
+
+    @staticmethod
+    def closeness(a, b):
+        return np.exp(-dist(a, b))
+
+    @property
+    def weight(self):
+        return 0.5
+
+    def reward(self, agent, world):
+        r = -sum(dist(agent, l) for l in world.landmarks) * self.weight
+        r -= sum(helpers.penalty(dist(agent, o)) for o in world.agents if o is not agent)
+        r += 1.0 if inside(agent.state.p_pos) else 0.0
+        return r + self.closeness(agent, world.landmarks[0])
+
+
+class Scenario(Base):
+    n_agents = 4
+
+    def observation(self, agent, world):
+        return np.concatenate([helpers.row_of(agent, world)] + [l.state.p_pos - agent.state.p_pos for l in world.landmarks])
+'''
+
+
+def test_helper_modules_next_to_the_file_inheritance_staticmethods_and_properties(tmp_path):
+    """A scenario split over files: `import helpers` / `from helpers import dist` (the user's own module next to the scenario file),
+    a Scenario that inherits from a base class, @staticmethod, @property, module-level functions with `if`s.  The helper module gets
+    the same treatment as the file -- the injected names while tracing, a predicated twin -- so `np.zeros` rows and `if d < 0.2`
+    inside it neither fail nor fork."""
+    import sys
+    (tmp_path / "helpers.py").write_text(_HELPERS_MODULE)
+    (tmp_path / "structured.py").write_text(_STRUCTURED_FILE)
+    before = list(sys.path)
+    try:
+        sc = mpe.scenarios.load(str(tmp_path / "structured.py")).Scenario()
+        t = symtrace.trace(sc)
+        assert t.predicated and t.A == 4 and max(t.paths["obs"] + t.paths["rew"]) == 1
+        assert symtrace.verify(sc, t, worlds=150) == 0.0
+        f = symtrace.trace(sc, predicate=False)                        # (without twins: the helper's `if` forks, once per other agent)
+        assert min(f.paths["rew"]) > 8 and symtrace.verify(sc, f, worlds=50) == 0.0
+        import helpers
+        assert helpers.np is np and "float" not in helpers.__dict__    # the helper module is itself again
+    finally:
+        sys.path[:] = before
+        sys.modules.pop("helpers", None)
+
+
 def test_what_is_still_not_modelled_falls_back_with_the_reason():
     class Heavy(_Base):
         def observation(self, agent, world):
