@@ -1197,3 +1197,13 @@ def test_the_math_module_accepts_symbolic_values_while_a_file_is_traced(tmp_path
     assert (math.sqrt, math.exp, math.atan2) == before and math.sqrt(9.0) == 3.0
     assert t.predicated and symtrace.verify(sc, t, worlds=200) <= 1e-15
     assert {"sqrt", "exp", "cos", "atan2", "tanh", "log", "abs"} <= set(n.op for n in symtrace.topo(t.rew))
+
+
+def test_trace_report_tool_says_what_make_env_would_do():
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(HERE), "tools", "trace_report.py")
+    r = subprocess.run([sys.executable, tool, os.path.join(FIXTURES, "survey.py")], capture_output=True, text=True)
+    assert r.returncode == 0 and "TRACED" in r.stdout and "per-world parameters" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, tool, os.path.join(FIXTURES, "patrol.py")], capture_output=True, text=True)
+    assert r.returncode == 1 and "HOST PATH -- scripted agents" in r.stdout, r.stdout + r.stderr
