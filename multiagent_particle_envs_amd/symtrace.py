@@ -817,7 +817,37 @@ def _predicate_tree(tree):
                                           for k, o in enumerate(node.ops)])
             return node          # (`is`, `in`, chains through calls: as written)
 
+        def _filtered(self, node):
+            """sum / len / min / max / any / all over ONE comprehension with `if` filters: the filter moved into the element
+            (`sum(E for x in xs if C)` -> `sum(E if C else 0 ...)`), so that a symbolic C selects instead of deciding how long a list is.
+            The same value whenever C is an ordinary truth value (min / max of nothing: +-inf instead of ValueError)."""
+            if not (isinstance(node.func, ast.Name) and node.func.id in ("sum", "len", "min", "max", "any", "all") and len(node.args) == 1
+                    and not node.keywords and isinstance(node.args[0], (ast.GeneratorExp, ast.ListComp))):
+                return None
+            comp = node.args[0]
+            if len(comp.generators) != 1 or not comp.generators[0].ifs or comp.generators[0].is_async:
+                return None
+            gen = comp.generators[0]
+            cond = gen.ifs[0] if len(gen.ifs) == 1 else ast.BoolOp(op=ast.And(), values=list(gen.ifs))
+            kind = node.func.id
+            inf = ast.Call(func=ast.Name(id="float", ctx=ast.Load()), args=[ast.Constant(value="inf")], keywords=[])
+            if kind in ("sum", "len"):
+                elt = ast.IfExp(test=cond, body=comp.elt if kind == "sum" else ast.Constant(value=1), orelse=ast.Constant(value=0))
+                func = "sum"
+            elif kind in ("min", "max"):
+                elt = ast.IfExp(test=cond, body=comp.elt, orelse=inf if kind == "min" else ast.UnaryOp(op=ast.USub(), operand=inf))
+                func = kind
+            elif kind == "any":
+                elt, func = ast.BoolOp(op=ast.And(), values=[cond, comp.elt]), "any"
+            else:
+                elt, func = ast.BoolOp(op=ast.Or(), values=[ast.UnaryOp(op=ast.Not(), operand=cond), comp.elt]), "all"
+            new_gen = ast.comprehension(target=gen.target, iter=gen.iter, ifs=[], is_async=0)
+            return ast.Call(func=ast.Name(id=func, ctx=ast.Load()), args=[ast.ListComp(elt=elt, generators=[new_gen])], keywords=[])
+
         def visit_Call(self, node):
+            moved = self._filtered(node)
+            if moved is not None:
+                node = moved
             self.generic_visit(node)
             if isinstance(node.func, ast.Attribute) and node.func.attr in ("min", "max", "any", "all", "clip", "argmin", "argmax", "sort", "astype") and \
                     not any(isinstance(a, ast.Starred) for a in node.args) and not any(k.arg is None for k in node.keywords):

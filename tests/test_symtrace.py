@@ -637,6 +637,62 @@ class Scenario(BaseScenario):
 '''
 
 
+_COUNTING_FILE = '''
+import numpy as np
+from multiagent.core import World, Agent, Landmark
+from multiagent.scenario import BaseScenario
+
+
+class Scenario(BaseScenario):
+    def make_world(self):
+        world = World()
+        world.agents = [Agent() for _ in range(5)]
+        for i, a in enumerate(world.agents):
+            a.name, a.silent, a.size = "agent %d" % i, True, 0.1
+        world.landmarks = [Landmark() for _ in range(6)]
+        for l in world.landmarks:
+            l.movable, l.collide = False, False
+        self.reset_world(world)
+        return world
+
+    def reset_world(self, world):
+        for e in world.agents + world.landmarks:
+            e.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            e.state.p_vel = np.zeros(world.dim_p)
+        for a in world.agents:
+            a.state.c = np.zeros(world.dim_c)
+
+    def near(self, a, b, r):
+        return np.linalg.norm(a.state.p_pos - b.state.p_pos) < r
+
+    def reward(self, agent, world):
+        bumps = len([a for a in world.agents if a is not agent and self.near(a, agent, 0.2)])
+        reach = sum(np.linalg.norm(l.state.p_pos - agent.state.p_pos) for l in world.landmarks if self.near(l, agent, 0.8))
+        crowd = sum(1 for a in world.agents if self.near(a, agent, 0.5) if a is not agent)
+        best = min(np.linalg.norm(l.state.p_pos - agent.state.p_pos) for l in world.landmarks if l.state.p_pos[0] > -5.0)
+        north = 1.0 if any(l.state.p_pos[1] > 0 for l in world.landmarks if self.near(l, agent, 0.6)) else 0.0
+        calm = 1.0 if all(abs(a.state.p_vel[0]) < 0.5 for a in world.agents if self.near(a, agent, 0.6)) else 0.0
+        return -bumps - 0.1 * reach - 0.01 * crowd - best + north + calm
+
+    def observation(self, agent, world):
+        return np.concatenate([agent.state.p_vel, agent.state.p_pos] + [a.state.p_pos - agent.state.p_pos for a in world.agents if a is not agent])
+'''
+
+
+def test_counting_and_summing_over_filtered_comprehensions_does_not_fork(tmp_path):
+    """`len([a for a in others if touching(a)])`, `sum(d(l) for l in landmarks if near(l))`, min / any / all over a filtered
+    generator: how LONG the list is would be a decision per element (2^N); the twin moves the filter into the element (`E if C else
+    0`), which selects.  A filter that is an ordinary truth value (`if a is not agent`) filters as written."""
+    path = tmp_path / "counting.py"
+    path.write_text(_COUNTING_FILE)
+    sc = mpe.scenarios.load(str(path)).Scenario()
+    t = symtrace.trace(sc)
+    assert t.predicated and max(t.paths["obs"] + t.paths["rew"]) == 1 and [len(r) for r in t.obs] == [12] * 5
+    assert symtrace.verify(sc, t, worlds=300) <= 1e-15
+    with pytest.raises(symtrace.TraceUnsupported, match="control-flow paths"):
+        symtrace.trace(sc, predicate=False)
+
+
 def test_nearest_of_n_is_n_paths_and_sorted_values_need_no_decision(tmp_path):
     """np.argmin / `min(objects, key=...)`: which element is smallest is a decision with N outcomes -- N paths (one test per candidate),
     where the running comparison of NumPy / Python forks 2^(N-1) ways; the VALUES of sorted() / np.sort / list.sort() come out of a
@@ -1105,13 +1161,18 @@ def _host_run_generated(tr, P, V, Cw, K, tmp_path, tag):
     return [out[:, off[i]:off[i + 1]] for i in range(tr.A)], out[:, off[-1]:off[-1] + tr.A], out[:, off[-1] + tr.A:]
 
 
-@pytest.mark.parametrize("name", ["convoy", "relay", "survey", "simple_tag", "simple_world_comm", "simple_crypto", "nav8", "vector8"])
+@pytest.mark.parametrize("name", ["convoy", "relay", "survey", "herd_info", "simple_tag", "simple_world_comm", "simple_crypto", "nav8", "vector8"])
 def test_generated_code_on_the_host_against_the_numpy_evaluation(name, tmp_path):
     """The code GENERATOR without a GPU: traced_obs / traced_shared / traced_rew as symtrace.hip_source writes them, compiled with
     g++ (plain-C++ stand-ins for the device intrinsics) and run on random worlds, against the fp64 NumPy evaluation of the same
     graphs -- fixtures, committed traces of the reference's files, and an 8-agent cooperative-navigation file whose shared reward
     terms go through traced_shared."""
-    if name in ("convoy", "relay", "survey"):
+    if name == "herd_info":          # benchmark_data's program (a count over a filtered generator): its rows in the place of the observations
+        import copy
+        full = symtrace.trace(mpe.scenarios.load(os.path.join(FIXTURES, "herd.py")).Scenario(), want_info=True)
+        tr = copy.copy(full)
+        tr.obs = [list(row) for row in full.info]
+    elif name in ("convoy", "relay", "survey"):
         tr = symtrace.trace(mpe.scenarios.load(os.path.join(FIXTURES, name + ".py")).Scenario())
     elif name == "nav8":
         path = tmp_path / "nav8.py"
