@@ -247,13 +247,15 @@ class Sym(object):
     def __mod__(self, o): return self._b("mod", o)
     def __rmod__(self, o): return self._b("mod", o, True)
 
+    # x // y as Python / NumPy compute it: (x - x % y) / y, an exact multiple of y up to rounding, to the nearest integer --
+    # floor(x / y) is one too many where x / y rounds UP to an integer (1.0 // 0.1 is 9.0, floor(1.0 / 0.1) is 10.0)
     def __floordiv__(self, o):
-        q = self._b("div", o)
-        return q if q is NotImplemented else q.floor()
+        m = self._b("mod", o)
+        return m if m is NotImplemented else ((self - m) / o).rint()
 
     def __rfloordiv__(self, o):
-        q = self._b("div", o, True)
-        return q if q is NotImplemented else q.floor()
+        m = self._b("mod", o, True)
+        return m if m is NotImplemented else ((o - m) / self).rint()
 
     # rounding: floor / ceil / rint are what math.floor, math.ceil, np.floor, np.ceil, np.rint, np.round and round() ask for
     def floor(self): return Sym(_Ctx.graph.unary("floor", self.n))
