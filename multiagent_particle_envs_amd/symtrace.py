@@ -1762,6 +1762,21 @@ _MISSING = object()
 
 
 # ---- the trace of one scenario ----------------------------------------------------------------------------------------------
+class _NotTraced(object):
+    """What stands where a callback must not look while it is traced: any use says what was read."""
+
+    def __init__(self, what):
+        object.__setattr__(self, "_what", what)
+
+    def _refuse(self, *a, **k):
+        raise TraceUnsupported("a callback reads %s: only the world's state is traced (docs/TRACER.md)" % object.__getattribute__(self, "_what"))
+
+    __getattr__ = __getitem__ = __iter__ = __len__ = __array__ = __float__ = __bool__ = __neg__ = __abs__ = _refuse
+    __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __rtruediv__ = __pow__ = __rpow__ = _refuse
+    __lt__ = __le__ = __gt__ = __ge__ = __eq__ = __ne__ = _refuse
+    __hash__ = None
+
+
 def _obj_vec(nodes):
     out = np.empty(len(nodes), dtype=object)
     out[:] = [Sym(n) for n in nodes]
@@ -2024,8 +2039,8 @@ def _trace_once(scenario, t, forced, want_done, max_paths, want_info=False):
     for i, a in enumerate(agents):
         # core.py:171-177: a silent agent's utterance is zeros; a speaking one's is its last communication action
         a.state.c = np.zeros(dc) if (a.silent or dc == 0) else _obj_vec([g.node("C", (), (i, c)) for c in range(dc)])
-        a.action.u = None
-        a.action.c = None
+        a.action.u = _NotTraced("agent.action.u (the action of the current step)")
+        a.action.c = _NotTraced("agent.action.c (the action of the current step)")
     # ---- the callbacks, every path -------------------------------------------------------------------------------------------
     out["obs"], out["rew"], out["done"] = [], [], []
     paths = {"obs": [], "rew": [], "done": []}

@@ -177,7 +177,7 @@ def test_what_the_tracer_refuses_and_why():
             w.agents[0].size = float(np.random.uniform(0.05, 0.2))
             return w
 
-    for cls, why in ((RandomSizes, "different entity counts or physics constants"), (Draws, "draws random numbers"), (Scripted, "scripted agents"), (ReadsAction, "TypeError|NoneType"),
+    for cls, why in ((RandomSizes, "different entity counts or physics constants"), (Draws, "draws random numbers"), (Scripted, "scripted agents"), (ReadsAction, "reads agent.action.u"),
                      (Unstored, "kept outside the state"), (Explodes, "control-flow paths"), (Concretises, "Python float")):
         with pytest.raises(symtrace.TraceUnsupported, match=why):
             symtrace.trace(cls(), max_paths=512 if cls is Explodes else None)
