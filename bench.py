@@ -524,9 +524,14 @@ def roofline_entry(leg, k_us, B, mode, floor_us, timing=None):
     tr = pmc_traffic("%s_A%d_L%d_B%d" % (leg.scenario, leg.A, leg.Lm, B)) if mode in ("graph", "eager") else None
     moves_pool = 25 * leg.A * B * 20
     resident = per_launch + moves_pool < L3_BYTES
+    kt = (tr or {}).get("kernel_trace")
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": tr["traffic_bytes_per_launch"] if tr else None,
             "traffic_source": tr["source"] if tr else None,
+            # the committed `rocprofv3 --kernel-trace --stats` durations of the same launch (profiles/), beside the live slope
+            "kernel_us_rocprof": {"mean": kt["mean_us"], "median": kt["median_us"], "source": kt["source"]} if kt else None,
+            "frac_at_rocprof_mean": per_launch / (kt["mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS if kt else None,
+            "regime_label": "l3+launch" if resident else "hbm",
             "regime": ("working set (%.0f MB per launch + %.0f MB of moves) fits the 256 MiB Infinity Cache: the PMC "
                        "'traffic' is fabric requests, largely L3 hits; the launch is launch/latency-limited, not HBM-limited"
                        % (per_launch / 1e6, moves_pool / 1e6)) if resident else
@@ -786,6 +791,114 @@ def box_fingerprint(torch, dev, smi=True):
     return fp
 
 
+LINE_BUDGET = 4096          # the driver parses rank 0's ONE line; round 5's 20 KB line came back `parsed: null`
+
+
+def sig(x, n=6):
+    """x rounded to n significant digits (floats only; everything else unchanged) -- the printed line is for reading."""
+    if isinstance(x, bool) or not isinstance(x, float) or x == 0.0 or not math.isfinite(x):
+        return x
+    return round(x, n - 1 - int(math.floor(math.log10(abs(x)))))
+
+
+def _pick(d, keys):
+    return {k: sig(d[k]) for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(out, full_path=None):
+    """The ONE line rank 0 prints: the contract's keys + `roofline` + `cpu_baseline` + one figure per BASELINE config, under
+    LINE_BUDGET bytes.  Everything else (`extra.*`, per-rank records, the box fingerprint, timing raw data, the long prose
+    notes) is the full record, written to `full_path` and named in `full_record`."""
+    cfg, roof, ex = out["config"], out["roofline"], out.get("extra", {})
+    line = {k: sig(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data") if k in out}
+    line["timed_steps"], line["timed_region_s"] = out.get("timed_steps"), sig(out.get("timed_region_s"), 4)
+    line["config"] = _pick(cfg, ("workload", "protocol", "batch_per_gpu", "global_batch", "mode", "timed_steps", "timed_region_s",
+                                 "repeats", "graph_replays_in_timed_region", "launcher", "barrier_backend", "ranks_seen",
+                                 "distinct_gpus", "sharding"))
+    line["config"]["workload"] = str(cfg.get("workload", ""))[:160]
+    line["config"]["timed_region"] = ("ms_per_step = timed_region_s / timed_steps: a graph of consecutive steps replayed until the "
+                                      "region holds >= %.1f s, median of %s repeats (--steps sets the graph's unit, not the region)"
+                                      % (cfg.get("region_ms", MIN_REGION_MS) * 1e-3, cfg.get("repeats")))
+    if cfg.get("scaling_diagnostic"):
+        line["config"]["value_over_n_times_rank0_solo"] = sig(cfg["scaling_diagnostic"]["value_over_n_times_rank0_solo"], 4)
+    if out.get("per_gpu_value"):
+        line["per_gpu_value"] = _pick(out["per_gpu_value"], ("min", "median", "max", "ranks"))
+    line["roofline"] = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_timed_region", "regime_label",
+                                    "l3_resident", "kernel", "kernel_us_per_launch", "kernel_us_rocprof",
+                                    "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch", "env_steps_per_launch",
+                                    "launch_floor_us", "measured_copy_GBps", "frac_of_measured_copy", "per_gpu"))
+    if "kernel_us_per_launch_by_rank" in roof:
+        line["roofline"]["kernel_us_per_launch_by_rank"] = [sig(x, 4) for x in roof["kernel_us_per_launch_by_rank"]]
+    hb = ex.get("hbm_resident")
+    if hb and "roofline" in hb:      # the same kernel where the working set cannot sit in the Infinity Cache: THE HBM fraction
+        line["roofline"]["hbm_resident_frac"] = sig(hb["roofline"]["frac"])
+        line["roofline"]["hbm_resident"] = {"worlds": hb["roofline"]["env_steps_per_launch"],
+                                            "kernel_us_per_launch": sig(hb["roofline"]["kernel_us_per_launch"]),
+                                            "kernel_us_rocprof": hb["roofline"].get("kernel_us_rocprof"),
+                                            "traffic": hb["roofline"].get("traffic"),
+                                            "algorithmic_bytes_per_launch": hb["roofline"]["algorithmic_bytes_per_launch"],
+                                            "value": sig(hb["value"]), "frac_timed_region": sig(
+                                                hb["roofline"]["algorithmic_bytes_per_launch"] / (hb["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS)}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "single_core", "value_in_reference_terms"))
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:230]
+        if cb.get("reference_build_container"):
+            line["cpu_baseline"]["reference_build_container"] = _pick(cb["reference_build_container"],
+                                                                      ("cores", "env_steps_per_s_1_process", "env_steps_per_s_all_cores"))
+        if cb.get("c_port"):
+            line["cpu_baseline"]["c_port"] = _pick(cb["c_port"], ("value", "cores", "single_core"))
+    cfgs = {}
+    for key, ent in (ex.get("configs") or {}).items():
+        if "roofline" not in ent:
+            cfgs[key] = {"error": str(ent.get("error", "?"))[:80]}
+            continue
+        c = {"value": sig(ent["value"]), "kernel_us": sig(ent["roofline"]["kernel_us_per_launch"], 4),
+             "frac": sig(ent["roofline"]["frac"], 4)}
+        if ent.get("fused_rollout"):
+            c["rollout_value"] = sig(ent["fused_rollout"]["value"])
+            c["rollout_frac_compulsory"] = sig(ent["fused_rollout"]["frac_compulsory"], 4)
+        if ent.get("step_server"):
+            c["step_server_value"] = sig(ent["step_server"]["value"])
+        cfgs[key] = c
+    if cfgs:
+        line["configs"] = cfgs
+    side = {}
+    for key in ("fused_rollout", "moves_resident", "int_action_ids", "python_api", "host_buffers", "step_server"):
+        if isinstance(ex.get(key), dict) and "value" in ex[key]:
+            side[key] = sig(ex[key]["value"])
+    for key, sub in (("user_scenario", "compiled_graph"), ("reference_style_file", "traced_graph")):
+        ent = ex.get(key)
+        if isinstance(ent, dict):        # (the headline's protocol on a user's scenario: a compiled row program / a traced file)
+            side[key] = sig(ent[sub]["value"]) if isinstance(ent.get(sub), dict) else "error"
+    if side:
+        line["env_steps_per_s"] = side
+    if full_path:
+        line["full_record"] = full_path
+    s = json.dumps(line, separators=(",", ":"))
+    for drop in ("env_steps_per_s", "per_gpu_value", "configs"):     # never over budget: shed the optional blocks, biggest last
+        if len(s) <= LINE_BUDGET:
+            break
+        line.pop(drop, None)
+        s = json.dumps(line, separators=(",", ":"))
+    assert len(s) <= LINE_BUDGET, len(s)
+    return s
+
+
+def write_full_record(out, path):
+    """The whole record (every leg, every raw timing, the box) as indented JSON; returns the path written, or None."""
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
+        return path
+    except OSError as e:
+        sys.stderr.write("bench.py: could not write the full record to %s (%s)\n" % (path, e))
+        return None
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -821,6 +934,9 @@ def parse_args(argv=None):
     ap.add_argument("--leg-json", default=None, help=argparse.SUPPRESS)      # internal: measure one config leg, print its entry
     ap.add_argument("--leg-floor-us", type=float, default=0.0, help=argparse.SUPPRESS)
     ap.add_argument("--leg-device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--full-json", default=os.path.join("gpurun_out", "bench_full.json"), metavar="PATH",
+                    help="where rank 0 writes the full record (every leg, raw timings, per-rank records, the box); the printed "
+                         "line is its compact form (< %d bytes)" % LINE_BUDGET)
     ap.add_argument("--streams", type=int, default=1,
                     help="cut the per-GPU batch into this many independent sub-batches, one HIP stream each")
     return ap.parse_args(argv)
@@ -861,8 +977,7 @@ def launch_ranks(args):
     if line.get("n_gpus") != n:
         sys.stderr.write("bench.py: ranks reported n_gpus=%r for --gpus %d\n" % (line.get("n_gpus"), n))
         return 1
-    line["config"]["launcher"] = "self-spawned (bench.py started the ranks)"
-    print(json.dumps(line))
+    print(lines[0])
     return 0
 
 
@@ -1105,7 +1220,7 @@ def main():
                                       if args.protocol == "fresh" else "resident ring of 16 tensors", EP),
                        "protocol": args.protocol, "batch_per_gpu": B, "global_batch": B * world, "mode": args.mode,
                        "graph_replays_in_timed_region": R, "timed_steps": K * R,
-                       "timed_region_s": dt, "repeats": args.repeats, "streams_per_gpu": args.streams,
+                       "timed_region_s": dt, "repeats": args.repeats, "region_ms": args.region_ms, "streams_per_gpu": args.streams,
                        "sharding": "worlds by batch index, no collective on the step path",
                        "barrier_backend": rv.backend, "barrier_note": rv.note,
                        "launcher": "torch.distributed.run / env" if world > 1 and not os.environ.get("MPE_SELF_SPAWNED") else
@@ -1155,7 +1270,8 @@ def main():
                     "value": cp[0], "unit": "env-steps/s", "cores": procs, "single_core": cp[1],
                     "sample": "oracle/mpe_oracle.c (the same algorithm in plain C, gcc -O2 -fopenmp, one world per "
                               "thread, fp64), %d threads x %.0f s" % (procs, min(args.cpu_seconds, 4.0))}
-        print(json.dumps(out))
+        full = write_full_record(out, args.full_json if os.path.isabs(args.full_json) else os.path.join(ROOT, args.full_json))
+        print(compact_line(out, args.full_json if full else None))
         sys.stdout.flush()
     leave(0)
 

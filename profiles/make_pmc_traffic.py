@@ -24,6 +24,16 @@ SOURCES = {
     "simple_spread_A64_L64_B4096": ("r4_pmc_spread64_B4096.txt", "bench.py --mode eager --protocol resident --agents 64 --batch 4096"),
     "simple_spread_A3_L3_B4096": ("r4_pmc_spread3_B4096.txt", "bench.py --mode eager --protocol resident --batch 4096"),
 }
+# key -> the newest committed `rocprofv3 --kernel-trace --stats` summary (tools/trace_summary.py) of that launch: bench.py prints
+# the dominant kernel's mean / median duration from it as `roofline.kernel_us_rocprof` beside its own HIP-event slope
+TRACES = {
+    "simple_spread_A3_L3_B65536": "r5_spread3_B65536_kernel_trace_summary.txt",
+    "simple_spread_A3_L3_B1048576": "r5_spread3_B1M_kernel_trace_summary.txt",
+    "simple_tag_A4_L2_B16384": "r5_tag_B16384_kernel_trace_summary.txt",
+    "simple_spread_A64_L64_B4096": "r5_spread64_B4096_kernel_trace_summary.txt",
+    "simple_spread_A3_L3_B4096": "r5_spread3_B4096_kernel_trace_summary.txt",
+}
+ROW = re.compile(r"^(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)%\s*$")
 LAST = re.compile(r"^traffic_bytes_per_launch\s+(\d+)\s+\(reads\s+(\d+)\s+\+\s+writes\s+(\d+)\)\s*$")
 
 
@@ -41,8 +51,22 @@ def entry(fname, command):
                       "profiles/pmc_summary.py: KiB units, FETCH_SIZE x2 per MI355X_MICROARCH.md)" % (fname, command)}
 
 
+def trace_entry(fname):
+    """Mean / median duration of the step kernel (the first `mpe::` row = the one with the largest share) in a kernel-trace summary."""
+    with open(os.path.join(HERE, fname)) as f:
+        for l in f:
+            m = ROW.match(l.rstrip("\n"))
+            if m and not l.startswith("#") and "mpe::" in m.group(1):
+                return {"mean_us": float(m.group(6)), "median_us": float(m.group(3)), "calls": int(m.group(2)),
+                        "source": "profiles/%s" % fname}
+    raise SystemExit("%s: no mpe:: kernel row" % fname)
+
+
 def build():
-    return {k: entry(f, c) for k, (f, c) in SOURCES.items()}
+    out = {k: entry(f, c) for k, (f, c) in SOURCES.items()}
+    for k, f in TRACES.items():
+        out[k]["kernel_trace"] = trace_entry(f)
+    return out
 
 
 def main():

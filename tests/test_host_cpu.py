@@ -325,3 +325,46 @@ def test_pmc_traffic_json_is_what_the_cited_files_say():
     spec.loader.exec_module(m)
     import json
     assert json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))) == m.build()
+
+
+def test_bench_line_is_compact_and_round_trips():
+    """The driver parses ONE line from rank 0 (round 5's 20 KB line came back `parsed: null`): the printed line is the compact
+    form of the full record -- under bench.LINE_BUDGET bytes whatever the record holds -- with the contract's keys, `roofline`
+    (kernel-only and timed-region fractions, the rocprof durations, the HBM-resident fraction) and `cpu_baseline`."""
+    import copy
+    import json
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_default_steps20_box31.json")))      # a real 20 KB record
+    assert len(json.dumps(rec)) > 15000
+    line = bench.compact_line(rec, "gpurun_out/bench_full.json")
+    assert len(line) < bench.LINE_BUDGET == 4096 and "\n" not in line
+    out = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "timed_steps", "timed_region_s"):
+        assert k in out, k
+    assert out["steps"] == 20 and out["warmup"] == 5 and out["n_gpus"] == 1 and out["vs_baseline"] is None
+    assert abs(out["value"] / rec["value"] - 1) < 1e-5 and abs(out["ms_per_step"] / rec["ms_per_step"] - 1) < 1e-5
+    assert abs(out["timed_steps"] * out["ms_per_step"] * 1e-3 / out["timed_region_s"] - 1) < 1e-3      # what the driver can check
+    assert "workload" in out["config"] and "model" not in out["config"] and out["config"]["batch_per_gpu"] == 65536
+    roof = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_timed_region", "kernel", "kernel_us_per_launch",
+              "algorithmic_bytes_per_launch", "hbm_resident_frac", "l3_resident"):
+        assert k in roof, k
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-5 and roof["frac_timed_region"] < roof["frac"]
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] == 16 and cpu["sample"] and cpu["unit"] == "env-steps/s"
+    assert cpu["reference_build_container"]["env_steps_per_s_all_cores"] > 0
+    assert set(out["configs"]) == {"C2_spread_n3_B4096", "C3_tag_B16384", "C4_spread_n64_B4096"}
+    assert out["full_record"] == "gpurun_out/bench_full.json"
+    # an 8-rank record with long per-rank blocks and prose: still one line under the budget, the contract's objects kept
+    big = copy.deepcopy(rec)
+    big["n_gpus"] = 8
+    big["config"]["ranks"] = [dict(rank=r, note="x" * 500) for r in range(8)]
+    big["roofline"]["kernel_us_per_launch_by_rank"] = [5.4 + 0.01 * r for r in range(8)]
+    big["roofline"]["per_gpu"] = True
+    big["extra"]["configs"]["C9_" + "y" * 3000] = big["extra"]["configs"]["C2_spread_n3_B4096"]
+    line8 = bench.compact_line(big, None)
+    out8 = json.loads(line8)
+    assert len(line8) < bench.LINE_BUDGET and len(out8["roofline"]["kernel_us_per_launch_by_rank"]) == 8
+    assert "roofline" in out8 and "cpu_baseline" in out8 and "full_record" not in out8
+    assert bench.sig(10358300123.4) == 10358300000.0 and bench.sig(0.00632694123) == 0.00632694 and bench.sig(7) == 7
