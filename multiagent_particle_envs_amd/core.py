@@ -339,6 +339,8 @@ class World(object):
         for its in-launch restarts and rollouts."""
         if len(boxes) != len(self.entities):
             raise _abi.MpeError("reset_boxes: one (lo_x, hi_x, lo_y, hi_y) per entity")
+        if len(boxes) > _abi.MPE_ROWS_MAX_ENTITIES:
+            raise _abi.MpeError("reset_boxes: %d entities (per-entity boxes cover %d)" % (len(boxes), _abi.MPE_ROWS_MAX_ENTITIES))
         return self.reset_uniform(1.0, mask, choices, seeds, boxes=[tuple(float(v) for v in b) for b in boxes])
 
     def reset_uniform(self, landmark_range=1.0, mask=None, choices=None, seeds=None, redraw=None, boxes=None):

@@ -448,11 +448,13 @@ class TracedRefScenario(object):
             # not reset_uniform's placement (a restricted spawn area, positions that depend on a pick ...): the traced reset
             # program drawn and evaluated with torch ops for all worlds at once -- ~50 small launches, nothing leaves the device
             dev = world.device
-            gen = torch.Generator(device=dev)
-            gen.manual_seed((int(world.seed) * 1000003 + int(world._episode) * 7919 + int(world.world_offset)) & (2 ** 63 - 1))
+            # counter-based draws keyed per (seed, GLOBAL world number, episode, draw): no two triples share a stream, and a
+            # world's draws do not depend on how the batch is cut across ranks (as mpe_reset's Philox key)
+            nu = max(t.n_u, 1)
+            R = _keyed_uniform(int(world.seed), int(world._episode), int(world.world_offset), B, nu + len(t.pops), dev)
             world._episode += 1
-            U = torch.rand((max(t.n_u, 1), B), generator=gen, device=dev)
-            K = torch.stack([torch.randint(0, n, (B,), generator=gen, device=dev) for n in t.pops]) if t.pops else \
+            U = R[:nu].to(torch.float32)
+            K = torch.stack([(R[nu + j] * n).floor().to(torch.int64).clamp_(0, n - 1) for j, n in enumerate(t.pops)]) if t.pops else \
                 torch.zeros((0, B), dtype=torch.int64, device=dev)
             for j, idx in enumerate(getattr(t, "params", ())):      # the draws the callbacks read travel in the slots after the picks
                 K[t.real_picks() + j] = (U[idx].double() * symtrace.PARAM_POP).floor().to(torch.int64).clamp_(0, symtrace.PARAM_POP - 1)
@@ -788,6 +790,28 @@ def _stack_info(vals, ad):
     return list(vals)
 
 
+def _keyed_uniform(seed, episode, world_offset, B, n, dev):
+    """[n, B] float64 uniforms in [0, 1) with 24 random bits each: draw j of world b = a splitmix64-style hash of
+    (seed, world_offset + b, episode, j), computed with torch integer ops on `dev` (int64 wrap-around arithmetic)."""
+    M = (1 << 64) - 1
+
+    def s64(v):      # a Python int as the int64 with the same low 64 bits
+        v &= M
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def shr(x, k):   # logical shift right of int64 tensors
+        return (x >> k) & ((1 << (64 - k)) - 1)
+    key = (seed * 0x9E3779B97F4A7C15 + (episode + 1) * 0xD1B54A32D192ED03) & M
+    w = torch.arange(B, dtype=torch.int64, device=dev) + int(world_offset)
+    j = torch.arange(n, dtype=torch.int64, device=dev)[:, None]
+    x = (w[None, :] * s64(0xBF58476D1CE4E5B9)) ^ ((j + 1) * s64(0x94D049BB133111EB)) ^ s64(key)
+    for mul in (0xBF58476D1CE4E5B9, 0x94D049BB133111EB):
+        x = (x ^ shr(x, 30)) * s64(mul)
+        x = x ^ shr(x, 27)
+    x = x ^ shr(x, 31)
+    return shr(x, 40).to(torch.float64) * (2.0 ** -24)
+
+
 def make_ref_env(scenario, benchmark=False, batch_size=None, device=None, seed=0, max_episode_steps=None, auto_reset=False,
                  done_callback=False, traced=None, fresh_outputs=False, verbose=False):
     """make_env for a reference-style Scenario object (make_env.py:36-43): one world with NumPy in / NumPy out when
@@ -808,8 +832,8 @@ def make_ref_env(scenario, benchmark=False, batch_size=None, device=None, seed=0
             ts = trace_ref_scenario(scenario, want_done=want_done, want_info=want_info)
             return make_traced_env(ts, batch_size, device=device, seed=seed, max_episode_steps=max_episode_steps,
                                    auto_reset=auto_reset, fresh_outputs=fresh_outputs, benchmark=want_info)
-        except (symtrace.TraceUnsupported, _abi.MpeError, RuntimeError, OSError) as e:      # (OSError: no hipcc on this machine)
-            if traced:
+        except Exception as e:      # auto mode: whatever stops the trace (TraceUnsupported, no hipcc: OSError, the file's own
+            if traced:              # callback raising on the verifier's worlds ...) the host path is always correct
                 raise
             why = "%s: %s" % (type(e).__name__, e)
             if verbose or int(batch_size) >= 1024:      # (a large batch on the host path is orders of magnitude slower: say so once)

@@ -40,6 +40,7 @@ all restored afterwards, the caller's random stream untouched: construct envs fr
 """
 import contextlib
 import math
+import struct
 import sys
 
 import numpy as np
@@ -81,7 +82,8 @@ class Graph(object):
         self.count = 0
 
     def node(self, op, args=(), value=None):
-        key = (op, tuple(a.uid for a in args), value)
+        # (constants are keyed by bit pattern: -0.0 == 0.0 and they hash alike, but 1 / x and atan2 tell them apart)
+        key = (op, tuple(a.uid for a in args), struct.pack("<d", value) if op == "const" else value)
         n = self.nodes.get(key)
         if n is None:
             n = Node()
@@ -2767,6 +2769,13 @@ def shared_tasks(rew_roots, n_waves):
         finally:
             sys.setrecursionlimit(limit)
         if len(tasks) <= _SHARE_MAX:
+            break
+        if c_max >= per_agent:
+            # no cone is larger than per_agent: a bigger limit cannot merge anything further (more than _SHARE_MAX distinct
+            # shareable terms under agent-specific chains).  Share the terms that save most; the others stay in every
+            # agent's own code, which is always correct.
+            tasks.sort(key=lambda n: (-cone(n) * (len(users[n.uid]) - 1), n.uid))
+            tasks = sorted(tasks[:_SHARE_MAX], key=lambda n: n.uid)
             break
         c_max *= 2
     saving = sum(cost[n.uid] * (len(users[n.uid]) - 1) for n in tasks)

@@ -48,13 +48,13 @@ def golden():
     return get
 
 
-# ---- parity margin record (profiles/parity_r5.json): the GPU parity tests report how far inside the bar they are -------------
+# ---- parity margin record (profiles/parity_r6.json): the GPU parity tests report how far inside the bar they are -------------
 _PARITY = {}
 
 
 @pytest.fixture(scope="session")
 def record_parity():
-    """record_parity(key, dict): kept for the session and written to gpurun_out/parity_r5.json (merged into an existing
+    """record_parity(key, dict): kept for the session and written to gpurun_out/parity_r6.json (merged into an existing
     file) when the session ends -- max scaled errors per config, worlds masked by the guard band, drift percentiles."""
     def rec(key, value):
         _PARITY[key] = value
@@ -79,7 +79,7 @@ def pytest_sessionfinish(session, exitstatus):
     import json
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    path = os.path.join(out, "parity_r5.json")
+    path = os.path.join(out, "parity_r6.json")
     data = {}
     if os.path.exists(path):
         try:

@@ -86,7 +86,7 @@ def replay(env, g, dev, name=None):
         assert same.sum() >= W // 2, "the seeded reset does not reproduce the reference's"
     if "choice" in g and g["choice"].shape[1]:
         assert np.array_equal(env.world.choice_i32.cpu().numpy().T, g["choice"])
-    worst = 0.0
+    worst, masked = 0.0, 0.0
     for i in range(n):
         worst = max(worst, close(obs[i][torch.as_tensor(same)], g["obs_reset%d" % i][same], "obs_reset%d" % i))
     env.world.set_state(g["pos0"], g["vel0"])
@@ -112,7 +112,8 @@ def replay(env, g, dev, name=None):
             K = env.world.choice_i32.cpu().numpy().T.astype(np.int64)
         roots = [x for row in tr.obs for x in row] + list(tr.rew)
         ok = symtrace.decision_margin(roots, W, P=g["pos"][t].astype(np.float64), V=V, Cw=Cw, K=K) > 2e-6
-        assert ok.mean() >= 0.95, ok.mean()
+        assert ok.mean() >= 0.99, ok.mean()          # (the fused-kernel tests' bar: at most 1 % of the worlds on a knife edge)
+        masked = max(masked, 1.0 - float(ok.mean()))
         okt = torch.as_tensor(ok)
         for i in range(n):
             worst = max(worst, close(obs[i][okt], g["obs%d" % i][t][ok], "obs%d t=%d" % (i, t)))
@@ -121,6 +122,9 @@ def replay(env, g, dev, name=None):
         if name is not None and tr.info is not None:
             ok_i = symtrace.decision_margin([x for row in tr.info for x in row], W, P=g["pos"][t].astype(np.float64), V=V, Cw=Cw, K=K) > 2e-6
             check_info(name, info, g, t, ok & ok_i)
+            assert (ok & ok_i).mean() >= 0.99, (ok & ok_i).mean()
+            masked = max(masked, 1.0 - float((ok & ok_i).mean()))
+    replay.masked = masked
     return worst
 
 
@@ -136,7 +140,8 @@ def test_committed_traces_of_the_nine_reference_files_on_the_device(name, golden
     assert (env.info_callback is not None) == (name in ("simple_spread", "simple_tag", "simple_adversary", "simple_crypto", "simple_world_comm"))
     worst = replay(env, g, "cuda", name)
     record_parity("traced_" + name, {"what": "the reference's %s.py traced into the step kernel, against the goldens its own env recorded"
-                                            % name, "worlds": W, "steps": int(g["rew"].shape[0]), "max_scaled_err": worst})
+                                            % name, "worlds": W, "steps": int(g["rew"].shape[0]), "max_scaled_err": worst,
+                                            "max_fraction_of_worlds_masked_knife_edge": replay.masked, "band": 2e-6})
 
 
 @pytest.mark.parametrize("name", ["herd", "relay", "convoy", "survey", "mesh", "scatter"])
@@ -149,7 +154,8 @@ def test_fixture_files_traced_against_reference_goldens_and_the_host_path(name, 
     assert type(env.ref_scenario).__module__.startswith("mpe_user_scenario_")
     worst = replay(env, g, "cuda", name)
     record_parity("traced_fixture_" + name, {"what": "tests/refstyle/%s.py traced, against goldens recorded by the reference's env" % name,
-                                             "worlds": W, "steps": int(g["rew"].shape[0]), "max_scaled_err": worst})
+                                             "worlds": W, "steps": int(g["rew"].shape[0]), "max_scaled_err": worst,
+                                            "max_fraction_of_worlds_masked_knife_edge": replay.masked, "band": 2e-6})
     # ... and against the same file on the host path, free-running on more worlds (crowded at t = 3: contacts)
     B = 600
     a, b = mpe.make_env(path, batch_size=B, seed=5, benchmark=True), mpe.make_env(path, batch_size=B, seed=5, traced=False, benchmark=True)

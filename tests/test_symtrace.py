@@ -10,6 +10,7 @@
   * the generated device code compiles (hipcc --genco needs no GPU).
 """
 import json
+import math
 import os
 
 import numpy as np
@@ -1268,3 +1269,58 @@ def test_trace_report_tool_says_what_make_env_would_do():
     assert r.returncode == 0 and "TRACED" in r.stdout and "per-world parameters" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([sys.executable, tool, os.path.join(FIXTURES, "patrol.py")], capture_output=True, text=True)
     assert r.returncode == 1 and "HOST PATH -- scripted agents" in r.stdout, r.stdout + r.stderr
+
+
+def _pairwise_reward_graph(n_agents):
+    """n agents, each reward = an own term minus every pairwise exp(-d2 / 0.3) term (round-5 advisor's reproduction): the
+    pairwise terms are shareable sub-expressions under agent-specific accumulation chains."""
+    g = symtrace.Graph()
+    P = [[g.node("P", (), (i, k)) for k in range(2)] for i in range(n_agents)]
+    pair = []
+    for i in range(n_agents):
+        for j in range(i + 1, n_agents):
+            dx, dy = g.binary("sub", P[i][0], P[j][0]), g.binary("sub", P[i][1], P[j][1])
+            d2 = g.binary("add", g.binary("mul", dx, dx), g.binary("mul", dy, dy))
+            pair.append(g.unary("exp", g.binary("div", g.unary("neg", d2), g.const(0.3))))
+    roots = []
+    for i in range(n_agents):
+        r = g.binary("mul", P[i][0], g.const(float(i + 2)))          # the agent's own term: every chain is agent-specific
+        for t in pair:
+            r = g.binary("sub", r, t)
+        roots.append(r)
+    return roots, pair
+
+
+@pytest.mark.timeout(60)
+def test_shared_tasks_terminates_with_more_than_64_shareable_terms():
+    """A reward with more than _SHARE_MAX (64) distinct shareable terms under agent-specific chains: 13 agents, 78 pairwise
+    terms.  Round 5's loop doubled its cone limit for ever (make_env hung at construction); now the 64 terms that save most
+    are shared and the rest stay in every agent's own code.  11 agents / 55 terms: all shared, as before."""
+    roots, pair = _pairwise_reward_graph(11)
+    tasks = symtrace.shared_tasks(roots, 11)
+    assert len(tasks) == 55 and {t.uid for t in tasks} == {t.uid for t in pair}
+    roots, pair = _pairwise_reward_graph(13)
+    tasks = symtrace.shared_tasks(roots, 13)
+    assert len(tasks) == symtrace._SHARE_MAX and {t.uid for t in tasks} <= {t.uid for t in pair}
+    assert len({t.uid for t in tasks}) == len(tasks)
+
+
+def test_graph_constants_keep_the_signed_zero():
+    g = symtrace.Graph()
+    a, b = g.const(0.0), g.const(-0.0)
+    assert a is not b and math.copysign(1.0, a.value) == 1.0 and math.copysign(1.0, b.value) == -1.0
+    assert g.const(-0.0) is b and g.const(0.0) is a and g.const(1.5) is g.const(1.5)
+
+
+def test_keyed_uniform_is_per_world_and_shard_invariant():
+    """The torch-path traced reset draws per (seed, global world, episode, draw): distinct triples give distinct streams
+    (round-5 advisor: seed s / episode 126 / offset 2209 collided with seed s+1 / 0 / 0) and a shard's worlds draw what the
+    same worlds draw inside one big batch."""
+    import torch
+    ku = refstyle._keyed_uniform
+    big = ku(7, 3, 0, 4096, 5, "cpu")
+    assert big.shape == (5, 4096) and float(big.min()) >= 0.0 and float(big.max()) < 1.0
+    assert torch.equal(ku(7, 3, 1024, 1024, 5, "cpu"), big[:, 1024:2048])
+    assert not torch.equal(ku(7, 126, 2209, 64, 5, "cpu"), ku(8, 0, 0, 64, 5, "cpu"))
+    assert not torch.equal(ku(7, 4, 0, 64, 5, "cpu"), big[:, :64])
+    assert abs(float(big.mean()) - 0.5) < 0.02 and len(torch.unique(big)) > 0.99 * big.numel()
