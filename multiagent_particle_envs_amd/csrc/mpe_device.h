@@ -91,12 +91,24 @@ __device__ __forceinline__ float sq2d(float dx, float dy) {
 __device__ __forceinline__ void contact_force(float dx, float dy, float dist_min, float cforce,
                                               float k, float kinv, float &fx, float &fy) {
   const float d2 = sq2d(dx, dy);
+#ifdef MPE_CONTACT_EXACT
+  // A/B build only (tools/c4_parity_ab.py, round-5 verdict Weak #2): the reference's own operation order with IEEE
+  // operations -- dist = sqrt(d2); pen = logaddexp(0, -(dist - dist_min) / k) * k; force = C * delta / dist * pen
+  // (core.py:186-193) -- correctly rounded sqrt and divisions, libm expf / log1pf.
+  (void)kinv;
+  const float dist = sqrtf(d2);
+  const float x = -(dist - dist_min) / k;
+  const float pen = (fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)))) * k;
+  fx = ((cforce * dx) / dist) * pen;
+  fy = ((cforce * dy) / dist) * pen;
+#else
   const float r = fast_rsq(d2);
   const float dist = d2 * r;
   const float pen = softplus0((dist_min - dist) * kinv) * k;
   const float s = (cforce * pen) * r;
   fx = dx * s;
   fy = dy * s;
+#endif
 }
 
 // World.integrate_state body for one movable entity (core.py:161-169); max_speed < 0 == None.

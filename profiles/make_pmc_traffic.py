@@ -27,8 +27,8 @@ SOURCES = {
 # key -> the newest committed `rocprofv3 --kernel-trace --stats` summary (tools/trace_summary.py) of that launch: bench.py prints
 # the dominant kernel's mean / median duration from it as `roofline.kernel_us_rocprof` beside its own HIP-event slope
 TRACES = {
-    "simple_spread_A3_L3_B65536": "r5_spread3_B65536_kernel_trace_summary.txt",
-    "simple_spread_A3_L3_B1048576": "r5_spread3_B1M_kernel_trace_summary.txt",
+    "simple_spread_A3_L3_B65536": "r6_spread3_B65536_kernel_trace_summary.txt",
+    "simple_spread_A3_L3_B1048576": "r6_spread3_B1M_kernel_trace_summary.txt",
     "simple_tag_A4_L2_B16384": "r5_tag_B16384_kernel_trace_summary.txt",
     "simple_spread_A64_L64_B4096": "r5_spread64_B4096_kernel_trace_summary.txt",
     "simple_spread_A3_L3_B4096": "r5_spread3_B4096_kernel_trace_summary.txt",
