@@ -543,6 +543,46 @@ def roofline_entry(leg, k_us, B, mode, floor_us, timing=None):
             "launch_floor_us": floor_us}
 
 
+def served_leg(torch, mpe, scenario, agents, B, EP, seed, region_ms, repeats=3, kw=None):
+    """The headline protocol through the STEP SERVER (rollout.ServedRollout; include/mpe_hip.h: mpe_step_server_*): fresh moves
+    for every step (one block draw per episode), a reset every EP steps (the server's in-launch reset), every step's rows /
+    rewards / dones / state written -- but each step COMMANDED (a doorbell launch behind the draw of its moves) to one resident
+    launch per episode instead of launched.  -> entry with value / ms_per_step / the timed-region roofline fraction."""
+    from multiagent_particle_envs_amd.rollout import ServedRollout
+    env = mpe.make_env(scenario, batch_size=B, seed=seed, **(kw or {}))
+    A, Lm = len(env.world.agents), len(env.world.landmarks)
+    roll = ServedRollout(env, episode_len=EP, timeout_s=10.0)
+    G = 2 * EP * 8                                    # steps per captured graph (a multiple of the move ring's period)
+    g = roll.capture(G)
+    g.replay()
+    torch.cuda.synchronize()
+    roll.srv.check()
+    t0 = time.perf_counter()
+    g.replay()
+    torch.cuda.synchronize()
+    reps = max(1, int(math.ceil(region_ms * 1e-3 / max(time.perf_counter() - t0, 1e-6))))
+    walls = []
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _r in range(reps):
+            g.replay()
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+    roll.srv.check()
+    walls.sort()
+    dt = walls[len(walls) // 2]
+    n = G * reps
+    bytes_step = algorithmic_bytes(A, Lm, int(env._obs_off[-1]), len(env.world.choice_pops), 0)
+    return {"what": "the headline protocol with every step COMMANDED to a resident step server (one launch per %d-step episode on its "
+                    "own stream; per step a doorbell launch on the caller's stream behind the draw of its moves) instead of launched: "
+                    "fresh moves from HBM, in-launch resets, every step's rows / rewards / dones / state written" % EP,
+            "value": B * n / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3 / n, "timed_steps": n, "timed_region_s": dt,
+            "repeats": {"min": B * n / walls[-1], "median": B * n / dt, "max": B * n / walls[0]},
+            "frac_timed_region": bytes_step * B / (dt / n) / 1e9 / HBM_PEAK_GBS,
+            "achieved_GBps": bytes_step * B / (dt / n) / 1e9, "algorithmic_bytes_per_env_step": bytes_step}
+
+
 CONFIG_LEGS = (("C2_spread_n3_B4096", "simple_spread", 3, 4096, 200),
                ("C3_tag_B16384", "simple_tag", 3, 16384, 200),
                ("C4_spread_n64_B4096", "simple_spread", 64, 4096, 50))
@@ -574,6 +614,14 @@ def run_config_leg(key, floor_us, seed, EP, dev_index):
     ent["fused_rollout"] = {"value": bb * kk * R2 / d2, "unit": "env-steps/s", "kernel_us_per_step": k2, "repeats": stats(r2_),
                             "compulsory_bytes_per_env_step": comp,
                             "frac_compulsory": comp * bb / (k2 * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    if lg.geometry()[3] == "mpe::k_split":      # (the step server serves the wave-per-agent shapes)
+        kw = dict(lg.kw)
+        lg.release()
+        torch.cuda.empty_cache()
+        try:
+            ent["step_server"] = served_leg(torch, mpe, scn, ag, bb, EP or 25, seed, SR, kw=kw)
+        except Exception as e:
+            ent["step_server"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     return ent
 
 
@@ -859,8 +907,8 @@ def compact_line(out, full_path=None):
         if ent.get("fused_rollout"):
             c["rollout_value"] = sig(ent["fused_rollout"]["value"])
             c["rollout_frac_compulsory"] = sig(ent["fused_rollout"]["frac_compulsory"], 4)
-        if ent.get("step_server"):
-            c["step_server_value"] = sig(ent["step_server"]["value"])
+        if isinstance(ent.get("step_server"), dict):
+            c["step_server_value"] = sig(ent["step_server"]["value"]) if "value" in ent["step_server"] else "error"
         cfgs[key] = c
     if cfgs:
         line["configs"] = cfgs
@@ -1137,6 +1185,12 @@ def main():
             "value": B * nh / dth, "unit": "env-steps/s", "ms_per_step": dth * 1e3 / nh,
             "pcie_bytes_per_env_step": io_bytes, "pcie_GBps": B * nh * io_bytes / dth / 1e9}
 
+    if solo and args.mode == "graph" and args.protocol == "fresh" and kname == "mpe::k_split" and leg.roll("resident").rollouts[0].pool_c is None:
+        try:
+            extra["step_server"] = served_leg(torch, mpe, args.scenario, args.agents, B, EP or 25, args.seed, 2 * SR, kw=leg.kw)
+        except Exception as e:
+            extra["step_server"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            torch.cuda.synchronize()
     done_at("headline_side_legs")
     default_line = solo and args.scenario == "simple_spread" and args.agents == 3 and B == 65536
     if default_line:

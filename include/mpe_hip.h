@@ -235,6 +235,41 @@ int mpe_rollout_random(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int6
                        int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0,
                        int64_t world_offset, int32_t trajectory, void *stream);
 
+/* ---- the step server: per-step commands to ONE resident launch -- NEW API, no reference counterpart ----------------------
+ * The reference's caller loop is one env.step per policy decision (bin/interactive.py:27-36, environment.py:80-104); as a
+ * launch per step every step pays the dependent-launch gap (1.0-2.0 us on top of the kernel's span).  A step server is ONE
+ * launch that performs the same steps ON COMMAND: mpe_step_server_start puts it on a stream of its own for up to T steps;
+ * the caller then commands steps one by one with mpe_step_server_ring -- a one-thread launch on the CALLER's stream, so it
+ * is ordered behind whatever produced that step's moves -- and the server executes global step g as soon as `commanded > g`:
+ *   moves    one-hot rows [A][B][5] in tensor g % ring of `act_ring` (ring consecutive tensors)
+ *   outputs  obs / rew / done / info_* block g % slots of bufs' output buffers (blocks of obs_off[A] * B floats / A * B
+ *            entries: `slots` consecutive blocks, as mpe_rollout_random's trajectory blocks); pos / vel after every step
+ *   resets   every episode_len global steps (0 = never) inside the launch, mpe_reset's draws (as mpe_rollout_random)
+ * and flag[wg] = g + 1 tells when workgroup wg's outputs of step g are in memory (mpe_step_server_wait: a launch on the
+ * caller's stream that ends when all flags have reached a step count; launches behind it read that step's outputs).
+ * Results are bit-identical to the T launches {mpe_reset at the boundaries; mpe_step}.  A server never outlives its
+ * commander: a wave that waits longer than timeout_us for its next command sets *status (1; a timed-out wait: 2) and the
+ * launch ends.  Who gains: callers whose moves for step g + 1 exist before step g has finished (recorded or scripted action
+ * sequences, action repeat, several env instances interleaved, the random-action benchmark) -- their steps run back to back
+ * at the kernel's span; a closed loop (policy reads step g's rows before it can command g + 1) pays ring + wait launches
+ * and is better served by mpe_step.  Scenarios without utterances, at shapes with a wave-per-agent kernel; B small enough
+ * for every 64-world workgroup to be resident (mpe_step_server_supported).                                               */
+typedef struct MpeStepServer {
+  uint64_t *door;          /* device, 1 word, zeroed by the caller once: steps commanded so far (absolute, monotonic)   */
+  uint64_t *flag;          /* device, mpe_step_server_flags(B) words, zeroed once: steps completed, per workgroup      */
+  uint32_t *status;        /* device, 1 word, zeroed once: 0 = fine, 1 = the server timed out, 2 = a wait timed out    */
+  const float *act_ring;   /* device, `ring` consecutive [A][B][5] move tensors                                         */
+  int32_t ring, slots;
+  uint64_t timeout_us;
+} MpeStepServer;
+int mpe_step_server_supported(const MpeScenarioDesc *desc, int64_t B);   /* 1 / 0 (< 0: invalid descriptor) */
+int64_t mpe_step_server_flags(int64_t B);
+int mpe_step_server_start(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, int32_t T, int32_t episode_len,
+                          float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
+                          const MpeStepServer *srv, void *server_stream);
+int mpe_step_server_ring(const MpeStepServer *srv, uint64_t steps_commanded, void *caller_stream);
+int mpe_step_server_wait(const MpeStepServer *srv, int64_t B, uint64_t steps_completed, void *caller_stream);
+
 /* ---- composable output stage: a USER scenario's observation / reward as a row program ---------------------------------
  * The reference's plug-in promise (README "Creating new environments", scenario.py:4-10) is that new scenarios are the
  * normal use; every shipped observation is a concatenation of a few segment kinds and every shipped reward an ordered

@@ -45,6 +45,11 @@ class MpeScenarioDesc(C.Structure):
     ]
 
 
+class MpeStepServer(C.Structure):      # include/mpe_hip.h: the step server's device words and ring geometry
+    _fields_ = [("door", C.c_void_p), ("flag", C.c_void_p), ("status", C.c_void_p), ("act_ring", C.c_void_p),
+                ("ring", C.c_int32), ("slots", C.c_int32), ("timeout_us", C.c_uint64)]
+
+
 class MpeBuffers(C.Structure):
     _fields_ = [
         ("pos", C.c_void_p), ("vel", C.c_void_p), ("act", C.c_void_p), ("ids", C.c_void_p), ("u", C.c_void_p),
@@ -116,6 +121,12 @@ EXPORTS = {
     "mpe_rollout_random": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_int32,
                                      C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32,
                                      C.c_void_p]),
+    "mpe_step_server_supported": (C.c_int, [C.POINTER(MpeScenarioDesc), C.c_int64]),
+    "mpe_step_server_flags": (C.c_int64, [C.c_int64]),
+    "mpe_step_server_start": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_int32, C.c_int32,
+                                        C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.POINTER(MpeStepServer), C.c_void_p]),
+    "mpe_step_server_ring": (C.c_int, [C.POINTER(MpeStepServer), C.c_uint64, C.c_void_p]),
+    "mpe_step_server_wait": (C.c_int, [C.POINTER(MpeStepServer), C.c_int64, C.c_uint64, C.c_void_p]),
 }
 
 _lib = None

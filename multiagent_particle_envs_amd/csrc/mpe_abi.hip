@@ -469,6 +469,70 @@ int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
                                       ra, s), what);
 }
 
+// ---- the step server (mpe_split.hip, SERVE) ------------------------------------------------------------------------------
+static int check_server(const MpeStepServer *srv, const char *what) {
+  if (!srv) return fail(MPE_EINVAL, "%s: srv is NULL", what);
+  if (!srv->door || !srv->flag || !srv->status) return fail(MPE_EINVAL, "%s: srv->door / flag / status must be device words", what);
+  return 0;
+}
+int mpe_step_server_supported(const MpeScenarioDesc *d, int64_t B) {
+  if (int rc = check_desc(d, "mpe_step_server_supported")) return rc;
+  if (B <= 0 || d->n_agents + d->n_landmarks > mpe::kNarrowMaxE) return 0;
+  return mpe::serve_supports(d->kind, d->n_agents, d->n_landmarks, d->n_adversaries) ? 1 : 0;
+}
+int64_t mpe_step_server_flags(int64_t B) { return B > 0 ? (int64_t)mpe::serve_grid((size_t)B) : 0; }
+int mpe_step_server_start(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, int32_t T, int32_t episode_len,
+                          float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset, const MpeStepServer *srv,
+                          void *stream) {
+  const char *what = "mpe_step_server_start";
+  if (int rc = check_desc(d, what)) return rc;
+  if (int rc = check_state(b, B, what)) return rc;
+  if (int rc = need(b->obs, what, "obs")) return rc;
+  if (int rc = check_info(d, b, what)) return rc;
+  if (int rc = check_server(srv, what)) return rc;
+  if (d->n_choices > 0 && d->kind >= MPE_SCN_ADVERSARY)
+    if (int rc = need(b->choice, what, "choice (the per-world picks of reset_world)")) return rc;
+  if (!srv->act_ring || srv->ring < 1 || srv->slots < 1) return fail(MPE_EINVAL, "%s: srv->act_ring, ring >= 1, slots >= 1", what);
+  if (T < 0 || episode_len < 0) return fail(MPE_EINVAL, "%s: T, episode_len must be >= 0", what);
+  if (B == 0 || T == 0) return 0;
+  if (d->n_agents + d->n_landmarks > mpe::kNarrowMaxE || !mpe::serve_supports(d->kind, d->n_agents, d->n_landmarks, d->n_adversaries))
+    return fail(MPE_EUNSUPPORTED, "%s: the step server exists for the wave-per-agent shapes of the scenarios without utterances", what);
+  mpe::RollArgs ra;
+  std::memset(&ra, 0, sizeof(ra));
+  ra.T = T;
+  ra.episode_len = episode_len;
+  ra.trajectory = 1;
+  ra.landmark_range = landmark_range;
+  ra.seed = seed;
+  ra.step0 = step0;
+  ra.world_offset = (uint64_t)world_offset;
+  mpe::ServeHandles h;
+  h.door = srv->door;
+  h.flag = srv->flag;
+  h.status = srv->status;
+  h.act_ring = srv->act_ring;
+  h.ring = srv->ring;
+  h.slots = srv->slots;
+  h.timeout_ticks = srv->timeout_us * 100ull;      // the 100 MHz wall clock (s_memrealtime)
+  const mpe::NarrowDesc n = make_narrow(d, b, (size_t)B);
+  const int rc = mpe::launch_split_serve(d->kind, d->n_agents, d->n_landmarks, d->n_adversaries, n, *b, (size_t)B, ra, h,
+                                         static_cast<hipStream_t>(stream));
+  if (rc == mpe::MPE_ESERVER_TOO_LARGE)
+    return fail(MPE_EUNSUPPORTED, "%s: %lld worlds = %u workgroups cannot all be resident on this GPU (a waiting workgroup holds "
+                "its slots): serve a smaller batch per server", what, (long long)B, mpe::serve_grid((size_t)B));
+  return hip_result(rc, what);
+}
+int mpe_step_server_ring(const MpeStepServer *srv, uint64_t steps_commanded, void *stream) {
+  if (int rc = check_server(srv, "mpe_step_server_ring")) return rc;
+  return hip_result(mpe::launch_serve_ring(srv->door, steps_commanded, static_cast<hipStream_t>(stream)), "mpe_step_server_ring");
+}
+int mpe_step_server_wait(const MpeStepServer *srv, int64_t B, uint64_t steps_completed, void *stream) {
+  if (int rc = check_server(srv, "mpe_step_server_wait")) return rc;
+  if (B <= 0) return 0;
+  return hip_result(mpe::launch_serve_wait(srv->flag, mpe::serve_grid((size_t)B), steps_completed, srv->status,
+                                           srv->timeout_us * 100ull, static_cast<hipStream_t>(stream)), "mpe_step_server_wait");
+}
+
 // ---- the composable output stage (mpe_rows.hip) -------------------------------------------------------------------------
 static int rows_header(const char *what, const MpeScenarioDesc *d, const MpeRowProgram *p, mpe::RowDims *h, mpe::RowTables *t) {
   if (int rc = check_desc(d, what)) return rc;

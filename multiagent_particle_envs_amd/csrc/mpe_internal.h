@@ -60,6 +60,22 @@ struct RollArgs {
   uint64_t seed, step0, world_offset;
 };
 bool split_supports(int kind, int A, int L, int nadv);
+// the step server (mpe_split.hip, SERVE): device words and ring geometry of one server (mpe_step_server_*)
+struct ServeHandles {
+  uint64_t *door, *flag;
+  uint32_t *status;
+  const float *act_ring;
+  int32_t ring, slots;
+  uint64_t timeout_ticks;
+};
+constexpr int MPE_ESERVER_TOO_LARGE = -1000;   // internal: the grid cannot be resident (mapped to MPE_EUNSUPPORTED with a message)
+bool serve_supports(int kind, int A, int L, int nadv);
+unsigned serve_grid(size_t B);
+int launch_serve_ring(uint64_t *door, uint64_t commanded, hipStream_t stream);
+int launch_serve_wait(const uint64_t *flag, unsigned n_flags, uint64_t completed, uint32_t *status, uint64_t timeout_ticks,
+                      hipStream_t stream);
+int launch_split_serve(int kind, int A, int L, int nadv, const NarrowDesc &d, const MpeBuffers &b, size_t B, const RollArgs &ra,
+                       const ServeHandles &h, hipStream_t stream);
 int launch_split(bool roll, int kind, int A, int L, int nadv, const NarrowDesc &d, const MpeBuffers &b, size_t B,
                  const RollArgs &ra, hipStream_t stream);
 

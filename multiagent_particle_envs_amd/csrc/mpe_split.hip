@@ -469,12 +469,49 @@ __device__ __forceinline__ void store_state(const MpeBuffers &b, size_t B, int i
   store_aux<AUX>(b.vel + wave_off((size_t)(2 * i + 1) * B + w0) + ln, mvy);
 }
 
+// ---- the step server (SERVE: a ROLL instantiation that is COMMANDED step by step) -----------------------------------------
+// The per-step launch is the reference's contract (one env.step per policy decision, environment.py:80-104), and a dependent
+// launch costs 1.0-2.0 us of launch-to-launch gap on top of the kernel's span (profiles/r6_device_span_*.txt).  The server is
+// ONE resident launch that executes the SAME steps on command: step g (global step number) runs when the doorbell word says
+// `door > g` -- rung by mpe_step_server_ring, a one-thread launch ordered on the CALLER's stream behind whatever produced
+// that step's moves -- reads its one-hot moves from tensor g % ring of the caller's move ring with system-scope loads
+// (another kernel wrote them while this one runs: no cache of ours may serve them), writes that step's rows / rewards /
+// dones / state WRITE-THROUGH (sc1: visible to other kernels when acknowledged, not at kernel end) into output block
+// g % slots, and publishes per workgroup `flag[wg] = g + 1` once every wave's stores of step g are acknowledged.  State
+// stays in registers between steps and episodes restart inside the launch (the rollout's in-kernel reset), so a launch
+// serves up to T steps; a wave that waits longer than `timeout_ticks` of the 100 MHz wall clock for its next command sets
+// `status` and leaves (a server never outlives its commander).  Same device functions in the same order as the per-step
+// kernel: bit-identical to T x {mpe_reset at the boundaries; mpe_step} (tests/test_gpu_server.py).
+//
+// Completion without a second barrier: the stores of step g are known acknowledged where the wave next waits for memory
+// anyway -- `s_waitcnt vmcnt(0)` in front of step g+1's barrier, behind which the reward wave publishes g+1.  A server that
+// is AHEAD of its commander (closed loop: the next doorbell rings only after the consumer saw this step) must not wait for
+// that barrier: a wave that finds its next doorbell unrung drains its stores and counts itself in LDS; the reward wave,
+// spinning on the same doorbell, publishes as soon as all agent waves are counted.
+struct ServeArgs {
+  unsigned long long *door;     // commanded steps (absolute count): step g may run when *door > g
+  unsigned long long *flag;     // [grid] completed steps per workgroup (absolute count)
+  unsigned int *status;         // != 0: a wave gave up waiting (timeout)
+  const float *act_ring;        // `ring` consecutive [A][B][5] move tensors; step g reads tensor g % ring
+  int32_t ring, slots;          // output block of step g: g % slots (blocks of obs_off[A] * B floats / A * B entries)
+  unsigned long long timeout_ticks;
+};
+__device__ __forceinline__ unsigned long long door_load(const unsigned long long *p) {
+  const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int KIND, int A, int L, int NADV, bool ROLL, int RP /* row-store policy: kRowsNt / kRowsSc1 (mpe_device.h) */,
-          bool DUALP = false /* the dual-role rollout: physics + rows waves per agent */>
+          bool DUALP = false /* the dual-role rollout: physics + rows waves per agent */,
+          bool SERVE = false /* the step server: ROLL commanded step by step (above) */>
 __global__ void __launch_bounds__((SplitShape<KIND, A, L, NADV>::waves(DUALP) * kWave))
 k_split(float *const g_pos, float *const g_vel, const float *const g_act, const int32_t *const g_ids, const size_t B,
         const int g_wpw, const int g_observe_only, const unsigned g_movable, const NarrowDesc d, const MpeBuffers b_in,
-        const RollArgs ra) {
+        const RollArgs ra, const ServeArgs sv) {
+  static_assert(!SERVE || (ROLL && !DUALP && RP == kRowsSc1 && KIND < MPE_SCN_SPEAKER_LISTENER),
+                "the step server: single-role rollout, write-through stores, scenarios without utterances");
   // The leading scalar arguments (13 dwords) repeat what the first global loads of a wave need -- the state and
   // action pointers, the batch size, the worlds per workgroup, the movable mask -- so that the CP can PRELOAD them
   // into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, _build.py): the wave's loads leave without a
@@ -488,7 +525,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
   b.act = g_act;
   b.ids = g_ids;
   constexpr int E = A + L, XW = S::XW;
-  constexpr int AUX = aux_policy<KIND, RP>();
+  constexpr int AUX = SERVE ? kRowsSc1 : aux_policy<KIND, RP>();   // (a served step's state / rewards / dones leave write-through)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & (kWave - 1);
   // uniform role of this wave: [0, A) the agent waves (in the dual-role rollout: the PHYSICS waves), then -- dual-role
@@ -527,8 +564,50 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
   int *const mv = reinterpret_cast<int *>(smem + (ROLL ? 2 : 1) * A * XW * kWave + A * S::tile_floats(ROLL));
 
   const int T = ROLL ? ra.T : 1;
-  const size_t obs_stride = ra.trajectory ? (size_t)d.obs_off[A] * B : 0;
-  const size_t row_stride = ra.trajectory ? (size_t)A * B : 0;
+  const size_t obs_stride = (ra.trajectory || SERVE) ? (size_t)d.obs_off[A] * B : 0;
+  const size_t row_stride = (ra.trajectory || SERVE) ? (size_t)A * B : 0;
+  // served steps: output block g % slots and move tensor g % ring of global step g, as counters (a 64-bit modulo per step
+  // costs ~130 instructions); `seen` = this wave's last look at the doorbell; cnt[parity] = agent waves drained while idle
+  int blk0 = 0, mvt0 = 0;
+  unsigned long long seen = 0;
+  int *const idle_cnt = reinterpret_cast<int *>(smem + SplitShape<KIND, A, L, NADV>::lds_bytes(true) / sizeof(float));
+  if constexpr (SERVE) {
+    blk0 = (int)(ra.step0 % (uint64_t)sv.slots);
+    mvt0 = (int)(ra.step0 % (uint64_t)sv.ring);
+    if (threadIdx.x < 2) idle_cnt[threadIdx.x] = 0;
+    __syncthreads();
+  }
+  auto block_of = [&](const int t) { return SERVE ? (blk0 + t) % sv.slots : t; };   // (32-bit; t < T)
+  // wait_door: until step g = step0 + t is commanded.  -> false: gave up (timeout): the wave leaves the kernel.
+  // `publisher`: the reward wave -- while idle it publishes the previous step as soon as every agent wave has drained.
+  auto wait_door = [&](const int t, const bool publisher) -> bool {
+    if constexpr (!SERVE) return true;
+    const unsigned long long g = ra.step0 + (unsigned long long)t;
+    if (seen > g) return true;
+    seen = door_load(sv.door);
+    if (seen > g) return true;
+    // ahead of the commander: this wave's stores of the steps so far are acknowledged before anybody is told so
+    drain_stores();
+    bool told = t == 0;      // (nothing of this launch to publish before its first step)
+    if (!publisher && !told && lane == 0) __hip_atomic_fetch_add(&idle_cnt[t & 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long t_begin = (unsigned long long)wall_clock64();
+    for (;;) {
+      if (publisher && !told) {
+        const int n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&idle_cnt[t & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (n >= A) {   // every agent wave drained: steps < g of this workgroup are complete
+          if (lane == 0) __hip_atomic_store(sv.flag + blockIdx.x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          told = true;
+        }
+      }
+      __builtin_amdgcn_s_sleep(4);
+      seen = door_load(sv.door);
+      if (seen > g) return true;
+      if ((unsigned long long)wall_clock64() - t_begin > sv.timeout_ticks) {
+        if (lane == 0) __hip_atomic_store(sv.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  };
 
   if (!is_agent) {
     // ---- the reward wave --------------------------------------------------------------------------
@@ -558,6 +637,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
     }
     for (int t = 0; t < T; ++t) {
       MPE_STAMP(0);
+      if (SERVE && !wait_door(t, true)) return;
       if (TRACK && cd >= 0) {
         if (cd == 0) {
           if (KIND == MPE_SCN_CRYPTO) goal_r = choice_draw(ra.seed, gw_r, ep_r, 0, d.choice_pop[0]);
@@ -571,7 +651,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
           --cd;
         }
       }
-      if (ROLL && !OWN_DRAW && t + 1 < T) {   // the moves of step t + 1: read by the agent waves behind this step's barrier
+      if (ROLL && !SERVE && !OWN_DRAW && t + 1 < T) {   // the moves of step t + 1: read by the agent waves behind this step's barrier
         const uint64_t gt1 = ra.step0 + (uint64_t)t + 1;
 #pragma unroll
         for (int q = 0; q < (A + 3) / 4; ++q) {
@@ -584,12 +664,22 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       }
       const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
       MPE_STAMP(1);
+      if (SERVE) drain_stores();   // this wave's outputs of step t - 1 are acknowledged ...
       __syncthreads();
+      if (SERVE) {                 // ... and so are every agent wave's (they drain in front of this barrier too): step t - 1 is complete
+        if (t > 0 && lane == 0) __hip_atomic_store(sv.flag + blockIdx.x, ra.step0 + (unsigned long long)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) idle_cnt[t & 1] = 0;      // (next used by step t + 2's waiters, who are behind step t + 1's barrier)
+      }
       MPE_STAMP(2);
       if (!(MPE_SPLIT_ABLATE & 2))
-      reward_wave<KIND, A, L, NADV, ROLL, AUX>(d, sz, b, X, lane, live, ln, B, w0, (size_t)t * row_stride + w0, ra.seed, gw_r,
+      reward_wave<KIND, A, L, NADV, ROLL, AUX>(d, sz, b, X, lane, live, ln, B, w0, (size_t)block_of(t) * row_stride + w0, ra.seed, gw_r,
                                           ra.step0 + (uint64_t)t, goal_r, food);
       MPE_STAMP(3);
+    }
+    if (SERVE) {   // the last step: every wave drains, then the workgroup says so
+      drain_stores();
+      __syncthreads();
+      if (lane == 0) __hip_atomic_store(sv.flag + blockIdx.x, ra.step0 + (unsigned long long)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     MPE_SPAN_END();
     return;
@@ -651,6 +741,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
 
   // ---- one step of agent i, in the pieces the two loop shapes below are made of ---------------------------------
   float gx = 0.f, gy = 0.f;   // this world's goal landmark (publish -> rows)
+  [[maybe_unused]] bool did_reset = false;   // served steps: an in-launch reset moved the landmarks / picks -> behind_barrier stores them
   // step_forces: [in-kernel reset,] this step's move, the action force and the contacts with every other entity in
   // ascending order (Q9) -- everything of World.step (core.py:117-155) up to the force on agent i
   auto step_forces = [&](const int t, float &fx, float &fy) {
@@ -670,12 +761,30 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         if (NCH >= 1) goal = choice_draw(ra.seed, gw, ep, 0, d.choice_pop[0]);
         if (NCH >= 2) pick1 = choice_draw(ra.seed, gw, ep, 1, d.choice_pop[1]);
         ++ep;
+        if (SERVE) did_reset = true;
       }
       // the one-hot row mpe_random_actions would write: drawn here at the first step, by the reward wave afterwards
       // (dual-role rollout of the kinds in MPE_SPLIT_DUAL_OWN_DRAW: always drawn here)
+      if constexpr (SERVE) {
+        // the caller's one-hot row of this step (environment.py:174-181: u = (a1 - a2, a3 - a4) * sensitivity), floats 1..4 of a
+        // 20-byte row as one 16-byte SYSTEM-scope load (sc0 sc1: the tensor was written by another kernel while this one runs)
+        const float *const mt = sv.act_ring + (size_t)((mvt0 + t) % sv.ring) * ((size_t)A * B * MPE_ACTION_DIM);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(mt + wave_off(((size_t)i * B + w0) * MPE_ACTION_DIM)), 0, 0x7fffffff, 0x00027000);
+        typedef int vi4 __attribute__((ext_vector_type(4)));
+        const vi4 m4 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ln * (MPE_ACTION_DIM * 4) + 4), 0, /* sc0 | sc1 */ 17);
+        if (movable_i) {
+          ux = (__builtin_bit_cast(float, m4.x) - __builtin_bit_cast(float, m4.y)) * accel_i;
+          uy = (__builtin_bit_cast(float, m4.z) - __builtin_bit_cast(float, m4.w)) * accel_i;
+        } else {
+          ux = 0.f;
+          uy = 0.f;
+        }
+      } else {
       const int m = (t == 0 || OWN_DRAW) ? action_draw(ra.seed, gw, gt, i) : mv[((t & 1) * A + i) * kWave + lane];
       ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * accel_i;
       uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * accel_i;
+      }
     } else if (step_world && movable_i) {
       if (b.act || b.ids) { ux = ux0 * accel_i; uy = uy0 * accel_i; }
       else fetch_action_wave(b, B, i, w0, ln, accel_i, ux, uy);   // pre-decoded Action.u (mpe_world_step's callers)
@@ -743,9 +852,25 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
     // arrival at this barrier -- so no wave can observe a post-step position in World.step, whatever
     // the dispatch order or timing of the waves (core.py:117-131: forces from the pre-step positions).
 #ifndef MPE_STRESS_STORE_BEFORE_BARRIER
-    if (movable_i && step_world && live && (!ROLL || t == T - 1) && !(MPE_SPLIT_ABLATE & 8))
-      store_state<AUX>(b, B, i, w0, ln, mx, my, mvx, mvy);
+    if (movable_i && step_world && live && (!ROLL || SERVE || t == T - 1) && !(MPE_SPLIT_ABLATE & 8))
+      store_state<AUX>(b, B, i, w0, ln, mx, my, mvx, mvy);   // (a served step leaves its state in HBM like a launched one)
 #endif
+    if constexpr (SERVE) {
+      if (did_reset && live) {   // what mpe_reset would have left in HBM in front of this step: landmarks, picks, an immovable agent
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+          if (l % A == i) {
+            store_aux<AUX>(b.pos + wave_off((size_t)(2 * (A + l)) * B + w0) + ln, px[A + l]);
+            store_aux<AUX>(b.pos + wave_off((size_t)(2 * (A + l) + 1) * B + w0) + ln, py[A + l]);
+          }
+        if (NCH >= 1 && i == 0) {
+          store_aux<AUX>(b.choice + wave_off(w0) + ln, goal);
+          if (NCH >= 2) store_aux<AUX>(b.choice + wave_off(B + w0) + ln, pick1);
+        }
+        if (!movable_i) store_state<AUX>(b, B, i, w0, ln, mx, my, mvx, mvy);
+      }
+      did_reset = false;
+    }
     if constexpr (KIND == MPE_SCN_ADVERSARY && !ROLL) {
       // benchmark_data (simple_adversary.py:57-67): the squared distance to the goal landmark (an adversary's datum, the
       // last of a good agent's) and to every landmark (a good agent's first L) -- each agent wave writes its own
@@ -775,7 +900,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
     if (MPE_SPLIT_ABLATE & 4) return;   // (no observation rows)
     const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
     const uint64_t gt = ra.step0 + (uint64_t)t;   // global step (the word stream of the rollout)
-    float *const obs_t = b.obs + (size_t)t * obs_stride;
+    float *const obs_t = b.obs + (size_t)block_of(t) * obs_stride;
     if (KIND == MPE_SCN_SIMPLE) {  // simple.py:45-50
       constexpr int D = 2 + 2 * L;
       {
@@ -1075,17 +1200,25 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
     for (int t = 0; t < T; ++t) {
       float fx, fy;
       MPE_STAMP(0);
+      if (SERVE && !wait_door(t, false)) return;
       step_forces(t, fx, fy);
       step_integrate(t, fx, fy);
       MPE_STAMP(1);
       publish(t);
       MPE_STAMP(2);
+      if (SERVE) drain_stores();   // step t - 1's rows and state are acknowledged: the reward wave says so behind this barrier
       __syncthreads();
       MPE_STAMP(3);
       behind_barrier(t);
       MPE_STAMP(4);
       rows(t);
       MPE_STAMP(5);   // this step's rows are on their way
+    }
+    if (SERVE) {
+      drain_stores();
+      __syncthreads();
+      MPE_SPAN_END();
+      return;
     }
   }
   if (ROLL && NCH >= 1 && ra.episode_len > 0 && live && i == 0) {   // the picks of the last in-kernel reset
@@ -1121,13 +1254,19 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
 
 constexpr size_t kRowsNtFromBytes = 8u << 20, kRollNtFromBytes = 12u << 20;   // bytes of rows per launch / per rollout step
 using SplitFn = void (*)(float *, float *, const float *, const int32_t *, const size_t, const int, const int, const unsigned,
-                         const NarrowDesc, const MpeBuffers, const RollArgs);
+                         const NarrowDesc, const MpeBuffers, const RollArgs, const ServeArgs);
 struct SplitEntry {
   int kind, A, L, nadv;
   SplitFn step, step_small, roll, roll_small;   // rows stored nontemporal; *_small: at agent scope (mpe_device.h)
   SplitFn roll_dual, roll_dual_small;           // the dual-role rollout (small batches), or nullptr
+  SplitFn serve;                                // the step server (scenarios without utterances), or nullptr
   size_t lds_step, lds_roll;
 };
+template <int KIND, int A, int L, int NADV>
+constexpr SplitFn serve_fn() {
+  if constexpr (KIND < MPE_SCN_SPEAKER_LISTENER) return k_split<KIND, A, L, NADV, true, kRowsSc1, false, true>;
+  else return nullptr;
+}
 template <int KIND, int A, int L, int NADV, int RP>
 constexpr SplitFn dual_fn() {
   if constexpr (dual_kind<KIND>() && SplitShape<KIND, A, L, NADV>::waves(true) * kWave <= 1024) return k_split<KIND, A, L, NADV, true, RP, true>;
@@ -1136,7 +1275,7 @@ constexpr SplitFn dual_fn() {
 #define MPE_SPLIT_ENTRY(KIND, A, L, NADV)                                                                         \
   { KIND, A, L, NADV, k_split<KIND, A, L, NADV, false, kRowsNt>, k_split<KIND, A, L, NADV, false, kRowsSc1>,       \
     k_split<KIND, A, L, NADV, true, kRowsNt>, k_split<KIND, A, L, NADV, true, kRowsSc1>,                           \
-    dual_fn<KIND, A, L, NADV, kRowsNt>(), dual_fn<KIND, A, L, NADV, kRowsSc1>(),                                   \
+    dual_fn<KIND, A, L, NADV, kRowsNt>(), dual_fn<KIND, A, L, NADV, kRowsSc1>(), serve_fn<KIND, A, L, NADV>(),     \
     SplitShape<KIND, A, L, NADV>::lds_bytes(false), SplitShape<KIND, A, L, NADV>::lds_bytes(true) }
 
 static const SplitEntry kSplitTable[] = {
@@ -1219,7 +1358,78 @@ int launch_split(bool roll, int kind, int A, int L, int nadv, const NarrowDesc &
     waves = 2 * A + 1;
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * kWave), roll ? e->lds_roll : e->lds_step, stream,
-                     b.pos, b.vel, b.act, b.ids, B, (int)r2.wpw, (int)r2.observe_only, (unsigned)d.movable, d, b, r2);
+                     b.pos, b.vel, b.act, b.ids, B, (int)r2.wpw, (int)r2.observe_only, (unsigned)d.movable, d, b, r2, ServeArgs{});
+  return (int)hipGetLastError();
+}
+
+bool serve_supports(int kind, int A, int L, int nadv) {
+  const SplitEntry *e = find_split(kind, A, L, nadv);
+  return e && e->serve;
+}
+unsigned serve_grid(size_t B) { return (unsigned)((B + kWave - 1) / kWave); }
+
+// The step server's launch: T commanded steps (mpe_step_server_start).  The grid is the per-step kernel's -- one workgroup per
+// 64 worlds -- and every workgroup must be RESIDENT for the launch to make progress on its own terms (a workgroup that waits
+// for a doorbell holds its CU slots): the caller (mpe_abi.hip) refuses grids beyond what the occupancy query admits.
+int launch_split_serve(int kind, int A, int L, int nadv, const NarrowDesc &d, const MpeBuffers &b, size_t B, const RollArgs &ra,
+                       const ServeHandles &h, hipStream_t stream) {
+  const SplitEntry *e = find_split(kind, A, L, nadv);
+  if (!e || !e->serve) return MPE_EUNSUPPORTED;
+  RollArgs r2 = ra;
+  r2.wpw = kWave;
+  ServeArgs sv;
+  sv.door = reinterpret_cast<unsigned long long *>(h.door);
+  sv.flag = reinterpret_cast<unsigned long long *>(h.flag);
+  sv.status = h.status;
+  sv.act_ring = h.act_ring;
+  sv.ring = h.ring;
+  sv.slots = h.slots;
+  sv.timeout_ticks = h.timeout_ticks;
+  const size_t lds = e->lds_roll + 16;   // + the two idle counters
+  const unsigned grid = serve_grid(B);
+  int per_cu = 0, dev = 0, n_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(e->serve), (A + 1) * kWave, lds) != hipSuccess ||
+      hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return MPE_EUNSUPPORTED;
+  }
+  // (one fewer per CU than the API's answer: the hardware admits one fewer at some SGPR counts, MI355X_MICROARCH.md)
+  if ((size_t)grid > (size_t)n_cu * (size_t)(per_cu > 1 ? per_cu - 1 : per_cu)) return MPE_ESERVER_TOO_LARGE;
+  hipLaunchKernelGGL(e->serve, dim3(grid), dim3((A + 1) * kWave), lds, stream, b.pos, b.vel, b.act, b.ids, B, (int)r2.wpw, 0,
+                     (unsigned)d.movable, d, b, r2, sv);
+  return (int)hipGetLastError();
+}
+
+// the commander's side of the step server: one-thread / one-thread-per-workgroup launches on the CALLER's stream
+__global__ void k_serve_ring(unsigned long long *const door, const unsigned long long commanded) {
+  // (stream order put this launch behind whatever produced the commanded steps' moves; their writes were released when that
+  //  launch ended.  Monotonic: a late ring with a smaller count changes nothing.)
+  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_fetch_max(door, commanded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void __launch_bounds__(256)
+k_serve_wait(const unsigned long long *const flag, const unsigned n_flags, const unsigned long long completed,
+             unsigned int *const status, const unsigned long long timeout_ticks) {
+  // ends when every workgroup of the server has published `completed` steps (or at the timeout): launches behind it on this
+  // stream read those steps' outputs, which were written through and acknowledged before their flag was stored
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_flags) return;
+  const unsigned long long t0 = (unsigned long long)wall_clock64();
+  while (__hip_atomic_load(flag + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < completed) {
+    __builtin_amdgcn_s_sleep(8);
+    if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
+      __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+}
+int launch_serve_ring(uint64_t *door, uint64_t commanded, hipStream_t stream) {
+  hipLaunchKernelGGL(k_serve_ring, dim3(1), dim3(64), 0, stream, reinterpret_cast<unsigned long long *>(door), (unsigned long long)commanded);
+  return (int)hipGetLastError();
+}
+int launch_serve_wait(const uint64_t *flag, unsigned n_flags, uint64_t completed, uint32_t *status, uint64_t timeout_ticks,
+                      hipStream_t stream) {
+  hipLaunchKernelGGL(k_serve_wait, dim3((n_flags + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const unsigned long long *>(flag),
+                     n_flags, (unsigned long long)completed, status, (unsigned long long)timeout_ticks);
   return (int)hipGetLastError();
 }
 

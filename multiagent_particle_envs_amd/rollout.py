@@ -345,3 +345,176 @@ def _copy_struct(s):
     c = type(s)()
     C.memmove(C.byref(c), C.byref(s), C.sizeof(s))
     return c
+
+
+class StepServer(object):
+    """Per-step COMMANDS to one resident launch instead of a launch per step (include/mpe_hip.h: the step server).
+
+        srv = StepServer(env, moves)          # moves: [ring, A, B, 5] one-hot tensors; step g reads moves[g % ring]
+        srv.start(T)                          # one launch on the server's own stream: up to T steps, gated by the doorbell
+        for g in range(T):
+            ... write moves[g % ring] on the current stream ...
+            srv.ring()                        # "step g may run": a one-thread launch on the CURRENT stream
+        srv.wait()                            # the current stream continues when every commanded step's outputs are in memory
+        out = srv.outputs(g)                  # views of output block g % slots: obs_n (list of [B, D_i]), rew [A, B], done [A, B]
+
+    The steps are the per-step kernel's, bit for bit (tests/test_gpu_server.py); episodes restart inside the launch every
+    `episode_len` global steps (mpe_reset's draws).  The server wins where the moves of step g + 1 exist before step g has
+    finished -- its steps then run back to back at the kernel's span, without the 1-2 us dependent-launch gap; a closed loop pays
+    a ring and a wait launch per step and is better served by env.step.  One server per env at a time; the env's own outputs
+    (env.step's ping-pong sets) are not touched: a served step's outputs live in the server's blocks."""
+
+    def __init__(self, env, moves, slots=2, episode_len=0, seed=None, timeout_s=2.0):
+        if not env.fused or getattr(env, "_prog", None) is not None:
+            raise _abi.MpeError("StepServer serves the fused built-in scenarios (a wave-per-agent kernel, no utterances)")
+        if env._py_obs or env._py_reward or env._py_done or env._py_info:
+            raise _abi.MpeError("StepServer evaluates the built-in callbacks only")
+        self.env, self.world = env, env.world
+        env._ensure_buffers()
+        w = self.world
+        A, B = len(w.agents), w.batch_size
+        self._L = _abi.lib()
+        self._desc = _copy_struct(env._desc)
+        if self._L.mpe_step_server_supported(C.byref(self._desc), B) != 1:
+            raise _abi.MpeError("no step server for this scenario / shape (scenarios without utterances at a wave-per-agent shape)")
+        if int(episode_len) and not env._device_restart_ok:
+            raise _abi.MpeError("StepServer's in-launch resets are world.reset_uniform's device draws: this env's reset_world is not that")
+        moves = moves if moves.dim() == 4 else moves[None]
+        if tuple(moves.shape[1:]) != (A, B, _abi.MPE_ACTION_DIM) or moves.dtype != torch.float32 or not moves.is_contiguous() \
+                or moves.device != w.device:
+            raise _abi.MpeError("moves: a contiguous float32 [ring, A, B, %d] tensor on the env's device" % _abi.MPE_ACTION_DIM)
+        self.moves, self.A, self.B = moves, A, B
+        self.slots, self.episode_len = int(slots), int(episode_len)
+        self.seed = int(w.seed if seed is None else seed) & (2 ** 64 - 1)
+        self._lr = float(getattr(env._scenario, "landmark_range", 1.0))
+        self.blocks = Trajectory(env, self.slots)
+        dev = w.device
+        self.door = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.flag = torch.zeros(int(self._L.mpe_step_server_flags(B)), dtype=torch.int64, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        s = _abi.MpeStepServer()
+        s.door, s.flag, s.status = self.door.data_ptr(), self.flag.data_ptr(), self.status.data_ptr()
+        s.act_ring, s.ring, s.slots, s.timeout_us = moves.data_ptr(), int(moves.shape[0]), self.slots, int(timeout_s * 1e6)
+        self._srv = s
+        self.stream = torch.cuda.Stream(device=dev)
+        self.t = 0              # global step at which the next start() begins (absolute: doorbell and flags count from 0)
+        self.commanded = 0
+        self.served_to = 0      # steps covered by the launches started so far
+        torch.cuda.synchronize(dev)      # (the words above are zero before anything can ring)
+
+    def start(self, T):
+        """Launch the server for global steps [served_to, served_to + T) on the server's stream, behind the current stream's
+        work so far (the state it starts from) and behind the previous server launch."""
+        cur = torch.cuda.current_stream(self.world.device)
+        self.stream.wait_stream(cur)
+        b = self.blocks.bufs
+        b.act = b.ids = b.u = None
+        with torch.cuda.stream(self.stream):
+            _abi.check(self._L.mpe_step_server_start(C.byref(self._desc), C.byref(b), self.B, int(T), self.episode_len, self._lr,
+                                                     self.seed, int(self.served_to), int(self.world.world_offset),
+                                                     C.byref(self._srv), _abi.raw_stream(self.world.device)), "mpe_step_server_start")
+        self.served_to += int(T)
+        self.env._scenario_state_stale = True
+        self.env._fast_acts.clear()
+
+    def ring(self, n=1):
+        """Command the next n steps: a one-thread launch on the CURRENT stream (behind whatever wrote their moves)."""
+        self.commanded += int(n)
+        if self.commanded > self.served_to:
+            raise _abi.MpeError("ring(): %d steps commanded, the launches started so far serve %d -- start() first" % (self.commanded, self.served_to))
+        _abi.check(self._L.mpe_step_server_ring(C.byref(self._srv), self.commanded, _abi.raw_stream(self.world.device)), "mpe_step_server_ring")
+
+    def wait(self, completed=None):
+        """The current stream continues when `completed` steps (default: all commanded so far) have their outputs in memory."""
+        _abi.check(self._L.mpe_step_server_wait(C.byref(self._srv), self.B, int(self.commanded if completed is None else completed),
+                                                _abi.raw_stream(self.world.device)), "mpe_step_server_wait")
+
+    def join(self):
+        """The current stream waits for the END of the server launches started so far (all their steps were commanded)."""
+        torch.cuda.current_stream(self.world.device).wait_stream(self.stream)
+
+    def outputs(self, g):
+        k = int(g) % self.slots
+        return self.blocks.obs[k], self.blocks.rew[k], self.blocks.done[k]
+
+    def check(self):
+        """After a synchronisation: raise if the server or a wait gave up (a doorbell that never rang)."""
+        st = int(self.status.item())
+        if st:
+            raise _abi.MpeError("step server: %s timed out waiting (status %d)" % ("the server" if st == 1 else "a wait", st))
+
+
+class ServedRollout(object):
+    """The random-action benchmark protocol through the step server: every step is COMMANDED on its own (a doorbell launch on the
+    caller's stream, behind the launch that drew its moves), none is launched.  Per `episode_len` steps: ONE
+    `mpe_random_actions_block` draw into one half of a 2 x episode_len move ring (the other half is being read), ONE server launch
+    of episode_len steps on the server's stream (the episode's reset is the server's in-launch reset: mpe_reset's draws), and
+    episode_len doorbells.  Fresh moves for every step, every step's rows / rewards / dones / state written -- the work of
+    RandomRollout(regenerate=True).enqueue, bit for bit (tests/test_gpu_server.py)."""
+
+    def __init__(self, env, episode_len=25, seed=None, slots=2, timeout_s=5.0):
+        w = env.world
+        env._ensure_buffers()
+        A, B = len(w.agents), w.batch_size
+        self.env, self.world, self.A, self.B, self.EP = env, w, A, B, int(episode_len)
+        assert self.EP >= 1
+        self.moves = torch.zeros((2 * self.EP, A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=w.device)
+        self.srv = StepServer(env, self.moves, slots=slots, episode_len=self.EP, seed=seed, timeout_s=timeout_s)
+        self.seed = self.srv.seed
+        self._L = _abi.lib()
+        self._read_done = [torch.cuda.Event(), torch.cuda.Event()]     # the server launch that read half h has ended
+        self.t = 0
+
+    def enqueue(self, steps):
+        """`steps` (a multiple of episode_len) commanded steps; returns when everything is ENQUEUED, the current stream joined
+        behind the last server launch."""
+        assert steps % self.EP == 0, "whole episodes"
+        dev = self.world.device
+        cur = torch.cuda.current_stream(dev)
+        recorded = [False, False]
+        for _ in range(steps // self.EP):
+            h = (self.t // self.EP) & 1
+            if recorded[h]:
+                cur.wait_event(self._read_done[h])      # the launch of two episodes ago has finished reading this half
+            _abi.check(self._L.mpe_random_actions_block(self.moves[h * self.EP].data_ptr(), None, self.A, self.B, self.seed, int(self.t),
+                                                        self.EP, int(self.world.world_offset), _abi.raw_stream(dev)), "mpe_random_actions_block")
+            self.srv.start(self.EP)
+            self._read_done[h].record(self.srv.stream)
+            recorded[h] = True
+            for _k in range(self.EP):
+                self.srv.ring()
+            self.t += self.EP
+        self.srv.join()
+
+    def capture(self, steps):
+        """`steps` commanded steps as ONE HIP graph (both streams inside it); replay() re-runs them.  `steps` must be a multiple
+        of 2 x episode_len (the move ring's period) for the replay to be periodic."""
+        assert steps % (2 * self.EP) == 0
+        dev = self.world.device
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            self.enqueue(2 * self.EP)        # code objects loaded outside the capture
+            torch.cuda.synchronize()
+            self.srv.check()
+            state = (self.t, self.srv.commanded, self.srv.served_to)
+            with torch.cuda.graph(g, stream=s):
+                self.enqueue(steps)
+            # a replay repeats the SAME absolute step numbers' commands: the doorbell and flag words go back with it
+            self.t, self.srv.commanded, self.srv.served_to = state
+        torch.cuda.current_stream(dev).wait_stream(s)
+        return _ServedGraph(g, self, steps)
+
+
+class _ServedGraph(object):
+    def __init__(self, graph, roll, steps):
+        self.graph, self.roll, self.steps = graph, roll, steps
+
+    def replay(self):
+        # the captured launches carry absolute step numbers [t0, t0 + steps): rewind the doorbell and the flags to t0 first
+        # (two small fills on the replay's stream, in front of the graph)
+        r = self.roll
+        r.srv.door.fill_(r.t)
+        r.srv.flag.fill_(r.t)
+        self.graph.replay()

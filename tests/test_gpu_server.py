@@ -1,0 +1,143 @@
+"""The step server (include/mpe_hip.h: mpe_step_server_*; rollout.StepServer): per-step COMMANDS to one resident launch.
+
+The served steps must be the per-step kernel's, bit for bit -- T x {mpe_reset at the episode boundaries; mpe_step} through
+RandomRollout.enqueue on a second env with the same seed and the same move tensors -- in every commanding pattern: all doorbells
+rung ahead (the pipelined regime the server exists for), one at a time with the host in between (the closed loop: the server is
+AHEAD of its commander and must publish a step's completion without waiting for the next command), in bursts; on ragged batches,
+with per-world picks (simple_adversary) and an immovable-free / adversary mix (simple_tag).  A server whose doorbell never rings
+gives up after its timeout and says so; shapes it cannot serve are refused with the reason."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import multiagent_particle_envs_amd as mpe
+from multiagent_particle_envs_amd import _abi
+from multiagent_particle_envs_amd.rollout import RandomRollout, StepServer
+
+pytestmark = pytest.mark.gpu
+
+
+def reference_steps(name, kw, B, T, EP, ring):
+    """T steps through the per-step launches: -> (the move ring, per step: obs rows of every agent, rew, done, pos, vel)."""
+    env = mpe.make_env(name, batch_size=B, seed=3, **kw)
+    rr = RandomRollout(env, episode_len=EP, pool=ring, regenerate=False)
+    out = []
+    for _ in range(T):
+        o = rr.enqueue(1)
+        torch.cuda.synchronize()
+        pos, vel = env.world.pos.clone(), env.world.vel.clone()
+        ch = env.world.choice_i32.clone() if env.world.choice_i32 is not None else None
+        out.append(([x.clone() for x in o.obs_n], o.rew.clone(), o.done.clone(), pos, vel, ch))
+    return rr.pool_t.clone(), out
+
+
+def same(step, srv, env, g, what):
+    obs, rew, done, pos, vel, ch = step
+    o_s, r_s, d_s = srv.outputs(g)
+    for i, (a, b) in enumerate(zip(o_s, obs)):
+        assert torch.equal(a, b), "%s: obs of agent %d at step %d" % (what, i, g)
+    assert torch.equal(r_s, rew) and torch.equal(d_s, done), "%s: rew / done at step %d" % (what, g)
+
+
+CASES = [("simple_spread", {}, 4096, 25), ("simple_spread", {}, 1000, 7), ("simple_tag", {}, 1000, 25),
+         ("simple_adversary", {}, 777, 10), ("simple_push", {}, 640, 25), ("simple", {}, 130, 5),
+         ("simple_spread", {"num_agents": 5}, 900, 25)]
+
+
+@pytest.mark.parametrize("name,kw,B,EP", CASES)
+def test_served_steps_are_the_launched_steps_bit_for_bit(name, kw, B, EP):
+    T, ring = 60, 16
+    moves, ref = reference_steps(name, kw, B, T, EP, ring)
+    env = mpe.make_env(name, batch_size=B, seed=3, **kw)
+    srv = StepServer(env, moves, slots=T, episode_len=EP, timeout_s=5.0)
+    srv.start(T)
+    srv.ring(T)                      # every step commanded ahead: the server runs them back to back
+    srv.join()
+    torch.cuda.synchronize()
+    srv.check()
+    assert int(srv.flag.min()) == T and int(srv.door.item()) == T
+    for g in range(T):
+        same(ref[g], srv, env, g, "all rung ahead")
+    assert torch.equal(env.world.pos, ref[-1][3]) and torch.equal(env.world.vel, ref[-1][4])      # the state after the last step, in HBM
+    if ref[-1][5] is not None:
+        assert torch.equal(env.world.choice_i32, ref[-1][5])
+
+
+@pytest.mark.parametrize("name,kw,B,EP", [CASES[1], CASES[3]])
+def test_closed_loop_commands_one_step_at_a_time(name, kw, B, EP):
+    """ring -> wait -> read -> ring ...: the server is ahead of its commander at every step (the idle path: a step's completion is
+    published without the next command), state visible in HBM after each step, host pauses in between."""
+    T, ring = 12, 4
+    moves, ref = reference_steps(name, kw, B, T, EP, ring)
+    env = mpe.make_env(name, batch_size=B, seed=3, **kw)
+    srv = StepServer(env, moves, slots=2, episode_len=EP, timeout_s=20.0)
+    srv.start(T)
+    for g in range(T):
+        srv.ring()
+        srv.wait()
+        torch.cuda.current_stream().synchronize()         # (only this stream: the server launch is still running on its own)
+        assert int(srv.status.item()) == 0
+        same(ref[g], srv, env, g, "closed loop")
+        assert torch.equal(env.world.pos, ref[g][3]) and torch.equal(env.world.vel, ref[g][4]), "state in HBM after step %d" % g
+        if g in (2, 7):
+            time.sleep(0.05)
+    srv.join()
+    torch.cuda.synchronize()
+    srv.check()
+
+
+def test_bursts_and_two_launches():
+    """Doorbells in bursts with the host asleep in between, over two consecutive server launches (the second starts from the
+    state the first left in HBM; doorbell and flags count on)."""
+    name, kw, B, EP = "simple_spread", {}, 2048, 25
+    T, ring = 50, 8
+    moves, ref = reference_steps(name, kw, B, T, EP, ring)
+    env = mpe.make_env(name, batch_size=B, seed=3, **kw)
+    srv = StepServer(env, moves, slots=T, episode_len=EP, timeout_s=20.0)
+    srv.start(30)
+    for n in (1, 3, 9, 17):
+        srv.ring(n)
+        srv.wait()
+        torch.cuda.current_stream().synchronize()
+        time.sleep(0.01)
+    srv.start(20)
+    srv.ring(20)
+    srv.join()
+    torch.cuda.synchronize()
+    srv.check()
+    for g in range(T):
+        same(ref[g], srv, env, g, "bursts")
+    assert torch.equal(env.world.pos, ref[-1][3])
+
+
+def test_a_server_nobody_commands_gives_up():
+    env = mpe.make_env("simple_spread", batch_size=512, seed=3)
+    moves = torch.zeros((2, 3, 512, _abi.MPE_ACTION_DIM), device="cuda")
+    srv = StepServer(env, moves, slots=2, timeout_s=0.2)
+    srv.start(3)
+    srv.ring(2)
+    t0 = time.time()
+    srv.join()
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 5.0
+    assert int(srv.status.item()) == 1 and int(srv.flag.min()) == 2      # two steps served, then the timeout
+    with pytest.raises(_abi.MpeError, match="timed out"):
+        srv.check()
+    with pytest.raises(_abi.MpeError, match="start"):
+        srv.ring(5)
+
+
+def test_what_the_server_refuses():
+    env = mpe.make_env("simple_speaker_listener", batch_size=256)
+    with pytest.raises(_abi.MpeError, match="step server"):
+        StepServer(env, torch.zeros((2, 2, 256, _abi.MPE_ACTION_DIM), device="cuda"))
+    env = mpe.make_env("simple_spread", batch_size=256)
+    with pytest.raises(_abi.MpeError, match="moves"):
+        StepServer(env, torch.zeros((2, 3, 255, _abi.MPE_ACTION_DIM), device="cuda"))
+    B = 1 << 20                                        # 16 384 workgroups cannot all be resident
+    env = mpe.make_env("simple_spread", batch_size=B)
+    srv = StepServer(env, torch.zeros((1, 3, B, _abi.MPE_ACTION_DIM), device="cuda"), slots=1)
+    with pytest.raises(_abi.MpeError, match="resident"):
+        srv.start(1)
