@@ -551,22 +551,20 @@ def served_leg(torch, mpe, scenario, agents, B, EP, seed, region_ms, repeats=3, 
     from multiagent_particle_envs_amd.rollout import ServedRollout
     env = mpe.make_env(scenario, batch_size=B, seed=seed, **(kw or {}))
     A, Lm = len(env.world.agents), len(env.world.landmarks)
-    roll = ServedRollout(env, episode_len=EP, timeout_s=10.0)
-    G = 2 * EP * 8                                    # steps per captured graph (a multiple of the move ring's period)
-    g = roll.capture(G)
-    g.replay()
+    roll = ServedRollout(env, episode_len=EP, timeout_s=10.0, graphs=True)
+    G = 2 * EP * 4                                    # steps per enqueue call
+    roll.enqueue(G)                                   # (captures the two caller-side episode graphs)
     torch.cuda.synchronize()
     roll.srv.check()
     t0 = time.perf_counter()
-    g.replay()
+    roll.enqueue(G)
     torch.cuda.synchronize()
     reps = max(1, int(math.ceil(region_ms * 1e-3 / max(time.perf_counter() - t0, 1e-6))))
     walls = []
     for _ in range(repeats):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _r in range(reps):
-            g.replay()
+        roll.enqueue(G * reps)
         torch.cuda.synchronize()
         walls.append(time.perf_counter() - t0)
     roll.srv.check()
@@ -575,8 +573,10 @@ def served_leg(torch, mpe, scenario, agents, B, EP, seed, region_ms, repeats=3, 
     n = G * reps
     bytes_step = algorithmic_bytes(A, Lm, int(env._obs_off[-1]), len(env.world.choice_pops), 0)
     return {"what": "the headline protocol with every step COMMANDED to a resident step server (one launch per %d-step episode on its "
-                    "own stream; per step a doorbell launch on the caller's stream behind the draw of its moves) instead of launched: "
-                    "fresh moves from HBM, in-launch resets, every step's rows / rewards / dones / state written" % EP,
+                    "own stream; per step a doorbell launch on the caller's stream behind the draw of its moves -- the draw and its "
+                    "doorbells replayed as one graph per episode) instead of launched: fresh moves from HBM, in-launch resets, "
+                    "every step's rows / rewards / dones / state written" % EP,
+            "server_stream_probe": roll.srv.stream_probe,
             "value": B * n / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3 / n, "timed_steps": n, "timed_region_s": dt,
             "repeats": {"min": B * n / walls[-1], "median": B * n / dt, "max": B * n / walls[0]},
             "frac_timed_region": bytes_step * B / (dt / n) / 1e9 / HBM_PEAK_GBS,

@@ -240,7 +240,8 @@ int mpe_rollout_random(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int6
  * launch per step every step pays the dependent-launch gap (1.0-2.0 us on top of the kernel's span).  A step server is ONE
  * launch that performs the same steps ON COMMAND: mpe_step_server_start puts it on a stream of its own for up to T steps;
  * the caller then commands steps one by one with mpe_step_server_ring -- a one-thread launch on the CALLER's stream, so it
- * is ordered behind whatever produced that step's moves -- and the server executes global step g as soon as `commanded > g`:
+ * is ordered behind whatever produced that step's moves; it adds n_steps to the doorbell word -- and the server executes
+ * global step g as soon as the doorbell exceeds g (steps are numbered from 0 over the life of the doorbell word):
  *   moves    one-hot rows [A][B][5] in tensor g % ring of `act_ring` (ring consecutive tensors)
  *   outputs  obs / rew / done / info_* block g % slots of bufs' output buffers (blocks of obs_off[A] * B floats / A * B
  *            entries: `slots` consecutive blocks, as mpe_rollout_random's trajectory blocks); pos / vel after every step
@@ -253,7 +254,11 @@ int mpe_rollout_random(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int6
  * sequences, action repeat, several env instances interleaved, the random-action benchmark) -- their steps run back to back
  * at the kernel's span; a closed loop (policy reads step g's rows before it can command g + 1) pays ring + wait launches
  * and is better served by mpe_step.  Scenarios without utterances, at shapes with a wave-per-agent kernel; B small enough
- * for every 64-world workgroup to be resident (mpe_step_server_supported).                                               */
+ * for every 64-world workgroup to be resident (mpe_step_server_supported).
+ * The two streams must map to different HARDWARE queues: HIP multiplexes streams onto a few of them, and a ring queued behind
+ * the resident server on the same hardware queue never starts (the server then times out).  Probe before trusting a pair of
+ * streams: mpe_step_server_wait on the candidate server stream with a short timeout_us, mpe_step_server_ring on the caller's
+ * stream with door == flag == one scratch word -- *status stays 0 only if the two ran concurrently (rollout.StepServer).   */
 typedef struct MpeStepServer {
   uint64_t *door;          /* device, 1 word, zeroed by the caller once: steps commanded so far (absolute, monotonic)   */
   uint64_t *flag;          /* device, mpe_step_server_flags(B) words, zeroed once: steps completed, per workgroup      */
@@ -267,7 +272,7 @@ int64_t mpe_step_server_flags(int64_t B);
 int mpe_step_server_start(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, int32_t T, int32_t episode_len,
                           float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
                           const MpeStepServer *srv, void *server_stream);
-int mpe_step_server_ring(const MpeStepServer *srv, uint64_t steps_commanded, void *caller_stream);
+int mpe_step_server_ring(const MpeStepServer *srv, uint64_t n_steps /* door += n_steps */, void *caller_stream);
 int mpe_step_server_wait(const MpeStepServer *srv, int64_t B, uint64_t steps_completed, void *caller_stream);
 
 /* ---- composable output stage: a USER scenario's observation / reward as a row program ---------------------------------

@@ -522,9 +522,9 @@ int mpe_step_server_start(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t
                 "its slots): serve a smaller batch per server", what, (long long)B, mpe::serve_grid((size_t)B));
   return hip_result(rc, what);
 }
-int mpe_step_server_ring(const MpeStepServer *srv, uint64_t steps_commanded, void *stream) {
+int mpe_step_server_ring(const MpeStepServer *srv, uint64_t n_steps, void *stream) {
   if (int rc = check_server(srv, "mpe_step_server_ring")) return rc;
-  return hip_result(mpe::launch_serve_ring(srv->door, steps_commanded, static_cast<hipStream_t>(stream)), "mpe_step_server_ring");
+  return hip_result(mpe::launch_serve_ring(srv->door, n_steps, static_cast<hipStream_t>(stream)), "mpe_step_server_ring");
 }
 int mpe_step_server_wait(const MpeStepServer *srv, int64_t B, uint64_t steps_completed, void *stream) {
   if (int rc = check_server(srv, "mpe_step_server_wait")) return rc;

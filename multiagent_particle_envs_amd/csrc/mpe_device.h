@@ -443,7 +443,11 @@ __device__ __forceinline__ void store_row4(float *p, float4 o) {
     __builtin_nontemporal_store(t, reinterpret_cast<vf4 *>(p));
   } else if constexpr (F == kRowsSc1) {
     vf4 t = {o.x, o.y, o.z, o.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t));
+    // `s_nop 1` INSIDE the string: a store of more than 64 bits reads its data registers over several cycles and hipcc pads
+    // nothing behind an asm statement -- its next instruction may overwrite the upper half before the store has read it
+    // (seen in the step server, round 6: the (z, w) halves of lanes 12-15 of every 16 in the first flush pass held garbage;
+    //  the launched kernels happened to schedule a harmless instruction there)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t));
   } else {
     *reinterpret_cast<float4 *>(p) = o;
   }

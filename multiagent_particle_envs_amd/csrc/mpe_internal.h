@@ -71,7 +71,7 @@ struct ServeHandles {
 constexpr int MPE_ESERVER_TOO_LARGE = -1000;   // internal: the grid cannot be resident (mapped to MPE_EUNSUPPORTED with a message)
 bool serve_supports(int kind, int A, int L, int nadv);
 unsigned serve_grid(size_t B);
-int launch_serve_ring(uint64_t *door, uint64_t commanded, hipStream_t stream);
+int launch_serve_ring(uint64_t *door, uint64_t n, hipStream_t stream);
 int launch_serve_wait(const uint64_t *flag, unsigned n_flags, uint64_t completed, uint32_t *status, uint64_t timeout_ticks,
                       hipStream_t stream);
 int launch_split_serve(int kind, int A, int L, int nadv, const NarrowDesc &d, const MpeBuffers &b, size_t B, const RollArgs &ra,

@@ -473,7 +473,7 @@ __device__ __forceinline__ void store_state(const MpeBuffers &b, size_t B, int i
 // The per-step launch is the reference's contract (one env.step per policy decision, environment.py:80-104), and a dependent
 // launch costs 1.0-2.0 us of launch-to-launch gap on top of the kernel's span (profiles/r6_device_span_*.txt).  The server is
 // ONE resident launch that executes the SAME steps on command: step g (global step number) runs when the doorbell word says
-// `door > g` -- rung by mpe_step_server_ring, a one-thread launch ordered on the CALLER's stream behind whatever produced
+// `door > g` -- rung (door += n) by mpe_step_server_ring, a one-thread launch ordered on the CALLER's stream behind whatever produced
 // that step's moves -- reads its one-hot moves from tensor g % ring of the caller's move ring with system-scope loads
 // (another kernel wrote them while this one runs: no cache of ours may serve them), writes that step's rows / rewards /
 // dones / state WRITE-THROUGH (sc1: visible to other kernels when acknowledged, not at kernel end) into output block
@@ -769,13 +769,16 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         // the caller's one-hot row of this step (environment.py:174-181: u = (a1 - a2, a3 - a4) * sensitivity), floats 1..4 of a
         // 20-byte row as one 16-byte SYSTEM-scope load (sc0 sc1: the tensor was written by another kernel while this one runs)
         const float *const mt = sv.act_ring + (size_t)((mvt0 + t) % sv.ring) * ((size_t)A * B * MPE_ACTION_DIM);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(mt + wave_off(((size_t)i * B + w0) * MPE_ACTION_DIM)), 0, 0x7fffffff, 0x00027000);
-        typedef int vi4 __attribute__((ext_vector_type(4)));
-        const vi4 m4 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ln * (MPE_ACTION_DIM * 4) + 4), 0, /* sc0 | sc1 */ 17);
+        // (inline asm: __builtin_amdgcn_raw_buffer_load_b128(..., aux = 17) compiles to a ONE-dword load on this toolchain; the
+        //  wait is part of the statement -- the compiler does not count asm loads -- and nothing of this wave's step can start
+        //  before its move anyway)
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        const float *const mp = mt + wave_off(((size_t)i * B + w0) * MPE_ACTION_DIM) + (ln * MPE_ACTION_DIM + 1);
+        vf4 m4;
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(m4) : "v"(mp) : "memory");
         if (movable_i) {
-          ux = (__builtin_bit_cast(float, m4.x) - __builtin_bit_cast(float, m4.y)) * accel_i;
-          uy = (__builtin_bit_cast(float, m4.z) - __builtin_bit_cast(float, m4.w)) * accel_i;
+          ux = (m4.x - m4.y) * accel_i;
+          uy = (m4.z - m4.w) * accel_i;
         } else {
           ux = 0.f;
           uy = 0.f;
@@ -1401,10 +1404,10 @@ int launch_split_serve(int kind, int A, int L, int nadv, const NarrowDesc &d, co
 }
 
 // the commander's side of the step server: one-thread / one-thread-per-workgroup launches on the CALLER's stream
-__global__ void k_serve_ring(unsigned long long *const door, const unsigned long long commanded) {
+__global__ void k_serve_ring(unsigned long long *const door, const unsigned long long n) {
   // (stream order put this launch behind whatever produced the commanded steps' moves; their writes were released when that
-  //  launch ended.  Monotonic: a late ring with a smaller count changes nothing.)
-  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_fetch_max(door, commanded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  //  launch ended.  The count is RELATIVE -- n more steps -- so a captured ring replays as "n more" whatever the step number.)
+  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_fetch_add(door, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ void __launch_bounds__(256)
 k_serve_wait(const unsigned long long *const flag, const unsigned n_flags, const unsigned long long completed,
@@ -1422,8 +1425,8 @@ k_serve_wait(const unsigned long long *const flag, const unsigned n_flags, const
     }
   }
 }
-int launch_serve_ring(uint64_t *door, uint64_t commanded, hipStream_t stream) {
-  hipLaunchKernelGGL(k_serve_ring, dim3(1), dim3(64), 0, stream, reinterpret_cast<unsigned long long *>(door), (unsigned long long)commanded);
+int launch_serve_ring(uint64_t *door, uint64_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(k_serve_ring, dim3(1), dim3(64), 0, stream, reinterpret_cast<unsigned long long *>(door), (unsigned long long)n);
   return (int)hipGetLastError();
 }
 int launch_serve_wait(const uint64_t *flag, unsigned n_flags, uint64_t completed, uint32_t *status, uint64_t timeout_ticks,

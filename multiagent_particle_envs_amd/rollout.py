@@ -396,11 +396,39 @@ class StepServer(object):
         s.door, s.flag, s.status = self.door.data_ptr(), self.flag.data_ptr(), self.status.data_ptr()
         s.act_ring, s.ring, s.slots, s.timeout_us = moves.data_ptr(), int(moves.shape[0]), self.slots, int(timeout_s * 1e6)
         self._srv = s
-        self.stream = torch.cuda.Stream(device=dev)
+        self._commander = _abi.raw_stream(dev).value
+        self.stream = self._concurrent_stream(dev)
         self.t = 0              # global step at which the next start() begins (absolute: doorbell and flags count from 0)
         self.commanded = 0
         self.served_to = 0      # steps covered by the launches started so far
         torch.cuda.synchronize(dev)      # (the words above are zero before anything can ring)
+
+    def _concurrent_stream(self, dev, probe_timeout_s=0.03):
+        """A stream whose launches run CONCURRENTLY with the current stream's: HIP multiplexes its streams onto a few hardware
+        queues, and a doorbell queued behind the resident server on the same hardware queue would never start.  Candidates (a
+        high-priority stream first: priorities have queues of their own) are probed with the library's own wait / ring pair on
+        a scratch word -- the wait, on the candidate, spins until the ring, on the current stream, has run."""
+        word = torch.zeros(1, dtype=torch.int64, device=dev)
+        st = torch.zeros(1, dtype=torch.int32, device=dev)
+        p = _abi.MpeStepServer()
+        p.door = p.flag = word.data_ptr()
+        p.status, p.timeout_us = st.data_ptr(), int(probe_timeout_s * 1e6)
+        tried = []
+        for k in range(8):
+            cand = torch.cuda.Stream(device=dev, priority=-1) if k == 0 else torch.cuda.Stream(device=dev)
+            word.zero_()
+            st.zero_()
+            torch.cuda.synchronize(dev)
+            with torch.cuda.stream(cand):
+                _abi.check(self._L.mpe_step_server_wait(C.byref(p), 1, 1, _abi.raw_stream(dev)), "mpe_step_server_wait (probe)")
+            _abi.check(self._L.mpe_step_server_ring(C.byref(p), 1, _abi.raw_stream(dev)), "mpe_step_server_ring (probe)")
+            torch.cuda.synchronize(dev)
+            if int(st.item()) == 0:
+                self.stream_probe = {"picked": k, "serialised_candidates": tried}
+                return cand
+            tried.append(k)
+        raise _abi.MpeError("StepServer: no stream runs concurrently with the current one (8 candidates probed): the doorbell "
+                            "could never overtake the resident server")
 
     def start(self, T):
         """Launch the server for global steps [served_to, served_to + T) on the server's stream, behind the current stream's
@@ -419,10 +447,13 @@ class StepServer(object):
 
     def ring(self, n=1):
         """Command the next n steps: a one-thread launch on the CURRENT stream (behind whatever wrote their moves)."""
+        if _abi.raw_stream(self.world.device).value != self._commander:
+            raise _abi.MpeError("ring(): command from the stream that was current when the StepServer was built (the one its server "
+                                "stream was probed against)")
         self.commanded += int(n)
         if self.commanded > self.served_to:
             raise _abi.MpeError("ring(): %d steps commanded, the launches started so far serve %d -- start() first" % (self.commanded, self.served_to))
-        _abi.check(self._L.mpe_step_server_ring(C.byref(self._srv), self.commanded, _abi.raw_stream(self.world.device)), "mpe_step_server_ring")
+        _abi.check(self._L.mpe_step_server_ring(C.byref(self._srv), int(n), _abi.raw_stream(self.world.device)), "mpe_step_server_ring")
 
     def wait(self, completed=None):
         """The current stream continues when `completed` steps (default: all commanded so far) have their outputs in memory."""
@@ -450,9 +481,14 @@ class ServedRollout(object):
     `mpe_random_actions_block` draw into one half of a 2 x episode_len move ring (the other half is being read), ONE server launch
     of episode_len steps on the server's stream (the episode's reset is the server's in-launch reset: mpe_reset's draws), and
     episode_len doorbells.  Fresh moves for every step, every step's rows / rewards / dones / state written -- the work of
-    RandomRollout(regenerate=True).enqueue, bit for bit (tests/test_gpu_server.py)."""
+    RandomRollout(regenerate=True).enqueue, bit for bit (tests/test_gpu_server.py).
 
-    def __init__(self, env, episode_len=25, seed=None, slots=2, timeout_s=5.0):
+    graphs=True: the caller-stream half of an episode -- the draw and its episode_len doorbells -- is ONE HIP graph per ring half,
+    replayed every other episode (its draw repeats the moves of the episode it was captured at: the graph protocol's usual
+    frozen step numbers); the server launches stay eager on the server's own, PROBED stream (inside a graph the mapping of
+    branches to hardware queues is not ours to probe)."""
+
+    def __init__(self, env, episode_len=25, seed=None, slots=2, timeout_s=5.0, graphs=False):
         w = env.world
         env._ensure_buffers()
         A, B = len(w.agents), w.batch_size
@@ -463,7 +499,17 @@ class ServedRollout(object):
         self.seed = self.srv.seed
         self._L = _abi.lib()
         self._read_done = [torch.cuda.Event(), torch.cuda.Event()]     # the server launch that read half h has ended
+        self._recorded = [False, False]
         self.t = 0
+        self._graphs = [None, None] if graphs else None
+
+    def _caller_half(self, h, t):
+        """The caller-stream work of the episode that starts at global step t and uses ring half h: draw, then the doorbells."""
+        dev = self.world.device
+        _abi.check(self._L.mpe_random_actions_block(self.moves[h * self.EP].data_ptr(), None, self.A, self.B, self.seed, int(t),
+                                                    self.EP, int(self.world.world_offset), _abi.raw_stream(dev)), "mpe_random_actions_block")
+        for _k in range(self.EP):
+            _abi.check(self._L.mpe_step_server_ring(C.byref(self.srv._srv), 1, _abi.raw_stream(dev)), "mpe_step_server_ring")
 
     def enqueue(self, steps):
         """`steps` (a multiple of episode_len) commanded steps; returns when everything is ENQUEUED, the current stream joined
@@ -471,50 +517,28 @@ class ServedRollout(object):
         assert steps % self.EP == 0, "whole episodes"
         dev = self.world.device
         cur = torch.cuda.current_stream(dev)
-        recorded = [False, False]
         for _ in range(steps // self.EP):
             h = (self.t // self.EP) & 1
-            if recorded[h]:
+            if self._recorded[h]:
                 cur.wait_event(self._read_done[h])      # the launch of two episodes ago has finished reading this half
-            _abi.check(self._L.mpe_random_actions_block(self.moves[h * self.EP].data_ptr(), None, self.A, self.B, self.seed, int(self.t),
-                                                        self.EP, int(self.world.world_offset), _abi.raw_stream(dev)), "mpe_random_actions_block")
-            self.srv.start(self.EP)
+            self.srv.start(self.EP)                     # (behind the current stream's work so far: the state it starts from)
             self._read_done[h].record(self.srv.stream)
-            recorded[h] = True
-            for _k in range(self.EP):
-                self.srv.ring()
+            self._recorded[h] = True
+            if self._graphs is None:
+                self._caller_half(h, self.t)
+            else:
+                if self._graphs[h] is None:
+                    self._caller_half(h, self.t)        # (code objects loaded, and this episode really commanded, outside the capture)
+                    g = torch.cuda.CUDAGraph()
+                    side = torch.cuda.Stream(device=dev)
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        with torch.cuda.graph(g, stream=side):
+                            self._caller_half(h, self.t)
+                    cur.wait_stream(side)
+                    self._graphs[h] = g
+                else:
+                    self._graphs[h].replay()
+            self.srv.commanded += self.EP
             self.t += self.EP
         self.srv.join()
-
-    def capture(self, steps):
-        """`steps` commanded steps as ONE HIP graph (both streams inside it); replay() re-runs them.  `steps` must be a multiple
-        of 2 x episode_len (the move ring's period) for the replay to be periodic."""
-        assert steps % (2 * self.EP) == 0
-        dev = self.world.device
-        g = torch.cuda.CUDAGraph()
-        s = torch.cuda.Stream(device=dev)
-        s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
-            self.enqueue(2 * self.EP)        # code objects loaded outside the capture
-            torch.cuda.synchronize()
-            self.srv.check()
-            state = (self.t, self.srv.commanded, self.srv.served_to)
-            with torch.cuda.graph(g, stream=s):
-                self.enqueue(steps)
-            # a replay repeats the SAME absolute step numbers' commands: the doorbell and flag words go back with it
-            self.t, self.srv.commanded, self.srv.served_to = state
-        torch.cuda.current_stream(dev).wait_stream(s)
-        return _ServedGraph(g, self, steps)
-
-
-class _ServedGraph(object):
-    def __init__(self, graph, roll, steps):
-        self.graph, self.roll, self.steps = graph, roll, steps
-
-    def replay(self):
-        # the captured launches carry absolute step numbers [t0, t0 + steps): rewind the doorbell and the flags to t0 first
-        # (two small fills on the replay's stream, in front of the graph)
-        r = self.roll
-        r.srv.door.fill_(r.t)
-        r.srv.flag.fill_(r.t)
-        self.graph.replay()

@@ -141,3 +141,33 @@ def test_what_the_server_refuses():
     srv = StepServer(env, torch.zeros((1, 3, B, _abi.MPE_ACTION_DIM), device="cuda"), slots=1)
     with pytest.raises(_abi.MpeError, match="resident"):
         srv.start(1)
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_served_rollout_is_the_fresh_moves_rollout(graphs):
+    """rollout.ServedRollout (bench.py's step-server leg): block draws into the halves of a 2-episode move ring, one server launch
+    and 25 doorbells per episode -- the state and the last step's outputs equal RandomRollout(regenerate=True)'s launches.  With
+    graphs=True the caller-side half of an episode replays as a HIP graph from the third episode on (its draw repeats the moves
+    of the episode it was captured at): compared over the first two episodes, then run on for the protocol's sake."""
+    from multiagent_particle_envs_amd.rollout import ServedRollout
+    B, EP = 4096, 25
+    K = 2 * EP if graphs else 4 * EP
+    ref_env = mpe.make_env("simple_spread", batch_size=B, seed=5)
+    rr = RandomRollout(ref_env, episode_len=EP, pool=EP, regenerate=True)
+    o = rr.enqueue(K)
+    torch.cuda.synchronize()
+    env = mpe.make_env("simple_spread", batch_size=B, seed=5)
+    roll = ServedRollout(env, episode_len=EP, slots=2, graphs=graphs)
+    roll.enqueue(K)
+    torch.cuda.synchronize()
+    roll.srv.check()
+    assert torch.equal(env.world.pos, ref_env.world.pos) and torch.equal(env.world.vel, ref_env.world.vel)
+    obs, rew, done = roll.srv.outputs(K - 1)
+    for a, b in zip(obs, o.obs_n):
+        assert torch.equal(a, b)
+    assert torch.equal(rew, o.rew) and int(roll.srv.flag.min()) == K and int(roll.srv.door.item()) == K
+    if graphs:
+        roll.enqueue(6 * EP)
+        torch.cuda.synchronize()
+        roll.srv.check()
+        assert int(roll.srv.flag.min()) == K + 6 * EP and bool(torch.isfinite(env.world.pos).all())
