@@ -543,44 +543,75 @@ def roofline_entry(leg, k_us, B, mode, floor_us, timing=None):
             "launch_floor_us": floor_us}
 
 
-def served_leg(torch, mpe, scenario, agents, B, EP, seed, region_ms, repeats=3, kw=None):
-    """The headline protocol through the STEP SERVER (rollout.ServedRollout; include/mpe_hip.h: mpe_step_server_*): fresh moves
-    for every step (one block draw per episode), a reset every EP steps (the server's in-launch reset), every step's rows /
-    rewards / dones / state written -- but each step COMMANDED (a doorbell launch behind the draw of its moves) to one resident
-    launch per episode instead of launched.  -> entry with value / ms_per_step / the timed-region roofline fraction."""
-    from multiagent_particle_envs_amd.rollout import ServedRollout
-    env = mpe.make_env(scenario, batch_size=B, seed=seed, **(kw or {}))
-    A, Lm = len(env.world.agents), len(env.world.landmarks)
-    roll = ServedRollout(env, episode_len=EP, timeout_s=10.0, graphs=True)
-    G = 2 * EP * 4                                    # steps per enqueue call
-    roll.enqueue(G)                                   # (captures the two caller-side episode graphs)
+def served_timed(torch, rv, roll, B, region_ms, repeats):
+    """Timed region of a ServedRollout, with the contract's bracket (barrier + synchronize both sides, median of `repeats`, MAX
+    over ranks): -> dict(dt, n, rate [min, median, max of this rank], launch_us, steps_per_launch)."""
+    G = 2 * roll.EP * 4
+    roll.enqueue(G)
     torch.cuda.synchronize()
     roll.srv.check()
     t0 = time.perf_counter()
     roll.enqueue(G)
     torch.cuda.synchronize()
-    reps = max(1, int(math.ceil(region_ms * 1e-3 / max(time.perf_counter() - t0, 1e-6))))
-    walls = []
+    reps = int(rv.reduce_max(max(1, int(math.ceil(region_ms * 1e-3 / max(time.perf_counter() - t0, 1e-6))))))
+    n = G * reps
+    walls, launches = [], []
     for _ in range(repeats):
+        roll.srv.launch_events = []
+        rv.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        roll.enqueue(G * reps)
+        roll.enqueue(n)
         torch.cuda.synchronize()
         walls.append(time.perf_counter() - t0)
+        rv.barrier()
+        launches.append([(e0.elapsed_time(e1) * 1e3, T) for e0, e1, T in roll.srv.launch_events])
+        roll.srv.launch_events = None
     roll.srv.check()
-    walls.sort()
-    dt = walls[len(walls) // 2]
-    n = G * reps
-    bytes_step = algorithmic_bytes(A, Lm, int(env._obs_off[-1]), len(env.world.choice_pops), 0)
-    return {"what": "the headline protocol with every step COMMANDED to a resident step server (one launch per %d-step episode on its "
-                    "own stream; per step a doorbell launch on the caller's stream behind the draw of its moves -- the draw and its "
-                    "doorbells replayed as one graph per episode) instead of launched: fresh moves from HBM, in-launch resets, "
-                    "every step's rows / rewards / dones / state written" % EP,
-            "server_stream_probe": roll.srv.stream_probe,
-            "value": B * n / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3 / n, "timed_steps": n, "timed_region_s": dt,
-            "repeats": {"min": B * n / walls[-1], "median": B * n / dt, "max": B * n / walls[0]},
-            "frac_timed_region": bytes_step * B / (dt / n) / 1e9 / HBM_PEAK_GBS,
-            "achieved_GBps": bytes_step * B / (dt / n) / 1e9, "algorithmic_bytes_per_env_step": bytes_step}
+    order = sorted(range(len(walls)), key=lambda i: walls[i])
+    med = order[len(order) // 2]
+    ev = launches[med]
+    return {"dt": rv.reduce_max(walls[med]), "n": n, "rate": [B * n / walls[order[-1]], B * n / walls[med], B * n / walls[order[0]]],
+            "launch_us": sum(u for u, _ in ev) / len(ev), "steps_per_launch": sum(T for _, T in ev) / float(len(ev)),
+            "launches_in_region": len(ev)}
+
+
+def served_leg(torch, mpe, scenario, agents, B, EP, seed, region_ms, repeats=3, kw=None, per_step_doorbells=True, rv=None):
+    """The headline protocol through the STEP SERVER (rollout.ServedRollout; include/mpe_hip.h: mpe_step_server_*): fresh moves
+    for every step (one block draw per episode), a reset every EP steps (the server's in-launch reset), every step's rows /
+    rewards / dones / state written, every step's moves read from HBM -- but the steps COMMANDED to one resident launch instead of
+    launched.  `value`: an episode's steps commanded by ONE doorbell behind the draw of their moves (they all exist then): the
+    server's own rate.  `per_step_doorbells`: the same with a doorbell LAUNCH per step -- bounded by the command processor's
+    dependent-launch rate (1.7-2 us each), and erratic: some stream pairings process one doorbell per ~33 us."""
+    from multiagent_particle_envs_amd.rollout import ServedRollout
+    from multiagent_particle_envs_amd import sharding
+    rv = rv if rv is not None else sharding.Rendezvous(0, 1, torch.device("cuda", torch.cuda.current_device()))
+
+    def run(ahead):
+        env = mpe.make_env(scenario, batch_size=B, seed=seed, **(kw or {}))
+        A, Lm = len(env.world.agents), len(env.world.landmarks)
+        bytes_step = algorithmic_bytes(A, Lm, int(env._obs_off[-1]), len(env.world.choice_pops), 0)
+        roll = ServedRollout(env, episode_len=EP, timeout_s=4.0, graphs=True, ring_ahead=ahead)
+        r = served_timed(torch, rv, roll, B, region_ms, repeats)
+        dt, n = r["dt"], r["n"]
+        return {"value": B * n / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3 / n, "timed_steps": n, "timed_region_s": dt,
+                "repeats": {"min": r["rate"][0], "median": r["rate"][1], "max": r["rate"][2]},
+                "frac_timed_region": bytes_step * B / (dt / n) / 1e9 / HBM_PEAK_GBS,
+                "achieved_GBps": bytes_step * B / (dt / n) / 1e9, "algorithmic_bytes_per_env_step": bytes_step,
+                "server_launch_us": r["launch_us"], "steps_per_server_launch": r["steps_per_launch"],
+                "server_stream_probe": roll.srv.stream_probe}
+    ent = run(True)
+    ent["what"] = ("the headline protocol with the steps COMMANDED to a resident step server (one launch per timed repeat on its own "
+                   "stream) instead of launched: per %d-step episode one block draw and ONE doorbell launch behind it on the caller's "
+                   "stream (replayed as a graph); fresh moves READ FROM HBM every step, in-launch resets, every step's rows / rewards "
+                   "/ dones / state written to its own block with its own completion flag" % EP)
+    if per_step_doorbells:
+        try:
+            ent["per_step_doorbells"] = run(False)
+        except Exception as e:
+            ent["per_step_doorbells"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            torch.cuda.synchronize()
+    return ent
 
 
 CONFIG_LEGS = (("C2_spread_n3_B4096", "simple_spread", 3, 4096, 200),
@@ -873,9 +904,12 @@ def compact_line(out, full_path=None):
     if out.get("per_gpu_value"):
         line["per_gpu_value"] = _pick(out["per_gpu_value"], ("min", "median", "max", "ranks"))
     line["roofline"] = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_timed_region", "regime_label",
-                                    "l3_resident", "kernel", "kernel_us_per_launch", "kernel_us_rocprof",
+                                    "l3_resident", "kernel", "kernel_us_per_launch", "kernel_us_per_step", "kernel_us_rocprof",
                                     "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch", "env_steps_per_launch",
                                     "launch_floor_us", "measured_copy_GBps", "frac_of_measured_copy", "per_gpu"))
+    if isinstance(roof.get("launched"), dict):      # the same protocol as one launch per step, when the line's value is the step server's
+        line["roofline"]["launched"] = _pick(roof["launched"], ("value", "ms_per_step", "kernel_us_per_launch", "kernel_us_rocprof", "frac",
+                                                              "frac_timed_region", "traffic"))
     if "kernel_us_per_launch_by_rank" in roof:
         line["roofline"]["kernel_us_per_launch_by_rank"] = [sig(x, 4) for x in roof["kernel_us_per_launch_by_rank"]]
     hb = ex.get("hbm_resident")
@@ -913,7 +947,8 @@ def compact_line(out, full_path=None):
     if cfgs:
         line["configs"] = cfgs
     side = {}
-    for key in ("fused_rollout", "moves_resident", "int_action_ids", "python_api", "host_buffers", "step_server"):
+    for key in ("fused_rollout", "moves_resident", "int_action_ids", "python_api", "host_buffers", "step_server",
+                "step_server_per_step_doorbells"):
         if isinstance(ex.get(key), dict) and "value" in ex[key]:
             side[key] = sig(ex[key]["value"])
     for key, sub in (("user_scenario", "compiled_graph"), ("reference_style_file", "traced_graph")):
@@ -960,6 +995,10 @@ def parse_args(argv=None):
     ap.add_argument("--protocol", default="fresh", choices=["fresh", "resident"],
                     help="fresh: every step's moves are newly drawn (one block draw per episode, timed); resident: a ring of "
                          "16 move tensors drawn once (round-1 headline)")
+    ap.add_argument("--commands", default="auto", choices=["auto", "launched", "served"],
+                    help="how the headline's steps are issued (graph mode, fresh protocol): launched -- one mpe_step launch per step; "
+                         "served -- commanded to the resident step server (mpe_step_server_*); auto -- both are measured, the line's "
+                         "value is the faster (the other is kept in the line)")
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--region-ms", type=float, default=MIN_REGION_MS,
                     help="minimum back-to-back GPU work per timed repeat of the headline leg")
@@ -1126,6 +1165,31 @@ def main():
     head_timing = leg.last_kernel_timing
     head_probe = leg.env.placement_probe
     floor_us = launch_floor_us(torch, dev)
+    # ---- the same protocol with the steps COMMANDED to the step server: every rank measures it under the same bracket; the line's
+    # value is the faster of the two ways to issue the steps (a failure on any rank keeps the launched figures for all)
+    served, served_err, solo_served = None, None, None
+    if args.commands != "launched" and args.mode == "graph" and args.protocol == "fresh" and args.streams == 1 and EP and \
+            kname == "mpe::k_split" and leg.roll("resident").rollouts[0].pool_c is None:
+        try:
+            from multiagent_particle_envs_amd.rollout import ServedRollout
+            env_s = mpe.make_env(args.scenario, batch_size=B, seed=args.seed, **leg.kw)
+            env_s.world.world_offset = rank * B
+            roll_s = ServedRollout(env_s, episode_len=EP, timeout_s=4.0, graphs=True, ring_ahead=True)
+            if world > 1:       # (rank 0 alone first, as for the launched steps: the N-GPU line's reference point)
+                if rank == 0:
+                    r1 = served_timed(torch, sharding.Rendezvous(0, 1, dev), roll_s, B, min(args.region_ms, 1000.0), 1)
+                    solo_served = B * r1["n"] / r1["dt"]
+                rv.barrier()
+            served = served_timed(torch, rv, roll_s, B, args.region_ms, args.repeats)
+            served["probe"] = roll_s.srv.stream_probe
+            del roll_s, env_s
+        except Exception as e:
+            served_err = "%s: %s" % (type(e).__name__, str(e)[:300])
+            torch.cuda.synchronize()
+        if rv.reduce_max(1.0 if served is None else 0.0) > 0:      # any rank failed: nobody switches
+            served = None
+        done_at("headline_step_server")
+    use_served = served is not None and (args.commands == "served" or served["dt"] / served["n"] < dt / (K * R))
     extra = {}
     solo = world == 1 and not args.no_extra and args.streams == 1
     SR = SIDE_REGION_MS
@@ -1185,11 +1249,21 @@ def main():
             "value": B * nh / dth, "unit": "env-steps/s", "ms_per_step": dth * 1e3 / nh,
             "pcie_bytes_per_env_step": io_bytes, "pcie_GBps": B * nh * io_bytes / dth / 1e9}
 
-    if solo and args.mode == "graph" and args.protocol == "fresh" and kname == "mpe::k_split" and leg.roll("resident").rollouts[0].pool_c is None:
+    if solo and served is not None:
+        # ... and with a doorbell LAUNCH per step instead of one per episode: bounded by the command processor's dependent-launch
+        # rate, erratic by stream pairing: a secondary figure
         try:
-            extra["step_server"] = served_leg(torch, mpe, args.scenario, args.agents, B, EP or 25, args.seed, 2 * SR, kw=leg.kw)
+            from multiagent_particle_envs_amd.rollout import ServedRollout
+            env_p = mpe.make_env(args.scenario, batch_size=B, seed=args.seed, **leg.kw)
+            roll_p = ServedRollout(env_p, episode_len=EP, timeout_s=4.0, graphs=True, ring_ahead=False)
+            rp = served_timed(torch, rv, roll_p, B, SR, 3)
+            extra["step_server_per_step_doorbells"] = {
+                "what": "the step server commanded by ONE DOORBELL LAUNCH PER STEP (25 per episode, replayed as a graph behind the draw)",
+                "value": B * rp["n"] / rp["dt"], "unit": "env-steps/s", "ms_per_step": rp["dt"] * 1e3 / rp["n"], "repeats": stats(rp["rate"]),
+                "server_stream_probe": roll_p.srv.stream_probe}
+            del roll_p, env_p
         except Exception as e:
-            extra["step_server"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            extra["step_server_per_step_doorbells"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             torch.cuda.synchronize()
     done_at("headline_side_legs")
     default_line = solo and args.scenario == "simple_spread" and args.agents == 3 and B == 65536
@@ -1235,7 +1309,9 @@ def main():
     recs = rv.gather({"rank": rank, "device": "cuda:%d" % local, "gpu_env": os.environ.get("HIP_VISIBLE_DEVICES"),
                       "name": box.get("name"), "uuid": box.get("uuid"), "pci": box.get("pci"), "cpus": cpus,
                       "world_offset": rank * B, "kernel_us_per_launch": k_us, "launch_floor_us": floor_us,
-                      "env_steps_per_s": stats(rate)})
+                      "env_steps_per_s": stats(served["rate"] if use_served else rate), "env_steps_per_s_launched": stats(rate),
+                      "server_launch_us": served["launch_us"] if served else None,
+                      "steps_per_server_launch": served["steps_per_launch"] if served else None})
     if rank == 0:
         copy_gbs = copy_ceiling_gbs(torch, dev)
         fill_gbs = fill_ceiling_gbs(torch, dev)
@@ -1292,6 +1368,61 @@ def main():
             "roofline": headline_roof,
             "repeats": stats(rate),
         }
+        if served is not None or served_err:
+            extra["step_server"] = {"error": served_err} if served is None else {
+                "what": "the headline protocol with the steps COMMANDED to the resident step server (ServedRollout, ring_ahead: one "
+                        "doorbell launch per episode behind the draw of its moves); max over ranks of the median repeat",
+                "value": B * served["n"] * world / served["dt"], "unit": "env-steps/s", "ms_per_step": served["dt"] * 1e3 / served["n"],
+                "timed_steps": served["n"], "timed_region_s": served["dt"], "server_launch_us": served["launch_us"],
+                "steps_per_server_launch": served["steps_per_launch"], "server_stream_probe": served.get("probe"),
+                "rank0_solo_env_steps_per_s": solo_served}
+        if use_served:
+            # ---- the line's value: the step server's figures; the launched steps' stay in roofline.launched ----------------
+            n_s, dt_s = served["n"], served["dt"]
+            l_us = max(r["server_launch_us"] for r in recs)          # per GPU: the slowest rank's server launch
+            spl = served["steps_per_launch"]
+            per_launch = bytes_step * B * spl
+            kt = (pmc_traffic("served_%s_A%d_L%d_B%d" % (args.scenario, A, Lm, B)) or {})
+            launched = {"value": out["value"], "ms_per_step": out["ms_per_step"], "timed_steps": out["timed_steps"],
+                        "kernel": headline_roof["kernel"], "kernel_us_per_launch": headline_roof["kernel_us_per_launch"],
+                        "kernel_us_rocprof": headline_roof.get("kernel_us_rocprof"), "frac": headline_roof["frac"],
+                        "frac_timed_region": headline_roof["frac_timed_region"], "traffic": headline_roof.get("traffic"),
+                        "algorithmic_bytes_per_launch": headline_roof["algorithmic_bytes_per_launch"]}
+            headline_roof.update({
+                "achieved": per_launch / (l_us * 1e-6) / 1e9, "frac": per_launch / (l_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "kernel": "mpe::k_split<SERVE> (the step server: one resident launch, %d commanded steps)" % int(spl),
+                "kernel_us_per_launch": l_us, "kernel_us_per_step": l_us / spl, "env_steps_per_launch": int(B * spl),
+                "algorithmic_bytes_per_launch": int(per_launch), "kernel_timing": None,
+                "traffic": kt.get("traffic_bytes_per_launch"), "traffic_source": kt.get("source"),
+                "kernel_us_rocprof": ({"mean": kt["kernel_trace"]["mean_us"], "median": kt["kernel_trace"]["median_us"],
+                                       "steps_per_launch": kt["kernel_trace"].get("steps_per_launch"),
+                                       "source": kt["kernel_trace"]["source"]} if kt.get("kernel_trace") else None),
+                "timed_region_us_per_step": dt_s * 1e6 / n_s,
+                "frac_timed_region": bytes_step * B / (dt_s / n_s) / 1e9 / HBM_PEAK_GBS,
+                "achieved_timed_region": bytes_step * B / (dt_s / n_s) / 1e9,
+                "frac_of_measured_copy": per_launch / (l_us * 1e-6) / 1e9 / copy_gbs,
+                "frac_definition": "frac = algorithmic bytes per server launch (bytes per env-step x worlds x commanded steps) / the "
+                                   "launch's HIP-event duration on the server's stream / peak; frac_timed_region = algorithmic bytes "
+                                   "per step / ms_per_step / peak (draws and doorbells included)",
+                "note": "the dominant kernel is the step server's launch: its duration is measured with HIP events on the server's "
+                        "stream around each launch of the timed region (mean of the median repeat; slowest rank); roofline.launched "
+                        "holds the same protocol issued as one mpe_step launch per step",
+                "launched": launched})
+            if world > 1:
+                headline_roof["kernel_us_per_launch_by_rank"] = [r["server_launch_us"] for r in recs]
+            out.update({"value": B * n_s * world / dt_s, "ms_per_step": dt_s * 1e3 / n_s, "timed_region_s": dt_s, "timed_steps": n_s,
+                        "per_gpu_value": per_gpu_stats(recs), "repeats": stats(served["rate"])})
+            out["config"].update({
+                "workload": "%s A=%d L=%d, %d worlds/GPU, one-hot random moves fresh for every step (one block draw per episode inside "
+                            "the timed region, read from HBM by every step), reset every %d steps; steps COMMANDED to the resident "
+                            "step server" % (args.scenario, A, Lm, B, EP),
+                "protocol": "fresh moves, steps commanded to the step server (one doorbell per episode)", "mode": "step-server",
+                "graph_replays_in_timed_region": None, "timed_steps": n_s, "timed_region_s": dt_s,
+                "server_launches_in_timed_region": served["launches_in_region"], "server_stream_probe": served.get("probe"),
+                "scaling_diagnostic": None if solo_served is None else {
+                    "what": "rank 0 alone (its neighbours idle at a barrier), one repeat of the same timed region, inside this job",
+                    "rank0_solo_env_steps_per_s": solo_served,
+                    "value_over_n_times_rank0_solo": (B * n_s * world / dt_s) / (world * solo_served)}})
         extra["box"] = box
         out["extra"] = extra
         # the CPU baseline runs LAST (rank 0 only; the other ranks wait in close()): every GPU leg is behind us

@@ -497,7 +497,9 @@ struct ServeArgs {
   unsigned long long timeout_ticks;
 };
 __device__ __forceinline__ unsigned long long door_load(const unsigned long long *p) {
-  const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // SYSTEM scope (sc0 sc1): an agent-scope (sc1) load is served by this XCD's L2, which keeps the line it fetched while the
+  // word still held the old count -- at 4096 worlds (a working set that never evicts it) a served step took 33 us that way
+  const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return ((unsigned long long)hi << 32) | lo;
 }
@@ -595,7 +597,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       if (publisher && !told) {
         const int n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&idle_cnt[t & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (n >= A) {   // every agent wave drained: steps < g of this workgroup are complete
-          if (lane == 0) __hip_atomic_store(sv.flag + blockIdx.x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) __hip_atomic_store(sv.flag + blockIdx.x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           told = true;
         }
       }
@@ -603,7 +605,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       seen = door_load(sv.door);
       if (seen > g) return true;
       if ((unsigned long long)wall_clock64() - t_begin > sv.timeout_ticks) {
-        if (lane == 0) __hip_atomic_store(sv.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(sv.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return false;
       }
     }
@@ -667,7 +669,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       if (SERVE) drain_stores();   // this wave's outputs of step t - 1 are acknowledged ...
       __syncthreads();
       if (SERVE) {                 // ... and so are every agent wave's (they drain in front of this barrier too): step t - 1 is complete
-        if (t > 0 && lane == 0) __hip_atomic_store(sv.flag + blockIdx.x, ra.step0 + (unsigned long long)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t > 0 && lane == 0) __hip_atomic_store(sv.flag + blockIdx.x, ra.step0 + (unsigned long long)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (lane == 0) idle_cnt[t & 1] = 0;      // (next used by step t + 2's waiters, who are behind step t + 1's barrier)
       }
       MPE_STAMP(2);
@@ -679,7 +681,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
     if (SERVE) {   // the last step: every wave drains, then the workgroup says so
       drain_stores();
       __syncthreads();
-      if (lane == 0) __hip_atomic_store(sv.flag + blockIdx.x, ra.step0 + (unsigned long long)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(sv.flag + blockIdx.x, ra.step0 + (unsigned long long)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     MPE_SPAN_END();
     return;
@@ -1407,7 +1409,7 @@ int launch_split_serve(int kind, int A, int L, int nadv, const NarrowDesc &d, co
 __global__ void k_serve_ring(unsigned long long *const door, const unsigned long long n) {
   // (stream order put this launch behind whatever produced the commanded steps' moves; their writes were released when that
   //  launch ended.  The count is RELATIVE -- n more steps -- so a captured ring replays as "n more" whatever the step number.)
-  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_fetch_add(door, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_fetch_add(door, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void __launch_bounds__(256)
 k_serve_wait(const unsigned long long *const flag, const unsigned n_flags, const unsigned long long completed,
@@ -1417,10 +1419,10 @@ k_serve_wait(const unsigned long long *const flag, const unsigned n_flags, const
   const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_flags) return;
   const unsigned long long t0 = (unsigned long long)wall_clock64();
-  while (__hip_atomic_load(flag + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < completed) {
+  while (__hip_atomic_load(flag + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < completed) {
     __builtin_amdgcn_s_sleep(8);
     if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
-      __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
   }

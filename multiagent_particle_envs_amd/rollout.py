@@ -364,7 +364,7 @@ class StepServer(object):
     a ring and a wait launch per step and is better served by env.step.  One server per env at a time; the env's own outputs
     (env.step's ping-pong sets) are not touched: a served step's outputs live in the server's blocks."""
 
-    def __init__(self, env, moves, slots=2, episode_len=0, seed=None, timeout_s=2.0):
+    def __init__(self, env, moves, slots=2, episode_len=0, seed=None, timeout_s=2.0, probe_graph=False):
         if not env.fused or getattr(env, "_prog", None) is not None:
             raise _abi.MpeError("StepServer serves the fused built-in scenarios (a wave-per-agent kernel, no utterances)")
         if env._py_obs or env._py_reward or env._py_done or env._py_info:
@@ -396,39 +396,66 @@ class StepServer(object):
         s.door, s.flag, s.status = self.door.data_ptr(), self.flag.data_ptr(), self.status.data_ptr()
         s.act_ring, s.ring, s.slots, s.timeout_us = moves.data_ptr(), int(moves.shape[0]), self.slots, int(timeout_s * 1e6)
         self._srv = s
-        self._commander = _abi.raw_stream(dev).value
-        self.stream = self._concurrent_stream(dev)
+        self._commander = _abi.raw_stream(dev).value      # commands come from the stream that is current NOW
+        self.stream = self._concurrent_stream(dev, graph=probe_graph)
+        self.launch_events = None
         self.t = 0              # global step at which the next start() begins (absolute: doorbell and flags count from 0)
         self.commanded = 0
         self.served_to = 0      # steps covered by the launches started so far
         torch.cuda.synchronize(dev)      # (the words above are zero before anything can ring)
 
-    def _concurrent_stream(self, dev, probe_timeout_s=0.03):
-        """A stream whose launches run CONCURRENTLY with the current stream's: HIP multiplexes its streams onto a few hardware
-        queues, and a doorbell queued behind the resident server on the same hardware queue would never start.  Candidates (a
-        high-priority stream first: priorities have queues of their own) are probed with the library's own wait / ring pair on
-        a scratch word -- the wait, on the candidate, spins until the ring, on the current stream, has run."""
+    def _concurrent_stream(self, dev, probe_timeout_s=0.05, n=40, graph=False):
+        """A stream whose launches run CONCURRENTLY with the commanding (current) stream's, at full rate: HIP multiplexes its
+        streams onto a few hardware queues.  A doorbell queued behind the resident server on the SAME hardware queue never starts;
+        with some pairings the doorbells ARE processed, but one per ~33 us instead of one per 1.7 us (seen with doorbells replayed
+        from a HIP graph: a graph's kernels keep a tie to the stream they were captured on, so capture, replay and probe all use
+        the commanding stream).  Candidates (a high-priority stream first: priorities have queues of their own) are probed with the
+        library's own wait / ring pair in the server's pattern: a wait launch on the candidate spins on a scratch word until n
+        one-thread rings on the commanding stream -- eager, or with graph=True replayed from a graph captured on it, as
+        ServedRollout issues them -- have counted it up; the rings' span, from events on the commanding stream, is the verdict."""
         word = torch.zeros(1, dtype=torch.int64, device=dev)
         st = torch.zeros(1, dtype=torch.int32, device=dev)
         p = _abi.MpeStepServer()
         p.door = p.flag = word.data_ptr()
         p.status, p.timeout_us = st.data_ptr(), int(probe_timeout_s * 1e6)
+        raw = lambda: _abi.raw_stream(dev)      # noqa: E731
+
+        def rings():
+            for _ in range(n):
+                _abi.check(self._L.mpe_step_server_ring(C.byref(p), 1, raw()), "mpe_step_server_ring (probe)")
+        g = None
+        if graph:
+            rings()                             # (code object loaded outside the capture)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=torch.cuda.current_stream(dev)):
+                rings()
         tried = []
-        for k in range(8):
-            cand = torch.cuda.Stream(device=dev, priority=-1) if k == 0 else torch.cuda.Stream(device=dev)
-            word.zero_()
-            st.zero_()
-            torch.cuda.synchronize(dev)
-            with torch.cuda.stream(cand):
-                _abi.check(self._L.mpe_step_server_wait(C.byref(p), 1, 1, _abi.raw_stream(dev)), "mpe_step_server_wait (probe)")
-            _abi.check(self._L.mpe_step_server_ring(C.byref(p), 1, _abi.raw_stream(dev)), "mpe_step_server_ring (probe)")
-            torch.cuda.synchronize(dev)
-            if int(st.item()) == 0:
-                self.stream_probe = {"picked": k, "serialised_candidates": tried}
+        for k in range(12):
+            cand = torch.cuda.Stream(device=dev, priority=-1) if k % 2 == 0 else torch.cuda.Stream(device=dev)
+            span = []
+            for attempt in range(2):            # (the first round also loads the code objects)
+                word.zero_()
+                st.zero_()
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                with torch.cuda.stream(cand):
+                    _abi.check(self._L.mpe_step_server_wait(C.byref(p), 1, n, raw()), "mpe_step_server_wait (probe)")
+                e0.record()
+                if g is not None:
+                    g.replay()
+                else:
+                    rings()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                span.append(e0.elapsed_time(e1) * 1e3 / n)
+            ok = int(st.item()) == 0 and span[-1] < 8.0        # us per ring: 1.7 from a graph, 3-5 eager (host-bound), ~33 when sliced
+            tried.append({"candidate": k, "us_per_ring": round(span[-1], 2), "timed_out": int(st.item()) != 0})
+            if ok:
+                self.stream_probe = {"picked": k, "graph_rings": bool(graph), "candidates": tried}
                 return cand
-            tried.append(k)
-        raise _abi.MpeError("StepServer: no stream runs concurrently with the current one (8 candidates probed): the doorbell "
-                            "could never overtake the resident server")
+        raise _abi.MpeError("StepServer: no stream runs concurrently with the commanding one at full rate (12 candidates probed: %r): "
+                            "the doorbells could not keep up with the resident server" % (tried,))
 
     def start(self, T):
         """Launch the server for global steps [served_to, served_to + T) on the server's stream, behind the current stream's
@@ -438,9 +465,16 @@ class StepServer(object):
         b = self.blocks.bufs
         b.act = b.ids = b.u = None
         with torch.cuda.stream(self.stream):
+            ev = None
+            if self.launch_events is not None:      # (bench.py: the server launch's own duration, HIP events on ITS stream)
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), int(T))
+                ev[0].record()
             _abi.check(self._L.mpe_step_server_start(C.byref(self._desc), C.byref(b), self.B, int(T), self.episode_len, self._lr,
                                                      self.seed, int(self.served_to), int(self.world.world_offset),
                                                      C.byref(self._srv), _abi.raw_stream(self.world.device)), "mpe_step_server_start")
+            if ev is not None:
+                ev[1].record()
+                self.launch_events.append(ev)
         self.served_to += int(T)
         self.env._scenario_state_stale = True
         self.env._fast_acts.clear()
@@ -484,61 +518,85 @@ class ServedRollout(object):
     RandomRollout(regenerate=True).enqueue, bit for bit (tests/test_gpu_server.py).
 
     graphs=True: the caller-stream half of an episode -- the draw and its episode_len doorbells -- is ONE HIP graph per ring half,
-    replayed every other episode (its draw repeats the moves of the episode it was captured at: the graph protocol's usual
-    frozen step numbers); the server launches stay eager on the server's own, PROBED stream (inside a graph the mapping of
-    branches to hardware queues is not ours to probe)."""
+    replayed every other episode (its draw repeats the moves of episodes 0 / 1: the graph protocol's usual frozen step numbers);
+    the server launches stay eager on the server's own, PROBED stream (inside a graph the mapping of branches to hardware
+    queues is not ours to probe).  ring_ahead=True: ONE doorbell per episode (all its steps commanded at once: their moves all
+    exist after the draw) -- the server's own rate, where per-step doorbells measure the command processor's launch rate."""
 
-    def __init__(self, env, episode_len=25, seed=None, slots=2, timeout_s=5.0, graphs=False):
+    def __init__(self, env, episode_len=25, seed=None, slots=2, timeout_s=5.0, graphs=False, ring_ahead=False, max_launch_episodes=160):
         w = env.world
         env._ensure_buffers()
         A, B = len(w.agents), w.batch_size
         self.env, self.world, self.A, self.B, self.EP = env, w, A, B, int(episode_len)
         assert self.EP >= 1
         self.moves = torch.zeros((2 * self.EP, A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=w.device)
-        self.srv = StepServer(env, self.moves, slots=slots, episode_len=self.EP, seed=seed, timeout_s=timeout_s)
+        # graphs: ONE commanding stream of our own for capture, replay and the server-stream probe (a graph's kernels keep a tie to
+        # the stream they were captured on; the default stream cannot capture)
+        self.cmd = torch.cuda.Stream(device=w.device) if graphs else None
+        if graphs:
+            self.cmd.wait_stream(torch.cuda.current_stream(w.device))
+            with torch.cuda.stream(self.cmd):
+                self.srv = StepServer(env, self.moves, slots=slots, episode_len=self.EP, seed=seed, timeout_s=timeout_s, probe_graph=True)
+        else:
+            self.srv = StepServer(env, self.moves, slots=slots, episode_len=self.EP, seed=seed, timeout_s=timeout_s)
         self.seed = self.srv.seed
         self._L = _abi.lib()
-        self._read_done = [torch.cuda.Event(), torch.cuda.Event()]     # the server launch that read half h has ended
-        self._recorded = [False, False]
+        self.ring_ahead, self.max_launch = bool(ring_ahead), int(max_launch_episodes) * self.EP
         self.t = 0
-        self._graphs = [None, None] if graphs else None
+        self._graphs = None
+        if graphs:
+            # Captured HERE, while no server is resident: torch's capture synchronises the device, and a resident server that is
+            # waiting for doorbells nobody has rung yet would never let that return.  (Capture records, it does not run: the
+            # doorbell word is untouched; the draw's code object is loaded by one eager call, the ring's by the probe.)
+            with torch.cuda.stream(self.cmd):
+                _abi.check(self._L.mpe_random_actions_block(self.moves.data_ptr(), None, A, B, self.seed, 0, 1, int(w.world_offset),
+                                                            _abi.raw_stream(w.device)), "mpe_random_actions_block")
+                gs = []
+                for h in (0, 1):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.cmd):
+                        self._caller_half(h, h * self.EP)
+                    gs.append(g)
+            self._graphs = gs
 
     def _caller_half(self, h, t):
         """The caller-stream work of the episode that starts at global step t and uses ring half h: draw, then the doorbells."""
         dev = self.world.device
         _abi.check(self._L.mpe_random_actions_block(self.moves[h * self.EP].data_ptr(), None, self.A, self.B, self.seed, int(t),
                                                     self.EP, int(self.world.world_offset), _abi.raw_stream(dev)), "mpe_random_actions_block")
+        if self.ring_ahead:      # the whole episode commanded at once (its moves all exist): the server's own rate
+            _abi.check(self._L.mpe_step_server_ring(C.byref(self.srv._srv), self.EP, _abi.raw_stream(dev)), "mpe_step_server_ring")
+            return
         for _k in range(self.EP):
             _abi.check(self._L.mpe_step_server_ring(C.byref(self.srv._srv), 1, _abi.raw_stream(dev)), "mpe_step_server_ring")
 
     def enqueue(self, steps):
         """`steps` (a multiple of episode_len) commanded steps; returns when everything is ENQUEUED, the current stream joined
-        behind the last server launch."""
+        behind the server launch(es).  ONE server launch serves up to `max_launch` steps: nothing waits behind the resident
+        kernel on its stream, and a ring half is handed back by the server's completion flags (a wait launch on the commanding
+        stream in front of the draw that overwrites it), not by a launch boundary."""
         assert steps % self.EP == 0, "whole episodes"
         dev = self.world.device
-        cur = torch.cuda.current_stream(dev)
-        for _ in range(steps // self.EP):
-            h = (self.t // self.EP) & 1
-            if self._recorded[h]:
-                cur.wait_event(self._read_done[h])      # the launch of two episodes ago has finished reading this half
-            self.srv.start(self.EP)                     # (behind the current stream's work so far: the state it starts from)
-            self._read_done[h].record(self.srv.stream)
-            self._recorded[h] = True
-            if self._graphs is None:
-                self._caller_half(h, self.t)
-            else:
-                if self._graphs[h] is None:
-                    self._caller_half(h, self.t)        # (code objects loaded, and this episode really commanded, outside the capture)
-                    g = torch.cuda.CUDAGraph()
-                    side = torch.cuda.Stream(device=dev)
-                    side.wait_stream(cur)
-                    with torch.cuda.stream(side):
-                        with torch.cuda.graph(g, stream=side):
-                            self._caller_half(h, self.t)
-                    cur.wait_stream(side)
-                    self._graphs[h] = g
+        if self.cmd is not None and torch.cuda.current_stream(dev) != self.cmd:
+            caller = torch.cuda.current_stream(dev)
+            self.cmd.wait_stream(caller)
+            with torch.cuda.stream(self.cmd):
+                self.enqueue(steps)
+            caller.wait_stream(self.cmd)
+            return
+        left = steps
+        while left > 0:
+            n = min(left, self.max_launch)
+            self.srv.start(n)                           # (behind the current stream's work so far: the state it starts from)
+            for _ in range(n // self.EP):
+                h = (self.t // self.EP) & 1
+                if self.t >= 2 * self.EP:
+                    self.srv.wait(self.t - self.EP)     # the episode that read this half (steps t - 2 EP .. t - EP) is complete
+                if self._graphs is None:
+                    self._caller_half(h, self.t)
                 else:
                     self._graphs[h].replay()
-            self.srv.commanded += self.EP
-            self.t += self.EP
-        self.srv.join()
+                self.srv.commanded += self.EP
+                self.t += self.EP
+            self.srv.join()
+            left -= n

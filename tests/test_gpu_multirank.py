@@ -190,7 +190,10 @@ def test_bench_single_gpu_line_carries_the_contract():
     roof = out["roofline"]
     assert len(lines[0]) < 4096
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and roof["regime_label"] == "l3+launch"
-    assert roof["kernel_us_rocprof"]["mean"] > 0 and roof["kernel_us_rocprof"]["source"].startswith("profiles/")
+    launched = roof["launched"] if out["config"]["mode"] == "step-server" else roof      # (the launched steps' figures, either way)
+    assert launched["kernel_us_rocprof"]["mean"] > 0 and launched["kernel_us_rocprof"]["source"].startswith("profiles/")
+    if out["config"]["mode"] == "step-server":
+        assert roof["launched"]["value"] < out["value"] and roof["kernel_us_per_step"] * 1e-3 <= out["ms_per_step"] * 1.05
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-5 and 0.2 < roof["frac"] < 1.0
     assert abs(out["timed_steps"] * out["ms_per_step"] * 1e-3 / out["timed_region_s"] - 1) < 1e-3
     assert roof["algorithmic_bytes_per_env_step"] == 411 and (roof["traffic"] is None or roof["traffic"] > 2e7)

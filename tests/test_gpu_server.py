@@ -145,10 +145,10 @@ def test_what_the_server_refuses():
 
 @pytest.mark.parametrize("graphs", [False, True])
 def test_served_rollout_is_the_fresh_moves_rollout(graphs):
-    """rollout.ServedRollout (bench.py's step-server leg): block draws into the halves of a 2-episode move ring, one server launch
-    and 25 doorbells per episode -- the state and the last step's outputs equal RandomRollout(regenerate=True)'s launches.  With
-    graphs=True the caller-side half of an episode replays as a HIP graph from the third episode on (its draw repeats the moves
-    of the episode it was captured at): compared over the first two episodes, then run on for the protocol's sake."""
+    """rollout.ServedRollout (bench.py's step-server leg): block draws into the halves of a 2-episode move ring, 25 doorbells per
+    episode, one server launch per enqueue -- the state and the last step's outputs equal RandomRollout(regenerate=True)'s
+    launches.  With graphs=True the caller-side half of an episode is a HIP graph per ring half (its draw repeats the moves of
+    episodes 0 / 1): compared over the first two episodes, then run on for the protocol's sake."""
     from multiagent_particle_envs_amd.rollout import ServedRollout
     B, EP = 4096, 25
     K = 2 * EP if graphs else 4 * EP
