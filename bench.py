@@ -895,16 +895,16 @@ def compact_line(out, full_path=None):
     line["config"] = _pick(cfg, ("workload", "protocol", "batch_per_gpu", "global_batch", "mode", "timed_steps", "timed_region_s",
                                  "repeats", "graph_replays_in_timed_region", "launcher", "barrier_backend", "ranks_seen",
                                  "distinct_gpus", "sharding"))
-    line["config"]["workload"] = str(cfg.get("workload", ""))[:160]
-    line["config"]["timed_region"] = ("ms_per_step = timed_region_s / timed_steps: a graph of consecutive steps replayed until the "
-                                      "region holds >= %.1f s, median of %s repeats (--steps sets the graph's unit, not the region)"
+    line["config"]["workload"] = str(cfg.get("workload_short") or cfg.get("workload", ""))[:150]
+    line["config"]["timed_region"] = ("ms_per_step = timed_region_s / timed_steps; region >= %.1f s of back-to-back steps, median of %s "
+                                      "repeats, max over ranks (--steps / --warmup do not size it)"
                                       % (cfg.get("region_ms", MIN_REGION_MS) * 1e-3, cfg.get("repeats")))
     if cfg.get("scaling_diagnostic"):
         line["config"]["value_over_n_times_rank0_solo"] = sig(cfg["scaling_diagnostic"]["value_over_n_times_rank0_solo"], 4)
-    if out.get("per_gpu_value"):
+    if out.get("per_gpu_value") and out.get("n_gpus", 1) > 1:
         line["per_gpu_value"] = _pick(out["per_gpu_value"], ("min", "median", "max", "ranks"))
     line["roofline"] = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_timed_region", "regime_label",
-                                    "l3_resident", "kernel", "kernel_us_per_launch", "kernel_us_per_step", "kernel_us_rocprof",
+                                    "l3_resident", "kernel", "kernel_us_per_launch", "kernel_us_per_step", "steps_per_launch", "kernel_us_rocprof",
                                     "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch", "env_steps_per_launch",
                                     "launch_floor_us", "measured_copy_GBps", "frac_of_measured_copy", "per_gpu"))
     if isinstance(roof.get("launched"), dict):      # the same protocol as one launch per step, when the line's value is the step server's
@@ -925,7 +925,7 @@ def compact_line(out, full_path=None):
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "single_core", "value_in_reference_terms"))
-        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:230]
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:180]
         if cb.get("reference_build_container"):
             line["cpu_baseline"]["reference_build_container"] = _pick(cb["reference_build_container"],
                                                                       ("cores", "env_steps_per_s_1_process", "env_steps_per_s_all_cores"))
@@ -1348,6 +1348,8 @@ def main():
                                    % (args.scenario, A, Lm, B,
                                       "fresh for every step: one block draw per episode inside the timed region"
                                       if args.protocol == "fresh" else "resident ring of 16 tensors", EP),
+                       "workload_short": "%s A=%d L=%d, %d worlds/GPU, %s one-hot moves, reset every %d steps; one mpe_step launch per step"
+                                         % (args.scenario, A, Lm, B, "fresh" if args.protocol == "fresh" else "resident", EP),
                        "protocol": args.protocol, "batch_per_gpu": B, "global_batch": B * world, "mode": args.mode,
                        "graph_replays_in_timed_region": R, "timed_steps": K * R,
                        "timed_region_s": dt, "repeats": args.repeats, "region_ms": args.region_ms, "streams_per_gpu": args.streams,
@@ -1390,7 +1392,7 @@ def main():
                         "algorithmic_bytes_per_launch": headline_roof["algorithmic_bytes_per_launch"]}
             headline_roof.update({
                 "achieved": per_launch / (l_us * 1e-6) / 1e9, "frac": per_launch / (l_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "kernel": "mpe::k_split<SERVE> (the step server: one resident launch, %d commanded steps)" % int(spl),
+                "kernel": "mpe::k_split<SERVE> (step server)", "steps_per_launch": spl,
                 "kernel_us_per_launch": l_us, "kernel_us_per_step": l_us / spl, "env_steps_per_launch": int(B * spl),
                 "algorithmic_bytes_per_launch": int(per_launch), "kernel_timing": None,
                 "traffic": kt.get("traffic_bytes_per_launch"), "traffic_source": kt.get("source"),
@@ -1416,7 +1418,9 @@ def main():
                 "workload": "%s A=%d L=%d, %d worlds/GPU, one-hot random moves fresh for every step (one block draw per episode inside "
                             "the timed region, read from HBM by every step), reset every %d steps; steps COMMANDED to the resident "
                             "step server" % (args.scenario, A, Lm, B, EP),
-                "protocol": "fresh moves, steps commanded to the step server (one doorbell per episode)", "mode": "step-server",
+                "workload_short": "%s A=%d L=%d, %d worlds/GPU, fresh one-hot moves read from HBM every step (block draw per episode, "
+                                  "timed), reset every %d steps; steps commanded to the step server" % (args.scenario, A, Lm, B, EP),
+                "protocol": "fresh, step-server (one doorbell per episode)", "mode": "step-server",
                 "graph_replays_in_timed_region": None, "timed_steps": n_s, "timed_region_s": dt_s,
                 "server_launches_in_timed_region": served["launches_in_region"], "server_stream_probe": served.get("probe"),
                 "scaling_diagnostic": None if solo_served is None else {

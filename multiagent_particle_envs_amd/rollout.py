@@ -409,7 +409,7 @@ class StepServer(object):
         streams onto a few hardware queues.  A doorbell queued behind the resident server on the SAME hardware queue never starts;
         with some pairings the doorbells ARE processed, but one per ~33 us instead of one per 1.7 us (seen with doorbells replayed
         from a HIP graph: a graph's kernels keep a tie to the stream they were captured on, so capture, replay and probe all use
-        the commanding stream).  Candidates (a high-priority stream first: priorities have queues of their own) are probed with the
+        the commanding stream).  Candidates are probed with the
         library's own wait / ring pair in the server's pattern: a wait launch on the candidate spins on a scratch word until n
         one-thread rings on the commanding stream -- eager, or with graph=True replayed from a graph captured on it, as
         ServedRollout issues them -- have counted it up; the rings' span, from events on the commanding stream, is the verdict."""
@@ -432,7 +432,12 @@ class StepServer(object):
                 rings()
         tried = []
         for k in range(12):
-            cand = torch.cuda.Stream(device=dev, priority=-1) if k % 2 == 0 else torch.cuda.Stream(device=dev)
+            # (normal priority only: with the server on a HIGH-priority stream 3 of 10 instances served one dispatch of the
+            #  commanding stream per ~33 us -- 32 us per step with a doorbell per step, 5.8 instead of 2.0 with one per episode --
+            #  although this probe passed; 0 of 20 with normal-priority streams.  profiles/r6_step_server.txt; MPE_SERVER_PRIORITY=1
+            #  brings the high-priority candidates back for the A/B.)
+            hp = (k % 2 == 0) and os.environ.get("MPE_SERVER_PRIORITY", "0") == "1"
+            cand = torch.cuda.Stream(device=dev, priority=-1) if hp else torch.cuda.Stream(device=dev)
             span = []
             for attempt in range(2):            # (the first round also loads the code objects)
                 word.zero_()
