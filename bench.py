@@ -366,7 +366,7 @@ class Leg(object):
             t0 = time.perf_counter()
             body()
             torch.cuda.synchronize()
-            reps = int(rv.reduce_max(max(1, int(math.ceil(region_ms * 1e-3 / max(time.perf_counter() - t0, 1e-6))))))
+            reps = int(rv.reduce_max(max(1, int(math.ceil(1.1 * region_ms * 1e-3 / max(time.perf_counter() - t0, 1e-6))))))
             R = r1 * reps
         walls, evs = [], []
         for _ in range(repeats):
@@ -904,7 +904,7 @@ def compact_line(out, full_path=None):
     if out.get("per_gpu_value") and out.get("n_gpus", 1) > 1:
         line["per_gpu_value"] = _pick(out["per_gpu_value"], ("min", "median", "max", "ranks"))
     line["roofline"] = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_timed_region", "regime_label",
-                                    "l3_resident", "kernel", "kernel_us_per_launch", "kernel_us_per_step", "steps_per_launch", "kernel_us_rocprof",
+                                    "l3_resident", "kernel", "kernel_us_per_launch", "kernel_us_per_step", "steps_per_launch", "kernel_us_rocprof", "traffic_per_step",
                                     "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch", "env_steps_per_launch",
                                     "launch_floor_us", "measured_copy_GBps", "frac_of_measured_copy", "per_gpu"))
     if isinstance(roof.get("launched"), dict):      # the same protocol as one launch per step, when the line's value is the step server's
@@ -1395,9 +1395,14 @@ def main():
                 "kernel": "mpe::k_split<SERVE> (step server)", "steps_per_launch": spl,
                 "kernel_us_per_launch": l_us, "kernel_us_per_step": l_us / spl, "env_steps_per_launch": int(B * spl),
                 "algorithmic_bytes_per_launch": int(per_launch), "kernel_timing": None,
-                "traffic": kt.get("traffic_bytes_per_launch"), "traffic_source": kt.get("source"),
-                "kernel_us_rocprof": ({"mean": kt["kernel_trace"]["mean_us"], "median": kt["kernel_trace"]["median_us"],
-                                       "steps_per_launch": kt["kernel_trace"].get("steps_per_launch"),
+                # the committed PMC passes / kernel trace profiled a launch of kt["steps_per_launch"] steps: scaled to this launch's
+                "traffic": int(kt["traffic_bytes_per_launch"] / kt["steps_per_launch"] * spl) if kt.get("traffic_bytes_per_launch") else None,
+                "traffic_per_step": kt["traffic_bytes_per_launch"] / kt["steps_per_launch"] if kt.get("traffic_bytes_per_launch") else None,
+                "traffic_source": (kt["source"] + "; that launch served %d steps: scaled by steps_per_launch" % kt["steps_per_launch"])
+                                  if kt.get("source") else None,
+                "kernel_us_rocprof": ({"mean_per_step": kt["kernel_trace"]["mean_us"] / kt["steps_per_launch"],
+                                       "median_per_step": kt["kernel_trace"]["median_us"] / kt["steps_per_launch"],
+                                       "steps_per_launch": kt["steps_per_launch"],
                                        "source": kt["kernel_trace"]["source"]} if kt.get("kernel_trace") else None),
                 "timed_region_us_per_step": dt_s * 1e6 / n_s,
                 "frac_timed_region": bytes_step * B / (dt_s / n_s) / 1e9 / HBM_PEAK_GBS,

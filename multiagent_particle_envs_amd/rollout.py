@@ -364,7 +364,7 @@ class StepServer(object):
     a ring and a wait launch per step and is better served by env.step.  One server per env at a time; the env's own outputs
     (env.step's ping-pong sets) are not touched: a served step's outputs live in the server's blocks."""
 
-    def __init__(self, env, moves, slots=2, episode_len=0, seed=None, timeout_s=2.0, probe_graph=False):
+    def __init__(self, env, moves, slots=2, episode_len=0, seed=None, timeout_s=2.0, probe_graph=False, probe=True):
         if not env.fused or getattr(env, "_prog", None) is not None:
             raise _abi.MpeError("StepServer serves the fused built-in scenarios (a wave-per-agent kernel, no utterances)")
         if env._py_obs or env._py_reward or env._py_done or env._py_info:
@@ -397,7 +397,10 @@ class StepServer(object):
         s.act_ring, s.ring, s.slots, s.timeout_us = moves.data_ptr(), int(moves.shape[0]), self.slots, int(timeout_s * 1e6)
         self._srv = s
         self._commander = _abi.raw_stream(dev).value      # commands come from the stream that is current NOW
-        self.stream = self._concurrent_stream(dev, graph=probe_graph)
+        if probe:
+            self.stream = self._concurrent_stream(dev, graph=probe_graph)
+        else:       # (every command will precede its launch -- tools/server_profile.py under a profiler that serialises dispatches)
+            self.stream, self.stream_probe = torch.cuda.Stream(device=dev), None
         self.launch_events = None
         self.t = 0              # global step at which the next start() begins (absolute: doorbell and flags count from 0)
         self.commanded = 0

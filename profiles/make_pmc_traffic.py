@@ -23,6 +23,8 @@ SOURCES = {
     "simple_tag_A4_L2_B16384": ("r4_pmc_tag_B16384.txt", "bench.py --mode eager --protocol resident --scenario simple_tag --batch 16384"),
     "simple_spread_A64_L64_B4096": ("r4_pmc_spread64_B4096.txt", "bench.py --mode eager --protocol resident --agents 64 --batch 4096"),
     "simple_spread_A3_L3_B4096": ("r4_pmc_spread3_B4096.txt", "bench.py --mode eager --protocol resident --batch 4096"),
+    # the step server's launch (mpe::k_split<..., SERVE>): ONE launch = 1000 commanded steps (tools/server_profile.py)
+    "served_simple_spread_A3_L3_B65536": ("r6_pmc_served_spread3_B65536.txt", "tools/server_profile.py 65536 1000 4", 1000),
 }
 # key -> the newest committed `rocprofv3 --kernel-trace --stats` summary (tools/trace_summary.py) of that launch: bench.py prints
 # the dominant kernel's mean / median duration from it as `roofline.kernel_us_rocprof` beside its own HIP-event slope
@@ -32,6 +34,7 @@ TRACES = {
     "simple_tag_A4_L2_B16384": "r5_tag_B16384_kernel_trace_summary.txt",
     "simple_spread_A64_L64_B4096": "r5_spread64_B4096_kernel_trace_summary.txt",
     "simple_spread_A3_L3_B4096": "r5_spread3_B4096_kernel_trace_summary.txt",
+    "served_simple_spread_A3_L3_B65536": "r6_served_spread3_B65536_kernel_trace_summary.txt",
 }
 ROW = re.compile(r"^(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)%\s*$")
 LAST = re.compile(r"^traffic_bytes_per_launch\s+(\d+)\s+\(reads\s+(\d+)\s+\+\s+writes\s+(\d+)\)\s*$")
@@ -63,9 +66,15 @@ def trace_entry(fname):
 
 
 def build():
-    out = {k: entry(f, c) for k, (f, c) in SOURCES.items()}
+    out = {}
+    for k, v in SOURCES.items():
+        out[k] = entry(v[0], v[1])
+        if len(v) > 2:      # a launch of several steps: per-step figures are the launch's / steps_per_launch
+            out[k]["steps_per_launch"] = v[2]
     for k, f in TRACES.items():
         out[k]["kernel_trace"] = trace_entry(f)
+        if "steps_per_launch" in out[k]:
+            out[k]["kernel_trace"]["steps_per_launch"] = out[k]["steps_per_launch"]
     return out
 
 
@@ -84,7 +93,7 @@ def main():
         json.dump(new, f, indent=1)
         f.write("\n")
     for k, v in new.items():
-        print("%-32s %12d B   %s" % (k, v["traffic_bytes_per_launch"], SOURCES[k][0]))
+        print("%-36s %14d B   %s" % (k, v["traffic_bytes_per_launch"], SOURCES[k][0]))
 
 
 if __name__ == "__main__":

@@ -194,6 +194,7 @@ def test_bench_single_gpu_line_carries_the_contract():
     assert launched["kernel_us_rocprof"]["mean"] > 0 and launched["kernel_us_rocprof"]["source"].startswith("profiles/")
     if out["config"]["mode"] == "step-server":
         assert roof["launched"]["value"] < out["value"] and roof["kernel_us_per_step"] * 1e-3 <= out["ms_per_step"] * 1.05
+        assert roof["kernel_us_rocprof"]["mean_per_step"] > 0 and roof["traffic"] > 0.5 * roof["algorithmic_bytes_per_launch"]
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-5 and 0.2 < roof["frac"] < 1.0
     assert abs(out["timed_steps"] * out["ms_per_step"] * 1e-3 / out["timed_region_s"] - 1) < 1e-3
     assert roof["algorithmic_bytes_per_env_step"] == 411 and (roof["traffic"] is None or roof["traffic"] > 2e7)
