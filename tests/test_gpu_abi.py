@@ -281,3 +281,20 @@ def test_a_c_program_steps_the_reference_kat_on_the_gpu(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr[-500:])
+
+
+def test_a_c_program_commands_the_step_server(tmp_path):
+    """tests/c/abi_server_gpu.c: mpe_step_server_ring / start / wait from C -- five commanded steps equal five mpe_step launches bit
+    for bit (rows, rewards, dones per block, the state in HBM), flags and status read back; no Python / torch in the process."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.dirname(_abi.LIB_PATH)
+    exe = str(tmp_path / "abi_server_gpu")
+    cmd = ["gcc", "-std=c99", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(root, "include"),
+           os.path.join(root, "tests", "c", "abi_server_gpu.c"), "-o", exe, "-L", lib_dir, "-lmpe_hip", "-L/opt/rocm/lib",
+           "-lamdhip64", "-lm", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "bit for bit" in r.stdout and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr[-500:])
