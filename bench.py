@@ -366,7 +366,7 @@ class Leg(object):
             t0 = time.perf_counter()
             body()
             torch.cuda.synchronize()
-            reps = int(rv.reduce_max(max(1, int(math.ceil(1.1 * region_ms * 1e-3 / max(time.perf_counter() - t0, 1e-6))))))
+            reps = int(rv.reduce_max(max(1, int(math.ceil(region_ms * 1e-3 / max(time.perf_counter() - t0, 1e-6))))))
             R = r1 * reps
         walls, evs = [], []
         for _ in range(repeats):
@@ -553,7 +553,11 @@ def served_timed(torch, rv, roll, B, region_ms, repeats):
     t0 = time.perf_counter()
     roll.enqueue(G)
     torch.cuda.synchronize()
-    reps = int(rv.reduce_max(max(1, int(math.ceil(region_ms * 1e-3 / max(time.perf_counter() - t0, 1e-6))))))
+    reps = max(1, int(math.ceil(region_ms * 1e-3 / max(time.perf_counter() - t0, 1e-6))))
+    t0 = time.perf_counter()      # (a second look at the region's own size: a short enqueue over-states the per-step time)
+    roll.enqueue(G * reps)
+    torch.cuda.synchronize()
+    reps = int(rv.reduce_max(max(1, int(math.ceil(1.03 * reps * region_ms * 1e-3 / max(time.perf_counter() - t0, 1e-6))))))
     n = G * reps
     walls, launches = [], []
     for _ in range(repeats):
@@ -893,8 +897,11 @@ def compact_line(out, full_path=None):
                                      "scaling", "vs_baseline", "dtype", "data") if k in out}
     line["timed_steps"], line["timed_region_s"] = out.get("timed_steps"), sig(out.get("timed_region_s"), 4)
     line["config"] = _pick(cfg, ("workload", "protocol", "batch_per_gpu", "global_batch", "mode", "timed_steps", "timed_region_s",
-                                 "repeats", "graph_replays_in_timed_region", "launcher", "barrier_backend", "ranks_seen",
-                                 "distinct_gpus", "sharding"))
+                                 "repeats", "launcher", "barrier_backend", "ranks_seen", "distinct_gpus"))
+    if cfg.get("graph_replays_in_timed_region"):
+        line["config"]["graph_replays_in_timed_region"] = cfg["graph_replays_in_timed_region"]
+    if out.get("n_gpus", 1) > 1:
+        line["config"]["sharding"] = cfg.get("sharding")
     line["config"]["workload"] = str(cfg.get("workload_short") or cfg.get("workload", ""))[:150]
     line["config"]["timed_region"] = ("ms_per_step = timed_region_s / timed_steps; region >= %.1f s of back-to-back steps, median of %s "
                                       "repeats, max over ranks (--steps / --warmup do not size it)"

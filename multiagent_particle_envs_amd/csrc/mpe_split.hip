@@ -512,8 +512,8 @@ __global__ void __launch_bounds__((SplitShape<KIND, A, L, NADV>::waves(DUALP) * 
 k_split(float *const g_pos, float *const g_vel, const float *const g_act, const int32_t *const g_ids, const size_t B,
         const int g_wpw, const int g_observe_only, const unsigned g_movable, const NarrowDesc d, const MpeBuffers b_in,
         const RollArgs ra, const ServeArgs sv) {
-  static_assert(!SERVE || (ROLL && !DUALP && RP == kRowsSc1 && KIND < MPE_SCN_SPEAKER_LISTENER),
-                "the step server: single-role rollout, write-through stores, scenarios without utterances");
+  static_assert(!SERVE || (ROLL && RP == kRowsSc1 && KIND < MPE_SCN_SPEAKER_LISTENER),
+                "the step server: a rollout instantiation, write-through stores, scenarios without utterances");
   // The leading scalar arguments (13 dwords) repeat what the first global loads of a wave need -- the state and
   // action pointers, the batch size, the worlds per workgroup, the movable mask -- so that the CP can PRELOAD them
   // into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, _build.py): the wave's loads leave without a
@@ -596,7 +596,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
     for (;;) {
       if (publisher && !told) {
         const int n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&idle_cnt[t & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if (n >= A) {   // every agent wave drained: steps < g of this workgroup are complete
+        if (n >= NAW) {   // every agent-side wave drained: steps < g of this workgroup are complete
           if (lane == 0) __hip_atomic_store(sv.flag + blockIdx.x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           told = true;
         }
@@ -1177,29 +1177,45 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         MPE_STAMP(4);
         rows(t);
         MPE_STAMP(5);
+        if constexpr (SERVE) {
+          // served: this wave has nothing to do before the next barrier but wait -- it drains its rows and counts itself (the
+          // reward wave publishes step t from its idle loop once the physics waves, idle too, have done the same)
+          drain_stores();
+          if (lane == 0) __hip_atomic_fetch_add(&idle_cnt[(t + 1) & 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
+      if (SERVE) __syncthreads();   // (the last step's completion: the reward wave publishes behind this barrier)
       MPE_SPAN_END();
       return;
     }
     // ---- PHYSICS wave of agent i: World.step of step t+1 behind barrier t, from the siblings' state of step t -----------
     float fx, fy;
     { [[maybe_unused]] const int t = 0; MPE_STAMP(0); }
+    if (SERVE && !wait_door(0, false)) return;
     step_forces(0, fx, fy);
     step_integrate(0, fx, fy);
     { [[maybe_unused]] const int t = 0; MPE_STAMP(1); }
     publish(0);
     for (int t = 0; t < T; ++t) {
       MPE_STAMP(2);
+      if (SERVE) drain_stores();   // step t - 1's state is acknowledged
       __syncthreads();
       MPE_STAMP(3);
       behind_barrier(t);
       MPE_STAMP(4);
       if (t + 1 < T) {
+        if (SERVE && !wait_door(t + 1, false)) return;
         step_forces(t + 1, fx, fy);
         step_integrate(t + 1, fx, fy);
         MPE_STAMP(5);
         publish(t + 1);
       }
+    }
+    if (SERVE) {
+      drain_stores();
+      __syncthreads();
+      MPE_SPAN_END();
+      return;
     }
   } else {
     for (int t = 0; t < T; ++t) {
@@ -1264,12 +1280,18 @@ struct SplitEntry {
   int kind, A, L, nadv;
   SplitFn step, step_small, roll, roll_small;   // rows stored nontemporal; *_small: at agent scope (mpe_device.h)
   SplitFn roll_dual, roll_dual_small;           // the dual-role rollout (small batches), or nullptr
-  SplitFn serve;                                // the step server (scenarios without utterances), or nullptr
+  SplitFn serve, serve_dual;                    // the step server (scenarios without utterances), single- and dual-role, or nullptr
   size_t lds_step, lds_roll;
 };
 template <int KIND, int A, int L, int NADV>
 constexpr SplitFn serve_fn() {
   if constexpr (KIND < MPE_SCN_SPEAKER_LISTENER) return k_split<KIND, A, L, NADV, true, kRowsSc1, false, true>;
+  else return nullptr;
+}
+template <int KIND, int A, int L, int NADV>
+constexpr SplitFn serve_dual_fn() {
+  if constexpr (KIND < MPE_SCN_SPEAKER_LISTENER && dual_kind<KIND>() && SplitShape<KIND, A, L, NADV>::waves(true) * kWave <= 1024)
+    return k_split<KIND, A, L, NADV, true, kRowsSc1, true, true>;
   else return nullptr;
 }
 template <int KIND, int A, int L, int NADV, int RP>
@@ -1281,6 +1303,7 @@ constexpr SplitFn dual_fn() {
   { KIND, A, L, NADV, k_split<KIND, A, L, NADV, false, kRowsNt>, k_split<KIND, A, L, NADV, false, kRowsSc1>,       \
     k_split<KIND, A, L, NADV, true, kRowsNt>, k_split<KIND, A, L, NADV, true, kRowsSc1>,                           \
     dual_fn<KIND, A, L, NADV, kRowsNt>(), dual_fn<KIND, A, L, NADV, kRowsSc1>(), serve_fn<KIND, A, L, NADV>(),     \
+    serve_dual_fn<KIND, A, L, NADV>(),                                                                             \
     SplitShape<KIND, A, L, NADV>::lds_bytes(false), SplitShape<KIND, A, L, NADV>::lds_bytes(true) }
 
 static const SplitEntry kSplitTable[] = {
@@ -1393,14 +1416,26 @@ int launch_split_serve(int kind, int A, int L, int nadv, const NarrowDesc &d, co
   const size_t lds = e->lds_roll + 16;   // + the two idle counters
   const unsigned grid = serve_grid(B);
   int per_cu = 0, dev = 0, n_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(e->serve), (A + 1) * kWave, lds) != hipSuccess ||
-      hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return MPE_EUNSUPPORTED;
+  }
+  // the dual-role server (a physics and a rows wave per agent, as the dual-role rollout) where the chip is under-filled
+  SplitFn fn = e->serve;
+  int waves = A + 1;
+#ifndef MPE_SERVE_NO_DUAL
+  if (e->serve_dual && grid <= (unsigned)n_cu * 3 / 2) {
+    fn = e->serve_dual;
+    waves = 2 * A + 1;
+  }
+#endif
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(fn), waves * kWave, lds) != hipSuccess) {
     (void)hipGetLastError();
     return MPE_EUNSUPPORTED;
   }
   // (one fewer per CU than the API's answer: the hardware admits one fewer at some SGPR counts, MI355X_MICROARCH.md)
   if ((size_t)grid > (size_t)n_cu * (size_t)(per_cu > 1 ? per_cu - 1 : per_cu)) return MPE_ESERVER_TOO_LARGE;
-  hipLaunchKernelGGL(e->serve, dim3(grid), dim3((A + 1) * kWave), lds, stream, b.pos, b.vel, b.act, b.ids, B, (int)r2.wpw, 0,
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * kWave), lds, stream, b.pos, b.vel, b.act, b.ids, B, (int)r2.wpw, 0,
                      (unsigned)d.movable, d, b, r2, sv);
   return (int)hipGetLastError();
 }
