@@ -642,6 +642,14 @@ class MultiAgentEnv(object):
             else:
                 agent.state.c = torch.zeros((self.batch_size, w.dim_c), dtype=torch.float32, device=w.device)
 
+    def step_many(self, moves, episode_len=0):
+        """`for t in range(T): env.step(moves[t])` as ONE launch (new API; rollout.step_many, DESIGN.md 2 "the step server"):
+        moves [T, n, B, 5] one-hot rows on the env's device -> [(obs_n, rew [n, B], done [n, B]) per step], bit-identical to the
+        T step() calls; for callers whose actions exist ahead of the steps (recorded / scripted sequences, action repeat).
+        Built-in scenarios without utterances, batched mode."""
+        from .rollout import step_many
+        return step_many(self, moves, episode_len)
+
     def step(self, action_n):
         """environment.py:80-104 for B worlds."""
         # ---- the common case in as few Python operations as it takes: one of the caller's preallocated [A,B,5] device

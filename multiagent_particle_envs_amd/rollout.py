@@ -465,14 +465,27 @@ class StepServer(object):
         raise _abi.MpeError("StepServer: no stream runs concurrently with the commanding one at full rate (12 candidates probed: %r): "
                             "the doorbells could not keep up with the resident server" % (tried,))
 
-    def start(self, T):
+    def run(self, T):
+        """T steps whose moves ALREADY EXIST (moves[g % ring] of the next T global steps): the doorbell first, then the launch, both
+        on the CURRENT stream -- every command precedes the launch, so nothing has to overtake anything: no second stream, no
+        probe, nothing resident that waits.  The caller's `for t in range(T): env.step(actions[t])` loop (bin/interactive.py:27-36)
+        with the caller's own actions, as ONE launch.  Outputs: outputs(g) per step, the state in world.pos / vel."""
+        self.served_to += int(T)      # (ring() checks the commands against the launches: this one is about to start)
+        self.ring(T)
+        self.served_to -= int(T)
+        self.start(T, on_current_stream=True)
+        return self
+
+    def start(self, T, on_current_stream=False):
         """Launch the server for global steps [served_to, served_to + T) on the server's stream, behind the current stream's
         work so far (the state it starts from) and behind the previous server launch."""
         cur = torch.cuda.current_stream(self.world.device)
-        self.stream.wait_stream(cur)
+        target = cur if on_current_stream else self.stream
+        if not on_current_stream:
+            self.stream.wait_stream(cur)
         b = self.blocks.bufs
         b.act = b.ids = b.u = None
-        with torch.cuda.stream(self.stream):
+        with torch.cuda.stream(target):
             ev = None
             if self.launch_events is not None:      # (bench.py: the server launch's own duration, HIP events on ITS stream)
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), int(T))
@@ -608,3 +621,27 @@ class ServedRollout(object):
                 self.t += self.EP
             self.srv.join()
             left -= n
+
+
+def step_many(env, moves, episode_len=0, seed=None):
+    """`for t in range(T): obs_n, reward_n, done_n, _ = env.step(moves[t])` as ONE launch: moves [T, A, B, 5] one-hot rows on the
+    env's device (the reference's action format, environment.py:174-181, stacked over the steps).  -> a list of T tuples
+    (obs_n, rew [A, B], done [A, B]) of views into the server's T output blocks (valid until the next call with the same T);
+    world.pos / vel hold the state after the last step.  Bit-identical to the T env.step calls (tests/test_gpu_server.py).
+    episode_len > 0: the worlds restart (world.reset_uniform's device draws) every episode_len steps, counted over the calls."""
+    T = int(moves.shape[0])
+    key = (T, int(episode_len))
+    cache = env.__dict__.setdefault("_step_many_servers", {})
+    srv = cache.get(key)
+    if srv is None or srv.moves.data_ptr() != moves.data_ptr() or tuple(srv.moves.shape) != tuple(moves.shape):
+        t0 = 0 if srv is None else srv.served_to
+        srv = StepServer(env, moves, slots=T, episode_len=episode_len, seed=seed, probe=False)
+        srv.served_to = srv.commanded = t0 - t0 % T      # (blocks and move tensors are indexed by the global step modulo T)
+        if t0 % T:
+            raise _abi.MpeError("step_many: a new move tensor mid-way through a block of %d steps" % T)
+        srv.door.fill_(srv.commanded)
+        srv.flag.fill_(srv.commanded)
+        cache[key] = srv
+    g0 = srv.served_to
+    srv.run(T)
+    return [srv.outputs(g0 + t) for t in range(T)]

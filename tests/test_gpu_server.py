@@ -173,3 +173,29 @@ def test_served_rollout_is_the_fresh_moves_rollout(graphs):
         torch.cuda.synchronize()
         roll.srv.check()
         assert int(roll.srv.flag.min()) == K + 6 * EP and bool(torch.isfinite(env.world.pos).all())
+
+
+@pytest.mark.parametrize("name,kw,B", [("simple_spread", {}, 3000), ("simple_tag", {}, 4096), ("simple_spread", {}, 40000)])
+def test_step_many_is_the_env_step_loop(name, kw, B):
+    """rollout.step_many(env, moves[T]): the caller's `for t: env.step(moves[t])` loop as ONE launch on the caller's own stream (the
+    doorbell rung T ahead, then the server launch: no second stream) -- bit-identical to the T env.step calls, twice in a row."""
+    from multiagent_particle_envs_amd.rollout import step_many
+    T = 9
+    ref = mpe.make_env(name, batch_size=B, seed=11, **kw)
+    env = mpe.make_env(name, batch_size=B, seed=11, **kw)
+    ref.reset()
+    env.world.set_state(*ref.world.get_state())
+    A = ref.n
+    g = torch.Generator(device="cpu").manual_seed(5)
+    moves = torch.empty((T, A, B, _abi.MPE_ACTION_DIM), device="cuda")
+    for rnd in range(2):
+        moves.copy_(torch.nn.functional.one_hot(torch.randint(0, 5, (T, A, B), generator=g), 5).float())
+        outs = step_many(env, moves)
+        torch.cuda.synchronize()
+        for t in range(T):
+            obs_n, rew_n, done_n, _ = ref.step(moves[t])
+            o_s, r_s, d_s = outs[t]
+            for i in range(A):
+                assert torch.equal(o_s[i], obs_n[i]), (rnd, t, i)
+                assert torch.equal(r_s[i], rew_n[i]) and torch.equal(d_s[i], done_n[i])
+        assert torch.equal(env.world.pos, ref.world.pos) and torch.equal(env.world.vel, ref.world.vel)
