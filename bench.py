@@ -544,19 +544,25 @@ def roofline_entry(leg, k_us, B, mode, floor_us, timing=None):
 
 
 def served_timed(torch, rv, roll, B, region_ms, repeats):
-    """Timed region of a ServedRollout, with the contract's bracket (barrier + synchronize both sides, median of `repeats`, MAX
-    over ranks): -> dict(dt, n, rate [min, median, max of this rank], launch_us, steps_per_launch)."""
+    """Timed region of a (warmed-up) ServedRollout, with the contract's bracket (barrier + synchronize both sides, median of
+    `repeats`, MAX over ranks): -> dict(dt, n, rate [min, median, max of this rank], launch_us, steps_per_launch).
+    Every rank makes the SAME sequence of rendezvous calls whatever happens to it: an error is kept and raised at the end."""
     G = 2 * roll.EP * 4
-    roll.enqueue(G)
-    torch.cuda.synchronize()
-    roll.srv.check()
+    err = []
+
+    def run(n):
+        if err:
+            return
+        try:
+            roll.enqueue(n)
+            torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001 (kept; the rendezvous sequence goes on)
+            err.append(e)
     t0 = time.perf_counter()
-    roll.enqueue(G)
-    torch.cuda.synchronize()
+    run(G)
     reps = max(1, int(math.ceil(region_ms * 1e-3 / max(time.perf_counter() - t0, 1e-6))))
     t0 = time.perf_counter()      # (a second look at the region's own size: a short enqueue over-states the per-step time)
-    roll.enqueue(G * reps)
-    torch.cuda.synchronize()
+    run(G * reps)
     reps = int(rv.reduce_max(max(1, int(math.ceil(1.03 * reps * region_ms * 1e-3 / max(time.perf_counter() - t0, 1e-6))))))
     n = G * reps
     walls, launches = [], []
@@ -565,17 +571,23 @@ def served_timed(torch, rv, roll, B, region_ms, repeats):
         rv.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        roll.enqueue(n)
-        torch.cuda.synchronize()
+        run(n)
         walls.append(time.perf_counter() - t0)
         rv.barrier()
-        launches.append([(e0.elapsed_time(e1) * 1e3, T) for e0, e1, T in roll.srv.launch_events])
+        try:
+            launches.append([(e0.elapsed_time(e1) * 1e3, T) for e0, e1, T in roll.srv.launch_events])
+        except Exception as e:      # noqa: BLE001
+            err.append(e)
+            launches.append([(float("nan"), 1)])
         roll.srv.launch_events = None
-    roll.srv.check()
     order = sorted(range(len(walls)), key=lambda i: walls[i])
     med = order[len(order) // 2]
+    dt = rv.reduce_max(walls[med])
+    if err:
+        raise err[0]
+    roll.srv.check()
     ev = launches[med]
-    return {"dt": rv.reduce_max(walls[med]), "n": n, "rate": [B * n / walls[order[-1]], B * n / walls[med], B * n / walls[order[0]]],
+    return {"dt": dt, "n": n, "rate": [B * n / walls[order[-1]], B * n / walls[med], B * n / walls[order[0]]],
             "launch_us": sum(u for u, _ in ev) / len(ev), "steps_per_launch": sum(T for _, T in ev) / float(len(ev)),
             "launches_in_region": len(ev)}
 
@@ -596,6 +608,9 @@ def served_leg(torch, mpe, scenario, agents, B, EP, seed, region_ms, repeats=3, 
         A, Lm = len(env.world.agents), len(env.world.landmarks)
         bytes_step = algorithmic_bytes(A, Lm, int(env._obs_off[-1]), len(env.world.choice_pops), 0)
         roll = ServedRollout(env, episode_len=EP, timeout_s=4.0, graphs=True, ring_ahead=ahead)
+        roll.enqueue(2 * EP * 4)
+        torch.cuda.synchronize()
+        roll.srv.check()
         r = served_timed(torch, rv, roll, B, region_ms, repeats)
         dt, n = r["dt"], r["n"]
         return {"value": B * n / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3 / n, "timed_steps": n, "timed_region_s": dt,
@@ -1177,22 +1192,38 @@ def main():
     served, served_err, solo_served = None, None, None
     if args.commands != "launched" and args.mode == "graph" and args.protocol == "fresh" and args.streams == 1 and EP and \
             kname == "mpe::k_split" and leg.roll("resident").rollouts[0].pool_c is None:
-        try:
+        roll_s = None
+        try:      # phase 1, no rendezvous inside: build the server (stream probe, graphs) and serve a few episodes
             from multiagent_particle_envs_amd.rollout import ServedRollout
             env_s = mpe.make_env(args.scenario, batch_size=B, seed=args.seed, **leg.kw)
             env_s.world.world_offset = rank * B
             roll_s = ServedRollout(env_s, episode_len=EP, timeout_s=4.0, graphs=True, ring_ahead=True)
-            if world > 1:       # (rank 0 alone first, as for the launched steps: the N-GPU line's reference point)
-                if rank == 0:
-                    r1 = served_timed(torch, sharding.Rendezvous(0, 1, dev), roll_s, B, min(args.region_ms, 1000.0), 1)
-                    solo_served = B * r1["n"] / r1["dt"]
-                rv.barrier()
-            served = served_timed(torch, rv, roll_s, B, args.region_ms, args.repeats)
-            served["probe"] = roll_s.srv.stream_probe
-            del roll_s, env_s
+            roll_s.enqueue(2 * EP * 4)
+            torch.cuda.synchronize()
+            roll_s.srv.check()
         except Exception as e:
             served_err = "%s: %s" % (type(e).__name__, str(e)[:300])
+            roll_s = None
             torch.cuda.synchronize()
+        if rv.reduce_max(1.0 if roll_s is None else 0.0) > 0:      # any rank without a server: nobody measures one
+            roll_s = None
+            served_err = served_err or "another rank could not bring its step server up"
+        if roll_s is not None:      # phase 2: every rank makes the same rendezvous calls (served_timed keeps its errors to the end)
+            if world > 1:           # (rank 0 alone first, as for the launched steps: the N-GPU line's reference point)
+                if rank == 0:
+                    try:
+                        r1 = served_timed(torch, sharding.Rendezvous(0, 1, dev), roll_s, B, min(args.region_ms, 1000.0), 1)
+                        solo_served = B * r1["n"] / r1["dt"]
+                    except Exception as e:
+                        served_err = "%s: %s" % (type(e).__name__, str(e)[:300])
+                rv.barrier()
+            try:
+                served = served_timed(torch, rv, roll_s, B, args.region_ms, args.repeats)
+                served["probe"] = roll_s.srv.stream_probe
+            except Exception as e:
+                served_err = "%s: %s" % (type(e).__name__, str(e)[:300])
+                torch.cuda.synchronize()
+            del roll_s, env_s
         if rv.reduce_max(1.0 if served is None else 0.0) > 0:      # any rank failed: nobody switches
             served = None
         done_at("headline_step_server")
@@ -1263,6 +1294,9 @@ def main():
             from multiagent_particle_envs_amd.rollout import ServedRollout
             env_p = mpe.make_env(args.scenario, batch_size=B, seed=args.seed, **leg.kw)
             roll_p = ServedRollout(env_p, episode_len=EP, timeout_s=4.0, graphs=True, ring_ahead=False)
+            roll_p.enqueue(2 * EP * 4)
+            torch.cuda.synchronize()
+            roll_p.srv.check()
             rp = served_timed(torch, rv, roll_p, B, SR, 3)
             extra["step_server_per_step_doorbells"] = {
                 "what": "the step server commanded by ONE DOORBELL LAUNCH PER STEP (25 per episode, replayed as a graph behind the draw)",
