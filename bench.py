@@ -944,6 +944,8 @@ def compact_line(out, full_path=None):
                                             "algorithmic_bytes_per_launch": hb["roofline"]["algorithmic_bytes_per_launch"],
                                             "value": sig(hb["value"]), "frac_timed_region": sig(
                                                 hb["roofline"]["algorithmic_bytes_per_launch"] / (hb["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS)}
+        if isinstance(hb.get("step_server"), dict) and "value" in hb["step_server"]:      # the same commanded to the step server
+            line["roofline"]["hbm_resident"]["step_server"] = _pick(hb["step_server"], ("value", "ms_per_step", "frac", "frac_timed_region"))
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "single_core", "value_in_reference_terms"))
@@ -1333,6 +1335,29 @@ def main():
                                  "ms_per_step": dtb * 1e3 / (25 * Rb), "roofline": rb}
         big.release()
         del big
+        torch.cuda.empty_cache()
+        # ... and commanded to the step server: 16 384 workgroups cannot be resident, so each episode's steps are commanded BEFORE its
+        # launch (one launch per episode behind its doorbell: nothing in it waits), the next episode's draw overlapping on the other stream
+        try:
+            from multiagent_particle_envs_amd.rollout import ServedRollout
+            env_b = mpe.make_env("simple_spread", batch_size=1 << 20, seed=args.seed)
+            roll_b = ServedRollout(env_b, episode_len=EP or 25, timeout_s=6.0, graphs=True, launch_per_episode=True)
+            roll_b.enqueue(2 * (EP or 25))
+            torch.cuda.synchronize()
+            roll_b.srv.check()
+            sb = served_timed(torch, rv, roll_b, 1 << 20, 2 * SR, 3)
+            per_b = rb["algorithmic_bytes_per_launch"]
+            extra["hbm_resident"]["step_server"] = {
+                "what": "the same at 1048576 worlds with the steps commanded to the step server: one launch per %d-step episode behind "
+                        "its doorbell (every command precedes its launch: no residency needed)" % (EP or 25),
+                "value": (1 << 20) * sb["n"] / sb["dt"], "unit": "env-steps/s", "ms_per_step": sb["dt"] * 1e3 / sb["n"],
+                "repeats": stats(sb["rate"]), "server_launch_us": sb["launch_us"], "steps_per_server_launch": sb["steps_per_launch"],
+                "frac": per_b * sb["steps_per_launch"] / (sb["launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "frac_timed_region": per_b / (sb["dt"] / sb["n"]) / 1e9 / HBM_PEAK_GBS}
+            del roll_b, env_b
+        except Exception as e:
+            extra["hbm_resident"]["step_server"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            torch.cuda.synchronize()
         torch.cuda.empty_cache()
         done_at("hbm_resident")
         # ---- BASELINE.json's other single-GPU configs, each in a process of its own ------------------------------------

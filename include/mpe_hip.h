@@ -122,6 +122,7 @@ const char *mpe_last_error(void);
 size_t mpe_sizeof_desc(void);
 size_t mpe_sizeof_buffers(void);
 size_t mpe_sizeof_row_program(void);
+size_t mpe_sizeof_step_server(void);
 /* Observation widths of the built-in scenarios: fills desc->obs_off[0..A]; returns D_total or <0. */
 int mpe_fill_obs_layout(MpeScenarioDesc *desc);
 /* Per-entity constants as one float table for the wave-per-world (large N) kernel:
@@ -266,6 +267,9 @@ typedef struct MpeStepServer {
   const float *act_ring;   /* device, `ring` consecutive [A][B][5] move tensors                                         */
   int32_t ring, slots;
   uint64_t timeout_us;
+  int32_t ahead;           /* != 0: every step of a launch is commanded BEFORE the launch starts (ring, then start, in stream order):
+                              the launch never waits, so its workgroups need not all be resident -- any batch size            */
+  int32_t reserved_;
 } MpeStepServer;
 int mpe_step_server_supported(const MpeScenarioDesc *desc, int64_t B);   /* 1 / 0 (< 0: invalid descriptor) */
 int64_t mpe_step_server_flags(int64_t B);

@@ -47,7 +47,7 @@ class MpeScenarioDesc(C.Structure):
 
 class MpeStepServer(C.Structure):      # include/mpe_hip.h: the step server's device words and ring geometry
     _fields_ = [("door", C.c_void_p), ("flag", C.c_void_p), ("status", C.c_void_p), ("act_ring", C.c_void_p),
-                ("ring", C.c_int32), ("slots", C.c_int32), ("timeout_us", C.c_uint64)]
+                ("ring", C.c_int32), ("slots", C.c_int32), ("timeout_us", C.c_uint64), ("ahead", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class MpeBuffers(C.Structure):
@@ -111,6 +111,7 @@ EXPORTS = {
                                            C.c_void_p, C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32,
                                            C.c_uint32, C.c_void_p]),
     "mpe_sizeof_row_program": (C.c_size_t, []),
+    "mpe_sizeof_step_server": (C.c_size_t, []),
     "mpe_rows_static_source": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeRowProgram), C.POINTER(C.c_int32), C.c_char_p,
                                          C.c_size_t, C.POINTER(C.c_size_t)]),
     "mpe_rows_load_image": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeRowProgram), C.POINTER(C.c_int32), C.c_void_p,
@@ -155,7 +156,7 @@ def lib():
     if handle.mpe_abi_version() != MPE_ABI_VERSION:
         raise MpeError("ABI version mismatch: library %d, binding %d" % (handle.mpe_abi_version(), MPE_ABI_VERSION))
     if handle.mpe_sizeof_desc() != C.sizeof(MpeScenarioDesc) or handle.mpe_sizeof_buffers() != C.sizeof(MpeBuffers) or \
-            handle.mpe_sizeof_row_program() != C.sizeof(MpeRowProgram):
+            handle.mpe_sizeof_row_program() != C.sizeof(MpeRowProgram) or handle.mpe_sizeof_step_server() != C.sizeof(MpeStepServer):
         raise MpeError("struct layout mismatch between include/mpe_hip.h and _abi.py")
     _lib = handle
     return _lib

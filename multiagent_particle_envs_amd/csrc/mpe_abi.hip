@@ -171,6 +171,7 @@ const char *mpe_last_error(void) { return g_err; }
 size_t mpe_sizeof_desc(void) { return sizeof(MpeScenarioDesc); }
 size_t mpe_sizeof_buffers(void) { return sizeof(MpeBuffers); }
 size_t mpe_sizeof_row_program(void) { return sizeof(MpeRowProgram); }
+size_t mpe_sizeof_step_server(void) { return sizeof(MpeStepServer); }
 
 int mpe_fill_obs_layout(MpeScenarioDesc *d) {
   if (int rc = check_desc(d, "mpe_fill_obs_layout")) return rc;
@@ -514,6 +515,7 @@ int mpe_step_server_start(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t
   h.ring = srv->ring;
   h.slots = srv->slots;
   h.timeout_ticks = srv->timeout_us * 100ull;      // the 100 MHz wall clock (s_memrealtime)
+  h.ahead = srv->ahead != 0;
   const mpe::NarrowDesc n = make_narrow(d, b, (size_t)B);
   const int rc = mpe::launch_split_serve(d->kind, d->n_agents, d->n_landmarks, d->n_adversaries, n, *b, (size_t)B, ra, h,
                                          static_cast<hipStream_t>(stream));

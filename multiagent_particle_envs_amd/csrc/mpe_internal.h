@@ -67,6 +67,7 @@ struct ServeHandles {
   const float *act_ring;
   int32_t ring, slots;
   uint64_t timeout_ticks;
+  bool ahead;              // every command precedes its launch: no residency needed
 };
 constexpr int MPE_ESERVER_TOO_LARGE = -1000;   // internal: the grid cannot be resident (mapped to MPE_EUNSUPPORTED with a message)
 bool serve_supports(int kind, int A, int L, int nadv);

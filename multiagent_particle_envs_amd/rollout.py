@@ -364,7 +364,7 @@ class StepServer(object):
     a ring and a wait launch per step and is better served by env.step.  One server per env at a time; the env's own outputs
     (env.step's ping-pong sets) are not touched: a served step's outputs live in the server's blocks."""
 
-    def __init__(self, env, moves, slots=2, episode_len=0, seed=None, timeout_s=2.0, probe_graph=False, probe=True):
+    def __init__(self, env, moves, slots=2, episode_len=0, seed=None, timeout_s=2.0, probe_graph=False, probe=True, ahead=False):
         if not env.fused or getattr(env, "_prog", None) is not None:
             raise _abi.MpeError("StepServer serves the fused built-in scenarios (a wave-per-agent kernel, no utterances)")
         if env._py_obs or env._py_reward or env._py_done or env._py_info:
@@ -395,6 +395,7 @@ class StepServer(object):
         s = _abi.MpeStepServer()
         s.door, s.flag, s.status = self.door.data_ptr(), self.flag.data_ptr(), self.status.data_ptr()
         s.act_ring, s.ring, s.slots, s.timeout_us = moves.data_ptr(), int(moves.shape[0]), self.slots, int(timeout_s * 1e6)
+        s.ahead = 1 if ahead else 0      # every launch's commands precede it (run(), per-episode launches): any batch size
         self._srv = s
         self._commander = _abi.raw_stream(dev).value      # commands come from the stream that is current NOW
         if probe:
@@ -544,7 +545,8 @@ class ServedRollout(object):
     queues is not ours to probe).  ring_ahead=True: ONE doorbell per episode (all its steps commanded at once: their moves all
     exist after the draw) -- the server's own rate, where per-step doorbells measure the command processor's launch rate."""
 
-    def __init__(self, env, episode_len=25, seed=None, slots=2, timeout_s=5.0, graphs=False, ring_ahead=False, max_launch_episodes=160):
+    def __init__(self, env, episode_len=25, seed=None, slots=2, timeout_s=5.0, graphs=False, ring_ahead=False, max_launch_episodes=160,
+                 launch_per_episode=False):
         w = env.world
         env._ensure_buffers()
         A, B = len(w.agents), w.batch_size
@@ -554,12 +556,23 @@ class ServedRollout(object):
         # graphs: ONE commanding stream of our own for capture, replay and the server-stream probe (a graph's kernels keep a tie to
         # the stream they were captured on; the default stream cannot capture)
         self.cmd = torch.cuda.Stream(device=w.device) if graphs else None
+        # launch_per_episode: ONE server launch per episode, started BEHIND that episode's doorbell (ring_ahead) -- every command
+        # precedes its launch, nothing in the launch ever waits, so the grid need not be resident: any batch size (1 048 576 worlds:
+        # 16 384 workgroups).  The launches sit on the server's stream, the next episode's draw overlaps them on the commanding one;
+        # a ring half is handed back by an event behind the launch that read it.
+        self.launch_per_episode = bool(launch_per_episode)
+        if self.launch_per_episode:
+            ring_ahead = True
+            self._read_done = [torch.cuda.Event(), torch.cuda.Event()]
+            self._recorded = [False, False]
         if graphs:
             self.cmd.wait_stream(torch.cuda.current_stream(w.device))
             with torch.cuda.stream(self.cmd):
-                self.srv = StepServer(env, self.moves, slots=slots, episode_len=self.EP, seed=seed, timeout_s=timeout_s, probe_graph=True)
+                self.srv = StepServer(env, self.moves, slots=slots, episode_len=self.EP, seed=seed, timeout_s=timeout_s, probe_graph=True,
+                                      ahead=self.launch_per_episode)
         else:
-            self.srv = StepServer(env, self.moves, slots=slots, episode_len=self.EP, seed=seed, timeout_s=timeout_s)
+            self.srv = StepServer(env, self.moves, slots=slots, episode_len=self.EP, seed=seed, timeout_s=timeout_s,
+                                  ahead=self.launch_per_episode)
         self.seed = self.srv.seed
         self._L = _abi.lib()
         self.ring_ahead, self.max_launch = bool(ring_ahead), int(max_launch_episodes) * self.EP
@@ -605,6 +618,25 @@ class ServedRollout(object):
                 self.enqueue(steps)
             caller.wait_stream(self.cmd)
             return
+        if self.launch_per_episode:
+            cur = torch.cuda.current_stream(dev)
+            for _ in range(steps // self.EP):
+                h = (self.t // self.EP) & 1
+                if self._recorded[h]:
+                    cur.wait_event(self._read_done[h])       # the launch that read this half has ended
+                self.srv.served_to += self.EP                 # (the commands come first: this episode's launch follows)
+                if self._graphs is None:
+                    self._caller_half(h, self.t)
+                else:
+                    self._graphs[h].replay()
+                self.srv.commanded += self.EP
+                self.srv.served_to -= self.EP
+                self.srv.start(self.EP)                       # behind the doorbell just rung (start waits for the current stream)
+                self._read_done[h].record(self.srv.stream)
+                self._recorded[h] = True
+                self.t += self.EP
+            self.srv.join()
+            return
         left = steps
         while left > 0:
             n = min(left, self.max_launch)
@@ -635,7 +667,7 @@ def step_many(env, moves, episode_len=0, seed=None):
     srv = cache.get(key)
     if srv is None or srv.moves.data_ptr() != moves.data_ptr() or tuple(srv.moves.shape) != tuple(moves.shape):
         t0 = 0 if srv is None else srv.served_to
-        srv = StepServer(env, moves, slots=T, episode_len=episode_len, seed=seed, probe=False)
+        srv = StepServer(env, moves, slots=T, episode_len=episode_len, seed=seed, probe=False, ahead=True)
         srv.served_to = srv.commanded = t0 - t0 % T      # (blocks and move tensors are indexed by the global step modulo T)
         if t0 % T:
             raise _abi.MpeError("step_many: a new move tensor mid-way through a block of %d steps" % T)

@@ -199,3 +199,29 @@ def test_step_many_is_the_env_step_loop(name, kw, B):
                 assert torch.equal(o_s[i], obs_n[i]), (rnd, t, i)
                 assert torch.equal(r_s[i], rew_n[i]) and torch.equal(d_s[i], done_n[i])
         assert torch.equal(env.world.pos, ref.world.pos) and torch.equal(env.world.vel, ref.world.vel)
+
+
+def test_launches_whose_commands_precede_them_need_no_residency():
+    """`ahead`: every step of a launch is commanded before the launch starts (ring, then start, in stream order) -- nothing in it
+    ever waits, so its 16 384 workgroups need not be resident: step_many and ServedRollout(launch_per_episode=True) at 1 048 576
+    worlds, bit-identical to the launched steps."""
+    from multiagent_particle_envs_amd.rollout import ServedRollout, step_many
+    B, EP = 1 << 20, 5
+    ref_env = mpe.make_env("simple_spread", batch_size=B, seed=5)
+    rr = RandomRollout(ref_env, episode_len=EP, pool=EP, regenerate=True)
+    o = rr.enqueue(3 * EP)
+    torch.cuda.synchronize()
+    env = mpe.make_env("simple_spread", batch_size=B, seed=5)
+    roll = ServedRollout(env, episode_len=EP, slots=2, graphs=False, launch_per_episode=True)
+    roll.enqueue(3 * EP)
+    torch.cuda.synchronize()
+    roll.srv.check()
+    assert torch.equal(env.world.pos, ref_env.world.pos) and torch.equal(env.world.vel, ref_env.world.vel)
+    obs, rew, done = roll.srv.outputs(3 * EP - 1)
+    assert all(torch.equal(a, b) for a, b in zip(obs, o.obs_n)) and torch.equal(rew, o.rew)
+    del roll, rr
+    moves = torch.nn.functional.one_hot(torch.randint(0, 5, (3, 3, B)), 5).float().cuda()
+    outs = step_many(env, moves)
+    for t in range(3):
+        obs_n, rew_n, _, _ = ref_env.step(moves[t])
+        assert all(torch.equal(a, b) for a, b in zip(outs[t][0], obs_n)) and torch.equal(outs[t][1][0], rew_n[0])
