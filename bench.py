@@ -918,8 +918,8 @@ def compact_line(out, full_path=None):
     if out.get("n_gpus", 1) > 1:
         line["config"]["sharding"] = cfg.get("sharding")
     line["config"]["workload"] = str(cfg.get("workload_short") or cfg.get("workload", ""))[:150]
-    line["config"]["timed_region"] = ("ms_per_step = timed_region_s / timed_steps; region >= %.1f s of back-to-back steps, median of %s "
-                                      "repeats, max over ranks (--steps / --warmup do not size it)"
+    line["config"]["timed_region"] = ("ms_per_step = timed_region_s / timed_steps; >= %.1f s of back-to-back steps, median of %s repeats, "
+                                      "max over ranks (--steps / --warmup do not size it)"
                                       % (cfg.get("region_ms", MIN_REGION_MS) * 1e-3, cfg.get("repeats")))
     if cfg.get("scaling_diagnostic"):
         line["config"]["value_over_n_times_rank0_solo"] = sig(cfg["scaling_diagnostic"]["value_over_n_times_rank0_solo"], 4)
@@ -939,17 +939,20 @@ def compact_line(out, full_path=None):
         line["roofline"]["hbm_resident_frac"] = sig(hb["roofline"]["frac"])
         line["roofline"]["hbm_resident"] = {"worlds": hb["roofline"]["env_steps_per_launch"],
                                             "kernel_us_per_launch": sig(hb["roofline"]["kernel_us_per_launch"]),
-                                            "kernel_us_rocprof": hb["roofline"].get("kernel_us_rocprof"),
+                                            "kernel_us_rocprof_mean": (hb["roofline"].get("kernel_us_rocprof") or {}).get("mean"),
                                             "traffic": hb["roofline"].get("traffic"),
                                             "algorithmic_bytes_per_launch": hb["roofline"]["algorithmic_bytes_per_launch"],
                                             "value": sig(hb["value"]), "frac_timed_region": sig(
                                                 hb["roofline"]["algorithmic_bytes_per_launch"] / (hb["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS)}
         if isinstance(hb.get("step_server"), dict) and "value" in hb["step_server"]:      # the same commanded to the step server
             line["roofline"]["hbm_resident"]["step_server"] = _pick(hb["step_server"], ("value", "ms_per_step", "frac", "frac_timed_region"))
+            if cfg.get("mode") == "step-server":      # the line's own way of issuing steps, beyond the cache: THE HBM fraction
+                line["roofline"]["hbm_resident_frac_launched"] = line["roofline"]["hbm_resident_frac"]
+                line["roofline"]["hbm_resident_frac"] = sig(hb["step_server"]["frac"])
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "single_core", "value_in_reference_terms"))
-        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:180]
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:130]
         if cb.get("reference_build_container"):
             line["cpu_baseline"]["reference_build_container"] = _pick(cb["reference_build_container"],
                                                                       ("cores", "env_steps_per_s_1_process", "env_steps_per_s_all_cores"))
