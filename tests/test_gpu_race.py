@@ -90,6 +90,7 @@ def test_rollout_and_scenario_suites_pass_under_the_delayed_wave_build():
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_rollout.py"),
                         os.path.join(ROOT, "tests", "test_f3_scenarios.py"), os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_server.py"),      # (the step server: the same loop, commanded)
                         "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
                        capture_output=True, text=True, env=env, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
