@@ -15,7 +15,16 @@ from HBM and writes every agent's obs / reward / done.  One "step" = every world
 
 Timed region: barrier + synchronize, a HIP graph of up to 8000 CONSECUTIVE steps replayed back to back until the region
 holds >= 2 s of GPU work (whatever --steps is: `--steps 20` and `--steps 1000` time the same graph), synchronize +
-barrier; median of 5 repeats, max over ranks; `value` = B * timed steps * ranks / that time.  Rank 0 prints ONE JSON line.
+barrier; median of 5 repeats, max over ranks; `value` = B * timed steps * ranks / that time.  Rank 0 prints ONE JSON line
+-- COMPACT (< 4096 bytes: the driver parses it; round 5's 20 KB line came back unparsed) -- and writes the full record
+(every leg, raw timings, per-rank records, the box) to --full-json (default gpurun_out/bench_full.json).
+
+Round 6: the SAME protocol is measured twice under the same bracket -- its steps LAUNCHED (one mpe_step per step, as
+above) and COMMANDED to the step server (include/mpe_hip.h: mpe_step_server_*; rollout.ServedRollout: per episode one
+block draw and one doorbell launch behind it on the commanding stream, the server's resident launch on a stream of its
+own; fresh moves read from HBM by every step, in-launch resets, every step's rows / rewards / dones / state written
+through to its own block) -- and the line's value is the faster (`config.mode`; --commands launched | served | auto);
+the other stays in the line (`roofline.launched`).
 
 N > 1 never measures fewer GPUs than asked for: with WORLD_SIZE unset `--gpus N` starts N ranks itself and fails when
 the node has fewer GPUs or a rank fails; with a launcher, WORLD_SIZE must equal --gpus.  The barrier travels over RCCL
