@@ -5,7 +5,7 @@ waits and the profile still works when the profiler serialises dispatches (PMC c
 overtake the resident server there).  Same kernel, same per-step work as the timed protocol (fresh moves read from HBM every
 step, in-launch resets every 25 steps, every step's rows / rewards / dones / state written through).
 
-    rocprofv3 --kernel-trace --stats ... -- python tools/server_profile.py [worlds] [T] [launches]
+    rocprofv3 --kernel-trace --stats ... -- python tools/server_profile.py [worlds] [T] [launches] [scenario]
 """
 import os
 import sys
@@ -23,8 +23,8 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     N = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-    env = mpe.make_env("simple_spread", batch_size=B, seed=0)
-    A = 3
+    env = mpe.make_env(sys.argv[4] if len(sys.argv) > 4 else "simple_spread", batch_size=B, seed=0)
+    A = env.n
     moves = torch.empty((T, A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device="cuda")
     L = _abi.lib()
     srv = StepServer(env, moves, slots=2, episode_len=25, timeout_s=3.0, probe=False)
