@@ -254,8 +254,9 @@ int mpe_rollout_random(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int6
  * launch ends.  Who gains: callers whose moves for step g + 1 exist before step g has finished (recorded or scripted action
  * sequences, action repeat, several env instances interleaved, the random-action benchmark) -- their steps run back to back
  * at the kernel's span; a closed loop (policy reads step g's rows before it can command g + 1) pays ring + wait launches
- * and is better served by mpe_step.  Scenarios without utterances, at shapes with a wave-per-agent kernel; B small enough
- * for every 64-world workgroup to be resident (mpe_step_server_supported).
+ * and is better served by mpe_step.  All nine scenarios at the shapes with a wave-per-agent kernel (the communication scenarios'
+ * utterances come from `comm_ring` as the moves from `act_ring`); a launch that may wait needs every 64-world workgroup resident
+ * (mpe_step_server_start says so), one whose commands precede it (`ahead`) takes any batch size.
  * The two streams must map to different HARDWARE queues: HIP multiplexes streams onto a few of them, and a ring queued behind
  * the resident server on the same hardware queue never starts (the server then times out).  Probe before trusting a pair of
  * streams: mpe_step_server_wait on the candidate server stream with a short timeout_us, mpe_step_server_ring on the caller's
@@ -267,6 +268,8 @@ typedef struct MpeStepServer {
   const float *act_ring;   /* device, `ring` consecutive [A][B][5] move tensors                                         */
   int32_t ring, slots;
   uint64_t timeout_us;
+  const float *comm_ring;  /* communication scenarios (kinds 5-8): `ring` consecutive [A][B][dim_c] utterance tensors (the speaking
+                              agents' rows, Action.c: environment.py:183-190); step g reads tensor g % ring; NULL otherwise          */
   int32_t ahead;           /* != 0: every step of a launch is commanded BEFORE the launch starts (ring, then start, in stream order):
                               the launch never waits, so its workgroups need not all be resident -- any batch size            */
   int32_t reserved_;

@@ -47,7 +47,8 @@ class MpeScenarioDesc(C.Structure):
 
 class MpeStepServer(C.Structure):      # include/mpe_hip.h: the step server's device words and ring geometry
     _fields_ = [("door", C.c_void_p), ("flag", C.c_void_p), ("status", C.c_void_p), ("act_ring", C.c_void_p),
-                ("ring", C.c_int32), ("slots", C.c_int32), ("timeout_us", C.c_uint64), ("ahead", C.c_int32), ("reserved_", C.c_int32)]
+                ("ring", C.c_int32), ("slots", C.c_int32), ("timeout_us", C.c_uint64), ("comm_ring", C.c_void_p),
+                ("ahead", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class MpeBuffers(C.Structure):

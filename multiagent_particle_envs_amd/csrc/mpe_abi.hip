@@ -497,7 +497,7 @@ int mpe_step_server_start(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t
   if (T < 0 || episode_len < 0) return fail(MPE_EINVAL, "%s: T, episode_len must be >= 0", what);
   if (B == 0 || T == 0) return 0;
   if (d->n_agents + d->n_landmarks > mpe::kNarrowMaxE || !mpe::serve_supports(d->kind, d->n_agents, d->n_landmarks, d->n_adversaries))
-    return fail(MPE_EUNSUPPORTED, "%s: the step server exists for the wave-per-agent shapes of the scenarios without utterances", what);
+    return fail(MPE_EUNSUPPORTED, "%s: the step server exists for the shapes with a wave-per-agent kernel", what);
   mpe::RollArgs ra;
   std::memset(&ra, 0, sizeof(ra));
   ra.T = T;
@@ -512,6 +512,9 @@ int mpe_step_server_start(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t
   h.flag = srv->flag;
   h.status = srv->status;
   h.act_ring = srv->act_ring;
+  h.comm_ring = srv->comm_ring;
+  if (d->kind >= MPE_SCN_SPEAKER_LISTENER && !srv->comm_ring)
+    return fail(MPE_EINVAL, "%s: srv->comm_ring (the utterance tensors of the communication scenarios) is NULL", what);
   h.ring = srv->ring;
   h.slots = srv->slots;
   h.timeout_ticks = srv->timeout_us * 100ull;      // the 100 MHz wall clock (s_memrealtime)

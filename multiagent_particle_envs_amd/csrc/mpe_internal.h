@@ -64,7 +64,7 @@ bool split_supports(int kind, int A, int L, int nadv);
 struct ServeHandles {
   uint64_t *door, *flag;
   uint32_t *status;
-  const float *act_ring;
+  const float *act_ring, *comm_ring;
   int32_t ring, slots;
   uint64_t timeout_ticks;
   bool ahead;              // every command precedes its launch: no residency needed

@@ -159,18 +159,26 @@ constexpr unsigned speakers_of() {
 }
 // The utterance of one agent in one world at this step: a row of MpeBuffers.comm (what the caller passed), or -- in
 // the fused rollout -- the one-hot of the word mpe_random_comm draws for (world, step, agent), recomputed where used.
-template <bool ROLL>
+// WM (word mode): 0 = the caller's row, 1 = drawn in the kernel (the rollout), 2 = the caller's row read at SYSTEM scope (the step
+// server: another kernel wrote the utterance ring while this one runs -- no cache of ours may serve it)
+constexpr int kWordRow = 0, kWordDrawn = 1, kWordRowSys = 2;
+template <int WM>
 struct Word {
   const float *row;
   int id;
-  __device__ __forceinline__ float operator[](int c) const { return ROLL ? (c == id ? 1.f : 0.f) : row[c]; }
+  __device__ __forceinline__ float operator[](int c) const {
+    if constexpr (WM == kWordDrawn) return c == id ? 1.f : 0.f;
+    else if constexpr (WM == kWordRowSys)
+      return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int *>(row) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    else return row[c];
+  }
 };
-template <int DC, bool ROLL>
-__device__ __forceinline__ Word<ROLL> word_of(const MpeBuffers &b, size_t B, size_t w0, unsigned ln, int j, uint64_t seed,
-                                              uint64_t gw, uint64_t gt) {
-  Word<ROLL> wd;
-  wd.row = ROLL ? nullptr : b.comm + wave_off(((size_t)j * B + w0) * DC) + ln * DC;
-  wd.id = ROLL ? comm_draw(seed, gw, gt, j, DC) : 0;
+template <int DC, int WM>
+__device__ __forceinline__ Word<WM> word_of(const MpeBuffers &b, size_t B, size_t w0, unsigned ln, int j, uint64_t seed,
+                                            uint64_t gw, uint64_t gt) {
+  Word<WM> wd;
+  wd.row = WM == kWordDrawn ? nullptr : b.comm + wave_off(((size_t)j * B + w0) * DC) + ln * DC;
+  wd.id = WM == kWordDrawn ? comm_draw(seed, gw, gt, j, DC) : 0;
   return wd;
 }
 
@@ -183,7 +191,7 @@ __device__ __forceinline__ Word<ROLL> word_of(const MpeBuffers &b, size_t B, siz
 template <int KIND, int RP>
 constexpr int aux_policy() { return (KIND == MPE_SCN_TAG && RP == kRowsSc1) ? kRowsSc1 : kRowsPlain; }
 
-template <int KIND, int A, int L, int NADV, bool ROLL, int AUX>
+template <int KIND, int A, int L, int NADV, bool ROLL, int AUX, int WM = (ROLL ? kWordDrawn : kWordRow)>
 __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const float *const sz /* pinned sz[] */, const MpeBuffers &b, const float *X, int lane,
                                             bool live, unsigned ln, size_t B, size_t w0 /* first world of the wave */,
                                             size_t ro /* uniform: row 0 of this step + w0 */, uint64_t seed, uint64_t gw,
@@ -369,7 +377,7 @@ __device__ __forceinline__ void reward_wave(const NarrowDesc &d, const float *co
       float err[2];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {   // a = 0: Eve (adversary), a = 1: Bob (good listener)
-        const Word<ROLL> c = word_of<DC, ROLL>(b, B, w0, ln, a, seed, gw, gt);
+        const Word<WM> c = word_of<DC, WM>(b, B, w0, ln, a, seed, gw, gt);
         float e = 0.f;
         bool silent = true;
 #pragma unroll
@@ -493,6 +501,7 @@ struct ServeArgs {
   unsigned long long *flag;     // [grid] completed steps per workgroup (absolute count)
   unsigned int *status;         // != 0: a wave gave up waiting (timeout)
   const float *act_ring;        // `ring` consecutive [A][B][5] move tensors; step g reads tensor g % ring
+  const float *comm_ring;       // communication scenarios: `ring` consecutive [A][B][dim_c] utterance tensors, likewise
   int32_t ring, slots;          // output block of step g: g % slots (blocks of obs_off[A] * B floats / A * B entries)
   unsigned long long timeout_ticks;
 };
@@ -512,8 +521,10 @@ __global__ void __launch_bounds__((SplitShape<KIND, A, L, NADV>::waves(DUALP) * 
 k_split(float *const g_pos, float *const g_vel, const float *const g_act, const int32_t *const g_ids, const size_t B,
         const int g_wpw, const int g_observe_only, const unsigned g_movable, const NarrowDesc d, const MpeBuffers b_in,
         const RollArgs ra, const ServeArgs sv) {
-  static_assert(!SERVE || (ROLL && RP == kRowsSc1 && KIND < MPE_SCN_SPEAKER_LISTENER),
-                "the step server: a rollout instantiation, write-through stores, scenarios without utterances");
+  static_assert(!SERVE || (ROLL && RP == kRowsSc1), "the step server: a rollout instantiation, write-through stores");
+  // the agents' utterances: the caller's rows (a launched step), drawn in the kernel (the rollout), or the caller's rows of THIS step
+  // out of the utterance ring, read at system scope (the step server)
+  constexpr int WM = SERVE ? kWordRowSys : (ROLL ? kWordDrawn : kWordRow);
   // The leading scalar arguments (13 dwords) repeat what the first global loads of a wave need -- the state and
   // action pointers, the batch size, the worlds per workgroup, the movable mask -- so that the CP can PRELOAD them
   // into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, _build.py): the wave's loads leave without a
@@ -580,6 +591,12 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
     __syncthreads();
   }
   auto block_of = [&](const int t) { return SERVE ? (blk0 + t) % sv.slots : t; };   // (32-bit; t < T)
+  auto with_words = [&](const int t) {      // the buffers with `comm` = the utterances of step t (served: tensor g mod ring)
+    MpeBuffers q = b;
+    if constexpr (SERVE)
+      q.comm = sv.comm_ring ? sv.comm_ring + (size_t)((mvt0 + t) % sv.ring) * ((size_t)A * B * SplitShape<KIND, A, L, NADV>::DC) : nullptr;
+    return q;
+  };
   // wait_door: until step g = step0 + t is commanded.  -> false: gave up (timeout): the wave leaves the kernel.
   // `publisher`: the reward wave -- while idle it publishes the previous step as soon as every agent wave has drained.
   auto wait_door = [&](const int t, const bool publisher) -> bool {
@@ -674,8 +691,8 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       }
       MPE_STAMP(2);
       if (!(MPE_SPLIT_ABLATE & 2))
-      reward_wave<KIND, A, L, NADV, ROLL, AUX>(d, sz, b, X, lane, live, ln, B, w0, (size_t)block_of(t) * row_stride + w0, ra.seed, gw_r,
-                                          ra.step0 + (uint64_t)t, goal_r, food);
+      reward_wave<KIND, A, L, NADV, ROLL, AUX, WM>(d, sz, with_words(t), X, lane, live, ln, B, w0, (size_t)block_of(t) * row_stride + w0,
+                                                   ra.seed, gw_r, ra.step0 + (uint64_t)t, goal_r, food);
       MPE_STAMP(3);
     }
     if (SERVE) {   // the last step: every wave drains, then the workgroup says so
@@ -906,6 +923,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
     const float *const X = xch + (ROLL ? (t & 1) * A * XW * kWave : 0);
     const uint64_t gt = ra.step0 + (uint64_t)t;   // global step (the word stream of the rollout)
     float *const obs_t = b.obs + (size_t)block_of(t) * obs_stride;
+    [[maybe_unused]] const MpeBuffers bw = with_words(t);
     if (KIND == MPE_SCN_SIMPLE) {  // simple.py:45-50
       constexpr int D = 2 + 2 * L;
       {
@@ -1043,7 +1061,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         put1<RS>(tile, lane, 0, mvx); put1<RS>(tile, lane, 1, mvy);
 #pragma unroll
         for (int l = 0; l < L; ++l) { put1<RS>(tile, lane, 2 + 2 * l, px[A + l] - mx); put1<RS>(tile, lane, 3 + 2 * l, py[A + l] - my); }
-        const Word<ROLL> c0 = word_of<DC, ROLL>(b, B, w0, ln, 0, ra.seed, gw, gt);
+        const Word<WM> c0 = word_of<DC, WM>(bw, B, w0, ln, 0, ra.seed, gw, gt);
 #pragma unroll
         for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, 2 + 2 * L + c, c0[c]);
         flush_rows<D, false, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
@@ -1057,13 +1075,13 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
       for (int l = 0; l < L; ++l) { put1<RS>(tile, lane, 2 + 2 * l, px[A + l] - mx); put1<RS>(tile, lane, 3 + 2 * l, py[A + l] - my); }
 #pragma unroll
       for (int c = 0; c < 3; ++c) put1<RS>(tile, lane, 2 + 2 * L + c, mine == c ? 0.75f : 0.25f);   // goal_b.color
-      const Word<ROLL> co = word_of<DC, ROLL>(b, B, w0, ln, 1 - i, ra.seed, gw, gt);
+      const Word<WM> co = word_of<DC, WM>(bw, B, w0, ln, 1 - i, ra.seed, gw, gt);
 #pragma unroll
       for (int c = 0; c < DC; ++c) put1<RS>(tile, lane, 5 + 2 * L + c, co[c]);
       flush_rows<D, false, RP>(tile, obs_t + B * obs_off_i + w0 * D, nvalid, lane, d.vec4);
     }
     if constexpr (KIND == MPE_SCN_CRYPTO) {  // simple_crypto.py:127-169 (goal = pick 0, key = pick 1; colours are one-hots of width dim_c)
-      const Word<ROLL> cs = word_of<DC, ROLL>(b, B, w0, ln, 2, ra.seed, gw, gt);   // the speaker's utterance
+      const Word<WM> cs = word_of<DC, WM>(bw, B, w0, ln, 2, ra.seed, gw, gt);   // the speaker's utterance
       static_assert((DC & 1) == 0, "crypto rows are written as pairs");
       if (i == 0) {          // Eve: what the speaker says
         constexpr int D = DC;
@@ -1127,7 +1145,7 @@ k_split(float *const g_pos, float *const g_vel, const float *const g_act, const 
         }
         if (ADV) {
           put1<RS>(tile, r, k, f1 ? 1.f : -1.f); put1<RS>(tile, r, k + 1, f2 ? 1.f : -1.f); k += 2;
-          const Word<ROLL> cl = word_of<DC, ROLL>(b, B, w0, ln, 0, ra.seed, gw, gt);   // world.agents[0].state.c
+          const Word<WM> cl = word_of<DC, WM>(bw, B, w0, ln, 0, ra.seed, gw, gt);   // world.agents[0].state.c
 #pragma unroll
           for (int c = 0; c < DC; ++c) put1<RS>(tile, r, k + c, cl[c]);
         }
@@ -1284,13 +1302,10 @@ struct SplitEntry {
   size_t lds_step, lds_roll;
 };
 template <int KIND, int A, int L, int NADV>
-constexpr SplitFn serve_fn() {
-  if constexpr (KIND < MPE_SCN_SPEAKER_LISTENER) return k_split<KIND, A, L, NADV, true, kRowsSc1, false, true>;
-  else return nullptr;
-}
+constexpr SplitFn serve_fn() { return k_split<KIND, A, L, NADV, true, kRowsSc1, false, true>; }
 template <int KIND, int A, int L, int NADV>
 constexpr SplitFn serve_dual_fn() {
-  if constexpr (KIND < MPE_SCN_SPEAKER_LISTENER && dual_kind<KIND>() && SplitShape<KIND, A, L, NADV>::waves(true) * kWave <= 1024)
+  if constexpr (dual_kind<KIND>() && SplitShape<KIND, A, L, NADV>::waves(true) * kWave <= 1024)
     return k_split<KIND, A, L, NADV, true, kRowsSc1, true, true>;
   else return nullptr;
 }
@@ -1410,6 +1425,7 @@ int launch_split_serve(int kind, int A, int L, int nadv, const NarrowDesc &d, co
   sv.flag = reinterpret_cast<unsigned long long *>(h.flag);
   sv.status = h.status;
   sv.act_ring = h.act_ring;
+  sv.comm_ring = h.comm_ring;
   sv.ring = h.ring;
   sv.slots = h.slots;
   sv.timeout_ticks = h.timeout_ticks;

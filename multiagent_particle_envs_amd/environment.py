@@ -642,13 +642,13 @@ class MultiAgentEnv(object):
             else:
                 agent.state.c = torch.zeros((self.batch_size, w.dim_c), dtype=torch.float32, device=w.device)
 
-    def step_many(self, moves, episode_len=0):
+    def step_many(self, moves, episode_len=0, comm=None):
         """`for t in range(T): env.step(moves[t])` as ONE launch (new API; rollout.step_many, DESIGN.md 2 "the step server"):
         moves [T, n, B, 5] one-hot rows on the env's device -> [(obs_n, rew [n, B], done [n, B]) per step], bit-identical to the
         T step() calls; for callers whose actions exist ahead of the steps (recorded / scripted sequences, action repeat).
-        Built-in scenarios without utterances, batched mode."""
+        The built-in scenarios (comm: [T, n, B, dim_c] utterance rows where agents speak), batched mode."""
         from .rollout import step_many
-        return step_many(self, moves, episode_len)
+        return step_many(self, moves, episode_len, comm=comm)
 
     def step(self, action_n):
         """environment.py:80-104 for B worlds."""

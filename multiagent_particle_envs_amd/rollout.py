@@ -364,9 +364,12 @@ class StepServer(object):
     a ring and a wait launch per step and is better served by env.step.  One server per env at a time; the env's own outputs
     (env.step's ping-pong sets) are not touched: a served step's outputs live in the server's blocks."""
 
-    def __init__(self, env, moves, slots=2, episode_len=0, seed=None, timeout_s=2.0, probe_graph=False, probe=True, ahead=False):
+    def __init__(self, env, moves, slots=2, episode_len=0, seed=None, timeout_s=2.0, probe_graph=False, probe=True, ahead=False,
+                 comm=None):
+        """comm: the communication scenarios' utterances, [ring, A, B, dim_c] one-hot rows (the speaking agents' rows are read;
+        step g reads comm[g % ring], as moves[g % ring])."""
         if not env.fused or getattr(env, "_prog", None) is not None:
-            raise _abi.MpeError("StepServer serves the fused built-in scenarios (a wave-per-agent kernel, no utterances)")
+            raise _abi.MpeError("StepServer serves the fused built-in scenarios (the shapes with a wave-per-agent kernel)")
         if env._py_obs or env._py_reward or env._py_done or env._py_info:
             raise _abi.MpeError("StepServer evaluates the built-in callbacks only")
         self.env, self.world = env, env.world
@@ -376,7 +379,7 @@ class StepServer(object):
         self._L = _abi.lib()
         self._desc = _copy_struct(env._desc)
         if self._L.mpe_step_server_supported(C.byref(self._desc), B) != 1:
-            raise _abi.MpeError("no step server for this scenario / shape (scenarios without utterances at a wave-per-agent shape)")
+            raise _abi.MpeError("no step server for this scenario / shape (the shapes with a wave-per-agent kernel: <= 16 entities)")
         if int(episode_len) and not env._device_restart_ok:
             raise _abi.MpeError("StepServer's in-launch resets are world.reset_uniform's device draws: this env's reset_world is not that")
         moves = moves if moves.dim() == 4 else moves[None]
@@ -384,6 +387,13 @@ class StepServer(object):
                 or moves.device != w.device:
             raise _abi.MpeError("moves: a contiguous float32 [ring, A, B, %d] tensor on the env's device" % _abi.MPE_ACTION_DIM)
         self.moves, self.A, self.B = moves, A, B
+        self.comm = None
+        if env._comm is not None:      # a communication scenario: the utterance ring next to the move ring
+            if comm is None or tuple(comm.shape) != (int(moves.shape[0]), A, B, int(w.dim_c)) or comm.dtype != torch.float32 \
+                    or not comm.is_contiguous() or comm.device != w.device:
+                raise _abi.MpeError("comm: a contiguous float32 [ring, A, B, %d] tensor of utterances on the env's device "
+                                    "(this scenario's agents speak)" % int(w.dim_c))
+            self.comm = comm
         self.slots, self.episode_len = int(slots), int(episode_len)
         self.seed = int(w.seed if seed is None else seed) & (2 ** 64 - 1)
         self._lr = float(getattr(env._scenario, "landmark_range", 1.0))
@@ -396,6 +406,7 @@ class StepServer(object):
         s.door, s.flag, s.status = self.door.data_ptr(), self.flag.data_ptr(), self.status.data_ptr()
         s.act_ring, s.ring, s.slots, s.timeout_us = moves.data_ptr(), int(moves.shape[0]), self.slots, int(timeout_s * 1e6)
         s.ahead = 1 if ahead else 0      # every launch's commands precede it (run(), per-episode launches): any batch size
+        s.comm_ring = self.comm.data_ptr() if self.comm is not None else None
         self._srv = s
         self._commander = _abi.raw_stream(dev).value      # commands come from the stream that is current NOW
         if probe:
@@ -497,6 +508,8 @@ class StepServer(object):
             if ev is not None:
                 ev[1].record()
                 self.launch_events.append(ev)
+            if self.comm is not None:      # the agents' comm state after the launch = what they said at its last step (core.py:171-177)
+                self.env._comm.copy_(self.comm[(self.served_to + int(T) - 1) % int(self.comm.shape[0])])
         self.served_to += int(T)
         self.env._scenario_state_stale = True
         self.env._fast_acts.clear()
@@ -553,6 +566,12 @@ class ServedRollout(object):
         self.env, self.world, self.A, self.B, self.EP = env, w, A, B, int(episode_len)
         assert self.EP >= 1
         self.moves = torch.zeros((2 * self.EP, A, B, _abi.MPE_ACTION_DIM), dtype=torch.float32, device=w.device)
+        self.words, self.speakers = None, 0      # communication scenarios: the speakers' uniform random words, drawn with the moves
+        if env._comm is not None:
+            self.words = torch.zeros((2 * self.EP, A, B, int(w.dim_c)), dtype=torch.float32, device=w.device)
+            for i, agent in enumerate(w.agents):
+                if not agent.silent:
+                    self.speakers |= 1 << i
         # graphs: ONE commanding stream of our own for capture, replay and the server-stream probe (a graph's kernels keep a tie to
         # the stream they were captured on; the default stream cannot capture)
         self.cmd = torch.cuda.Stream(device=w.device) if graphs else None
@@ -569,10 +588,10 @@ class ServedRollout(object):
             self.cmd.wait_stream(torch.cuda.current_stream(w.device))
             with torch.cuda.stream(self.cmd):
                 self.srv = StepServer(env, self.moves, slots=slots, episode_len=self.EP, seed=seed, timeout_s=timeout_s, probe_graph=True,
-                                      ahead=self.launch_per_episode)
+                                      ahead=self.launch_per_episode, comm=self.words)
         else:
             self.srv = StepServer(env, self.moves, slots=slots, episode_len=self.EP, seed=seed, timeout_s=timeout_s,
-                                  ahead=self.launch_per_episode)
+                                  ahead=self.launch_per_episode, comm=self.words)
         self.seed = self.srv.seed
         self._L = _abi.lib()
         self.ring_ahead, self.max_launch = bool(ring_ahead), int(max_launch_episodes) * self.EP
@@ -598,6 +617,9 @@ class ServedRollout(object):
         dev = self.world.device
         _abi.check(self._L.mpe_random_actions_block(self.moves[h * self.EP].data_ptr(), None, self.A, self.B, self.seed, int(t),
                                                     self.EP, int(self.world.world_offset), _abi.raw_stream(dev)), "mpe_random_actions_block")
+        if self.words is not None:
+            _abi.check(self._L.mpe_random_comm(self.words[h * self.EP].data_ptr(), self.A, self.B, int(self.world.dim_c), self.speakers,
+                                               self.seed, int(t), self.EP, int(self.world.world_offset), _abi.raw_stream(dev)), "mpe_random_comm")
         if self.ring_ahead:      # the whole episode commanded at once (its moves all exist): the server's own rate
             _abi.check(self._L.mpe_step_server_ring(C.byref(self.srv._srv), self.EP, _abi.raw_stream(dev)), "mpe_step_server_ring")
             return
@@ -655,19 +677,21 @@ class ServedRollout(object):
             left -= n
 
 
-def step_many(env, moves, episode_len=0, seed=None):
+def step_many(env, moves, episode_len=0, seed=None, comm=None):
     """`for t in range(T): obs_n, reward_n, done_n, _ = env.step(moves[t])` as ONE launch: moves [T, A, B, 5] one-hot rows on the
     env's device (the reference's action format, environment.py:174-181, stacked over the steps).  -> a list of T tuples
     (obs_n, rew [A, B], done [A, B]) of views into the server's T output blocks (valid until the next call with the same T);
     world.pos / vel hold the state after the last step.  Bit-identical to the T env.step calls (tests/test_gpu_server.py).
-    episode_len > 0: the worlds restart (world.reset_uniform's device draws) every episode_len steps, counted over the calls."""
+    episode_len > 0: the worlds restart (world.reset_uniform's device draws) every episode_len steps, counted over the calls.
+    comm: [T, A, B, dim_c] utterance rows for the communication scenarios."""
     T = int(moves.shape[0])
     key = (T, int(episode_len))
     cache = env.__dict__.setdefault("_step_many_servers", {})
     srv = cache.get(key)
-    if srv is None or srv.moves.data_ptr() != moves.data_ptr() or tuple(srv.moves.shape) != tuple(moves.shape):
+    if srv is None or srv.moves.data_ptr() != moves.data_ptr() or tuple(srv.moves.shape) != tuple(moves.shape) or \
+            (comm is not None and (srv.comm is None or srv.comm.data_ptr() != comm.data_ptr())):
         t0 = 0 if srv is None else srv.served_to
-        srv = StepServer(env, moves, slots=T, episode_len=episode_len, seed=seed, probe=False, ahead=True)
+        srv = StepServer(env, moves, slots=T, episode_len=episode_len, seed=seed, probe=False, ahead=True, comm=comm)
         srv.served_to = srv.commanded = t0 - t0 % T      # (blocks and move tensors are indexed by the global step modulo T)
         if t0 % T:
             raise _abi.MpeError("step_many: a new move tensor mid-way through a block of %d steps" % T)

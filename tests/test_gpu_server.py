@@ -30,7 +30,8 @@ def reference_steps(name, kw, B, T, EP, ring):
         pos, vel = env.world.pos.clone(), env.world.vel.clone()
         ch = env.world.choice_i32.clone() if env.world.choice_i32 is not None else None
         out.append(([x.clone() for x in o.obs_n], o.rew.clone(), o.done.clone(), pos, vel, ch))
-    return rr.pool_t.clone(), out
+    comm = rr.pool_c.clone() if rr.pool_c is not None else None
+    return (rr.pool_t.clone(), comm, env._comm.clone() if env._comm is not None else None), out
 
 
 def same(step, srv, env, g, what):
@@ -45,15 +46,18 @@ def same(step, srv, env, g, what):
 #  agent; beyond, the single-role one: the 32 768- and 40 000-world cases)
 CASES = [("simple_spread", {}, 4096, 25), ("simple_spread", {}, 1000, 7), ("simple_tag", {}, 1000, 25),
          ("simple_adversary", {}, 777, 10), ("simple_push", {}, 640, 25), ("simple", {}, 130, 5),
-         ("simple_spread", {"num_agents": 5}, 900, 25), ("simple_spread", {}, 32768, 25), ("simple_tag", {}, 40000, 9)]
+         ("simple_spread", {"num_agents": 5}, 900, 25), ("simple_spread", {}, 32768, 25), ("simple_tag", {}, 40000, 9),
+         # the communication scenarios: the speakers' words come from an utterance ring as the moves from the move ring
+         ("simple_speaker_listener", {}, 1000, 25), ("simple_reference", {}, 700, 6), ("simple_crypto", {}, 1500, 25),
+         ("simple_world_comm", {}, 600, 10)]
 
 
 @pytest.mark.parametrize("name,kw,B,EP", CASES)
 def test_served_steps_are_the_launched_steps_bit_for_bit(name, kw, B, EP):
     T, ring = (60, 16) if B < 20000 else (28, 8)
-    moves, ref = reference_steps(name, kw, B, T, EP, ring)
+    (moves, comm, comm_after), ref = reference_steps(name, kw, B, T, EP, ring)
     env = mpe.make_env(name, batch_size=B, seed=3, **kw)
-    srv = StepServer(env, moves, slots=T, episode_len=EP, timeout_s=5.0)
+    srv = StepServer(env, moves, slots=T, episode_len=EP, timeout_s=5.0, comm=comm)
     srv.start(T)
     srv.ring(T)                      # every step commanded ahead: the server runs them back to back
     srv.join()
@@ -65,16 +69,18 @@ def test_served_steps_are_the_launched_steps_bit_for_bit(name, kw, B, EP):
     assert torch.equal(env.world.pos, ref[-1][3]) and torch.equal(env.world.vel, ref[-1][4])      # the state after the last step, in HBM
     if ref[-1][5] is not None:
         assert torch.equal(env.world.choice_i32, ref[-1][5])
+    if comm_after is not None:       # the agents' comm state afterwards = their last words
+        assert torch.equal(env._comm, comm_after)
 
 
-@pytest.mark.parametrize("name,kw,B,EP", [CASES[1], CASES[3], CASES[7]])
+@pytest.mark.parametrize("name,kw,B,EP", [CASES[1], CASES[3], CASES[7], CASES[11]])
 def test_closed_loop_commands_one_step_at_a_time(name, kw, B, EP):
     """ring -> wait -> read -> ring ...: the server is ahead of its commander at every step (the idle path: a step's completion is
     published without the next command), state visible in HBM after each step, host pauses in between."""
     T, ring = 12, 4
-    moves, ref = reference_steps(name, kw, B, T, EP, ring)
+    (moves, comm, _), ref = reference_steps(name, kw, B, T, EP, ring)
     env = mpe.make_env(name, batch_size=B, seed=3, **kw)
-    srv = StepServer(env, moves, slots=2, episode_len=EP, timeout_s=20.0)
+    srv = StepServer(env, moves, slots=2, episode_len=EP, timeout_s=20.0, comm=comm)
     srv.start(T)
     for g in range(T):
         srv.ring()
@@ -95,7 +101,7 @@ def test_bursts_and_two_launches():
     state the first left in HBM; doorbell and flags count on)."""
     name, kw, B, EP = "simple_spread", {}, 2048, 25
     T, ring = 50, 8
-    moves, ref = reference_steps(name, kw, B, T, EP, ring)
+    (moves, _, _), ref = reference_steps(name, kw, B, T, EP, ring)
     env = mpe.make_env(name, batch_size=B, seed=3, **kw)
     srv = StepServer(env, moves, slots=T, episode_len=EP, timeout_s=20.0)
     srv.start(30)
@@ -133,8 +139,11 @@ def test_a_server_nobody_commands_gives_up():
 
 def test_what_the_server_refuses():
     env = mpe.make_env("simple_speaker_listener", batch_size=256)
-    with pytest.raises(_abi.MpeError, match="step server"):
+    with pytest.raises(_abi.MpeError, match="utterances"):      # a scenario whose agents speak needs the utterance ring
         StepServer(env, torch.zeros((2, 2, 256, _abi.MPE_ACTION_DIM), device="cuda"))
+    env = mpe.make_env("simple_spread", batch_size=256, num_agents=10)      # 20 entities: no wave-per-agent kernel
+    with pytest.raises(_abi.MpeError, match="step server"):
+        StepServer(env, torch.zeros((2, 10, 256, _abi.MPE_ACTION_DIM), device="cuda"))
     env = mpe.make_env("simple_spread", batch_size=256)
     with pytest.raises(_abi.MpeError, match="moves"):
         StepServer(env, torch.zeros((2, 3, 255, _abi.MPE_ACTION_DIM), device="cuda"))
@@ -145,8 +154,9 @@ def test_what_the_server_refuses():
         srv.start(1)
 
 
+@pytest.mark.parametrize("name", ["simple_spread", "simple_reference"])
 @pytest.mark.parametrize("graphs", [False, True])
-def test_served_rollout_is_the_fresh_moves_rollout(graphs):
+def test_served_rollout_is_the_fresh_moves_rollout(graphs, name):
     """rollout.ServedRollout (bench.py's step-server leg): block draws into the halves of a 2-episode move ring, 25 doorbells per
     episode, one server launch per enqueue -- the state and the last step's outputs equal RandomRollout(regenerate=True)'s
     launches.  With graphs=True the caller-side half of an episode is a HIP graph per ring half (its draw repeats the moves of
@@ -154,11 +164,11 @@ def test_served_rollout_is_the_fresh_moves_rollout(graphs):
     from multiagent_particle_envs_amd.rollout import ServedRollout
     B, EP = 4096, 25
     K = 2 * EP if graphs else 4 * EP
-    ref_env = mpe.make_env("simple_spread", batch_size=B, seed=5)
+    ref_env = mpe.make_env(name, batch_size=B, seed=5)
     rr = RandomRollout(ref_env, episode_len=EP, pool=EP, regenerate=True)
     o = rr.enqueue(K)
     torch.cuda.synchronize()
-    env = mpe.make_env("simple_spread", batch_size=B, seed=5)
+    env = mpe.make_env(name, batch_size=B, seed=5)
     roll = ServedRollout(env, episode_len=EP, slots=2, graphs=graphs)
     roll.enqueue(K)
     torch.cuda.synchronize()
