@@ -370,7 +370,7 @@ def test_bench_line_is_compact_and_round_trips():
     assert bench.sig(10358300123.4) == 10358300000.0 and bench.sig(0.00632694123) == 0.00632694 and bench.sig(7) == 7
     # a round-6 record (the line's value is the step server's; the launched steps' figures ride in roofline.launched), and the line
     # the GPU box printed from it
-    rec6 = json.load(open(os.path.join(ROOT, "profiles", "r6_bench_default_steps20_box13.json")))
+    rec6 = json.load(open(os.path.join(ROOT, "profiles", "r6_bench_default_steps20_box16.json")))
     line6 = bench.compact_line(rec6, rec6.get("full_record"))
     out6 = json.loads(line6)
     assert len(line6) < bench.LINE_BUDGET and out6["config"]["mode"] == "step-server"
@@ -378,5 +378,5 @@ def test_bench_line_is_compact_and_round_trips():
     assert r6["launched"]["value"] < out6["value"] and r6["launched"]["frac_timed_region"] < r6["frac_timed_region"] < 1.0
     assert r6["kernel_us_rocprof"]["source"].startswith("profiles/") and r6["traffic"] > 0 and r6["hbm_resident_frac"] > 0.5
     assert abs(out6["timed_steps"] * out6["ms_per_step"] * 1e-3 / out6["timed_region_s"] - 1) < 1e-3 and out6["timed_region_s"] >= 2.0
-    printed = json.loads(open(os.path.join(ROOT, "profiles", "r6_bench_line_box13.json")).read().strip().splitlines()[-1])
+    printed = json.loads(open(os.path.join(ROOT, "profiles", "r6_bench_line_box16.json")).read().strip().splitlines()[-1])
     assert printed["value"] == out6["value"] and printed["roofline"]["frac"] == r6["frac"]
