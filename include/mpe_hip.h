@@ -236,6 +236,17 @@ int mpe_rollout_random(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int6
                        int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0,
                        int64_t world_offset, int32_t trajectory, void *stream);
 
+/* mpe_rollout_actions / mpe_rollout_rows_actions: mpe_rollout_random / mpe_rollout_rows with the CALLER's moves -- act_seq = T
+ * consecutive [A][B][5] one-hot (or soft) action tensors, step t of the launch reads tensor t -- instead of moves drawn in the
+ * kernel: the caller's `for t in range(T): env.step(actions[t])` loop (bin/interactive.py:27-36 pattern; environment.py:80-104 per
+ * step) as ONE launch, bit-identical to the T mpe_step / mpe_step_rows launches.  mpe_rollout_actions covers simple_spread /
+ * simple_tag beyond 16 entities (the wave-per-world kernels; the wave-per-agent shapes take the caller's moves through the step
+ * server below: ring, then start, with srv->ahead = 1); mpe_rollout_rows_actions every row-program env whose agents do not speak.  */
+int mpe_rollout_actions(const MpeScenarioDesc *desc, const MpeBuffers *bufs, int64_t B, int32_t T, int32_t episode_len,
+                        float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset, int32_t trajectory,
+                        const float *act_seq, void *stream);
+/* (mpe_rollout_rows_actions is declared behind mpe_rollout_rows, below) */
+
 /* ---- the step server: per-step commands to ONE resident launch -- NEW API, no reference counterpart ----------------------
  * The reference's caller loop is one env.step per policy decision (bin/interactive.py:27-36, environment.py:80-104); as a
  * launch per step every step pays the dependent-launch gap (1.0-2.0 us on top of the kernel's span).  A step server is ONE
@@ -431,6 +442,10 @@ int mpe_step_rows_episode(const MpeScenarioDesc *desc, const MpeBuffers *bufs, M
 int mpe_rollout_rows(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowProgram *prog, int64_t B, int32_t T,
                      int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
                      int32_t trajectory, uint32_t speakers, void *stream);
+/* ... with the CALLER's moves (act_seq: T consecutive [A][B][5] tensors; see mpe_rollout_actions): agents that do not speak */
+int mpe_rollout_rows_actions(const MpeScenarioDesc *desc, const MpeBuffers *bufs, MpeRowProgram *prog, int64_t B, int32_t T,
+                             int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
+                             int32_t trajectory, const float *act_seq, void *stream);
 
 /* mpe_rollout_rows_episode: T consecutive mpe_step_rows_episode steps in ONE launch, the moves (and words) drawn in the kernel as in
  * mpe_rollout_rows: the episodes end, per world, where the program's done tests or max_episode_steps say -- the finished worlds

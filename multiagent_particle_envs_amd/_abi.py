@@ -123,6 +123,11 @@ EXPORTS = {
     "mpe_rollout_random": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_int32,
                                      C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32,
                                      C.c_void_p]),
+    "mpe_rollout_actions": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_int32, C.c_int32, C.c_float,
+                                      C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mpe_rollout_rows_actions": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.POINTER(MpeRowProgram), C.c_int64,
+                                           C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_void_p,
+                                           C.c_void_p]),
     "mpe_step_server_supported": (C.c_int, [C.POINTER(MpeScenarioDesc), C.c_int64]),
     "mpe_step_server_flags": (C.c_int64, [C.c_int64]),
     "mpe_step_server_start": (C.c_int, [C.POINTER(MpeScenarioDesc), C.POINTER(MpeBuffers), C.c_int64, C.c_int32, C.c_int32,

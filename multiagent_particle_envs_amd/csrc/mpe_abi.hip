@@ -433,10 +433,23 @@ int mpe_episode_tick(int32_t *episode_step, uint8_t *done, int32_t n_agents, int
                                              clear_finished, static_cast<hipStream_t>(stream)), what);
 }
 
+static int rollout_fused(const char *what, const float *act_seq, const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, int32_t T,
+                         int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
+                         int32_t trajectory, void *stream);
 int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, int32_t T, int32_t episode_len,
                        float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
                        int32_t trajectory, void *stream) {
-  const char *what = "mpe_rollout_random";
+  return rollout_fused("mpe_rollout_random", nullptr, d, b, B, T, episode_len, landmark_range, seed, step0, world_offset, trajectory, stream);
+}
+int mpe_rollout_actions(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, int32_t T, int32_t episode_len,
+                        float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
+                        int32_t trajectory, const float *act_seq, void *stream) {
+  if (!act_seq) return fail(MPE_EINVAL, "mpe_rollout_actions: act_seq is NULL");
+  return rollout_fused("mpe_rollout_actions", act_seq, d, b, B, T, episode_len, landmark_range, seed, step0, world_offset, trajectory, stream);
+}
+static int rollout_fused(const char *what, const float *act_seq, const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B, int32_t T,
+                         int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
+                         int32_t trajectory, void *stream) {
   if (int rc = check_desc(d, what)) return rc;
   if (int rc = check_state(b, B, what)) return rc;
   if (int rc = need(b->obs, what, "obs")) return rc;
@@ -456,6 +469,7 @@ int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
   ra.seed = seed;
   ra.step0 = step0;
   ra.world_offset = (uint64_t)world_offset;
+  ra.act_seq = act_seq;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d->n_agents + d->n_landmarks > mpe::kNarrowMaxE ||
       !mpe::split_supports(d->kind, d->n_agents, d->n_landmarks, d->n_adversaries)) {
@@ -465,6 +479,9 @@ int mpe_rollout_random(const MpeScenarioDesc *d, const MpeBuffers *b, int64_t B,
     const mpe::WideDesc w = make_wide(d);
     return hip_result(mpe::launch_wide(true, true, w, *b, (size_t)B, s, &ra), what);
   }
+  if (act_seq)      // (the wave-per-agent shapes take the caller's moves through the step server: its launch with every command ahead)
+    return fail(MPE_EUNSUPPORTED, "%s: this shape has a wave-per-agent kernel -- its T-step launch with the caller's moves is the step "
+                "server's (mpe_step_server_ring, then mpe_step_server_start with srv->ahead = 1)", what);
   const mpe::NarrowDesc n = make_narrow(d, b, (size_t)B);
   return hip_result(mpe::launch_split(true, d->kind, d->n_agents, d->n_landmarks, d->n_adversaries, n, *b, (size_t)B,
                                       ra, s), what);
@@ -859,10 +876,25 @@ static int episode_args(const char *what, int mode, const MpeScenarioDesc *d, co
   return 0;
 }
 
+static int rollout_rows(const char *what, const float *act_seq, const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B,
+                        int32_t T, int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
+                        int32_t trajectory, uint32_t speakers, void *stream);
 int mpe_rollout_rows(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B, int32_t T, int32_t episode_len,
                      float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset, int32_t trajectory, uint32_t speakers,
                      void *stream) {
-  const char *what = "mpe_rollout_rows";
+  return rollout_rows("mpe_rollout_rows", nullptr, d, b, p, B, T, episode_len, landmark_range, seed, step0, world_offset, trajectory,
+                      speakers, stream);
+}
+int mpe_rollout_rows_actions(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B, int32_t T, int32_t episode_len,
+                             float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset, int32_t trajectory,
+                             const float *act_seq, void *stream) {
+  if (!act_seq) return fail(MPE_EINVAL, "mpe_rollout_rows_actions: act_seq is NULL");
+  return rollout_rows("mpe_rollout_rows_actions", act_seq, d, b, p, B, T, episode_len, landmark_range, seed, step0, world_offset,
+                      trajectory, 0u, stream);
+}
+static int rollout_rows(const char *what, const float *act_seq, const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgram *p, int64_t B,
+                        int32_t T, int32_t episode_len, float landmark_range, uint64_t seed, uint64_t step0, int64_t world_offset,
+                        int32_t trajectory, uint32_t speakers, void *stream) {
   if (T < 0 || episode_len < 0) return fail(MPE_EINVAL, "%s: T, episode_len must be >= 0", what);
   if (!d) return fail(MPE_EINVAL, "%s: desc is NULL", what);
   if (speakers != 0) {
@@ -880,6 +912,7 @@ int mpe_rollout_rows(const MpeScenarioDesc *d, const MpeBuffers *b, MpeRowProgra
   ra.seed = seed;
   ra.step0 = step0;
   ra.world_offset = (uint64_t)world_offset;
+  ra.act_seq = act_seq;
   mpe::RowEpisode ep;      // (off; carries the picks' populations and the world numbering the in-kernel resets draw with)
   std::memset(&ep, 0, sizeof(ep));
   ep.n_choices = d->n_choices;

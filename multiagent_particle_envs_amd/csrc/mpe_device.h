@@ -160,6 +160,13 @@ __device__ __forceinline__ void fetch_action(const MpeBuffers &b, size_t B, int 
   else { ux = b.u[(size_t)(2 * i) * B + w]; uy = b.u[(size_t)(2 * i + 1) * B + w]; }
 }
 
+// The caller's move of agent i in world w at step t of a T-step launch (RollArgs.act_seq: T consecutive [A][B][5] tensors):
+// decode_row, the launched step's own decode -- same differences, same product.
+__device__ __forceinline__ void fetch_action_seq(const float *act_seq, int t, int A, size_t B, int i, size_t w, float sens,
+                                                 float &ux, float &uy) {
+  decode_row(act_seq + (((size_t)t * (size_t)A + (size_t)i) * B + w) * MPE_ACTION_DIM, sens, ux, uy);
+}
+
 // A wave-uniform element offset pinned to SGPRs.  The value is uniform by construction (kernel
 // arguments, blockIdx, the wave's agent index); passing its halves through readfirstlane keeps LLVM
 // from re-associating "uniform offset + lane" into per-lane 64-bit multiply-adds, so that

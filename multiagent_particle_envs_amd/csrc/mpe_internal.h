@@ -58,6 +58,8 @@ struct RollArgs {
   int32_t wpw;          // worlds per workgroup of the wave-per-agent kernels (set by launch_split)
   float landmark_range;
   uint64_t seed, step0, world_offset;
+  const float *act_seq;   // rollouts of the wide / row-program kernels: the CALLER's moves, T consecutive [A][B][5] tensors (step t of
+                          // the launch reads tensor t) instead of moves drawn in the kernel; nullptr = drawn (mpe_rollout_random / _rows)
 };
 bool split_supports(int kind, int A, int L, int nadv);
 // the step server (mpe_split.hip, SERVE): device words and ring geometry of one server (mpe_step_server_*)

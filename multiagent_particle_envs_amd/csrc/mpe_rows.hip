@@ -370,10 +370,14 @@ __device__ __forceinline__ void rows_body(const MpeBuffers &b, const RowEpisode 
         float mx = P(i, 0), my = P(i, 1), mvx = V(i, 0), mvy = V(i, 1);
         if ((h.movable >> i) & 1ull) {
           float ux, uy;
-          if constexpr (ROLL) {    // the one-hot row mpe_random_actions_block would write for (seed, world, step, agent)
-            const int m = action_draw(ra.seed, gw, gstep, i);
-            ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * TF(MPE_TAB(accel), i);
-            uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * TF(MPE_TAB(accel), i);
+          if constexpr (ROLL) {    // the one-hot row mpe_random_actions_block would write for (seed, world, step, agent) -- or the caller's
+            if (ra.act_seq) {
+              fetch_action_seq(ra.act_seq, t, A, B, i, w0 + ln, TF(MPE_TAB(accel), i), ux, uy);
+            } else {
+              const int m = action_draw(ra.seed, gw, gstep, i);
+              ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * TF(MPE_TAB(accel), i);
+              uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * TF(MPE_TAB(accel), i);
+            }
           } else if (i == wave) {  // prefetched at kernel entry; a one-hot row / an id decodes to exact -1 / 0 / +1: scale now
             const bool raw = b.act || b.ids;
             ux = raw ? act_x * TF(MPE_TAB(accel), i) : act_x;

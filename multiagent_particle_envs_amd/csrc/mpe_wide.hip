@@ -461,11 +461,16 @@ k_wave(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_gr
         for (int i = lane; i < A; i += kWave) V[i] = make_float2(0.f, 0.f);
         ++ep;
       }
-      for (int i = lane; i < A; i += kWave) {   // the one-hot row mpe_random_actions would write, decoded
-        const int m = action_draw(ra.seed, gw, gt, i);
+      for (int i = lane; i < A; i += kWave) {   // the one-hot row mpe_random_actions would write, decoded -- or the caller's (act_seq)
         const float sens = aconst[i].z;
-        const float ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * sens;
-        const float uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * sens;
+        float ux, uy;
+        if (ra.act_seq) {
+          fetch_action_seq(ra.act_seq, t, A, B, i, w, sens, ux, uy);
+        } else {
+          const int m = action_draw(ra.seed, gw, gt, i);
+          ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * sens;
+          uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * sens;
+        }
         U[i] = make_float2(ux + 0.f, uy + 0.f);
       }
       wave_sync();
@@ -1022,9 +1027,14 @@ k_duo_roll(const WideDesc d, const MpeBuffers b, const size_t B, const RollArgs 
       const int i = have ? lane : 0;
       float2 me = Qc[L + i], v = Vs(g, cur)[i];
       if (movable) {
-        const int m = action_draw(ra.seed, gw, gt, i);   // the one-hot row mpe_random_actions would write, decoded
-        const float ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * d.a_accel;
-        const float uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * d.a_accel;
+        float ux, uy;      // the one-hot row mpe_random_actions would write, decoded -- or the caller's (act_seq)
+        if (ra.act_seq) {
+          fetch_action_seq(ra.act_seq, t, A, B, i, w, d.a_accel, ux, uy);
+        } else {
+          const int m = action_draw(ra.seed, gw, gt, i);
+          ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * d.a_accel;
+          uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * d.a_accel;
+        }
         float ax = ux + 0.f, ay = uy + 0.f;   // action force first, then the partners in ascending order (Q9)
         if (collide) {
           const float ri = d.a_size, rfar = ri + kFarX * d.cmargin, reach = rfar + ri;
@@ -1235,11 +1245,16 @@ k_multi(const WideDesc d, const MpeBuffers b, const size_t B, const unsigned n_g
         }
         ++ep;
       }
-      if (have) {   // the one-hot row mpe_random_actions would write, decoded
-        const int m = action_draw(ra.seed, gw, gt, a);
+      if (have) {   // the one-hot row mpe_random_actions would write, decoded -- or the caller's (act_seq)
         const float sens = aconst[a].z;
-        const float ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * sens;
-        const float uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * sens;
+        float ux, uy;
+        if (ra.act_seq) {
+          fetch_action_seq(ra.act_seq, t, A, B, a, w, sens, ux, uy);
+        } else {
+          const int m = action_draw(ra.seed, gw, gt, a);
+          ux = ((m == 1 ? 1.f : 0.f) - (m == 2 ? 1.f : 0.f)) * sens;
+          uy = ((m == 3 ? 1.f : 0.f) - (m == 4 ? 1.f : 0.f)) * sens;
+        }
         U[a] = make_float2(ux + 0.f, uy + 0.f);
       }
       wave_sync();

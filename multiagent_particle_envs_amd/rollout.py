@@ -687,6 +687,9 @@ def step_many(env, moves, episode_len=0, seed=None, comm=None):
     T = int(moves.shape[0])
     key = (T, int(episode_len))
     cache = env.__dict__.setdefault("_step_many_servers", {})
+    prog = getattr(env, "_prog", None)
+    if prog is not None or _abi.lib().mpe_step_server_supported(C.byref(env._desc), env.world.batch_size) != 1:
+        return _rollout_actions(env, moves, int(episode_len), seed, comm, cache, key)
     srv = cache.get(key)
     if srv is None or srv.moves.data_ptr() != moves.data_ptr() or tuple(srv.moves.shape) != tuple(moves.shape) or \
             (comm is not None and (srv.comm is None or srv.comm.data_ptr() != comm.data_ptr())):
@@ -701,3 +704,45 @@ def step_many(env, moves, episode_len=0, seed=None, comm=None):
     g0 = srv.served_to
     srv.run(T)
     return [srv.outputs(g0 + t) for t in range(T)]
+
+
+def _rollout_actions(env, moves, episode_len, seed, comm, cache, key):
+    """step_many for the envs the step server does not serve: row-program envs (user scenarios, traced reference-style files:
+    mpe_rollout_rows_actions) and simple_spread / simple_tag beyond 16 entities (mpe_rollout_actions) -- their fused T-step rollout
+    with the CALLER's moves (RollArgs.act_seq) instead of moves drawn in the kernel."""
+    if not env.fused:
+        raise _abi.MpeError("step_many: this env steps through Python callbacks (use env.step / GraphedStep)")
+    if env._py_obs or env._py_reward or env._py_done or env._py_info:
+        raise _abi.MpeError("step_many evaluates the device-side callbacks only")
+    w = env.world
+    env._ensure_buffers()
+    A, B, T = len(w.agents), w.batch_size, int(moves.shape[0])
+    if tuple(moves.shape[1:]) != (A, B, _abi.MPE_ACTION_DIM) or moves.dtype != torch.float32 or not moves.is_contiguous() \
+            or moves.device != w.device:
+        raise _abi.MpeError("moves: a contiguous float32 [T, A, B, %d] tensor on the env's device" % _abi.MPE_ACTION_DIM)
+    prog = getattr(env, "_prog", None)
+    if comm is not None or any(not a.silent for a in w.agents):
+        raise _abi.MpeError("step_many: speaking agents are served for the built-in scenarios at their wave-per-agent shapes only")
+    if prog is not None and bool(getattr(env, "_episode_in_launch", False)):
+        raise _abi.MpeError("step_many: this env ends its episodes inside the launch (done programs / max_episode_steps): use env.step")
+    if episode_len and not env._device_restart_ok:
+        raise _abi.MpeError("step_many(episode_len > 0): the in-launch resets are world.reset_uniform's device draws; this env's reset_world is not that")
+    st = cache.get(key)
+    if st is None or not isinstance(st, dict):
+        st = cache[key] = {"traj": Trajectory(env, T), "t": 0, "desc": _copy_struct(env._desc)}
+    traj = st["traj"]
+    b = traj.bufs
+    b.act = b.ids = b.u = None
+    L = _abi.lib()
+    sd = int(w.seed if seed is None else seed) & (2 ** 64 - 1)
+    lr = float(getattr(env._scenario, "landmark_range", 1.0))
+    if prog is not None:
+        _abi.check(L.mpe_rollout_rows_actions(C.byref(st["desc"]), C.byref(b), prog.ref, B, T, int(episode_len), lr, sd, int(st["t"]),
+                                              int(w.world_offset), 1, moves.data_ptr(), _abi.raw_stream(w.device)), "mpe_rollout_rows_actions")
+    else:
+        _abi.check(L.mpe_rollout_actions(C.byref(st["desc"]), C.byref(b), B, T, int(episode_len), lr, sd, int(st["t"]),
+                                         int(w.world_offset), 1, moves.data_ptr(), _abi.raw_stream(w.device)), "mpe_rollout_actions")
+    st["t"] += T
+    env._scenario_state_stale = True
+    env._fast_acts.clear()
+    return [(traj.obs[t], traj.rew[t], traj.done[t]) for t in range(T)]

@@ -235,3 +235,36 @@ def test_launches_whose_commands_precede_them_need_no_residency():
     for t in range(3):
         obs_n, rew_n, _, _ = ref_env.step(moves[t])
         assert all(torch.equal(a, b) for a, b in zip(outs[t][0], obs_n)) and torch.equal(outs[t][1][0], rew_n[0])
+
+
+@pytest.mark.parametrize("what", ["spread10", "spread40", "tag12", "corral", "convoy"])
+def test_step_many_beyond_the_server(what):
+    """env.step_many where the step server does not serve: simple_spread / simple_tag beyond 16 entities (the wave-per-world
+    rollouts with the caller's moves: mpe_rollout_actions) and row-program envs -- a user scenario (examples/corral.py) and a
+    traced reference-style file (tests/refstyle/convoy.py): mpe_rollout_rows_actions -- bit-identical to the env.step loop."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name, kw, B = {"spread10": ("simple_spread", {"num_agents": 10}, 3000), "spread40": ("simple_spread", {"num_agents": 40}, 700),
+                   "tag12": ("simple_tag", {"num_good_agents": 4, "num_adversaries": 8, "num_landmarks": 3}, 1500),
+                   "corral": (os.path.join(root, "examples", "corral.py"), {}, 4096),
+                   "convoy": (os.path.join(root, "tests", "refstyle", "convoy.py"), {}, 2000)}[what]
+    T = 7
+    ref = mpe.make_env(name, batch_size=B, seed=11, **kw)
+    env = mpe.make_env(name, batch_size=B, seed=11, **kw)
+    ref.reset()
+    env.reset()
+    assert torch.equal(env.world.pos, ref.world.pos)
+    A = ref.n
+    g = torch.Generator(device="cpu").manual_seed(6)
+    moves = torch.empty((T, A, B, _abi.MPE_ACTION_DIM), device="cuda")
+    for rnd in range(2):
+        moves.copy_(torch.nn.functional.one_hot(torch.randint(0, 5, (T, A, B), generator=g), 5).float())
+        outs = env.step_many(moves)
+        torch.cuda.synchronize()
+        for t in range(T):
+            obs_n, rew_n, done_n, _ = ref.step(moves[t])
+            o_s, r_s, d_s = outs[t]
+            for i in range(A):
+                assert torch.equal(o_s[i], obs_n[i]), (rnd, t, i)
+                assert torch.equal(r_s[i], rew_n[i]) and torch.equal(d_s[i], done_n[i])
+        assert torch.equal(env.world.pos, ref.world.pos) and torch.equal(env.world.vel, ref.world.vel)
